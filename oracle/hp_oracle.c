@@ -1,0 +1,780 @@
+/*
+ * hp_oracle.c -- TEST INFRASTRUCTURE ONLY.  NOT PART OF THE PRODUCT.
+ * See hp_oracle.h for scope and pinning status.  Build: oracle/Makefile
+ * (gcc -O2 -ffp-contract=off: the reference is built for baseline x86-64,
+ * which has no FMA, so no multiply-add is ever contracted).
+ */
+#include "hp_oracle.h"
+
+#define _GNU_SOURCE
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ======================================================================== */
+/* Tables                                                                   */
+/* ======================================================================== */
+
+static int g_tables_ready = 0;
+static double g_roots[2080], g_weights[2080];
+static double g_nl[13][11];
+static double g_rec[13][2];
+static uint64_t g_count[13];
+static uint64_t g_bidx[455][3];
+static uint64_t g_sumton[50];
+
+/* --- double-double helpers, used only to produce correctly rounded
+ *     Gauss-Legendre nodes/weights.  Include/HP/Legendre.h:7-2089,2091-4173
+ *     holds ~290-digit decimal literals, i.e. the correctly rounded doubles. */
+typedef struct {
+    double hi, lo;
+} dd;
+static dd dd_qts(double a, double b) {
+    double s = a + b;
+    dd r = {s, b - (s - a)};
+    return r;
+}
+static dd dd_ts(double a, double b) {
+    double s = a + b, bb = s - a;
+    dd r = {s, (a - (s - bb)) + (b - bb)};
+    return r;
+}
+static dd dd_tp(double a, double b) {
+    double p = a * b;
+    dd r = {p, fma(a, b, -p)};
+    return r;
+}
+static dd dd_add(dd a, dd b) {
+    dd s = dd_ts(a.hi, b.hi), t = dd_ts(a.lo, b.lo);
+    s.lo += t.hi;
+    s = dd_qts(s.hi, s.lo);
+    s.lo += t.lo;
+    return dd_qts(s.hi, s.lo);
+}
+static dd dd_from(double a) {
+    dd r = {a, 0.0};
+    return r;
+}
+static dd dd_sub(dd a, dd b) {
+    dd nb = {-b.hi, -b.lo};
+    return dd_add(a, nb);
+}
+static dd dd_mul(dd a, dd b) {
+    dd p = dd_tp(a.hi, b.hi);
+    p.lo += a.hi * b.lo + a.lo * b.hi;
+    return dd_qts(p.hi, p.lo);
+}
+static dd dd_div(dd a, dd b) {
+    double q1 = a.hi / b.hi;
+    dd r = dd_sub(a, dd_mul(b, dd_from(q1)));
+    double q2 = r.hi / b.hi;
+    r = dd_sub(r, dd_mul(b, dd_from(q2)));
+    double q3 = r.hi / b.hi;
+    return dd_add(dd_qts(q1, q2), dd_from(q3));
+}
+/* P_n(x) and P_n'(x) by the Bonnet recurrence */
+static void dd_legendre(int n, dd x, dd* pn, dd* dpn) {
+    dd p0 = dd_from(1.0), p1 = x;
+    for (int k = 2; k <= n; ++k) {
+        dd a = dd_mul(dd_mul(dd_from(2.0 * k - 1.0), x), p1);
+        dd b = dd_mul(dd_from(k - 1.0), p0);
+        dd pk = dd_div(dd_sub(a, b), dd_from((double)k));
+        p0 = p1;
+        p1 = pk;
+    }
+    *pn = p1;
+    *dpn = dd_div(dd_mul(dd_from((double)n), dd_sub(dd_mul(x, p1), p0)), dd_sub(dd_mul(x, x), dd_from(1.0)));
+}
+
+/* One n-point rule in the order Legendre.h stores it: 0 first for odd n, then
+ * (-x,+x) pairs by ascending |x| -- except n = 6 and n = 9, whose pairs are
+ * stored in the order (2nd,1st,3rd) and (3rd,4th,1st,2nd) smallest.  n = 9 is
+ * the rule of every degree-2 fit (Octree.cpp:1016-1017), so the quirk changes
+ * the summation order of the coarse pass. */
+static void gl_rule(int n, double* x, double* w) {
+    int m = n / 2, o = n & 1;
+    double ax[32], aw[32];
+    if (o) {
+        dd pn, dp;
+        dd_legendre(n, dd_from(0.0), &pn, &dp);
+        x[0] = 0.0;
+        w[0] = dd_div(dd_from(2.0), dd_mul(dp, dp)).hi;
+    }
+    for (int k = 0; k < m; ++k) {
+        dd xx = dd_from(cos(M_PI * ((m - k) - 0.25) / (n + 0.5)));
+        dd pn, dp;
+        for (int it = 0; it < 8; ++it) {
+            dd_legendre(n, xx, &pn, &dp);
+            xx = dd_sub(xx, dd_div(pn, dp));
+        }
+        dd_legendre(n, xx, &pn, &dp);
+        dd one_m = dd_sub(dd_from(1.0), dd_mul(xx, xx));
+        ax[k] = xx.hi;
+        aw[k] = dd_div(dd_from(2.0), dd_mul(one_m, dd_mul(dp, dp))).hi;
+    }
+    static const int perm6[3] = {1, 0, 2};
+    static const int perm9[4] = {2, 3, 0, 1};
+    for (int k = 0; k < m; ++k) {
+        int src = (n == 6) ? perm6[k] : (n == 9) ? perm9[k] : k;
+        x[o + 2 * k] = -ax[src];
+        x[o + 2 * k + 1] = ax[src];
+        w[o + 2 * k] = aw[src];
+        w[o + 2 * k + 1] = aw[src];
+    }
+}
+
+/* Include/HP/Utility.h:25-35 SqrtConst: 100 Newton steps from guess = x */
+static double sqrt_const(double x) {
+    double guess = x;
+    for (int i = 0; i < 100; ++i) guess = 0.5 * (guess + x / guess);
+    return guess;
+}
+/* Include/HP/Utility.h:14-24 PowConst */
+static double pow_const(double base, unsigned n) { return n == 0 ? 1.0 : base * pow_const(base, n - 1); }
+
+void ora_tables_init(void) {
+    if (g_tables_ready) return;
+    /* Legendre.h: rule n occupies [n(n-1)/2, n(n+1)/2) */
+    for (int n = 1; n <= 64; ++n) gl_rule(n, g_roots + n * (n - 1) / 2, g_weights + n * (n - 1) / 2);
+    /* Utility.h:40-57 SumToN */
+    for (uint64_t i = 0; i <= 49; ++i) {
+        uint64_t s = 0;
+        for (uint64_t j = 0; j <= i; ++j) s += j;
+        g_sumton[i] = s;
+    }
+    /* Utility.h:63-78 NormalisedLengths[i][j] = SqrtConst((2i+1) * 2^j) */
+    for (unsigned i = 0; i <= 12; ++i)
+        for (unsigned j = 0; j <= 10; ++j) g_nl[i][j] = sqrt_const((2.0 * i + 1.0) * pow_const(2.0, j));
+    /* Utility.h:87-106: (u32)(1/6.0 * (i+1) * (i+2) * (i+3)) in f64 => count[6] = 83 */
+    {
+        const double f = 1.0 / 6.0;
+        for (uint64_t i = 0; i <= 12; ++i) g_count[i] = (uint64_t)(f * (i + 1) * (i + 2) * (i + 3));
+    }
+    /* Utility.h:112-127 recurrence constants */
+    g_rec[0][0] = 0.0;
+    g_rec[0][1] = 0.0;
+    for (unsigned i = 1; i <= 12; ++i) {
+        g_rec[i][0] = (2.0 * i - 1.0) / i;
+        g_rec[i][1] = (i - 1.0) / i;
+    }
+    /* Utility.h:133-160 BasisIndexValues: by total degree p, then i, then j ascending */
+    {
+        unsigned v = 0;
+        for (unsigned p = 0; p <= 12; ++p)
+            for (unsigned i = 0; i <= p; ++i)
+                for (unsigned j = 0; j <= p - i; ++j)
+                    for (unsigned k = 0; k <= p - i - j; ++k)
+                        if (i + j + k == p) {
+                            g_bidx[v][0] = i;
+                            g_bidx[v][1] = j;
+                            g_bidx[v][2] = k;
+                            ++v;
+                        }
+    }
+    g_tables_ready = 1;
+}
+const double* ora_gl_roots(void) { ora_tables_init(); return g_roots; }
+const double* ora_gl_weights(void) { ora_tables_init(); return g_weights; }
+const double* ora_normalised_lengths(void) { ora_tables_init(); return &g_nl[0][0]; }
+const double* ora_recurrence(void) { ora_tables_init(); return &g_rec[0][0]; }
+const uint64_t* ora_coeff_count(void) { ora_tables_init(); return g_count; }
+const uint64_t* ora_basis_index(void) { ora_tables_init(); return &g_bidx[0][0]; }
+const uint64_t* ora_sum_to_n(void) { ora_tables_init(); return g_sumton; }
+
+/* ======================================================================== */
+/* Config                                                                   */
+/* ======================================================================== */
+
+/* Source/HP/Config.cpp:5-14.  threadCount is left at 1 (the oracle is serial);
+ * padding is zeroed so that serialised bytes are reproducible. */
+void ora_config_default(ora_config* c) {
+    memset(c, 0, sizeof(*c));
+    c->target_error_threshold = pow(10, -10);
+    c->weighting_type = 0;
+    c->continuity_enforce = 1;
+    c->continuity_strength = 8.0;
+    c->thread_count = 1;
+    for (int a = 0; a < 3; ++a) {
+        c->root_min[a] = -0.5f;
+        c->root_max[a] = 0.5f;
+    }
+    c->enable_logging = 0;
+}
+
+/* ======================================================================== */
+/* Fields                                                                   */
+/* ======================================================================== */
+
+/* Eigen's Vector3d::norm() reduces as x^2 + (y^2 + z^2); the reference test
+ * fields are written with it (Source/Tests/HPUnitTests.cpp:48-51). */
+static double norm3(double x, double y, double z) { return sqrt(x * x + (y * y + z * z)); }
+
+static double prim_eval(const ora_prim* pr, const double pt[3]) {
+    const double* p = pr->p;
+    switch (pr->kind) {
+        case ORA_PRIM_SPHERE: /* centre p[0..2], radius p[3] */
+            return norm3(pt[0] - p[0], pt[1] - p[1], pt[2] - p[2]) - p[3];
+        case ORA_PRIM_BOX: { /* centre p[0..2], half extents p[3..5]; exact box SDF */
+            double qx = fabs(pt[0] - p[0]) - p[3];
+            double qy = fabs(pt[1] - p[1]) - p[4];
+            double qz = fabs(pt[2] - p[2]) - p[5];
+            double mx = fmax(qx, 0.0), my = fmax(qy, 0.0), mz = fmax(qz, 0.0);
+            double outside = norm3(mx, my, mz);
+            double inside = fmin(fmax(qx, fmax(qy, qz)), 0.0);
+            return outside + inside;
+        }
+        case ORA_PRIM_TORUS_Y: { /* centre p[0..2], major R p[3], minor r p[4], axis y */
+            double dx = pt[0] - p[0], dy = pt[1] - p[1], dz = pt[2] - p[2];
+            double l = sqrt(dx * dx + dz * dz) - p[3];
+            return sqrt(l * l + dy * dy) - p[4];
+        }
+        case ORA_PRIM_PLANE: /* normal p[0..2], offset p[3] */
+            return (p[0] * pt[0] + (p[1] * pt[1] + p[2] * pt[2])) + p[3];
+        default:
+            return 0.0;
+    }
+}
+
+static double combine(int op, double acc, double d) {
+    switch (op) {
+        case ORA_OP_UNION: return fmin(acc, d);
+        case ORA_OP_INTERSECT: return fmax(acc, d);
+        case ORA_OP_SUBTRACT: return fmax(acc, -d);
+        default: return acc;
+    }
+}
+
+double ora_field_eval(const ora_field* f, const double pt[3]) {
+    switch (f->kind) {
+        case ORA_FIELD_ANALYTIC: {
+            double acc = prim_eval(&f->prims[0], pt);
+            for (int i = 1; i < f->nprims; ++i) acc = combine(f->prims[i].op, acc, prim_eval(&f->prims[i], pt));
+            return acc;
+        }
+        case ORA_FIELD_CALLBACK:
+            return f->cb(pt, 0, f->user);
+        case ORA_FIELD_MESH: {
+            /* user glue of SURVEY 3.4: (f64) mesh.SignedDistanceAtPt(p.cast<f32>()) */
+            float p32[3] = {(float)pt[0], (float)pt[1], (float)pt[2]};
+            return (double)ora_mesh_signed_distance(f->mesh, p32, NULL, NULL);
+        }
+        case ORA_FIELD_TREE_CSG: {
+            /* Octree.cpp:355-400: Union min(old,F), Subtract max(-old,F), Intersect max(old,F) */
+            double o = ora_query(f->tree, pt);
+            double n = ora_field_eval(f->inner, pt);
+            switch (f->csg_op) {
+                case ORA_OP_UNION: return o < n ? o : n;          /* std::min(old, F) */
+                case ORA_OP_SUBTRACT: return (o * -1.0) < n ? n : (o * -1.0); /* std::max(-old, F) */
+                default: return o < n ? n : o;                     /* std::max(old, F) */
+            }
+        }
+        default:
+            return 0.0;
+    }
+}
+
+/* ======================================================================== */
+/* Per-node numerics                                                        */
+/* ======================================================================== */
+
+/* Octree::LpX, Octree.cpp:988-1004 */
+double ora_lpx(uint64_t p, double x) {
+    ora_tables_init();
+    double LiMinus2 = 0.0, LiMinus1 = 1.0, Li = 1.0;
+    for (uint64_t i = 1; i <= p; ++i) {
+        Li = g_rec[i][0] * x * LiMinus1 - g_rec[i][1] * LiMinus2;
+        LiMinus2 = LiMinus1;
+        LiMinus1 = Li;
+    }
+    return Li;
+}
+
+/* Octree::CornerAABB, Octree.cpp:1096-1112 (f32 midpoint) */
+void ora_corner_aabb(const float bmin[3], const float bmax[3], unsigned i, float omin[3], float omax[3]) {
+    for (int d = 0; d < 3; ++d) {
+        omin[d] = bmin[d];
+        omax[d] = bmax[d];
+        float mid = (bmax[d] + bmin[d]) * 0.5f;
+        if (i & (1u << d))
+            omin[d] = mid;
+        else
+            omax[d] = mid;
+    }
+}
+
+/* Octree::FitPolynomial, Octree.cpp:1007-1093 with the callback wrapper of
+ * Octree.cpp:322-328 folded in (F = F_(pt * rootBounds + centre)). */
+double ora_fit_polynomial(const ora_field* f, const ora_config* cfg, double* coeffs, int basis_degree,
+                          const float bmin[3], const float bmax[3], int degree, int depth, int literal) {
+    ora_tables_init();
+    /* :1012-1013 */
+    const uint64_t startingIdx = basis_degree > 0 ? g_count[basis_degree] : 0;
+    const uint64_t endingIdx = g_count[degree];
+    /* :1016-1017 */
+    const uint64_t GQStart = g_sumton[4 * degree];
+    const uint64_t GQEnd = g_sumton[4 * degree + 1];
+    const uint64_t nq = GQEnd - GQStart;
+    /* :1020-1022  sizes()/center() are f32 ops (Eigen AlignedBox3f), then cast */
+    double scale[3], centre[3];
+    for (int a = 0; a < 3; ++a) {
+        scale[a] = (double)(bmax[a] - bmin[a]) * 0.5;
+        centre[a] = (double)((bmin[a] + bmax[a]) / 2.0f);
+    }
+    const double scalesMult = scale[0] * (scale[1] * scale[2]); /* Eigen prod(): a*(b*c) */
+    /* Octree.cpp:322,324 */
+    double rootBounds[3], rootCentre[3];
+    for (int a = 0; a < 3; ++a) {
+        rootBounds[a] = (double)(cfg->root_max[a] - cfg->root_min[a]);
+        rootCentre[a] = (double)((cfg->root_min[a] + cfg->root_max[a]) / 2.0f);
+    }
+    /* :1025 */
+    memset(coeffs + startingIdx, 0, (endingIdx - startingIdx) * sizeof(double));
+
+    /* per-axis cache of LpX(idx, root) -- same values the literal path recomputes */
+    double T[13][49];
+    if (!literal)
+        for (int p = 0; p <= degree; ++p)
+            for (uint64_t q = 0; q < nq; ++q) T[p][q] = ora_lpx((uint64_t)p, g_roots[GQStart + q]);
+
+    /* :1028-1056 */
+    for (uint64_t i = GQStart; i < GQEnd; ++i)
+        for (uint64_t j = GQStart; j < GQEnd; ++j)
+            for (uint64_t k = GQStart; k < GQEnd; ++k) {
+                const double us[3] = {g_roots[i], g_roots[j], g_roots[k]};
+                const double wprod = g_weights[i] * (g_weights[j] * g_weights[k]);
+                double world[3];
+                for (int a = 0; a < 3; ++a) {
+                    double s = us[a] * scale[a] + centre[a]; /* :1039 */
+                    world[a] = s * rootBounds[a] + rootCentre[a]; /* :327 */
+                }
+                const double FaabSample = scalesMult * wprod * ora_field_eval(f, world); /* :1040 */
+                const uint64_t qi[3] = {i - GQStart, j - GQStart, k - GQStart};
+                for (uint64_t c = startingIdx; c < endingIdx; ++c) {
+                    double Lp = 1.0;
+                    for (int p = 0; p < 3; ++p) {
+                        const uint64_t bi = g_bidx[c][p];
+                        Lp *= literal ? ora_lpx(bi, us[p]) : T[bi][qi[p]];
+                        Lp *= g_nl[bi][depth];
+                    }
+                    coeffs[c] += Lp * FaabSample;
+                }
+            }
+    /* :1062-1069 */
+    double newError = 0.0;
+    for (uint64_t i = 0; i < endingIdx; ++i)
+        if ((g_bidx[i][0] + g_bidx[i][1] + g_bidx[i][2]) == (uint64_t)degree) newError += coeffs[i] * coeffs[i];
+    /* nearness weighting None (:1073-1076).  Polynomial/Exponential weighting
+     * (:1209-1247) draws from std::rand() and is parity-unpinned; not restated. */
+    return newError;
+}
+
+/* EstimateHImprovement (Octree.cpp:804-826), EstimatePImprovement (:829-856),
+ * decision (:594-601). */
+void ora_job(const ora_field* f, const ora_config* cfg, const float bmin[3], const float bmax[3], int depth,
+             int degree, double err, const double* coeffs, double* p_coeffs, double* h_coeffs,
+             ora_job_result* out, int literal) {
+    ora_tables_init();
+    memset(out, 0, sizeof(*out));
+    const int coarse = fabs(err - ORA_INITIAL_NODE_ERR) < DBL_EPSILON; /* :806,:831 */
+    out->coarse = coarse;
+    /* H */
+    if (coarse || depth >= ORA_TREE_MAX_DEPTH) {
+        /* :806-810 coarse -> 0.  depth == 10: the reference fits children at
+         * depth 11 (out-of-range NormalisedLengths read) and never uses the
+         * result (:601); skipped here. */
+        out->h_imp = 0.0;
+    } else {
+        double maxNewErr = 0.0;
+        for (unsigned i = 0; i < 8; ++i) {
+            float cmin[3], cmax[3];
+            ora_corner_aabb(bmin, bmax, i, cmin, cmax);
+            out->h_err[i] = ora_fit_polynomial(f, cfg, h_coeffs + (uint64_t)i * g_count[degree], 0, cmin, cmax, degree,
+                                               depth + 1, literal);
+            maxNewErr = maxNewErr > out->h_err[i] ? maxNewErr : out->h_err[i]; /* std::max */
+        }
+        out->h_imp = (1.0 / (7.0 * (double)g_count[degree])) * (err - 8.0 * maxNewErr); /* :825 */
+    }
+    /* P */
+    if (coarse) {
+        out->p_err = ora_fit_polynomial(f, cfg, p_coeffs, 0, bmin, bmax, 2, depth, literal); /* :838-842 */
+        out->p_imp = out->p_err;
+    } else if (degree >= ORA_BASIS_MAX_DEGREE - 1) {
+        /* degree 11: the reference fits 11->12 and never uses it (:600); skipped */
+        out->p_imp = 0.0;
+    } else {
+        memcpy(p_coeffs, coeffs, sizeof(double) * g_count[degree]); /* :847 */
+        out->p_err = ora_fit_polynomial(f, cfg, p_coeffs, degree, bmin, bmax, degree + 1, depth, literal);
+        out->p_imp = (1.0 / (double)(g_count[degree + 1] - g_count[degree])) * (err - 8.0 * out->p_err); /* :854 */
+    }
+    /* :600-601 */
+    out->refine_p = degree < (ORA_BASIS_MAX_DEGREE - 1) && (depth == ORA_TREE_MAX_DEPTH || out->p_imp > out->h_imp);
+    /* A coarse job whose P error is exactly 0 would fall into the H branch
+     * with null child bases in the reference (UB): canonical rule:
+     * coarse jobs always P-refine. */
+    if (coarse) out->refine_p = 1;
+    out->refine_h = depth < ORA_TREE_MAX_DEPTH && !out->refine_p;
+}
+
+/* Octree::FApprox, Octree.cpp:859-901 */
+double ora_fapprox(const double* coeffs, int degree, const float bmin[3], const float bmax[3],
+                   const double pt[3], int depth) {
+    ora_tables_init();
+    double unitPt[3];
+    for (int a = 0; a < 3; ++a)
+        unitPt[a] = (pt[a] - (double)((bmin[a] + bmax[a]) / 2.0f)) * (double)(2 << depth); /* :862 */
+    double LpXLookup[13][3];
+    for (int i = 0; i < 3; ++i) {
+        LpXLookup[0][i] = g_nl[0][depth];
+        double LjMinus2 = 0.0, LjMinus1 = 1.0, Lj = 1.0;
+        for (int j = 1; j <= degree; ++j) {
+            Lj = g_rec[j][0] * unitPt[i] * LjMinus1 - g_rec[j][1] * LjMinus2; /* :879 */
+            LjMinus2 = LjMinus1;
+            LjMinus1 = Lj;
+            LpXLookup[j][i] = Lj * g_nl[j][depth];
+        }
+    }
+    double fApprox = 0.0;
+    for (uint64_t i = 0; i < g_count[degree]; ++i) {
+        double Lp = 1.0;
+        for (int j = 0; j < 3; ++j) Lp *= LpXLookup[g_bidx[i][j]][j];
+        fApprox += coeffs[i] * Lp;
+    }
+    return fApprox;
+}
+
+/* ======================================================================== */
+/* Tree build under the canonical round schedule                             */
+/* ======================================================================== */
+
+typedef struct {
+    uint64_t idx;
+    double err;
+} heap_ent;
+typedef struct {
+    heap_ent* e;
+    uint64_t n, cap;
+} heap_t;
+/* strict total order: larger error first, then smaller node index */
+static int ent_before(heap_ent a, heap_ent b) { return a.err > b.err || (a.err == b.err && a.idx < b.idx); }
+static void heap_push(heap_t* h, heap_ent v) {
+    if (h->n == h->cap) {
+        h->cap = h->cap ? h->cap * 2 : 1024;
+        h->e = (heap_ent*)realloc(h->e, h->cap * sizeof(heap_ent));
+    }
+    uint64_t i = h->n++;
+    h->e[i] = v;
+    while (i > 0) {
+        uint64_t p = (i - 1) / 2;
+        if (!ent_before(h->e[i], h->e[p])) break;
+        heap_ent t = h->e[i];
+        h->e[i] = h->e[p];
+        h->e[p] = t;
+        i = p;
+    }
+}
+static heap_ent heap_pop(heap_t* h) {
+    heap_ent top = h->e[0];
+    h->e[0] = h->e[--h->n];
+    uint64_t i = 0;
+    for (;;) {
+        uint64_t l = 2 * i + 1, r = l + 1, b = i;
+        if (l < h->n && ent_before(h->e[l], h->e[b])) b = l;
+        if (r < h->n && ent_before(h->e[r], h->e[b])) b = r;
+        if (b == i) break;
+        heap_ent t = h->e[i];
+        h->e[i] = h->e[b];
+        h->e[b] = t;
+        i = b;
+    }
+    return top;
+}
+
+typedef struct {
+    ora_tree* t;
+    double** cptr; /* per-node coefficient pointer during the build (Node::Basis::coeffs) */
+    uint64_t cap;
+} builder;
+
+static void node_init(ora_node* n) { /* Source/HP/Node.cpp:5-15 (+ zeroed padding) */
+    memset(n, 0, sizeof(*n));
+    n->childIdx = (uint64_t)-1;
+    for (int a = 0; a < 3; ++a) { /* AlignedBox::setEmpty() */
+        n->aabb_min[a] = FLT_MAX;
+        n->aabb_max[a] = -FLT_MAX;
+    }
+    n->degree = ORA_INTERIOR_DEGREE;
+    n->depth = ORA_TREE_MAX_DEPTH + 1;
+}
+static void ensure_nodes(builder* b, uint64_t want) {
+    ora_tree* t = b->t;
+    if (want <= t->cap_nodes) return;
+    uint64_t nc = t->cap_nodes ? t->cap_nodes : 8192;
+    while (nc < want) nc *= 2;
+    t->nodes = (ora_node*)realloc(t->nodes, nc * sizeof(ora_node));
+    b->cptr = (double**)realloc(b->cptr, nc * sizeof(double*));
+    for (uint64_t i = t->cap_nodes; i < nc; ++i) b->cptr[i] = NULL;
+    t->cap_nodes = nc;
+}
+/* Octree::Subdivide, Octree.cpp:1115-1128 */
+static void subdivide(builder* b, uint64_t idx) {
+    ora_tree* t = b->t;
+    ensure_nodes(b, t->n_nodes + 8);
+    t->nodes[idx].childIdx = t->n_nodes;
+    for (unsigned i = 0; i < 8; ++i) {
+        ora_node* n = &t->nodes[t->n_nodes];
+        node_init(n);
+        ora_corner_aabb(t->nodes[idx].aabb_min, t->nodes[idx].aabb_max, i, n->aabb_min, n->aabb_max);
+        n->depth = (uint8_t)(t->nodes[idx].depth + 1);
+        b->cptr[t->n_nodes] = NULL;
+        t->n_nodes++;
+    }
+}
+/* Octree::UniformlyRefine, Octree.cpp:112-191: pre-order DFS, subdividing on
+ * first visit, to depth 4; leaves get degree 0 and error 100. */
+static void uniformly_refine(builder* b, uint64_t idx, unsigned depth, heap_t* h) {
+    if (depth < 4) {
+        subdivide(b, idx);
+        uint64_t c = b->t->nodes[idx].childIdx;
+        for (unsigned i = 0; i < 8; ++i) uniformly_refine(b, c + i, depth + 1, h);
+    } else {
+        b->cptr[idx] = (double*)calloc(g_count[2], sizeof(double)); /* :172 (malloc; zeroed here) */
+        b->t->nodes[idx].degree = 0;                               /* :173 */
+        heap_ent e = {idx, ORA_INITIAL_NODE_ERR};                  /* :176-177 */
+        heap_push(h, e);
+    }
+}
+
+static int cmp_idx(const void* a, const void* b) {
+    uint64_t x = ((const heap_ent*)a)->idx, y = ((const heap_ent*)b)->idx;
+    return x < y ? -1 : x > y;
+}
+
+static void set_root_vectors(ora_tree* t) {
+    for (int a = 0; a < 3; ++a) {
+        /* Octree.cpp:322-323 / :419-420: f32 centre, f32 reciprocal of f32 size */
+        t->root_centre[a] = (double)((t->config.root_min[a] + t->config.root_max[a]) / 2.0f);
+        t->root_inv_sizes[a] = (double)(1.0f / (t->config.root_max[a] - t->config.root_min[a]));
+    }
+}
+
+ora_tree* ora_create(const ora_config* cfg, const ora_field* f, uint64_t K, int literal, ora_build_stats* stats) {
+    ora_tables_init();
+    ora_build_stats st;
+    memset(&st, 0, sizeof(st));
+    builder b;
+    memset(&b, 0, sizeof(b));
+    b.t = (ora_tree*)calloc(1, sizeof(ora_tree));
+    ora_tree* t = b.t;
+    t->config = *cfg;
+    set_root_vectors(t);
+    heap_t h = {0, 0, 0};
+
+    /* CreateRoot, Octree.cpp:792-801 */
+    ensure_nodes(&b, 1);
+    node_init(&t->nodes[0]);
+    t->n_nodes = 1;
+    t->nodes[0].depth = 0;
+    for (int a = 0; a < 3; ++a) {
+        t->nodes[0].aabb_min[a] = -0.5f;
+        t->nodes[0].aabb_max[a] = 0.5f;
+    }
+    subdivide(&b, 0);
+    /* UniformlyRefine: the reference walks children 0..7 of the root */
+    for (unsigned i = 0; i < 8; ++i) uniformly_refine(&b, t->nodes[0].childIdx + i, 1, &h);
+
+    /* RunBuildThreadPool, Octree.cpp:194-309, canonical rounds */
+    double total = pow(8, 4) * ORA_INITIAL_NODE_ERR; /* :212 */
+    heap_ent* batch = NULL;
+    uint64_t batch_cap = 0;
+    double* pbuf = (double*)malloc(sizeof(double) * ORA_NCOEF_MAX);
+    double* hbuf = (double*)malloc(sizeof(double) * 8 * ORA_NCOEF_MAX);
+    for (;;) {
+        if (total < cfg->target_error_threshold || h.n == 0) break; /* :216 */
+        uint64_t want = (st.rounds == 0) ? h.n : (K < h.n ? K : h.n);
+        if (want > batch_cap) {
+            batch_cap = want;
+            batch = (heap_ent*)realloc(batch, batch_cap * sizeof(heap_ent));
+        }
+        for (uint64_t i = 0; i < want; ++i) batch[i] = heap_pop(&h);
+        qsort(batch, want, sizeof(heap_ent), cmp_idx); /* apply in nodeIdx order */
+        for (uint64_t bi = 0; bi < want; ++bi) {
+            const uint64_t idx = batch[bi].idx;
+            const double err = batch[bi].err;
+            ora_node nd = t->nodes[idx]; /* copy: subdivide() may realloc */
+            const int p = nd.degree, d = nd.depth;
+            ora_job_result r;
+            ora_job(f, cfg, nd.aabb_min, nd.aabb_max, d, p, err, b.cptr[idx], pbuf, hbuf, &r, literal);
+            st.jobs++;
+            st.fits += r.coarse ? 1 : ((d < ORA_TREE_MAX_DEPTH ? 8 : 0) + (p < ORA_BASIS_MAX_DEGREE - 1 ? 1 : 0));
+            if (r.refine_p) { /* :253-260, :286-290 */
+                const int np = r.coarse ? 2 : p + 1;
+                free(b.cptr[idx]);
+                b.cptr[idx] = (double*)malloc(sizeof(double) * g_count[np]);
+                memcpy(b.cptr[idx], pbuf, sizeof(double) * g_count[np]);
+                t->nodes[idx].degree = (uint8_t)np;
+                total += (r.p_err - err);
+                heap_ent e = {idx, r.p_err};
+                heap_push(&h, e);
+                st.p_refines++;
+            } else if (r.refine_h) { /* :262-279, :286-290 */
+                free(b.cptr[idx]);
+                b.cptr[idx] = NULL;
+                t->nodes[idx].degree = ORA_INTERIOR_DEGREE;
+                subdivide(&b, idx);
+                total -= err;
+                const uint64_t c0 = t->nodes[idx].childIdx;
+                for (unsigned i = 0; i < 8; ++i) {
+                    b.cptr[c0 + i] = (double*)malloc(sizeof(double) * g_count[p]);
+                    memcpy(b.cptr[c0 + i], hbuf + (uint64_t)i * g_count[p], sizeof(double) * g_count[p]);
+                    t->nodes[c0 + i].degree = (uint8_t)p;
+                    total += r.h_err[i];
+                    heap_ent e = {c0 + i, r.h_err[i]};
+                    heap_push(&h, e);
+                }
+                st.h_refines++;
+            } else {
+                st.dropped++; /* :643-655 */
+            }
+        }
+        st.rounds++;
+    }
+    free(batch);
+    free(pbuf);
+    free(hbuf);
+    free(h.e);
+    st.total_error = total;
+
+    /* ReallocCoeffs, Octree.cpp:474-555: DFS children 0..7, leaves packed in visit order */
+    uint64_t nCoeffs = 0;
+    for (uint64_t i = 0; i < t->n_nodes; ++i)
+        if (t->nodes[i].degree != ORA_INTERIOR_DEGREE) nCoeffs += g_count[t->nodes[i].degree];
+    t->n_coeffs = nCoeffs;
+    t->coeff_store = (double*)malloc(sizeof(double) * (nCoeffs ? nCoeffs : 1));
+    {
+        uint64_t cur = 0;
+        uint64_t stack_node[ORA_TREE_MAX_DEPTH + 2];
+        int stack_child[ORA_TREE_MAX_DEPTH + 2];
+        int sp = 0;
+        stack_node[0] = 0;
+        stack_child[0] = 0;
+        while (sp >= 0) {
+            if (stack_child[sp] == 8) {
+                --sp;
+                continue;
+            }
+            uint64_t n = t->nodes[stack_node[sp]].childIdx + (uint64_t)stack_child[sp]++;
+            if (t->nodes[n].childIdx == (uint64_t)-1) {
+                uint64_t cnt = g_count[t->nodes[n].degree];
+                memcpy(t->coeff_store + cur, b.cptr[n], sizeof(double) * cnt);
+                free(b.cptr[n]);
+                b.cptr[n] = NULL;
+                t->nodes[n].coeffsStart = cur;
+                cur += cnt;
+            } else {
+                ++sp;
+                stack_node[sp] = n;
+                stack_child[sp] = 0;
+            }
+        }
+    }
+    free(b.cptr);
+    if (stats) *stats = st;
+    return t;
+}
+
+void ora_tree_free(ora_tree* t) {
+    if (!t) return;
+    free(t->nodes);
+    free(t->coeff_store);
+    free(t);
+}
+
+/* ======================================================================== */
+/* Serialisation: [u64 nCoeffs][f64 x nCoeffs][u64 nNodes][Node x nNodes][Config] */
+/* Octree.cpp:424-456 / 403-421                                              */
+/* ======================================================================== */
+
+size_t ora_tree_block_size(const ora_tree* t) {
+    return 8 + 8 * (size_t)t->n_coeffs + 8 + sizeof(ora_node) * (size_t)t->n_nodes + sizeof(ora_config);
+}
+void ora_tree_to_block(const ora_tree* t, void* out) {
+    uint8_t* p = (uint8_t*)out;
+    memcpy(p, &t->n_coeffs, 8);
+    p += 8;
+    memcpy(p, t->coeff_store, 8 * (size_t)t->n_coeffs);
+    p += 8 * (size_t)t->n_coeffs;
+    memcpy(p, &t->n_nodes, 8);
+    p += 8;
+    for (uint64_t i = 0; i < t->n_nodes; ++i) {
+        ora_node n = t->nodes[i];
+        memset(n.pad0, 0, sizeof n.pad0);
+        memset(n.pad1, 0, sizeof n.pad1);
+        if (n.degree == ORA_INTERIOR_DEGREE) n.coeffsStart = 0; /* stale pointer in the reference */
+        memcpy(p, &n, sizeof n);
+        p += sizeof n;
+    }
+    ora_config c = t->config;
+    memset(c.pad0, 0, sizeof c.pad0);
+    memset(c.pad1, 0, sizeof c.pad1);
+    memset(c.pad2, 0, sizeof c.pad2);
+    memcpy(p, &c, sizeof c);
+}
+ora_tree* ora_tree_from_block(const void* block, size_t size) {
+    if (!block || size < 16 + sizeof(ora_config)) return NULL;
+    const uint8_t* p = (const uint8_t*)block;
+    ora_tree* t = (ora_tree*)calloc(1, sizeof(ora_tree));
+    memcpy(&t->n_coeffs, p, 8);
+    p += 8;
+    if (8 + 8 * (size_t)t->n_coeffs + 8 > size) {
+        free(t);
+        return NULL;
+    }
+    t->coeff_store = (double*)malloc(8 * (size_t)(t->n_coeffs ? t->n_coeffs : 1));
+    memcpy(t->coeff_store, p, 8 * (size_t)t->n_coeffs);
+    p += 8 * (size_t)t->n_coeffs;
+    memcpy(&t->n_nodes, p, 8);
+    p += 8;
+    if (8 + 8 * (size_t)t->n_coeffs + 8 + sizeof(ora_node) * (size_t)t->n_nodes + sizeof(ora_config) > size) {
+        free(t->coeff_store);
+        free(t);
+        return NULL;
+    }
+    t->cap_nodes = t->n_nodes;
+    t->nodes = (ora_node*)malloc(sizeof(ora_node) * (size_t)(t->n_nodes ? t->n_nodes : 1));
+    memcpy(t->nodes, p, sizeof(ora_node) * (size_t)t->n_nodes);
+    p += sizeof(ora_node) * (size_t)t->n_nodes;
+    memcpy(&t->config, p, sizeof(ora_config));
+    set_root_vectors(t); /* :419-420 */
+    return t;
+}
+
+/* ======================================================================== */
+/* Query, Octree.cpp:662-702                                                 */
+/* ======================================================================== */
+
+double ora_query(const ora_tree* t, const double pt_[3]) {
+    double pt[3];
+    for (int a = 0; a < 3; ++a) pt[a] = (pt_[a] - t->root_centre[a]) * t->root_inv_sizes[a]; /* :665 */
+    /* :668  contains() on the f32 cast, inclusive */
+    for (int a = 0; a < 3; ++a) {
+        float pf = (float)pt[a];
+        if (!(t->nodes[0].aabb_min[a] <= pf && pf <= t->nodes[0].aabb_max[a])) return DBL_MAX;
+    }
+    uint64_t cur = 0;
+    for (;;) {
+        const ora_node* n = &t->nodes[cur];
+        const float half = (n->aabb_max[0] - n->aabb_min[0]) * 0.5f; /* :679 x extent for every axis */
+        const uint64_t xIdx = (pt[0] >= (double)(n->aabb_min[0] + half));
+        const uint64_t yIdx = (uint64_t)(pt[1] >= (double)(n->aabb_min[1] + half)) << 1;
+        const uint64_t zIdx = (uint64_t)(pt[2] >= (double)(n->aabb_min[2] + half)) << 2;
+        const uint64_t childIdx = n->childIdx + xIdx + yIdx + zIdx;
+        const ora_node* c = &t->nodes[childIdx];
+        if (c->degree != ORA_INTERIOR_DEGREE)
+            return ora_fapprox(t->coeff_store + c->coeffsStart, c->degree, c->aabb_min, c->aabb_max, pt, c->depth);
+        cur = childIdx;
+    }
+}
+void ora_query_batch(const ora_tree* t, const double* xyz, size_t n, double* out) {
+    for (size_t i = 0; i < n; ++i) out[i] = ora_query(t, xyz + 3 * i);
+}
