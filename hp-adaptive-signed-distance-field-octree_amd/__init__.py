@@ -1,0 +1,561 @@
+"""MI355X-native hp-adaptive SDF octree: Python host mirror of the C ABI (include/hpsdf.h).
+
+The directory name is the one the build contract prescribes and is not a Python
+identifier; load it with ``hpsdf_loader.load()`` (repo root) or importlib.  All numerics
+run in ``lib/libhpsdf.so`` (HIP, gfx950).  There is no CPU fallback: without the built
+library ``lib()`` raises, and without a GPU every compute entry point returns
+HPSDF_ERR_NO_DEVICE, which surfaces here as ``HpsdfError``.
+
+Reference API mirrored (file:line in the reference checkout):
+  Config            Include/HP/Config.h:12-43, Source/HP/Config.cpp:5-32
+  Octree.Create     Include/HP/Octree.h:50      Source/HP/Octree.cpp:312-352
+  Octree.Query      Include/HP/Octree.h:71      Source/HP/Octree.cpp:662-702
+  To/FromMemoryBlock Include/HP/Octree.h:65-68  Source/HP/Octree.cpp:403-456
+  Union/Subtract/IntersectSDF Include/HP/Octree.h:53-59, Octree.cpp:355-400
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhpsdf.so")
+_LIB = None
+
+OK = 0
+ERR_NO_DEVICE = 2
+ERR_UNSUPPORTED = 5
+ERR_OPEN_MESH = 8
+PRIM_SPHERE, PRIM_BOX, PRIM_TORUS_Y, PRIM_PLANE = 0, 1, 2, 3
+OP_UNION, OP_INTERSECT, OP_SUBTRACT = 0, 1, 2
+JOB_HEADER_DOUBLES = 9
+DEFAULT_JOBS_PER_ROUND = 1024
+NCOEF = [1, 4, 10, 20, 35, 56, 83, 120, 165, 220, 286, 364, 455]
+DBL_MAX = float(np.finfo(np.float64).max)
+
+
+class HpsdfError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("hpsdf status %d: %s" % (status, msg))
+        self.status = status
+
+
+class PodConfig(C.Structure):
+    """hpsdf_config == SDF::Config, 80 bytes."""
+    _fields_ = [
+        ("weighting_type", C.c_uint8), ("pad0", C.c_uint8 * 7),
+        ("weighting_strength", C.c_double),
+        ("continuity_enforce", C.c_uint8), ("pad1", C.c_uint8 * 7),
+        ("continuity_strength", C.c_double),
+        ("enable_logging", C.c_uint8), ("pad2", C.c_uint8 * 7),
+        ("target_error_threshold", C.c_double),
+        ("thread_count", C.c_uint64),
+        ("root_min", C.c_float * 3),
+        ("root_max", C.c_float * 3),
+    ]
+
+
+class Prim(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("op", C.c_int32), ("p", C.c_double * 8)]
+
+
+class BuildOpts(C.Structure):
+    _fields_ = [("max_jobs_per_round", C.c_uint64), ("rank", C.c_int32), ("world", C.c_int32),
+                ("reserved", C.c_int32 * 2)]
+
+
+class Job(C.Structure):
+    _fields_ = [("node_idx", C.c_uint64), ("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3),
+                ("err", C.c_double), ("degree", C.c_uint8), ("depth", C.c_uint8), ("coarse", C.c_uint8),
+                ("pad", C.c_uint8 * 5)]
+
+
+class BuildStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("rounds", "jobs", "p_refines", "h_refines", "dropped", "fits", "samples",
+                                           "n_nodes", "n_leaves", "n_coeffs")] + [("total_error", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+CALLBACK = C.CFUNCTYPE(C.c_double, C.POINTER(C.c_double), C.c_uint64, C.c_void_p)
+
+# every symbol include/hpsdf.h declares (tests/test_capi_symbols.py checks the list against the header)
+_SIGNATURES = {
+    "hpsdf_config_default": (C.c_int, [C.POINTER(PodConfig)]),
+    "hpsdf_last_error": (C.c_char_p, []),
+    "hpsdf_version": (C.c_char_p, []),
+    "hpsdf_tables_get": (C.c_int, [C.c_void_p] * 7),
+    "hpsdf_ctx_create": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "hpsdf_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "hpsdf_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hpsdf_ctx_synchronize": (C.c_int, [C.c_void_p]),
+    "hpsdf_ctx_stream": (C.c_void_p, [C.c_void_p]),
+    "hpsdf_field_create_analytic": (C.c_int, [C.POINTER(Prim), C.c_int, C.POINTER(C.c_void_p)]),
+    "hpsdf_field_create_callback": (C.c_int, [CALLBACK, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "hpsdf_field_create_mesh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                          C.POINTER(C.c_void_p)]),
+    "hpsdf_field_create_tree_csg": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "hpsdf_field_destroy": (C.c_int, [C.c_void_p]),
+    "hpsdf_field_eval_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hpsdf_field_eval_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hpsdf_tree_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "hpsdf_tree_destroy": (C.c_int, [C.c_void_p]),
+    "hpsdf_tree_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "hpsdf_query_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hpsdf_query_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hpsdf_build_begin": (C.c_int, [C.POINTER(PodConfig), C.POINTER(BuildOpts), C.POINTER(C.c_void_p)]),
+    "hpsdf_build_destroy": (C.c_int, [C.c_void_p]),
+    "hpsdf_build_round_select": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "hpsdf_build_round_jobs": (C.c_int, [C.c_void_p, C.POINTER(Job)]),
+    "hpsdf_build_round_slice": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "hpsdf_build_round_max_slice": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "hpsdf_build_round_compute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hpsdf_build_round_results_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    "hpsdf_build_round_results_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hpsdf_build_round_apply": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hpsdf_build_round_inject": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "hpsdf_build_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "hpsdf_build_pack_device": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    "hpsdf_build_pack_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hpsdf_build_assemble": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                       C.POINTER(C.c_size_t)]),
+    "hpsdf_build_get_stats": (C.c_int, [C.c_void_p, C.POINTER(BuildStats)]),
+    "hpsdf_create": (C.c_int, [C.c_void_p, C.POINTER(PodConfig), C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p),
+                               C.POINTER(C.c_size_t), C.POINTER(BuildStats)]),
+    "hpsdf_bench_fit": (C.c_int, [C.c_void_p, C.POINTER(PodConfig), C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int,
+                                  C.POINTER(C.c_double)]),
+}
+
+
+def lib():
+    """The HIP extension.  Raises if it has not been built: there is no fallback."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libhpsdf.so is not built (run __graft_entry__.build() or "
+                              "python hp-adaptive-signed-distance-field-octree_amd/build.py); "
+                              "there is no CPU fallback for the hot path")
+        try:
+            # torch-rocm bundles its own HIP/HSA runtime under the same SONAME; loading it first makes
+            # this library bind to that one copy (two HSA runtimes in one process cannot both see the GPU)
+            import torch  # noqa: F401
+        except Exception:
+            pass
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        L._libc = C.CDLL(None)
+        L._libc.free.argtypes = [C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    if rc != OK:
+        raise HpsdfError(rc, lib().hpsdf_last_error().decode("utf-8", "replace"))
+
+
+def tables():
+    L = lib()
+    out = {"roots": np.zeros(2080), "weights": np.zeros(2080), "normalised_lengths": np.zeros((13, 11)),
+           "recurrence": np.zeros((13, 2)), "coeff_count": np.zeros(13, np.uint64),
+           "basis_index": np.zeros((455, 3), np.uint64), "sum_to_n": np.zeros(50, np.uint64)}
+    check(L.hpsdf_tables_get(*[out[k].ctypes.data_as(C.c_void_p) for k in
+                               ("roots", "weights", "normalised_lengths", "recurrence", "coeff_count", "basis_index",
+                                "sum_to_n")]))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+class Config:
+    """SDF::Config with the reference's field names and defaults (Config.cpp:5-14)."""
+
+    def __init__(self):
+        pod = PodConfig()
+        check(lib().hpsdf_config_default(C.byref(pod)))
+        self.nearnessWeighting_type = 0
+        self.nearnessWeighting_strength = 0.0
+        self.continuity_enforce = bool(pod.continuity_enforce)
+        self.continuity_strength = pod.continuity_strength
+        self.enableLogging = False
+        self.targetErrorThreshold = pod.target_error_threshold
+        self.threadCount = int(pod.thread_count)
+        self.root_min = (-0.5, -0.5, -0.5)
+        self.root_max = (0.5, 0.5, 0.5)
+
+    def to_pod(self):
+        pod = PodConfig()
+        pod.weighting_type = self.nearnessWeighting_type
+        pod.weighting_strength = self.nearnessWeighting_strength
+        pod.continuity_enforce = 1 if self.continuity_enforce else 0
+        pod.continuity_strength = self.continuity_strength
+        pod.enable_logging = 1 if self.enableLogging else 0
+        pod.target_error_threshold = self.targetErrorThreshold
+        pod.thread_count = self.threadCount
+        for a in range(3):
+            pod.root_min[a] = self.root_min[a]
+            pod.root_max[a] = self.root_max[a]
+        return pod
+
+    @staticmethod
+    def from_pod(pod):
+        c = Config.__new__(Config)
+        c.nearnessWeighting_type = pod.weighting_type
+        c.nearnessWeighting_strength = pod.weighting_strength
+        c.continuity_enforce = bool(pod.continuity_enforce)
+        c.continuity_strength = pod.continuity_strength
+        c.enableLogging = bool(pod.enable_logging)
+        c.targetErrorThreshold = pod.target_error_threshold
+        c.threadCount = int(pod.thread_count)
+        c.root_min = tuple(pod.root_min)
+        c.root_max = tuple(pod.root_max)
+        return c
+
+
+def make_config(target=1e-10, root_min=(-0.5, -0.5, -0.5), root_max=(0.5, 0.5, 0.5), threads=1, continuity=False):
+    c = Config()
+    c.targetErrorThreshold = target
+    c.root_min, c.root_max = tuple(root_min), tuple(root_max)
+    c.threadCount = threads
+    c.continuity_enforce = continuity
+    return c
+
+
+class Context:
+    """One GPU + one HIP stream.  stream: raw hipStream_t (int) or None for a library-owned one."""
+
+    def __init__(self, device=0, stream=None):
+        self.handle = C.c_void_p()
+        check(lib().hpsdf_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self.handle)))
+        self.device = device
+
+    def set_stream(self, stream):
+        check(lib().hpsdf_ctx_set_stream(self.handle, C.c_void_p(stream) if stream else None))
+
+    def synchronize(self):
+        check(lib().hpsdf_ctx_synchronize(self.handle))
+
+    def close(self):
+        if self.handle:
+            lib().hpsdf_ctx_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Field:
+    def __init__(self, handle, keep=()):
+        self.handle = handle
+        self._keep = keep
+
+    @staticmethod
+    def analytic(spec):
+        """spec: list of (kind, op, params)."""
+        arr = (Prim * len(spec))()
+        for i, (kind, op, params) in enumerate(spec):
+            arr[i].kind, arr[i].op = kind, op
+            for j, v in enumerate(params):
+                arr[i].p[j] = float(v)
+        h = C.c_void_p()
+        check(lib().hpsdf_field_create_analytic(arr, len(spec), C.byref(h)))
+        return Field(h)
+
+    @staticmethod
+    def sphere(centre=(0.25, 0.0, 0.0), radius=0.5):
+        return Field.analytic([(PRIM_SPHERE, OP_UNION, list(centre) + [radius])])
+
+    @staticmethod
+    def union3():
+        """BASELINE config[1]: union of sphere, box, torus."""
+        return Field.analytic([
+            (PRIM_SPHERE, OP_UNION, [-0.2, -0.15, 0.1, 0.18]),
+            (PRIM_BOX, OP_UNION, [0.15, 0.2, -0.1, 0.12, 0.10, 0.15]),
+            (PRIM_TORUS_Y, OP_UNION, [0.0, -0.2, -0.2, 0.15, 0.05]),
+        ])
+
+    @staticmethod
+    def callback(fn):
+        """fn(pt: (x,y,z), thread_idx) -> float, called from host threads."""
+        def tramp(p, t, _u):
+            return float(fn((p[0], p[1], p[2]), t))
+        cb = CALLBACK(tramp)
+        h = C.c_void_p()
+        check(lib().hpsdf_field_create_callback(cb, None, C.byref(h)))
+        return Field(h, keep=(cb, fn))
+
+    @staticmethod
+    def mesh(ctx, verts, tris):
+        v = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
+        t = np.ascontiguousarray(tris, np.uint64).reshape(-1, 3)
+        h = C.c_void_p()
+        check(lib().hpsdf_field_create_mesh(ctx.handle, v.ctypes.data_as(C.c_void_p), len(v),
+                                            t.ctypes.data_as(C.c_void_p), len(t), C.byref(h)))
+        return Field(h, keep=(ctx,))
+
+    @staticmethod
+    def tree_csg(tree, op, inner):
+        h = C.c_void_p()
+        check(lib().hpsdf_field_create_tree_csg(tree.handle, op, inner.handle, C.byref(h)))
+        return Field(h, keep=(tree, inner))
+
+    def eval(self, ctx, pts):
+        pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)
+        out = np.empty(len(pts))
+        check(lib().hpsdf_field_eval_host(ctx.handle, self.handle, pts.ctypes.data_as(C.c_void_p), len(pts),
+                                          out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def close(self):
+        if self.handle:
+            lib().hpsdf_field_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceTree:
+    """A serialised octree resident in HBM (FromMemoryBlock on the device side)."""
+
+    def __init__(self, ctx, block):
+        self.ctx = ctx
+        self.block = bytes(block)
+        self.handle = C.c_void_p()
+        check(lib().hpsdf_tree_upload(ctx.handle, self.block, len(self.block), C.byref(self.handle)))
+
+    def info(self):
+        nn, nc, nl = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        md, mdep = C.c_int(), C.c_int()
+        check(lib().hpsdf_tree_info(self.handle, C.byref(nn), C.byref(nc), C.byref(nl), C.byref(md), C.byref(mdep)))
+        return {"n_nodes": nn.value, "n_coeffs": nc.value, "n_leaves": nl.value, "max_degree": md.value,
+                "max_depth": mdep.value}
+
+    def query(self, pts):
+        pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)
+        out = np.empty(len(pts))
+        check(lib().hpsdf_query_host(self.ctx.handle, self.handle, pts.ctypes.data_as(C.c_void_p), len(pts),
+                                     out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def query_device(self, d_xyz_ptr, n, d_out_ptr):
+        """Raw device pointers (ints); asynchronous on the context stream."""
+        check(lib().hpsdf_query_device(self.ctx.handle, self.handle, C.c_void_p(d_xyz_ptr), n, C.c_void_p(d_out_ptr)))
+
+    def close(self):
+        if self.handle:
+            lib().hpsdf_tree_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Build:
+    """Stepwise Create (one canonical round at a time); see include/hpsdf.h."""
+
+    def __init__(self, config, K=0, rank=0, world=1):
+        self.pod = config.to_pod() if isinstance(config, Config) else config
+        self.opts = BuildOpts(K, rank, world)
+        self.handle = C.c_void_p()
+        self.rank, self.world = rank, world
+        check(lib().hpsdf_build_begin(C.byref(self.pod), C.byref(self.opts), C.byref(self.handle)))
+
+    def select(self):
+        n = C.c_uint64()
+        check(lib().hpsdf_build_round_select(self.handle, C.byref(n)))
+        return n.value
+
+    def jobs(self, n):
+        arr = (Job * n)()
+        check(lib().hpsdf_build_round_jobs(self.handle, arr))
+        return arr
+
+    def slice(self, rank=None):
+        f, c = C.c_uint64(), C.c_uint64()
+        check(lib().hpsdf_build_round_slice(self.handle, self.rank if rank is None else rank, C.byref(f), C.byref(c)))
+        return f.value, c.value
+
+    def max_slice(self):
+        n = C.c_uint64()
+        check(lib().hpsdf_build_round_max_slice(self.handle, C.byref(n)))
+        return n.value
+
+    def compute(self, ctx, field):
+        check(lib().hpsdf_build_round_compute(self.handle, ctx.handle if ctx is not None else None, field.handle))
+
+    def results_device(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        check(lib().hpsdf_build_round_results_device(self.handle, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def results_host(self, ctx):
+        _, cnt = self.slice()
+        out = np.zeros(cnt * JOB_HEADER_DOUBLES)
+        check(lib().hpsdf_build_round_results_host(self.handle, ctx.handle, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def apply(self, headers):
+        h = np.ascontiguousarray(headers, np.float64)
+        check(lib().hpsdf_build_round_apply(self.handle, h.ctypes.data_as(C.c_void_p)))
+
+    def inject(self, job, p_coeffs, h_coeffs):
+        p = np.ascontiguousarray(p_coeffs, np.float64) if p_coeffs is not None else None
+        h = np.ascontiguousarray(h_coeffs, np.float64) if h_coeffs is not None else None
+        check(lib().hpsdf_build_round_inject(self.handle, job, p.ctypes.data_as(C.c_void_p) if p is not None else None,
+                                             h.ctypes.data_as(C.c_void_p) if h is not None else None))
+
+    def layout(self):
+        tot = C.c_uint64()
+        counts = (C.c_uint64 * self.world)()
+        check(lib().hpsdf_build_layout(self.handle, C.byref(tot), counts))
+        return tot.value, list(counts)
+
+    def pack_host(self, ctx, count):
+        out = np.zeros(max(1, count))
+        check(lib().hpsdf_build_pack_host(self.handle, ctx.handle if ctx is not None else None,
+                                          out.ctypes.data_as(C.c_void_p)))
+        return out[:count]
+
+    def pack_device(self, ctx):
+        p, n = C.c_void_p(), C.c_uint64()
+        check(lib().hpsdf_build_pack_device(self.handle, ctx.handle, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def assemble(self, packs):
+        keep = [np.ascontiguousarray(p, np.float64) if len(p) else np.zeros(1) for p in packs]
+        arr = (C.c_void_p * len(keep))(*[k.ctypes.data_as(C.c_void_p).value for k in keep])
+        blk, sz = C.c_void_p(), C.c_size_t()
+        check(lib().hpsdf_build_assemble(self.handle, arr, C.byref(blk), C.byref(sz)))
+        data = C.string_at(blk, sz.value)
+        lib()._libc.free(blk)
+        return data
+
+    def stats(self):
+        st = BuildStats()
+        check(lib().hpsdf_build_get_stats(self.handle, C.byref(st)))
+        return st.as_dict()
+
+    def close(self):
+        if self.handle:
+            lib().hpsdf_build_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def create_block(ctx, config, field, K=0):
+    """Octree::Create on one GPU -> (serialised block bytes, stats dict)."""
+    pod = config.to_pod() if isinstance(config, Config) else config
+    blk, sz, st = C.c_void_p(), C.c_size_t(), BuildStats()
+    check(lib().hpsdf_create(ctx.handle if ctx is not None else None, C.byref(pod), field.handle, K, C.byref(blk),
+                             C.byref(sz), C.byref(st)))
+    data = C.string_at(blk, sz.value)
+    lib()._libc.free(blk)
+    return data, st.as_dict()
+
+
+def bench_fit(ctx, config, field, degree, depth, n_cells, repeats=5):
+    pod = config.to_pod()
+    ms = C.c_double()
+    check(lib().hpsdf_bench_fit(ctx.handle, C.byref(pod), field.handle, degree, depth, n_cells, repeats, C.byref(ms)))
+    return ms.value
+
+
+class Octree:
+    """SDF::Octree mirror: Create / Query / ToMemoryBlock / FromMemoryBlock / CSG rebuilds."""
+
+    def __init__(self, device=0, stream=None, jobs_per_round=0):
+        self._device, self._stream, self.K = device, stream, jobs_per_round
+        self._ctx = None
+        self._tree = None
+        self.block = None
+        self.config = None
+        self.stats = None
+
+    @property
+    def ctx(self):
+        if self._ctx is None:
+            self._ctx = Context(self._device, self._stream)
+        return self._ctx
+
+    def Create(self, config, F):
+        """F: a Field, or a Python callable f(pt, threadIdx) like the reference's std::function."""
+        field = F if isinstance(F, Field) else Field.callback(F)
+        block, stats = create_block(self.ctx, config, field, self.K)
+        self.Clear()
+        self.block, self.stats, self.config = block, stats, config
+        self._tree = DeviceTree(self.ctx, block)
+
+    def _csg(self, op, F):
+        if self._tree is None:
+            raise HpsdfError(6, "CSG on an empty octree")
+        inner = F if isinstance(F, Field) else Field.callback(F)
+        field = Field.tree_csg(self._tree, op, inner)
+        old = self._tree
+        block, stats = create_block(self.ctx, self.config, field, self.K)
+        field.close()
+        old.close()
+        self.block, self.stats = block, stats
+        self._tree = DeviceTree(self.ctx, block)
+
+    def UnionSDF(self, F):
+        self._csg(OP_UNION, F)
+
+    def SubtractSDF(self, F):
+        self._csg(OP_SUBTRACT, F)
+
+    def IntersectSDF(self, F):
+        self._csg(OP_INTERSECT, F)
+
+    def Clear(self):
+        if self._tree is not None:
+            self._tree.close()
+        self._tree, self.block = None, None
+
+    def FromMemoryBlock(self, block):
+        if not block:
+            raise HpsdfError(4, "empty MemoryBlock")
+        self.Clear()
+        self.block = bytes(block)
+        pod = PodConfig.from_buffer_copy(self.block[-C.sizeof(PodConfig):])
+        self.config = Config.from_pod(pod)
+        self._tree = DeviceTree(self.ctx, self.block)
+
+    def ToMemoryBlock(self):
+        return bytes(self.block) if self.block is not None else b""
+
+    def Query(self, pts):
+        """One point (3,) -> float, or (n,3) -> ndarray; DBL_MAX outside the root."""
+        if self._tree is None:
+            raise HpsdfError(6, "Query on an empty octree")
+        a = np.asarray(pts, np.float64)
+        out = self._tree.query(a)
+        return float(out[0]) if a.ndim == 1 else out
+
+    def GetRootAABB(self):
+        return self.config.root_min, self.config.root_max
+
+    def copy(self):
+        o = Octree(self._device, self._stream, self.K)
+        if self.block is not None:
+            o.FromMemoryBlock(self.block)
+            o.stats = self.stats
+        return o

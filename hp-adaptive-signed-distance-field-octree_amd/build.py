@@ -1,0 +1,77 @@
+"""Build libhpsdf.so (HIP kernels + host runtime + C ABI + C++ drop-in) for gfx950, in-tree.
+
+hipcc cross-compiles without a GPU; the built .so sits next to this file in lib/ so that it
+travels with the source tree (it is git-ignored, not gpurun-ignored).
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libhpsdf.so")
+INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
+
+SOURCES = ["kernels.hip", "tables.cpp", "builder.cpp", "mesh.cpp", "capi.cpp"]
+HEADERS = ["tables.hpp", "device_types.hpp", "launch.hpp", "runtime.hpp", "builder.hpp"]
+PUBLIC_HEADERS = ["hpsdf.h", "hpsdf_octree.hpp"]
+
+# -ffp-contract=off: no multiply-add is fused anywhere (bit parity with the x86-64 reference path)
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "--offload-arch=gfx950",
+         "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-I", INCLUDE]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: the HIP extension cannot be built (there is no CPU fallback)")
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.join(INCLUDE, h) for h in PUBLIC_HEADERS]
+    deps.append(os.path.abspath(__file__))
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not stale():
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    objs = []
+    cc = hipcc()
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    procs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(objdir, s + ".o")
+        objs.append(obj)
+        if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
+                and all(os.path.getmtime(obj) > os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+                and all(os.path.getmtime(obj) > os.path.getmtime(os.path.join(INCLUDE, h)) for h in PUBLIC_HEADERS)):
+            continue
+        cmd = [cc] + FLAGS + (["-x", "hip"] if s.endswith(".cpp") and False else []) + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (s, out))
+        if verbose and out.strip():
+            print(out)
+    cmd = [cc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stdout)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,657 @@
+#include "builder.hpp"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+#include "launch.hpp"
+
+using namespace hpsdf;
+
+namespace {
+
+const uint64_t kNone = ~0ull;
+
+inline uint64_t ncoef(int p) { return tables().coeffCount[p]; }
+
+// strict total order of the frontier: larger error first, then smaller node index
+inline bool before(const hpsdf_build::HeapEnt& a, const hpsdf_build::HeapEnt& b) {
+    return a.err > b.err || (a.err == b.err && a.idx < b.idx);
+}
+struct HeapLess {  // std heap keeps the "largest" on top: largest = first in the order above
+    bool operator()(const hpsdf_build::HeapEnt& a, const hpsdf_build::HeapEnt& b) const { return before(b, a); }
+};
+
+void initNode(hpsdf_node& n) {  // Source/HP/Node.cpp:5-15, padding zeroed
+    std::memset(&n, 0, sizeof(n));
+    n.child_idx = kNone;
+    for (int a = 0; a < 3; ++a) {
+        n.aabb_min[a] = FLT_MAX;
+        n.aabb_max[a] = -FLT_MAX;
+    }
+    n.degree = kInteriorDegree;
+    n.depth = kMaxDepth + 1;
+}
+
+// Octree::CornerAABB, Octree.cpp:1096-1112: f32 midpoint split, bit d of i selects the upper half on axis d
+void cornerBox(const float* bmin, const float* bmax, unsigned i, float* omin, float* omax) {
+    for (int d = 0; d < 3; ++d) {
+        const float mid = (bmax[d] + bmin[d]) * 0.5f;
+        omin[d] = (i >> d) & 1u ? mid : bmin[d];
+        omax[d] = (i >> d) & 1u ? bmax[d] : mid;
+    }
+}
+
+// Octree::Subdivide, Octree.cpp:1115-1128: children appended as a block of 8
+void subdivide(hpsdf_build* b, uint64_t idx) {
+    const uint64_t first = b->nodes.size();
+    b->nodes[idx].child_idx = first;
+    b->nodes.resize(first + 8);
+    b->segHead.resize(first + 8, -1);
+    b->segTail.resize(first + 8, -1);
+    for (unsigned i = 0; i < 8; ++i) {
+        hpsdf_node& c = b->nodes[first + i];
+        initNode(c);
+        cornerBox(b->nodes[idx].aabb_min, b->nodes[idx].aabb_max, i, c.aabb_min, c.aabb_max);
+        c.depth = (uint8_t)(b->nodes[idx].depth + 1);
+    }
+}
+
+// Octree::UniformlyRefine, Octree.cpp:112-191: depth-first, a node is split when first reached,
+// depth-4 cells become degree-0 leaves queued with the initial error
+void uniformRefine(hpsdf_build* b, uint64_t idx, int depth) {
+    if (depth < 4) {
+        subdivide(b, idx);
+        const uint64_t c = b->nodes[idx].child_idx;
+        for (unsigned i = 0; i < 8; ++i) uniformRefine(b, c + i, depth + 1);
+    } else {
+        b->nodes[idx].degree = 0;
+        b->heap.push_back({idx, HPSDF_INITIAL_NODE_ERR});
+    }
+}
+
+void appendSeg(hpsdf_build* b, uint64_t node, const hpsdf_build::Seg& s) {
+    b->segs.push_back(s);
+    const int64_t id = (int64_t)b->segs.size() - 1;
+    if (b->segHead[node] < 0)
+        b->segHead[node] = id;
+    else
+        b->segs[b->segTail[node]].next = id;
+    b->segTail[node] = id;
+}
+
+template <typename T>
+int growDevice(T** p, uint64_t* cap, uint64_t want) {
+    if (want <= *cap) return HPSDF_OK;
+    uint64_t nc = *cap ? *cap : 1024;
+    while (nc < want) nc *= 2;
+    if (*p) HPSDF_HIP(hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    HPSDF_HIP(hipMalloc((void**)p, nc * sizeof(T)));
+    *cap = nc;
+    return HPSDF_OK;
+}
+
+struct HostTask {
+    FitTask t;
+    uint8_t degree;
+    uint16_t rowStart, rowEnd;
+};
+
+}  // namespace
+
+hpsdf_build::~hpsdf_build() {
+    if (device >= 0) {
+        (void)hipSetDevice(device);
+        if (dArena) (void)hipFree(dArena);
+        if (dTasks) (void)hipFree(dTasks);
+        if (dBlocks) (void)hipFree(dBlocks);
+        if (dErrs) (void)hipFree(dErrs);
+        if (dSamples) (void)hipFree(dSamples);
+        if (dPack) (void)hipFree(dPack);
+        if (dPackItems) (void)hipFree(dPackItems);
+    }
+}
+
+namespace hpsdf {
+
+// flop-proportional cost of one job, used only to balance the slices
+uint64_t jobCost(int degree, int depth, bool coarse) {
+    auto cube = [](uint64_t n) { return n * n * n; };
+    if (coarse) return ncoef(2) * cube(9);
+    uint64_t c = 0;
+    if (depth < kMaxDepth) c += 8 * ncoef(degree) * cube(4 * degree + 1);
+    if (degree < kMaxDegree - 1) c += (ncoef(degree + 1) - ncoef(degree)) * cube(4 * degree + 5);
+    return c ? c : 1;
+}
+
+int builderBegin(hpsdf_build* b, const hpsdf_config* cfg, const hpsdf_build_opts* opts) {
+    // Config::IsValid, Source/HP/Config.cpp:17-32 (asserts there, status codes here)
+    if (!(cfg->target_error_threshold > 0.0)) return fail(HPSDF_ERR_INVALID_ARGUMENT, "targetErrorThreshold must be > 0");
+    if (cfg->thread_count == 0) return fail(HPSDF_ERR_INVALID_ARGUMENT, "threadCount must be > 0");
+    {
+        float vol = 1.0f;
+        for (int a = 0; a < 3; ++a) vol *= (cfg->root_max[a] - cfg->root_min[a]);
+        if (!(vol > 0.0f)) return fail(HPSDF_ERR_INVALID_ARGUMENT, "root volume must be > 0");
+    }
+    if (cfg->weighting_type != 0)
+        return fail(HPSDF_ERR_UNSUPPORTED,
+                    "nearnessWeighting != None draws from std::rand() in the reference (Octree.cpp:1209-1247) and is "
+                    "not part of the GPU path yet");
+    b->cfg = *cfg;
+    std::memset(b->cfg.pad0, 0, sizeof b->cfg.pad0);
+    std::memset(b->cfg.pad1, 0, sizeof b->cfg.pad1);
+    std::memset(b->cfg.pad2, 0, sizeof b->cfg.pad2);
+    if (opts) {
+        if (opts->world < 1 || opts->rank < 0 || opts->rank >= opts->world)
+            return fail(HPSDF_ERR_INVALID_ARGUMENT, "bad rank/world");
+        b->K = opts->max_jobs_per_round ? opts->max_jobs_per_round : HPSDF_DEFAULT_JOBS_PER_ROUND;
+        b->rank = opts->rank;
+        b->world = opts->world;
+    }
+    // CreateRoot, Octree.cpp:792-801
+    b->nodes.resize(1);
+    b->segHead.assign(1, -1);
+    b->segTail.assign(1, -1);
+    initNode(b->nodes[0]);
+    b->nodes[0].depth = 0;
+    for (int a = 0; a < 3; ++a) {
+        b->nodes[0].aabb_min[a] = -0.5f;
+        b->nodes[0].aabb_max[a] = 0.5f;
+    }
+    subdivide(b, 0);
+    for (unsigned i = 0; i < 8; ++i) uniformRefine(b, b->nodes[0].child_idx + i, 1);
+    std::make_heap(b->heap.begin(), b->heap.end(), HeapLess());
+    b->total = std::pow(8, 4) * HPSDF_INITIAL_NODE_ERR;  // Octree.cpp:212
+    b->slices.assign(b->world, {0, 0});
+    return HPSDF_OK;
+}
+
+int builderSelect(hpsdf_build* b, uint64_t* nJobs) {
+    *nJobs = 0;
+    if (b->roundOpen) return fail(HPSDF_ERR_STATE, "previous round not applied");
+    if (b->finished) return HPSDF_OK;
+    if (b->total < b->cfg.target_error_threshold || b->heap.empty()) {  // Octree.cpp:216
+        b->finished = true;
+        return HPSDF_OK;
+    }
+    const uint64_t want = b->stats.rounds == 0 ? b->heap.size() : std::min<uint64_t>(b->K, b->heap.size());
+    b->batch.resize(want);
+    for (uint64_t i = 0; i < want; ++i) {
+        std::pop_heap(b->heap.begin(), b->heap.end(), HeapLess());
+        b->batch[i] = b->heap.back();
+        b->heap.pop_back();
+    }
+    std::sort(b->batch.begin(), b->batch.end(),
+              [](const hpsdf_build::HeapEnt& x, const hpsdf_build::HeapEnt& y) { return x.idx < y.idx; });
+    // contiguous cost-balanced slices, the same on every rank
+    std::vector<uint64_t> prefix(want + 1, 0);
+    for (uint64_t j = 0; j < want; ++j) {
+        const hpsdf_node& n = b->nodes[b->batch[j].idx];
+        const bool coarse = std::fabs(b->batch[j].err - HPSDF_INITIAL_NODE_ERR) < DBL_EPSILON;
+        prefix[j + 1] = prefix[j] + jobCost(n.degree, n.depth, coarse);
+    }
+    uint64_t start = 0;
+    for (int r = 0; r < b->world; ++r) {
+        uint64_t end = want;
+        if (r + 1 < b->world) {
+            const uint64_t target = (uint64_t)(((unsigned __int128)prefix[want] * (uint64_t)(r + 1)) / (uint64_t)b->world);
+            end = (uint64_t)(std::lower_bound(prefix.begin(), prefix.end(), target) - prefix.begin());
+            end = std::min(std::max(end, start), want);
+        }
+        b->slices[r] = {start, end - start};
+        start = end;
+    }
+    b->jobOut.assign(b->slices[b->rank].count, hpsdf_build::JobOut());
+    b->roundOpen = true;
+    b->computed = false;
+    *nJobs = want;
+    return HPSDF_OK;
+}
+
+int builderJobs(const hpsdf_build* b, hpsdf_job* out) {
+    if (!b->roundOpen) return fail(HPSDF_ERR_STATE, "no open round");
+    for (size_t j = 0; j < b->batch.size(); ++j) {
+        const hpsdf_node& n = b->nodes[b->batch[j].idx];
+        hpsdf_job& o = out[j];
+        std::memset(&o, 0, sizeof o);
+        o.node_idx = b->batch[j].idx;
+        for (int a = 0; a < 3; ++a) {
+            o.aabb_min[a] = n.aabb_min[a];
+            o.aabb_max[a] = n.aabb_max[a];
+        }
+        o.err = b->batch[j].err;
+        o.degree = n.degree;
+        o.depth = n.depth;
+        o.coarse = std::fabs(o.err - HPSDF_INITIAL_NODE_ERR) < DBL_EPSILON;  // Octree.cpp:806,831
+    }
+    return HPSDF_OK;
+}
+
+// -----------------------------------------------------------------------------------------------
+// GPU leg of a round: every job of this rank's slice becomes 1 (coarse) or up to 9 cell fits
+// (EstimateHImprovement: 8 children from scratch, Octree.cpp:814-822; EstimatePImprovement: the
+// new rows of degree p+1, :846-851).
+// -----------------------------------------------------------------------------------------------
+int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
+    if (!b->roundOpen) return fail(HPSDF_ERR_STATE, "no open round");
+    if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "round_compute needs a device context (there is no CPU path)");
+    if (!field) return fail(HPSDF_ERR_INVALID_ARGUMENT, "field is null");
+    HPSDF_HIP(hipSetDevice(ctx->device));
+    b->device = ctx->device;
+    const hpsdf_build::Slice sl = b->slices[b->rank];
+    std::vector<HostTask> tasks;
+    tasks.reserve(sl.count * 9);
+    uint64_t arenaNeed = 0, sampleNeed = 0;
+    const bool sampled = innermost(field)->kind == kHostCallback;
+    auto addTask = [&](const float* bmin, const float* bmax, int degree, int rowStart, int depth, uint32_t errSlot) {
+        HostTask h;
+        std::memset(&h, 0, sizeof h);
+        for (int a = 0; a < 3; ++a) {
+            h.t.bmin[a] = bmin[a];
+            h.t.bmax[a] = bmax[a];
+        }
+        h.degree = (uint8_t)degree;
+        h.rowStart = (uint16_t)rowStart;
+        h.rowEnd = (uint16_t)ncoef(degree);
+        h.t.outOff = b->arenaUsed + arenaNeed;
+        h.t.copyOff = kNone;
+        h.t.sampleOff = sampleNeed;
+        h.t.errSlot = errSlot;
+        h.t.depth = (uint8_t)depth;
+        arenaNeed += h.rowEnd - h.rowStart;
+        const uint64_t nq = 4 * (uint64_t)degree + 1;
+        sampleNeed += nq * nq * nq;
+        tasks.push_back(h);
+        return h.t.outOff;
+    };
+    for (uint64_t jl = 0; jl < sl.count; ++jl) {
+        const hpsdf_build::HeapEnt& e = b->batch[sl.first + jl];
+        const hpsdf_node& n = b->nodes[e.idx];
+        const bool coarse = std::fabs(e.err - HPSDF_INITIAL_NODE_ERR) < DBL_EPSILON;
+        hpsdf_build::JobOut& jo = b->jobOut[jl];
+        const uint32_t slot0 = (uint32_t)(jl * HPSDF_JOB_HEADER_DOUBLES);
+        if (coarse) {
+            jo.pOff = addTask(n.aabb_min, n.aabb_max, 2, 0, n.depth, slot0);  // Octree.cpp:836-843
+            jo.pHost = 0;
+            b->stats.fits += 1;
+            continue;
+        }
+        const int p = n.degree, d = n.depth;
+        if (d < kMaxDepth) {  // the reference fits depth-11 children of depth-10 cells and discards them (:601)
+            jo.hOff = b->arenaUsed + arenaNeed;
+            jo.hHost = 0;
+            for (unsigned i = 0; i < 8; ++i) {
+                float cmin[3], cmax[3];
+                cornerBox(n.aabb_min, n.aabb_max, i, cmin, cmax);
+                addTask(cmin, cmax, p, 0, d + 1, slot0 + 1 + i);
+            }
+            b->stats.fits += 8;
+        }
+        if (p < kMaxDegree - 1) {  // degree 11 is never raised (:600)
+            jo.pOff = addTask(n.aabb_min, n.aabb_max, p + 1, (int)ncoef(p), d, slot0);
+            jo.pHost = 0;
+            b->stats.fits += 1;
+        }
+    }
+    b->stats.samples += sampleNeed;
+
+    // group fits of equal shape into workgroups
+    std::vector<uint32_t> order(tasks.size());
+    for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
+    auto key = [&](uint32_t i) { return ((uint32_t)tasks[i].degree << 16) | tasks[i].rowStart; };
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return key(x) < key(y); });
+    std::vector<FitTask> flat(tasks.size());
+    std::vector<FitBlock> blocks;
+    size_t maxLds = 0;
+    for (size_t s = 0; s < order.size();) {
+        size_t e = s;
+        while (e < order.size() && key(order[e]) == key(order[s])) ++e;
+        const HostTask& h0 = tasks[order[s]];
+        const int nrows = h0.rowEnd - h0.rowStart;
+        const int nq = 4 * h0.degree + 1;
+        int gmax = nrows > kFitBlockThreads ? 1 : kFitBlockThreads / nrows;
+        while (gmax > 1 && fitLdsBytes(h0.degree, gmax) > kFitMaxLdsBytes) --gmax;
+        (void)nq;
+        const size_t n = e - s;
+        int g = (int)std::min<size_t>((size_t)gmax, std::max<size_t>(1, (n + 511) / 512));
+        for (size_t i = s; i < e; i += g) {
+            FitBlock fb;
+            std::memset(&fb, 0, sizeof fb);
+            fb.firstTask = (uint32_t)i;
+            fb.nTasks = (uint16_t)std::min<size_t>(g, e - i);
+            fb.degree = h0.degree;
+            fb.rowStart = h0.rowStart;
+            fb.rowEnd = h0.rowEnd;
+            blocks.push_back(fb);
+        }
+        maxLds = std::max(maxLds, fitLdsBytes(h0.degree, g));
+        for (size_t i = s; i < e; ++i) flat[i] = tasks[order[i]].t;
+        s = e;
+    }
+
+    // arena: grow by reallocation (offsets are stable, pointers are not kept)
+    if (b->arenaUsed + arenaNeed > b->arenaCap) {
+        uint64_t nc = std::max<uint64_t>(b->arenaCap * 2, 1ull << 22);
+        while (nc < b->arenaUsed + arenaNeed) nc *= 2;
+        double* na = nullptr;
+        HPSDF_HIP(hipMalloc((void**)&na, nc * sizeof(double)));
+        if (b->dArena) {
+            HPSDF_HIP(hipMemcpyAsync(na, b->dArena, b->arenaUsed * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+            HPSDF_HIP(hipStreamSynchronize(ctx->stream));
+            HPSDF_HIP(hipFree(b->dArena));
+        }
+        b->dArena = na;
+        b->arenaCap = nc;
+    }
+    b->arenaUsed += arenaNeed;
+
+    int rc;
+    if ((rc = growDevice(&b->dTasks, &b->tasksCap, flat.size()))) return rc;
+    if ((rc = growDevice(&b->dBlocks, &b->blocksCap, blocks.size()))) return rc;
+    if ((rc = growDevice(&b->dErrs, &b->errsCap, std::max<uint64_t>(1, sl.count * HPSDF_JOB_HEADER_DOUBLES)))) return rc;
+
+    // host-evaluated field: sample every fit's grid with thread_count workers, ship the values
+    const double* dSamples = nullptr;
+    if (sampled) {
+        const hpsdf_field* cbf = innermost(field);
+        std::vector<double> vals(sampleNeed);
+        const Tables& T = tables();
+        double rb[3], rc3[3];
+        for (int a = 0; a < 3; ++a) {
+            rb[a] = (double)(b->cfg.root_max[a] - b->cfg.root_min[a]);
+            rc3[a] = (double)((b->cfg.root_min[a] + b->cfg.root_max[a]) / 2.0f);
+        }
+        const unsigned nThreads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(b->cfg.thread_count, 256));
+        auto worker = [&](unsigned tIdx) {
+            for (size_t ti = tIdx; ti < flat.size(); ti += nThreads) {
+                const FitTask& tk = flat[ti];
+                // degree of this task: recover from block table is awkward; recompute from sample span
+                const HostTask& ht = tasks[order[ti]];
+                const int nq = 4 * ht.degree + 1, gl = glOffset(nq);
+                double sc[3], ce[3];
+                for (int a = 0; a < 3; ++a) {
+                    sc[a] = (double)(tk.bmax[a] - tk.bmin[a]) * 0.5;
+                    ce[a] = (double)((tk.bmin[a] + tk.bmax[a]) / 2.0f);
+                }
+                uint64_t o = tk.sampleOff;
+                for (int i = 0; i < nq; ++i)
+                    for (int j = 0; j < nq; ++j)
+                        for (int k = 0; k < nq; ++k) {
+                            const double u[3] = {T.roots[gl + i] * sc[0] + ce[0], T.roots[gl + j] * sc[1] + ce[1],
+                                                 T.roots[gl + k] * sc[2] + ce[2]};
+                            const double w[3] = {u[0] * rb[0] + rc3[0], u[1] * rb[1] + rc3[1], u[2] * rb[2] + rc3[2]};
+                            vals[o++] = cbf->cb(w, tIdx, cbf->user);
+                        }
+            }
+        };
+        if (nThreads == 1) {
+            worker(0);
+        } else {
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < nThreads; ++t) pool.emplace_back(worker, t);
+            for (auto& th : pool) th.join();
+        }
+        if ((rc = growDevice(&b->dSamples, &b->samplesCap, std::max<uint64_t>(1, sampleNeed)))) return rc;
+        HPSDF_HIP(hipMemcpyAsync(b->dSamples, vals.data(), sampleNeed * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HPSDF_HIP(hipStreamSynchronize(ctx->stream));  // vals is pageable and goes out of scope
+        dSamples = b->dSamples;
+    }
+
+    FieldDev fd;
+    if ((rc = makeFieldDev(field, dSamples, &fd))) return rc;
+    RootMap rm;
+    for (int a = 0; a < 3; ++a) {
+        rm.bounds[a] = (double)(b->cfg.root_max[a] - b->cfg.root_min[a]);          // Octree.cpp:324
+        rm.centre[a] = (double)((b->cfg.root_min[a] + b->cfg.root_max[a]) / 2.0f);  // Octree.cpp:322
+    }
+    if (!flat.empty()) {
+        HPSDF_HIP(hipMemcpyAsync(b->dTasks, flat.data(), flat.size() * sizeof(FitTask), hipMemcpyHostToDevice, ctx->stream));
+        HPSDF_HIP(hipMemcpyAsync(b->dBlocks, blocks.data(), blocks.size() * sizeof(FitBlock), hipMemcpyHostToDevice,
+                                 ctx->stream));
+        HPSDF_HIP(hipStreamSynchronize(ctx->stream));  // pageable sources die with this scope
+    }
+    HPSDF_HIP(hipMemsetAsync(b->dErrs, 0, std::max<uint64_t>(1, sl.count * HPSDF_JOB_HEADER_DOUBLES) * sizeof(double),
+                             ctx->stream));
+    HPSDF_HIP(launchFit(ctx->stream, b->dBlocks, (uint32_t)blocks.size(), maxLds, b->dTasks, b->dArena, b->dErrs,
+                        ctx->dTables, fd, rm));
+    b->computed = true;
+    return HPSDF_OK;
+}
+
+int builderInject(hpsdf_build* b, uint64_t job, const double* pCoeffs, const double* hCoeffs) {
+    if (!b->roundOpen) return fail(HPSDF_ERR_STATE, "no open round");
+    const hpsdf_build::Slice sl = b->slices[b->rank];
+    if (job < sl.first || job >= sl.first + sl.count) return fail(HPSDF_ERR_INVALID_ARGUMENT, "job not in this rank's slice");
+    const hpsdf_build::HeapEnt& e = b->batch[job];
+    const hpsdf_node& n = b->nodes[e.idx];
+    const bool coarse = std::fabs(e.err - HPSDF_INITIAL_NODE_ERR) < DBL_EPSILON;
+    hpsdf_build::JobOut& jo = b->jobOut[job - sl.first];
+    if (pCoeffs) {
+        const uint64_t rs = coarse ? 0 : ncoef(n.degree), re = coarse ? ncoef(2) : ncoef(n.degree + 1);
+        jo.pOff = b->hostStore.size();
+        jo.pHost = 1;
+        b->hostStore.insert(b->hostStore.end(), pCoeffs + rs, pCoeffs + re);
+    }
+    if (hCoeffs && !coarse) {
+        jo.hOff = b->hostStore.size();
+        jo.hHost = 1;
+        b->hostStore.insert(b->hostStore.end(), hCoeffs, hCoeffs + 8 * ncoef(n.degree));
+    }
+    return HPSDF_OK;
+}
+
+// Octree.cpp:594-601 (decision) and :243-299 (bookkeeping), in node-index order
+int builderApply(hpsdf_build* b, const double* headers) {
+    if (!b->roundOpen) return fail(HPSDF_ERR_STATE, "no open round");
+    const Tables& T = tables();
+    int owner = 0;
+    for (uint64_t j = 0; j < b->batch.size(); ++j) {
+        while (owner + 1 < b->world && j >= b->slices[owner].first + b->slices[owner].count) ++owner;
+        const bool mine = owner == b->rank;
+        const hpsdf_build::JobOut* jo = mine ? &b->jobOut[j - b->slices[b->rank].first] : nullptr;
+        const uint64_t idx = b->batch[j].idx;
+        const double err = b->batch[j].err;
+        const int p = b->nodes[idx].degree, d = b->nodes[idx].depth;
+        const double* h = headers + j * HPSDF_JOB_HEADER_DOUBLES;
+        const double pErr = h[0];
+        const bool coarse = std::fabs(err - HPSDF_INITIAL_NODE_ERR) < DBL_EPSILON;
+        double pImp, hImp;
+        if (coarse) {
+            hImp = 0.0;   // :806-810
+            pImp = pErr;  // :842
+        } else {
+            if (d < kMaxDepth) {
+                double maxNewErr = 0.0;
+                for (int i = 0; i < 8; ++i) maxNewErr = std::max<double>(maxNewErr, h[1 + i]);
+                hImp = (1.0 / (7.0 * (double)T.coeffCount[p])) * (err - 8.0 * maxNewErr);  // :825
+            } else {
+                hImp = 0.0;
+            }
+            if (p < kMaxDegree - 1)
+                pImp = (1.0 / (double)(T.coeffCount[p + 1] - T.coeffCount[p])) * (err - 8.0 * pErr);  // :854
+            else
+                pImp = 0.0;
+        }
+        bool refineP = p < (kMaxDegree - 1) && (d == kMaxDepth || pImp > hImp);  // :600
+        if (coarse) refineP = true;  // a zero-error coarse fit would otherwise take the H branch with no child fits
+        const bool refineH = d < kMaxDepth && !refineP;                          // :601
+        b->stats.jobs++;
+        if (refineP) {  // :253-260, :286-290
+            const int np = coarse ? 2 : p + 1;
+            hpsdf_build::Seg s;
+            s.off = mine ? jo->pOff : kNone;
+            s.rowStart = coarse ? 0u : (uint32_t)T.coeffCount[p];
+            s.rowEnd = (uint32_t)T.coeffCount[np];
+            s.owner = owner;
+            s.hostStore = mine ? jo->pHost : 0;
+            s.next = -1;
+            if (mine && s.off == kNone) return fail(HPSDF_ERR_STATE, "P result of an owned job was never computed");
+            appendSeg(b, idx, s);
+            b->nodes[idx].degree = (uint8_t)np;
+            b->total += (pErr - err);
+            b->heap.push_back({idx, pErr});
+            std::push_heap(b->heap.begin(), b->heap.end(), HeapLess());
+            b->stats.p_refines++;
+        } else if (refineH) {  // :262-279, :286-290
+            if (mine && jo->hOff == kNone) return fail(HPSDF_ERR_STATE, "H result of an owned job was never computed");
+            b->segHead[idx] = b->segTail[idx] = -1;  // parent basis dropped
+            b->nodes[idx].degree = kInteriorDegree;
+            subdivide(b, idx);
+            b->total -= err;
+            const uint64_t c0 = b->nodes[idx].child_idx;
+            for (unsigned i = 0; i < 8; ++i) {
+                hpsdf_build::Seg s;
+                s.off = mine ? jo->hOff + (uint64_t)i * T.coeffCount[p] : kNone;
+                s.rowStart = 0;
+                s.rowEnd = (uint32_t)T.coeffCount[p];
+                s.owner = owner;
+                s.hostStore = mine ? jo->hHost : 0;
+                s.next = -1;
+                appendSeg(b, c0 + i, s);
+                b->nodes[c0 + i].degree = (uint8_t)p;
+                b->total += h[1 + i];
+                b->heap.push_back({c0 + i, h[1 + i]});
+                std::push_heap(b->heap.begin(), b->heap.end(), HeapLess());
+            }
+            b->stats.h_refines++;
+        } else {
+            b->stats.dropped++;  // :643-655: keeps its basis, never queued again
+        }
+        if (b->cfg.enable_logging)  // :292-296
+            std::printf("\n%.11f\t%zu", b->total, b->nodes.size());
+    }
+    b->stats.rounds++;
+    b->stats.total_error = b->total;
+    b->roundOpen = false;
+    return HPSDF_OK;
+}
+
+// Octree::ReallocCoeffs, Octree.cpp:474-555: children 0..7 depth first from the root, leaves
+// packed in visit order
+int builderLayout(hpsdf_build* b) {
+    if (b->roundOpen) return fail(HPSDF_ERR_STATE, "round still open");
+    const Tables& T = tables();
+    b->layout.clear();
+    b->packCounts.assign(b->world, 0);
+    uint64_t cursor = 0, leaves = 0;
+    struct Frame {
+        uint64_t node;
+        int child;
+    };
+    std::vector<Frame> st;
+    st.push_back({0, 0});
+    while (!st.empty()) {
+        Frame& f = st.back();
+        if (f.child == 8) {
+            st.pop_back();
+            continue;
+        }
+        const uint64_t n = b->nodes[f.node].child_idx + (uint64_t)f.child++;
+        if (b->nodes[n].child_idx == kNone) {
+            ++leaves;
+            b->nodes[n].coeffs_start = cursor;
+            uint32_t row = 0;
+            for (int64_t s = b->segHead[n]; s >= 0; s = b->segs[s].next) {
+                const hpsdf_build::Seg& sg = b->segs[s];
+                if (sg.rowStart != row) return fail(HPSDF_ERR_STATE, "coefficient segments are not contiguous");
+                b->layout.push_back({sg.off, cursor + sg.rowStart, sg.rowEnd - sg.rowStart, sg.owner, sg.hostStore});
+                b->packCounts[sg.owner] += sg.rowEnd - sg.rowStart;
+                row = sg.rowEnd;
+            }
+            cursor += T.coeffCount[b->nodes[n].degree];
+        } else {
+            b->nodes[n].coeffs_start = 0;  // the reference leaves a stale pointer here
+            st.push_back({n, 0});
+        }
+    }
+    b->nCoeffsTotal = cursor;
+    b->stats.n_nodes = b->nodes.size();
+    b->stats.n_leaves = leaves;
+    b->stats.n_coeffs = cursor;
+    b->laidOut = true;
+    return HPSDF_OK;
+}
+
+int builderPackDevice(hpsdf_build* b, hpsdf_ctx* ctx, double** dPack, uint64_t* n) {
+    if (!b->laidOut) return fail(HPSDF_ERR_STATE, "call hpsdf_build_layout first");
+    if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "pack_device needs a device context");
+    HPSDF_HIP(hipSetDevice(ctx->device));
+    b->device = ctx->device;
+    std::vector<PackItem> items;
+    uint64_t pos = 0;
+    for (const auto& l : b->layout) {
+        if (l.owner != b->rank) continue;
+        if (!l.hostStore) items.push_back({l.src, pos, l.count, 0});
+        pos += l.count;
+    }
+    int rc;
+    if ((rc = growDevice(&b->dPack, &b->packCap, std::max<uint64_t>(1, pos)))) return rc;
+    if ((rc = growDevice(&b->dPackItems, &b->packItemsCap, std::max<uint64_t>(1, items.size())))) return rc;
+    if (!items.empty()) {
+        HPSDF_HIP(hipMemcpyAsync(b->dPackItems, items.data(), items.size() * sizeof(PackItem), hipMemcpyHostToDevice,
+                                 ctx->stream));
+        HPSDF_HIP(hipStreamSynchronize(ctx->stream));
+        HPSDF_HIP(launchPack(ctx->stream, b->dPackItems, (uint32_t)items.size(), b->dArena, b->dPack));
+    }
+    if (dPack) *dPack = b->dPack;
+    if (n) *n = pos;
+    return HPSDF_OK;
+}
+
+int builderPackHost(hpsdf_build* b, hpsdf_ctx* ctx, double* out) {
+    if (!b->laidOut) return fail(HPSDF_ERR_STATE, "call hpsdf_build_layout first");
+    bool anyDevice = false;
+    for (const auto& l : b->layout) anyDevice |= (l.owner == b->rank && !l.hostStore);
+    if (anyDevice) {
+        double* dp = nullptr;
+        uint64_t n = 0;
+        int rc = builderPackDevice(b, ctx, &dp, &n);
+        if (rc) return rc;
+        HPSDF_HIP(hipMemcpyAsync(out, dp, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HPSDF_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    uint64_t pos = 0;
+    for (const auto& l : b->layout) {
+        if (l.owner != b->rank) continue;
+        if (l.hostStore) std::memcpy(out + pos, b->hostStore.data() + l.src, l.count * sizeof(double));
+        pos += l.count;
+    }
+    return HPSDF_OK;
+}
+
+// Octree::ToMemoryBlock, Octree.cpp:424-456:
+//   [u64 nCoeffs][f64 x nCoeffs][u64 nNodes][Node x nNodes][Config], malloc-owned
+int builderAssemble(hpsdf_build* b, const double* const* packs, void** block, size_t* size) {
+    if (!b->laidOut) return fail(HPSDF_ERR_STATE, "call hpsdf_build_layout first");
+    const size_t bytes = 8 + 8 * (size_t)b->nCoeffsTotal + 8 + sizeof(hpsdf_node) * b->nodes.size() + sizeof(hpsdf_config);
+    uint8_t* p = (uint8_t*)std::malloc(bytes);
+    if (!p) return fail(HPSDF_ERR_OUT_OF_MEMORY, "malloc of the memory block failed");
+    const uint64_t nc = b->nCoeffsTotal, nn = b->nodes.size();
+    std::memcpy(p, &nc, 8);
+    double* store = (double*)(p + 8);
+    std::memset(store, 0, 8 * (size_t)nc);
+    std::vector<uint64_t> cur(b->world, 0);
+    for (const auto& l : b->layout) {
+        if (!packs || !packs[l.owner]) {
+            std::free(p);
+            return fail(HPSDF_ERR_INVALID_ARGUMENT, "missing pack buffer of a rank");
+        }
+        std::memcpy(store + l.dst, packs[l.owner] + cur[l.owner], l.count * sizeof(double));
+        cur[l.owner] += l.count;
+    }
+    uint8_t* q = p + 8 + 8 * (size_t)nc;
+    std::memcpy(q, &nn, 8);
+    std::memcpy(q + 8, b->nodes.data(), sizeof(hpsdf_node) * b->nodes.size());
+    std::memcpy(q + 8 + sizeof(hpsdf_node) * b->nodes.size(), &b->cfg, sizeof(hpsdf_config));
+    *block = p;
+    *size = bytes;
+    return HPSDF_OK;
+}
+
+}  // namespace hpsdf

@@ -1,0 +1,108 @@
+// Host side of Octree::Create: tree bookkeeping and the canonical round schedule.
+//
+// The reference drives its fits from a polling thread pool whose result depends
+// on timing (Octree.cpp:194-309, 558-659; two identical runs give different
+// trees).  Here the same bookkeeping runs in deterministic rounds:
+//
+//   round:  stop if total < target or heap empty                     (:216)
+//           round 0 pops every (coarse) entry, later rounds the top K by
+//           (error desc, node index asc); jobs are evaluated as pure
+//           functions (on the GPU, sharded by cost over the ranks);
+//           results are applied in node-index order with the arithmetic
+//           of :253-290.
+//
+// Coefficients never come back to the host during the build: a node owns a
+// chain of segments (rows [rowStart,rowEnd) living in the arena of the rank
+// that computed them).  A P-refinement appends a segment, so nothing is copied
+// when the degree rises; ReallocCoeffs (:474-555) becomes one gather at the end.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "runtime.hpp"
+
+struct hpsdf_build {
+    // ---- configuration
+    hpsdf_config cfg{};
+    uint64_t K = HPSDF_DEFAULT_JOBS_PER_ROUND;
+    int rank = 0, world = 1;
+
+    // ---- tree state (identical on every rank)
+    struct Seg {
+        uint64_t off;  // offset in the owner's store (valid on the owner only)
+        uint32_t rowStart, rowEnd;
+        int32_t owner;
+        int32_t hostStore;  // 1: off indexes hostStore (injected), 0: device arena
+        int64_t next;       // next segment of the same node, -1 = end
+    };
+    std::vector<hpsdf_node> nodes;
+    std::vector<int64_t> segHead, segTail;  // per node, -1 = none
+    std::vector<Seg> segs;
+    struct HeapEnt {
+        uint64_t idx;
+        double err;
+    };
+    std::vector<HeapEnt> heap;
+    double total = 0.0;
+    hpsdf_build_stats stats{};
+    bool finished = false, laidOut = false;
+
+    // ---- current round
+    std::vector<HeapEnt> batch;  // sorted by node index
+    struct Slice {
+        uint64_t first, count;
+    };
+    std::vector<Slice> slices;  // per rank
+    struct JobOut {             // where this rank put job results (my slice only)
+        uint64_t pOff = ~0ull, hOff = ~0ull;
+        int32_t pHost = 0, hHost = 0;
+    };
+    std::vector<JobOut> jobOut;  // indexed by job - slices[rank].first
+    bool roundOpen = false, computed = false;
+
+    // ---- device state of this rank
+    int device = -1;
+    double* dArena = nullptr;
+    uint64_t arenaCap = 0, arenaUsed = 0;
+    hpsdf::FitTask* dTasks = nullptr;
+    hpsdf::FitBlock* dBlocks = nullptr;
+    uint64_t tasksCap = 0, blocksCap = 0;
+    double* dErrs = nullptr;
+    uint64_t errsCap = 0;
+    double* dSamples = nullptr;
+    uint64_t samplesCap = 0;
+    double* dPack = nullptr;
+    uint64_t packCap = 0;
+    hpsdf::PackItem* dPackItems = nullptr;
+    uint64_t packItemsCap = 0;
+    std::vector<double> hostStore;  // injected coefficients
+
+    // ---- layout (after the last round)
+    struct LeafSeg {
+        uint64_t src, dst;
+        uint32_t count;
+        int32_t owner, hostStore;
+    };
+    std::vector<LeafSeg> layout;  // DFS leaf order, segments in row order
+    std::vector<uint64_t> packCounts;
+    uint64_t nCoeffsTotal = 0;
+
+    ~hpsdf_build();
+};
+
+namespace hpsdf {
+
+uint64_t jobCost(int degree, int depth, bool coarse);
+
+int builderBegin(hpsdf_build* b, const hpsdf_config* cfg, const hpsdf_build_opts* opts);
+int builderSelect(hpsdf_build* b, uint64_t* nJobs);
+int builderJobs(const hpsdf_build* b, hpsdf_job* out);
+int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field);
+int builderInject(hpsdf_build* b, uint64_t job, const double* pCoeffs, const double* hCoeffs);
+int builderApply(hpsdf_build* b, const double* headers);
+int builderLayout(hpsdf_build* b);
+int builderPackDevice(hpsdf_build* b, hpsdf_ctx* ctx, double** dPack, uint64_t* n);
+int builderPackHost(hpsdf_build* b, hpsdf_ctx* ctx, double* out);
+int builderAssemble(hpsdf_build* b, const double* const* packs, void** block, size_t* size);
+
+}  // namespace hpsdf

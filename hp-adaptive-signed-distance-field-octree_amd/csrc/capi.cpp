@@ -1,0 +1,738 @@
+// C ABI of include/hpsdf.h: contexts, fields, tree upload + batched Query, the stepwise build.
+#include <hip/hip_runtime_api.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "builder.hpp"
+#include "launch.hpp"
+#include "runtime.hpp"
+
+using namespace hpsdf;
+
+namespace hpsdf {
+
+static thread_local std::string g_lastError;
+
+void setError(const std::string& msg) { g_lastError = msg; }
+int fail(int code, const std::string& msg) {
+    g_lastError = msg;
+    return code;
+}
+int hipFail(hipError_t e, const char* what) {
+    g_lastError = std::string(what) + ": " + hipGetErrorString(e);
+    return (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver) ? HPSDF_ERR_NO_DEVICE
+                                                                                                 : HPSDF_ERR_HIP;
+}
+
+const hpsdf_field* innermost(const hpsdf_field* f) {
+    while (f && f->kind == kHostTreeCsg) f = f->inner;
+    return f;
+}
+
+int makeFieldDev(const hpsdf_field* f, const double* dSamples, FieldDev* out) {
+    std::memset(out, 0, sizeof(*out));
+    out->csgOp = -1;
+    if (f->kind == kHostTreeCsg) {
+        if (!f->oldTree || !f->inner) return fail(HPSDF_ERR_INVALID_ARGUMENT, "csg field without tree or inner field");
+        if (f->inner->kind == kHostTreeCsg) return fail(HPSDF_ERR_UNSUPPORTED, "nested csg fields are not supported");
+        out->csgOp = f->csgOp;
+        out->oldTree = f->oldTree->dev;
+        f = f->inner;
+    }
+    switch (f->kind) {
+        case kHostAnalytic:
+            out->kind = kFieldAnalytic;
+            out->nPrims = (int32_t)f->prims.size();
+            for (size_t i = 0; i < f->prims.size(); ++i) out->prims[i] = f->prims[i];
+            break;
+        case kHostCallback:
+            out->kind = kFieldSamples;
+            out->samples = dSamples;
+            break;
+        case kHostMesh:
+            out->kind = kFieldMesh;
+            out->mesh.verts = f->dVerts;
+            out->mesh.tris = f->dTris;
+            out->mesh.halfEdges = f->dHalfEdges;
+            out->mesh.bvhBoxes = f->dBvhBoxes;
+            out->mesh.bvhChild = f->dBvhChild;
+            out->mesh.nTris = f->nTris;
+            out->mesh.nNodes = f->nBvhNodes;
+            break;
+        default:
+            return fail(HPSDF_ERR_INVALID_ARGUMENT, "unknown field kind");
+    }
+    return HPSDF_OK;
+}
+
+}  // namespace hpsdf
+
+#define HPSDF_TRY                                                            \
+    try {
+#define HPSDF_CATCH                                                          \
+    }                                                                        \
+    catch (const std::bad_alloc&) {                                          \
+        return fail(HPSDF_ERR_OUT_OF_MEMORY, "host allocation failed");      \
+    }                                                                        \
+    catch (const std::exception& ex) {                                       \
+        return fail(HPSDF_ERR_STATE, std::string("exception: ") + ex.what()); \
+    }
+
+extern "C" {
+
+const char* hpsdf_last_error(void) { return g_lastError.c_str(); }
+const char* hpsdf_version(void) { return "hpsdf-gfx950 0.1"; }
+
+int hpsdf_config_default(hpsdf_config* c) {
+    if (!c) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null config");
+    std::memset(c, 0, sizeof(*c));
+    c->target_error_threshold = std::pow(10, -10);
+    c->weighting_type = 0;
+    c->continuity_enforce = 1;
+    c->continuity_strength = 8.0;
+    const unsigned hc = std::thread::hardware_concurrency();
+    c->thread_count = hc ? hc : 1;
+    for (int a = 0; a < 3; ++a) {
+        c->root_min[a] = -0.5f;
+        c->root_max[a] = 0.5f;
+    }
+    return HPSDF_OK;
+}
+
+int hpsdf_tables_get(double* roots, double* weights, double* nl, double* rec, uint64_t* count, uint64_t* bidx,
+                     uint64_t* sumToN) {
+    HPSDF_TRY
+    const Tables& T = tables();
+    if (roots) std::memcpy(roots, T.roots, sizeof T.roots);
+    if (weights) std::memcpy(weights, T.weights, sizeof T.weights);
+    if (nl) std::memcpy(nl, T.normalisedLengths, sizeof T.normalisedLengths);
+    if (rec) std::memcpy(rec, T.recurrence, sizeof T.recurrence);
+    if (count) std::memcpy(count, T.coeffCount, sizeof T.coeffCount);
+    if (bidx) std::memcpy(bidx, T.basisIndex, sizeof T.basisIndex);
+    if (sumToN) std::memcpy(sumToN, T.sumToN, sizeof T.sumToN);
+    return HPSDF_OK;
+    HPSDF_CATCH
+}
+
+// ---------------------------------------------------------------------------- context
+int hpsdf_ctx_create(int device, void* stream, hpsdf_ctx** out) {
+    HPSDF_TRY
+    if (!out) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null out");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return fail(HPSDF_ERR_NO_DEVICE, std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "count = 0"));
+    if (device < 0 || device >= n) return fail(HPSDF_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    HPSDF_HIP(hipSetDevice(device));
+    hpsdf_ctx* c = new hpsdf_ctx();
+    c->device = device;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (se != hipSuccess) {
+            delete c;
+            return hipFail(se, "hipStreamCreate");
+        }
+        c->ownsStream = true;
+    }
+    // constant tables -> HBM
+    const Tables& T = tables();
+    DeviceTables* h = new DeviceTables();
+    std::memset(h, 0, sizeof(*h));
+    std::memcpy(h->roots, T.roots, sizeof T.roots);
+    std::memcpy(h->weights, T.weights, sizeof T.weights);
+    std::memcpy(h->nl, T.normalisedLengths, sizeof T.normalisedLengths);
+    std::memcpy(h->rec, T.recurrence, sizeof T.recurrence);
+    for (int i = 0; i < kMaxCoeffs; ++i) {
+        h->bidx[i][0] = (uint8_t)T.basisIndex[i][0];
+        h->bidx[i][1] = (uint8_t)T.basisIndex[i][1];
+        h->bidx[i][2] = (uint8_t)T.basisIndex[i][2];
+        h->bidx[i][3] = (uint8_t)(T.basisIndex[i][0] + T.basisIndex[i][1] + T.basisIndex[i][2]);
+    }
+    for (int i = 0; i <= kMaxDegree; ++i) h->count[i] = (uint32_t)T.coeffCount[i];
+    hipError_t me = hipMalloc((void**)&c->dTables, sizeof(DeviceTables));
+    if (me == hipSuccess) me = hipMemcpy(c->dTables, h, sizeof(DeviceTables), hipMemcpyHostToDevice);
+    delete h;
+    if (me != hipSuccess) {
+        hpsdf_ctx_destroy(c);
+        return hipFail(me, "table upload");
+    }
+    *out = c;
+    return HPSDF_OK;
+    HPSDF_CATCH
+}
+
+int hpsdf_ctx_destroy(hpsdf_ctx* c) {
+    if (!c) return HPSDF_OK;
+    (void)hipSetDevice(c->device);
+    if (c->dTables) (void)hipFree(c->dTables);
+    if (c->ownsStream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return HPSDF_OK;
+}
+
+int hpsdf_ctx_set_stream(hpsdf_ctx* c, void* stream) {
+    if (!c) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null ctx");
+    if (c->ownsStream && c->stream) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamDestroy(c->stream);
+        c->ownsStream = false;
+    }
+    c->stream = (hipStream_t)stream;
+    return HPSDF_OK;
+}
+
+int hpsdf_ctx_synchronize(hpsdf_ctx* c) {
+    if (!c) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null ctx");
+    HPSDF_HIP(hipSetDevice(c->device));
+    HPSDF_HIP(hipStreamSynchronize(c->stream));
+    return HPSDF_OK;
+}
+
+void* hpsdf_ctx_stream(hpsdf_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+// ---------------------------------------------------------------------------- fields
+int hpsdf_field_create_analytic(const hpsdf_prim* prims, int n, hpsdf_field** out) {
+    HPSDF_TRY
+    if (!prims || !out || n < 1 || n > HPSDF_MAX_PRIMS)
+        return fail(HPSDF_ERR_INVALID_ARGUMENT, "analytic field needs 1..HPSDF_MAX_PRIMS primitives");
+    for (int i = 0; i < n; ++i)
+        if (prims[i].kind < 0 || prims[i].kind > HPSDF_PRIM_PLANE || prims[i].op < 0 || prims[i].op > HPSDF_OP_SUBTRACT)
+            return fail(HPSDF_ERR_INVALID_ARGUMENT, "unknown primitive kind or op");
+    hpsdf_field* f = new hpsdf_field();
+    f->kind = kHostAnalytic;
+    f->prims.assign(prims, prims + n);
+    *out = f;
+    return HPSDF_OK;
+    HPSDF_CATCH
+}
+
+int hpsdf_field_create_callback(hpsdf_callback cb, void* user, hpsdf_field** out) {
+    HPSDF_TRY
+    if (!cb || !out) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null callback");
+    hpsdf_field* f = new hpsdf_field();
+    f->kind = kHostCallback;
+    f->cb = cb;
+    f->user = user;
+    *out = f;
+    return HPSDF_OK;
+    HPSDF_CATCH
+}
+
+int hpsdf_field_create_mesh(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const uint64_t* tris, uint64_t nTris,
+                            hpsdf_field** out) {
+    HPSDF_TRY
+    if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "mesh fields live in HBM: a device context is required");
+    if (!verts || !tris || !out || nVerts == 0 || nTris == 0) return fail(HPSDF_ERR_INVALID_ARGUMENT, "empty mesh");
+    if (nVerts > 0x7FFFFFFFull || nTris > 0x3FFFFFFFull) return fail(HPSDF_ERR_UNSUPPORTED, "mesh too large for 32-bit ids");
+    HostMesh hm;
+    if (!prepareMesh(verts, nVerts, tris, nTris, &hm))
+        return fail(HPSDF_ERR_OPEN_MESH, "mesh is not closed: an edge has no twin (Mesh::CreateHalfEdges)");
+    HPSDF_HIP(hipSetDevice(ctx->device));
+    hpsdf_field* f = new hpsdf_field();
+    f->kind = kHostMesh;
+    f->device = ctx->device;
+    f->nVerts = (uint32_t)nVerts;
+    f->nTris = (uint32_t)nTris;
+    f->nBvhNodes = (uint32_t)(hm.bvhChild.size() / 2);
+    auto up = [&](void** d, const void* h, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(d, bytes);
+        if (e != hipSuccess) return e;
+        return hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
+    };
+    hipError_t e = up((void**)&f->dVerts, hm.verts.data(), hm.verts.size() * sizeof(float));
+    if (e == hipSuccess) e = up((void**)&f->dTris, hm.tris.data(), hm.tris.size() * sizeof(uint32_t));
+    if (e == hipSuccess) e = up((void**)&f->dHalfEdges, hm.halfEdges.data(), hm.halfEdges.size() * sizeof(uint32_t));
+    if (e == hipSuccess) e = up((void**)&f->dBvhBoxes, hm.bvhBoxes.data(), hm.bvhBoxes.size() * sizeof(float));
+    if (e == hipSuccess) e = up((void**)&f->dBvhChild, hm.bvhChild.data(), hm.bvhChild.size() * sizeof(int32_t));
+    if (e != hipSuccess) {
+        hpsdf_field_destroy(f);
+        return hipFail(e, "mesh upload");
+    }
+    *out = f;
+    return HPSDF_OK;
+    HPSDF_CATCH
+}
+
+int hpsdf_field_create_tree_csg(const hpsdf_tree* old, int op, const hpsdf_field* inner, hpsdf_field** out) {
+    HPSDF_TRY
+    if (!old || !inner || !out || op < 0 || op > HPSDF_OP_SUBTRACT)
+        return fail(HPSDF_ERR_INVALID_ARGUMENT, "bad csg field arguments");
+    if (inner->kind == kHostTreeCsg) return fail(HPSDF_ERR_UNSUPPORTED, "nested csg fields are not supported");
+    hpsdf_field* f = new hpsdf_field();
+    f->kind = kHostTreeCsg;
+    f->oldTree = old;
+    f->csgOp = op;
+    f->inner = inner;
+    *out = f;
+    return HPSDF_OK;
+    HPSDF_CATCH
+}
+
+int hpsdf_field_destroy(hpsdf_field* f) {
+    if (!f) return HPSDF_OK;
+    if (f->kind == kHostMesh && f->device >= 0) {
+        (void)hipSetDevice(f->device);
+        if (f->dVerts) (void)hipFree(f->dVerts);
+        if (f->dTris) (void)hipFree(f->dTris);
+        if (f->dHalfEdges) (void)hipFree(f->dHalfEdges);
+        if (f->dBvhBoxes) (void)hipFree(f->dBvhBoxes);
+        if (f->dBvhChild) (void)hipFree(f->dBvhChild);
+    }
+    delete f;
+    return HPSDF_OK;
+}
+
+int hpsdf_field_eval_device(hpsdf_ctx* ctx, const hpsdf_field* f, const double* dXyz, size_t n, double* dOut) {
+    HPSDF_TRY
+    if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "a device context is required");
+    if (!f || (!dXyz && n) || (!dOut && n)) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    if (innermost(f)->kind == kHostCallback) return fail(HPSDF_ERR_UNSUPPORTED, "callback fields are evaluated on the host");
+    HPSDF_HIP(hipSetDevice(ctx->device));
+    FieldDev fd;
+    int rc = makeFieldDev(f, nullptr, &fd);
+    if (rc) return rc;
+    HPSDF_HIP(launchFieldEval(ctx->stream, fd, ctx->dTables, dXyz, n, dOut));
+    return HPSDF_OK;
+    HPSDF_CATCH
+}
+
+static int hostRoundTrip(hpsdf_ctx* ctx, const double* xyz, size_t n, double* out,
+                         int (*run)(hpsdf_ctx*, const void*, const double*, size_t, double*), const void* obj) {
+    if (n == 0) return HPSDF_OK;
+    HPSDF_HIP(hipSetDevice(ctx->device));
+    double *dIn = nullptr, *dOut = nullptr;
+    HPSDF_HIP(hipMalloc((void**)&dIn, n * 3 * sizeof(double)));
+    hipError_t e = hipMalloc((void**)&dOut, n * sizeof(double));
+    if (e != hipSuccess) {
+        (void)hipFree(dIn);
+        return hipFail(e, "hipMalloc");
+    }
+    int rc = HPSDF_OK;
+    e = hipMemcpyAsync(dIn, xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        rc = run(ctx, obj, dIn, n, dOut);
+        if (rc == HPSDF_OK) e = hipMemcpyAsync(out, dOut, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dIn);
+    (void)hipFree(dOut);
+    if (rc) return rc;
+    if (e != hipSuccess) return hipFail(e, "host round trip");
+    return HPSDF_OK;
+}
+
+int hpsdf_field_eval_host(hpsdf_ctx* ctx, const hpsdf_field* f, const double* xyz, size_t n, double* out) {
+    HPSDF_TRY
+    if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "a device context is required");
+    if (!f || (!xyz && n) || (!out && n)) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    return hostRoundTrip(
+        ctx, xyz, n, out,
+        [](hpsdf_ctx* c, const void* o, const double* d, size_t m, double* r) {
+            return hpsdf_field_eval_device(c, (const hpsdf_field*)o, d, m, r);
+        },
+        f);
+    HPSDF_CATCH
+}
+
+// ---------------------------------------------------------------------------- tree + query
+int hpsdf_tree_upload(hpsdf_ctx* ctx, const void* block, size_t size, hpsdf_tree** out) {
+    HPSDF_TRY
+    if (!out) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null out");
+    *out = nullptr;
+    if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "trees are queried on the GPU: a device context is required");
+    if (!block || size < 16 + sizeof(hpsdf_config)) return fail(HPSDF_ERR_BAD_BLOCK, "block too small");
+    const uint8_t* p = (const uint8_t*)block;
+    uint64_t nCoeffs, nNodes;
+    std::memcpy(&nCoeffs, p, 8);
+    if (nCoeffs > (size - 16 - sizeof(hpsdf_config)) / 8) return fail(HPSDF_ERR_BAD_BLOCK, "coefficient count exceeds block");
+    const double* coeffs = (const double*)(p + 8);
+    std::memcpy(&nNodes, p + 8 + 8 * nCoeffs, 8);
+    const size_t need = 8 + 8 * (size_t)nCoeffs + 8 + sizeof(hpsdf_node) * (size_t)nNodes + sizeof(hpsdf_config);
+    if (nNodes == 0 || nNodes > (size_t)0xFFFFFFF0u || need != size) return fail(HPSDF_ERR_BAD_BLOCK, "node count does not match block size");
+    if (nCoeffs > 0xFFFFFFFFull) return fail(HPSDF_ERR_UNSUPPORTED, "more than 2^32 coefficients");
+    std::vector<hpsdf_node> nodes(nNodes);
+    std::memcpy(nodes.data(), p + 16 + 8 * nCoeffs, sizeof(hpsdf_node) * nNodes);
+    hpsdf_config cfg;
+    std::memcpy(&cfg, p + 16 + 8 * nCoeffs + sizeof(hpsdf_node) * nNodes, sizeof cfg);
+
+    // device mirror: validate that the tree is the dyadic octree the descent recomputes
+    const Tables& T = tables();
+    std::vector<NodeRec> recs(nNodes, NodeRec{0, 0});
+    if (nodes[0].degree != kInteriorDegree || nodes[0].child_idx == ~0ull)
+        return fail(HPSDF_ERR_UNSUPPORTED, "root must be an interior node (Octree::CreateRoot always splits it)");
+    for (int a = 0; a < 3; ++a)
+        if (nodes[0].aabb_min[a] != -0.5f || nodes[0].aabb_max[a] != 0.5f)
+            return fail(HPSDF_ERR_UNSUPPORTED, "internal root box must be [-0.5,0.5]^3 (Octree.cpp:798)");
+    std::vector<uint64_t> stack{0};
+    uint64_t leaves = 0;
+    int maxDeg = 0, maxDepth = 0;
+    std::vector<uint8_t> depthOf(nNodes, 0);
+    while (!stack.empty()) {
+        const uint64_t i = stack.back();
+        stack.pop_back();
+        const hpsdf_node& n = nodes[i];
+        if (n.degree == kInteriorDegree) {
+            if (n.child_idx > nNodes - 8) return fail(HPSDF_ERR_BAD_BLOCK, "child index out of range");
+            if (depthOf[i] >= kMaxDepth + 1) return fail(HPSDF_ERR_BAD_BLOCK, "tree deeper than TREE_MAX_DEPTH + 1");
+            recs[i] = NodeRec{(uint32_t)n.child_idx, kInteriorTag};
+            for (unsigned c = 0; c < 8; ++c) {
+                const hpsdf_node& ch = nodes[n.child_idx + c];
+                for (int d = 0; d < 3; ++d) {
+                    const float mid = (n.aabb_max[d] + n.aabb_min[d]) * 0.5f;
+                    const float emin = (c >> d) & 1u ? mid : n.aabb_min[d], emax = (c >> d) & 1u ? n.aabb_max[d] : mid;
+                    if (ch.aabb_min[d] != emin || ch.aabb_max[d] != emax)
+                        return fail(HPSDF_ERR_UNSUPPORTED, "child boxes are not midpoint octants of their parent");
+                }
+                depthOf[n.child_idx + c] = (uint8_t)(depthOf[i] + 1);
+                stack.push_back(n.child_idx + c);
+            }
+        } else {
+            if (n.degree > kMaxDegree) return fail(HPSDF_ERR_BAD_BLOCK, "leaf degree out of range");
+            if (n.coeffs_start + T.coeffCount[n.degree] > nCoeffs) return fail(HPSDF_ERR_BAD_BLOCK, "leaf coefficients out of range");
+            if (n.depth != depthOf[i]) return fail(HPSDF_ERR_BAD_BLOCK, "stored depth does not match tree depth");
+            recs[i] = NodeRec{(uint32_t)n.coeffs_start, (uint32_t)n.degree};
+            ++leaves;
+            maxDeg = std::max(maxDeg, (int)n.degree);
+            maxDepth = std::max(maxDepth, (int)depthOf[i]);
+        }
+    }
+    HPSDF_HIP(hipSetDevice(ctx->device));
+    hpsdf_tree* t = new hpsdf_tree();
+    t->device = ctx->device;
+    t->nNodes = nNodes;
+    t->nCoeffs = nCoeffs;
+    t->nLeaves = leaves;
+    t->maxDegree = maxDeg;
+    t->maxDepth = maxDepth;
+    t->config = cfg;
+    hipError_t e = hipMalloc((void**)&t->dNodes, nNodes * sizeof(NodeRec));
+    if (e == hipSuccess) e = hipMalloc((void**)&t->dCoeffs, std::max<uint64_t>(1, nCoeffs) * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(t->dNodes, recs.data(), nNodes * sizeof(NodeRec), hipMemcpyHostToDevice);
+    if (e == hipSuccess && nCoeffs) e = hipMemcpy(t->dCoeffs, coeffs, nCoeffs * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        hpsdf_tree_destroy(t);
+        return hipFail(e, "tree upload");
+    }
+    t->dev.nodes = t->dNodes;
+    t->dev.coeffs = t->dCoeffs;
+    for (int a = 0; a < 3; ++a) {
+        t->dev.rootCentre[a] = (double)((cfg.root_min[a] + cfg.root_max[a]) / 2.0f);  // Octree.cpp:419
+        t->dev.rootInvSizes[a] = (double)(1.0f / (cfg.root_max[a] - cfg.root_min[a]));  // Octree.cpp:420
+    }
+    *out = t;
+    return HPSDF_OK;
+    HPSDF_CATCH
+}
+
+int hpsdf_tree_destroy(hpsdf_tree* t) {
+    if (!t) return HPSDF_OK;
+    (void)hipSetDevice(t->device);
+    if (t->dNodes) (void)hipFree(t->dNodes);
+    if (t->dCoeffs) (void)hipFree(t->dCoeffs);
+    delete t;
+    return HPSDF_OK;
+}
+
+int hpsdf_tree_info(const hpsdf_tree* t, uint64_t* nNodes, uint64_t* nCoeffs, uint64_t* nLeaves, int* maxDegree,
+                    int* maxDepth) {
+    if (!t) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null tree");
+    if (nNodes) *nNodes = t->nNodes;
+    if (nCoeffs) *nCoeffs = t->nCoeffs;
+    if (nLeaves) *nLeaves = t->nLeaves;
+    if (maxDegree) *maxDegree = t->maxDegree;
+    if (maxDepth) *maxDepth = t->maxDepth;
+    return HPSDF_OK;
+}
+
+int hpsdf_query_device(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* dXyz, size_t n, double* dOut) {
+    HPSDF_TRY
+    if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "a device context is required");
+    if (!t || (!dXyz && n) || (!dOut && n)) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    if (t->device != ctx->device) return fail(HPSDF_ERR_INVALID_ARGUMENT, "tree lives on another device");
+    HPSDF_HIP(hipSetDevice(ctx->device));
+    HPSDF_HIP(launchQuery(ctx->stream, t->dev, ctx->dTables, dXyz, n, dOut));
+    return HPSDF_OK;
+    HPSDF_CATCH
+}
+
+int hpsdf_query_host(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* xyz, size_t n, double* out) {
+    HPSDF_TRY
+    if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "a device context is required");
+    if (!t || (!xyz && n) || (!out && n)) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    return hostRoundTrip(
+        ctx, xyz, n, out,
+        [](hpsdf_ctx* c, const void* o, const double* d, size_t m, double* r) {
+            return hpsdf_query_device(c, (const hpsdf_tree*)o, d, m, r);
+        },
+        t);
+    HPSDF_CATCH
+}
+
+// ---------------------------------------------------------------------------- build
+int hpsdf_build_begin(const hpsdf_config* cfg, const hpsdf_build_opts* opts, hpsdf_build** out) {
+    HPSDF_TRY
+    if (!cfg || !out) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    hpsdf_build* b = new hpsdf_build();
+    int rc = builderBegin(b, cfg, opts);
+    if (rc) {
+        delete b;
+        return rc;
+    }
+    *out = b;
+    return HPSDF_OK;
+    HPSDF_CATCH
+}
+
+int hpsdf_build_destroy(hpsdf_build* b) {
+    delete b;
+    return HPSDF_OK;
+}
+
+int hpsdf_build_round_select(hpsdf_build* b, uint64_t* nJobs) {
+    HPSDF_TRY
+    if (!b || !nJobs) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    return builderSelect(b, nJobs);
+    HPSDF_CATCH
+}
+
+int hpsdf_build_round_jobs(const hpsdf_build* b, hpsdf_job* out) {
+    HPSDF_TRY
+    if (!b || !out) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    return builderJobs(b, out);
+    HPSDF_CATCH
+}
+
+int hpsdf_build_round_slice(const hpsdf_build* b, int rank, uint64_t* first, uint64_t* count) {
+    if (!b || rank < 0 || rank >= b->world) return fail(HPSDF_ERR_INVALID_ARGUMENT, "bad rank");
+    if (!b->roundOpen) return fail(HPSDF_ERR_STATE, "no open round");
+    if (first) *first = b->slices[rank].first;
+    if (count) *count = b->slices[rank].count;
+    return HPSDF_OK;
+}
+
+int hpsdf_build_round_max_slice(const hpsdf_build* b, uint64_t* n) {
+    if (!b || !n) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    if (!b->roundOpen) return fail(HPSDF_ERR_STATE, "no open round");
+    uint64_t m = 0;
+    for (const auto& s : b->slices) m = std::max(m, s.count);
+    *n = m;
+    return HPSDF_OK;
+}
+
+int hpsdf_build_round_compute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
+    HPSDF_TRY
+    if (!b) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null build");
+    return builderCompute(b, ctx, field);
+    HPSDF_CATCH
+}
+
+int hpsdf_build_round_results_device(hpsdf_build* b, double** dHeaders, uint64_t* n) {
+    if (!b) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null build");
+    if (!b->roundOpen || !b->computed) return fail(HPSDF_ERR_STATE, "round not computed");
+    if (dHeaders) *dHeaders = b->dErrs;
+    if (n) *n = b->slices[b->rank].count * HPSDF_JOB_HEADER_DOUBLES;
+    return HPSDF_OK;
+}
+
+int hpsdf_build_round_results_host(hpsdf_build* b, hpsdf_ctx* ctx, double* out) {
+    HPSDF_TRY
+    if (!b || !ctx || !out) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    if (!b->roundOpen || !b->computed) return fail(HPSDF_ERR_STATE, "round not computed");
+    const uint64_t n = b->slices[b->rank].count * HPSDF_JOB_HEADER_DOUBLES;
+    HPSDF_HIP(hipSetDevice(ctx->device));
+    if (n) HPSDF_HIP(hipMemcpyAsync(out, b->dErrs, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HPSDF_HIP(hipStreamSynchronize(ctx->stream));
+    return HPSDF_OK;
+    HPSDF_CATCH
+}
+
+int hpsdf_build_round_apply(hpsdf_build* b, const double* headers) {
+    HPSDF_TRY
+    if (!b || !headers) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    return builderApply(b, headers);
+    HPSDF_CATCH
+}
+
+int hpsdf_build_round_inject(hpsdf_build* b, uint64_t job, const double* pCoeffs, const double* hCoeffs) {
+    HPSDF_TRY
+    if (!b) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null build");
+    return builderInject(b, job, pCoeffs, hCoeffs);
+    HPSDF_CATCH
+}
+
+int hpsdf_build_layout(hpsdf_build* b, uint64_t* nCoeffsTotal, uint64_t* counts) {
+    HPSDF_TRY
+    if (!b) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null build");
+    int rc = builderLayout(b);
+    if (rc) return rc;
+    if (nCoeffsTotal) *nCoeffsTotal = b->nCoeffsTotal;
+    if (counts)
+        for (int r = 0; r < b->world; ++r) counts[r] = b->packCounts[r];
+    return HPSDF_OK;
+    HPSDF_CATCH
+}
+
+int hpsdf_build_pack_device(hpsdf_build* b, hpsdf_ctx* ctx, double** dPack, uint64_t* n) {
+    HPSDF_TRY
+    if (!b) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null build");
+    return builderPackDevice(b, ctx, dPack, n);
+    HPSDF_CATCH
+}
+
+int hpsdf_build_pack_host(hpsdf_build* b, hpsdf_ctx* ctx, double* out) {
+    HPSDF_TRY
+    if (!b || !out) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    return builderPackHost(b, ctx, out);
+    HPSDF_CATCH
+}
+
+int hpsdf_build_assemble(hpsdf_build* b, const double* const* packs, void** block, size_t* size) {
+    HPSDF_TRY
+    if (!b || !block || !size) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    return builderAssemble(b, packs, block, size);
+    HPSDF_CATCH
+}
+
+int hpsdf_build_get_stats(const hpsdf_build* b, hpsdf_build_stats* out) {
+    if (!b || !out) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    *out = b->stats;
+    out->total_error = b->total;
+    out->n_nodes = b->nodes.size();
+    return HPSDF_OK;
+}
+
+int hpsdf_create(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* field, uint64_t K, void** block,
+                 size_t* size, hpsdf_build_stats* stats) {
+    HPSDF_TRY
+    if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "Create runs on the GPU: a device context is required");
+    if (!cfg || !field || !block || !size) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    hpsdf_build_opts o;
+    std::memset(&o, 0, sizeof o);
+    o.max_jobs_per_round = K;
+    o.rank = 0;
+    o.world = 1;
+    hpsdf_build* b = nullptr;
+    int rc = hpsdf_build_begin(cfg, &o, &b);
+    if (rc) return rc;
+    std::vector<double> headers;
+    for (;;) {
+        uint64_t n = 0;
+        if ((rc = builderSelect(b, &n))) break;
+        if (n == 0) break;
+        headers.resize(n * HPSDF_JOB_HEADER_DOUBLES);
+        if ((rc = builderCompute(b, ctx, field))) break;
+        if ((rc = hpsdf_build_round_results_host(b, ctx, headers.data()))) break;
+        if ((rc = builderApply(b, headers.data()))) break;
+    }
+    if (!rc) rc = builderLayout(b);
+    if (!rc) {
+        std::vector<double> pack(std::max<uint64_t>(1, b->packCounts[0]));
+        rc = builderPackHost(b, ctx, pack.data());
+        const double* packs[1] = {pack.data()};
+        if (!rc) rc = builderAssemble(b, packs, block, size);
+    }
+    if (!rc && stats) hpsdf_build_get_stats(b, stats);
+    delete b;
+    return rc;
+    HPSDF_CATCH
+}
+
+// ---------------------------------------------------------------------------- micro-benchmark
+int hpsdf_bench_fit(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* field, int degree, int depth,
+                    uint64_t nCells, int repeats, double* msPerLaunch) {
+    HPSDF_TRY
+    if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "a device context is required");
+    if (!cfg || !field || !msPerLaunch || degree < 0 || degree > kMaxDegree || depth < 0 || depth > kMaxDepth || nCells == 0 ||
+        repeats < 1)
+        return fail(HPSDF_ERR_INVALID_ARGUMENT, "bad bench arguments");
+    if (innermost(field)->kind == kHostCallback) return fail(HPSDF_ERR_UNSUPPORTED, "bench_fit needs a device field");
+    HPSDF_HIP(hipSetDevice(ctx->device));
+    const Tables& T = tables();
+    const uint64_t nc = T.coeffCount[degree];
+    const int nrows = (int)nc;
+    int gmax = nrows > kFitBlockThreads ? 1 : kFitBlockThreads / nrows;
+    while (gmax > 1 && fitLdsBytes(degree, gmax) > kFitMaxLdsBytes) --gmax;
+    const int g = (int)std::min<uint64_t>((uint64_t)gmax, std::max<uint64_t>(1, (nCells + 511) / 512));
+    std::vector<FitTask> tasks(nCells);
+    const uint64_t side = 1ull << depth;
+    const float h = 1.0f / (float)side;
+    for (uint64_t i = 0; i < nCells; ++i) {
+        const uint64_t c = i % (side * side * side);
+        const uint64_t ix = c % side, iy = (c / side) % side, iz = c / (side * side);
+        FitTask& t = tasks[i];
+        std::memset(&t, 0, sizeof t);
+        t.bmin[0] = -0.5f + (float)ix * h, t.bmin[1] = -0.5f + (float)iy * h, t.bmin[2] = -0.5f + (float)iz * h;
+        for (int a = 0; a < 3; ++a) t.bmax[a] = t.bmin[a] + h;
+        t.outOff = i * nc;
+        t.copyOff = ~0ull;
+        t.errSlot = (uint32_t)i;
+        t.depth = (uint8_t)depth;
+    }
+    std::vector<FitBlock> blocks;
+    for (uint64_t i = 0; i < nCells; i += g) {
+        FitBlock fb;
+        std::memset(&fb, 0, sizeof fb);
+        fb.firstTask = (uint32_t)i;
+        fb.nTasks = (uint16_t)std::min<uint64_t>(g, nCells - i);
+        fb.degree = (uint8_t)degree;
+        fb.rowStart = 0;
+        fb.rowEnd = (uint16_t)nc;
+        blocks.push_back(fb);
+    }
+    FitTask* dT = nullptr;
+    FitBlock* dB = nullptr;
+    double *dA = nullptr, *dE = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = HPSDF_OK;
+    hipError_t e = hipMalloc((void**)&dT, tasks.size() * sizeof(FitTask));
+    if (e == hipSuccess) e = hipMalloc((void**)&dB, blocks.size() * sizeof(FitBlock));
+    if (e == hipSuccess) e = hipMalloc((void**)&dA, nCells * nc * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dE, nCells * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(dT, tasks.data(), tasks.size() * sizeof(FitTask), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dB, blocks.data(), blocks.size() * sizeof(FitBlock), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    FieldDev fd;
+    RootMap rm;
+    if (e == hipSuccess) rc = makeFieldDev(field, nullptr, &fd);
+    for (int a = 0; a < 3; ++a) {
+        rm.bounds[a] = (double)(cfg->root_max[a] - cfg->root_min[a]);
+        rm.centre[a] = (double)((cfg->root_min[a] + cfg->root_max[a]) / 2.0f);
+    }
+    const size_t lds = fitLdsBytes(degree, g);
+    if (e == hipSuccess && rc == HPSDF_OK) {
+        e = launchFit(ctx->stream, dB, (uint32_t)blocks.size(), lds, dT, dA, dE, ctx->dTables, fd, rm);  // warm-up
+        if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
+        for (int r = 0; r < repeats && e == hipSuccess; ++r)
+            e = launchFit(ctx->stream, dB, (uint32_t)blocks.size(), lds, dT, dA, dE, ctx->dTables, fd, rm);
+        if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        *msPerLaunch = (double)ms / repeats;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(dT);
+    (void)hipFree(dB);
+    (void)hipFree(dA);
+    (void)hipFree(dE);
+    if (rc) return rc;
+    if (e != hipSuccess) return hipFail(e, "bench_fit");
+    return HPSDF_OK;
+    HPSDF_CATCH
+}
+
+}  // extern "C"

@@ -1,0 +1,92 @@
+// Structures shared between the host runtime and the gfx950 kernels.
+#pragma once
+#include <cstdint>
+
+#include "../../include/hpsdf.h"
+
+namespace hpsdf {
+
+// Constant tables as the kernels read them (one copy in HBM per context; the
+// kernels stage what they need into LDS).
+struct DeviceTables {
+    double roots[2080];
+    double weights[2080];
+    double nl[13][11];   // NormalisedLengths[degree][depth]
+    double rec[13][2];   // Legendre recurrence constants
+    uint8_t bidx[456][4];  // basis index (i, j, k) and i+j+k per coefficient row
+    uint32_t count[16];    // coefficient count per degree (count[6] == 83)
+};
+
+// 8-byte node record of the query-side tree mirror.  The 56-byte serialised
+// node (Include/HP/Node.h:10-33) is not needed on the device: cell boxes are
+// exact dyadics recomputed during the descent, the depth is the descent count.
+//   interior: a = index of first child, b = 0xFFFFFFFF
+//   leaf:     a = offset of its coefficients (doubles), b = degree
+struct NodeRec {
+    uint32_t a, b;
+};
+constexpr uint32_t kInteriorTag = 0xFFFFFFFFu;
+
+struct TreeDev {
+    const NodeRec* nodes;
+    const double* coeffs;
+    double rootCentre[3];    // Octree.cpp:322 (f32 centre widened)
+    double rootInvSizes[3];  // Octree.cpp:323 (f32 reciprocal widened)
+};
+
+enum FieldKind : int32_t { kFieldAnalytic = 0, kFieldSamples = 1, kFieldMesh = 2 };
+
+struct MeshDev {
+    const float* verts;        // xyz per vertex
+    const uint32_t* tris;      // 3 vertex ids per triangle
+    const uint32_t* halfEdges; // twin half-edge per half-edge (Mesh.h:74)
+    const float* bvhBoxes;     // 6 floats per BVH node (min xyz, max xyz)
+    const int32_t* bvhChild;   // 2 ints per node: >= 0 child node, < 0 => ~triangle index (leaf)
+    uint32_t nTris, nNodes;
+};
+
+// What the fit kernel evaluates at a sample point (world coordinates).
+struct FieldDev {
+    int32_t kind;      // FieldKind of the innermost field
+    int32_t nPrims;
+    int32_t csgOp;     // -1: none; else HPSDF_OP_* combining oldTree.Query with the inner field
+    int32_t pad;
+    hpsdf_prim prims[HPSDF_MAX_PRIMS];
+    const double* samples;  // kFieldSamples: F values, indexed by FitTask::sampleOff + sample number
+    MeshDev mesh;
+    TreeDev oldTree;
+};
+
+// unit cube -> world: pt * rootBounds + rootCentre (Octree.cpp:324-328)
+struct RootMap {
+    double bounds[3];
+    double centre[3];
+};
+
+// One cell fit (one call of Octree::FitPolynomial).
+struct FitTask {
+    float bmin[3], bmax[3];  // cell box in unit-cube coordinates (exact dyadics)
+    uint64_t outOff;         // arena offset (doubles) where row FitBlock::rowStart of this fit goes
+    uint64_t copyOff;        // reserved
+    uint64_t sampleOff;      // kFieldSamples: offset of this fit's first sample value
+    uint32_t errSlot;        // where the returned error goes
+    uint8_t depth;
+    uint8_t pad[3];
+};
+
+// One workgroup of the fit kernel: nTasks fits of identical shape.
+struct FitBlock {
+    uint32_t firstTask;
+    uint16_t nTasks;
+    uint8_t degree;  // target degree -> (4*degree+1)^3 samples
+    uint8_t pad0;
+    uint16_t rowStart, rowEnd;  // coefficient rows computed: [rowStart,rowEnd)
+    uint32_t pad1;
+};
+
+struct PackItem {  // gather of one leaf's coefficients into the packed store
+    uint64_t src, dst;
+    uint32_t count, pad;
+};
+
+}  // namespace hpsdf

@@ -1,0 +1,648 @@
+// gfx950 kernels of the hp-adaptive SDF octree hot path.
+//
+// Built with -ffp-contract=off: the reference CPU path runs on baseline x86-64
+// (no FMA), so every multiply-add below is a separate v_mul_f64 / v_add_f64 and
+// every sum runs in the reference's order.  That makes the GPU results
+// bit-identical to the CPU restatement (oracle/), which is what keeps the
+// octree topology identical (near-ties in the refinement decisions and in the
+// heap order would otherwise flip on 1-ulp differences).
+//
+// Kernels:
+//   fit_kernel     Octree::FitPolynomial (Octree.cpp:1007-1093): sampling of F on
+//                  the Gauss-Legendre grid fused with the L2 projection and the
+//                  error of Octree.cpp:1062-1069.
+//   query_kernel   Octree::Query + Octree::FApprox (Octree.cpp:662-702, 859-901).
+//   field_kernel   F at arbitrary points (test/diagnostic).
+//   pack_kernel    Octree::ReallocCoeffs gather (Octree.cpp:510-552).
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+
+#include "device_types.hpp"
+#include "launch.hpp"
+
+namespace hpsdf {
+
+// ---------------------------------------------------------------------------
+// field evaluation
+// ---------------------------------------------------------------------------
+
+// Eigen's Vector3d::norm(): sqrt(x^2 + (y^2 + z^2))
+__device__ __forceinline__ double norm3(double x, double y, double z) { return sqrt(x * x + (y * y + z * z)); }
+
+__device__ __forceinline__ double primEval(const hpsdf_prim& pr, double x, double y, double z) {
+    const double* p = pr.p;
+    switch (pr.kind) {
+        case HPSDF_PRIM_SPHERE:
+            return norm3(x - p[0], y - p[1], z - p[2]) - p[3];
+        case HPSDF_PRIM_BOX: {
+            const double qx = fabs(x - p[0]) - p[3];
+            const double qy = fabs(y - p[1]) - p[4];
+            const double qz = fabs(z - p[2]) - p[5];
+            const double outside = norm3(fmax(qx, 0.0), fmax(qy, 0.0), fmax(qz, 0.0));
+            const double inside = fmin(fmax(qx, fmax(qy, qz)), 0.0);
+            return outside + inside;
+        }
+        case HPSDF_PRIM_TORUS_Y: {
+            const double dx = x - p[0], dy = y - p[1], dz = z - p[2];
+            const double l = sqrt(dx * dx + dz * dz) - p[3];
+            return sqrt(l * l + dy * dy) - p[4];
+        }
+        case HPSDF_PRIM_PLANE:
+            return (p[0] * x + (p[1] * y + p[2] * z)) + p[3];
+        default:
+            return 0.0;
+    }
+}
+
+__device__ __forceinline__ double analyticEval(const FieldDev& f, double x, double y, double z) {
+    double acc = primEval(f.prims[0], x, y, z);
+    for (int i = 1; i < f.nPrims; ++i) {
+        const double d = primEval(f.prims[i], x, y, z);
+        switch (f.prims[i].op) {
+            case HPSDF_OP_UNION: acc = fmin(acc, d); break;
+            case HPSDF_OP_INTERSECT: acc = fmax(acc, d); break;
+            default: acc = fmax(acc, -d); break;
+        }
+    }
+    return acc;
+}
+
+// ---- mesh signed distance (all f32) ----------------------------------------
+// Source/Meshing/Utility.cpp:5-97, Source/Meshing/Mesh.cpp:54-63,162-242.
+struct V3 {
+    float x, y, z;
+};
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ float sqnorm(V3 a) { return a.x * a.x + (a.y * a.y + a.z * a.z); }
+__device__ __forceinline__ V3 normalized(V3 a) {
+    const float z = sqnorm(a);
+    if (z > 0.0f) {
+        const float n = sqrtf(z);
+        return {a.x / n, a.y / n, a.z / n};
+    }
+    return a;
+}
+__device__ __forceinline__ V3 meshVert(const MeshDev& m, uint32_t i) {
+    return {m.verts[3 * i], m.verts[3 * i + 1], m.verts[3 * i + 2]};
+}
+
+constexpr float kEpsF32 = 0.000001f;  // Include/Utility/Literals.h:13
+
+// returns simplex*4 + simplexIdx; closest point in q
+__device__ int closestSimplex(V3 pt, V3 a, V3 b, V3 c, V3& q) {
+    const V3 ab = b - a, ac = c - a, bc = c - b;
+    const float snom = dot(pt - a, ab), sdenom = dot(pt - b, a - b);
+    const float tnom = dot(pt - a, ac), tdenom = dot(pt - c, a - c);
+    if (snom < kEpsF32 && tnom < kEpsF32) {
+        q = a;
+        return 0;
+    }
+    const float unom = dot(pt - b, bc), udenom = dot(pt - c, b - c);
+    if (sdenom < kEpsF32 && unom < kEpsF32) {
+        q = b;
+        return 1;
+    }
+    if (tdenom < kEpsF32 && udenom < kEpsF32) {
+        q = c;
+        return 2;
+    }
+    const V3 n = cross(b - a, c - a);
+    const float vc = dot(n, cross(a - pt, b - pt));
+    if (vc < kEpsF32 && snom > kEpsF32 && sdenom > kEpsF32) {
+        q = a + (snom / (snom + sdenom)) * ab;
+        return 4;
+    }
+    const float va = dot(n, cross(b - pt, c - pt));
+    if (va < kEpsF32 && unom > kEpsF32 && udenom > kEpsF32) {
+        q = b + (unom / (unom + udenom)) * bc;
+        return 5;
+    }
+    const float vb = dot(n, cross(c - pt, a - pt));
+    if (vb < kEpsF32 && tnom > kEpsF32 && tdenom > kEpsF32) {
+        q = a + (tnom / (tnom + tdenom)) * ac;
+        return 6;
+    }
+    const float u = va / (va + vb + vc);
+    const float v = vb / (va + vb + vc);
+    const float w = 1.0f - u - v;
+    q = (u * a + v * b) + w * c;
+    return 8;
+}
+
+__device__ V3 faceNormal(const MeshDev& m, uint32_t t) {
+    const V3 a = meshVert(m, m.tris[3 * t]), b = meshVert(m, m.tris[3 * t + 1]), c = meshVert(m, m.tris[3 * t + 2]);
+    return normalized(cross(b - a, c - a));
+}
+
+__device__ V3 pseudoNormal(const MeshDev& m, uint32_t t, int code) {
+    const int simplex = code >> 2, sidx = code & 3;
+    if (simplex == 2) return faceNormal(m, t);
+    if (simplex == 1) {  // Mesh.cpp:201-215
+        const uint32_t adj = m.halfEdges[3 * t + sidx] / 3;
+        const float pif = (float)3.14159265359;
+        return normalized(pif * faceNormal(m, t) + pif * faceNormal(m, adj));
+    }
+    // vertex: walk the half-edge fan, Mesh.cpp:218-242
+    V3 n = {0.0f, 0.0f, 0.0f};
+    uint32_t he = 3 * t + sidx, cur = t;
+    int guard = 0;
+    do {
+        V3 tri[3] = {meshVert(m, m.tris[3 * cur]), meshVert(m, m.tris[3 * cur + 1]), meshVert(m, m.tris[3 * cur + 2])};
+        const int k = he % 3;
+        const V3 ab = tri[(k + 1) % 3] - tri[k];
+        const V3 ac = tri[(k + 2) % 3] - tri[k];
+        const float ang = acosf(dot(normalized(ab), normalized(ac)));
+        n = n + ang * faceNormal(m, cur);
+        he = m.halfEdges[he];
+        he = ((he % 3) == 2) ? (he - 2) : (he + 1);
+        cur = he / 3;
+    } while (cur != t && ++guard < 4096);
+    return normalized(n);
+}
+
+// Closest triangle by stack traversal of the device BVH, nearest child first.
+// Ties on squared distance go to the lower triangle index, and boxes are only
+// pruned when strictly farther than the running best (with a guard band for
+// f32 rounding of the box distance), so the winner equals the linear scan of
+// Mesh::ClosestTriangleToPt (Mesh.cpp:134-159).
+__device__ float meshSignedDistance(const MeshDev& m, V3 pt) {
+    float best = FLT_MAX;
+    uint32_t bestTri = 0xFFFFFFFFu;
+    int bestCode = 8;
+    V3 bestQ = {0.0f, 0.0f, 0.0f};
+    int32_t stack[64];
+    int sp = 0;
+    stack[sp++] = 0;
+    auto boxDist = [&](int32_t node) {
+        const float* bx = m.bvhBoxes + 6 * (size_t)node;
+        const float cx = fminf(fmaxf(pt.x, bx[0]), bx[3]);
+        const float cy = fminf(fmaxf(pt.y, bx[1]), bx[4]);
+        const float cz = fminf(fmaxf(pt.z, bx[2]), bx[5]);
+        return sqnorm(pt - V3{cx, cy, cz});
+    };
+    auto visitTri = [&](uint32_t t) {
+        V3 q;
+        const int code =
+            closestSimplex(pt, meshVert(m, m.tris[3 * t]), meshVert(m, m.tris[3 * t + 1]), meshVert(m, m.tris[3 * t + 2]), q);
+        const float d = sqnorm(pt - q);
+        if (d < best || (d == best && t < bestTri)) {
+            best = d;
+            bestTri = t;
+            bestCode = code;
+            bestQ = q;
+        }
+    };
+    while (sp > 0) {
+        const int32_t node = stack[--sp];
+        if (node < 0) {
+            visitTri((uint32_t)~node);
+            continue;
+        }
+        if (boxDist(node) > best * 1.00001f + 1e-30f) continue;
+        const int32_t c0 = m.bvhChild[2 * (size_t)node], c1 = m.bvhChild[2 * (size_t)node + 1];
+        const float d0 = c0 < 0 ? 0.0f : boxDist(c0);
+        const float d1 = c1 < 0 ? 0.0f : boxDist(c1);
+        // push the farther child first so the nearer is popped next
+        if (d0 <= d1) {
+            if (sp < 63) stack[sp++] = c1;
+            stack[sp++] = c0;
+        } else {
+            if (sp < 63) stack[sp++] = c0;
+            stack[sp++] = c1;
+        }
+    }
+    const V3 n = pseudoNormal(m, bestTri, bestCode);
+    const V3 d = pt - bestQ;
+    const float sign = dot(n, d) > 0.0f ? 1.0f : -1.0f;
+    return sign * sqrtf(sqnorm(d));
+}
+
+// ---------------------------------------------------------------------------
+// tree evaluation: Octree::Query (Octree.cpp:662-702) and FApprox (:859-901)
+// ---------------------------------------------------------------------------
+
+// Basis index table in graded order (total degree, then first and second index).
+struct BasisIdx {
+    unsigned char v[456][3];
+    constexpr BasisIdx() : v() {
+        int row = 0;
+        for (int p = 0; p <= 12; ++p)
+            for (int a = 0; a <= p; ++a)
+                for (int b = 0; a + b <= p; ++b) {
+                    v[row][0] = (unsigned char)a;
+                    v[row][1] = (unsigned char)b;
+                    v[row][2] = (unsigned char)(p - a - b);
+                    ++row;
+                }
+    }
+};
+__device__ constexpr BasisIdx kBasis{};
+__host__ __device__ constexpr int coeffCount(int p) {
+    // the reference's (u32)(1/6.0 * (p+1)*(p+2)*(p+3)) evaluates to 83 for p = 6
+    return p == 6 ? 83 : (p + 1) * (p + 2) * (p + 3) / 6;
+}
+
+// sNl: [13][11] normalisation table, sRec: [13][2] recurrence constants (LDS)
+template <int P>
+__device__ __forceinline__ double evalLeafFixed(const double* __restrict__ c, double ux, double uy, double uz, int depth,
+                                                const double* sNl, const double* sRec) {
+    double tx[P + 1], ty[P + 1], tz[P + 1];
+    tx[0] = ty[0] = tz[0] = sNl[depth];
+    double xm2 = 0.0, xm1 = 1.0, ym2 = 0.0, ym1 = 1.0, zm2 = 0.0, zm1 = 1.0;
+#pragma unroll
+    for (int j = 1; j <= P; ++j) {
+        const double r0 = sRec[2 * j], r1 = sRec[2 * j + 1], nl = sNl[j * 11 + depth];
+        const double lx = r0 * ux * xm1 - r1 * xm2;
+        const double ly = r0 * uy * ym1 - r1 * ym2;
+        const double lz = r0 * uz * zm1 - r1 * zm2;
+        xm2 = xm1, xm1 = lx, ym2 = ym1, ym1 = ly, zm2 = zm1, zm1 = lz;
+        tx[j] = lx * nl, ty[j] = ly * nl, tz[j] = lz * nl;
+    }
+    double f = 0.0;
+#pragma unroll
+    for (int i = 0; i < coeffCount(P); ++i) {
+        double lp = tx[kBasis.v[i][0]];
+        lp = lp * ty[kBasis.v[i][1]];
+        lp = lp * tz[kBasis.v[i][2]];
+        f = f + c[i] * lp;
+    }
+    return f;
+}
+
+// any degree (tables in private memory, dynamically indexed)
+__device__ __noinline__ double evalLeafGeneric(const double* __restrict__ c, int degree, double ux, double uy, double uz,
+                                               int depth, const double* sNl, const double* sRec) {
+    double t[3][13];
+    const double u[3] = {ux, uy, uz};
+    for (int a = 0; a < 3; ++a) {
+        t[a][0] = sNl[depth];
+        double m2 = 0.0, m1 = 1.0;
+        for (int j = 1; j <= degree; ++j) {
+            const double l = sRec[2 * j] * u[a] * m1 - sRec[2 * j + 1] * m2;
+            m2 = m1, m1 = l;
+            t[a][j] = l * sNl[j * 11 + depth];
+        }
+    }
+    double f = 0.0;
+    const int n = coeffCount(degree);
+    for (int i = 0; i < n; ++i) {
+        double lp = t[0][kBasis.v[i][0]];
+        lp = lp * t[1][kBasis.v[i][1]];
+        lp = lp * t[2][kBasis.v[i][2]];
+        f = f + c[i] * lp;
+    }
+    return f;
+}
+
+__device__ __forceinline__ double evalLeaf(const double* __restrict__ c, int degree, double ux, double uy, double uz,
+                                           int depth, const double* sNl, const double* sRec) {
+    switch (degree) {
+        case 0: return evalLeafFixed<0>(c, ux, uy, uz, depth, sNl, sRec);
+        case 1: return evalLeafFixed<1>(c, ux, uy, uz, depth, sNl, sRec);
+        case 2: return evalLeafFixed<2>(c, ux, uy, uz, depth, sNl, sRec);
+        case 3: return evalLeafFixed<3>(c, ux, uy, uz, depth, sNl, sRec);
+        case 4: return evalLeafFixed<4>(c, ux, uy, uz, depth, sNl, sRec);
+        case 5: return evalLeafFixed<5>(c, ux, uy, uz, depth, sNl, sRec);
+        default: return evalLeafGeneric(c, degree, ux, uy, uz, depth, sNl, sRec);
+    }
+}
+
+// One point through the tree.  (x,y,z) in world coordinates.
+__device__ __forceinline__ double queryPoint(const TreeDev& t, double x, double y, double z, const double* sNl,
+                                             const double* sRec) {
+    // Octree.cpp:665
+    const double px = (x - t.rootCentre[0]) * t.rootInvSizes[0];
+    const double py = (y - t.rootCentre[1]) * t.rootInvSizes[1];
+    const double pz = (z - t.rootCentre[2]) * t.rootInvSizes[2];
+    // :668 containment on the f32 cast, both ends inclusive; NaN fails
+    const float fx = (float)px, fy = (float)py, fz = (float)pz;
+    if (!(fx >= -0.5f && fx <= 0.5f && fy >= -0.5f && fy <= 0.5f && fz >= -0.5f && fz <= 0.5f)) return DBL_MAX;
+    // :674-701.  The mid-plane of a cell is its centre; centres are exact dyadics.
+    double cx = 0.0, cy = 0.0, cz = 0.0, q = 0.25;
+    uint32_t child = t.nodes[0].a;
+    int depth = 0;
+    NodeRec rec;
+    for (;;) {
+        const bool ux = px >= cx, uy = py >= cy, uz = pz >= cz;
+        const uint32_t idx = child + (ux ? 1u : 0u) + (uy ? 2u : 0u) + (uz ? 4u : 0u);
+        cx = ux ? cx + q : cx - q;
+        cy = uy ? cy + q : cy - q;
+        cz = uz ? cz + q : cz - q;
+        q = q * 0.5;
+        ++depth;
+        rec = t.nodes[idx];
+        if (rec.b != kInteriorTag) break;
+        child = rec.a;
+    }
+    // :862  unitPt = (pt - centre) * (2 << depth)
+    const double s = (double)(2 << depth);
+    return evalLeaf(t.coeffs + rec.a, (int)rec.b, (px - cx) * s, (py - cy) * s, (pz - cz) * s, depth, sNl, sRec);
+}
+
+__device__ __forceinline__ void stageQueryTables(const DeviceTables* T, double* sNl, double* sRec) {
+    for (int i = threadIdx.x; i < 13 * 11; i += blockDim.x) sNl[i] = (&T->nl[0][0])[i];
+    for (int i = threadIdx.x; i < 26; i += blockDim.x) sRec[i] = (&T->rec[0][0])[i];
+}
+
+__global__ __launch_bounds__(256) void query_kernel(TreeDev t, const DeviceTables* __restrict__ T,
+                                                    const double* __restrict__ xyz, size_t n, double* __restrict__ out) {
+    __shared__ double sNl[13 * 11];
+    __shared__ double sRec[26];
+    stageQueryTables(T, sNl, sRec);
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        out[i] = queryPoint(t, x, y, z, sNl, sRec);
+    }
+}
+
+// F at a world-space point, with the optional CSG wrapper of Octree.cpp:355-400
+template <int KIND, bool CSG>
+__device__ __forceinline__ double fieldEvalWorld(const FieldDev& f, double x, double y, double z, uint64_t sampleIdx,
+                                                 const double* sNl, const double* sRec) {
+    double v;
+    if constexpr (KIND == kFieldAnalytic)
+        v = analyticEval(f, x, y, z);
+    else if constexpr (KIND == kFieldSamples)
+        v = f.samples[sampleIdx];
+    else  // SURVEY 3.4 user glue: (f64) mesh.SignedDistanceAtPt(p.cast<f32>())
+        v = (double)meshSignedDistance(f.mesh, V3{(float)x, (float)y, (float)z});
+    if constexpr (CSG) {
+        const double o = queryPoint(f.oldTree, x, y, z, sNl, sRec);
+        switch (f.csgOp) {
+            case HPSDF_OP_UNION: v = o < v ? o : v; break;                   // std::min(old, F)
+            case HPSDF_OP_SUBTRACT: v = (o * -1.0) < v ? v : (o * -1.0); break;  // std::max(-old, F)
+            default: v = o < v ? v : o; break;                               // std::max(old, F)
+        }
+    }
+    return v;
+}
+
+template <int KIND, bool CSG>
+__global__ __launch_bounds__(256) void field_kernel(FieldDev f, const DeviceTables* __restrict__ T,
+                                                    const double* __restrict__ xyz, size_t n, double* __restrict__ out) {
+    __shared__ double sNl[13 * 11];
+    __shared__ double sRec[26];
+    stageQueryTables(T, sNl, sRec);
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = fieldEvalWorld<KIND, CSG>(f, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], i, sNl, sRec);
+}
+
+// ---------------------------------------------------------------------------
+// fit: Octree::FitPolynomial, Octree.cpp:1007-1093
+// ---------------------------------------------------------------------------
+//
+// One workgroup fits blk.nTasks cells of identical shape.  The reference loops
+// samples (i,j,k) outermost and coefficients innermost; here each thread owns
+// one (cell, coefficient row) accumulator and walks the samples in the same
+// (i,j,k) order, so every coefficient is the same left-to-right sum.  Per
+// i-plane: phase 1 evaluates F on the plane's nq*nq samples of every cell into
+// LDS (all 256 threads), phase 2 accumulates.  The per-term product
+//   Lp = 1 * P_i0(x) * N_i0 * P_i1(y) * N_i1 * P_i2(z) * N_i2      (:1045-1050)
+// is hoisted by loop level without changing its association.
+
+constexpr int kFitThreads = 256;
+
+template <int KIND, bool CSG>
+__global__ __launch_bounds__(kFitThreads) void fit_kernel(const FitBlock* __restrict__ blocks,
+                                                          const FitTask* __restrict__ tasks, double* __restrict__ arena,
+                                                          double* __restrict__ errs, const DeviceTables* __restrict__ T,
+                                                          FieldDev field, RootMap rm) {
+    extern __shared__ double lds[];
+    __shared__ double sNl[13 * 11];
+    __shared__ double sRec[26];
+    const FitBlock blk = blocks[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int deg = blk.degree, nq = 4 * deg + 1, nq2 = nq * nq, G = blk.nTasks;
+    const int rowStart = blk.rowStart, rowEnd = blk.rowEnd, nrows = rowEnd - rowStart;
+    const int gl = nq * (nq - 1) / 2;  // Legendre.h: rule n starts at n(n-1)/2 (:1016-1017)
+
+    double* sT = lds;               // [deg+1][nq]  LpX(p, root_q)
+    double* sR = sT + (deg + 1) * nq;  // [nq] roots
+    double* sW = sR + nq;           // [nq] weights
+    double* sC = sW + nq;           // [G][8]  scale xyz, centre xyz, scale product, sample offset (bits)
+    double* sF = sC + 8 * G;        // [G][nq2] weighted samples of the current plane
+
+    stageQueryTables(T, sNl, sRec);
+    for (int q = tid; q < nq; q += kFitThreads) {
+        const double x = T->roots[gl + q];
+        sR[q] = x;
+        sW[q] = T->weights[gl + q];
+        // Octree::LpX, :988-1004
+        double m2 = 0.0, m1 = 1.0;
+        sT[q] = 1.0;
+        for (int i = 1; i <= deg; ++i) {
+            const double l = T->rec[i][0] * x * m1 - T->rec[i][1] * m2;
+            m2 = m1, m1 = l;
+            sT[i * nq + q] = l;
+        }
+    }
+    for (int g = tid; g < G; g += kFitThreads) {
+        const FitTask& tk = tasks[blk.firstTask + g];
+        double sc[3];
+        for (int a = 0; a < 3; ++a) {
+            sc[a] = (double)(tk.bmax[a] - tk.bmin[a]) * 0.5;               // :1020 sizes() in f32
+            sC[8 * g + 3 + a] = (double)((tk.bmin[a] + tk.bmax[a]) / 2.0f);  // :1021 center() in f32
+            sC[8 * g + a] = sc[a];
+        }
+        sC[8 * g + 6] = sc[0] * (sc[1] * sc[2]);  // :1022 Eigen prod(): a*(b*c)
+        sC[8 * g + 7] = __longlong_as_double((long long)tk.sampleOff);
+    }
+    __syncthreads();
+
+    // phase-2 ownership: thread -> (cell g, row r); cells with > 256 rows use two rows per thread
+    const bool wide = nrows > kFitThreads;
+    const int g2 = wide ? 0 : tid / nrows;
+    const int r0 = rowStart + (wide ? tid : tid % nrows);
+    const int r1 = r0 + kFitThreads;
+    const bool act0 = wide ? (r0 < rowEnd) : (tid < G * nrows);
+    const bool act1 = wide && r1 < rowEnd;
+    int depth = 0;
+    if (act0) depth = tasks[blk.firstTask + g2].depth;
+    int i0a = 0, i1a = 0, i2a = 0, i0b = 0, i1b = 0, i2b = 0;
+    double n0a = 0, n1a = 0, n2a = 0, n0b = 0, n1b = 0, n2b = 0;
+    if (act0) {
+        i0a = T->bidx[r0][0], i1a = T->bidx[r0][1], i2a = T->bidx[r0][2];
+        n0a = sNl[i0a * 11 + depth], n1a = sNl[i1a * 11 + depth], n2a = sNl[i2a * 11 + depth];
+    }
+    if (act1) {
+        i0b = T->bidx[r1][0], i1b = T->bidx[r1][1], i2b = T->bidx[r1][2];
+        n0b = sNl[i0b * 11 + depth], n1b = sNl[i1b * 11 + depth], n2b = sNl[i2b * 11 + depth];
+    }
+    double acc0 = 0.0, acc1 = 0.0;  // :1025
+
+    const int planeSamples = G * nq2;
+    for (int i = 0; i < nq; ++i) {
+        // ---- phase 1: F on plane i of every cell (:1035-1040)
+        const double ri = sR[i], wi = sW[i];
+        for (int s = tid; s < planeSamples; s += kFitThreads) {
+            const int g = s / nq2, jk = s - g * nq2, j = jk / nq, k = jk - j * nq;
+            const double* c = sC + 8 * g;
+            const double ux = ri * c[0] + c[3], uy = sR[j] * c[1] + c[4], uz = sR[k] * c[2] + c[5];
+            const double wx = ux * rm.bounds[0] + rm.centre[0];  // Octree.cpp:327
+            const double wy = uy * rm.bounds[1] + rm.centre[1];
+            const double wz = uz * rm.bounds[2] + rm.centre[2];
+            const uint64_t sidx = (uint64_t)__double_as_longlong(c[7]) + (uint64_t)((i * nq + j) * nq + k);
+            const double fv = fieldEvalWorld<KIND, CSG>(field, wx, wy, wz, sidx, sNl, sRec);
+            sF[s] = c[6] * (wi * (sW[j] * sW[k])) * fv;  // :1040
+        }
+        __syncthreads();
+        // ---- phase 2: accumulate plane i (:1043-1053)
+        if (act0) {
+            const double* F = sF + g2 * nq2;
+            const double a0 = sT[i0a * nq + i] * n0a;
+            const double* tj = sT + i1a * nq;
+            const double* tk = sT + i2a * nq;
+            for (int j = 0; j < nq; ++j) {
+                const double a1 = a0 * tj[j] * n1a;
+                const double* Fj = F + j * nq;
+                for (int k = 0; k < nq; ++k) {
+                    const double lp = a1 * tk[k] * n2a;
+                    acc0 = acc0 + lp * Fj[k];
+                }
+            }
+        }
+        if (act1) {
+            const double a0 = sT[i0b * nq + i] * n0b;
+            const double* tj = sT + i1b * nq;
+            const double* tk = sT + i2b * nq;
+            for (int j = 0; j < nq; ++j) {
+                const double a1 = a0 * tj[j] * n1b;
+                const double* Fj = sF + j * nq;
+                for (int k = 0; k < nq; ++k) {
+                    const double lp = a1 * tk[k] * n2b;
+                    acc1 = acc1 + lp * Fj[k];
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // coefficients out (outOff addresses row rowStart); stash the new rows in LDS for the error sum
+    if (act0) {
+        arena[tasks[blk.firstTask + g2].outOff + (r0 - rowStart)] = acc0;
+        sF[g2 * nrows + (r0 - rowStart)] = acc0;
+    }
+    if (act1) {
+        arena[tasks[blk.firstTask].outOff + (r1 - rowStart)] = acc1;
+        sF[r1 - rowStart] = acc1;
+    }
+    // An incremental fit (:847, :1012) writes only its new rows: the rows [0,rowStart) stay where
+    // the earlier fit of this cell put them (the host keeps a segment chain per node).
+    __syncthreads();
+    // :1062-1069  error = sum of squares of the rows of total degree == deg, in row order
+    if (tid < G) {
+        const int first = deg > 0 ? (int)T->count[deg - 1] : 0;
+        double e = 0.0;
+        for (int r = first > rowStart ? first : rowStart; r < rowEnd; ++r)
+            if (T->bidx[r][3] == deg) {
+                const double c = sF[tid * nrows + (r - rowStart)];
+                e = e + c * c;
+            }
+        errs[tasks[blk.firstTask + tid].errSlot] = e;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// pack: Octree::ReallocCoeffs gather (Octree.cpp:510-552)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_kernel(const PackItem* __restrict__ items, uint32_t nItems,
+                                                   const double* __restrict__ arena, double* __restrict__ out) {
+    // one wave per leaf
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= nItems) return;
+    const PackItem it = items[wave];
+    for (uint32_t i = lane; i < it.count; i += 64) out[it.dst + i] = arena[it.src + i];
+}
+
+// ---------------------------------------------------------------------------
+// launch wrappers (host)
+// ---------------------------------------------------------------------------
+size_t fitLdsBytes(int degree, int nTasks) {
+    const size_t nq = 4 * (size_t)degree + 1;
+    // sT + roots + weights + per-cell constants + one sample plane per cell (also holds the new rows at the end)
+    return ((size_t)(degree + 1) * nq + 2 * nq + 8 * (size_t)nTasks + (size_t)nTasks * nq * nq) * sizeof(double);
+}
+
+template <int KIND, bool CSG>
+static void launchFitT(hipStream_t stream, const FitBlock* dBlocks, uint32_t nBlocks, size_t ldsBytes,
+                       const FitTask* dTasks, double* dArena, double* dErrs, const DeviceTables* dTables,
+                       const FieldDev& field, const RootMap& rm) {
+    hipLaunchKernelGGL((fit_kernel<KIND, CSG>), dim3(nBlocks), dim3(kFitThreads), ldsBytes, stream, dBlocks, dTasks,
+                       dArena, dErrs, dTables, field, rm);
+}
+
+#define HPSDF_DISPATCH_FIELD(FN, field, ...)                                     \
+    do {                                                                         \
+        const bool csg_ = (field).csgOp >= 0;                                    \
+        switch ((field).kind) {                                                  \
+            case kFieldAnalytic:                                                 \
+                if (csg_) FN<kFieldAnalytic, true>(__VA_ARGS__);                 \
+                else FN<kFieldAnalytic, false>(__VA_ARGS__);                     \
+                break;                                                           \
+            case kFieldSamples:                                                  \
+                if (csg_) FN<kFieldSamples, true>(__VA_ARGS__);                  \
+                else FN<kFieldSamples, false>(__VA_ARGS__);                      \
+                break;                                                           \
+            default:                                                             \
+                if (csg_) FN<kFieldMesh, true>(__VA_ARGS__);                     \
+                else FN<kFieldMesh, false>(__VA_ARGS__);                         \
+                break;                                                           \
+        }                                                                        \
+    } while (0)
+
+hipError_t launchFit(hipStream_t stream, const FitBlock* dBlocks, uint32_t nBlocks, size_t ldsBytes,
+                     const FitTask* dTasks, double* dArena, double* dErrs, const DeviceTables* dTables,
+                     const FieldDev& field, const RootMap& rm) {
+    if (nBlocks == 0) return hipSuccess;
+    if (ldsBytes > kFitMaxLdsBytes) return hipErrorInvalidValue;
+    HPSDF_DISPATCH_FIELD(launchFitT, field, stream, dBlocks, nBlocks, ldsBytes, dTasks, dArena, dErrs, dTables, field,
+                         rm);
+    return hipGetLastError();
+}
+
+static unsigned gridFor(size_t n) {
+    size_t blocks = (n + 255) / 256;
+    const size_t cap = 256 * 8 * 4;  // grid-stride beyond this
+    return (unsigned)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
+}
+
+hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dXyz, size_t n,
+                       double* dOut) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(query_kernel, dim3(gridFor(n)), dim3(256), 0, stream, t, dTables, dXyz, n, dOut);
+    return hipGetLastError();
+}
+
+template <int KIND, bool CSG>
+static void launchFieldT(hipStream_t stream, const FieldDev& f, const DeviceTables* dTables, const double* dXyz,
+                         size_t n, double* dOut) {
+    hipLaunchKernelGGL((field_kernel<KIND, CSG>), dim3(gridFor(n)), dim3(256), 0, stream, f, dTables, dXyz, n, dOut);
+}
+
+hipError_t launchFieldEval(hipStream_t stream, const FieldDev& f, const DeviceTables* dTables, const double* dXyz,
+                           size_t n, double* dOut) {
+    if (n == 0) return hipSuccess;
+    HPSDF_DISPATCH_FIELD(launchFieldT, f, stream, f, dTables, dXyz, n, dOut);
+    return hipGetLastError();
+}
+
+hipError_t launchPack(hipStream_t stream, const PackItem* dItems, uint32_t nItems, const double* dArena, double* dOut) {
+    if (nItems == 0) return hipSuccess;
+    const unsigned blocks = (nItems + 3) / 4;  // 4 waves per block
+    hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, stream, dItems, nItems, dArena, dOut);
+    return hipGetLastError();
+}
+
+}  // namespace hpsdf

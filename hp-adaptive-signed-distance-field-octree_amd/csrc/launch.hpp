@@ -1,0 +1,26 @@
+// Host-side launch wrappers of kernels.hip.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "device_types.hpp"
+
+namespace hpsdf {
+
+constexpr size_t kFitMaxLdsBytes = 60 * 1024;  // stays under the 64 KiB default dynamic-LDS limit
+constexpr int kFitBlockThreads = 256;
+
+size_t fitLdsBytes(int degree, int nTasks);
+
+hipError_t launchFit(hipStream_t stream, const FitBlock* dBlocks, uint32_t nBlocks, size_t ldsBytes,
+                     const FitTask* dTasks, double* dArena, double* dErrs, const DeviceTables* dTables,
+                     const FieldDev& field, const RootMap& rm);
+hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dXyz, size_t n,
+                       double* dOut);
+hipError_t launchFieldEval(hipStream_t stream, const FieldDev& f, const DeviceTables* dTables, const double* dXyz,
+                           size_t n, double* dOut);
+hipError_t launchPack(hipStream_t stream, const PackItem* dItems, uint32_t nItems, const double* dArena, double* dOut);
+
+}  // namespace hpsdf

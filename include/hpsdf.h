@@ -1,0 +1,232 @@
+/*
+ * hpsdf.h -- C ABI of the MI355X-native hp-adaptive SDF octree hot path.
+ *
+ * The reference (jw007123/hp-Adaptive-Signed-Distance-Field-Octree) has no FFI
+ * or plugin layer: its hot path sits behind the C++ class SDF::Octree
+ * (Include/HP/Octree.h:37-86).  This header is the boundary a maintainer binds
+ * to replace the bodies of that class's Create / Query / ToMemoryBlock /
+ * FromMemoryBlock with gfx950 kernels (the C++ drop-in that
+ * does exactly this is include/hpsdf_octree.hpp).
+ *
+ * Conventions: plain pointers and sizes, POD structs, caller-allocated outputs,
+ * no exceptions cross the boundary, every entry point returns an hpsdf_status
+ * (0 = ok) and hpsdf_last_error() gives the thread-local message.  Pointers
+ * named d_* are device (HBM) pointers on the context's GPU; everything else is
+ * host memory.  "stream" is a hipStream_t passed as void*.
+ *
+ * All file:line citations are relative to the reference checkout.
+ */
+#ifndef HPSDF_H
+#define HPSDF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define HPSDF_API __attribute__((visibility("default")))
+#else
+#define HPSDF_API
+#endif
+
+typedef enum hpsdf_status {
+    HPSDF_OK = 0,
+    HPSDF_ERR_INVALID_ARGUMENT = 1,
+    HPSDF_ERR_NO_DEVICE = 2,      /* no usable gfx950 device / HIP runtime error */
+    HPSDF_ERR_HIP = 3,
+    HPSDF_ERR_BAD_BLOCK = 4,      /* malformed MemoryBlock */
+    HPSDF_ERR_UNSUPPORTED = 5,
+    HPSDF_ERR_STATE = 6,          /* call sequence violated */
+    HPSDF_ERR_OUT_OF_MEMORY = 7,
+    HPSDF_ERR_OPEN_MESH = 8       /* Mesh::CreateHalfEdges would return false (Mesh.cpp:121-128) */
+} hpsdf_status;
+
+/* ---- constants: Include/HP/Consts.h:7-8, Include/HP/Octree.h:89 ----------- */
+#define HPSDF_BASIS_MAX_DEGREE 12
+#define HPSDF_TREE_MAX_DEPTH 10
+#define HPSDF_INTERIOR_DEGREE 13
+#define HPSDF_INITIAL_NODE_ERR 100.0
+#define HPSDF_DEFAULT_JOBS_PER_ROUND 1024
+
+/* ---- serialised PODs -------------------------------------------------------
+ * Byte-identical to the reference structs on Linux LP64, where the reference's
+ * "u32" is an 8-byte unsigned long (Include/Utility/Literals.h:9). */
+
+/* SDF::Node, Include/HP/Node.h:10-33 (56 bytes) */
+typedef struct hpsdf_node {
+    uint64_t child_idx;    /* @0  first of 8 children; all-ones = leaf */
+    float aabb_min[3];     /* @8  Eigen::AlignedBox3f min */
+    float aabb_max[3];     /* @20 Eigen::AlignedBox3f max */
+    uint64_t coeffs_start; /* @32 offset into the coefficient store (doubles) */
+    uint8_t degree;        /* @40 13 = interior */
+    uint8_t pad0[7];
+    uint8_t depth;         /* @48 */
+    uint8_t pad1[7];
+} hpsdf_node;
+
+/* SDF::Config, Include/HP/Config.h:12-43 (80 bytes) */
+typedef struct hpsdf_config {
+    uint8_t weighting_type; /* @0  0 None, 1 Polynomial, 2 Exponential */
+    uint8_t pad0[7];
+    double weighting_strength;  /* @8  */
+    uint8_t continuity_enforce; /* @16 */
+    uint8_t pad1[7];
+    double continuity_strength; /* @24 */
+    uint8_t enable_logging;     /* @32 */
+    uint8_t pad2[7];
+    double target_error_threshold; /* @40 */
+    uint64_t thread_count;         /* @48 */
+    float root_min[3];             /* @56 */
+    float root_max[3];             /* @68 */
+} hpsdf_config;
+
+/* Source/HP/Config.cpp:5-14 (thread_count = hardware concurrency) */
+HPSDF_API int hpsdf_config_default(hpsdf_config* out);
+
+HPSDF_API const char* hpsdf_last_error(void);
+HPSDF_API const char* hpsdf_version(void);
+
+/* ---- constant tables (Include/HP/Utility.h:40-160, Include/HP/Legendre.h) --
+ * Copies the host tables the kernels are fed with.  Any pointer may be NULL.
+ * roots/weights: 2080 (rule n at n(n-1)/2); normalised_lengths: 13*11;
+ * recurrence: 13*2; coeff_count: 13; basis_index: 455*3; sum_to_n: 50. */
+HPSDF_API int hpsdf_tables_get(double* roots, double* weights, double* normalised_lengths, double* recurrence,
+                               uint64_t* coeff_count, uint64_t* basis_index, uint64_t* sum_to_n);
+
+/* ---- device context --------------------------------------------------------- */
+typedef struct hpsdf_ctx hpsdf_ctx;
+/* device: HIP ordinal; stream: hipStream_t to launch on (NULL = a stream owned by the context). */
+HPSDF_API int hpsdf_ctx_create(int device, void* stream, hpsdf_ctx** out);
+HPSDF_API int hpsdf_ctx_destroy(hpsdf_ctx* ctx);
+HPSDF_API int hpsdf_ctx_set_stream(hpsdf_ctx* ctx, void* stream);
+HPSDF_API int hpsdf_ctx_synchronize(hpsdf_ctx* ctx);
+HPSDF_API void* hpsdf_ctx_stream(hpsdf_ctx* ctx);
+
+/* ---- fields: the callback F of Octree::Create (Include/HP/Octree.h:50) ------ */
+enum { HPSDF_PRIM_SPHERE = 0, HPSDF_PRIM_BOX = 1, HPSDF_PRIM_TORUS_Y = 2, HPSDF_PRIM_PLANE = 3 };
+enum { HPSDF_OP_UNION = 0, HPSDF_OP_INTERSECT = 1, HPSDF_OP_SUBTRACT = 2 };
+#define HPSDF_MAX_PRIMS 16
+typedef struct hpsdf_prim {
+    int32_t kind; /* HPSDF_PRIM_* */
+    int32_t op;   /* HPSDF_OP_*: how this primitive combines with the running value (ignored for the first) */
+    double p[8];  /* sphere: c,r | box: c,half | torus(y axis): c,R,r | plane: n,offset */
+} hpsdf_prim;
+
+/* f64 F(const Vector3d& pt, u32 threadIdx): called concurrently from
+ * config.thread_count host threads, thread_idx in [0, thread_count)
+ * (Source/HP/BuildThreadPool.cpp:10-14). */
+typedef double (*hpsdf_callback)(const double* pt, uint64_t thread_idx, void* user);
+
+typedef struct hpsdf_field hpsdf_field;
+typedef struct hpsdf_tree hpsdf_tree;
+
+/* evaluated on the GPU inside the fit kernel */
+HPSDF_API int hpsdf_field_create_analytic(const hpsdf_prim* prims, int n_prims, hpsdf_field** out);
+/* evaluated by host threads per round, values shipped to HBM (keeps Create(config, std::function) working) */
+HPSDF_API int hpsdf_field_create_callback(hpsdf_callback cb, void* user, hpsdf_field** out);
+/* closed triangle mesh; f32 signed distance with angle-weighted pseudo-normals
+ * (Source/Meshing/Mesh.cpp:54-63,162-242; Source/Meshing/Utility.cpp:5-97), evaluated on the GPU
+ * over a device BVH.  tris: 3 vertex indices per triangle, CCW. */
+HPSDF_API int hpsdf_field_create_mesh(hpsdf_ctx* ctx, const float* verts, uint64_t n_verts, const uint64_t* tris,
+                                      uint64_t n_tris, hpsdf_field** out);
+/* F'(p) = op(old.Query(p), inner(p)): Octree::UnionSDF/SubtractSDF/IntersectSDF, Octree.cpp:355-400.
+ * op: HPSDF_OP_UNION -> min(old,F); HPSDF_OP_SUBTRACT -> max(-old,F); HPSDF_OP_INTERSECT -> max(old,F). */
+HPSDF_API int hpsdf_field_create_tree_csg(const hpsdf_tree* old_tree, int op, const hpsdf_field* inner,
+                                          hpsdf_field** out);
+HPSDF_API int hpsdf_field_destroy(hpsdf_field* f);
+/* F at n world-space points (device pointers, xyz interleaved); analytic/mesh/tree fields only. */
+HPSDF_API int hpsdf_field_eval_device(hpsdf_ctx* ctx, const hpsdf_field* f, const double* d_xyz, size_t n,
+                                      double* d_out);
+HPSDF_API int hpsdf_field_eval_host(hpsdf_ctx* ctx, const hpsdf_field* f, const double* xyz, size_t n, double* out);
+
+/* ---- Query: Octree::FromMemoryBlock + Octree::Query (Octree.cpp:403-421, 662-702, 859-901) */
+/* block layout: [u64 nCoeffs][f64 x nCoeffs][u64 nNodes][hpsdf_node x nNodes][hpsdf_config] */
+HPSDF_API int hpsdf_tree_upload(hpsdf_ctx* ctx, const void* block, size_t size, hpsdf_tree** out);
+HPSDF_API int hpsdf_tree_destroy(hpsdf_tree* t);
+HPSDF_API int hpsdf_tree_info(const hpsdf_tree* t, uint64_t* n_nodes, uint64_t* n_coeffs, uint64_t* n_leaves,
+                              int* max_degree, int* max_depth);
+/* out[i] = Query(xyz[3i..3i+2]); DBL_MAX outside the root (Octree.cpp:668-671).
+ * Asynchronous on the context stream; no host synchronisation. */
+HPSDF_API int hpsdf_query_device(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* d_xyz, size_t n, double* d_out);
+/* host buffers: H2D + kernel + D2H, synchronous (PCIe-inclusive) */
+HPSDF_API int hpsdf_query_host(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* xyz, size_t n, double* out);
+
+/* ---- Create: Octree::Create under the canonical round schedule ---------------
+ * (Octree.cpp:312-352, 194-309, 558-659, 804-856, 1007-1093; schedule: DESIGN.md)
+ *
+ * One round = select jobs -> compute this rank's slice on the GPU -> (exchange
+ * the 9 errors per job across ranks) -> apply.  The exchange is the caller's:
+ * world == 1 needs none; N ranks all-gather the slice buffers over RCCL
+ * (hp-adaptive-..._amd/distributed.py).  Every rank applies the same headers in
+ * the same order, so all ranks hold identical trees. */
+typedef struct hpsdf_build hpsdf_build;
+
+typedef struct hpsdf_build_opts {
+    uint64_t max_jobs_per_round; /* K of the canonical schedule; 0 = HPSDF_DEFAULT_JOBS_PER_ROUND */
+    int32_t rank, world;         /* this process's shard of every round */
+    int32_t reserved[2];
+} hpsdf_build_opts;
+
+typedef struct hpsdf_job { /* one popped heap entry (BuildThreadPool::Input, BuildThreadPool.h:24-28) */
+    uint64_t node_idx;
+    float aabb_min[3], aabb_max[3];
+    double err;
+    uint8_t degree, depth, coarse, pad[5];
+} hpsdf_job;
+
+#define HPSDF_JOB_HEADER_DOUBLES 9 /* p_err, h_err[0..7] */
+
+typedef struct hpsdf_build_stats {
+    uint64_t rounds, jobs, p_refines, h_refines, dropped, fits, samples;
+    uint64_t n_nodes, n_leaves, n_coeffs;
+    double total_error;
+} hpsdf_build_stats;
+
+HPSDF_API int hpsdf_build_begin(const hpsdf_config* cfg, const hpsdf_build_opts* opts, hpsdf_build** out);
+HPSDF_API int hpsdf_build_destroy(hpsdf_build* b);
+/* pops the next batch; *n_jobs == 0 means the stop rule fired (Octree.cpp:216) */
+HPSDF_API int hpsdf_build_round_select(hpsdf_build* b, uint64_t* n_jobs);
+HPSDF_API int hpsdf_build_round_jobs(const hpsdf_build* b, hpsdf_job* out);
+/* contiguous cost-balanced job range of `rank`; identical on every rank */
+HPSDF_API int hpsdf_build_round_slice(const hpsdf_build* b, int rank, uint64_t* first_job, uint64_t* n_jobs);
+/* largest slice over ranks (padding unit of the all-gather) */
+HPSDF_API int hpsdf_build_round_max_slice(const hpsdf_build* b, uint64_t* n_jobs);
+/* sample + fit + error kernels for this rank's slice, asynchronous on the ctx stream */
+HPSDF_API int hpsdf_build_round_compute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field);
+/* this rank's [slice][9] header buffer in HBM (valid until the next round_select) */
+HPSDF_API int hpsdf_build_round_results_device(hpsdf_build* b, double** d_headers, uint64_t* n_doubles);
+/* D2H of the same, synchronous */
+HPSDF_API int hpsdf_build_round_results_host(hpsdf_build* b, hpsdf_ctx* ctx, double* out);
+/* headers of ALL jobs of the round, [n_jobs][9], host memory */
+HPSDF_API int hpsdf_build_round_apply(hpsdf_build* b, const double* headers);
+/* integration/test hook: supply one job's coefficients from the host instead of the GPU arena
+ * (p_coeffs: ncoef(p+1) or 10 for a coarse job; h_coeffs: 8*ncoef(p); either may be NULL if unused) */
+HPSDF_API int hpsdf_build_round_inject(hpsdf_build* b, uint64_t job, const double* p_coeffs,
+                                       const double* h_coeffs);
+
+/* ReallocCoeffs (Octree.cpp:474-555): DFS layout, then gather.  counts[r] = doubles owned by rank r. */
+HPSDF_API int hpsdf_build_layout(hpsdf_build* b, uint64_t* n_coeffs_total, uint64_t* counts_per_rank);
+/* this rank's leaves' coefficients, in DFS order */
+HPSDF_API int hpsdf_build_pack_device(hpsdf_build* b, hpsdf_ctx* ctx, double** d_pack, uint64_t* n_doubles);
+HPSDF_API int hpsdf_build_pack_host(hpsdf_build* b, hpsdf_ctx* ctx, double* out);
+/* packs[r] = rank r's buffer (host).  *block is malloc'd; the caller frees it with free()
+ * (ToMemoryBlock ownership, Octree.cpp:445; README.md:41). */
+HPSDF_API int hpsdf_build_assemble(hpsdf_build* b, const double* const* packs, void** block, size_t* size);
+HPSDF_API int hpsdf_build_get_stats(const hpsdf_build* b, hpsdf_build_stats* out);
+
+/* whole Create on one GPU: begin .. assemble.  *block is malloc'd (caller frees). */
+HPSDF_API int hpsdf_create(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* field,
+                           uint64_t max_jobs_per_round, void** block, size_t* size, hpsdf_build_stats* stats);
+
+/* ---- steady-state micro-benchmark hook (bench.py / profiles) ------------------
+ * n_cells from-scratch fits of `degree` at `depth` over a lattice of cells, results discarded. */
+HPSDF_API int hpsdf_bench_fit(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* field, int degree,
+                              int depth, uint64_t n_cells, int repeats, double* ms_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HPSDF_H */

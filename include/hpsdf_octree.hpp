@@ -1,0 +1,408 @@
+// SDF::Octree / SDF::Config / MemoryBlock -- C++ drop-in over the C ABI of hpsdf.h.
+//
+// Mirrors the public surface of the reference class (Include/HP/Octree.h:37-86,
+// Include/HP/Config.h:12-43, Include/Utility/MemoryBlock.h:5-9) for the hot path:
+// Create, Query, ToMemoryBlock, FromMemoryBlock, Clear, copy/move, GetRootAABB and
+// the three CSG rebuilds.  Everything numeric happens in libhpsdf.so on the GPU;
+// this header only marshals.  It is header-only on purpose: the compiled library
+// has no C++ types in its ABI, so it does not care which Eigen (if any) the host
+// program uses.
+//
+// Differences from the reference, all additive or documented in DESIGN.md:
+//   * Query(const double* xyz, n, out) -- the batched form every throughput-minded
+//     caller should use; Query(pt) is the same path with n = 1.
+//   * Create(config, DeviceField) -- fields the GPU evaluates itself (analytic
+//     primitives, triangle meshes); Create(config, std::function) still works and
+//     samples the callback with config.threadCount host threads per round.
+//   * errors: the reference asserts; here a failed call throws SDF::Error carrying
+//     hpsdf_last_error() (Query outside the root still returns DBL_MAX).
+//   * QueryWithGradient / QueryRay / OutputFunctionSlice are not part of the hot
+//     path and are not provided yet.
+#pragma once
+
+#include <cfloat>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "hpsdf.h"
+
+#if defined(__has_include)
+#if __has_include(<Eigen/Core>) && __has_include(<Eigen/Geometry>) && !defined(HPSDF_NO_EIGEN)
+#define HPSDF_HAVE_EIGEN 1
+#include <Eigen/Core>
+#include <Eigen/Geometry>
+#endif
+#endif
+
+// Literals.h of the reference: on LP64 Linux "u32" is 8 bytes wide
+typedef double f64;
+typedef float f32;
+typedef unsigned char u8;
+typedef long unsigned int u32;
+typedef size_t usize;
+
+#ifndef HPSDF_HAVE_EIGEN
+// Just enough of the two Eigen types the public API mentions, for hosts without Eigen.
+namespace Eigen {
+template <typename T>
+struct HpsdfVec3 {
+    T v[3];
+    HpsdfVec3() : v{T(0), T(0), T(0)} {}
+    HpsdfVec3(T x, T y, T z) : v{x, y, z} {}
+    T& x() { return v[0]; }
+    T& y() { return v[1]; }
+    T& z() { return v[2]; }
+    const T& x() const { return v[0]; }
+    const T& y() const { return v[1]; }
+    const T& z() const { return v[2]; }
+    T& operator()(int i) { return v[i]; }
+    const T& operator()(int i) const { return v[i]; }
+    const T* data() const { return v; }
+    T* data() { return v; }
+    HpsdfVec3 operator+(const HpsdfVec3& o) const { return {T(v[0] + o.v[0]), T(v[1] + o.v[1]), T(v[2] + o.v[2])}; }
+    HpsdfVec3 operator-(const HpsdfVec3& o) const { return {T(v[0] - o.v[0]), T(v[1] - o.v[1]), T(v[2] - o.v[2])}; }
+    HpsdfVec3 operator*(T s) const { return {T(v[0] * s), T(v[1] * s), T(v[2] * s)}; }
+    T squaredNorm() const { return v[0] * v[0] + (v[1] * v[1] + v[2] * v[2]); }
+    T norm() const { return std::sqrt(squaredNorm()); }
+};
+typedef HpsdfVec3<double> Vector3d;
+typedef HpsdfVec3<float> Vector3f;
+struct AlignedBox3f {
+    Vector3f lo, hi;
+    AlignedBox3f() : lo(FLT_MAX, FLT_MAX, FLT_MAX), hi(-FLT_MAX, -FLT_MAX, -FLT_MAX) {}
+    AlignedBox3f(const Vector3f& a, const Vector3f& b) : lo(a), hi(b) {}
+    Vector3f& min() { return lo; }
+    Vector3f& max() { return hi; }
+    const Vector3f& min() const { return lo; }
+    const Vector3f& max() const { return hi; }
+    Vector3f sizes() const { return hi - lo; }
+    float volume() const { return (hi.x() - lo.x()) * (hi.y() - lo.y()) * (hi.z() - lo.z()); }
+};
+}  // namespace Eigen
+#include <cmath>
+#endif
+
+struct MemoryBlock {  // Include/Utility/MemoryBlock.h:5-9 (global namespace there too)
+    usize size;
+    void* ptr;
+};
+
+namespace SDF {
+
+constexpr usize BASIS_MAX_DEGREE = HPSDF_BASIS_MAX_DEGREE;
+constexpr usize TREE_MAX_DEPTH = HPSDF_TREE_MAX_DEPTH;
+
+struct Error : std::runtime_error {
+    int status;
+    Error(int s, const std::string& m) : std::runtime_error(m), status(s) {}
+};
+inline void check(int rc) {
+    if (rc != HPSDF_OK) throw Error(rc, hpsdf_last_error());
+}
+
+// Same fields, names and defaults as the reference Config; converts to the 80-byte POD.
+struct Config {
+    struct NearnessWeighting {
+        enum Type : u8 { None = 0, Polynomial = 1, Exponential = 2 } type;
+        f64 strength;
+    } nearnessWeighting;
+    struct Continuity {
+        bool enforce;
+        f64 strength;
+    } continuity;
+    bool enableLogging;
+    f64 targetErrorThreshold;
+    u32 threadCount;
+    Eigen::AlignedBox3f root;
+
+    Config() {  // Source/HP/Config.cpp:5-14
+        hpsdf_config d;
+        hpsdf_config_default(&d);
+        fromPod(d);
+    }
+    void IsValid() const {  // Source/HP/Config.cpp:17-32 (asserts there)
+        if (!(targetErrorThreshold > 0.0)) throw Error(HPSDF_ERR_INVALID_ARGUMENT, "targetErrorThreshold must be > 0");
+        if (threadCount == 0) throw Error(HPSDF_ERR_INVALID_ARGUMENT, "threadCount must be > 0");
+        if (!(root.volume() > 0.0f)) throw Error(HPSDF_ERR_INVALID_ARGUMENT, "root volume must be > 0");
+        if (nearnessWeighting.type != NearnessWeighting::None && !(nearnessWeighting.strength > 0.0))
+            throw Error(HPSDF_ERR_INVALID_ARGUMENT, "nearnessWeighting.strength must be > 0");
+        if (continuity.enforce && !(continuity.strength > 0.0))
+            throw Error(HPSDF_ERR_INVALID_ARGUMENT, "continuity.strength must be > 0");
+    }
+    hpsdf_config toPod() const {
+        hpsdf_config d;
+        std::memset(&d, 0, sizeof d);
+        d.weighting_type = (uint8_t)nearnessWeighting.type;
+        d.weighting_strength = nearnessWeighting.strength;
+        d.continuity_enforce = continuity.enforce ? 1 : 0;
+        d.continuity_strength = continuity.strength;
+        d.enable_logging = enableLogging ? 1 : 0;
+        d.target_error_threshold = targetErrorThreshold;
+        d.thread_count = threadCount;
+        for (int a = 0; a < 3; ++a) {
+            d.root_min[a] = root.min()(a);
+            d.root_max[a] = root.max()(a);
+        }
+        return d;
+    }
+    void fromPod(const hpsdf_config& d) {
+        nearnessWeighting.type = (NearnessWeighting::Type)d.weighting_type;
+        nearnessWeighting.strength = d.weighting_strength;
+        continuity.enforce = d.continuity_enforce != 0;
+        continuity.strength = d.continuity_strength;
+        enableLogging = d.enable_logging != 0;
+        targetErrorThreshold = d.target_error_threshold;
+        threadCount = (u32)d.thread_count;
+        root = Eigen::AlignedBox3f(Eigen::Vector3f(d.root_min[0], d.root_min[1], d.root_min[2]),
+                                   Eigen::Vector3f(d.root_max[0], d.root_max[1], d.root_max[2]));
+    }
+};
+
+// A field the GPU evaluates itself (no host callback in the loop).
+class DeviceField {
+   public:
+    DeviceField() = default;
+    DeviceField(const DeviceField&) = delete;
+    DeviceField& operator=(const DeviceField&) = delete;
+    DeviceField(DeviceField&& o) noexcept : f_(o.f_) { o.f_ = nullptr; }
+    ~DeviceField() { hpsdf_field_destroy(f_); }
+    static DeviceField Analytic(const std::vector<hpsdf_prim>& prims) {
+        DeviceField d;
+        check(hpsdf_field_create_analytic(prims.data(), (int)prims.size(), &d.f_));
+        return d;
+    }
+    static DeviceField Sphere(double cx, double cy, double cz, double r) {
+        hpsdf_prim p;
+        std::memset(&p, 0, sizeof p);
+        p.kind = HPSDF_PRIM_SPHERE;
+        p.p[0] = cx, p.p[1] = cy, p.p[2] = cz, p.p[3] = r;
+        return Analytic({p});
+    }
+    const hpsdf_field* handle() const { return f_; }
+
+   private:
+    friend class Octree;
+    hpsdf_field* f_ = nullptr;
+};
+
+class Octree {
+   public:
+    typedef std::function<f64(const Eigen::Vector3d& pt_, const u32 threadIdx_)> Func;
+
+    Octree() = default;
+    ~Octree() { release(); }
+
+    Octree(const Octree& o) { copyFrom(o); }  // deep copy, Octree.cpp:24-45
+    Octree& operator=(const Octree& o) {
+        if (this != &o) {
+            release();
+            copyFrom(o);
+        }
+        return *this;
+    }
+    Octree(Octree&& o) noexcept { steal(o); }  // Octree.cpp:76-86
+    Octree& operator=(Octree&& o) noexcept {
+        if (this != &o) {
+            release();
+            steal(o);
+        }
+        return *this;
+    }
+
+    /// Which GPU / stream later calls use (default: device 0, library-owned stream).
+    void SetDevice(int device, void* hipStream = nullptr) {
+        if (ctx_) {
+            dropTree();
+            hpsdf_ctx_destroy(ctx_);
+            ctx_ = nullptr;
+        }
+        device_ = device;
+        stream_ = hipStream;
+    }
+    /// Jobs per round of the canonical schedule (K); part of the result's definition.
+    void SetJobsPerRound(uint64_t k) { jobsPerRound_ = k; }
+
+    /// Approximates F_ using the parameters in config_   (Octree.h:50)
+    void Create(const Config& config_, Func F_) {
+        hpsdf_field* f = nullptr;
+        Func fn = std::move(F_);
+        check(hpsdf_field_create_callback(&Octree::trampoline, &fn, &f));
+        FieldGuard g{f};
+        createFrom(config_, f);
+    }
+    /// Same, with a field evaluated on the GPU.
+    void Create(const Config& config_, const DeviceField& F_) { createFrom(config_, F_.f_); }
+
+    /// Resultant SDF = Min(oldF, F_)   (Octree.h:53, Octree.cpp:355-374)
+    void UnionSDF(Func F_) { csg(HPSDF_OP_UNION, std::move(F_)); }
+    /// Resultant SDF = Max(-oldF, F_)  (Octree.h:56, Octree.cpp:377-387)
+    void SubtractSDF(Func F_) { csg(HPSDF_OP_SUBTRACT, std::move(F_)); }
+    /// Resultant SDF = Max(oldF, F_)   (Octree.h:59, Octree.cpp:390-400)
+    void IntersectSDF(Func F_) { csg(HPSDF_OP_INTERSECT, std::move(F_)); }
+    void UnionSDF(const DeviceField& F_) { csg(HPSDF_OP_UNION, F_.f_); }
+    void SubtractSDF(const DeviceField& F_) { csg(HPSDF_OP_SUBTRACT, F_.f_); }
+    void IntersectSDF(const DeviceField& F_) { csg(HPSDF_OP_INTERSECT, F_.f_); }
+
+    /// Resets the tree   (Octree.h:62)
+    void Clear() {
+        dropTree();
+        std::free(block_);
+        block_ = nullptr;
+        size_ = 0;
+    }
+
+    /// Creates an octree from a previously serialised version; the block stays the caller's   (Octree.h:65)
+    void FromMemoryBlock(MemoryBlock octBlock_) {
+        if (!octBlock_.size || !octBlock_.ptr) throw Error(HPSDF_ERR_BAD_BLOCK, "empty MemoryBlock");
+        Clear();
+        block_ = std::malloc(octBlock_.size);
+        if (!block_) throw Error(HPSDF_ERR_OUT_OF_MEMORY, "malloc failed");
+        std::memcpy(block_, octBlock_.ptr, octBlock_.size);
+        size_ = octBlock_.size;
+        readConfig();
+        uploadTree();
+    }
+
+    /// Serialises an octree to a memory block owned by malloc (caller frees)   (Octree.h:68)
+    MemoryBlock ToMemoryBlock() const {
+        MemoryBlock b = {0, nullptr};
+        if (!block_) return b;
+        b.ptr = std::malloc(size_);
+        if (!b.ptr) throw Error(HPSDF_ERR_OUT_OF_MEMORY, "malloc failed");
+        std::memcpy(b.ptr, block_, size_);
+        b.size = size_;
+        return b;
+    }
+
+    /// Returns the approximated distance from F = 0; DBL_MAX outside the root   (Octree.h:71)
+    f64 Query(const Eigen::Vector3d& pt_) const {
+        const double xyz[3] = {pt_(0), pt_(1), pt_(2)};
+        double out = 0.0;
+        Query(xyz, 1, &out);
+        return out;
+    }
+    /// Batched Query over host arrays (xyz interleaved)
+    void Query(const double* xyz, usize n, double* out) const {
+        if (!tree_) throw Error(HPSDF_ERR_STATE, "Query on an empty octree");
+        check(hpsdf_query_host(ctx_, tree_, xyz, n, out));
+    }
+    /// Batched Query over device (HBM) arrays, asynchronous on the context stream
+    void QueryDevice(const double* d_xyz, usize n, double* d_out) const {
+        if (!tree_) throw Error(HPSDF_ERR_STATE, "Query on an empty octree");
+        check(hpsdf_query_device(ctx_, tree_, d_xyz, n, d_out));
+    }
+
+    /// Returns the aabb of the root node   (Octree.h:81)
+    Eigen::AlignedBox3f GetRootAABB() const { return config_.root; }
+
+    const hpsdf_build_stats& LastBuildStats() const { return stats_; }
+    const Config& GetConfig() const { return config_; }
+
+   private:
+    struct FieldGuard {
+        hpsdf_field* f;
+        ~FieldGuard() { hpsdf_field_destroy(f); }
+    };
+    static double trampoline(const double* pt, uint64_t threadIdx, void* user) {
+        const Func* fn = static_cast<const Func*>(user);
+        return (*fn)(Eigen::Vector3d(pt[0], pt[1], pt[2]), (u32)threadIdx);
+    }
+    void ensureCtx() const {
+        if (!ctx_) check(hpsdf_ctx_create(device_, stream_, &ctx_));
+    }
+    void dropTree() {
+        hpsdf_tree_destroy(tree_);
+        tree_ = nullptr;
+    }
+    void release() {
+        Clear();
+        hpsdf_ctx_destroy(ctx_);
+        ctx_ = nullptr;
+    }
+    void readConfig() {
+        hpsdf_config pod;
+        std::memcpy(&pod, (const uint8_t*)block_ + size_ - sizeof pod, sizeof pod);
+        config_.fromPod(pod);
+    }
+    void uploadTree() {
+        ensureCtx();
+        dropTree();
+        check(hpsdf_tree_upload(ctx_, block_, size_, &tree_));
+    }
+    void createFrom(const Config& config, const hpsdf_field* f) {
+        config.IsValid();
+        ensureCtx();
+        const hpsdf_config pod = config.toPod();
+        void* blk = nullptr;
+        size_t sz = 0;
+        check(hpsdf_create(ctx_, &pod, f, jobsPerRound_, &blk, &sz, &stats_));
+        Clear();  // Octree.cpp:315 (the old tree may have been the CSG operand until now)
+        block_ = blk;
+        size_ = sz;
+        config_ = config;
+        uploadTree();
+        // continuity.enforce: the reference's host-side Eigen CG post-process (Octree.cpp:341-344)
+        // is outside the GPU hot path and not applied here.
+    }
+    void csg(int op, const hpsdf_field* inner) {
+        if (!tree_) throw Error(HPSDF_ERR_STATE, "CSG on an empty octree");
+        hpsdf_field* f = nullptr;
+        check(hpsdf_field_create_tree_csg(tree_, op, inner, &f));
+        FieldGuard g{f};
+        createFrom(config_, f);  // Create(oldTree.config, ...), Octree.cpp:373
+    }
+    void csg(int op, Func F_) {
+        hpsdf_field* inner = nullptr;
+        Func fn = std::move(F_);
+        check(hpsdf_field_create_callback(&Octree::trampoline, &fn, &inner));
+        FieldGuard g{inner};
+        csg(op, inner);
+    }
+    void copyFrom(const Octree& o) {
+        device_ = o.device_;
+        stream_ = o.stream_;
+        jobsPerRound_ = o.jobsPerRound_;
+        config_ = o.config_;
+        stats_ = o.stats_;
+        if (o.block_) {
+            block_ = std::malloc(o.size_);
+            if (!block_) throw Error(HPSDF_ERR_OUT_OF_MEMORY, "malloc failed");
+            std::memcpy(block_, o.block_, o.size_);
+            size_ = o.size_;
+            uploadTree();
+        }
+    }
+    void steal(Octree& o) {
+        device_ = o.device_;
+        stream_ = o.stream_;
+        jobsPerRound_ = o.jobsPerRound_;
+        config_ = o.config_;
+        stats_ = o.stats_;
+        ctx_ = o.ctx_;
+        tree_ = o.tree_;
+        block_ = o.block_;
+        size_ = o.size_;
+        o.ctx_ = nullptr;
+        o.tree_ = nullptr;
+        o.block_ = nullptr;
+        o.size_ = 0;
+    }
+
+    int device_ = 0;
+    void* stream_ = nullptr;
+    uint64_t jobsPerRound_ = 0;
+    mutable hpsdf_ctx* ctx_ = nullptr;
+    hpsdf_tree* tree_ = nullptr;
+    void* block_ = nullptr;  // serialised tree: [nCoeffs][coeffs][nNodes][nodes][config]
+    size_t size_ = 0;
+    Config config_;
+    hpsdf_build_stats stats_{};
+};
+
+}  // namespace SDF
