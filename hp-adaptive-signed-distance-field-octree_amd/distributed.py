@@ -1,0 +1,99 @@
+"""Multi-GPU Create/Query: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+
+Create
+    The tree, the frontier heap and the field are replicated; every rank selects the same jobs and
+    computes only its cost-balanced slice of each round on its GPU.  Per round the ranks exchange
+    the 9 errors of every job (72 B/job) with ONE all-gather of max-slice-padded buffers -- the
+    coefficients stay in the arena of the rank that fitted them.  After the last round one
+    all-gather (variable sizes, padded) reassembles the serialised tree on every rank.  Every rank
+    applies identical headers in identical order, so the MemoryBlock is byte-identical for any
+    world size (tests/test_distributed_gloo.py, tests/test_gpu_create.py).
+
+Query
+    The tree is replicated (<= a few MB); points are split contiguously; no collective.
+
+The exchange runs on whatever device the process group lives on: HBM tensors for nccl, host tensors
+for gloo (CPU tests inject oracle-computed job results through ``compute=``; the product path
+always computes on the GPU).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import Build, JOB_HEADER_DOUBLES
+
+
+class _DevPtr:
+    """Wraps a raw HBM pointer for torch.as_tensor (no copy)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def _gather_padded(local, pad_to, group, world):
+    """all-gather of equal-size (padded) 1-D float64 tensors -> [world, pad_to] tensor."""
+    buf = torch.zeros(pad_to, dtype=torch.float64, device=local.device)
+    buf[: local.numel()] = local
+    out = torch.empty(world * pad_to, dtype=torch.float64, device=local.device)
+    dist.all_gather_into_tensor(out, buf, group=group)
+    return out.view(world, pad_to)
+
+
+def create_distributed(ctx, config, field, K=0, group=None, compute=None):
+    """Octree::Create sharded over the ranks of ``group``.  Returns (block bytes, stats) on every rank.
+
+    compute(build, jobs, first, count) -> (headers [count,9] ndarray) may replace the GPU leg
+    (test hook: it must also ``build.inject`` the coefficients of its jobs).
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    on_gpu = compute is None
+    dev = torch.device("cuda", ctx.device) if on_gpu else torch.device("cpu")
+    b = Build(config, K, rank, world)
+    while True:
+        n = b.select()
+        if n == 0:
+            break
+        first, count = b.slice()
+        if on_gpu:
+            b.compute(ctx, field)
+            ptr, nd = b.results_device()
+            ctx.synchronize()  # the fit kernel ran on the context stream; the collective runs on torch's
+            local = torch.as_tensor(_DevPtr(ptr, nd), device=dev) if nd else torch.empty(0, dtype=torch.float64, device=dev)
+        else:
+            local = torch.from_numpy(np.ascontiguousarray(compute(b, b.jobs(n), first, count), np.float64).reshape(-1))
+        if world == 1:
+            headers = local.cpu().numpy().reshape(n, JOB_HEADER_DOUBLES)
+        else:
+            pad = b.max_slice() * JOB_HEADER_DOUBLES
+            gathered = _gather_padded(local, pad, group, world).cpu().numpy()
+            headers = np.empty((n, JOB_HEADER_DOUBLES))
+            for r in range(world):
+                f, c = b.slice(r)
+                headers[f:f + c] = gathered[r, : c * JOB_HEADER_DOUBLES].reshape(c, JOB_HEADER_DOUBLES)
+        b.apply(headers)
+    _, counts = b.layout()
+    if on_gpu:
+        ptr, nd = b.pack_device(ctx)
+        ctx.synchronize()
+        mine = torch.as_tensor(_DevPtr(ptr, nd), device=dev) if nd else torch.empty(0, dtype=torch.float64, device=dev)
+    else:
+        mine = torch.from_numpy(b.pack_host(None, counts[rank]))
+    if world == 1:
+        packs = [mine.cpu().numpy()]
+    else:
+        g = _gather_padded(mine, max(1, max(counts)), group, world).cpu().numpy()
+        packs = [g[r, : counts[r]] for r in range(world)]
+    block = b.assemble(packs)
+    stats = b.stats()
+    b.close()
+    return block, stats
+
+
+def shard_points(n, rank, world):
+    """Contiguous split of n query points: rank r gets [lo, hi)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)

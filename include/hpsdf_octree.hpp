@@ -21,6 +21,7 @@
 #pragma once
 
 #include <cfloat>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -85,7 +86,6 @@ struct AlignedBox3f {
     float volume() const { return (hi.x() - lo.x()) * (hi.y() - lo.y()) * (hi.z() - lo.z()); }
 };
 }  // namespace Eigen
-#include <cmath>
 #endif
 
 struct MemoryBlock {  // Include/Utility/MemoryBlock.h:5-9 (global namespace there too)

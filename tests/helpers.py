@@ -1,0 +1,144 @@
+"""Shared test helpers: fields by name, point sets, synthetic blocks, meshes."""
+import hashlib
+
+import numpy as np
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def oracle_field(O, name):
+    if name == "sphere":
+        return O.sphere_field()
+    if name == "union3":
+        return O.union3_field()
+    if name == "sphere075":
+        return O.sphere_field((0.25, 0.0, 0.0), 0.75)
+    raise KeyError(name)
+
+
+def product_field(H, name):
+    if name == "sphere":
+        return H.Field.sphere()
+    if name == "union3":
+        return H.Field.union3()
+    if name == "sphere075":
+        return H.Field.sphere((0.25, 0.0, 0.0), 0.75)
+    raise KeyError(name)
+
+
+def query_points(O, root_min, root_max, n=10000):
+    """Same construction as tests/golden/make_golden.py."""
+    p = O.splitmix64_points(n)
+    lo, hi = np.array(root_min), np.array(root_max)
+    p = (p + 0.5) * (hi - lo) + lo
+    p[:64] = (p[:64] - lo) * 3.0 + lo - (hi - lo)
+    return p
+
+
+def edge_points(rng, n=4000):
+    """Points on cell mid-planes, root faces, corners, just outside, NaN -- the descent's edge cases."""
+    p = rng.uniform(-0.5, 0.5, (n, 3))
+    k = n // 8
+    grid = np.arange(-8, 9) / 16.0  # depth-4 mid-planes and faces
+    p[:k, 0] = rng.choice(grid, k)
+    p[k:2 * k, 1] = rng.choice(grid, k)
+    p[2 * k:3 * k] = rng.choice(grid, (k, 3))
+    p[3 * k:4 * k] = rng.choice([-0.5, 0.5], (k, 3))
+    p[4 * k:5 * k, 2] = 0.5 + 1e-9          # f32 cast rounds back onto the face: still inside
+    p[5 * k:6 * k, 0] = np.nextafter(np.float32(0.5), np.float32(1.0)).astype(np.float64)  # first f32 outside
+    p[6 * k:6 * k + 8] = np.nan
+    p[6 * k + 8:6 * k + 16] = np.inf
+    p[6 * k + 16:6 * k + 24, 1] = -0.5 - 1e-3
+    return p
+
+
+NCOEF = [1, 4, 10, 20, 35, 56, 83, 120, 165, 220, 286, 364, 455]
+
+
+def synthetic_block(rng, degrees, depth=1, root_min=(-0.5,) * 3, root_max=(0.5,) * 3):
+    """A hand-made MemoryBlock: root + 8 children; child i is a leaf of degree degrees[i]
+    (or, with depth=2, child 0 is split again into 8 leaves of degrees[0]).  Random coefficients."""
+    nodes = []
+
+    def node(child, bmin, bmax, start, degree, dep):
+        b = np.zeros(56, np.uint8)
+        b[0:8] = np.array([child], np.uint64).view(np.uint8)
+        b[8:32] = np.array(list(bmin) + list(bmax), np.float32).view(np.uint8)
+        b[32:40] = np.array([start], np.uint64).view(np.uint8)
+        b[40] = degree
+        b[48] = dep
+        return b
+
+    def corner(bmin, bmax, i):
+        lo, hi = list(bmin), list(bmax)
+        for d in range(3):
+            mid = (np.float32(bmax[d]) + np.float32(bmin[d])) * np.float32(0.5)
+            if (i >> d) & 1:
+                lo[d] = mid
+            else:
+                hi[d] = mid
+        return lo, hi
+
+    coeffs = []
+    leaf = np.uint64(0xFFFFFFFFFFFFFFFF)
+    rmin, rmax = [-0.5] * 3, [0.5] * 3
+    nodes.append(node(1, rmin, rmax, 0, 13, 0))
+    level1 = []
+    for i in range(8):
+        lo, hi = corner(rmin, rmax, i)
+        level1.append((lo, hi))
+    cur = 0
+    extra = []
+    for i, (lo, hi) in enumerate(level1):
+        if depth == 2 and i == 0:
+            nodes.append(node(9, lo, hi, 0, 13, 1))
+            for j in range(8):
+                l2, h2 = corner(lo, hi, j)
+                extra.append(node(leaf, l2, h2, cur, degrees[0], 2))
+                c = rng.standard_normal(NCOEF[degrees[0]])
+                coeffs.append(c)
+                cur += len(c)
+        else:
+            nodes.append(node(leaf, lo, hi, cur, degrees[i], 1))
+            c = rng.standard_normal(NCOEF[degrees[i]])
+            coeffs.append(c)
+            cur += len(c)
+    nodes += extra
+    coeffs = np.concatenate(coeffs)
+    cfg = np.zeros(80, np.uint8)
+    cfg[40:48] = np.array([1e-10], np.float64).view(np.uint8)
+    cfg[48:56] = np.array([1], np.uint64).view(np.uint8)
+    cfg[56:80] = np.array(list(root_min) + list(root_max), np.float32).view(np.uint8)
+    blk = (np.array([len(coeffs)], np.uint64).tobytes() + coeffs.tobytes() + np.array([len(nodes)], np.uint64).tobytes()
+           + np.concatenate(nodes).tobytes() + cfg.tobytes())
+    return blk
+
+
+def icosphere(level=1, radius=0.35, centre=(0.0, 0.0, 0.0)):
+    """Closed, consistently CCW (outward) triangle mesh: 20 * 4^level triangles."""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
+         (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6),
+         (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10),
+         (8, 6, 7), (9, 8, 1)]
+    v = [np.array(x, np.float64) / np.linalg.norm(x) for x in v]
+    for _ in range(level):
+        cache, nf = {}, []
+
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in cache:
+                m = v[a] + v[b]
+                v.append(m / np.linalg.norm(m))
+                cache[key] = len(v) - 1
+            return cache[key]
+
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    verts = (np.array(v) * radius + np.array(centre)).astype(np.float32)
+    return verts, np.array(f, np.uint64)

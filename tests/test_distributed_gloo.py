@@ -1,0 +1,63 @@
+"""N > 1 path on CPU: two processes, torch.distributed gloo, the product's own exchange code
+(hp-adaptive-..._amd/distributed.py) and scheduler; the GPU leg of each round is replaced by the
+oracle through the compute= test hook.  Every rank must end with the oracle's exact MemoryBlock."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+from conftest import ROOT
+
+WORKER = r'''
+import hashlib, json, os, sys
+import numpy as np
+ROOT = sys.argv[1]; case = json.loads(sys.argv[2]); out = sys.argv[3]
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch, torch.distributed as dist
+import hpsdf_loader, oracle as O
+from helpers import oracle_field
+H = hpsdf_loader.load()
+import importlib
+D = importlib.import_module("hpsdf_amd.distributed")
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+f = oracle_field(O, case["field"])
+ocfg = O.default_config(case["target"], case["root_min"], case["root_max"])
+cfg = H.make_config(case["target"], case["root_min"], case["root_max"])
+def compute(b, jobs, first, count):
+    hdr = np.zeros((count, 9))
+    for j in range(first, first + count):
+        jb = jobs[j]
+        res, pc, hc = O.job(f, ocfg, tuple(jb.aabb_min), tuple(jb.aabb_max), jb.depth, jb.degree, jb.err,
+                            None if jb.coarse else np.zeros(O.NCOEF[jb.degree]))
+        hdr[j - first, 0] = res.p_err; hdr[j - first, 1:] = list(res.h_err)
+        b.inject(j, pc, hc.reshape(-1))
+    return hdr
+block, stats = D.create_distributed(None, cfg, None, case["K"], compute=compute)
+lo, hi = D.shard_points(1000, rank, world)
+json.dump({"sha": hashlib.sha256(block).hexdigest(), "stats": stats, "shard": [lo, hi]}, open(out + ".%d" % rank, "w"))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("case", ["C1_sphere_1e-4", "A2_sphere_1e-8_K1024"])
+def test_world2_gloo_block_identical(golden, case, O, H):
+    g = golden["blocks"][case]
+    with tempfile.TemporaryDirectory() as td:
+        wpath = os.path.join(td, "worker.py")
+        open(wpath, "w").write(WORKER)
+        out = os.path.join(td, "res")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+               "127.0.0.1", "--master-port", "29517", wpath, ROOT, json.dumps(g), out]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        res = [json.load(open(out + ".%d" % k)) for k in range(2)]
+    for k in range(2):
+        assert res[k]["sha"] == g["block_sha256"]
+        assert res[k]["stats"]["n_nodes"] == g["n_nodes"] and res[k]["stats"]["jobs"] == g["stats"]["jobs"]
+    assert res[0]["shard"] == [0, 500] and res[1]["shard"] == [500, 1000]

@@ -1,0 +1,84 @@
+"""Pins the oracle's FitPolynomial / job estimates against the known-answer values SURVEY.md
+records from the reference's own Octree::FitPolynomial (Octree.cpp:1007-1093)."""
+import numpy as np
+import pytest
+
+
+def rel(a, b):
+    return abs(a - b) / abs(b)
+
+
+@pytest.mark.parametrize("p", [2, 3, 4, 5, 6, 7])
+def test_fit_scratch_kat(O, golden, p):
+    k = golden["kats"]
+    cell = k["fit_cell"]
+    cfg = O.default_config(1e-4)
+    co, err = O.fit_polynomial(O.sphere_field(), cfg, cell["min"], cell["max"], p, cell["depth"])
+    want = k["fit_scratch"][str(p)]
+    assert len(co) == want["ncoef"]
+    # SURVEY prints 11 / 13 significant digits
+    assert rel(err, want["error"]) < 5e-11
+    assert rel(co[0], want["c0"]) < 5e-13
+    assert rel(co[-1], want["clast"]) < 5e-12
+
+
+@pytest.mark.parametrize("p", [2, 3, 4, 5, 6])
+def test_fit_incremental_kat(O, golden, p):
+    cell = golden["kats"]["fit_cell"]
+    cfg = O.default_config(1e-4)
+    f = O.sphere_field()
+    c_lo, _ = O.fit_polynomial(f, cfg, cell["min"], cell["max"], p, cell["depth"])
+    c_hi, err = O.fit_polynomial(f, cfg, cell["min"], cell["max"], p + 1, cell["depth"], coeffs_in=c_lo, basis_degree=p)
+    assert rel(err, golden["kats"]["fit_incremental_error"]["%d->%d" % (p, p + 1)]) < 5e-7
+    assert np.array_equal(c_hi[:len(c_lo)], c_lo)  # old rows untouched (Octree.cpp:1012,1025)
+    # the new rows come from the (4p+5)-point grid alone, i.e. they equal a from-scratch fit's rows
+    c_s, _ = O.fit_polynomial(f, cfg, cell["min"], cell["max"], p + 1, cell["depth"])
+    assert np.array_equal(c_hi[len(c_lo):], c_s[len(c_lo):])
+
+
+@pytest.mark.parametrize("p", [1, 2, 3, 4])
+def test_literal_inner_loop_equals_cached_tables(O, p):
+    """The reference re-runs LpX per (sample, coefficient, axis); caching its values changes nothing."""
+    cfg = O.default_config(1e-4, (-0.25, -0.25, -0.25), (5.0, 5.0, 5.0))
+    f = O.union3_field()
+    a, ea = O.fit_polynomial(f, cfg, (0.0, -0.25, 0.125), (0.125, -0.125, 0.25), p, 3, literal=True)
+    b, eb = O.fit_polynomial(f, cfg, (0.0, -0.25, 0.125), (0.125, -0.125, 0.25), p, 3, literal=False)
+    assert np.array_equal(a, b) and ea == eb
+
+
+def test_polynomial_field_is_reproduced_exactly(O):
+    """A plane is degree 1: the degree-2 fit must reproduce it to rounding and report ~0 error."""
+    f = O.AnalyticField([(O.PRIM_PLANE, O.OP_UNION, [0.3, -0.2, 0.5, 0.1])])
+    cfg = O.default_config(1e-4)
+    bmin, bmax = (0.0, 0.0, -0.25), (0.25, 0.25, 0.0)
+    co, err = O.fit_polynomial(f, cfg, bmin, bmax, 2, 2)
+    assert err < 1e-30
+    pts = np.random.default_rng(1).uniform(0, 1, (50, 3)) * 0.25 + np.array(bmin)
+    L = O.lib()
+    import ctypes as C
+    for p in pts:
+        v = L.ora_fapprox(co.ctypes.data_as(C.POINTER(C.c_double)), 2, (C.c_float * 3)(*bmin), (C.c_float * 3)(*bmax),
+                          p.ctypes.data_as(C.POINTER(C.c_double)), 2)
+        assert abs(v - f.eval(p[None])[0]) < 1e-14
+
+
+def test_job_decision_rules(O):
+    cfg = O.default_config(1e-8)
+    f = O.sphere_field()
+    bmin, bmax = (0.1875, -0.0625, 0.0), (0.25, 0.0, 0.0625)
+    # coarse job: H skipped, P = degree-2 fit, always P-refines (Octree.cpp:806-810, 836-843)
+    r, pc, hc = O.job(f, cfg, bmin, bmax, 4, 0, 100.0, None)
+    assert r.coarse and r.refine_p and not r.refine_h and r.h_imp == 0.0 and r.p_imp == r.p_err
+    assert abs(r.p_err / 4.1877641798e-09 - 1) < 1e-10
+    # regular job at p=2: eq. (8)/(9)
+    c2, e2 = O.fit_polynomial(f, cfg, bmin, bmax, 2, 4)
+    r, pc, hc = O.job(f, cfg, bmin, bmax, 4, 2, e2, c2)
+    assert r.h_imp == (1.0 / (7.0 * 10)) * (e2 - 8.0 * max(r.h_err))
+    assert r.p_imp == (1.0 / 10.0) * (e2 - 8.0 * r.p_err)
+    assert r.refine_p == (r.p_imp > r.h_imp) and r.refine_h == (not r.refine_p)
+    assert np.array_equal(pc[:10], c2)
+    # depth 10: never H; degree 11: never P (Octree.cpp:600-601)
+    r, _, _ = O.job(f, cfg, (0.0, 0.0, 0.0), (2.0 ** -10,) * 3, 10, 2, 1e-20, np.zeros(10))
+    assert r.refine_p and not r.refine_h
+    r, _, _ = O.job(f, cfg, (0.0, 0.0, 0.0), (0.25,) * 3, 2, 11, 1e-3, np.zeros(364))
+    assert not r.refine_p and r.refine_h

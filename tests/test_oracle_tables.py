@@ -1,0 +1,56 @@
+"""Pins the oracle's constant tables: against the reference's own headers (compiled where they lie,
+oracle/_ref) when the checkout is present, and against the committed hashes of those tables always."""
+import numpy as np
+import pytest
+
+from conftest import bits
+from helpers import sha
+
+NAMES = ("roots", "weights", "normalised_lengths", "recurrence", "coeff_count", "basis_index", "sum_to_n")
+
+
+def test_oracle_tables_match_reference_headers_bitwise(O):
+    ref = O.ref_tables()
+    if ref is None:
+        pytest.skip("oracle/_ref not built (reference checkout absent); hashes are checked instead")
+    t = O.tables()
+    for k in NAMES:
+        assert np.array_equal(bits(t[k]), bits(ref[k])), k
+
+
+def test_oracle_tables_match_committed_reference_hashes(O, golden):
+    t = O.tables()
+    for k in NAMES:
+        assert sha(t[k]) == golden["tables"][k]["sha256"], k
+
+
+def test_known_quirks(O, golden):
+    t = O.tables()
+    # Include/HP/Utility.h:87-106: the f64 evaluation truncates 84 to 83 for degree 6
+    assert [int(x) for x in t["coeff_count"]] == [1, 4, 10, 20, 35, 56, 83, 120, 165, 220, 286, 364, 455]
+    assert t["basis_index"][82:86].astype(int).tolist() == [[5, 1, 0], [6, 0, 0], [0, 0, 7], [0, 1, 6]]
+    assert t["basis_index"][:12].astype(int).tolist() == [[0, 0, 0], [0, 0, 1], [0, 1, 0], [1, 0, 0], [0, 0, 2], [0, 1, 1],
+                                                          [0, 2, 0], [1, 0, 1], [1, 1, 0], [2, 0, 0], [0, 0, 3], [0, 1, 2]]
+    # Legendre.h stores the 9-point rule's pairs as 3rd,4th,1st,2nd smallest |x|
+    a = np.abs(t["roots"][36:45])
+    assert a[0] == 0 and a[1] == a[2] and a[1] > a[5] and a[3] > a[1] and a[5] < a[7]
+    assert np.allclose(a, golden["tables"]["spot"]["gl9_abs_order"], rtol=0, atol=0)
+
+
+def test_gauss_legendre_rules_integrate(O):
+    t = O.tables()
+    for n in range(1, 65):
+        s = n * (n - 1) // 2
+        x, w = t["roots"][s:s + n], t["weights"][s:s + n]
+        assert abs(w.sum() - 2.0) < 1e-14
+        assert abs((w * x * x).sum() - (2.0 / 3.0 if n > 1 else 0.0)) < 1e-14
+        assert np.array_equal(np.sort(np.abs(x[n % 2:]))[::2], np.sort(np.abs(x[n % 2:]))[1::2])  # exact +- pairs
+
+
+def test_normalised_lengths_values(O):
+    nl = O.tables()["normalised_lengths"]
+    for i in range(13):
+        for j in range(11):
+            # Utility.h:25-35 is a 100-step Newton iteration, not a correctly rounded sqrt: some entries sit
+            # 1 ulp off (e.g. [4][1]); the bit-exact pin is the reference-hash test above
+            assert abs(nl[i, j] - np.sqrt((2 * i + 1) * 2.0 ** j)) <= 4.5e-16 * nl[i, j]
