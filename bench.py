@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Headline benchmark: BASELINE.json config[1] -- union of sphere/box/torus, targetError = 1e-5,
+Create() on the GPU(s) and Query() over 10 M SplitMix64(12345) points per GPU, resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one batched Query() pass over this rank's 10 M points (the data-parallel leg of the
+metric; weak scaling: every rank queries its own 10 M points against the replicated tree, no
+collective).  Create() -- sharded over the ranks with one RCCL all-gather per round -- is timed in the
+same run and reported as create_ms next to it.  Rank 0 prints ONE JSON line.
+
+roofline: the dominant kernel is query_kernel, HBM-bound, 32 algorithmic bytes per point
+(24 in + 8 out); its average launch duration is measured live with events on the
+stream it is launched on.  cpu_baseline: the CPU oracle ("port", one core) on the same points,
+rank 0 at N = 1 only.  The oracle is the checker and the baseline here, never the measured path.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_PEAK_TFLOPS = 78.6  # MI355X datasheet, vector = matrix FP64
+N_POINTS = 10_000_000
+TARGET = 1e-5
+JOBS_PER_ROUND = 1024
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=N_POINTS, help="query points per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fit-bench", action="store_true", help="also run the steady-state fit micro-benchmark")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("--gpus %d needs the torch.distributed.run launcher (one process per GPU)" % args.gpus)
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import hpsdf_loader
+    H = hpsdf_loader.load()
+    import importlib
+    D = importlib.import_module("hpsdf_amd.distributed")
+    import oracle as O  # point generator + baseline only
+
+    stream = torch.cuda.Stream()  # the kernels launch on this stream; torch events on it time them
+    with torch.cuda.stream(stream):
+        ctx = H.Context(local, stream.cuda_stream)
+        cfg = H.make_config(TARGET)
+        field = H.Field.union3()
+
+        # ---------------- Create(): sharded over the ranks, timed over a few repetitions
+        def create():
+            return D.create_distributed(ctx, cfg, field, JOBS_PER_ROUND) if world > 1 else \
+                H.create_block(ctx, cfg, field, JOBS_PER_ROUND)
+
+        block, stats = create()  # warm-up (also first hipMalloc of the arena)
+        create_times = []
+        for _ in range(5):
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            block, stats = create()
+            torch.cuda.synchronize()
+            create_times.append((time.perf_counter() - t0) * 1e3)
+        create_ms = float(np.median(create_times))
+        if world > 1:
+            t = torch.tensor([create_ms], device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            create_ms = float(t.item())
+
+        # ---------------- Query(): this rank's points, resident in HBM
+        n = args.points
+        pts = O.splitmix64_points(n, seed=12345 + rank)
+        d_xyz = torch.from_numpy(pts).cuda()
+        d_out = torch.empty(n, dtype=torch.float64, device="cuda")
+        tree = H.DeviceTree(ctx, block)
+        torch.cuda.synchronize()
+
+        def step():
+            tree.query_device(d_xyz.data_ptr(), n, d_out.data_ptr())
+
+        for _ in range(args.warmup):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(stream)
+        for _ in range(args.steps):
+            step()
+        e1.record(stream)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        kernel_ms = e0.elapsed_time(e1) / args.steps  # average launch duration of query_kernel
+        if world > 1:
+            t = torch.tensor([wall], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall = float(t.item())
+
+        # sanity: the timed output is the real answer (spot parity against the oracle on rank 0)
+        got = d_out[:: max(1, n // 2000)].cpu().numpy()
+
+        fit = None
+        if args.fit_bench and rank == 0:
+            fit = {}
+            for p in (2, 3, 4, 5):
+                cells = 65536 if p <= 3 else 16384
+                ms = H.bench_fit(ctx, cfg, field, p, 5, cells, 3)
+                flops = 2.0 * H.NCOEF[p] * (4 * p + 1) ** 3 * cells
+                fit["p%d" % p] = {"cells": cells, "ms": ms, "tflops_algorithmic": flops / ms / 1e9,
+                                  "frac_fp64_peak": flops / ms / 1e9 / FP64_PEAK_TFLOPS}
+
+    ms_per_step = wall * 1e3 / args.steps
+    value = world * n * args.steps / wall / 1e6  # Mpts/s, whole job
+    achieved = 32.0 * n / (kernel_ms * 1e-3) / 1e9  # GB/s, algorithmic bytes / launch duration
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    otree = O.Tree.from_block(block)
+    want = otree.query(pts[:: max(1, n // 2000)])
+    assert np.array_equal(got, want), "timed Query output differs from the oracle"
+
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "query_pmc.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "Query() Mpts/sec at targetError=1e-5 (union3 field, 10M SplitMix64 pts per GPU, HBM-resident); "
+                  "Create() ms reported as create_ms",
+        "value": value, "unit": "Mpts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: union(sphere,box,torus) analytic SDF, targetError=1e-5, "
+                               "continuity off, %d random Query() points per GPU" % n,
+                   "jobs_per_round": JOBS_PER_ROUND, "points_per_gpu": n, "sharding": "replicated tree, points split"},
+        "create_ms": create_ms,
+        "create": {"nodes": stats["n_nodes"], "leaves": stats["n_leaves"], "coeffs": stats["n_coeffs"],
+                   "rounds": stats["rounds"], "jobs": stats["jobs"], "fits": stats["fits"], "samples": stats["samples"],
+                   "block_bytes": len(block), "ms_all": create_times},
+        "roofline": {"kernel": "query_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": 32 * n,
+                     "avg_launch_ms": kernel_ms},
+    }
+    if fit:
+        out["fit_microbench"] = fit
+    if world == 1 and not args.no_cpu_baseline:
+        # bounded sample: the oracle's Query over the first 5 M points, once; Create once (cached tables)
+        m = min(n, 5_000_000)
+        t0 = time.perf_counter()
+        otree.query(pts[:m])
+        tq = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        O.Tree.create(O.default_config(TARGET), O.union3_field(), JOBS_PER_ROUND)
+        tc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": m / tq / 1e6, "unit": "Mpts/s", "cores": 1, "kind": "port",
+                               "sample": "oracle Query() over the first %d of the same points, one pass; "
+                                         "oracle Create() of the same config once" % m,
+                               "create_ms": tc * 1e3, "host_cpus": os.cpu_count()}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
