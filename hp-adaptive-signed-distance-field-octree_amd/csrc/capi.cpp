@@ -375,8 +375,10 @@ int hpsdf_tree_upload(hpsdf_ctx* ctx, const void* block, size_t size, hpsdf_tree
         if (nodes[0].aabb_min[a] != -0.5f || nodes[0].aabb_max[a] != 0.5f)
             return fail(HPSDF_ERR_UNSUPPORTED, "internal root box must be [-0.5,0.5]^3 (Octree.cpp:798)");
     std::vector<uint64_t> stack{0};
+    std::vector<double> padded;
+    padded.reserve(nCoeffs + nNodes);
     uint64_t leaves = 0;
-    int maxDeg = 0, maxDepth = 0;
+    int maxDeg = 0, maxDepth = 0, minLeafDepth = kMaxDepth + 1;
     std::vector<uint8_t> depthOf(nNodes, 0);
     while (!stack.empty()) {
         const uint64_t i = stack.back();
@@ -401,11 +403,29 @@ int hpsdf_tree_upload(hpsdf_ctx* ctx, const void* block, size_t size, hpsdf_tree
             if (n.degree > kMaxDegree) return fail(HPSDF_ERR_BAD_BLOCK, "leaf degree out of range");
             if (n.coeffs_start + T.coeffCount[n.degree] > nCoeffs) return fail(HPSDF_ERR_BAD_BLOCK, "leaf coefficients out of range");
             if (n.depth != depthOf[i]) return fail(HPSDF_ERR_BAD_BLOCK, "stored depth does not match tree depth");
-            recs[i] = NodeRec{(uint32_t)n.coeffs_start, (uint32_t)n.degree};
+            // device mirror: every leaf's block starts on a 16-byte boundary
+            recs[i] = NodeRec{(uint32_t)padded.size(), (uint32_t)n.degree};
+            padded.insert(padded.end(), coeffs + n.coeffs_start, coeffs + n.coeffs_start + T.coeffCount[n.degree]);
+            if (padded.size() & 1) padded.push_back(0.0);
             ++leaves;
             maxDeg = std::max(maxDeg, (int)n.degree);
             maxDepth = std::max(maxDepth, (int)depthOf[i]);
+            minLeafDepth = std::min(minLeafDepth, (int)depthOf[i]);
         }
+    }
+    if (padded.size() > 0xFFFFFFF0ull) return fail(HPSDF_ERR_UNSUPPORTED, "more than 2^32 coefficients");
+    // dense table of the deepest complete level (<= 5): table[path] = node reached by that octant path
+    const int topDepth = std::max(1, std::min(5, minLeafDepth));
+    std::vector<TopEntry> top((size_t)1 << (3 * topDepth));
+    for (size_t code = 0; code < top.size(); ++code) {
+        uint64_t cur = 0;
+        for (int l = topDepth - 1; l >= 0; --l) cur = nodes[cur].child_idx + ((code >> (3 * l)) & 7u);
+        TopEntry& te = top[code];
+        std::memset(&te, 0, sizeof te);
+        te.a = recs[cur].a;
+        te.b = recs[cur].b;
+        if (te.b <= 2u)  // small leaf: coefficients ride in the same line
+            std::memcpy(te.c, coeffs + nodes[cur].coeffs_start, sizeof(double) * T.coeffCount[te.b]);
     }
     HPSDF_HIP(hipSetDevice(ctx->device));
     hpsdf_tree* t = new hpsdf_tree();
@@ -417,15 +437,21 @@ int hpsdf_tree_upload(hpsdf_ctx* ctx, const void* block, size_t size, hpsdf_tree
     t->maxDepth = maxDepth;
     t->config = cfg;
     hipError_t e = hipMalloc((void**)&t->dNodes, nNodes * sizeof(NodeRec));
-    if (e == hipSuccess) e = hipMalloc((void**)&t->dCoeffs, std::max<uint64_t>(1, nCoeffs) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&t->dCoeffs, std::max<size_t>(2, padded.size()) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&t->dTop, top.size() * sizeof(TopEntry));
     if (e == hipSuccess) e = hipMemcpy(t->dNodes, recs.data(), nNodes * sizeof(NodeRec), hipMemcpyHostToDevice);
-    if (e == hipSuccess && nCoeffs) e = hipMemcpy(t->dCoeffs, coeffs, nCoeffs * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(t->dTop, top.data(), top.size() * sizeof(TopEntry), hipMemcpyHostToDevice);
+    if (e == hipSuccess && !padded.empty())
+        e = hipMemcpy(t->dCoeffs, padded.data(), padded.size() * sizeof(double), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         hpsdf_tree_destroy(t);
         return hipFail(e, "tree upload");
     }
     t->dev.nodes = t->dNodes;
+    t->dev.top = t->dTop;
     t->dev.coeffs = t->dCoeffs;
+    t->dev.topDepth = topDepth;
+    t->dev.maxDegree = maxDeg;
     for (int a = 0; a < 3; ++a) {
         t->dev.rootCentre[a] = (double)((cfg.root_min[a] + cfg.root_max[a]) / 2.0f);  // Octree.cpp:419
         t->dev.rootInvSizes[a] = (double)(1.0f / (cfg.root_max[a] - cfg.root_min[a]));  // Octree.cpp:420
@@ -439,6 +465,7 @@ int hpsdf_tree_destroy(hpsdf_tree* t) {
     if (!t) return HPSDF_OK;
     (void)hipSetDevice(t->device);
     if (t->dNodes) (void)hipFree(t->dNodes);
+    if (t->dTop) (void)hipFree(t->dTop);
     if (t->dCoeffs) (void)hipFree(t->dCoeffs);
     delete t;
     return HPSDF_OK;

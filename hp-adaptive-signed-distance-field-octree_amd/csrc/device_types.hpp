@@ -21,15 +21,27 @@ struct DeviceTables {
 // node (Include/HP/Node.h:10-33) is not needed on the device: cell boxes are
 // exact dyadics recomputed during the descent, the depth is the descent count.
 //   interior: a = index of first child, b = 0xFFFFFFFF
-//   leaf:     a = offset of its coefficients (doubles), b = degree
+//   leaf:     a = offset of its coefficients in the device mirror (doubles, even => 16-byte aligned), b = degree
 struct NodeRec {
     uint32_t a, b;
 };
 constexpr uint32_t kInteriorTag = 0xFFFFFFFFu;
 
+// Entry of the dense top-level table: one 128-byte line.  a/b as in NodeRec; a leaf of degree <= 2 also
+// carries its coefficients inline (c[0..9]); larger leaves and interior nodes go through nodes/coeffs.
+struct alignas(128) TopEntry {
+    uint32_t a, b;
+    uint32_t pad[2];
+    double c[14];
+};
+static_assert(sizeof(TopEntry) == 128, "one line per entry");
+
 struct TreeDev {
     const NodeRec* nodes;
-    const double* coeffs;
+    const TopEntry* top;     // dense table of the nodes at depth topDepth, indexed by the octant path
+    const double* coeffs;    // per-leaf blocks padded to an even count
+    int32_t topDepth;        // every node above this depth is interior (1..5)
+    int32_t maxDegree;
     double rootCentre[3];    // Octree.cpp:322 (f32 centre widened)
     double rootInvSizes[3];  // Octree.cpp:323 (f32 reciprocal widened)
 };

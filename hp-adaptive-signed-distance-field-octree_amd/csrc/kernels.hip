@@ -250,10 +250,13 @@ __host__ __device__ constexpr int coeffCount(int p) {
     return p == 6 ? 83 : (p + 1) * (p + 2) * (p + 3) / 6;
 }
 
-// sNl: [13][11] normalisation table, sRec: [13][2] recurrence constants (LDS)
-template <int P>
-__device__ __forceinline__ double evalLeafFixed(const double* __restrict__ c, double ux, double uy, double uz, int depth,
-                                                const double* sNl, const double* sRec) {
+// sNl: [13][11] normalisation table, sRec: [13][2] recurrence constants (LDS).  cv holds the leaf's
+// coefficients; values and summation order are those of Octree.cpp:888-898.
+template <int P, int NV>
+__device__ __forceinline__ double evalLeafVals(const double (&cv)[NV], double ux, double uy, double uz, int depth,
+                                               const double* sNl, const double* sRec) {
+    constexpr int N = coeffCount(P);
+    static_assert(NV >= N, "coefficient registers");
     double tx[P + 1], ty[P + 1], tz[P + 1];
     tx[0] = ty[0] = tz[0] = sNl[depth];
     double xm2 = 0.0, xm1 = 1.0, ym2 = 0.0, ym1 = 1.0, zm2 = 0.0, zm1 = 1.0;
@@ -268,13 +271,30 @@ __device__ __forceinline__ double evalLeafFixed(const double* __restrict__ c, do
     }
     double f = 0.0;
 #pragma unroll
-    for (int i = 0; i < coeffCount(P); ++i) {
+    for (int i = 0; i < N; ++i) {
         double lp = tx[kBasis.v[i][0]];
         lp = lp * ty[kBasis.v[i][1]];
         lp = lp * tz[kBasis.v[i][2]];
-        f = f + c[i] * lp;
+        f = f + cv[i] * lp;
     }
     return f;
+}
+
+// c is 16-byte aligned in the device mirror (hpsdf_tree_upload pads every leaf to an even count), so
+// the coefficients come in as double2.
+template <int P>
+__device__ __forceinline__ double evalLeafFixed(const double* __restrict__ c, double ux, double uy, double uz, int depth,
+                                                const double* sNl, const double* sRec) {
+    constexpr int N = coeffCount(P);
+    double cv[N + 1];
+    const double2* __restrict__ c2 = reinterpret_cast<const double2*>(c);
+#pragma unroll
+    for (int i = 0; i < (N + 1) / 2; ++i) {
+        const double2 v = c2[i];
+        cv[2 * i] = v.x;
+        cv[2 * i + 1] = v.y;
+    }
+    return evalLeafVals<P>(cv, ux, uy, uz, depth, sNl, sRec);
 }
 
 // any degree (tables in private memory, dynamically indexed)
@@ -302,20 +322,34 @@ __device__ __noinline__ double evalLeafGeneric(const double* __restrict__ c, int
     return f;
 }
 
+// MAXP: the largest leaf degree of the tree this instantiation serves (2, 3, 5 unrolled; 12 adds the
+// generic path).  A smaller MAXP keeps registers (and so latency-hiding waves) for the common trees.
+template <int MAXP>
 __device__ __forceinline__ double evalLeaf(const double* __restrict__ c, int degree, double ux, double uy, double uz,
                                            int depth, const double* sNl, const double* sRec) {
-    switch (degree) {
-        case 0: return evalLeafFixed<0>(c, ux, uy, uz, depth, sNl, sRec);
-        case 1: return evalLeafFixed<1>(c, ux, uy, uz, depth, sNl, sRec);
-        case 2: return evalLeafFixed<2>(c, ux, uy, uz, depth, sNl, sRec);
-        case 3: return evalLeafFixed<3>(c, ux, uy, uz, depth, sNl, sRec);
-        case 4: return evalLeafFixed<4>(c, ux, uy, uz, depth, sNl, sRec);
-        case 5: return evalLeafFixed<5>(c, ux, uy, uz, depth, sNl, sRec);
-        default: return evalLeafGeneric(c, degree, ux, uy, uz, depth, sNl, sRec);
+    if constexpr (MAXP <= 2) {
+        if (degree == 2) return evalLeafFixed<2>(c, ux, uy, uz, depth, sNl, sRec);
+        if (degree == 1) return evalLeafFixed<1>(c, ux, uy, uz, depth, sNl, sRec);
+        return evalLeafFixed<0>(c, ux, uy, uz, depth, sNl, sRec);
+    } else {
+        switch (degree) {
+            case 0: return evalLeafFixed<0>(c, ux, uy, uz, depth, sNl, sRec);
+            case 1: return evalLeafFixed<1>(c, ux, uy, uz, depth, sNl, sRec);
+            case 2: return evalLeafFixed<2>(c, ux, uy, uz, depth, sNl, sRec);
+            case 3: return evalLeafFixed<3>(c, ux, uy, uz, depth, sNl, sRec);
+            default:
+                if constexpr (MAXP >= 5) {
+                    if (degree == 4) return evalLeafFixed<4>(c, ux, uy, uz, depth, sNl, sRec);
+                    if (degree == 5) return evalLeafFixed<5>(c, ux, uy, uz, depth, sNl, sRec);
+                }
+                if constexpr (MAXP > 5) return evalLeafGeneric(c, degree, ux, uy, uz, depth, sNl, sRec);
+                return 0.0;
+        }
     }
 }
 
 // One point through the tree.  (x,y,z) in world coordinates.
+template <int MAXP>
 __device__ __forceinline__ double queryPoint(const TreeDev& t, double x, double y, double z, const double* sNl,
                                              const double* sRec) {
     // Octree.cpp:665
@@ -325,26 +359,56 @@ __device__ __forceinline__ double queryPoint(const TreeDev& t, double x, double 
     // :668 containment on the f32 cast, both ends inclusive; NaN fails
     const float fx = (float)px, fy = (float)py, fz = (float)pz;
     if (!(fx >= -0.5f && fx <= 0.5f && fy >= -0.5f && fy <= 0.5f && fz >= -0.5f && fz <= 0.5f)) return DBL_MAX;
-    // :674-701.  The mid-plane of a cell is its centre; centres are exact dyadics.
+    // :674-701.  The mid-plane of a cell is its centre; centres are exact dyadics.  The levels that are
+    // complete in this tree (topDepth of them; Octree::UniformlyRefine makes that 4) need no node reads:
+    // the same comparisons give the path, and one table lookup gives the node reached.
     double cx = 0.0, cy = 0.0, cz = 0.0, q = 0.25;
-    uint32_t child = t.nodes[0].a;
+    uint32_t code = 0;
     int depth = 0;
-    NodeRec rec;
-    for (;;) {
+    for (; depth < t.topDepth; ++depth) {
         const bool ux = px >= cx, uy = py >= cy, uz = pz >= cz;
-        const uint32_t idx = child + (ux ? 1u : 0u) + (uy ? 2u : 0u) + (uz ? 4u : 0u);
+        code = code * 8u + (ux ? 1u : 0u) + (uy ? 2u : 0u) + (uz ? 4u : 0u);
+        cx = ux ? cx + q : cx - q;
+        cy = uy ? cy + q : cy - q;
+        cz = uz ? cz + q : cz - q;
+        q = q * 0.5;
+    }
+    // One 128-byte line per top-level cell: the node record and, for a leaf of degree <= 2, its
+    // coefficients inline -- the common case costs a single L2 line per point.  The coefficient loads
+    // do not wait for the record (same line, issued together).
+    const TopEntry* __restrict__ e = t.top + code;
+    const uint2 hdr = *reinterpret_cast<const uint2*>(e);
+    double cv[10];
+    {
+        const double2* __restrict__ c2 = reinterpret_cast<const double2*>(e->c);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const double2 v = c2[i];
+            cv[2 * i] = v.x;
+            cv[2 * i + 1] = v.y;
+        }
+    }
+    NodeRec rec{hdr.x, hdr.y};
+    if (rec.b <= 2u) {  // leaf at the table level, coefficients already here
+        const double s = (double)(2 << depth);
+        const double ux = (px - cx) * s, uy = (py - cy) * s, uz = (pz - cz) * s;
+        if (rec.b == 2u) return evalLeafVals<2>(cv, ux, uy, uz, depth, sNl, sRec);
+        if (rec.b == 1u) return evalLeafVals<1>(cv, ux, uy, uz, depth, sNl, sRec);
+        return evalLeafVals<0>(cv, ux, uy, uz, depth, sNl, sRec);
+    }
+    while (rec.b == kInteriorTag) {
+        const bool ux = px >= cx, uy = py >= cy, uz = pz >= cz;
+        const uint32_t idx = rec.a + (ux ? 1u : 0u) + (uy ? 2u : 0u) + (uz ? 4u : 0u);
         cx = ux ? cx + q : cx - q;
         cy = uy ? cy + q : cy - q;
         cz = uz ? cz + q : cz - q;
         q = q * 0.5;
         ++depth;
         rec = t.nodes[idx];
-        if (rec.b != kInteriorTag) break;
-        child = rec.a;
     }
     // :862  unitPt = (pt - centre) * (2 << depth)
     const double s = (double)(2 << depth);
-    return evalLeaf(t.coeffs + rec.a, (int)rec.b, (px - cx) * s, (py - cy) * s, (pz - cz) * s, depth, sNl, sRec);
+    return evalLeaf<MAXP>(t.coeffs + rec.a, (int)rec.b, (px - cx) * s, (py - cy) * s, (pz - cz) * s, depth, sNl, sRec);
 }
 
 __device__ __forceinline__ void stageQueryTables(const DeviceTables* T, double* sNl, double* sRec) {
@@ -352,16 +416,96 @@ __device__ __forceinline__ void stageQueryTables(const DeviceTables* T, double* 
     for (int i = threadIdx.x; i < 26; i += blockDim.x) sRec[i] = (&T->rec[0][0])[i];
 }
 
+// Batched Query.  Random points share nothing, so per point the tree costs one 128-byte top-table line
+// out of L2; fetched lane-by-lane that is 6 divergent 16-byte requests per point and the texture
+// addresser becomes the limit.  Here the wave fetches cooperatively: in step k the 8 lanes of every
+// group read the 8 consecutive 16-byte chunks of the line of the group's k-th point, straight into LDS
+// (global_load_lds_dwordx4: lane-linear destination, per-lane source), i.e. 8 whole lines per
+// wave-instruction instead of 64 fragments; afterwards every lane reads back its own point's row.
+// Leaves that are not inline in the table (degree > 2, or deeper than the table) continue lane-by-lane.
+template <int MAXP>
 __global__ __launch_bounds__(256) void query_kernel(TreeDev t, const DeviceTables* __restrict__ T,
                                                     const double* __restrict__ xyz, size_t n, double* __restrict__ out) {
     __shared__ double sNl[13 * 11];
     __shared__ double sRec[26];
+    __shared__ double2 sRows[4][8][64];  // per wave: step k -> 64 lanes x 16 B
     stageQueryTables(T, sNl, sRec);
     __syncthreads();
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-        out[i] = queryPoint(t, x, y, z, sNl, sRec);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane & ~7, sub = lane & 7;
+    for (size_t base = (size_t)blockIdx.x * 256; base < n; base += (size_t)gridDim.x * 256) {
+        const size_t i = base + threadIdx.x;
+        const bool valid = i < n;
+        const size_t il = valid ? i : n - 1;
+        const double x = xyz[3 * il], y = xyz[3 * il + 1], z = xyz[3 * il + 2];
+        // Octree.cpp:665
+        const double px = (x - t.rootCentre[0]) * t.rootInvSizes[0];
+        const double py = (y - t.rootCentre[1]) * t.rootInvSizes[1];
+        const double pz = (z - t.rootCentre[2]) * t.rootInvSizes[2];
+        // :668 containment on the f32 cast, both ends inclusive; NaN fails
+        const float fx = (float)px, fy = (float)py, fz = (float)pz;
+        const bool inside = fx >= -0.5f && fx <= 0.5f && fy >= -0.5f && fy <= 0.5f && fz >= -0.5f && fz <= 0.5f;
+        // :674-701 for the complete top levels: comparisons only
+        double cx = 0.0, cy = 0.0, cz = 0.0, q = 0.25;
+        uint32_t code = 0;
+        int depth = 0;
+        for (; depth < t.topDepth; ++depth) {
+            const bool ux = px >= cx, uy = py >= cy, uz = pz >= cz;
+            code = code * 8u + (ux ? 1u : 0u) + (uy ? 2u : 0u) + (uz ? 4u : 0u);
+            cx = ux ? cx + q : cx - q;
+            cy = uy ? cy + q : cy - q;
+            cz = uz ? cz + q : cz - q;
+            q = q * 0.5;
+        }
+        if (!inside) code = 0;  // any valid line; the result is DBL_MAX
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t ck = __shfl(code, grp | k, 64);
+            const char* src = reinterpret_cast<const char*>(t.top + ck) + sub * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)&sRows[wave][k][0], 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // lane (group g, sub k) owns the row that step k wrote at lanes 8g..8g+7: [record][c0 c1]..[c8 c9]
+        const double2* row = &sRows[wave][sub][grp];
+        const uint2 hdr = *reinterpret_cast<const uint2*>(row);
+        double cv[10];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const double2 v = row[1 + c];
+            cv[2 * c] = v.x;
+            cv[2 * c + 1] = v.y;
+        }
+        double r;
+        if (!inside) {
+            r = DBL_MAX;  // :668-671
+        } else if (hdr.y <= 2u) {
+            // :862  unitPt = (pt - centre) * (2 << depth)
+            const double s = (double)(2 << depth);
+            const double ux = (px - cx) * s, uy = (py - cy) * s, uz = (pz - cz) * s;
+            if (hdr.y == 2u)
+                r = evalLeafVals<2>(cv, ux, uy, uz, depth, sNl, sRec);
+            else if (hdr.y == 1u)
+                r = evalLeafVals<1>(cv, ux, uy, uz, depth, sNl, sRec);
+            else
+                r = evalLeafVals<0>(cv, ux, uy, uz, depth, sNl, sRec);
+        } else {
+            NodeRec rec{hdr.x, hdr.y};
+            while (rec.b == kInteriorTag) {
+                const bool ux = px >= cx, uy = py >= cy, uz = pz >= cz;
+                const uint32_t idx = rec.a + (ux ? 1u : 0u) + (uy ? 2u : 0u) + (uz ? 4u : 0u);
+                cx = ux ? cx + q : cx - q;
+                cy = uy ? cy + q : cy - q;
+                cz = uz ? cz + q : cz - q;
+                q = q * 0.5;
+                ++depth;
+                rec = t.nodes[idx];
+            }
+            const double s = (double)(2 << depth);
+            r = evalLeaf<MAXP>(t.coeffs + rec.a, (int)rec.b, (px - cx) * s, (py - cy) * s, (pz - cz) * s, depth, sNl, sRec);
+        }
+        if (valid) out[i] = r;
+        __builtin_amdgcn_wave_barrier();  // rows are rewritten by the next tile's DMA
     }
 }
 
@@ -377,7 +521,7 @@ __device__ __forceinline__ double fieldEvalWorld(const FieldDev& f, double x, do
     else  // SURVEY 3.4 user glue: (f64) mesh.SignedDistanceAtPt(p.cast<f32>())
         v = (double)meshSignedDistance(f.mesh, V3{(float)x, (float)y, (float)z});
     if constexpr (CSG) {
-        const double o = queryPoint(f.oldTree, x, y, z, sNl, sRec);
+        const double o = queryPoint<12>(f.oldTree, x, y, z, sNl, sRec);
         switch (f.csgOp) {
             case HPSDF_OP_UNION: v = o < v ? o : v; break;                   // std::min(old, F)
             case HPSDF_OP_SUBTRACT: v = (o * -1.0) < v ? v : (o * -1.0); break;  // std::max(-old, F)
@@ -621,7 +765,15 @@ static unsigned gridFor(size_t n) {
 hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dXyz, size_t n,
                        double* dOut) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(query_kernel, dim3(gridFor(n)), dim3(256), 0, stream, t, dTables, dXyz, n, dOut);
+    const dim3 grid(gridFor(n)), block(256);
+    if (t.maxDegree <= 2)
+        hipLaunchKernelGGL(query_kernel<2>, grid, block, 0, stream, t, dTables, dXyz, n, dOut);
+    else if (t.maxDegree <= 3)
+        hipLaunchKernelGGL(query_kernel<3>, grid, block, 0, stream, t, dTables, dXyz, n, dOut);
+    else if (t.maxDegree <= 5)
+        hipLaunchKernelGGL(query_kernel<5>, grid, block, 0, stream, t, dTables, dXyz, n, dOut);
+    else
+        hipLaunchKernelGGL(query_kernel<12>, grid, block, 0, stream, t, dTables, dXyz, n, dOut);
     return hipGetLastError();
 }
 

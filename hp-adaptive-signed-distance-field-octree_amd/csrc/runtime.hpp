@@ -19,6 +19,7 @@ struct hpsdf_ctx {
 struct hpsdf_tree {
     int device = 0;
     hpsdf::NodeRec* dNodes = nullptr;
+    hpsdf::TopEntry* dTop = nullptr;
     double* dCoeffs = nullptr;
     hpsdf::TreeDev dev{};
     uint64_t nNodes = 0, nCoeffs = 0, nLeaves = 0;
