@@ -84,39 +84,35 @@ void appendSeg(hpsdf_build* b, uint64_t node, const hpsdf_build::Seg& s) {
     b->segTail[node] = id;
 }
 
-template <typename T>
-int growDevice(T** p, uint64_t* cap, uint64_t want) {
-    if (want <= *cap) return HPSDF_OK;
-    uint64_t nc = *cap ? *cap : 1024;
-    while (nc < want) nc *= 2;
-    if (*p) HPSDF_HIP(hipFree(*p));
-    *p = nullptr;
-    *cap = 0;
-    HPSDF_HIP(hipMalloc((void**)p, nc * sizeof(T)));
-    *cap = nc;
-    return HPSDF_OK;
-}
-
-struct HostTask {
-    FitTask t;
-    uint8_t degree;
-    uint16_t rowStart, rowEnd;
-};
-
 }  // namespace
 
 hpsdf_build::~hpsdf_build() {
-    if (device >= 0) {
-        (void)hipSetDevice(device);
-        if (dArena) (void)hipFree(dArena);
-        if (dTasks) (void)hipFree(dTasks);
-        if (dBlocks) (void)hipFree(dBlocks);
-        if (dErrs) (void)hipFree(dErrs);
-        if (dSamples) (void)hipFree(dSamples);
-        if (dPack) (void)hipFree(dPack);
-        if (dPackItems) (void)hipFree(dPackItems);
+    if (ws) {
+        if (ownsWs) {
+            ws->release();
+            delete ws;
+        } else {
+            ws->inUse = false;
+        }
     }
 }
+
+namespace {
+int acquireWorkspace(hpsdf_build* b, hpsdf_ctx* ctx) {
+    if (b->ws) return HPSDF_OK;
+    if (!ctx->ws.inUse) {
+        ctx->ws.inUse = true;
+        ctx->ws.device = ctx->device;
+        b->ws = &ctx->ws;
+        b->ownsWs = false;
+    } else {
+        b->ws = new Workspace();
+        b->ws->device = ctx->device;
+        b->ownsWs = true;
+    }
+    return HPSDF_OK;
+}
+}  // namespace
 
 namespace hpsdf {
 
@@ -182,10 +178,15 @@ int builderSelect(hpsdf_build* b, uint64_t* nJobs) {
     }
     const uint64_t want = b->stats.rounds == 0 ? b->heap.size() : std::min<uint64_t>(b->K, b->heap.size());
     b->batch.resize(want);
-    for (uint64_t i = 0; i < want; ++i) {
-        std::pop_heap(b->heap.begin(), b->heap.end(), HeapLess());
-        b->batch[i] = b->heap.back();
-        b->heap.pop_back();
+    if (want == b->heap.size()) {  // the whole frontier (always the case in round 0): no heap work needed
+        b->batch.assign(b->heap.begin(), b->heap.end());
+        b->heap.clear();
+    } else {
+        for (uint64_t i = 0; i < want; ++i) {
+            std::pop_heap(b->heap.begin(), b->heap.end(), HeapLess());
+            b->batch[i] = b->heap.back();
+            b->heap.pop_back();
+        }
     }
     std::sort(b->batch.begin(), b->batch.end(),
               [](const hpsdf_build::HeapEnt& x, const hpsdf_build::HeapEnt& y) { return x.idx < y.idx; });
@@ -243,41 +244,99 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
     if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "round_compute needs a device context (there is no CPU path)");
     if (!field) return fail(HPSDF_ERR_INVALID_ARGUMENT, "field is null");
     HPSDF_HIP(hipSetDevice(ctx->device));
-    b->device = ctx->device;
+    acquireWorkspace(b, ctx);
+    Workspace& ws = *b->ws;
+    const Tables& T = tables();
     const hpsdf_build::Slice sl = b->slices[b->rank];
-    std::vector<HostTask> tasks;
-    tasks.reserve(sl.count * 9);
-    uint64_t arenaNeed = 0, sampleNeed = 0;
     const bool sampled = innermost(field)->kind == kHostCallback;
-    auto addTask = [&](const float* bmin, const float* bmax, int degree, int rowStart, int depth, uint32_t errSlot) {
-        HostTask h;
-        std::memset(&h, 0, sizeof h);
-        for (int a = 0; a < 3; ++a) {
-            h.t.bmin[a] = bmin[a];
-            h.t.bmax[a] = bmax[a];
+
+    // ---- pass 1: count the fits of every shape.  class id = 2*degree + (incremental ? 1 : 0)
+    constexpr int kClasses = 2 * (kMaxDegree + 1);
+    uint32_t classCount[kClasses] = {0};
+    for (uint64_t jl = 0; jl < sl.count; ++jl) {
+        const hpsdf_build::HeapEnt& e = b->batch[sl.first + jl];
+        const hpsdf_node& n = b->nodes[e.idx];
+        if (std::fabs(e.err - HPSDF_INITIAL_NODE_ERR) < DBL_EPSILON) {
+            classCount[2 * 2] += 1;  // Octree.cpp:836-843: degree-2 fit from scratch
+            continue;
         }
-        h.degree = (uint8_t)degree;
-        h.rowStart = (uint16_t)rowStart;
-        h.rowEnd = (uint16_t)ncoef(degree);
-        h.t.outOff = b->arenaUsed + arenaNeed;
-        h.t.copyOff = kNone;
-        h.t.sampleOff = sampleNeed;
-        h.t.errSlot = errSlot;
-        h.t.depth = (uint8_t)depth;
-        arenaNeed += h.rowEnd - h.rowStart;
-        const uint64_t nq = 4 * (uint64_t)degree + 1;
+        if (n.depth < kMaxDepth) classCount[2 * n.degree] += 8;            // :814-822
+        if (n.degree < kMaxDegree - 1) classCount[2 * (n.degree + 1) + 1] += 1;  // :846-851
+    }
+    uint32_t classFirst[kClasses + 1];
+    classFirst[0] = 0;
+    for (int c = 0; c < kClasses; ++c) classFirst[c + 1] = classFirst[c] + classCount[c];
+    const uint32_t nTasks = classFirst[kClasses];
+
+    // ---- workgroup table: G fits of one shape per workgroup
+    uint32_t nBlocks = 0;
+    int classG[kClasses], classPlanes[kClasses];
+    uint32_t classBlockFirst[kClasses + 1];
+    for (int c = 0; c < kClasses; ++c) {
+        classG[c] = 1;
+        classPlanes[c] = 1;
+        classBlockFirst[c] = nBlocks;
+        if (!classCount[c]) continue;
+        const int deg = c / 2;
+        const int nrows = (c & 1) ? (int)(T.coeffCount[deg] - T.coeffCount[deg - 1]) : (int)T.coeffCount[deg];
+        const int g = fitCellsPerBlock(deg, nrows, classCount[c]);
+        classG[c] = g;
+        classPlanes[c] = fitPlanesPerChunk(deg, g);
+        nBlocks += (classCount[c] + g - 1) / g;
+    }
+    classBlockFirst[kClasses] = nBlocks;
+    hipError_t he = ws.tasks.ensure(std::max<uint32_t>(1, nTasks));
+    if (he == hipSuccess) he = ws.blocks.ensure(std::max<uint32_t>(1, nBlocks));
+    if (he == hipSuccess) he = ws.errs.ensure(std::max<uint64_t>(1, sl.count * HPSDF_JOB_HEADER_DOUBLES));
+    if (he != hipSuccess) return hipFail(he, "workspace allocation");
+    {
+        uint32_t bi = 0;
+        for (int c = 0; c < kClasses; ++c) {
+            const int deg = c / 2, g = classG[c];
+            for (uint32_t i = 0; i < classCount[c]; i += g) {
+                FitBlock& fb = ws.blocks.host[bi++];
+                std::memset(&fb, 0, sizeof fb);
+                fb.firstTask = classFirst[c] + i;
+                fb.nTasks = (uint16_t)std::min<uint32_t>(g, classCount[c] - i);
+                fb.degree = (uint8_t)deg;
+                fb.planesPerChunk = (uint8_t)classPlanes[c];
+                fb.rowStart = (uint16_t)((c & 1) ? T.coeffCount[deg - 1] : 0);
+                fb.rowEnd = (uint16_t)T.coeffCount[deg];
+            }
+        }
+    }
+
+    // ---- pass 2: fill the tasks, grouped by shape; arena offsets and sample offsets in job order
+    uint32_t cursor[kClasses];
+    for (int c = 0; c < kClasses; ++c) cursor[c] = classFirst[c];
+    uint64_t arenaNeed = 0, sampleNeed = 0;
+    auto addTask = [&](int cls, const float* bmin, const float* bmax, int depth, uint32_t errSlot) {
+        const int deg = cls / 2;
+        const uint64_t rows = (cls & 1) ? T.coeffCount[deg] - T.coeffCount[deg - 1] : T.coeffCount[deg];
+        FitTask& t = ws.tasks.host[cursor[cls]++];
+        for (int a = 0; a < 3; ++a) {
+            t.bmin[a] = bmin[a];
+            t.bmax[a] = bmax[a];
+        }
+        t.outOff = b->arenaUsed + arenaNeed;
+        t.copyOff = kNone;
+        t.sampleOff = sampleNeed;
+        t.errSlot = errSlot;
+        t.depth = (uint8_t)depth;
+        t.pad[0] = (uint8_t)deg;  // host-side note for the sampler below
+        t.pad[1] = t.pad[2] = 0;
+        arenaNeed += rows;
+        const uint64_t nq = 4 * (uint64_t)deg + 1;
         sampleNeed += nq * nq * nq;
-        tasks.push_back(h);
-        return h.t.outOff;
+        return t.outOff;
     };
     for (uint64_t jl = 0; jl < sl.count; ++jl) {
         const hpsdf_build::HeapEnt& e = b->batch[sl.first + jl];
         const hpsdf_node& n = b->nodes[e.idx];
-        const bool coarse = std::fabs(e.err - HPSDF_INITIAL_NODE_ERR) < DBL_EPSILON;
         hpsdf_build::JobOut& jo = b->jobOut[jl];
         const uint32_t slot0 = (uint32_t)(jl * HPSDF_JOB_HEADER_DOUBLES);
-        if (coarse) {
-            jo.pOff = addTask(n.aabb_min, n.aabb_max, 2, 0, n.depth, slot0);  // Octree.cpp:836-843
+        if (std::fabs(e.err - HPSDF_INITIAL_NODE_ERR) < DBL_EPSILON) {
+            jo.pOff = addTask(2 * 2, n.aabb_min, n.aabb_max, n.depth, slot0);
             jo.pHost = 0;
             b->stats.fits += 1;
             continue;
@@ -289,79 +348,42 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
             for (unsigned i = 0; i < 8; ++i) {
                 float cmin[3], cmax[3];
                 cornerBox(n.aabb_min, n.aabb_max, i, cmin, cmax);
-                addTask(cmin, cmax, p, 0, d + 1, slot0 + 1 + i);
+                addTask(2 * p, cmin, cmax, d + 1, slot0 + 1 + i);
             }
             b->stats.fits += 8;
         }
         if (p < kMaxDegree - 1) {  // degree 11 is never raised (:600)
-            jo.pOff = addTask(n.aabb_min, n.aabb_max, p + 1, (int)ncoef(p), d, slot0);
+            jo.pOff = addTask(2 * (p + 1) + 1, n.aabb_min, n.aabb_max, d, slot0);
             jo.pHost = 0;
             b->stats.fits += 1;
         }
     }
     b->stats.samples += sampleNeed;
 
-    // group fits of equal shape into workgroups
-    std::vector<uint32_t> order(tasks.size());
-    for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
-    auto key = [&](uint32_t i) { return ((uint32_t)tasks[i].degree << 16) | tasks[i].rowStart; };
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return key(x) < key(y); });
-    std::vector<FitTask> flat(tasks.size());
-    std::vector<FitBlock> blocks;
-    size_t maxLds = 0;
-    for (size_t s = 0; s < order.size();) {
-        size_t e = s;
-        while (e < order.size() && key(order[e]) == key(order[s])) ++e;
-        const HostTask& h0 = tasks[order[s]];
-        const int nrows = h0.rowEnd - h0.rowStart;
-        const int nq = 4 * h0.degree + 1;
-        int gmax = nrows > kFitBlockThreads ? 1 : kFitBlockThreads / nrows;
-        while (gmax > 1 && fitLdsBytes(h0.degree, gmax) > kFitMaxLdsBytes) --gmax;
-        (void)nq;
-        const size_t n = e - s;
-        int g = (int)std::min<size_t>((size_t)gmax, std::max<size_t>(1, (n + 511) / 512));
-        for (size_t i = s; i < e; i += g) {
-            FitBlock fb;
-            std::memset(&fb, 0, sizeof fb);
-            fb.firstTask = (uint32_t)i;
-            fb.nTasks = (uint16_t)std::min<size_t>(g, e - i);
-            fb.degree = h0.degree;
-            fb.rowStart = h0.rowStart;
-            fb.rowEnd = h0.rowEnd;
-            blocks.push_back(fb);
-        }
-        maxLds = std::max(maxLds, fitLdsBytes(h0.degree, g));
-        for (size_t i = s; i < e; ++i) flat[i] = tasks[order[i]].t;
-        s = e;
-    }
-
-    // arena: grow by reallocation (offsets are stable, pointers are not kept)
-    if (b->arenaUsed + arenaNeed > b->arenaCap) {
-        uint64_t nc = std::max<uint64_t>(b->arenaCap * 2, 1ull << 22);
+    // ---- arena: grow by reallocation (offsets are stable, the pointer is not kept anywhere)
+    if (b->arenaUsed + arenaNeed > ws.arenaCap) {
+        uint64_t nc = std::max<uint64_t>(ws.arenaCap * 2, 1ull << 22);
         while (nc < b->arenaUsed + arenaNeed) nc *= 2;
         double* na = nullptr;
         HPSDF_HIP(hipMalloc((void**)&na, nc * sizeof(double)));
-        if (b->dArena) {
-            HPSDF_HIP(hipMemcpyAsync(na, b->dArena, b->arenaUsed * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        if (ws.arena) {
+            if (b->arenaUsed)
+                HPSDF_HIP(hipMemcpyAsync(na, ws.arena, b->arenaUsed * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
             HPSDF_HIP(hipStreamSynchronize(ctx->stream));
-            HPSDF_HIP(hipFree(b->dArena));
+            HPSDF_HIP(hipFree(ws.arena));
         }
-        b->dArena = na;
-        b->arenaCap = nc;
+        ws.arena = na;
+        ws.arenaCap = nc;
     }
     b->arenaUsed += arenaNeed;
 
-    int rc;
-    if ((rc = growDevice(&b->dTasks, &b->tasksCap, flat.size()))) return rc;
-    if ((rc = growDevice(&b->dBlocks, &b->blocksCap, blocks.size()))) return rc;
-    if ((rc = growDevice(&b->dErrs, &b->errsCap, std::max<uint64_t>(1, sl.count * HPSDF_JOB_HEADER_DOUBLES)))) return rc;
-
-    // host-evaluated field: sample every fit's grid with thread_count workers, ship the values
+    // ---- host-evaluated field: sample every fit's grid with thread_count workers, ship the values
     const double* dSamples = nullptr;
     if (sampled) {
+        he = ws.samples.ensure(std::max<uint64_t>(1, sampleNeed));
+        if (he != hipSuccess) return hipFail(he, "sample buffer");
         const hpsdf_field* cbf = innermost(field);
-        std::vector<double> vals(sampleNeed);
-        const Tables& T = tables();
+        double* vals = ws.samples.host;
         double rb[3], rc3[3];
         for (int a = 0; a < 3; ++a) {
             rb[a] = (double)(b->cfg.root_max[a] - b->cfg.root_min[a]);
@@ -369,11 +391,9 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
         }
         const unsigned nThreads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(b->cfg.thread_count, 256));
         auto worker = [&](unsigned tIdx) {
-            for (size_t ti = tIdx; ti < flat.size(); ti += nThreads) {
-                const FitTask& tk = flat[ti];
-                // degree of this task: recover from block table is awkward; recompute from sample span
-                const HostTask& ht = tasks[order[ti]];
-                const int nq = 4 * ht.degree + 1, gl = glOffset(nq);
+            for (uint32_t ti = tIdx; ti < nTasks; ti += nThreads) {
+                const FitTask& tk = ws.tasks.host[ti];
+                const int nq = 4 * (int)tk.pad[0] + 1, gl = glOffset(nq);
                 double sc[3], ce[3];
                 for (int a = 0; a < 3; ++a) {
                     sc[a] = (double)(tk.bmax[a] - tk.bmin[a]) * 0.5;
@@ -397,29 +417,33 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
             for (unsigned t = 0; t < nThreads; ++t) pool.emplace_back(worker, t);
             for (auto& th : pool) th.join();
         }
-        if ((rc = growDevice(&b->dSamples, &b->samplesCap, std::max<uint64_t>(1, sampleNeed)))) return rc;
-        HPSDF_HIP(hipMemcpyAsync(b->dSamples, vals.data(), sampleNeed * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        HPSDF_HIP(hipStreamSynchronize(ctx->stream));  // vals is pageable and goes out of scope
-        dSamples = b->dSamples;
+        HPSDF_HIP(hipMemcpyAsync(ws.samples.dev, vals, sampleNeed * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        dSamples = ws.samples.dev;
     }
 
     FieldDev fd;
+    int rc;
     if ((rc = makeFieldDev(field, dSamples, &fd))) return rc;
     RootMap rm;
     for (int a = 0; a < 3; ++a) {
         rm.bounds[a] = (double)(b->cfg.root_max[a] - b->cfg.root_min[a]);          // Octree.cpp:324
         rm.centre[a] = (double)((b->cfg.root_min[a] + b->cfg.root_max[a]) / 2.0f);  // Octree.cpp:322
     }
-    if (!flat.empty()) {
-        HPSDF_HIP(hipMemcpyAsync(b->dTasks, flat.data(), flat.size() * sizeof(FitTask), hipMemcpyHostToDevice, ctx->stream));
-        HPSDF_HIP(hipMemcpyAsync(b->dBlocks, blocks.data(), blocks.size() * sizeof(FitBlock), hipMemcpyHostToDevice,
-                                 ctx->stream));
-        HPSDF_HIP(hipStreamSynchronize(ctx->stream));  // pageable sources die with this scope
+    // pinned sources: the copies, the memset and the kernel are all asynchronous on the context stream
+    if (nTasks) {
+        HPSDF_HIP(hipMemcpyAsync(ws.tasks.dev, ws.tasks.host, nTasks * sizeof(FitTask), hipMemcpyHostToDevice, ctx->stream));
+        HPSDF_HIP(hipMemcpyAsync(ws.blocks.dev, ws.blocks.host, nBlocks * sizeof(FitBlock), hipMemcpyHostToDevice, ctx->stream));
     }
-    HPSDF_HIP(hipMemsetAsync(b->dErrs, 0, std::max<uint64_t>(1, sl.count * HPSDF_JOB_HEADER_DOUBLES) * sizeof(double),
+    HPSDF_HIP(hipMemsetAsync(ws.errs.dev, 0, std::max<uint64_t>(1, sl.count * HPSDF_JOB_HEADER_DOUBLES) * sizeof(double),
                              ctx->stream));
-    HPSDF_HIP(launchFit(ctx->stream, b->dBlocks, (uint32_t)blocks.size(), maxLds, b->dTasks, b->dArena, b->dErrs,
-                        ctx->dTables, fd, rm));
+    // one launch per shape class: the degree is a compile-time constant of the kernel
+    for (int c = 0; c < kClasses; ++c) {
+        const uint32_t nb = classBlockFirst[c + 1] - classBlockFirst[c];
+        if (!nb) continue;
+        const int deg = c / 2;
+        HPSDF_HIP(launchFit(ctx->stream, deg, ws.blocks.dev + classBlockFirst[c], nb, fitLdsBytes(deg, classG[c], classPlanes[c]),
+                            ws.tasks.dev, ws.arena, ws.errs.dev, ctx->dTables, fd, rm));
+    }
     b->computed = true;
     return HPSDF_OK;
 }
@@ -582,24 +606,28 @@ int builderPackDevice(hpsdf_build* b, hpsdf_ctx* ctx, double** dPack, uint64_t* 
     if (!b->laidOut) return fail(HPSDF_ERR_STATE, "call hpsdf_build_layout first");
     if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "pack_device needs a device context");
     HPSDF_HIP(hipSetDevice(ctx->device));
-    b->device = ctx->device;
-    std::vector<PackItem> items;
-    uint64_t pos = 0;
+    acquireWorkspace(b, ctx);
+    Workspace& ws = *b->ws;
+    uint64_t pos = 0, nItems = 0;
+    for (const auto& l : b->layout)
+        if (l.owner == b->rank) {
+            nItems += l.hostStore ? 0 : 1;
+            pos += l.count;
+        }
+    hipError_t he = ws.pack.ensure(std::max<uint64_t>(1, pos));
+    if (he == hipSuccess) he = ws.items.ensure(std::max<uint64_t>(1, nItems));
+    if (he != hipSuccess) return hipFail(he, "pack buffers");
+    uint64_t at = 0, it = 0;
     for (const auto& l : b->layout) {
         if (l.owner != b->rank) continue;
-        if (!l.hostStore) items.push_back({l.src, pos, l.count, 0});
-        pos += l.count;
+        if (!l.hostStore) ws.items.host[it++] = PackItem{l.src, at, l.count, 0};
+        at += l.count;
     }
-    int rc;
-    if ((rc = growDevice(&b->dPack, &b->packCap, std::max<uint64_t>(1, pos)))) return rc;
-    if ((rc = growDevice(&b->dPackItems, &b->packItemsCap, std::max<uint64_t>(1, items.size())))) return rc;
-    if (!items.empty()) {
-        HPSDF_HIP(hipMemcpyAsync(b->dPackItems, items.data(), items.size() * sizeof(PackItem), hipMemcpyHostToDevice,
-                                 ctx->stream));
-        HPSDF_HIP(hipStreamSynchronize(ctx->stream));
-        HPSDF_HIP(launchPack(ctx->stream, b->dPackItems, (uint32_t)items.size(), b->dArena, b->dPack));
+    if (nItems) {
+        HPSDF_HIP(hipMemcpyAsync(ws.items.dev, ws.items.host, nItems * sizeof(PackItem), hipMemcpyHostToDevice, ctx->stream));
+        HPSDF_HIP(launchPack(ctx->stream, ws.items.dev, (uint32_t)nItems, ws.arena, ws.pack.dev));
     }
-    if (dPack) *dPack = b->dPack;
+    if (dPack) *dPack = ws.pack.dev;
     if (n) *n = pos;
     return HPSDF_OK;
 }
@@ -613,8 +641,9 @@ int builderPackHost(hpsdf_build* b, hpsdf_ctx* ctx, double* out) {
         uint64_t n = 0;
         int rc = builderPackDevice(b, ctx, &dp, &n);
         if (rc) return rc;
-        HPSDF_HIP(hipMemcpyAsync(out, dp, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HPSDF_HIP(hipMemcpyAsync(b->ws->pack.host, dp, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HPSDF_HIP(hipStreamSynchronize(ctx->stream));
+        std::memcpy(out, b->ws->pack.host, n * sizeof(double));
     }
     uint64_t pos = 0;
     for (const auto& l : b->layout) {

@@ -60,21 +60,11 @@ struct hpsdf_build {
     std::vector<JobOut> jobOut;  // indexed by job - slices[rank].first
     bool roundOpen = false, computed = false;
 
-    // ---- device state of this rank
-    int device = -1;
-    double* dArena = nullptr;
-    uint64_t arenaCap = 0, arenaUsed = 0;
-    hpsdf::FitTask* dTasks = nullptr;
-    hpsdf::FitBlock* dBlocks = nullptr;
-    uint64_t tasksCap = 0, blocksCap = 0;
-    double* dErrs = nullptr;
-    uint64_t errsCap = 0;
-    double* dSamples = nullptr;
-    uint64_t samplesCap = 0;
-    double* dPack = nullptr;
-    uint64_t packCap = 0;
-    hpsdf::PackItem* dPackItems = nullptr;
-    uint64_t packItemsCap = 0;
+    // ---- device state of this rank: buffers borrowed from the context's workspace (or private ones
+    //      when several builds share a context); the context must outlive the build
+    hpsdf::Workspace* ws = nullptr;
+    bool ownsWs = false;
+    uint64_t arenaUsed = 0;
     std::vector<double> hostStore;  // injected coefficients
 
     // ---- layout (after the last round)

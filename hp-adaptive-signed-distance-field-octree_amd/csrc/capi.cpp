@@ -2,6 +2,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -176,6 +177,7 @@ int hpsdf_ctx_destroy(hpsdf_ctx* c) {
     if (!c) return HPSDF_OK;
     (void)hipSetDevice(c->device);
     if (c->dTables) (void)hipFree(c->dTables);
+    c->ws.release();
     if (c->ownsStream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return HPSDF_OK;
@@ -568,7 +570,7 @@ int hpsdf_build_round_compute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field*
 int hpsdf_build_round_results_device(hpsdf_build* b, double** dHeaders, uint64_t* n) {
     if (!b) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null build");
     if (!b->roundOpen || !b->computed) return fail(HPSDF_ERR_STATE, "round not computed");
-    if (dHeaders) *dHeaders = b->dErrs;
+    if (dHeaders) *dHeaders = b->ws ? b->ws->errs.dev : nullptr;
     if (n) *n = b->slices[b->rank].count * HPSDF_JOB_HEADER_DOUBLES;
     return HPSDF_OK;
 }
@@ -579,8 +581,9 @@ int hpsdf_build_round_results_host(hpsdf_build* b, hpsdf_ctx* ctx, double* out) 
     if (!b->roundOpen || !b->computed) return fail(HPSDF_ERR_STATE, "round not computed");
     const uint64_t n = b->slices[b->rank].count * HPSDF_JOB_HEADER_DOUBLES;
     HPSDF_HIP(hipSetDevice(ctx->device));
-    if (n) HPSDF_HIP(hipMemcpyAsync(out, b->dErrs, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (n) HPSDF_HIP(hipMemcpyAsync(b->ws->errs.host, b->ws->errs.dev, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HPSDF_HIP(hipStreamSynchronize(ctx->stream));
+    if (n) std::memcpy(out, b->ws->errs.host, n * sizeof(double));
     return HPSDF_OK;
     HPSDF_CATCH
 }
@@ -650,28 +653,52 @@ int hpsdf_create(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* fie
     o.max_jobs_per_round = K;
     o.rank = 0;
     o.world = 1;
+    const bool trace = std::getenv("HPSDF_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tSel = 0, tCmp = 0, tRes = 0, tApp = 0, t0 = now(), t1;
     hpsdf_build* b = nullptr;
     int rc = hpsdf_build_begin(cfg, &o, &b);
     if (rc) return rc;
+    const double tBegin = now() - t0;
     std::vector<double> headers;
     for (;;) {
         uint64_t n = 0;
+        t1 = now();
         if ((rc = builderSelect(b, &n))) break;
+        tSel += now() - t1;
         if (n == 0) break;
         headers.resize(n * HPSDF_JOB_HEADER_DOUBLES);
+        t1 = now();
         if ((rc = builderCompute(b, ctx, field))) break;
+        tCmp += now() - t1;
+        t1 = now();
         if ((rc = hpsdf_build_round_results_host(b, ctx, headers.data()))) break;
+        tRes += now() - t1;
+        t1 = now();
         if ((rc = builderApply(b, headers.data()))) break;
+        tApp += now() - t1;
     }
+    t1 = now();
     if (!rc) rc = builderLayout(b);
+    const double tLay = now() - t1;
+    t1 = now();
+    double tPack = 0, tAsm = 0;
     if (!rc) {
         std::vector<double> pack(std::max<uint64_t>(1, b->packCounts[0]));
         rc = builderPackHost(b, ctx, pack.data());
+        tPack = now() - t1;
+        t1 = now();
         const double* packs[1] = {pack.data()};
         if (!rc) rc = builderAssemble(b, packs, block, size);
+        tAsm = now() - t1;
     }
     if (!rc && stats) hpsdf_build_get_stats(b, stats);
+    t1 = now();
     delete b;
+    if (trace)
+        std::fprintf(stderr, "[hpsdf_create] us: begin %.0f select %.0f compute(host+launch) %.0f results(wait+D2H) %.0f apply %.0f "
+                             "layout %.0f pack %.0f assemble %.0f destroy %.0f total %.0f\n",
+                     tBegin, tSel, tCmp, tRes, tApp, tLay, tPack, tAsm, now() - t1, now() - t0);
     return rc;
     HPSDF_CATCH
 }
@@ -689,9 +716,8 @@ int hpsdf_bench_fit(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* 
     const Tables& T = tables();
     const uint64_t nc = T.coeffCount[degree];
     const int nrows = (int)nc;
-    int gmax = nrows > kFitBlockThreads ? 1 : kFitBlockThreads / nrows;
-    while (gmax > 1 && fitLdsBytes(degree, gmax) > kFitMaxLdsBytes) --gmax;
-    const int g = (int)std::min<uint64_t>((uint64_t)gmax, std::max<uint64_t>(1, (nCells + 511) / 512));
+    const int g = fitCellsPerBlock(degree, nrows, (uint32_t)std::min<uint64_t>(nCells, 0xFFFFFFFFull));
+    const int planes = fitPlanesPerChunk(degree, g);
     std::vector<FitTask> tasks(nCells);
     const uint64_t side = 1ull << depth;
     const float h = 1.0f / (float)side;
@@ -714,6 +740,7 @@ int hpsdf_bench_fit(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* 
         fb.firstTask = (uint32_t)i;
         fb.nTasks = (uint16_t)std::min<uint64_t>(g, nCells - i);
         fb.degree = (uint8_t)degree;
+        fb.planesPerChunk = (uint8_t)planes;
         fb.rowStart = 0;
         fb.rowEnd = (uint16_t)nc;
         blocks.push_back(fb);
@@ -738,12 +765,12 @@ int hpsdf_bench_fit(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* 
         rm.bounds[a] = (double)(cfg->root_max[a] - cfg->root_min[a]);
         rm.centre[a] = (double)((cfg->root_min[a] + cfg->root_max[a]) / 2.0f);
     }
-    const size_t lds = fitLdsBytes(degree, g);
+    const size_t lds = fitLdsBytes(degree, g, planes);
     if (e == hipSuccess && rc == HPSDF_OK) {
-        e = launchFit(ctx->stream, dB, (uint32_t)blocks.size(), lds, dT, dA, dE, ctx->dTables, fd, rm);  // warm-up
+        e = launchFit(ctx->stream, degree, dB, (uint32_t)blocks.size(), lds, dT, dA, dE, ctx->dTables, fd, rm);  // warm-up
         if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
         for (int r = 0; r < repeats && e == hipSuccess; ++r)
-            e = launchFit(ctx->stream, dB, (uint32_t)blocks.size(), lds, dT, dA, dE, ctx->dTables, fd, rm);
+            e = launchFit(ctx->stream, degree, dB, (uint32_t)blocks.size(), lds, dT, dA, dE, ctx->dTables, fd, rm);
         if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
         if (e == hipSuccess) e = hipEventSynchronize(e1);
         float ms = 0.f;

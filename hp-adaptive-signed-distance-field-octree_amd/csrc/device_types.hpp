@@ -91,7 +91,7 @@ struct FitBlock {
     uint32_t firstTask;
     uint16_t nTasks;
     uint8_t degree;  // target degree -> (4*degree+1)^3 samples
-    uint8_t pad0;
+    uint8_t planesPerChunk;  // i-planes of samples staged in LDS at a time
     uint16_t rowStart, rowEnd;  // coefficient rows computed: [rowStart,rowEnd)
     uint32_t pad1;
 };

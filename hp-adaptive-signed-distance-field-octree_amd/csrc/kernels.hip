@@ -16,8 +16,10 @@
 //   pack_kernel    Octree::ReallocCoeffs gather (Octree.cpp:510-552).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
 #include <cstdint>
+#include <cstdlib>
 
 #include "device_types.hpp"
 #include "launch.hpp"
@@ -550,15 +552,50 @@ __global__ __launch_bounds__(256) void field_kernel(FieldDev f, const DeviceTabl
 // One workgroup fits blk.nTasks cells of identical shape.  The reference loops
 // samples (i,j,k) outermost and coefficients innermost; here each thread owns
 // one (cell, coefficient row) accumulator and walks the samples in the same
-// (i,j,k) order, so every coefficient is the same left-to-right sum.  Per
-// i-plane: phase 1 evaluates F on the plane's nq*nq samples of every cell into
-// LDS (all 256 threads), phase 2 accumulates.  The per-term product
+// (i,j,k) order, so every coefficient is the same left-to-right sum.  The
+// samples are processed in chunks of whole i-planes (as many as LDS holds):
+// phase 1 evaluates F on the chunk's samples of every cell into LDS (all 256
+// threads), phase 2 accumulates.  The per-term product
 //   Lp = 1 * P_i0(x) * N_i0 * P_i1(y) * N_i1 * P_i2(z) * N_i2      (:1045-1050)
 // is hoisted by loop level without changing its association.
+//
+// DEG > 0 fixes the degree at compile time (nq = 4*DEG+1): the innermost loop
+// unrolls, the thread's P_i2 row lives in registers and the LDS reads of a row
+// are issued together instead of one dependent read per term; DEG == 0 is the
+// any-degree version (rows walked in groups of four, nq = 4p+1).
 
 constexpr int kFitThreads = 256;
 
-template <int KIND, bool CSG>
+// acc += sum_k ((a1 * tk[k]) * n2) * F[k], k ascending
+template <int NQ>
+__device__ __forceinline__ double fitRowFixed(double acc, double a1, const double (&tk)[NQ], double n2,
+                                              const double* __restrict__ F) {
+    double f[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) f[k] = F[k];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        const double lp = a1 * tk[k] * n2;
+        acc = acc + lp * f[k];
+    }
+    return acc;
+}
+__device__ __forceinline__ double fitRowAny(double acc, double a1, const double* __restrict__ tk, double n2,
+                                            const double* __restrict__ F, int nq) {
+    int k = 0;
+    for (; k + 4 <= nq; k += 4) {
+        const double f0 = F[k], f1 = F[k + 1], f2 = F[k + 2], f3 = F[k + 3];
+        const double t0 = tk[k], t1 = tk[k + 1], t2 = tk[k + 2], t3 = tk[k + 3];
+        acc = acc + (a1 * t0 * n2) * f0;
+        acc = acc + (a1 * t1 * n2) * f1;
+        acc = acc + (a1 * t2 * n2) * f2;
+        acc = acc + (a1 * t3 * n2) * f3;
+    }
+    for (; k < nq; ++k) acc = acc + (a1 * tk[k] * n2) * F[k];
+    return acc;
+}
+
+template <int KIND, bool CSG, int DEG>
 __global__ __launch_bounds__(kFitThreads) void fit_kernel(const FitBlock* __restrict__ blocks,
                                                           const FitTask* __restrict__ tasks, double* __restrict__ arena,
                                                           double* __restrict__ errs, const DeviceTables* __restrict__ T,
@@ -568,15 +605,17 @@ __global__ __launch_bounds__(kFitThreads) void fit_kernel(const FitBlock* __rest
     __shared__ double sRec[26];
     const FitBlock blk = blocks[blockIdx.x];
     const int tid = threadIdx.x;
-    const int deg = blk.degree, nq = 4 * deg + 1, nq2 = nq * nq, G = blk.nTasks;
+    const int deg = DEG > 0 ? DEG : (int)blk.degree;
+    const int nq = 4 * deg + 1, nq2 = nq * nq, G = blk.nTasks;
     const int rowStart = blk.rowStart, rowEnd = blk.rowEnd, nrows = rowEnd - rowStart;
     const int gl = nq * (nq - 1) / 2;  // Legendre.h: rule n starts at n(n-1)/2 (:1016-1017)
+    const int planes = blk.planesPerChunk;  // i-planes per chunk
 
     double* sT = lds;               // [deg+1][nq]  LpX(p, root_q)
     double* sR = sT + (deg + 1) * nq;  // [nq] roots
     double* sW = sR + nq;           // [nq] weights
     double* sC = sW + nq;           // [G][8]  scale xyz, centre xyz, scale product, sample offset (bits)
-    double* sF = sC + 8 * G;        // [G][nq2] weighted samples of the current plane
+    double* sF = sC + 8 * G;        // [G][planes][nq2] weighted samples of the current chunk
 
     stageQueryTables(T, sNl, sRec);
     for (int q = tid; q < nq; q += kFitThreads) {
@@ -624,49 +663,57 @@ __global__ __launch_bounds__(kFitThreads) void fit_kernel(const FitBlock* __rest
         i0b = T->bidx[r1][0], i1b = T->bidx[r1][1], i2b = T->bidx[r1][2];
         n0b = sNl[i0b * 11 + depth], n1b = sNl[i1b * 11 + depth], n2b = sNl[i2b * 11 + depth];
     }
+    constexpr int NQF = DEG > 0 ? 4 * DEG + 1 : 1;
+    double tkReg[NQF];  // this thread's P_i2 row (DEG > 0)
+    if (DEG > 0) {
+#pragma unroll
+        for (int k = 0; k < NQF; ++k) tkReg[k] = sT[i2a * nq + k];
+    }
     double acc0 = 0.0, acc1 = 0.0;  // :1025
 
-    const int planeSamples = G * nq2;
-    for (int i = 0; i < nq; ++i) {
-        // ---- phase 1: F on plane i of every cell (:1035-1040)
-        const double ri = sR[i], wi = sW[i];
-        for (int s = tid; s < planeSamples; s += kFitThreads) {
-            const int g = s / nq2, jk = s - g * nq2, j = jk / nq, k = jk - j * nq;
+    const int cellStride = planes * nq2;  // doubles per cell in sF
+    for (int iBase = 0; iBase < nq; iBase += planes) {
+        const int np = min(planes, nq - iBase);
+        // ---- phase 1: F on planes [iBase, iBase+np) of every cell (:1035-1040)
+        const int chunkSamples = np * nq2, total = G * chunkSamples;
+        for (int s = tid; s < total; s += kFitThreads) {
+            const int g = s / chunkSamples, rem = s - g * chunkSamples;
+            const int il = rem / nq2, jk = rem - il * nq2, j = jk / nq, k = jk - j * nq, i = iBase + il;
             const double* c = sC + 8 * g;
-            const double ux = ri * c[0] + c[3], uy = sR[j] * c[1] + c[4], uz = sR[k] * c[2] + c[5];
+            const double ux = sR[i] * c[0] + c[3], uy = sR[j] * c[1] + c[4], uz = sR[k] * c[2] + c[5];
             const double wx = ux * rm.bounds[0] + rm.centre[0];  // Octree.cpp:327
             const double wy = uy * rm.bounds[1] + rm.centre[1];
             const double wz = uz * rm.bounds[2] + rm.centre[2];
             const uint64_t sidx = (uint64_t)__double_as_longlong(c[7]) + (uint64_t)((i * nq + j) * nq + k);
             const double fv = fieldEvalWorld<KIND, CSG>(field, wx, wy, wz, sidx, sNl, sRec);
-            sF[s] = c[6] * (wi * (sW[j] * sW[k])) * fv;  // :1040
+            sF[g * cellStride + rem] = c[6] * (sW[i] * (sW[j] * sW[k])) * fv;  // :1040
         }
         __syncthreads();
-        // ---- phase 2: accumulate plane i (:1043-1053)
+        // ---- phase 2: accumulate the chunk, planes ascending (:1043-1053)
         if (act0) {
-            const double* F = sF + g2 * nq2;
-            const double a0 = sT[i0a * nq + i] * n0a;
             const double* tj = sT + i1a * nq;
             const double* tk = sT + i2a * nq;
-            for (int j = 0; j < nq; ++j) {
-                const double a1 = a0 * tj[j] * n1a;
-                const double* Fj = F + j * nq;
-                for (int k = 0; k < nq; ++k) {
-                    const double lp = a1 * tk[k] * n2a;
-                    acc0 = acc0 + lp * Fj[k];
+            for (int il = 0; il < np; ++il) {
+                const double* F = sF + g2 * cellStride + il * nq2;
+                const double a0 = sT[i0a * nq + iBase + il] * n0a;
+                for (int j = 0; j < nq; ++j) {
+                    const double a1 = a0 * tj[j] * n1a;
+                    if (DEG > 0)
+                        acc0 = fitRowFixed<NQF>(acc0, a1, tkReg, n2a, F + j * nq);
+                    else
+                        acc0 = fitRowAny(acc0, a1, tk, n2a, F + j * nq, nq);
                 }
             }
         }
         if (act1) {
-            const double a0 = sT[i0b * nq + i] * n0b;
             const double* tj = sT + i1b * nq;
             const double* tk = sT + i2b * nq;
-            for (int j = 0; j < nq; ++j) {
-                const double a1 = a0 * tj[j] * n1b;
-                const double* Fj = sF + j * nq;
-                for (int k = 0; k < nq; ++k) {
-                    const double lp = a1 * tk[k] * n2b;
-                    acc1 = acc1 + lp * Fj[k];
+            for (int il = 0; il < np; ++il) {
+                const double* F = sF + il * nq2;
+                const double a0 = sT[i0b * nq + iBase + il] * n0b;
+                for (int j = 0; j < nq; ++j) {
+                    const double a1 = a0 * tj[j] * n1b;
+                    acc1 = fitRowAny(acc1, a1, tk, n2b, F + j * nq, nq);
                 }
             }
         }
@@ -713,18 +760,47 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackItem* __restrict__ 
 // ---------------------------------------------------------------------------
 // launch wrappers (host)
 // ---------------------------------------------------------------------------
-size_t fitLdsBytes(int degree, int nTasks) {
+size_t fitLdsBytes(int degree, int nTasks, int planes) {
     const size_t nq = 4 * (size_t)degree + 1;
-    // sT + roots + weights + per-cell constants + one sample plane per cell (also holds the new rows at the end)
-    return ((size_t)(degree + 1) * nq + 2 * nq + 8 * (size_t)nTasks + (size_t)nTasks * nq * nq) * sizeof(double);
+    // sT + roots + weights + per-cell constants + `planes` sample planes per cell (also holds the new rows at the end)
+    return ((size_t)(degree + 1) * nq + 2 * nq + 8 * (size_t)nTasks + (size_t)nTasks * planes * nq * nq) * sizeof(double);
+}
+
+int fitPlanesPerChunk(int degree, int nTasks) {
+    const int nq = 4 * degree + 1;
+    int planes = nq;
+    while (planes > 1 && fitLdsBytes(degree, nTasks, planes) > kFitChunkLdsBytes) --planes;
+    return planes;
+}
+
+int fitCellsPerBlock(int degree, int nrows, uint32_t count) {
+    int gmax = nrows > kFitBlockThreads ? 1 : kFitBlockThreads / nrows;
+    while (gmax > 1 && fitLdsBytes(degree, gmax, 1) > kFitMaxLdsBytes) --gmax;
+    // enough workgroups to cover the chip twice before cells are stacked into one workgroup
+    int g = (int)std::min<uint32_t>((uint32_t)gmax, std::max<uint32_t>(1, (count + 511) / 512));
+    if (const char* e = std::getenv("HPSDF_FIT_G")) g = std::max(1, std::min(gmax, std::atoi(e)));  // tuning knob
+    return g;
 }
 
 template <int KIND, bool CSG>
-static void launchFitT(hipStream_t stream, const FitBlock* dBlocks, uint32_t nBlocks, size_t ldsBytes,
+static void launchFitT(hipStream_t stream, int degree, const FitBlock* dBlocks, uint32_t nBlocks, size_t ldsBytes,
                        const FitTask* dTasks, double* dArena, double* dErrs, const DeviceTables* dTables,
                        const FieldDev& field, const RootMap& rm) {
-    hipLaunchKernelGGL((fit_kernel<KIND, CSG>), dim3(nBlocks), dim3(kFitThreads), ldsBytes, stream, dBlocks, dTasks,
-                       dArena, dErrs, dTables, field, rm);
+#define HPSDF_FIT_CASE(D)                                                                                          \
+    case D:                                                                                                        \
+        hipLaunchKernelGGL((fit_kernel<KIND, CSG, D>), dim3(nBlocks), dim3(kFitThreads), ldsBytes, stream, dBlocks, \
+                           dTasks, dArena, dErrs, dTables, field, rm);                                             \
+        break;
+    switch (degree) {
+        HPSDF_FIT_CASE(2)
+        HPSDF_FIT_CASE(3)
+        HPSDF_FIT_CASE(4)
+        HPSDF_FIT_CASE(5)
+        default:
+            hipLaunchKernelGGL((fit_kernel<KIND, CSG, 0>), dim3(nBlocks), dim3(kFitThreads), ldsBytes, stream, dBlocks,
+                               dTasks, dArena, dErrs, dTables, field, rm);
+    }
+#undef HPSDF_FIT_CASE
 }
 
 #define HPSDF_DISPATCH_FIELD(FN, field, ...)                                     \
@@ -746,13 +822,15 @@ static void launchFitT(hipStream_t stream, const FitBlock* dBlocks, uint32_t nBl
         }                                                                        \
     } while (0)
 
-hipError_t launchFit(hipStream_t stream, const FitBlock* dBlocks, uint32_t nBlocks, size_t ldsBytes,
+// One launch per degree: `degree` selects the compile-time-specialised kernel (0 = any; the blocks then carry
+// their own degree).
+hipError_t launchFit(hipStream_t stream, int degree, const FitBlock* dBlocks, uint32_t nBlocks, size_t ldsBytes,
                      const FitTask* dTasks, double* dArena, double* dErrs, const DeviceTables* dTables,
                      const FieldDev& field, const RootMap& rm) {
     if (nBlocks == 0) return hipSuccess;
     if (ldsBytes > kFitMaxLdsBytes) return hipErrorInvalidValue;
-    HPSDF_DISPATCH_FIELD(launchFitT, field, stream, dBlocks, nBlocks, ldsBytes, dTasks, dArena, dErrs, dTables, field,
-                         rm);
+    HPSDF_DISPATCH_FIELD(launchFitT, field, stream, degree, dBlocks, nBlocks, ldsBytes, dTasks, dArena, dErrs, dTables,
+                         field, rm);
     return hipGetLastError();
 }
 

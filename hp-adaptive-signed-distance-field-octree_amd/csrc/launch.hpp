@@ -12,9 +12,13 @@ namespace hpsdf {
 constexpr size_t kFitMaxLdsBytes = 60 * 1024;  // stays under the 64 KiB default dynamic-LDS limit
 constexpr int kFitBlockThreads = 256;
 
-size_t fitLdsBytes(int degree, int nTasks);
+constexpr size_t kFitChunkLdsBytes = 40 * 1024;  // sample planes staged per chunk (keeps >= 3 workgroups per CU)
+size_t fitLdsBytes(int degree, int nTasks, int planes);
+int fitPlanesPerChunk(int degree, int nTasks);
+// fits of one shape stacked into one workgroup (count = fits of that shape in the launch)
+int fitCellsPerBlock(int degree, int nrows, uint32_t count);
 
-hipError_t launchFit(hipStream_t stream, const FitBlock* dBlocks, uint32_t nBlocks, size_t ldsBytes,
+hipError_t launchFit(hipStream_t stream, int degree, const FitBlock* dBlocks, uint32_t nBlocks, size_t ldsBytes,
                      const FitTask* dTasks, double* dArena, double* dErrs, const DeviceTables* dTables,
                      const FieldDev& field, const RootMap& rm);
 hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dXyz, size_t n,

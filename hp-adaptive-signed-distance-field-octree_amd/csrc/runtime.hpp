@@ -9,11 +9,67 @@
 #include "device_types.hpp"
 #include "tables.hpp"
 
+namespace hpsdf {
+
+// A device buffer with a pinned host twin (async copies need no host synchronisation).
+template <typename T>
+struct Staged {
+    T* dev = nullptr;
+    T* host = nullptr;
+    uint64_t cap = 0;
+    hipError_t ensure(uint64_t n) {
+        if (n <= cap) return hipSuccess;
+        uint64_t nc = cap ? cap : 1024;
+        while (nc < n) nc *= 2;
+        release();
+        hipError_t e = hipMalloc((void**)&dev, nc * sizeof(T));
+        if (e == hipSuccess) e = hipHostMalloc((void**)&host, nc * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) cap = nc;
+        return e;
+    }
+    void release() {
+        if (dev) (void)hipFree(dev);
+        if (host) (void)hipHostFree(host);
+        dev = host = nullptr;
+        cap = 0;
+    }
+};
+
+// Per-context scratch of the build: the coefficient arena and the per-round staging buffers.  Kept
+// across Create() calls (hipMalloc/hipFree cost more than a whole coarse round).
+struct Workspace {
+    int device = -1;
+    bool inUse = false;
+    double* arena = nullptr;
+    uint64_t arenaCap = 0;
+    Staged<FitTask> tasks;
+    Staged<FitBlock> blocks;
+    Staged<double> errs;
+    Staged<double> samples;
+    Staged<double> pack;
+    Staged<PackItem> items;
+    void release() {
+        if (device >= 0) (void)hipSetDevice(device);
+        if (arena) (void)hipFree(arena);
+        arena = nullptr;
+        arenaCap = 0;
+        tasks.release();
+        blocks.release();
+        errs.release();
+        samples.release();
+        pack.release();
+        items.release();
+    }
+};
+
+}  // namespace hpsdf
+
 struct hpsdf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool ownsStream = false;
     hpsdf::DeviceTables* dTables = nullptr;
+    hpsdf::Workspace ws;
 };
 
 struct hpsdf_tree {
