@@ -51,10 +51,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world == 1:
         raise SystemExit("--gpus %d needs the torch.distributed.run launcher (one process per GPU)" % args.gpus)
+    # functional dry-run of the N > 1 path on a one-GPU box: every rank on device 0, exchange over gloo
+    share_gpu = os.environ.get("HPSDF_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     import hpsdf_loader
     H = hpsdf_loader.load()

@@ -250,39 +250,38 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
     const hpsdf_build::Slice sl = b->slices[b->rank];
     const bool sampled = innermost(field)->kind == kHostCallback;
 
-    // ---- pass 1: count the fits of every shape.  class id = 2*degree + (incremental ? 1 : 0)
-    constexpr int kClasses = 2 * (kMaxDegree + 1);
-    uint32_t classCount[kClasses] = {0};
+    // ---- pass 1: count the fits of every shape.  A class = (degree, from-scratch | incremental, depth):
+    //      all cells of a workgroup share these, so the kernel forms each basis product once.
+    constexpr int kDepths = kMaxDepth + 2;
+    constexpr int kClasses = 2 * (kMaxDegree + 1) * kDepths;
+    auto classOf = [](int degree, bool incremental, int depth) { return (2 * degree + (incremental ? 1 : 0)) * kDepths + depth; };
+    std::vector<uint32_t> classCount(kClasses, 0);
     for (uint64_t jl = 0; jl < sl.count; ++jl) {
         const hpsdf_build::HeapEnt& e = b->batch[sl.first + jl];
         const hpsdf_node& n = b->nodes[e.idx];
         if (std::fabs(e.err - HPSDF_INITIAL_NODE_ERR) < DBL_EPSILON) {
-            classCount[2 * 2] += 1;  // Octree.cpp:836-843: degree-2 fit from scratch
+            classCount[classOf(2, false, n.depth)] += 1;  // Octree.cpp:836-843: degree-2 fit from scratch
             continue;
         }
-        if (n.depth < kMaxDepth) classCount[2 * n.degree] += 8;            // :814-822
-        if (n.degree < kMaxDegree - 1) classCount[2 * (n.degree + 1) + 1] += 1;  // :846-851
+        if (n.depth < kMaxDepth) classCount[classOf(n.degree, false, n.depth + 1)] += 8;          // :814-822
+        if (n.degree < kMaxDegree - 1) classCount[classOf(n.degree + 1, true, n.depth)] += 1;  // :846-851
     }
-    uint32_t classFirst[kClasses + 1];
-    classFirst[0] = 0;
+    std::vector<uint32_t> classFirst(kClasses + 1, 0);
     for (int c = 0; c < kClasses; ++c) classFirst[c + 1] = classFirst[c] + classCount[c];
     const uint32_t nTasks = classFirst[kClasses];
 
-    // ---- workgroup table: G fits of one shape per workgroup
+    // ---- workgroup table
     uint32_t nBlocks = 0;
-    int classG[kClasses], classPlanes[kClasses];
-    uint32_t classBlockFirst[kClasses + 1];
+    std::vector<FitShape> classShape(kClasses);
+    std::vector<uint32_t> classBlockFirst(kClasses + 1, 0);
     for (int c = 0; c < kClasses; ++c) {
-        classG[c] = 1;
-        classPlanes[c] = 1;
         classBlockFirst[c] = nBlocks;
         if (!classCount[c]) continue;
-        const int deg = c / 2;
-        const int nrows = (c & 1) ? (int)(T.coeffCount[deg] - T.coeffCount[deg - 1]) : (int)T.coeffCount[deg];
-        const int g = fitCellsPerBlock(deg, nrows, classCount[c]);
-        classG[c] = g;
-        classPlanes[c] = fitPlanesPerChunk(deg, g);
-        nBlocks += (classCount[c] + g - 1) / g;
+        const int deg = c / kDepths / 2;
+        const bool incr = (c / kDepths) & 1;
+        const int nrows = incr ? (int)(T.coeffCount[deg] - T.coeffCount[deg - 1]) : (int)T.coeffCount[deg];
+        classShape[c] = fitShape(deg, nrows, classCount[c]);
+        nBlocks += (classCount[c] + classShape[c].cells - 1) / classShape[c].cells;
     }
     classBlockFirst[kClasses] = nBlocks;
     hipError_t he = ws.tasks.ensure(std::max<uint32_t>(1, nTasks));
@@ -292,28 +291,29 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
     {
         uint32_t bi = 0;
         for (int c = 0; c < kClasses; ++c) {
-            const int deg = c / 2, g = classG[c];
+            if (!classCount[c]) continue;
+            const int deg = c / kDepths / 2, g = classShape[c].cells;
+            const bool incr = (c / kDepths) & 1;
             for (uint32_t i = 0; i < classCount[c]; i += g) {
                 FitBlock& fb = ws.blocks.host[bi++];
                 std::memset(&fb, 0, sizeof fb);
                 fb.firstTask = classFirst[c] + i;
                 fb.nTasks = (uint16_t)std::min<uint32_t>(g, classCount[c] - i);
                 fb.degree = (uint8_t)deg;
-                fb.planesPerChunk = (uint8_t)classPlanes[c];
-                fb.rowStart = (uint16_t)((c & 1) ? T.coeffCount[deg - 1] : 0);
+                fb.planesPerChunk = (uint8_t)classShape[c].planes;
+                fb.rowStart = (uint16_t)(incr ? T.coeffCount[deg - 1] : 0);
                 fb.rowEnd = (uint16_t)T.coeffCount[deg];
+                fb.depth = (uint8_t)(c % kDepths);
             }
         }
     }
 
     // ---- pass 2: fill the tasks, grouped by shape; arena offsets and sample offsets in job order
-    uint32_t cursor[kClasses];
-    for (int c = 0; c < kClasses; ++c) cursor[c] = classFirst[c];
+    std::vector<uint32_t> cursor(classFirst.begin(), classFirst.end() - 1);
     uint64_t arenaNeed = 0, sampleNeed = 0;
-    auto addTask = [&](int cls, const float* bmin, const float* bmax, int depth, uint32_t errSlot) {
-        const int deg = cls / 2;
-        const uint64_t rows = (cls & 1) ? T.coeffCount[deg] - T.coeffCount[deg - 1] : T.coeffCount[deg];
-        FitTask& t = ws.tasks.host[cursor[cls]++];
+    auto addTask = [&](int deg, bool incr, const float* bmin, const float* bmax, int depth, uint32_t errSlot) {
+        const uint64_t rows = incr ? T.coeffCount[deg] - T.coeffCount[deg - 1] : T.coeffCount[deg];
+        FitTask& t = ws.tasks.host[cursor[classOf(deg, incr, depth)]++];
         for (int a = 0; a < 3; ++a) {
             t.bmin[a] = bmin[a];
             t.bmax[a] = bmax[a];
@@ -336,7 +336,7 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
         hpsdf_build::JobOut& jo = b->jobOut[jl];
         const uint32_t slot0 = (uint32_t)(jl * HPSDF_JOB_HEADER_DOUBLES);
         if (std::fabs(e.err - HPSDF_INITIAL_NODE_ERR) < DBL_EPSILON) {
-            jo.pOff = addTask(2 * 2, n.aabb_min, n.aabb_max, n.depth, slot0);
+            jo.pOff = addTask(2, false, n.aabb_min, n.aabb_max, n.depth, slot0);
             jo.pHost = 0;
             b->stats.fits += 1;
             continue;
@@ -348,12 +348,12 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
             for (unsigned i = 0; i < 8; ++i) {
                 float cmin[3], cmax[3];
                 cornerBox(n.aabb_min, n.aabb_max, i, cmin, cmax);
-                addTask(2 * p, cmin, cmax, d + 1, slot0 + 1 + i);
+                addTask(p, false, cmin, cmax, d + 1, slot0 + 1 + i);
             }
             b->stats.fits += 8;
         }
         if (p < kMaxDegree - 1) {  // degree 11 is never raised (:600)
-            jo.pOff = addTask(2 * (p + 1) + 1, n.aabb_min, n.aabb_max, d, slot0);
+            jo.pOff = addTask(p + 1, true, n.aabb_min, n.aabb_max, d, slot0);
             jo.pHost = 0;
             b->stats.fits += 1;
         }
@@ -437,12 +437,23 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
     HPSDF_HIP(hipMemsetAsync(ws.errs.dev, 0, std::max<uint64_t>(1, sl.count * HPSDF_JOB_HEADER_DOUBLES) * sizeof(double),
                              ctx->stream));
     // one launch per shape class: the degree is a compile-time constant of the kernel
-    for (int c = 0; c < kClasses; ++c) {
-        const uint32_t nb = classBlockFirst[c + 1] - classBlockFirst[c];
-        if (!nb) continue;
-        const int deg = c / 2;
-        HPSDF_HIP(launchFit(ctx->stream, deg, ws.blocks.dev + classBlockFirst[c], nb, fitLdsBytes(deg, classG[c], classPlanes[c]),
-                            ws.tasks.dev, ws.arena, ws.errs.dev, ctx->dTables, fd, rm));
+    // the blocks of one degree are contiguous (classes are ordered degree-major) and carry their own rows and
+    // depth, so one launch per (degree, cells-per-thread) run covers them
+    for (int c = 0; c < kClasses;) {
+        if (!classCount[c]) {
+            ++c;
+            continue;
+        }
+        const int deg = c / kDepths / 2, cpt = classShape[c].cellsPerThread;
+        size_t ldsBytes = 0;
+        int e = c;
+        while (e < kClasses && e / kDepths / 2 == deg && (!classCount[e] || classShape[e].cellsPerThread == cpt)) {
+            if (classCount[e]) ldsBytes = std::max(ldsBytes, classShape[e].ldsBytes);
+            ++e;
+        }
+        HPSDF_HIP(launchFit(ctx->stream, deg, cpt, ws.blocks.dev + classBlockFirst[c], classBlockFirst[e] - classBlockFirst[c],
+                            ldsBytes, ws.tasks.dev, ws.arena, ws.errs.dev, ctx->dTables, fd, rm));
+        c = e;
     }
     b->computed = true;
     return HPSDF_OK;

@@ -716,8 +716,8 @@ int hpsdf_bench_fit(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* 
     const Tables& T = tables();
     const uint64_t nc = T.coeffCount[degree];
     const int nrows = (int)nc;
-    const int g = fitCellsPerBlock(degree, nrows, (uint32_t)std::min<uint64_t>(nCells, 0xFFFFFFFFull));
-    const int planes = fitPlanesPerChunk(degree, g);
+    const FitShape shape = fitShape(degree, nrows, (uint32_t)std::min<uint64_t>(nCells, 0xFFFFFFFFull));
+    const int g = shape.cells, planes = shape.planes;
     std::vector<FitTask> tasks(nCells);
     const uint64_t side = 1ull << depth;
     const float h = 1.0f / (float)side;
@@ -741,6 +741,7 @@ int hpsdf_bench_fit(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* 
         fb.nTasks = (uint16_t)std::min<uint64_t>(g, nCells - i);
         fb.degree = (uint8_t)degree;
         fb.planesPerChunk = (uint8_t)planes;
+        fb.depth = (uint8_t)depth;
         fb.rowStart = 0;
         fb.rowEnd = (uint16_t)nc;
         blocks.push_back(fb);
@@ -765,12 +766,12 @@ int hpsdf_bench_fit(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* 
         rm.bounds[a] = (double)(cfg->root_max[a] - cfg->root_min[a]);
         rm.centre[a] = (double)((cfg->root_min[a] + cfg->root_max[a]) / 2.0f);
     }
-    const size_t lds = fitLdsBytes(degree, g, planes);
+    const size_t lds = shape.ldsBytes;
     if (e == hipSuccess && rc == HPSDF_OK) {
-        e = launchFit(ctx->stream, degree, dB, (uint32_t)blocks.size(), lds, dT, dA, dE, ctx->dTables, fd, rm);  // warm-up
+        e = launchFit(ctx->stream, degree, shape.cellsPerThread, dB, (uint32_t)blocks.size(), lds, dT, dA, dE, ctx->dTables, fd, rm);  // warm-up
         if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
         for (int r = 0; r < repeats && e == hipSuccess; ++r)
-            e = launchFit(ctx->stream, degree, dB, (uint32_t)blocks.size(), lds, dT, dA, dE, ctx->dTables, fd, rm);
+            e = launchFit(ctx->stream, degree, shape.cellsPerThread, dB, (uint32_t)blocks.size(), lds, dT, dA, dE, ctx->dTables, fd, rm);
         if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
         if (e == hipSuccess) e = hipEventSynchronize(e1);
         float ms = 0.f;

@@ -93,7 +93,8 @@ struct FitBlock {
     uint8_t degree;  // target degree -> (4*degree+1)^3 samples
     uint8_t planesPerChunk;  // i-planes of samples staged in LDS at a time
     uint16_t rowStart, rowEnd;  // coefficient rows computed: [rowStart,rowEnd)
-    uint32_t pad1;
+    uint8_t depth;              // depth of every cell of the workgroup
+    uint8_t pad1[3];
 };
 
 struct PackItem {  // gather of one leaf's coefficients into the packed store

@@ -567,19 +567,6 @@ __global__ __launch_bounds__(256) void field_kernel(FieldDev f, const DeviceTabl
 constexpr int kFitThreads = 256;
 
 // acc += sum_k ((a1 * tk[k]) * n2) * F[k], k ascending
-template <int NQ>
-__device__ __forceinline__ double fitRowFixed(double acc, double a1, const double (&tk)[NQ], double n2,
-                                              const double* __restrict__ F) {
-    double f[NQ];
-#pragma unroll
-    for (int k = 0; k < NQ; ++k) f[k] = F[k];
-#pragma unroll
-    for (int k = 0; k < NQ; ++k) {
-        const double lp = a1 * tk[k] * n2;
-        acc = acc + lp * f[k];
-    }
-    return acc;
-}
 __device__ __forceinline__ double fitRowAny(double acc, double a1, const double* __restrict__ tk, double n2,
                                             const double* __restrict__ F, int nq) {
     int k = 0;
@@ -595,11 +582,15 @@ __device__ __forceinline__ double fitRowAny(double acc, double a1, const double*
     return acc;
 }
 
-template <int KIND, bool CSG, int DEG>
+// R > 1 (DEG > 0 only): a thread owns one row of R cells.  The product Lp of a sample does not depend on
+// the cell (all cells of a workgroup share degree and depth), so it is formed once per sample and used
+// for R accumulators: 2 + 3/R multiply/add instructions per (cell, sample, row) instead of 5.
+template <int KIND, bool CSG, int DEG, int R>
 __global__ __launch_bounds__(kFitThreads) void fit_kernel(const FitBlock* __restrict__ blocks,
                                                           const FitTask* __restrict__ tasks, double* __restrict__ arena,
                                                           double* __restrict__ errs, const DeviceTables* __restrict__ T,
                                                           FieldDev field, RootMap rm) {
+    static_assert(R == 1 || DEG > 0, "cell blocking needs a compile-time degree");
     extern __shared__ double lds[];
     __shared__ double sNl[13 * 11];
     __shared__ double sRec[26];
@@ -610,6 +601,7 @@ __global__ __launch_bounds__(kFitThreads) void fit_kernel(const FitBlock* __rest
     const int rowStart = blk.rowStart, rowEnd = blk.rowEnd, nrows = rowEnd - rowStart;
     const int gl = nq * (nq - 1) / 2;  // Legendre.h: rule n starts at n(n-1)/2 (:1016-1017)
     const int planes = blk.planesPerChunk;  // i-planes per chunk
+    const int depth = blk.depth;            // every cell of the workgroup has this depth
 
     double* sT = lds;               // [deg+1][nq]  LpX(p, root_q)
     double* sR = sT + (deg + 1) * nq;  // [nq] roots
@@ -644,15 +636,15 @@ __global__ __launch_bounds__(kFitThreads) void fit_kernel(const FitBlock* __rest
     }
     __syncthreads();
 
-    // phase-2 ownership: thread -> (cell g, row r); cells with > 256 rows use two rows per thread
+    // phase-2 ownership: thread -> (cell slot, row); a slot is R consecutive cells; cells with > 256 rows
+    // (any-degree kernel only) use two rows per thread
     const bool wide = nrows > kFitThreads;
-    const int g2 = wide ? 0 : tid / nrows;
+    const int slot = wide ? 0 : tid / nrows;
+    const int g2 = slot * R;  // first cell of this thread
     const int r0 = rowStart + (wide ? tid : tid % nrows);
     const int r1 = r0 + kFitThreads;
-    const bool act0 = wide ? (r0 < rowEnd) : (tid < G * nrows);
+    const bool act0 = wide ? (r0 < rowEnd) : (tid < ((G + R - 1) / R) * nrows);
     const bool act1 = wide && r1 < rowEnd;
-    int depth = 0;
-    if (act0) depth = tasks[blk.firstTask + g2].depth;
     int i0a = 0, i1a = 0, i2a = 0, i0b = 0, i1b = 0, i2b = 0;
     double n0a = 0, n1a = 0, n2a = 0, n0b = 0, n1b = 0, n2b = 0;
     if (act0) {
@@ -669,17 +661,30 @@ __global__ __launch_bounds__(kFitThreads) void fit_kernel(const FitBlock* __rest
 #pragma unroll
         for (int k = 0; k < NQF; ++k) tkReg[k] = sT[i2a * nq + k];
     }
-    double acc0 = 0.0, acc1 = 0.0;  // :1025
+    double acc[R];  // :1025
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.0;
+    double acc1 = 0.0;
 
     const int cellStride = planes * nq2;  // doubles per cell in sF
     for (int iBase = 0; iBase < nq; iBase += planes) {
         const int np = min(planes, nq - iBase);
         // ---- phase 1: F on planes [iBase, iBase+np) of every cell (:1035-1040)
         const int chunkSamples = np * nq2, total = G * chunkSamples;
+        const float invChunk = 1.0f / (float)chunkSamples;
         for (int s = tid; s < total; s += kFitThreads) {
-            const int g = s / chunkSamples, rem = s - g * chunkSamples;
-            const int il = rem / nq2, jk = rem - il * nq2, j = jk / nq, k = jk - j * nq, i = iBase + il;
+            // s -> (cell g, sample rem) without an integer division by the run-time chunk size
+            int g = (int)(((float)s + 0.5f) * invChunk);
+            int rem = s - g * chunkSamples;
+            if (rem < 0) {
+                --g;
+                rem += chunkSamples;
+            } else if (rem >= chunkSamples) {
+                ++g;
+                rem -= chunkSamples;
+            }
             const double* c = sC + 8 * g;
+            const int il = rem / nq2, jk = rem - il * nq2, j = jk / nq, k = jk - j * nq, i = iBase + il;
             const double ux = sR[i] * c[0] + c[3], uy = sR[j] * c[1] + c[4], uz = sR[k] * c[2] + c[5];
             const double wx = ux * rm.bounds[0] + rm.centre[0];  // Octree.cpp:327
             const double wy = uy * rm.bounds[1] + rm.centre[1];
@@ -698,10 +703,22 @@ __global__ __launch_bounds__(kFitThreads) void fit_kernel(const FitBlock* __rest
                 const double a0 = sT[i0a * nq + iBase + il] * n0a;
                 for (int j = 0; j < nq; ++j) {
                     const double a1 = a0 * tj[j] * n1a;
-                    if (DEG > 0)
-                        acc0 = fitRowFixed<NQF>(acc0, a1, tkReg, n2a, F + j * nq);
-                    else
-                        acc0 = fitRowAny(acc0, a1, tk, n2a, F + j * nq, nq);
+                    if constexpr (DEG > 0) {
+                        double lp[NQF];
+#pragma unroll
+                        for (int k = 0; k < NQF; ++k) lp[k] = a1 * tkReg[k] * n2a;
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            const double* Fr = F + r * cellStride + j * nq;
+                            double f[NQF];
+#pragma unroll
+                            for (int k = 0; k < NQF; ++k) f[k] = Fr[k];
+#pragma unroll
+                            for (int k = 0; k < NQF; ++k) acc[r] = acc[r] + lp[k] * f[k];
+                        }
+                    } else {
+                        acc[0] = fitRowAny(acc[0], a1, tk, n2a, F + j * nq, nq);
+                    }
                 }
             }
         }
@@ -722,8 +739,12 @@ __global__ __launch_bounds__(kFitThreads) void fit_kernel(const FitBlock* __rest
 
     // coefficients out (outOff addresses row rowStart); stash the new rows in LDS for the error sum
     if (act0) {
-        arena[tasks[blk.firstTask + g2].outOff + (r0 - rowStart)] = acc0;
-        sF[g2 * nrows + (r0 - rowStart)] = acc0;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (g2 + r < G) {
+                arena[tasks[blk.firstTask + g2 + r].outOff + (r0 - rowStart)] = acc[r];
+                sF[(g2 + r) * nrows + (r0 - rowStart)] = acc[r];
+            }
     }
     if (act1) {
         arena[tasks[blk.firstTask].outOff + (r1 - rowStart)] = acc1;
@@ -733,15 +754,15 @@ __global__ __launch_bounds__(kFitThreads) void fit_kernel(const FitBlock* __rest
     // the earlier fit of this cell put them (the host keeps a segment chain per node).
     __syncthreads();
     // :1062-1069  error = sum of squares of the rows of total degree == deg, in row order
-    if (tid < G) {
+    for (int g = tid; g < G; g += kFitThreads) {
         const int first = deg > 0 ? (int)T->count[deg - 1] : 0;
         double e = 0.0;
         for (int r = first > rowStart ? first : rowStart; r < rowEnd; ++r)
             if (T->bidx[r][3] == deg) {
-                const double c = sF[tid * nrows + (r - rowStart)];
+                const double c = sF[g * nrows + (r - rowStart)];
                 e = e + c * c;
             }
-        errs[tasks[blk.firstTask + tid].errSlot] = e;
+        errs[tasks[blk.firstTask + g].errSlot] = e;
     }
 }
 
@@ -766,41 +787,61 @@ size_t fitLdsBytes(int degree, int nTasks, int planes) {
     return ((size_t)(degree + 1) * nq + 2 * nq + 8 * (size_t)nTasks + (size_t)nTasks * planes * nq * nq) * sizeof(double);
 }
 
-int fitPlanesPerChunk(int degree, int nTasks) {
-    const int nq = 4 * degree + 1;
-    int planes = nq;
-    while (planes > 1 && fitLdsBytes(degree, nTasks, planes) > kFitChunkLdsBytes) --planes;
-    return planes;
-}
-
-int fitCellsPerBlock(int degree, int nrows, uint32_t count) {
-    int gmax = nrows > kFitBlockThreads ? 1 : kFitBlockThreads / nrows;
-    while (gmax > 1 && fitLdsBytes(degree, gmax, 1) > kFitMaxLdsBytes) --gmax;
+// Shape of the workgroups of one class: `count` fits of `nrows` coefficient rows at `degree`.
+FitShape fitShape(int degree, int nrows, uint32_t count) {
+    FitShape sh;
+    const int slots = nrows > kFitThreads ? 1 : kFitThreads / nrows;
+    // Cell blocking (4 cells per thread sharing each basis product) is implemented in the kernel but measured
+    // slower on MI355X (p=2, 65536 cells: 296 us vs 240 us): its 64 KB of LDS per workgroup leaves two workgroups
+    // per CU to hide the phase barriers, and the kernel is not VALU-bound (52 % VALU-active).  Kept off.
+    sh.cellsPerThread = 1;
+    (void)count;
+    int gmax = slots * sh.cellsPerThread;
+    while (gmax > sh.cellsPerThread && fitLdsBytes(degree, gmax, 1) > kFitMaxLdsBytes) gmax -= sh.cellsPerThread;
+    if (fitLdsBytes(degree, gmax, 1) > kFitMaxLdsBytes) {  // blocking does not fit: fall back
+        sh.cellsPerThread = 1;
+        gmax = slots;
+        while (gmax > 1 && fitLdsBytes(degree, gmax, 1) > kFitMaxLdsBytes) --gmax;
+    }
     // enough workgroups to cover the chip twice before cells are stacked into one workgroup
-    int g = (int)std::min<uint32_t>((uint32_t)gmax, std::max<uint32_t>(1, (count + 511) / 512));
-    if (const char* e = std::getenv("HPSDF_FIT_G")) g = std::max(1, std::min(gmax, std::atoi(e)));  // tuning knob
-    return g;
+    int g = sh.cellsPerThread > 1 ? gmax
+                                  : (int)std::min<uint32_t>((uint32_t)gmax, std::max<uint32_t>(1, (count + 511) / 512));
+    if (const char* e = std::getenv("HPSDF_FIT_G")) {  // tuning knobs
+        sh.cellsPerThread = 1;
+        g = std::max(1, std::min(slots, std::atoi(e)));
+        while (g > 1 && fitLdsBytes(degree, g, 1) > kFitMaxLdsBytes) --g;
+    }
+    sh.cells = g;
+    const int nq = 4 * degree + 1;
+    const size_t budget = sh.cellsPerThread > 1 ? kFitMaxLdsBytes : kFitChunkLdsBytes;
+    sh.planes = nq;
+    while (sh.planes > 1 && fitLdsBytes(degree, g, sh.planes) > budget) --sh.planes;
+    sh.ldsBytes = fitLdsBytes(degree, g, sh.planes);
+    return sh;
 }
 
 template <int KIND, bool CSG>
-static void launchFitT(hipStream_t stream, int degree, const FitBlock* dBlocks, uint32_t nBlocks, size_t ldsBytes,
-                       const FitTask* dTasks, double* dArena, double* dErrs, const DeviceTables* dTables,
-                       const FieldDev& field, const RootMap& rm) {
-#define HPSDF_FIT_CASE(D)                                                                                          \
-    case D:                                                                                                        \
-        hipLaunchKernelGGL((fit_kernel<KIND, CSG, D>), dim3(nBlocks), dim3(kFitThreads), ldsBytes, stream, dBlocks, \
-                           dTasks, dArena, dErrs, dTables, field, rm);                                             \
+static void launchFitT(hipStream_t stream, int degree, int cellsPerThread, const FitBlock* dBlocks, uint32_t nBlocks,
+                       size_t ldsBytes, const FitTask* dTasks, double* dArena, double* dErrs,
+                       const DeviceTables* dTables, const FieldDev& field, const RootMap& rm) {
+#define HPSDF_FIT_LAUNCH(D, RR)                                                                                       \
+    hipLaunchKernelGGL((fit_kernel<KIND, CSG, D, RR>), dim3(nBlocks), dim3(kFitThreads), ldsBytes, stream, dBlocks, \
+                       dTasks, dArena, dErrs, dTables, field, rm)
+#define HPSDF_FIT_CASE(D)       \
+    case D:                     \
+        HPSDF_FIT_LAUNCH(D, 1); \
         break;
+    if (cellsPerThread != 1 && cellsPerThread != 4) cellsPerThread = 1;
     switch (degree) {
         HPSDF_FIT_CASE(2)
         HPSDF_FIT_CASE(3)
         HPSDF_FIT_CASE(4)
         HPSDF_FIT_CASE(5)
         default:
-            hipLaunchKernelGGL((fit_kernel<KIND, CSG, 0>), dim3(nBlocks), dim3(kFitThreads), ldsBytes, stream, dBlocks,
-                               dTasks, dArena, dErrs, dTables, field, rm);
+            HPSDF_FIT_LAUNCH(0, 1);
     }
 #undef HPSDF_FIT_CASE
+#undef HPSDF_FIT_LAUNCH
 }
 
 #define HPSDF_DISPATCH_FIELD(FN, field, ...)                                     \
@@ -824,13 +865,13 @@ static void launchFitT(hipStream_t stream, int degree, const FitBlock* dBlocks, 
 
 // One launch per degree: `degree` selects the compile-time-specialised kernel (0 = any; the blocks then carry
 // their own degree).
-hipError_t launchFit(hipStream_t stream, int degree, const FitBlock* dBlocks, uint32_t nBlocks, size_t ldsBytes,
-                     const FitTask* dTasks, double* dArena, double* dErrs, const DeviceTables* dTables,
-                     const FieldDev& field, const RootMap& rm) {
+hipError_t launchFit(hipStream_t stream, int degree, int cellsPerThread, const FitBlock* dBlocks, uint32_t nBlocks,
+                     size_t ldsBytes, const FitTask* dTasks, double* dArena, double* dErrs,
+                     const DeviceTables* dTables, const FieldDev& field, const RootMap& rm) {
     if (nBlocks == 0) return hipSuccess;
     if (ldsBytes > kFitMaxLdsBytes) return hipErrorInvalidValue;
-    HPSDF_DISPATCH_FIELD(launchFitT, field, stream, degree, dBlocks, nBlocks, ldsBytes, dTasks, dArena, dErrs, dTables,
-                         field, rm);
+    HPSDF_DISPATCH_FIELD(launchFitT, field, stream, degree, cellsPerThread, dBlocks, nBlocks, ldsBytes, dTasks, dArena,
+                         dErrs, dTables, field, rm);
     return hipGetLastError();
 }
 

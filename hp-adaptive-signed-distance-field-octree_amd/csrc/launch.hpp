@@ -14,11 +14,16 @@ constexpr int kFitBlockThreads = 256;
 
 constexpr size_t kFitChunkLdsBytes = 40 * 1024;  // sample planes staged per chunk (keeps >= 3 workgroups per CU)
 size_t fitLdsBytes(int degree, int nTasks, int planes);
-int fitPlanesPerChunk(int degree, int nTasks);
-// fits of one shape stacked into one workgroup (count = fits of that shape in the launch)
-int fitCellsPerBlock(int degree, int nrows, uint32_t count);
+struct FitShape {
+    int cells;           // fits per workgroup
+    int cellsPerThread;  // 1, or 4 with cell blocking
+    int planes;          // i-planes staged per chunk
+    size_t ldsBytes;
+};
+FitShape fitShape(int degree, int nrows, uint32_t count);
 
-hipError_t launchFit(hipStream_t stream, int degree, const FitBlock* dBlocks, uint32_t nBlocks, size_t ldsBytes,
+
+hipError_t launchFit(hipStream_t stream, int degree, int cellsPerThread, const FitBlock* dBlocks, uint32_t nBlocks, size_t ldsBytes,
                      const FitTask* dTasks, double* dArena, double* dErrs, const DeviceTables* dTables,
                      const FieldDev& field, const RootMap& rm);
 hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dXyz, size_t n,
