@@ -559,3 +559,21 @@ class Octree:
             o.FromMemoryBlock(self.block)
             o.stats = self.stats
         return o
+
+
+def load_obj(path):
+    """Minimal OBJ reader for the mesh field: `v x y z` and triangular `f a b c` / `a/t/n` / `a//n` records
+    (the three face formats Source/Meshing/ObjParser.cpp:11-164 accepts).  Returns (verts f32 [n,3], tris u64 [m,3]),
+    0-based.  One-off host preprocessing, not part of the hot path."""
+    verts, tris = [], []
+    with open(path) as fh:
+        for line in fh:
+            if line.startswith("v "):
+                p = line.split()
+                verts.append((float(p[1]), float(p[2]), float(p[3])))
+            elif line.startswith("f "):
+                idx = [int(tok.split("/")[0]) for tok in line.split()[1:]]
+                if len(idx) != 3:
+                    raise ValueError("only triangles are supported: " + line.strip())
+                tris.append([i - 1 if i > 0 else len(verts) + i for i in idx])
+    return np.asarray(verts, np.float32), np.asarray(tris, np.uint64)

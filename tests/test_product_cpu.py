@@ -168,3 +168,17 @@ def test_product_sources_do_not_touch_the_oracle():
                 assert "liboracle" not in txt and "hp_oracle" not in txt and "import oracle" not in txt, fn
     for fn in ("hpsdf.h", "hpsdf_octree.hpp"):
         assert "oracle" not in open(os.path.join(ROOT, "include", fn)).read().replace("oracle/", "").lower() or True
+
+
+def test_obj_loader_and_reference_mesh_fixture(H, O, tmp_path):
+    p = tmp_path / "tet.obj"
+    p.write_text("# tetrahedron\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\nvn 0 0 1\nf 1 3 2\nf 1/1/1 2/2/1 4/3/1\nf 2//1 3//1 4//1\nf -4 -1 -2\n")
+    v, t = H.load_obj(str(p))
+    assert v.shape == (4, 3) and v.dtype == np.float32
+    assert t.tolist() == [[0, 2, 1], [0, 1, 3], [1, 2, 3], [0, 3, 2]]
+    O.MeshField(v, t)  # closed: every half-edge has a twin
+    with pytest.raises(ValueError):
+        O.MeshField(v, t[:3])  # open mesh is rejected like Mesh::CreateHalfEdges (Mesh.cpp:121-128)
+    d = np.load(os.path.join(ROOT, "tests", "golden", "halfedge_fail_mesh.npz"))
+    assert d["verts"].shape == (11422, 3) and d["tris"].shape == (22840, 3)
+    O.MeshField(d["verts"], d["tris"].astype(np.uint64))
