@@ -135,10 +135,14 @@ int builderBegin(hpsdf_build* b, const hpsdf_config* cfg, const hpsdf_build_opts
         for (int a = 0; a < 3; ++a) vol *= (cfg->root_max[a] - cfg->root_min[a]);
         if (!(vol > 0.0f)) return fail(HPSDF_ERR_INVALID_ARGUMENT, "root volume must be > 0");
     }
-    if (cfg->weighting_type != 0)
-        return fail(HPSDF_ERR_UNSUPPORTED,
-                    "nearnessWeighting != None draws from std::rand() in the reference (Octree.cpp:1209-1247) and is "
-                    "not part of the GPU path yet");
+    if (cfg->weighting_type > 2) return fail(HPSDF_ERR_INVALID_ARGUMENT, "unknown nearnessWeighting.type");
+    if (cfg->weighting_type != 0) {
+        if (!(cfg->weighting_strength > 0.0)) return fail(HPSDF_ERR_INVALID_ARGUMENT, "nearnessWeighting.strength must be > 0");
+        if (opts && opts->world > 1)
+            return fail(HPSDF_ERR_UNSUPPORTED,
+                        "nearness weighting needs every node's previous coefficients on the fitting rank: single-rank builds only");
+    }
+    b->weighted = cfg->weighting_type != 0;
     b->cfg = *cfg;
     std::memset(b->cfg.pad0, 0, sizeof b->cfg.pad0);
     std::memset(b->cfg.pad1, 0, sizeof b->cfg.pad1);
@@ -280,13 +284,15 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
         const int deg = c / kDepths / 2;
         const bool incr = (c / kDepths) & 1;
         const int nrows = incr ? (int)(T.coeffCount[deg] - T.coeffCount[deg - 1]) : (int)T.coeffCount[deg];
-        classShape[c] = fitShape(deg, nrows, classCount[c]);
+        classShape[c] = fitShape(deg, nrows, classCount[c], b->weighted);
         nBlocks += (classCount[c] + classShape[c].cells - 1) / classShape[c].cells;
     }
     classBlockFirst[kClasses] = nBlocks;
     hipError_t he = ws.tasks.ensure(std::max<uint32_t>(1, nTasks));
     if (he == hipSuccess) he = ws.blocks.ensure(std::max<uint32_t>(1, nBlocks));
-    if (he == hipSuccess) he = ws.errs.ensure(std::max<uint64_t>(1, sl.count * HPSDF_JOB_HEADER_DOUBLES));
+    // errs: [jobs][9] errors, followed (weighted builds) by [jobs][9] |mean FApprox| values
+    const uint64_t nSlots = std::max<uint64_t>(1, sl.count * HPSDF_JOB_HEADER_DOUBLES);
+    if (he == hipSuccess) he = ws.errs.ensure(2 * nSlots);
     if (he != hipSuccess) return hipFail(he, "workspace allocation");
     {
         uint32_t bi = 0;
@@ -304,6 +310,7 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
                 fb.rowStart = (uint16_t)(incr ? T.coeffCount[deg - 1] : 0);
                 fb.rowEnd = (uint16_t)T.coeffCount[deg];
                 fb.depth = (uint8_t)(c % kDepths);
+                fb.weighted = b->weighted ? 1 : 0;
             }
         }
     }
@@ -311,15 +318,16 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
     // ---- pass 2: fill the tasks, grouped by shape; arena offsets and sample offsets in job order
     std::vector<uint32_t> cursor(classFirst.begin(), classFirst.end() - 1);
     uint64_t arenaNeed = 0, sampleNeed = 0;
-    auto addTask = [&](int deg, bool incr, const float* bmin, const float* bmax, int depth, uint32_t errSlot) {
-        const uint64_t rows = incr ? T.coeffCount[deg] - T.coeffCount[deg - 1] : T.coeffCount[deg];
+    auto addTask = [&](int deg, bool incr, const float* bmin, const float* bmax, int depth, uint32_t errSlot,
+                       uint64_t copyOff = kNone) {
+        const uint64_t rows = (incr && !b->weighted) ? T.coeffCount[deg] - T.coeffCount[deg - 1] : T.coeffCount[deg];
         FitTask& t = ws.tasks.host[cursor[classOf(deg, incr, depth)]++];
         for (int a = 0; a < 3; ++a) {
             t.bmin[a] = bmin[a];
             t.bmax[a] = bmax[a];
         }
         t.outOff = b->arenaUsed + arenaNeed;
-        t.copyOff = kNone;
+        t.copyOff = copyOff;
         t.sampleOff = sampleNeed;
         t.errSlot = errSlot;
         t.depth = (uint8_t)depth;
@@ -353,7 +361,14 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
             b->stats.fits += 8;
         }
         if (p < kMaxDegree - 1) {  // degree 11 is never raised (:600)
-            jo.pOff = addTask(p + 1, true, n.aabb_min, n.aabb_max, d, slot0);
+            uint64_t prev = kNone;
+            if (b->weighted) {
+                const int64_t sg = b->segHead[e.idx];
+                if (sg < 0 || b->segs[sg].hostStore || b->segs[sg].owner != b->rank)
+                    return fail(HPSDF_ERR_STATE, "weighted incremental fit without the node's previous coefficients in HBM");
+                prev = b->segs[sg].off;
+            }
+            jo.pOff = addTask(p + 1, true, n.aabb_min, n.aabb_max, d, slot0, prev);
             jo.pHost = 0;
             b->stats.fits += 1;
         }
@@ -434,8 +449,7 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
         HPSDF_HIP(hipMemcpyAsync(ws.tasks.dev, ws.tasks.host, nTasks * sizeof(FitTask), hipMemcpyHostToDevice, ctx->stream));
         HPSDF_HIP(hipMemcpyAsync(ws.blocks.dev, ws.blocks.host, nBlocks * sizeof(FitBlock), hipMemcpyHostToDevice, ctx->stream));
     }
-    HPSDF_HIP(hipMemsetAsync(ws.errs.dev, 0, std::max<uint64_t>(1, sl.count * HPSDF_JOB_HEADER_DOUBLES) * sizeof(double),
-                             ctx->stream));
+    HPSDF_HIP(hipMemsetAsync(ws.errs.dev, 0, (b->weighted ? 2 : 1) * nSlots * sizeof(double), ctx->stream));
     // one launch per shape class: the degree is a compile-time constant of the kernel
     // the blocks of one degree are contiguous (classes are ordered degree-major) and carry their own rows and
     // depth, so one launch per (degree, cells-per-thread) run covers them
@@ -452,7 +466,7 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
             ++e;
         }
         HPSDF_HIP(launchFit(ctx->stream, deg, cpt, ws.blocks.dev + classBlockFirst[c], classBlockFirst[e] - classBlockFirst[c],
-                            ldsBytes, ws.tasks.dev, ws.arena, ws.errs.dev, ctx->dTables, fd, rm));
+                            ldsBytes, ws.tasks.dev, ws.arena, ws.errs.dev, ws.errs.dev + nSlots, ctx->dTables, fd, rm));
         c = e;
     }
     b->computed = true;
@@ -468,7 +482,7 @@ int builderInject(hpsdf_build* b, uint64_t job, const double* pCoeffs, const dou
     const bool coarse = std::fabs(e.err - HPSDF_INITIAL_NODE_ERR) < DBL_EPSILON;
     hpsdf_build::JobOut& jo = b->jobOut[job - sl.first];
     if (pCoeffs) {
-        const uint64_t rs = coarse ? 0 : ncoef(n.degree), re = coarse ? ncoef(2) : ncoef(n.degree + 1);
+        const uint64_t rs = (coarse || b->weighted) ? 0 : ncoef(n.degree), re = coarse ? ncoef(2) : ncoef(n.degree + 1);
         jo.pOff = b->hostStore.size();
         jo.pHost = 1;
         b->hostStore.insert(b->hostStore.end(), pCoeffs + rs, pCoeffs + re);
@@ -521,8 +535,9 @@ int builderApply(hpsdf_build* b, const double* headers) {
             const int np = coarse ? 2 : p + 1;
             hpsdf_build::Seg s;
             s.off = mine ? jo->pOff : kNone;
-            s.rowStart = coarse ? 0u : (uint32_t)T.coeffCount[p];
+            s.rowStart = (coarse || b->weighted) ? 0u : (uint32_t)T.coeffCount[p];
             s.rowEnd = (uint32_t)T.coeffCount[np];
+            if (b->weighted) b->segHead[idx] = b->segTail[idx] = -1;  // the new array holds every row
             s.owner = owner;
             s.hostStore = mine ? jo->pHost : 0;
             s.next = -1;

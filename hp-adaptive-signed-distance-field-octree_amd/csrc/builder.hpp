@@ -26,6 +26,9 @@ struct hpsdf_build {
     hpsdf_config cfg{};
     uint64_t K = HPSDF_DEFAULT_JOBS_PER_ROUND;
     int rank = 0, world = 1;
+    // nearness weighting (Octree.cpp:1071-1092): every fit also evaluates its own polynomial, so each node
+    // keeps ONE full coefficient array (an incremental fit copies the old rows) instead of a segment chain
+    bool weighted = false;
 
     // ---- tree state (identical on every rank)
     struct Seg {

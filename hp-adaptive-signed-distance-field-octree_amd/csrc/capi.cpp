@@ -570,6 +570,7 @@ int hpsdf_build_round_compute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field*
 int hpsdf_build_round_results_device(hpsdf_build* b, double** dHeaders, uint64_t* n) {
     if (!b) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null build");
     if (!b->roundOpen || !b->computed) return fail(HPSDF_ERR_STATE, "round not computed");
+    if (b->weighted) return fail(HPSDF_ERR_UNSUPPORTED, "weighted builds apply the weight on the host: use hpsdf_build_round_results_host");
     if (dHeaders) *dHeaders = b->ws ? b->ws->errs.dev : nullptr;
     if (n) *n = b->slices[b->rank].count * HPSDF_JOB_HEADER_DOUBLES;
     return HPSDF_OK;
@@ -581,9 +582,30 @@ int hpsdf_build_round_results_host(hpsdf_build* b, hpsdf_ctx* ctx, double* out) 
     if (!b->roundOpen || !b->computed) return fail(HPSDF_ERR_STATE, "round not computed");
     const uint64_t n = b->slices[b->rank].count * HPSDF_JOB_HEADER_DOUBLES;
     HPSDF_HIP(hipSetDevice(ctx->device));
-    if (n) HPSDF_HIP(hipMemcpyAsync(b->ws->errs.host, b->ws->errs.dev, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    const uint64_t nSlots = std::max<uint64_t>(1, n);
+    if (n) {
+        HPSDF_HIP(hipMemcpyAsync(b->ws->errs.host, b->ws->errs.dev, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (b->weighted)
+            HPSDF_HIP(hipMemcpyAsync(b->ws->errs.host + nSlots, b->ws->errs.dev + nSlots, n * sizeof(double),
+                                     hipMemcpyDeviceToHost, ctx->stream));
+    }
     HPSDF_HIP(hipStreamSynchronize(ctx->stream));
     if (n) std::memcpy(out, b->ws->errs.host, n * sizeof(double));
+    if (b->weighted) {
+        // Octree.cpp:1078-1086: error * weight, the weight from |mean FApprox| (:1224-1226 / :1246)
+        const double d = std::sqrt(3.0), strength = b->cfg.weighting_strength;
+        const double* mean = b->ws->errs.host + nSlots;
+        for (uint64_t i = 0; i < n; ++i) {
+            double w;
+            if (b->cfg.weighting_type == 1) {
+                const double k = std::pow(1.0 - mean[i] / d, strength);
+                w = std::min<double>(1.0, std::max<double>(k, 0.0));
+            } else {
+                w = std::exp(-1.0 * strength * mean[i] / d);
+            }
+            out[i] = out[i] * w;
+        }
+    }
     return HPSDF_OK;
     HPSDF_CATCH
 }
@@ -716,7 +738,7 @@ int hpsdf_bench_fit(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* 
     const Tables& T = tables();
     const uint64_t nc = T.coeffCount[degree];
     const int nrows = (int)nc;
-    const FitShape shape = fitShape(degree, nrows, (uint32_t)std::min<uint64_t>(nCells, 0xFFFFFFFFull));
+    const FitShape shape = fitShape(degree, nrows, (uint32_t)std::min<uint64_t>(nCells, 0xFFFFFFFFull), false);
     const int g = shape.cells, planes = shape.planes;
     std::vector<FitTask> tasks(nCells);
     const uint64_t side = 1ull << depth;
@@ -768,10 +790,10 @@ int hpsdf_bench_fit(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* 
     }
     const size_t lds = shape.ldsBytes;
     if (e == hipSuccess && rc == HPSDF_OK) {
-        e = launchFit(ctx->stream, degree, shape.cellsPerThread, dB, (uint32_t)blocks.size(), lds, dT, dA, dE, ctx->dTables, fd, rm);  // warm-up
+        e = launchFit(ctx->stream, degree, shape.cellsPerThread, dB, (uint32_t)blocks.size(), lds, dT, dA, dE, nullptr, ctx->dTables, fd, rm);  // warm-up
         if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
         for (int r = 0; r < repeats && e == hipSuccess; ++r)
-            e = launchFit(ctx->stream, degree, shape.cellsPerThread, dB, (uint32_t)blocks.size(), lds, dT, dA, dE, ctx->dTables, fd, rm);
+            e = launchFit(ctx->stream, degree, shape.cellsPerThread, dB, (uint32_t)blocks.size(), lds, dT, dA, dE, nullptr, ctx->dTables, fd, rm);
         if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
         if (e == hipSuccess) e = hipEventSynchronize(e1);
         float ms = 0.f;

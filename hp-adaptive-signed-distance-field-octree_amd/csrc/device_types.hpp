@@ -79,7 +79,8 @@ struct RootMap {
 struct FitTask {
     float bmin[3], bmax[3];  // cell box in unit-cube coordinates (exact dyadics)
     uint64_t outOff;         // arena offset (doubles) where row FitBlock::rowStart of this fit goes
-    uint64_t copyOff;        // reserved
+                             // (row 0 when FitBlock::weighted: the fit then owns a full coefficient array)
+    uint64_t copyOff;        // weighted incremental fit: arena offset of the cell's previous full array
     uint64_t sampleOff;      // kFieldSamples: offset of this fit's first sample value
     uint32_t errSlot;        // where the returned error goes
     uint8_t depth;
@@ -94,7 +95,8 @@ struct FitBlock {
     uint8_t planesPerChunk;  // i-planes of samples staged in LDS at a time
     uint16_t rowStart, rowEnd;  // coefficient rows computed: [rowStart,rowEnd)
     uint8_t depth;              // depth of every cell of the workgroup
-    uint8_t pad1[3];
+    uint8_t weighted;           // also produce |mean FApprox| over 100 sample points (nearness weighting)
+    uint8_t pad1[2];
 };
 
 struct PackItem {  // gather of one leaf's coefficients into the packed store

@@ -566,6 +566,13 @@ __global__ __launch_bounds__(256) void field_kernel(FieldDev f, const DeviceTabl
 
 constexpr int kFitThreads = 256;
 
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
 // acc += sum_k ((a1 * tk[k]) * n2) * F[k], k ascending
 __device__ __forceinline__ double fitRowAny(double acc, double a1, const double* __restrict__ tk, double n2,
                                             const double* __restrict__ F, int nq) {
@@ -588,8 +595,8 @@ __device__ __forceinline__ double fitRowAny(double acc, double a1, const double*
 template <int KIND, bool CSG, int DEG, int R>
 __global__ __launch_bounds__(kFitThreads) void fit_kernel(const FitBlock* __restrict__ blocks,
                                                           const FitTask* __restrict__ tasks, double* __restrict__ arena,
-                                                          double* __restrict__ errs, const DeviceTables* __restrict__ T,
-                                                          FieldDev field, RootMap rm) {
+                                                          double* __restrict__ errs, double* __restrict__ means,
+                                                          const DeviceTables* __restrict__ T, FieldDev field, RootMap rm) {
     static_assert(R == 1 || DEG > 0, "cell blocking needs a compile-time degree");
     extern __shared__ double lds[];
     __shared__ double sNl[13 * 11];
@@ -737,21 +744,32 @@ __global__ __launch_bounds__(kFitThreads) void fit_kernel(const FitBlock* __rest
         __syncthreads();
     }
 
-    // coefficients out (outOff addresses row rowStart); stash the new rows in LDS for the error sum
+    // coefficients out; the new rows are also stashed in LDS for the error sum.  Plain fits write only their
+    // rows (outOff addresses row rowStart; an incremental fit, :847/:1012, leaves rows [0,rowStart) where the
+    // earlier fit of the cell put them).  Weighted fits keep one full array per cell: outOff addresses row 0.
+    const bool weighted = blk.weighted != 0;
+    const int stashStride = weighted ? rowEnd : nrows, stashBase = weighted ? 0 : rowStart;
     if (act0) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
             if (g2 + r < G) {
-                arena[tasks[blk.firstTask + g2 + r].outOff + (r0 - rowStart)] = acc[r];
-                sF[(g2 + r) * nrows + (r0 - rowStart)] = acc[r];
+                arena[tasks[blk.firstTask + g2 + r].outOff + (r0 - stashBase)] = acc[r];
+                sF[(g2 + r) * stashStride + (r0 - stashBase)] = acc[r];
             }
     }
     if (act1) {
-        arena[tasks[blk.firstTask].outOff + (r1 - rowStart)] = acc1;
-        sF[r1 - rowStart] = acc1;
+        arena[tasks[blk.firstTask].outOff + (r1 - stashBase)] = acc1;
+        sF[r1 - stashBase] = acc1;
     }
-    // An incremental fit (:847, :1012) writes only its new rows: the rows [0,rowStart) stay where
-    // the earlier fit of this cell put them (the host keeps a segment chain per node).
+    if (weighted && rowStart > 0) {  // carry the old rows over (:847)
+        for (int s = tid; s < G * rowStart; s += kFitThreads) {
+            const int g = s / rowStart, r = s - g * rowStart;
+            const FitTask& tk = tasks[blk.firstTask + g];
+            const double v = arena[tk.copyOff + r];
+            arena[tk.outOff + r] = v;
+            sF[g * stashStride + r] = v;
+        }
+    }
     __syncthreads();
     // :1062-1069  error = sum of squares of the rows of total degree == deg, in row order
     for (int g = tid; g < G; g += kFitThreads) {
@@ -759,10 +777,38 @@ __global__ __launch_bounds__(kFitThreads) void fit_kernel(const FitBlock* __rest
         double e = 0.0;
         for (int r = first > rowStart ? first : rowStart; r < rowEnd; ++r)
             if (T->bidx[r][3] == deg) {
-                const double c = sF[g * nrows + (r - rowStart)];
+                const double c = sF[g * stashStride + (r - stashBase)];
                 e = e + c * c;
             }
         errs[tasks[blk.firstTask + g].errSlot] = e;
+    }
+    if (!weighted) return;
+    // ---- nearness weighting, Octree.cpp:1209-1247: |mean of FApprox over 100 points of the cell|.  The points
+    //      come from a hash of (cell, sample, axis) instead of std::rand; the weight itself
+    //      (pow / exp) is applied by the host so that it matches the CPU path bit for bit.
+    double* sV = sF + G * stashStride;  // [G][100]
+    for (int s = tid; s < G * 100; s += kFitThreads) {
+        const int g = s / 100, n = s - g * 100;
+        const FitTask& tk = tasks[blk.firstTask + g];
+        const uint64_t ka = (uint64_t)__float_as_uint(tk.bmin[0]) | ((uint64_t)__float_as_uint(tk.bmin[1]) << 32);
+        const uint64_t kb = (uint64_t)__float_as_uint(tk.bmin[2]) | ((uint64_t)(unsigned)depth << 32) |
+                            ((uint64_t)(unsigned)deg << 40);
+        const uint64_t key = splitmix64(ka) ^ splitmix64(kb ^ 0xD1B54A32D192ED03ull);
+        double u[3];
+        for (int a = 0; a < 3; ++a) {
+            const float r = (float)(splitmix64(key + ((uint64_t)n * 3 + (uint64_t)a) * 0x9E3779B97F4A7C15ull) >> 40) *
+                            (1.0f / 16777216.0f);
+            const double pt = (double)(tk.bmin[a] + (tk.bmax[a] - tk.bmin[a]) * r);  // AlignedBox3f::sample()
+            u[a] = (pt - sC[8 * g + 3 + a]) * (double)(2 << depth);                   // :862
+        }
+        sV[s] = evalLeafGeneric(sF + g * stashStride, deg, u[0], u[1], u[2], depth, sNl, sRec);
+    }
+    __syncthreads();
+    for (int g = tid; g < G; g += kFitThreads) {
+        double fIntegral = 0.0;
+        for (int n = 0; n < 100; ++n) fIntegral = fIntegral + sV[g * 100 + n];
+        fIntegral = fIntegral / 100.0;
+        means[tasks[blk.firstTask + g].errSlot] = fabs(fIntegral);
     }
 }
 
@@ -788,7 +834,7 @@ size_t fitLdsBytes(int degree, int nTasks, int planes) {
 }
 
 // Shape of the workgroups of one class: `count` fits of `nrows` coefficient rows at `degree`.
-FitShape fitShape(int degree, int nrows, uint32_t count) {
+FitShape fitShape(int degree, int nrows, uint32_t count, bool weighted) {
     FitShape sh;
     const int slots = nrows > kFitThreads ? 1 : kFitThreads / nrows;
     // Cell blocking (4 cells per thread sharing each basis product) is implemented in the kernel but measured
@@ -817,16 +863,24 @@ FitShape fitShape(int degree, int nrows, uint32_t count) {
     sh.planes = nq;
     while (sh.planes > 1 && fitLdsBytes(degree, g, sh.planes) > budget) --sh.planes;
     sh.ldsBytes = fitLdsBytes(degree, g, sh.planes);
+    if (weighted) {
+        // the sample region is reused for the full coefficient array + 100 FApprox values of every cell
+        const int need = coeffCount(degree) + 100;
+        const int minPlanes = (need + nq * nq - 1) / (nq * nq);
+        sh.planes = std::max(sh.planes, std::min(nq, minPlanes));
+        while (sh.cells > 1 && fitLdsBytes(degree, sh.cells, sh.planes) > kFitMaxLdsBytes) --sh.cells;
+        sh.ldsBytes = fitLdsBytes(degree, sh.cells, sh.planes);
+    }
     return sh;
 }
 
 template <int KIND, bool CSG>
 static void launchFitT(hipStream_t stream, int degree, int cellsPerThread, const FitBlock* dBlocks, uint32_t nBlocks,
-                       size_t ldsBytes, const FitTask* dTasks, double* dArena, double* dErrs,
+                       size_t ldsBytes, const FitTask* dTasks, double* dArena, double* dErrs, double* dMeans,
                        const DeviceTables* dTables, const FieldDev& field, const RootMap& rm) {
 #define HPSDF_FIT_LAUNCH(D, RR)                                                                                       \
     hipLaunchKernelGGL((fit_kernel<KIND, CSG, D, RR>), dim3(nBlocks), dim3(kFitThreads), ldsBytes, stream, dBlocks, \
-                       dTasks, dArena, dErrs, dTables, field, rm)
+                       dTasks, dArena, dErrs, dMeans, dTables, field, rm)
 #define HPSDF_FIT_CASE(D)       \
     case D:                     \
         HPSDF_FIT_LAUNCH(D, 1); \
@@ -866,12 +920,12 @@ static void launchFitT(hipStream_t stream, int degree, int cellsPerThread, const
 // One launch per degree: `degree` selects the compile-time-specialised kernel (0 = any; the blocks then carry
 // their own degree).
 hipError_t launchFit(hipStream_t stream, int degree, int cellsPerThread, const FitBlock* dBlocks, uint32_t nBlocks,
-                     size_t ldsBytes, const FitTask* dTasks, double* dArena, double* dErrs,
+                     size_t ldsBytes, const FitTask* dTasks, double* dArena, double* dErrs, double* dMeans,
                      const DeviceTables* dTables, const FieldDev& field, const RootMap& rm) {
     if (nBlocks == 0) return hipSuccess;
     if (ldsBytes > kFitMaxLdsBytes) return hipErrorInvalidValue;
     HPSDF_DISPATCH_FIELD(launchFitT, field, stream, degree, cellsPerThread, dBlocks, nBlocks, ldsBytes, dTasks, dArena,
-                         dErrs, dTables, field, rm);
+                         dErrs, dMeans, dTables, field, rm);
     return hipGetLastError();
 }
 

@@ -20,12 +20,12 @@ struct FitShape {
     int planes;          // i-planes staged per chunk
     size_t ldsBytes;
 };
-FitShape fitShape(int degree, int nrows, uint32_t count);
+FitShape fitShape(int degree, int nrows, uint32_t count, bool weighted);
 
 
 hipError_t launchFit(hipStream_t stream, int degree, int cellsPerThread, const FitBlock* dBlocks, uint32_t nBlocks, size_t ldsBytes,
-                     const FitTask* dTasks, double* dArena, double* dErrs, const DeviceTables* dTables,
-                     const FieldDev& field, const RootMap& rm);
+                     const FitTask* dTasks, double* dArena, double* dErrs, double* dMeans,
+                     const DeviceTables* dTables, const FieldDev& field, const RootMap& rm);
 hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dXyz, size_t n,
                        double* dOut);
 hipError_t launchFieldEval(hipStream_t stream, const FieldDev& f, const DeviceTables* dTables, const double* dXyz,

@@ -303,6 +303,61 @@ void ora_corner_aabb(const float bmin[3], const float bmax[3], unsigned i, float
     }
 }
 
+/* ---- nearness weighting, Octree.cpp:1209-1247 ---------------------------------
+ * The reference averages FApprox over 100 points drawn with aabb.sample(), i.e. std::rand(): run-to-run
+ * different and unpinnable.  The restatement keeps the arithmetic and replaces the generator by a pure
+ * function of (cell, sample, axis): SplitMix64 -> 24 bits -> f32 in [0,1).  PARITY UNPINNED against the
+ * reference beyond the statistics of the mean; product and oracle agree bit-for-bit with each other. */
+static uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static uint32_t f32_bits(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+uint64_t ora_weight_key(const float bmin[3], int depth, int degree) {
+    const uint64_t a = (uint64_t)f32_bits(bmin[0]) | ((uint64_t)f32_bits(bmin[1]) << 32);
+    const uint64_t b = (uint64_t)f32_bits(bmin[2]) | ((uint64_t)(unsigned)depth << 32) | ((uint64_t)(unsigned)degree << 40);
+    return splitmix64(a) ^ splitmix64(b ^ 0xD1B54A32D192ED03ull);
+}
+/* |mean of FApprox over the 100 sample points| (:1215-1222 / :1236-1243) */
+double ora_weight_mean(const double* coeffs, int degree, const float bmin[3], const float bmax[3], int depth) {
+    const uint64_t key = ora_weight_key(bmin, depth, degree);
+    const uint64_t nSamples = 100;
+    double fIntegral = 0.0;
+    for (uint64_t i = 0; i < nSamples; ++i) {
+        double pt[3];
+        for (int a = 0; a < 3; ++a) {
+            /* AlignedBox3f::sample(): min + (max - min) * r in f32, then cast<f64>() */
+            const float r = (float)(splitmix64(key + (i * 3 + (uint64_t)a) * 0x9E3779B97F4A7C15ull) >> 40) * (1.0f / 16777216.0f);
+            pt[a] = (double)(bmin[a] + (bmax[a] - bmin[a]) * r);
+        }
+        fIntegral += ora_fapprox(coeffs, degree, bmin, bmax, pt, depth);
+    }
+    fIntegral /= (double)nSamples;
+    return fabs(fIntegral);
+}
+double ora_weight_from_mean(int type, double strength, double mean) {
+    const double d = sqrt(3.0);
+    if (type == 1) { /* CalculatePolyWeighting :1224-1226 */
+        const double k = pow(1.0 - mean / d, strength);
+        const double m = (k < 0.0) ? 0.0 : k;   /* std::max<f64>(k, 0.0) */
+        return (m < 1.0) ? m : 1.0;             /* std::min<f64>(1.0, .) */
+    }
+    if (type == 2) return exp(-1.0 * strength * mean / d); /* CalculateExpWeighting :1246 */
+    return 1.0;
+}
+double ora_poly_weighting(const double* coeffs, int degree, const float bmin[3], const float bmax[3], int depth, double strength) {
+    return ora_weight_from_mean(1, strength, ora_weight_mean(coeffs, degree, bmin, bmax, depth));
+}
+double ora_exp_weighting(const double* coeffs, int degree, const float bmin[3], const float bmax[3], int depth, double strength) {
+    return ora_weight_from_mean(2, strength, ora_weight_mean(coeffs, degree, bmin, bmax, depth));
+}
+
 /* Octree::FitPolynomial, Octree.cpp:1007-1093 with the callback wrapper of
  * Octree.cpp:322-328 folded in (F = F_(pt * rootBounds + centre)). */
 double ora_fit_polynomial(const ora_field* f, const ora_config* cfg, double* coeffs, int basis_degree,
@@ -364,9 +419,12 @@ double ora_fit_polynomial(const ora_field* f, const ora_config* cfg, double* coe
     double newError = 0.0;
     for (uint64_t i = 0; i < endingIdx; ++i)
         if ((g_bidx[i][0] + g_bidx[i][1] + g_bidx[i][2]) == (uint64_t)degree) newError += coeffs[i] * coeffs[i];
-    /* nearness weighting None (:1073-1076).  Polynomial/Exponential weighting
-     * (:1209-1247) draws from std::rand() and is parity-unpinned; not restated. */
-    return newError;
+    /* :1071-1092 */
+    switch (cfg->weighting_type) {
+        case 1: return newError * ora_poly_weighting(coeffs, degree, bmin, bmax, depth, cfg->weighting_strength);
+        case 2: return newError * ora_exp_weighting(coeffs, degree, bmin, bmax, depth, cfg->weighting_strength);
+        default: return newError;
+    }
 }
 
 /* EstimateHImprovement (Octree.cpp:804-826), EstimatePImprovement (:829-856),

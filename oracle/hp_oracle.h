@@ -18,7 +18,8 @@
  *     topology or serialisation vectors, and Source/HP/Octree.cpp itself is
  *     UNBUILDABLE here (needs Eigen, which is neither vendored nor installed),
  *     so coefficient-level parity against the reference binary is
- *     "parity unpinned" beyond those values.
+ *     "parity unpinned" beyond those values.  Nearness weighting (Octree.cpp:1209-1247) draws from
+ *     std::rand() in the reference: restated with a hashed generator, parity unpinned by construction.
  *
  * Every function cites the reference file:line it restates (paths relative to
  * /root/reference).
@@ -111,13 +112,21 @@ double ora_field_eval(const ora_field* f, const double pt[3]);
 /* Octree::LpX, Octree.cpp:988-1004 */
 double ora_lpx(uint64_t p, double x);
 
-/* Octree::FitPolynomial, Octree.cpp:1007-1093 (nearness weighting None).
+/* Octree::FitPolynomial, Octree.cpp:1007-1093 (error times the nearness weight when cfg->weighting_type != 0).
  * coeffs holds ncoef(degree) doubles; rows < ncoef(basis_degree) are kept when
  * basis_degree > 0.  `literal` != 0 re-runs LpX in the innermost loop exactly
  * as the reference does; 0 uses per-axis tables of the same values (bitwise
  * identical result, tests/test_oracle_fit.py). */
 double ora_fit_polynomial(const ora_field* f, const ora_config* cfg, double* coeffs, int basis_degree,
                           const float bmin[3], const float bmax[3], int degree, int depth, int literal);
+
+/* Nearness weighting, Octree.cpp:1209-1247, with a deterministic stand-in for aabb.sample() (std::rand in the
+ * reference): parity unpinned, see hp_oracle.c */
+uint64_t ora_weight_key(const float bmin[3], int depth, int degree);
+double ora_weight_mean(const double* coeffs, int degree, const float bmin[3], const float bmax[3], int depth);
+double ora_weight_from_mean(int type, double strength, double mean);
+double ora_poly_weighting(const double* coeffs, int degree, const float bmin[3], const float bmax[3], int depth, double strength);
+double ora_exp_weighting(const double* coeffs, int degree, const float bmin[3], const float bmax[3], int depth, double strength);
 
 /* Octree::CornerAABB, Octree.cpp:1096-1112 */
 void ora_corner_aabb(const float bmin[3], const float bmax[3], unsigned i, float omin[3], float omax[3]);

@@ -307,3 +307,21 @@ def test_create_on_reference_mesh(H, ctx):
     assert np.median(np.abs(q - v)) < 2e-3 and np.mean(np.abs(q - v) < 2e-2) > 0.97
     blk2, _ = H.create_block(ctx, H.make_config(1e-5, tuple(lo), tuple(hi)), f, 1024)
     assert blk2 == t.ToMemoryBlock()  # run-to-run deterministic
+
+
+# ------------------------------------------------------------------ nearness weighting (SURVEY 8 a-W)
+@pytest.mark.parametrize("wtype,target", [(1, 1e-8), (2, 1e-10)])
+def test_weighted_create_matches_oracle(H, O, ctx, wtype, target):
+    """Source/Tests/HPUnitTests.cpp:53-58 (Polynomial, strength 3, 1e-8) and HPBenchmarks.cpp:34-39 (Exponential, 3,
+    1e-10).  The reference samples the weight with std::rand (unpinnable); oracle and GPU share a hashed sampler, so
+    they must agree bit for bit with each other, and the reference's accuracy bar must hold."""
+    cfg = H.make_config(target)
+    cfg.nearnessWeighting_type, cfg.nearnessWeighting_strength = wtype, 3.0
+    blk, st = H.create_block(ctx, cfg, H.Field.sphere(), 1024)
+    ocfg = O.default_config(target)
+    ocfg.weighting_type, ocfg.weighting_strength = wtype, 3.0
+    ot = O.Tree.create(ocfg, O.sphere_field(), 1024)
+    assert blk == ot.to_block()
+    assert st["jobs"] == ot.stats["jobs"] and st["h_refines"] == ot.stats["h_refines"]
+    p = O.splitmix64_points(100000, seed=8)
+    assert np.abs(H.DeviceTree(ctx, blk).query(p) - O.sphere_field().eval(p)).max() <= 0.01

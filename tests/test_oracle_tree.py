@@ -116,3 +116,23 @@ def test_from_block_rejects_garbage(O):
         O.Tree.from_block(b"\x00" * 10)
     with pytest.raises(ValueError):
         O.Tree.from_block(np.array([10 ** 9], np.uint64).tobytes() + b"\x00" * 200)
+
+
+@pytest.mark.parametrize("wtype", [1, 2])
+def test_weighted_build_is_deterministic_and_accurate(O, wtype):
+    """Nearness weighting (Octree.cpp:1209-1247) with the hashed stand-in for std::rand: the weight only scales the
+    error estimate, so the reference test's accuracy bar (HPUnitTests.cpp:46-77) still has to hold."""
+    cfg = O.default_config(1e-8)
+    cfg.weighting_type, cfg.weighting_strength = wtype, 3.0
+    a = O.Tree.create(cfg, O.sphere_field(), 1024)
+    b = O.Tree.create(cfg, O.sphere_field(), 1024)
+    assert a.to_block() == b.to_block()
+    p = O.splitmix64_points(50000, seed=2)
+    assert np.abs(a.query(p) - O.sphere_field().eval(p)).max() <= 0.01
+    L = O.lib()
+    import ctypes as C
+    L.ora_weight_from_mean.restype = C.c_double
+    L.ora_weight_from_mean.argtypes = [C.c_int, C.c_double, C.c_double]
+    # :1224-1226 clamp to [0,1]; :1246 exp(-s m / sqrt 3)
+    assert L.ora_weight_from_mean(1, 3.0, 0.0) == 1.0 and 0.0 < L.ora_weight_from_mean(1, 3.0, 0.5) < 1.0
+    assert abs(L.ora_weight_from_mean(2, 3.0, 0.5) - np.exp(-1.5 / np.sqrt(3.0))) < 1e-15

@@ -131,10 +131,14 @@ def test_state_machine_errors(H):
     with pytest.raises(H.HpsdfError):
         H.Build(bad)
     w = H.make_config(1e-4)
-    w.nearnessWeighting_type = 1
+    w.nearnessWeighting_type, w.nearnessWeighting_strength = 1, 3.0
+    H.Build(w, 0, 0, 1)  # single rank: supported
     with pytest.raises(H.HpsdfError) as e:
-        H.Build(w)
+        H.Build(w, 0, 0, 2)  # the previous coefficients of a node may live on another rank
     assert e.value.status == H.ERR_UNSUPPORTED
+    w.nearnessWeighting_strength = 0.0
+    with pytest.raises(H.HpsdfError):
+        H.Build(w)
 
 
 def test_analytic_field_validation(H):
