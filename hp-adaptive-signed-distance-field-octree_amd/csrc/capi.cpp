@@ -177,6 +177,8 @@ int hpsdf_ctx_destroy(hpsdf_ctx* c) {
     if (!c) return HPSDF_OK;
     (void)hipSetDevice(c->device);
     if (c->dTables) (void)hipFree(c->dTables);
+    if (c->dDefer) (void)hipFree(c->dDefer);
+    if (c->dDeferCount) (void)hipFree(c->dDeferCount);
     c->ws.release();
     if (c->ownsStream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -437,6 +439,7 @@ int hpsdf_tree_upload(hpsdf_ctx* ctx, const void* block, size_t size, hpsdf_tree
     t->nLeaves = leaves;
     t->maxDegree = maxDeg;
     t->maxDepth = maxDepth;
+    t->allInline = maxDeg <= 2 && maxDepth <= topDepth;
     t->config = cfg;
     hipError_t e = hipMalloc((void**)&t->dNodes, nNodes * sizeof(NodeRec));
     if (e == hipSuccess) e = hipMalloc((void**)&t->dCoeffs, std::max<size_t>(2, padded.size()) * sizeof(double));
@@ -454,6 +457,7 @@ int hpsdf_tree_upload(hpsdf_ctx* ctx, const void* block, size_t size, hpsdf_tree
     t->dev.coeffs = t->dCoeffs;
     t->dev.topDepth = topDepth;
     t->dev.maxDegree = maxDeg;
+    for (int j = 0; j < 3; ++j) t->dev.nlTop[j] = T.normalisedLengths[j][topDepth];
     for (int a = 0; a < 3; ++a) {
         t->dev.rootCentre[a] = (double)((cfg.root_min[a] + cfg.root_max[a]) / 2.0f);  // Octree.cpp:419
         t->dev.rootInvSizes[a] = (double)(1.0f / (cfg.root_max[a] - cfg.root_min[a]));  // Octree.cpp:420
@@ -490,7 +494,20 @@ int hpsdf_query_device(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* dXyz, 
     if (!t || (!dXyz && n) || (!dOut && n)) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
     if (t->device != ctx->device) return fail(HPSDF_ERR_INVALID_ARGUMENT, "tree lives on another device");
     HPSDF_HIP(hipSetDevice(ctx->device));
-    HPSDF_HIP(launchQuery(ctx->stream, t->dev, ctx->dTables, dXyz, n, dOut));
+    if (!ctx->dDeferCount) HPSDF_HIP(hipMalloc((void**)&ctx->dDeferCount, sizeof(uint32_t)));
+    const size_t kChunk = (size_t)1 << 31;  // deferred indices are 32-bit
+    for (size_t off = 0; off < n; off += kChunk) {
+        const size_t m = std::min(kChunk, n - off);
+        if (!t->allInline && ctx->deferCap < m) {
+            if (ctx->dDefer) HPSDF_HIP(hipFree(ctx->dDefer));
+            ctx->dDefer = nullptr;
+            ctx->deferCap = 0;
+            HPSDF_HIP(hipMalloc((void**)&ctx->dDefer, m * sizeof(uint32_t)));
+            ctx->deferCap = m;
+        }
+        HPSDF_HIP(launchQuery(ctx->stream, t->dev, ctx->dTables, dXyz + 3 * off, m, dOut + off, ctx->dDeferCount, ctx->dDefer,
+                              t->allInline));
+    }
     return HPSDF_OK;
     HPSDF_CATCH
 }

@@ -42,6 +42,7 @@ struct TreeDev {
     const double* coeffs;    // per-leaf blocks padded to an even count
     int32_t topDepth;        // every node above this depth is interior (1..5)
     int32_t maxDegree;
+    double nlTop[3];         // NormalisedLengths[j][topDepth], j <= 2 (degrees of the inline leaves)
     double rootCentre[3];    // Octree.cpp:322 (f32 centre widened)
     double rootInvSizes[3];  // Octree.cpp:323 (f32 reciprocal widened)
 };

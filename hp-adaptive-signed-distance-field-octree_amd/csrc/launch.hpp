@@ -27,7 +27,7 @@ hipError_t launchFit(hipStream_t stream, int degree, int cellsPerThread, const F
                      const FitTask* dTasks, double* dArena, double* dErrs, double* dMeans,
                      const DeviceTables* dTables, const FieldDev& field, const RootMap& rm);
 hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dXyz, size_t n,
-                       double* dOut);
+                       double* dOut, uint32_t* dDeferCount, uint32_t* dDeferIdx, bool allInline);
 hipError_t launchFieldEval(hipStream_t stream, const FieldDev& f, const DeviceTables* dTables, const double* dXyz,
                            size_t n, double* dOut);
 hipError_t launchPack(hipStream_t stream, const PackItem* dItems, uint32_t nItems, const double* dArena, double* dOut);

@@ -70,6 +70,10 @@ struct hpsdf_ctx {
     bool ownsStream = false;
     hpsdf::DeviceTables* dTables = nullptr;
     hpsdf::Workspace ws;
+    // Query scratch: indices of the points that need the lane-by-lane pass (+ their count)
+    uint32_t* dDefer = nullptr;
+    uint64_t deferCap = 0;
+    uint32_t* dDeferCount = nullptr;
 };
 
 struct hpsdf_tree {
@@ -80,6 +84,7 @@ struct hpsdf_tree {
     hpsdf::TreeDev dev{};
     uint64_t nNodes = 0, nCoeffs = 0, nLeaves = 0;
     int maxDegree = 0, maxDepth = 0;
+    bool allInline = false;  // every leaf sits in the top table with degree <= 2: Query is one kernel
     hpsdf_config config{};
 };
 

@@ -73,14 +73,16 @@ __device__ __forceinline__ double eval2(const double* cv, double ux, double uy, 
     return f;
 }
 
-enum { V_STREAM = 0, V_STREAM_DESCEND, V_THIN, V_FAT, V_FAT_NT, V_THIN128, V_FAT_K2, V_FAT_K4, V_FAT_1PT, V_FAT_LDSLOAD, V_NOLOAD_FAT, V_COOP, V_COOP_DIRECT, V_FATGATHER_NOEVAL, V_EVAL_FIXEDLEAF, V_COOP_DMA, V_COOP_DMA_NOEVAL, V_COUNT };
+enum { V_STREAM = 0, V_STREAM_DESCEND, V_THIN, V_FAT, V_FAT_NT, V_THIN128, V_FAT_K2, V_FAT_K4, V_FAT_1PT, V_FAT_LDSLOAD, V_NOLOAD_FAT, V_COOP, V_COOP_DIRECT, V_FATGATHER_NOEVAL, V_EVAL_FIXEDLEAF, V_COOP_DMA, V_COOP_DMA_NOEVAL, V_COOP_DMA_HALF, V_COOP_DMA_K2, V_COOP_DMA_BIGLDS, V_COOP_DMA_QUARTER, V_COOP_DMA_EIGHTH, V_COUNT };
 const char* kNames[] = {"stream only (xyz in, 1 add, out)", "stream + descent arithmetic", "thin table + coeffs 80B stride",
                         "fat table (1 line/pt)", "fat + nontemporal stream", "thin table + coeffs 128B stride",
                         "fat, 2 pts/thread interleaved", "fat, 4 pts/thread interleaved", "fat, 1 pt/thread (no grid-stride)",
                         "fat, coalesced 16B loads via LDS", "fat, points synthesised (no HBM read)",
                         "coop: LDS point loads + 8-lane line fetch + LDS transpose", "coop line fetch, strided point loads",
                         "fat gather, no eval (sum coeffs)", "eval with fixed leaf (no gather)",
-                        "coop line fetch by LDS-DMA (global_load_lds x4)", "coop LDS-DMA, no eval"};
+                        "coop line fetch by LDS-DMA (global_load_lds x4)", "coop LDS-DMA, no eval",
+                        "coop LDS-DMA in two half passes (4 KB/wave)", "coop LDS-DMA, 2 tiles per iteration", "coop LDS-DMA + 32 KB dummy LDS",
+                        "coop LDS-DMA in four passes (2 KB/wave)", "coop LDS-DMA in eight passes (1 KB/wave)"};
 
 template <int V>
 __device__ __forceinline__ double onePoint(const Tree& t, double px, double py, double pz) {
@@ -228,6 +230,156 @@ __global__ __launch_bounds__(256) void lab(Tree t, const double* __restrict__ xy
         }
         return;
     }
+    if (V == V_COOP_DMA_BIGLDS) {
+        __shared__ double2 sd[4][8][64];
+        __shared__ double dummy[4096];
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, grp = lane & ~7, j = lane & 7;
+        if (n == 1) dummy[threadIdx.x] = 1.0;
+        for (size_t base = (size_t)blockIdx.x * 256; base < n; base += (size_t)gridDim.x * 256) {
+            const size_t i = base + threadIdx.x < n ? base + threadIdx.x : n - 1;
+            const double px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+            uint32_t code;
+            double cx, cy, cz;
+            descend4(px, py, pz, code, cx, cy, cz);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t ck = __shfl(code, grp | k, 64);
+                const char* src = reinterpret_cast<const char*>(t.fat + ck) + j * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)&sd[w][k][0], 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const double2* row = &sd[w][j][grp];
+            double cv[10];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const double2 v = row[1 + q];
+                cv[2 * q] = v.x, cv[2 * q + 1] = v.y;
+            }
+            const double r = eval2(cv, (px - cx) * 32.0, (py - cy) * 32.0, (pz - cz) * 32.0) + (n == 1 ? dummy[lane] : 0.0);
+            if (base + threadIdx.x < n) out[base + threadIdx.x] = r;
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
+    if (V == V_COOP_DMA_HALF) {
+        __shared__ double2 sd[4][4][64];  // 4 KB per wave
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, grp = lane & ~7, j = lane & 7;
+        for (size_t base = (size_t)blockIdx.x * 256; base < n; base += (size_t)gridDim.x * 256) {
+            const size_t i = base + threadIdx.x < n ? base + threadIdx.x : n - 1;
+            const double px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+            uint32_t code;
+            double cx, cy, cz;
+            descend4(px, py, pz, code, cx, cy, cz);
+            double cv[10];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t ck = __shfl(code, grp | (half * 4 + k), 64);
+                    const char* src = reinterpret_cast<const char*>(t.fat + ck) + j * 16;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)&sd[w][k][0], 16, 0, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                if ((j >> 2) == half) {
+                    const double2* row = &sd[w][j & 3][grp];
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) {
+                        const double2 v = row[1 + q];
+                        cv[2 * q] = v.x, cv[2 * q + 1] = v.y;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+            const double r = eval2(cv, (px - cx) * 32.0, (py - cy) * 32.0, (pz - cz) * 32.0);
+            if (base + threadIdx.x < n) out[base + threadIdx.x] = r;
+        }
+        return;
+    }
+    if (V == V_COOP_DMA_QUARTER || V == V_COOP_DMA_EIGHTH) {
+        constexpr int S = V == V_COOP_DMA_QUARTER ? 2 : 1;  // steps per pass
+        __shared__ double2 sd[4][S][64];
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, grp = lane & ~7, j = lane & 7;
+        for (size_t base = (size_t)blockIdx.x * 256; base < n; base += (size_t)gridDim.x * 256) {
+            const size_t i = base + threadIdx.x < n ? base + threadIdx.x : n - 1;
+            const double px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+            uint32_t code;
+            double cx, cy, cz;
+            descend4(px, py, pz, code, cx, cy, cz);
+            double cv[10];
+#pragma unroll
+            for (int pass = 0; pass < 8 / S; ++pass) {
+#pragma unroll
+                for (int k = 0; k < S; ++k) {
+                    const uint32_t ck = __shfl(code, grp | (pass * S + k), 64);
+                    const char* src = reinterpret_cast<const char*>(t.fat + ck) + j * 16;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)&sd[w][k][0], 16, 0, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                if ((j / S) == pass) {
+                    const double2* row = &sd[w][j % S][grp];
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) {
+                        const double2 v = row[1 + q];
+                        cv[2 * q] = v.x, cv[2 * q + 1] = v.y;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+            const double r = eval2(cv, (px - cx) * 32.0, (py - cy) * 32.0, (pz - cz) * 32.0);
+            if (base + threadIdx.x < n) out[base + threadIdx.x] = r;
+        }
+        return;
+    }
+    if (V == V_COOP_DMA_K2) {
+        __shared__ double2 sd[4][2][8][64];  // two tiles in flight per wave
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, grp = lane & ~7, j = lane & 7;
+        for (size_t base = (size_t)blockIdx.x * 512; base < n; base += (size_t)gridDim.x * 512) {
+            double px[2], py[2], pz[2], cx[2], cy[2], cz[2];
+            uint32_t code[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const size_t i0 = base + h * 256 + threadIdx.x;
+                const size_t i = i0 < n ? i0 : n - 1;
+                px[h] = xyz[3 * i], py[h] = xyz[3 * i + 1], pz[h] = xyz[3 * i + 2];
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                descend4(px[h], py[h], pz[h], code[h], cx[h], cy[h], cz[h]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t ck = __shfl(code[h], grp | k, 64);
+                    const char* src = reinterpret_cast<const char*>(t.fat + ck) + j * 16;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)&sd[w][h][k][0], 16, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const double2* row = &sd[w][h][j][grp];
+                double cv[10];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    const double2 v = row[1 + q];
+                    cv[2 * q] = v.x, cv[2 * q + 1] = v.y;
+                }
+                const double r = eval2(cv, (px[h] - cx[h]) * 32.0, (py[h] - cy[h]) * 32.0, (pz[h] - cz[h]) * 32.0);
+                const size_t i0 = base + h * 256 + threadIdx.x;
+                if (i0 < n) out[i0] = r;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
     if (V == V_FAT_LDSLOAD) {
         __shared__ double sp[256 * 3];
         for (size_t base = (size_t)blockIdx.x * 256; base < n; base += (size_t)gridDim.x * 256) {
@@ -324,7 +476,7 @@ int main(int argc, char** argv) {
         return a;
     };
     const int full = (int)((n + 255) / 256);
-    const int grids[] = {8192, full};
+    const int grids[] = {8192, 16384, full};
 #define RUN(V, blocks)                                                                                         \
     {                                                                                                          \
         float ms = run<V>(t, dx, n, dout, blocks, 10);                                                         \
@@ -347,6 +499,11 @@ int main(int argc, char** argv) {
         RUN(V_EVAL_FIXEDLEAF, g);
         RUN(V_COOP_DMA, g);
         RUN(V_COOP_DMA_NOEVAL, g);
+        RUN(V_COOP_DMA_HALF, g);
+        RUN(V_COOP_DMA_K2, g);
+        RUN(V_COOP_DMA_BIGLDS, g);
+        RUN(V_COOP_DMA_QUARTER, g);
+        RUN(V_COOP_DMA_EIGHTH, g);
         printf("\n");
     }
     return 0;
