@@ -63,8 +63,7 @@ int makeFieldDev(const hpsdf_field* f, const double* dSamples, FieldDev* out) {
             out->mesh.verts = f->dVerts;
             out->mesh.tris = f->dTris;
             out->mesh.halfEdges = f->dHalfEdges;
-            out->mesh.bvhBoxes = f->dBvhBoxes;
-            out->mesh.bvhChild = f->dBvhChild;
+            out->mesh.bvh = f->dBvh;
             out->mesh.nTris = f->nTris;
             out->mesh.nNodes = f->nBvhNodes;
             break;
@@ -248,7 +247,7 @@ int hpsdf_field_create_mesh(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts,
     f->device = ctx->device;
     f->nVerts = (uint32_t)nVerts;
     f->nTris = (uint32_t)nTris;
-    f->nBvhNodes = (uint32_t)(hm.bvhChild.size() / 2);
+    f->nBvhNodes = (uint32_t)hm.bvh.size();
     auto up = [&](void** d, const void* h, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(d, bytes);
         if (e != hipSuccess) return e;
@@ -257,8 +256,7 @@ int hpsdf_field_create_mesh(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts,
     hipError_t e = up((void**)&f->dVerts, hm.verts.data(), hm.verts.size() * sizeof(float));
     if (e == hipSuccess) e = up((void**)&f->dTris, hm.tris.data(), hm.tris.size() * sizeof(uint32_t));
     if (e == hipSuccess) e = up((void**)&f->dHalfEdges, hm.halfEdges.data(), hm.halfEdges.size() * sizeof(uint32_t));
-    if (e == hipSuccess) e = up((void**)&f->dBvhBoxes, hm.bvhBoxes.data(), hm.bvhBoxes.size() * sizeof(float));
-    if (e == hipSuccess) e = up((void**)&f->dBvhChild, hm.bvhChild.data(), hm.bvhChild.size() * sizeof(int32_t));
+    if (e == hipSuccess) e = up((void**)&f->dBvh, hm.bvh.data(), hm.bvh.size() * sizeof(BvhNode));
     if (e != hipSuccess) {
         hpsdf_field_destroy(f);
         return hipFail(e, "mesh upload");
@@ -290,8 +288,7 @@ int hpsdf_field_destroy(hpsdf_field* f) {
         if (f->dVerts) (void)hipFree(f->dVerts);
         if (f->dTris) (void)hipFree(f->dTris);
         if (f->dHalfEdges) (void)hipFree(f->dHalfEdges);
-        if (f->dBvhBoxes) (void)hipFree(f->dBvhBoxes);
-        if (f->dBvhChild) (void)hipFree(f->dBvhChild);
+        if (f->dBvh) (void)hipFree(f->dBvh);
     }
     delete f;
     return HPSDF_OK;

@@ -49,12 +49,22 @@ struct TreeDev {
 
 enum FieldKind : int32_t { kFieldAnalytic = 0, kFieldSamples = 1, kFieldMesh = 2 };
 
+// Binary BVH node, one 64-byte line: the boxes of BOTH children (so a visit decides about both subtrees from
+// one load, and a leaf child is tested against its triangle's box before the triangle itself) and the child
+// references: >= 0 an inner node, < 0 the triangle ~c.
+struct alignas(64) BvhNode {
+    float lo0[3], hi0[3];
+    float lo1[3], hi1[3];
+    int32_t c0, c1;
+    uint32_t pad[2];
+};
+static_assert(sizeof(BvhNode) == 64, "one line per node");
+
 struct MeshDev {
     const float* verts;        // xyz per vertex
     const uint32_t* tris;      // 3 vertex ids per triangle
     const uint32_t* halfEdges; // twin half-edge per half-edge (Mesh.h:74)
-    const float* bvhBoxes;     // 6 floats per BVH node (min xyz, max xyz)
-    const int32_t* bvhChild;   // 2 ints per node: >= 0 child node, < 0 => ~triangle index (leaf)
+    const BvhNode* bvh;        // node 0 is the root
     uint32_t nTris, nNodes;
 };
 

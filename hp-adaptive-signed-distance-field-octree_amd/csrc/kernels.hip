@@ -170,26 +170,16 @@ __device__ V3 pseudoNormal(const MeshDev& m, uint32_t t, int code) {
     return normalized(n);
 }
 
-// Closest triangle by stack traversal of the device BVH, nearest child first.
-// Ties on squared distance go to the lower triangle index, and boxes are only
-// pruned when strictly farther than the running best (with a guard band for
-// f32 rounding of the box distance), so the winner equals the linear scan of
-// Mesh::ClosestTriangleToPt (Mesh.cpp:134-159).
-__device__ float meshSignedDistance(const MeshDev& m, V3 pt) {
+// Closest triangle by stack traversal of the device BVH, nearer child first.  Ties on squared distance go to
+// the lower triangle index, and a box is pruned only when it is strictly farther than the running best (with a
+// guard band for f32 rounding of the box distance), so the winner equals the linear scan of
+// Mesh::ClosestTriangleToPt (Mesh.cpp:134-159) whatever the visiting order.  `hint` (the winner of the
+// caller's previous, nearby query) is tested first so that the bound is tight from the start.
+__device__ float meshSignedDistance(const MeshDev& m, V3 pt, uint32_t& hint) {
     float best = FLT_MAX;
     uint32_t bestTri = 0xFFFFFFFFu;
     int bestCode = 8;
     V3 bestQ = {0.0f, 0.0f, 0.0f};
-    int32_t stack[64];
-    int sp = 0;
-    stack[sp++] = 0;
-    auto boxDist = [&](int32_t node) {
-        const float* bx = m.bvhBoxes + 6 * (size_t)node;
-        const float cx = fminf(fmaxf(pt.x, bx[0]), bx[3]);
-        const float cy = fminf(fmaxf(pt.y, bx[1]), bx[4]);
-        const float cz = fminf(fmaxf(pt.z, bx[2]), bx[5]);
-        return sqnorm(pt - V3{cx, cy, cz});
-    };
     auto visitTri = [&](uint32_t t) {
         V3 q;
         const int code =
@@ -202,28 +192,52 @@ __device__ float meshSignedDistance(const MeshDev& m, V3 pt) {
             bestQ = q;
         }
     };
+    auto boxDist = [&](const float* lo, const float* hi) {
+        const float cx = fminf(fmaxf(pt.x, lo[0]), hi[0]);
+        const float cy = fminf(fmaxf(pt.y, lo[1]), hi[1]);
+        const float cz = fminf(fmaxf(pt.z, lo[2]), hi[2]);
+        return sqnorm(pt - V3{cx, cy, cz});
+    };
+    auto worthIt = [&](float d) { return !(d > best * 1.00001f + 1e-30f); };
+    if (hint < m.nTris) visitTri(hint);
+    int32_t stack[48];
+    float stackD[48];
+    int sp = 0;
+    stack[sp] = 0;
+    stackD[sp++] = 0.0f;
     while (sp > 0) {
-        const int32_t node = stack[--sp];
-        if (node < 0) {
-            visitTri((uint32_t)~node);
-            continue;
+        --sp;
+        if (!worthIt(stackD[sp])) continue;  // the bound may have tightened since the push
+        const BvhNode n = m.bvh[stack[sp]];
+        const float d0 = boxDist(n.lo0, n.hi0), d1 = boxDist(n.lo1, n.hi1);
+        // nearer child first; leaves are resolved at once (they tighten the bound for the sibling)
+        const bool swap = d1 < d0;
+        const int32_t ca = swap ? n.c1 : n.c0, cb = swap ? n.c0 : n.c1;
+        const float da = swap ? d1 : d0, db = swap ? d0 : d1;
+        int32_t pushA = -1;
+        if (worthIt(da)) {
+            if (ca < 0)
+                visitTri((uint32_t)~ca);
+            else
+                pushA = ca;
         }
-        if (boxDist(node) > best * 1.00001f + 1e-30f) continue;
-        const int32_t c0 = m.bvhChild[2 * (size_t)node], c1 = m.bvhChild[2 * (size_t)node + 1];
-        const float d0 = c0 < 0 ? 0.0f : boxDist(c0);
-        const float d1 = c1 < 0 ? 0.0f : boxDist(c1);
-        // push the farther child first so the nearer is popped next
-        if (d0 <= d1) {
-            if (sp < 63) stack[sp++] = c1;
-            stack[sp++] = c0;
-        } else {
-            if (sp < 63) stack[sp++] = c0;
-            stack[sp++] = c1;
+        if (worthIt(db)) {
+            if (cb < 0)
+                visitTri((uint32_t)~cb);
+            else if (sp < 47) {
+                stack[sp] = cb;
+                stackD[sp++] = db;
+            }
+        }
+        if (pushA >= 0 && sp < 48) {  // on top: popped next
+            stack[sp] = pushA;
+            stackD[sp++] = da;
         }
     }
-    const V3 n = pseudoNormal(m, bestTri, bestCode);
+    hint = bestTri;
+    const V3 nrm = pseudoNormal(m, bestTri, bestCode);
     const V3 d = pt - bestQ;
-    const float sign = dot(n, d) > 0.0f ? 1.0f : -1.0f;
+    const float sign = dot(nrm, d) > 0.0f ? 1.0f : -1.0f;
     return sign * sqrtf(sqnorm(d));
 }
 
@@ -572,14 +586,14 @@ __global__ __launch_bounds__(256) void query_deep_kernel(TreeDev t, const Device
 // F at a world-space point, with the optional CSG wrapper of Octree.cpp:355-400
 template <int KIND, bool CSG>
 __device__ __forceinline__ double fieldEvalWorld(const FieldDev& f, double x, double y, double z, uint64_t sampleIdx,
-                                                 const double* sNl, const double* sRec) {
+                                                 const double* sNl, const double* sRec, uint32_t& meshHint) {
     double v;
     if constexpr (KIND == kFieldAnalytic)
         v = analyticEval(f, x, y, z);
     else if constexpr (KIND == kFieldSamples)
         v = f.samples[sampleIdx];
     else  // SURVEY 3.4 user glue: (f64) mesh.SignedDistanceAtPt(p.cast<f32>())
-        v = (double)meshSignedDistance(f.mesh, V3{(float)x, (float)y, (float)z});
+        v = (double)meshSignedDistance(f.mesh, V3{(float)x, (float)y, (float)z}, meshHint);
     if constexpr (CSG) {
         const double o = queryPoint<12>(f.oldTree, x, y, z, sNl, sRec);
         switch (f.csgOp) {
@@ -599,8 +613,9 @@ __global__ __launch_bounds__(256) void field_kernel(FieldDev f, const DeviceTabl
     stageQueryTables(T, sNl, sRec);
     __syncthreads();
     const size_t stride = (size_t)gridDim.x * blockDim.x;
+    uint32_t hint = 0xFFFFFFFFu;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        out[i] = fieldEvalWorld<KIND, CSG>(f, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], i, sNl, sRec);
+        out[i] = fieldEvalWorld<KIND, CSG>(f, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], i, sNl, sRec, hint);
 }
 
 // ---------------------------------------------------------------------------
@@ -726,6 +741,7 @@ __global__ __launch_bounds__(kFitThreads) void fit_kernel(const FitBlock* __rest
 #pragma unroll
         for (int k = 0; k < NQF; ++k) tkReg[k] = sT[i2a * nq + k];
     }
+    uint32_t meshHint = 0xFFFFFFFFu;  // closest triangle of this thread's previous sample (mesh fields)
     double acc[R];  // :1025
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = 0.0;
@@ -755,7 +771,7 @@ __global__ __launch_bounds__(kFitThreads) void fit_kernel(const FitBlock* __rest
             const double wy = uy * rm.bounds[1] + rm.centre[1];
             const double wz = uz * rm.bounds[2] + rm.centre[2];
             const uint64_t sidx = (uint64_t)__double_as_longlong(c[7]) + (uint64_t)((i * nq + j) * nq + k);
-            const double fv = fieldEvalWorld<KIND, CSG>(field, wx, wy, wz, sidx, sNl, sRec);
+            const double fv = fieldEvalWorld<KIND, CSG>(field, wx, wy, wz, sidx, sNl, sRec, meshHint);
             sF[g * cellStride + rem] = c[6] * (sW[i] * (sW[j] * sW[k])) * fv;  // :1040
         }
         __syncthreads();

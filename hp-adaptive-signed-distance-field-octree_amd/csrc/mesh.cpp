@@ -65,40 +65,30 @@ bool twinHalfEdges(const std::vector<uint32_t>& tris, std::vector<uint32_t>& he)
 }
 
 struct Builder {
-    const std::vector<float>& verts;
-    const std::vector<uint32_t>& tris;
     std::vector<float> triBox;  // 6 per triangle
     std::vector<float> cen;     // 3 per triangle
     std::vector<uint32_t> ids;
-    std::vector<float>& boxes;
-    std::vector<int32_t>& child;
+    std::vector<BvhNode>& nodes;
 
-    int32_t newNode() {
-        const int32_t id = (int32_t)(child.size() / 2);
-        child.push_back(0);
-        child.push_back(0);
-        boxes.resize(boxes.size() + 6);
-        return id;
-    }
-    // median split on the longest centroid axis; a leaf reference is ~triangle
-    int32_t build(size_t lo, size_t hi) {
-        if (hi - lo == 1) return ~(int32_t)ids[lo];
-        const int32_t node = newNode();
-        float bmin[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, bmax[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-        float cmin[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, cmax[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-        for (size_t i = lo; i < hi; ++i) {
-            const uint32_t t = ids[i];
+    // median split on the longest centroid axis; returns the child reference (node index, or ~triangle for a
+    // leaf) and the box of the subtree
+    int32_t build(size_t lo, size_t hi, float* bmin, float* bmax) {
+        if (hi - lo == 1) {
+            const uint32_t t = ids[lo];
             for (int a = 0; a < 3; ++a) {
-                bmin[a] = std::min(bmin[a], triBox[6 * t + a]);
-                bmax[a] = std::max(bmax[a], triBox[6 * t + 3 + a]);
-                cmin[a] = std::min(cmin[a], cen[3 * t + a]);
-                cmax[a] = std::max(cmax[a], cen[3 * t + a]);
+                bmin[a] = triBox[6 * t + a];
+                bmax[a] = triBox[6 * t + 3 + a];
             }
+            return ~(int32_t)t;
         }
-        for (int a = 0; a < 3; ++a) {
-            boxes[6 * (size_t)node + a] = bmin[a];
-            boxes[6 * (size_t)node + 3 + a] = bmax[a];
-        }
+        const int32_t node = (int32_t)nodes.size();
+        nodes.emplace_back();
+        float cmin[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, cmax[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (size_t i = lo; i < hi; ++i)
+            for (int a = 0; a < 3; ++a) {
+                cmin[a] = std::min(cmin[a], cen[3 * ids[i] + a]);
+                cmax[a] = std::max(cmax[a], cen[3 * ids[i] + a]);
+            }
         int axis = 0;
         for (int a = 1; a < 3; ++a)
             if (cmax[a] - cmin[a] > cmax[axis] - cmin[axis]) axis = a;
@@ -107,10 +97,18 @@ struct Builder {
             const float cx = cen[3 * x + axis], cy = cen[3 * y + axis];
             return cx < cy || (cx == cy && x < y);
         });
-        const int32_t l = build(lo, mid);
-        const int32_t r = build(mid, hi);
-        child[2 * (size_t)node] = l;
-        child[2 * (size_t)node + 1] = r;
+        float l0[3], h0[3], l1[3], h1[3];
+        const int32_t c0 = build(lo, mid, l0, h0);
+        const int32_t c1 = build(mid, hi, l1, h1);
+        BvhNode& n = nodes[node];
+        std::memset(&n, 0, sizeof n);
+        for (int a = 0; a < 3; ++a) {
+            n.lo0[a] = l0[a], n.hi0[a] = h0[a], n.lo1[a] = l1[a], n.hi1[a] = h1[a];
+            bmin[a] = std::min(l0[a], l1[a]);
+            bmax[a] = std::max(h0[a], h1[a]);
+        }
+        n.c0 = c0;
+        n.c1 = c1;
         return node;
     }
 };
@@ -125,7 +123,9 @@ bool prepareMesh(const float* verts, uint64_t nVerts, const uint64_t* tris, uint
         out->tris[i] = (uint32_t)tris[i];
     }
     if (!twinHalfEdges(out->tris, out->halfEdges)) return false;
-    Builder b{out->verts, out->tris, {}, {}, {}, out->bvhBoxes, out->bvhChild};
+    out->bvh.clear();
+    out->bvh.reserve(nTris);
+    Builder b{{}, {}, {}, out->bvh};
     b.triBox.resize(6 * nTris);
     b.cen.resize(3 * nTris);
     b.ids.resize(nTris);
@@ -139,14 +139,19 @@ bool prepareMesh(const float* verts, uint64_t nVerts, const uint64_t* tris, uint
             b.triBox[6 * t + 3 + a] = hi;
             b.cen[3 * t + a] = 0.5f * (lo + hi);
         }
-    out->bvhBoxes.clear();
-    out->bvhChild.clear();
     if (nTris == 1) {  // degenerate: a root with the single triangle on both sides
-        out->bvhChild = {~0, ~0};
-        out->bvhBoxes.assign(b.triBox.begin(), b.triBox.begin() + 6);
+        BvhNode n;
+        std::memset(&n, 0, sizeof n);
+        for (int a = 0; a < 3; ++a) {
+            n.lo0[a] = n.lo1[a] = b.triBox[a];
+            n.hi0[a] = n.hi1[a] = b.triBox[3 + a];
+        }
+        n.c0 = n.c1 = ~0;
+        out->bvh.push_back(n);
         return true;
     }
-    b.build(0, nTris);
+    float bmin[3], bmax[3];
+    b.build(0, nTris, bmin, bmax);
     return true;
 }
 

@@ -100,8 +100,7 @@ struct hpsdf_field {
     float* dVerts = nullptr;
     uint32_t* dTris = nullptr;
     uint32_t* dHalfEdges = nullptr;
-    float* dBvhBoxes = nullptr;
-    int32_t* dBvhChild = nullptr;
+    hpsdf::BvhNode* dBvh = nullptr;
     uint32_t nTris = 0, nVerts = 0, nBvhNodes = 0;
     // csg wrapper
     const hpsdf_tree* oldTree = nullptr;
@@ -130,8 +129,7 @@ struct HostMesh {
     std::vector<float> verts;
     std::vector<uint32_t> tris;
     std::vector<uint32_t> halfEdges;
-    std::vector<float> bvhBoxes;
-    std::vector<int32_t> bvhChild;
+    std::vector<BvhNode> bvh;
 };
 // returns false when the mesh is not closed (Mesh::CreateHalfEdges, Mesh.cpp:87-131)
 bool prepareMesh(const float* verts, uint64_t nVerts, const uint64_t* tris, uint64_t nTris, HostMesh* out);
