@@ -105,6 +105,8 @@ _SIGNATURES = {
                                   C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "hpsdf_query_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hpsdf_query_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hpsdf_query_gradient_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "hpsdf_query_gradient_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "hpsdf_build_begin": (C.c_int, [C.POINTER(PodConfig), C.POINTER(BuildOpts), C.POINTER(C.c_void_p)]),
     "hpsdf_build_destroy": (C.c_int, [C.c_void_p]),
     "hpsdf_build_round_select": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
@@ -348,6 +350,14 @@ class DeviceTree:
                                      out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def query_with_gradient(self, pts, grad_init=None):
+        pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)
+        out = np.empty(len(pts))
+        grad = np.zeros((len(pts), 3)) if grad_init is None else np.array(grad_init, np.float64).reshape(-1, 3).copy()
+        check(lib().hpsdf_query_gradient_host(self.ctx.handle, self.handle, pts.ctypes.data_as(C.c_void_p), len(pts),
+                                              out.ctypes.data_as(C.c_void_p), grad.ctypes.data_as(C.c_void_p)))
+        return out, grad
+
     def query_device(self, d_xyz_ptr, n, d_out_ptr):
         """Raw device pointers (ints); asynchronous on the context stream."""
         check(lib().hpsdf_query_device(self.ctx.handle, self.handle, C.c_void_p(d_xyz_ptr), n, C.c_void_p(d_out_ptr)))
@@ -549,6 +559,12 @@ class Octree:
         a = np.asarray(pts, np.float64)
         out = self._tree.query(a)
         return float(out[0]) if a.ndim == 1 else out
+
+    def QueryWithGradient(self, pts):
+        """(n,3) -> (values, unit 'gradients' as the reference's central-difference shortcut computes them)."""
+        if self._tree is None:
+            raise HpsdfError(6, "Query on an empty octree")
+        return self._tree.query_with_gradient(pts)
 
     def GetRootAABB(self):
         return self.config.root_min, self.config.root_max

@@ -522,6 +522,46 @@ int hpsdf_query_host(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* xyz, siz
     HPSDF_CATCH
 }
 
+int hpsdf_query_gradient_device(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* dXyz, size_t n, double* dOut,
+                                double* dGrad) {
+    HPSDF_TRY
+    if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "a device context is required");
+    if (!t || (n && (!dXyz || !dOut || !dGrad))) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    if (t->device != ctx->device) return fail(HPSDF_ERR_INVALID_ARGUMENT, "tree lives on another device");
+    HPSDF_HIP(hipSetDevice(ctx->device));
+    HPSDF_HIP(launchQueryGrad(ctx->stream, t->dev, ctx->dTables, dXyz, n, dOut, dGrad));
+    return HPSDF_OK;
+    HPSDF_CATCH
+}
+
+int hpsdf_query_gradient_host(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* xyz, size_t n, double* out,
+                              double* grad) {
+    HPSDF_TRY
+    if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "a device context is required");
+    if (!t || (n && (!xyz || !out || !grad))) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return HPSDF_OK;
+    HPSDF_HIP(hipSetDevice(ctx->device));
+    double *dIn = nullptr, *dOut = nullptr, *dGrad = nullptr;
+    hipError_t e = hipMalloc((void**)&dIn, n * 3 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dOut, n * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&dGrad, n * 3 * sizeof(double));
+    int rc = HPSDF_OK;
+    if (e == hipSuccess) e = hipMemcpyAsync(dIn, xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    // rows of points outside the root keep what the caller passed in (the reference leaves its output untouched)
+    if (e == hipSuccess) e = hipMemcpyAsync(dGrad, grad, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) rc = hpsdf_query_gradient_device(ctx, t, dIn, n, dOut, dGrad);
+    if (e == hipSuccess && rc == HPSDF_OK) e = hipMemcpyAsync(out, dOut, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && rc == HPSDF_OK) e = hipMemcpyAsync(grad, dGrad, n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dIn);
+    (void)hipFree(dOut);
+    (void)hipFree(dGrad);
+    if (rc) return rc;
+    if (e != hipSuccess) return hipFail(e, "query_gradient_host");
+    return HPSDF_OK;
+    HPSDF_CATCH
+}
+
 // ---------------------------------------------------------------------------- build
 int hpsdf_build_begin(const hpsdf_config* cfg, const hpsdf_build_opts* opts, hpsdf_build** out) {
     HPSDF_TRY

@@ -28,6 +28,8 @@ hipError_t launchFit(hipStream_t stream, int degree, int cellsPerThread, const F
                      const DeviceTables* dTables, const FieldDev& field, const RootMap& rm);
 hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dXyz, size_t n,
                        double* dOut, uint32_t* dDeferCount, uint32_t* dDeferIdx, bool allInline);
+hipError_t launchQueryGrad(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dXyz,
+                           size_t n, double* dOut, double* dGrad);
 hipError_t launchFieldEval(hipStream_t stream, const FieldDev& f, const DeviceTables* dTables, const double* dXyz,
                            size_t n, double* dOut);
 hipError_t launchPack(hipStream_t stream, const PackItem* dItems, uint32_t nItems, const double* dArena, double* dOut);

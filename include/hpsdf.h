@@ -154,6 +154,13 @@ HPSDF_API int hpsdf_query_device(hpsdf_ctx* ctx, const hpsdf_tree* t, const doub
 /* host buffers: H2D + kernel + D2H, synchronous (PCIe-inclusive) */
 HPSDF_API int hpsdf_query_host(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* xyz, size_t n, double* out);
 
+/* Octree::QueryWithGradient (Octree.cpp:749-789, 904-985): out[i] as Query; grad[3i..] = the reference's
+ * normalised central-difference "gradient".  Rows of points outside the root are left untouched. */
+HPSDF_API int hpsdf_query_gradient_device(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* d_xyz, size_t n,
+                                          double* d_out, double* d_grad);
+HPSDF_API int hpsdf_query_gradient_host(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* xyz, size_t n, double* out,
+                                        double* grad);
+
 /* ---- Create: Octree::Create under the canonical round schedule ---------------
  * (Octree.cpp:312-352, 194-309, 558-659, 804-856, 1007-1093; schedule: DESIGN.md)
  *

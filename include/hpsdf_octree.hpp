@@ -16,8 +16,8 @@
 //     samples the callback with config.threadCount host threads per round.
 //   * errors: the reference asserts; here a failed call throws SDF::Error carrying
 //     hpsdf_last_error() (Query outside the root still returns DBL_MAX).
-//   * QueryWithGradient / QueryRay / OutputFunctionSlice are not part of the hot
-//     path and are not provided yet.
+//   * QueryRay / OutputFunctionSlice are not part of the hot path and are not
+//     provided yet.
 #pragma once
 
 #include <cfloat>
@@ -296,6 +296,20 @@ class Octree {
     void QueryDevice(const double* d_xyz, usize n, double* d_out) const {
         if (!tree_) throw Error(HPSDF_ERR_STATE, "Query on an empty octree");
         check(hpsdf_query_device(ctx_, tree_, d_xyz, n, d_out));
+    }
+
+    /// As with Query, but with the unit "gradient" calculated via CD   (Octree.h:78, Octree.cpp:749-789)
+    f64 QueryWithGradient(const Eigen::Vector3d& pt_, Eigen::Vector3d& unitNormal_) const {
+        const double xyz[3] = {pt_(0), pt_(1), pt_(2)};
+        double out = 0.0, g[3] = {unitNormal_(0), unitNormal_(1), unitNormal_(2)};
+        QueryWithGradient(xyz, 1, &out, g);
+        unitNormal_ = Eigen::Vector3d(g[0], g[1], g[2]);
+        return out;
+    }
+    /// Batched form; rows of grad for points outside the root are left untouched
+    void QueryWithGradient(const double* xyz, usize n, double* out, double* grad) const {
+        if (!tree_) throw Error(HPSDF_ERR_STATE, "Query on an empty octree");
+        check(hpsdf_query_gradient_host(ctx_, tree_, xyz, n, out, grad));
     }
 
     /// Returns the aabb of the root node   (Octree.h:81)

@@ -501,6 +501,58 @@ double ora_fapprox(const double* coeffs, int degree, const float bmin[3], const 
     return fApprox;
 }
 
+/* Octree::FApproxWithGradient, Octree.cpp:904-985: value as FApprox; "gradient" by central differences of
+ * the per-axis basis factor only (the reference's own shortcut), then normalised. */
+double ora_fapprox_with_gradient(const double* coeffs, int degree, const float bmin[3], const float bmax[3],
+                                 const double pt[3], int depth, double grad[3]) {
+    ora_tables_init();
+    double unitPt[3];
+    for (int a = 0; a < 3; ++a)
+        unitPt[a] = (pt[a] - (double)((bmin[a] + bmax[a]) / 2.0f)) * (double)(2 << depth); /* :907 */
+    const double eps = 0.0001;
+    double L[13][3][3];
+    for (int i = 0; i < 3; ++i) {
+        L[0][i][0] = L[0][i][1] = L[0][i][2] = g_nl[0][depth];
+        double a2 = 0.0, a1 = 1.0, a0 = 1.0, b2 = 0.0, b1 = 1.0, b0 = 1.0, c2 = 0.0, c1 = 1.0, c0 = 1.0;
+        for (int j = 1; j <= degree; ++j) {
+            a0 = g_rec[j][0] * unitPt[i] * a1 - g_rec[j][1] * a2; /* :937 */
+            a2 = a1;
+            a1 = a0;
+            b0 = g_rec[j][0] * (unitPt[i] + eps) * b1 - g_rec[j][1] * b2; /* :941 */
+            b2 = b1;
+            b1 = b0;
+            c0 = g_rec[j][0] * (unitPt[i] - eps) * c1 - g_rec[j][1] * c2; /* :945 */
+            c2 = c1;
+            c1 = c0;
+            L[j][i][0] = a0 * g_nl[j][depth];
+            L[j][i][1] = b0 * g_nl[j][depth];
+            L[j][i][2] = c0 * g_nl[j][depth];
+        }
+    }
+    for (int k = 0; k < 3; ++k) { /* :956-968 */
+        double p1 = 0.0, m1 = 0.0;
+        for (uint64_t i = 0; i < g_count[degree]; ++i) {
+            p1 += coeffs[i] * L[g_bidx[i][k]][k][1];
+            m1 += coeffs[i] * L[g_bidx[i][k]][k][2];
+        }
+        grad[k] = (p1 - m1) / (2.0 * eps);
+    }
+    { /* Eigen normalize(): divide by sqrt(squaredNorm) when > 0 */
+        const double z = grad[0] * grad[0] + (grad[1] * grad[1] + grad[2] * grad[2]);
+        if (z > 0.0) {
+            const double n = sqrt(z);
+            grad[0] /= n, grad[1] /= n, grad[2] /= n;
+        }
+    }
+    double f = 0.0; /* :972-984 */
+    for (uint64_t i = 0; i < g_count[degree]; ++i) {
+        double Lp = 1.0;
+        for (int j = 0; j < 3; ++j) Lp *= L[g_bidx[i][j]][j][0];
+        f += coeffs[i] * Lp;
+    }
+    return f;
+}
+
 /* ======================================================================== */
 /* Tree build under the canonical round schedule                             */
 /* ======================================================================== */
@@ -832,6 +884,31 @@ double ora_query(const ora_tree* t, const double pt_[3]) {
             return ora_fapprox(t->coeff_store + c->coeffsStart, c->degree, c->aabb_min, c->aabb_max, pt, c->depth);
         cur = childIdx;
     }
+}
+/* Octree::QueryWithGradient, Octree.cpp:749-789 (grad is left untouched outside the root) */
+double ora_query_with_gradient(const ora_tree* t, const double pt_[3], double grad[3]) {
+    double pt[3];
+    for (int a = 0; a < 3; ++a) pt[a] = (pt_[a] - t->root_centre[a]) * t->root_inv_sizes[a];
+    for (int a = 0; a < 3; ++a) {
+        float pf = (float)pt[a];
+        if (!(t->nodes[0].aabb_min[a] <= pf && pf <= t->nodes[0].aabb_max[a])) return DBL_MAX;
+    }
+    uint64_t cur = 0;
+    for (;;) {
+        const ora_node* n = &t->nodes[cur];
+        const float half = (n->aabb_max[0] - n->aabb_min[0]) * 0.5f;
+        const uint64_t childIdx = n->childIdx + (uint64_t)(pt[0] >= (double)(n->aabb_min[0] + half)) +
+                                  ((uint64_t)(pt[1] >= (double)(n->aabb_min[1] + half)) << 1) +
+                                  ((uint64_t)(pt[2] >= (double)(n->aabb_min[2] + half)) << 2);
+        const ora_node* c = &t->nodes[childIdx];
+        if (c->degree != ORA_INTERIOR_DEGREE)
+            return ora_fapprox_with_gradient(t->coeff_store + c->coeffsStart, c->degree, c->aabb_min, c->aabb_max, pt,
+                                             c->depth, grad);
+        cur = childIdx;
+    }
+}
+void ora_query_gradient_batch(const ora_tree* t, const double* xyz, size_t n, double* out, double* grad) {
+    for (size_t i = 0; i < n; ++i) out[i] = ora_query_with_gradient(t, xyz + 3 * i, grad + 3 * i);
 }
 void ora_query_batch(const ora_tree* t, const double* xyz, size_t n, double* out) {
     for (size_t i = 0; i < n; ++i) out[i] = ora_query(t, xyz + 3 * i);

@@ -180,6 +180,11 @@ ora_tree* ora_tree_from_block(const void* block, size_t size);
 /* Octree::Query, Octree.cpp:662-702 */
 double ora_query(const ora_tree* t, const double pt[3]);
 void ora_query_batch(const ora_tree* t, const double* xyz, size_t n, double* out);
+/* Octree::QueryWithGradient / FApproxWithGradient, Octree.cpp:749-789, 904-985 */
+double ora_fapprox_with_gradient(const double* coeffs, int degree, const float bmin[3], const float bmax[3],
+                                 const double pt[3], int depth, double grad[3]);
+double ora_query_with_gradient(const ora_tree* t, const double pt[3], double grad[3]);
+void ora_query_gradient_batch(const ora_tree* t, const double* xyz, size_t n, double* out, double* grad);
 
 /* ---- mesh field (Source/Meshing) -- see hp_oracle_mesh.c ---------------- */
 typedef struct ora_mesh ora_mesh;

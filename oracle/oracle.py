@@ -111,6 +111,7 @@ def lib():
     L.ora_query.restype = C.c_double
     L.ora_query.argtypes = [C.c_void_p, dp]
     L.ora_query_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.ora_query_gradient_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.ora_mesh_create.restype = C.c_void_p
     L.ora_mesh_create.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
     L.ora_mesh_free.argtypes = [C.c_void_p]
@@ -324,6 +325,15 @@ class Tree:
         out = np.empty(len(pts))
         lib().ora_query_batch(self.handle, pts.ctypes.data_as(C.c_void_p), len(pts), out.ctypes.data_as(C.c_void_p))
         return out
+
+    def query_with_gradient(self, pts, grad_init=None):
+        """grad rows of points outside the root keep grad_init (the reference leaves the output untouched)."""
+        pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)
+        out = np.empty(len(pts))
+        grad = np.zeros((len(pts), 3)) if grad_init is None else np.array(grad_init, np.float64).reshape(-1, 3).copy()
+        lib().ora_query_gradient_batch(self.handle, pts.ctypes.data_as(C.c_void_p), len(pts),
+                                       out.ctypes.data_as(C.c_void_p), grad.ctypes.data_as(C.c_void_p))
+        return out, grad
 
     def __del__(self):
         if getattr(self, "handle", None):

@@ -47,6 +47,11 @@ int main(int argc, char** argv) {
         hpOctree.Query(xyz.data(), 1000, out.data());
         for (int i = 0; i < 1000; ++i)
             if (out[i] != hpOctree.Query(Eigen::Vector3d(xyz[3*i], xyz[3*i+1], xyz[3*i+2]))) { printf("batched != scalar\n"); return 7; }
+        Eigen::Vector3d nrm(0, 0, 0);
+        const double qg = hpOctree.QueryWithGradient(p, nrm);   // Include/HP/Octree.h:78
+        if (qg != q0 || std::fabs(nrm.norm() - 1.0) > 1e-12) { printf("QueryWithGradient\n"); return 8; }
+        const Eigen::Vector3d tn((p.x() - 0.25), p.y(), p.z());
+        if ((nrm.x() * tn.x() + nrm.y() * tn.y() + nrm.z() * tn.z()) / tn.norm() < 0.9) { printf("gradient direction\n"); return 9; }
         free(a.ptr); free(b.ptr);
         printf("OK %zu\n", a.size);
         return 0;

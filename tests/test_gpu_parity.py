@@ -325,3 +325,24 @@ def test_weighted_create_matches_oracle(H, O, ctx, wtype, target):
     assert st["jobs"] == ot.stats["jobs"] and st["h_refines"] == ot.stats["h_refines"]
     p = O.splitmix64_points(100000, seed=8)
     assert np.abs(H.DeviceTree(ctx, blk).query(p) - O.sphere_field().eval(p)).max() <= 0.01
+
+
+def test_query_with_gradient_bitwise(H, O, ctx, golden):
+    """Octree::QueryWithGradient (Octree.cpp:749-789, 904-985; reference benchmark HPBenchmarks.cpp:169-203)."""
+    g = golden["blocks"]["A1_union3_1e-7_K1024"]
+    ot = O.Tree.create(O.default_config(g["target"]), O.union3_field(), g["K"])
+    tree = H.DeviceTree(ctx, ot.to_block())
+    pts = np.concatenate([O.splitmix64_points(50000, seed=31), edge_points(np.random.default_rng(2), 2000)])
+    init = np.full((len(pts), 3), 7.0)
+    gv, gg = tree.query_with_gradient(pts, init)
+    wv, wg = ot.query_with_gradient(pts, init)
+    assert np.array_equal(bits(gv), bits(wv)) and np.array_equal(bits(gg), bits(wg))
+    outside = gv == DBL_MAX
+    assert outside.sum() > 0 and np.all(gg[outside] == 7.0)  # untouched, like the reference's output argument
+    assert np.allclose(np.linalg.norm(gg[~outside], axis=1), 1.0, atol=1e-12)
+    assert np.array_equal(bits(gv), bits(tree.query(pts)))
+    rng = np.random.default_rng(4)
+    blk = synthetic_block(rng, [8, 9, 10, 11, 12, 6, 7, 2], depth=2)
+    p2 = rng.uniform(-0.5, 0.5, (3000, 3))
+    a, b = H.DeviceTree(ctx, blk).query_with_gradient(p2), O.Tree.from_block(blk).query_with_gradient(p2)
+    assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(bits(a[1]), bits(b[1]))

@@ -136,3 +136,17 @@ def test_weighted_build_is_deterministic_and_accurate(O, wtype):
     # :1224-1226 clamp to [0,1]; :1246 exp(-s m / sqrt 3)
     assert L.ora_weight_from_mean(1, 3.0, 0.0) == 1.0 and 0.0 < L.ora_weight_from_mean(1, 3.0, 0.5) < 1.0
     assert abs(L.ora_weight_from_mean(2, 3.0, 0.5) - np.exp(-1.5 / np.sqrt(3.0))) < 1e-15
+
+
+def test_query_with_gradient_oracle(O):
+    """Octree.cpp:749-789, 904-985: same value as Query; unit-length output aligned with the true normal."""
+    t = O.Tree.create(O.default_config(1e-8), O.sphere_field(), 1024)
+    p = O.splitmix64_points(5000, seed=3) * 0.8
+    v, g = t.query_with_gradient(p)
+    assert np.array_equal(v, t.query(p))
+    true = p - np.array([0.25, 0.0, 0.0])
+    true /= np.linalg.norm(true, axis=1, keepdims=True)
+    cos = (g * true).sum(1)
+    assert np.allclose(np.linalg.norm(g, axis=1), 1.0, atol=1e-12) and cos.mean() > 0.999 and cos.min() > 0.9
+    v2, g2 = t.query_with_gradient(np.array([[3.0, 0.0, 0.0]]), np.array([[5.0, 6.0, 7.0]]))
+    assert v2[0] == DBL_MAX and g2.tolist() == [[5.0, 6.0, 7.0]]
