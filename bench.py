@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--points", type=int, default=N_POINTS, help="query points per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fit-bench", action="store_true", help="also run the steady-state fit micro-benchmark")
+    ap.add_argument("--sorted-ceiling", action="store_true",
+                    help="also time Query on the same points sorted by depth-4 cell (locality ceiling, SURVEY 8d)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -131,15 +133,38 @@ def main():
         # sanity: the timed output is the real answer (spot parity against the oracle on rank 0)
         got = d_out[:: max(1, n // 2000)].cpu().numpy()
 
+        # locality ceiling: the same points sorted by depth-4 cell, so neighbouring lanes share tree lines
+        sorted_ms = None
+        if rank == 0 and args.sorted_ceiling:
+            cell = ((d_xyz + 0.5) * 16.0).floor().clamp_(0, 15).to(torch.int64)
+            order = torch.argsort(cell[:, 0] * 256 + cell[:, 1] * 16 + cell[:, 2])
+            d_sorted = d_xyz[order].contiguous()
+            d_out2 = torch.empty_like(d_out)
+            torch.cuda.synchronize()
+            tree.query_device(d_sorted.data_ptr(), n, d_out2.data_ptr())
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0.record(stream)
+            for _ in range(5):
+                tree.query_device(d_sorted.data_ptr(), n, d_out2.data_ptr())
+            s1.record(stream)
+            torch.cuda.synchronize()
+            sorted_ms = s0.elapsed_time(s1) / 5
+            assert torch.equal(d_out2, d_out[order]), "sorted-point Query differs from the unsorted one"
+            del d_sorted, d_out2, order, cell
+
         fit = None
         if args.fit_bench and rank == 0:
             fit = {}
+            plane = H.Field.analytic([(H.PRIM_PLANE, H.OP_UNION, [0.3, -0.2, 0.5, 0.1])])  # F costs ~nothing: contraction only
             for p in (2, 3, 4, 5):
                 cells = 65536 if p <= 3 else 16384
-                ms = H.bench_fit(ctx, cfg, field, p, 5, cells, 3)
                 flops = 2.0 * H.NCOEF[p] * (4 * p + 1) ** 3 * cells
+                ms = H.bench_fit(ctx, cfg, field, p, 5, cells, 3)
+                ms_c = H.bench_fit(ctx, cfg, plane, p, 5, cells, 3)
                 fit["p%d" % p] = {"cells": cells, "ms": ms, "tflops_algorithmic": flops / ms / 1e9,
-                                  "frac_fp64_peak": flops / ms / 1e9 / FP64_PEAK_TFLOPS}
+                                  "frac_fp64_peak": flops / ms / 1e9 / FP64_PEAK_TFLOPS,
+                                  "contraction_only_ms": ms_c, "contraction_only_tflops": flops / ms_c / 1e9,
+                                  "contraction_only_frac_fp64_peak": flops / ms_c / 1e9 / FP64_PEAK_TFLOPS}
 
     ms_per_step = wall * 1e3 / args.steps
     value = world * n * args.steps / wall / 1e6  # Mpts/s, whole job
@@ -179,6 +204,9 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": 32 * n,
                      "avg_launch_ms": kernel_ms},
     }
+    if sorted_ms is not None:
+        out["query_cell_sorted_points"] = {"avg_launch_ms": sorted_ms, "mpts_per_s": n / sorted_ms / 1e3,
+                                           "frac_hbm_peak": 32.0 * n / (sorted_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     if fit:
         out["fit_microbench"] = fit
     if world == 1 and not args.no_cpu_baseline:

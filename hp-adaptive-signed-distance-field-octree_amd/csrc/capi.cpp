@@ -418,9 +418,12 @@ int hpsdf_tree_upload(hpsdf_ctx* ctx, const void* block, size_t size, hpsdf_tree
     // dense table of the deepest complete level (<= 5): table[path] = node reached by that octant path
     const int topDepth = std::max(1, std::min(5, minLeafDepth));
     std::vector<TopEntry> top((size_t)1 << (3 * topDepth));
-    for (size_t code = 0; code < top.size(); ++code) {
+    for (size_t code = 0; code < top.size(); ++code) {  // code = x + side * (y + side * z), cell coordinates at topDepth
+        const size_t mask = ((size_t)1 << topDepth) - 1;
+        const size_t kx = code & mask, ky = (code >> topDepth) & mask, kz = code >> (2 * topDepth);
         uint64_t cur = 0;
-        for (int l = topDepth - 1; l >= 0; --l) cur = nodes[cur].child_idx + ((code >> (3 * l)) & 7u);
+        for (int l = topDepth - 1; l >= 0; --l)  // bit l of a coordinate picks the upper half at that level (Octree.cpp:1101)
+            cur = nodes[cur].child_idx + ((kx >> l) & 1u) + 2 * ((ky >> l) & 1u) + 4 * ((kz >> l) & 1u);
         TopEntry& te = top[code];
         std::memset(&te, 0, sizeof te);
         te.a = recs[cur].a;

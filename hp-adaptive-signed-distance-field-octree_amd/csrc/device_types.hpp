@@ -38,7 +38,7 @@ static_assert(sizeof(TopEntry) == 128, "one line per entry");
 
 struct TreeDev {
     const NodeRec* nodes;
-    const TopEntry* top;     // dense table of the nodes at depth topDepth, indexed by the octant path
+    const TopEntry* top;     // dense table of the nodes at depth topDepth, indexed by cell: x + side*(y + side*z)
     const double* coeffs;    // per-leaf blocks padded to an even count
     int32_t topDepth;        // every node above this depth is interior (1..5)
     int32_t maxDegree;

@@ -412,16 +412,19 @@ __device__ __forceinline__ double queryPoint(const TreeDev& t, double x, double 
     // complete in this tree (topDepth of them; Octree::UniformlyRefine makes that 4) need no node reads:
     // the same comparisons give the path, and one table lookup gives the node reached.
     double cx = 0.0, cy = 0.0, cz = 0.0, q = 0.25;
-    uint32_t code = 0;
+    uint32_t ix = 0, iy = 0, iz = 0;
     int depth = 0;
     for (; depth < t.topDepth; ++depth) {
         const bool ux = px >= cx, uy = py >= cy, uz = pz >= cz;
-        code = code * 8u + (ux ? 1u : 0u) + (uy ? 2u : 0u) + (uz ? 4u : 0u);
+        ix = ix * 2u + (ux ? 1u : 0u);
+        iy = iy * 2u + (uy ? 1u : 0u);
+        iz = iz * 2u + (uz ? 1u : 0u);
         cx = ux ? cx + q : cx - q;
         cy = uy ? cy + q : cy - q;
         cz = uz ? cz + q : cz - q;
         q = q * 0.5;
     }
+    const uint32_t code = ix + ((iy + (iz << t.topDepth)) << t.topDepth);  // the table is indexed by cell (x, y, z)
     // One 128-byte line per top-level cell: the node record and, for a leaf of degree <= 2, its
     // coefficients inline -- the common case costs a single L2 line per point.  The coefficient loads
     // do not wait for the record (same line, issued together).
@@ -474,18 +477,42 @@ __device__ __forceinline__ void stageQueryTables(const DeviceTables* T, double* 
 // Points whose table entry is not an inline leaf (interior node, or a leaf of degree > 2) are not finished
 // here: their indices go to a deferred list that query_deep_kernel walks lane-by-lane.  Keeping that path out
 // of this kernel is what keeps it at ~64 VGPRs (8 waves/SIMD) -- inlined or called, it doubles the registers.
-template <int TOPD>
+// STAGED: the wave's 64 points (1536 contiguous bytes) also come in through LDS-DMA -- two wave-instructions
+// instead of three 24-byte-strided ones; the texture addresser is the busiest unit of this kernel (measured
+// ~75 %), so its instruction count is what matters.  Needs a 16-byte aligned point array.
+template <int TOPD, bool STAGED>
 __global__ __launch_bounds__(256, 7) void query_kernel(TreeDev t, const DeviceTables* __restrict__ T,
                                                     const double* __restrict__ xyz, size_t n, double* __restrict__ out,
                                                     uint32_t* __restrict__ deferCount, uint32_t* __restrict__ deferIdx) {
-    __shared__ double2 sRows[4][4][64];  // per wave: 4 steps x 64 lanes x 16 B (two passes; less LDS = more waves)
+    // per wave: 4 steps x 64 lanes x 16 B (two passes; less LDS = more waves).  Each step's kilobyte is followed by
+    // 32 bytes of padding: a lane reads row (sub & 3), so without it the four lanes of a group hit the same banks
+    // one kilobyte apart (measured: 70 % of the LDS cycles were bank conflicts).
+    __shared__ double2 sRows[4][4][66];
     (void)T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane & ~7, sub = lane & 7;
     for (size_t base = (size_t)blockIdx.x * 256; base < n; base += (size_t)gridDim.x * 256) {
         const size_t i = base + threadIdx.x;
         const bool valid = i < n;
         const size_t il = valid ? i : n - 1;
-        const double x = xyz[3 * il], y = xyz[3 * il + 1], z = xyz[3 * il + 2];
+        double x, y, z;
+        const size_t waveBase = base + (size_t)wave * 64;
+        if (STAGED && waveBase + 64 <= n) {  // wave-uniform
+            const char* src = reinterpret_cast<const char*>(xyz + 3 * waveBase) + lane * 16;
+            char* win = reinterpret_cast<char*>(&sRows[wave][0][0]);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)win, 16, 0, 0);
+            if (lane < 32)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 1024),
+                                                 (__attribute__((address_space(3))) void*)(win + 1024), 16, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const double* pp = reinterpret_cast<const double*>(win) + 3 * lane;
+            x = pp[0], y = pp[1], z = pp[2];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();  // the window is reused for the table rows below
+        } else {
+            x = xyz[3 * il], y = xyz[3 * il + 1], z = xyz[3 * il + 2];
+        }
         // Octree.cpp:665
         const double px = (x - t.rootCentre[0]) * t.rootInvSizes[0];
         const double py = (y - t.rootCentre[1]) * t.rootInvSizes[1];
@@ -493,20 +520,40 @@ __global__ __launch_bounds__(256, 7) void query_kernel(TreeDev t, const DeviceTa
         // :668 containment on the f32 cast, both ends inclusive; NaN fails
         const float fx = (float)px, fy = (float)py, fz = (float)pz;
         const bool inside = fx >= -0.5f && fx <= 0.5f && fy >= -0.5f && fy <= 0.5f && fz >= -0.5f && fz <= 0.5f;
-        // :674-701 for the complete top levels: comparisons only
-        double cx = 0.0, cy = 0.0, cz = 0.0, q = 0.25;
-        uint32_t code = 0;
-        int depth = 0;
-        const int topDepth = TOPD > 0 ? TOPD : t.topDepth;  // TOPD = 4: what Octree::UniformlyRefine builds
+        // :674-701 for the complete top levels.  The comparison chain "p >= mid-plane" level by level selects the
+        // cell k with lo_k <= p < lo_k + h (h = 2^-topDepth, lo_k = -0.5 + k h, all exact dyadics; k clamped to the
+        // grid because the containment test above ran on the f32 cast).  k is computed directly -- floor((p+0.5)/h)
+        // can be off by one when p + 0.5 rounds across a cell boundary, so it is corrected by the same exact
+        // comparisons the chain would make.
+        const int topDepth = TOPD > 0 ? TOPD : t.topDepth;
+        const int side = 1 << topDepth;
+        const double h = 1.0 / (double)side, fside = (double)side;
+        int kx, ky, kz;
+        double cx, cy, cz;
+        {
+            const double p3[3] = {px, py, pz};
+            int k3[3];
+            double c3[3];
 #pragma unroll
-        for (; depth < topDepth; ++depth) {
-            const bool ux = px >= cx, uy = py >= cy, uz = pz >= cz;
-            code = code * 8u + (ux ? 1u : 0u) + (uy ? 2u : 0u) + (uz ? 4u : 0u);
-            cx = ux ? cx + q : cx - q;
-            cy = uy ? cy + q : cy - q;
-            cz = uz ? cz + q : cz - q;
-            q = q * 0.5;
+            for (int a = 0; a < 3; ++a) {
+                int k = (int)floor((p3[a] + 0.5) * fside);
+                k = k < 0 ? 0 : (k > side - 1 ? side - 1 : k);
+                double lo = -0.5 + (double)k * h;
+                if (p3[a] < lo && k > 0) {
+                    --k;
+                    lo = lo - h;
+                } else if (p3[a] >= lo + h && k < side - 1) {
+                    ++k;
+                    lo = lo + h;
+                }
+                k3[a] = k;
+                c3[a] = lo + 0.5 * h;
+            }
+            kx = k3[0], ky = k3[1], kz = k3[2];
+            cx = c3[0], cy = c3[1], cz = c3[2];
         }
+        const int depth = topDepth;
+        uint32_t code = (uint32_t)(kx + ((ky + (kz << topDepth)) << topDepth));
         if (!inside) code = 0;  // any valid line; the result is DBL_MAX
         // lane (group g, sub k) owns the row that step k writes at lanes 8g..8g+7: [record][c0 c1]..[c8 c9].
         // Two passes of four steps through a 4 KB per-wave window (measured: 110 vs 121 us for one 8 KB pass).
@@ -518,8 +565,9 @@ __global__ __launch_bounds__(256, 7) void query_kernel(TreeDev t, const DeviceTa
             for (int k = 0; k < 4; ++k) {
                 const uint32_t ck = __shfl(code, grp | (pass * 4 + k), 64);
                 const char* src = reinterpret_cast<const char*>(t.top + ck) + sub * 16;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)&sRows[wave][k][0], 16, 0, 0);
+                if (sub < 6)  // bytes 96..127 of an entry are padding
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)&sRows[wave][k][0], 16, 0, 0);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
@@ -1096,10 +1144,22 @@ hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables*
         hipError_t e = hipMemsetAsync(dDeferCount, 0, sizeof(uint32_t), stream);
         if (e != hipSuccess) return e;
     }
-    if (t.topDepth == 4)
-        hipLaunchKernelGGL((query_kernel<4>), grid, block, 0, stream, t, dTables, dXyz, n, dOut, dDeferCount, dDeferIdx);
-    else
-        hipLaunchKernelGGL((query_kernel<0>), grid, block, 0, stream, t, dTables, dXyz, n, dOut, dDeferCount, dDeferIdx);
+    // measured: staging the points through LDS-DMA is not faster (114 us either way, slower on sorted points)
+    const bool staged = false;
+#define HPSDF_QUERY(TOPD, ST) \
+    hipLaunchKernelGGL((query_kernel<TOPD, ST>), grid, block, 0, stream, t, dTables, dXyz, n, dOut, dDeferCount, dDeferIdx)
+    if (t.topDepth == 4) {
+        if (staged)
+            HPSDF_QUERY(4, true);
+        else
+            HPSDF_QUERY(4, false);
+    } else {
+        if (staged)
+            HPSDF_QUERY(0, true);
+        else
+            HPSDF_QUERY(0, false);
+    }
+#undef HPSDF_QUERY
     if (!allInline) {
         const dim3 dgrid(std::min<unsigned>(gridFor(n), 4096u));
         if (t.maxDegree <= 3)

@@ -73,7 +73,7 @@ __device__ __forceinline__ double eval2(const double* cv, double ux, double uy, 
     return f;
 }
 
-enum { V_STREAM = 0, V_STREAM_DESCEND, V_THIN, V_FAT, V_FAT_NT, V_THIN128, V_FAT_K2, V_FAT_K4, V_FAT_1PT, V_FAT_LDSLOAD, V_NOLOAD_FAT, V_COOP, V_COOP_DIRECT, V_FATGATHER_NOEVAL, V_EVAL_FIXEDLEAF, V_COOP_DMA, V_COOP_DMA_NOEVAL, V_COOP_DMA_HALF, V_COOP_DMA_K2, V_COOP_DMA_BIGLDS, V_COOP_DMA_QUARTER, V_COOP_DMA_EIGHTH, V_COUNT };
+enum { V_STREAM = 0, V_STREAM_DESCEND, V_THIN, V_FAT, V_FAT_NT, V_THIN128, V_FAT_K2, V_FAT_K4, V_FAT_1PT, V_FAT_LDSLOAD, V_NOLOAD_FAT, V_COOP, V_COOP_DIRECT, V_FATGATHER_NOEVAL, V_EVAL_FIXEDLEAF, V_COOP_DMA, V_COOP_DMA_NOEVAL, V_COOP_DMA_HALF, V_COOP_DMA_K2, V_COOP_DMA_BIGLDS, V_COOP_DMA_QUARTER, V_COOP_DMA_EIGHTH, V_COOP_DMA_HALF_PF, V_COUNT };
 const char* kNames[] = {"stream only (xyz in, 1 add, out)", "stream + descent arithmetic", "thin table + coeffs 80B stride",
                         "fat table (1 line/pt)", "fat + nontemporal stream", "thin table + coeffs 128B stride",
                         "fat, 2 pts/thread interleaved", "fat, 4 pts/thread interleaved", "fat, 1 pt/thread (no grid-stride)",
@@ -82,7 +82,8 @@ const char* kNames[] = {"stream only (xyz in, 1 add, out)", "stream + descent ar
                         "fat gather, no eval (sum coeffs)", "eval with fixed leaf (no gather)",
                         "coop line fetch by LDS-DMA (global_load_lds x4)", "coop LDS-DMA, no eval",
                         "coop LDS-DMA in two half passes (4 KB/wave)", "coop LDS-DMA, 2 tiles per iteration", "coop LDS-DMA + 32 KB dummy LDS",
-                        "coop LDS-DMA in four passes (2 KB/wave)", "coop LDS-DMA in eight passes (1 KB/wave)"};
+                        "coop LDS-DMA in four passes (2 KB/wave)", "coop LDS-DMA in eight passes (1 KB/wave)",
+                        "half passes + next tile's points prefetched (asm loads, vmcnt(3))"};
 
 template <int V>
 __device__ __forceinline__ double onePoint(const Tree& t, double px, double py, double pz) {
@@ -338,6 +339,60 @@ __global__ __launch_bounds__(256) void lab(Tree t, const double* __restrict__ xy
         }
         return;
     }
+    if (V == V_COOP_DMA_HALF_PF) {
+        __shared__ double2 sd[4][4][64];
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, grp = lane & ~7, j = lane & 7;
+        const size_t step = (size_t)gridDim.x * 256;
+        size_t base = (size_t)blockIdx.x * 256;
+        if (base >= n) return;
+        double nx, ny, nz;
+        {
+            const size_t i = base + threadIdx.x < n ? base + threadIdx.x : n - 1;
+            nx = xyz[3 * i], ny = xyz[3 * i + 1], nz = xyz[3 * i + 2];
+        }
+        for (; base < n; base += step) {
+            const double px = nx, py = ny, pz = nz;
+            uint32_t code;
+            double cx, cy, cz;
+            descend4(px, py, pz, code, cx, cy, cz);
+            double cv[10];
+            const size_t nb = base + step;
+            const size_t ni = (nb + threadIdx.x < n) ? nb + threadIdx.x : n - 1;
+            const double* np = xyz + 3 * ni;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t ck = __shfl(code, grp | (half * 4 + k), 64);
+                    const char* src = reinterpret_cast<const char*>(t.fat + ck) + j * 16;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)&sd[w][k][0], 16, 0, 0);
+                }
+                if (half == 0) {
+                    // next tile's points: issued behind the first four DMAs, allowed to stay in flight across their wait
+                    asm volatile("global_load_dwordx2 %0, %3, off\n\tglobal_load_dwordx2 %1, %3, off offset:8\n\tglobal_load_dwordx2 %2, %3, off offset:16"
+                                 : "=&v"(nx), "=&v"(ny), "=&v"(nz) : "v"(np) : "memory");
+                    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_wave_barrier();
+                if ((j >> 2) == half) {
+                    const double2* row = &sd[w][j & 3][grp];
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) {
+                        const double2 v = row[1 + q];
+                        cv[2 * q] = v.x, cv[2 * q + 1] = v.y;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+            const double r = eval2(cv, (px - cx) * 32.0, (py - cy) * 32.0, (pz - cz) * 32.0);
+            if (base + threadIdx.x < n) out[base + threadIdx.x] = r;
+        }
+        return;
+    }
     if (V == V_COOP_DMA_K2) {
         __shared__ double2 sd[4][2][8][64];  // two tiles in flight per wave
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, grp = lane & ~7, j = lane & 7;
@@ -476,7 +531,7 @@ int main(int argc, char** argv) {
         return a;
     };
     const int full = (int)((n + 255) / 256);
-    const int grids[] = {8192, 16384, full};
+    const int grids[] = {2048, 4096, 8192, 16384};
 #define RUN(V, blocks)                                                                                         \
     {                                                                                                          \
         float ms = run<V>(t, dx, n, dout, blocks, 10);                                                         \
@@ -504,6 +559,7 @@ int main(int argc, char** argv) {
         RUN(V_COOP_DMA_BIGLDS, g);
         RUN(V_COOP_DMA_QUARTER, g);
         RUN(V_COOP_DMA_EIGHTH, g);
+        RUN(V_COOP_DMA_HALF_PF, g);
         printf("\n");
     }
     return 0;
