@@ -346,3 +346,52 @@ def test_query_with_gradient_bitwise(H, O, ctx, golden):
     p2 = rng.uniform(-0.5, 0.5, (3000, 3))
     a, b = H.DeviceTree(ctx, blk).query_with_gradient(p2), O.Tree.from_block(blk).query_with_gradient(p2)
     assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(bits(a[1]), bits(b[1]))
+
+
+def test_csg_with_host_callback_inner_field(H, O, ctx):
+    """UnionSDF(std::function): F' = min(old.Query, F_) with F_ sampled on the host and old.Query on the GPU."""
+    import math
+    target, K = 1e-5, 1024
+
+    def other(pt, thread_idx):
+        dx, dy, dz = pt[0] + 0.25, pt[1], pt[2]
+        return math.sqrt(dx * dx + (dy * dy + dz * dz)) - 0.5
+
+    t = H.Octree(jobs_per_round=K)
+    t.Create(H.make_config(target, threads=2), H.Field.sphere((0.25, 0, 0), 0.5))
+    t.UnionSDF(other)
+    ocfg = O.default_config(target)
+    old = O.Tree.create(ocfg, O.sphere_field((0.25, 0, 0), 0.5), K)
+    want = O.Tree.create(ocfg, O.TreeCsgField(old, O.sphere_field((-0.25, 0, 0), 0.5), O.OP_UNION), K)
+    got = bytearray(t.ToMemoryBlock())
+    got[-80 + 48:-80 + 56] = np.array([1], np.uint64).tobytes()  # threadCount differs (2 vs 1), nothing else may
+    assert bytes(got) == want.to_block()
+
+
+def test_polynomial_field_is_represented_exactly(H, O, ctx):
+    """A plane is inside the degree-2 space: every leaf stays at degree 2 and Query reproduces it to rounding."""
+    spec = [(H.PRIM_PLANE, H.OP_UNION, [0.3, -0.2, 0.5, 0.1])]
+    blk, st = H.create_block(ctx, H.make_config(1e-12), H.Field.analytic(spec), 1024)
+    assert st["n_nodes"] == 4681 and st["rounds"] == 1
+    assert blk == O.Tree.create(O.default_config(1e-12), O.AnalyticField(spec), 1024).to_block()
+    p = O.splitmix64_points(100000, seed=6)
+    q = H.DeviceTree(ctx, blk).query(p)
+    assert np.abs(q - (0.3 * p[:, 0] - 0.2 * p[:, 1] + 0.5 * p[:, 2] + 0.1)).max() < 1e-13
+
+
+def test_capi_argument_checks(H, ctx):
+    L = H.lib()
+    import ctypes as C
+    assert L.hpsdf_query_device(None, None, None, 0, None) == H.ERR_NO_DEVICE
+    assert L.hpsdf_query_device(ctx.handle, None, None, 5, None) == 1  # HPSDF_ERR_INVALID_ARGUMENT
+    assert L.hpsdf_tree_upload(ctx.handle, None, 0, C.byref(C.c_void_p())) == 4  # HPSDF_ERR_BAD_BLOCK
+    assert L.hpsdf_field_eval_host(ctx.handle, None, None, 0, None) == 1
+    assert b"" != L.hpsdf_last_error()
+    blk, _ = H.create_block(ctx, H.make_config(1e-4), H.Field.sphere(), 0)  # K = 0 -> default
+    tree = H.DeviceTree(ctx, blk)
+    assert tree.query(np.zeros((0, 3))).shape == (0,)
+    assert tree.query(np.array([[0.1, 0.2, 0.3]])).shape == (1,)
+    f = H.Field.callback(lambda p, t: 0.0)
+    with pytest.raises(H.HpsdfError) as e:
+        f.eval(ctx, np.zeros((4, 3)))
+    assert e.value.status == H.ERR_UNSUPPORTED
