@@ -78,6 +78,14 @@ class BuildStats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class ContinuityStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_pairs", "n_pairs_analytic", "n_pairs_numeric", "nnz", "iterations")] + \
+               [(n, C.c_double) for n in ("residual", "jump_before", "jump_after", "assemble_ms", "solve_ms")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 CALLBACK = C.CFUNCTYPE(C.c_double, C.POINTER(C.c_double), C.c_uint64, C.c_void_p)
 
 # every symbol include/hpsdf.h declares (tests/test_capi_symbols.py checks the list against the header)
@@ -107,6 +115,12 @@ _SIGNATURES = {
     "hpsdf_query_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hpsdf_query_gradient_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "hpsdf_query_gradient_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "hpsdf_query_ray_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                         C.c_void_p, C.c_void_p]),
+    "hpsdf_query_ray_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                       C.c_void_p, C.c_void_p]),
+    "hpsdf_function_slice": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                       C.c_uint64, C.c_void_p, C.c_void_p]),
     "hpsdf_build_begin": (C.c_int, [C.POINTER(PodConfig), C.POINTER(BuildOpts), C.POINTER(C.c_void_p)]),
     "hpsdf_build_destroy": (C.c_int, [C.c_void_p]),
     "hpsdf_build_round_select": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
@@ -124,6 +138,12 @@ _SIGNATURES = {
     "hpsdf_build_assemble": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                        C.POINTER(C.c_size_t)]),
     "hpsdf_build_get_stats": (C.c_int, [C.c_void_p, C.POINTER(BuildStats)]),
+    "hpsdf_continuity_post_process": (C.c_int, [C.c_void_p, C.c_size_t, C.c_double, C.c_int, C.c_uint64,
+                                                C.POINTER(ContinuityStats)]),
+    "hpsdf_continuity_matrix": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64, C.POINTER(C.POINTER(C.c_uint64)),
+                                          C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(C.c_double)),
+                                          C.POINTER(ContinuityStats)]),
+    "hpsdf_continuity_last_stats": (C.c_int, [C.POINTER(ContinuityStats)]),
     "hpsdf_create": (C.c_int, [C.c_void_p, C.POINTER(PodConfig), C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p),
                                C.POINTER(C.c_size_t), C.POINTER(BuildStats)]),
     "hpsdf_bench_fit": (C.c_int, [C.c_void_p, C.POINTER(PodConfig), C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int,
@@ -358,6 +378,28 @@ class DeviceTree:
                                               out.ctypes.data_as(C.c_void_p), grad.ctypes.data_as(C.c_void_p)))
         return out, grad
 
+    def query_ray(self, origins, directions, t_max, t_init=None):
+        """Octree::QueryRay per row -> (hit u8 [n], t f64 [n]); t rows of misses keep t_init."""
+        o = np.ascontiguousarray(origins, np.float64).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, np.float64).reshape(-1, 3)
+        n = len(o)
+        tm = np.ascontiguousarray(np.broadcast_to(np.asarray(t_max, np.float64), (n,)))
+        hit = np.zeros(n, np.uint8)
+        t = np.zeros(n) if t_init is None else np.array(t_init, np.float64).reshape(n).copy()
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        check(lib().hpsdf_query_ray_host(self.ctx.handle, self.handle, vp(o), vp(d), vp(tm), n, vp(hit), vp(t)))
+        return hit, t
+
+    def function_slice(self, c, view_min, view_max, n_samples=2048):
+        """Octree::OutputFunctionSlice up to the byte image -> (rgb u8 [n,n,3], values f64 [n,n])."""
+        n = int(n_samples)
+        rgb = np.zeros((n, n, 3), np.uint8)
+        vals = np.zeros((n, n))
+        f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])
+        check(lib().hpsdf_function_slice(self.ctx.handle, self.handle, float(c), f3(view_min), f3(view_max), n,
+                                         rgb.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p)))
+        return rgb, vals
+
     def query_device(self, d_xyz_ptr, n, d_out_ptr):
         """Raw device pointers (ints); asynchronous on the context stream."""
         check(lib().hpsdf_query_device(self.ctx.handle, self.handle, C.c_void_p(d_xyz_ptr), n, C.c_void_p(d_out_ptr)))
@@ -482,6 +524,37 @@ def create_block(ctx, config, field, K=0):
     return data, st.as_dict()
 
 
+def continuity_post_process(block, tol=0.0, max_iter=0, threads=0):
+    """Octree::PerformContinuityPostProcess (Octree.cpp:1717-1762) on a serialised block, host side.
+    Returns (new block bytes, stats dict).  tol 0 = the reference's EPSILON_F32."""
+    buf = C.create_string_buffer(bytes(block), len(block))
+    st = ContinuityStats()
+    check(lib().hpsdf_continuity_post_process(buf, len(block), tol, max_iter, threads, C.byref(st)))
+    return buf.raw, st.as_dict()
+
+
+def continuity_matrix(block, threads=0):
+    """(row_ptr, col, val, stats) of the jump-energy matrix M (no regularisation), CSR."""
+    b = bytes(block)
+    rp, ci, v = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)(), C.POINTER(C.c_double)()
+    st = ContinuityStats()
+    check(lib().hpsdf_continuity_matrix(b, len(b), threads, C.byref(rp), C.byref(ci), C.byref(v), C.byref(st)))
+    n = int(np.frombuffer(b[:8], np.uint64)[0])
+    row_ptr = np.ctypeslib.as_array(rp, shape=(n + 1,)).copy()
+    nnz = int(row_ptr[-1])
+    col = np.ctypeslib.as_array(ci, shape=(max(nnz, 1),))[:nnz].copy()
+    val = np.ctypeslib.as_array(v, shape=(max(nnz, 1),))[:nnz].copy()
+    for p in (rp, ci, v):
+        lib()._libc.free(C.cast(p, C.c_void_p))
+    return row_ptr, col, val, st.as_dict()
+
+
+def continuity_last_stats():
+    st = ContinuityStats()
+    check(lib().hpsdf_continuity_last_stats(C.byref(st)))
+    return st.as_dict()
+
+
 def bench_fit(ctx, config, field, degree, depth, n_cells, repeats=5):
     pod = config.to_pod()
     ms = C.c_double()
@@ -566,6 +639,23 @@ class Octree:
             raise HpsdfError(6, "Query on an empty octree")
         return self._tree.query_with_gradient(pts)
 
+    def QueryRay(self, origins, directions, t_max):
+        """Octree::QueryRay (Octree.h:75) for one ray -> (hit, t) or (n,3) arrays -> (hit[n], t[n])."""
+        if self._tree is None:
+            raise HpsdfError(6, "Query on an empty octree")
+        o = np.asarray(origins, np.float64)
+        hit, t = self._tree.query_ray(o, directions, t_max)
+        return (bool(hit[0]), float(t[0])) if o.ndim == 1 else (hit, t)
+
+    def OutputFunctionSlice(self, fname, c, view_min, view_max, n_samples=2048):
+        """Octree::OutputFunctionSlice (Octree.h:83-86): writes <fname>.bmp (24-bit, bottom-up rows as
+        stb_image_write lays them out) and returns the (n,n,3) RGB array."""
+        if self._tree is None:
+            raise HpsdfError(6, "Query on an empty octree")
+        rgb, _ = self._tree.function_slice(c, view_min, view_max, n_samples)
+        write_bmp(fname + ".bmp", rgb)
+        return rgb
+
     def GetRootAABB(self):
         return self.config.root_min, self.config.root_max
 
@@ -575,6 +665,20 @@ class Octree:
             o.FromMemoryBlock(self.block)
             o.stats = self.stats
         return o
+
+
+def write_bmp(path, rgb):
+    """24-bit uncompressed BMP of an (h, w, 3) RGB array: 14-byte file header, 40-byte BITMAPINFOHEADER, rows
+    bottom-up, BGR, padded to 4 bytes -- the layout stbi_write_bmp produces for comp = 3."""
+    import struct
+    h, w, _ = rgb.shape
+    pad = (-3 * w) % 4
+    rows = np.zeros((h, 3 * w + pad), np.uint8)
+    rows[:, :3 * w] = rgb[::-1, :, ::-1].reshape(h, 3 * w)
+    with open(path, "wb") as fh:
+        fh.write(struct.pack("<2sIHHI", b"BM", 14 + 40 + rows.size, 0, 0, 14 + 40))
+        fh.write(struct.pack("<IiiHHIIiiII", 40, w, h, 1, 24, 0, 0, 0, 0, 0, 0))
+        fh.write(rows.tobytes())
 
 
 def load_obj(path):

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "builder.hpp"
+#include "continuity.hpp"
 #include "launch.hpp"
 #include "runtime.hpp"
 
@@ -21,6 +22,7 @@ using namespace hpsdf;
 namespace hpsdf {
 
 static thread_local std::string g_lastError;
+static thread_local hpsdf_continuity_stats g_lastContinuity = {};
 
 void setError(const std::string& msg) { g_lastError = msg; }
 int fail(int code, const std::string& msg) {
@@ -565,6 +567,124 @@ int hpsdf_query_gradient_host(hpsdf_ctx* ctx, const hpsdf_tree* t, const double*
     HPSDF_CATCH
 }
 
+int hpsdf_query_ray_device(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* dOrigins, const double* dDirs,
+                           const double* dTMax, size_t n, uint8_t* dHit, double* dT) {
+    HPSDF_TRY
+    if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "a device context is required");
+    if (!t || (n && (!dOrigins || !dDirs || !dTMax || !dHit || !dT))) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    if (t->device != ctx->device) return fail(HPSDF_ERR_INVALID_ARGUMENT, "tree lives on another device");
+    HPSDF_HIP(hipSetDevice(ctx->device));
+    HPSDF_HIP(launchQueryRay(ctx->stream, t->dev, ctx->dTables, dOrigins, dDirs, dTMax, n, dHit, dT));
+    return HPSDF_OK;
+    HPSDF_CATCH
+}
+
+namespace {
+// frees its device buffers on every exit path
+struct DevBufs {
+    std::vector<void*> p;
+    ~DevBufs() {
+        for (void* q : p)
+            if (q) (void)hipFree(q);
+    }
+    hipError_t alloc(void** out, size_t bytes) {
+        hipError_t e = hipMalloc(out, bytes ? bytes : 8);
+        if (e == hipSuccess) p.push_back(*out);
+        return e;
+    }
+};
+}  // namespace
+
+int hpsdf_query_ray_host(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* origins, const double* dirs,
+                         const double* tMax, size_t n, uint8_t* hit, double* tOut) {
+    HPSDF_TRY
+    if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "a device context is required");
+    if (!t || (n && (!origins || !dirs || !tMax || !hit || !tOut))) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return HPSDF_OK;
+    HPSDF_HIP(hipSetDevice(ctx->device));
+    DevBufs bufs;
+    double *dO = nullptr, *dD = nullptr, *dM = nullptr, *dT = nullptr;
+    uint8_t* dH = nullptr;
+    HPSDF_HIP(bufs.alloc((void**)&dO, n * 3 * sizeof(double)));
+    HPSDF_HIP(bufs.alloc((void**)&dD, n * 3 * sizeof(double)));
+    HPSDF_HIP(bufs.alloc((void**)&dM, n * sizeof(double)));
+    HPSDF_HIP(bufs.alloc((void**)&dT, n * sizeof(double)));
+    HPSDF_HIP(bufs.alloc((void**)&dH, n));
+    HPSDF_HIP(hipMemcpyAsync(dO, origins, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HPSDF_HIP(hipMemcpyAsync(dD, dirs, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HPSDF_HIP(hipMemcpyAsync(dM, tMax, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    // t of a miss keeps the caller's value (the reference leaves t_ untouched)
+    HPSDF_HIP(hipMemcpyAsync(dT, tOut, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    int rc = hpsdf_query_ray_device(ctx, t, dO, dD, dM, n, dH, dT);
+    if (rc) {
+        (void)hipStreamSynchronize(ctx->stream);
+        return rc;
+    }
+    HPSDF_HIP(hipMemcpyAsync(hit, dH, n, hipMemcpyDeviceToHost, ctx->stream));
+    HPSDF_HIP(hipMemcpyAsync(tOut, dT, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HPSDF_HIP(hipStreamSynchronize(ctx->stream));
+    return HPSDF_OK;
+    HPSDF_CATCH
+}
+
+// (u8)f64 as the reference's x86-64 build performs it: truncating conversion to a 32-bit integer
+// (out of range and NaN give INT_MIN), then the low byte
+static uint8_t f64ToU8(double q) {
+    int32_t v;
+    if (!(q > -2147483649.0 && q < 2147483648.0))
+        v = INT32_MIN;
+    else
+        v = (int32_t)q;
+    return (uint8_t)(v & 0xFF);
+}
+
+int hpsdf_function_slice(hpsdf_ctx* ctx, const hpsdf_tree* t, double c, const float* viewMin, const float* viewMax,
+                         uint64_t nSamples, uint8_t* rgb, double* values) {
+    HPSDF_TRY
+    if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "a device context is required");
+    if (!t || !viewMin || !viewMax || !rgb) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    if (nSamples == 0 || nSamples > 32768) return fail(HPSDF_ERR_INVALID_ARGUMENT, "n_samples must be in [1, 32768]");
+    if (t->device != ctx->device) return fail(HPSDF_ERR_INVALID_ARGUMENT, "tree lives on another device");
+    HPSDF_HIP(hipSetDevice(ctx->device));
+    const size_t total = (size_t)nSamples * nSamples;
+    DevBufs bufs;
+    double* dV = nullptr;
+    HPSDF_HIP(bufs.alloc((void**)&dV, total * sizeof(double)));
+    const float step = (viewMax[0] - viewMin[0]) / (float)nSamples;  // Octree.cpp:1149
+    HPSDF_HIP(launchSlice(ctx->stream, t->dev, ctx->dTables, c, viewMin[0], viewMin[1], step, (uint32_t)nSamples, dV));
+    std::vector<double> own;
+    double* v = values;
+    if (!v) {
+        own.resize(total);
+        v = own.data();
+    }
+    HPSDF_HIP(hipMemcpyAsync(v, dV, total * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HPSDF_HIP(hipStreamSynchronize(ctx->stream));
+    // Octree.cpp:1140-1167 ranges, :1172-1196 bytes
+    double posFirst = DBL_MAX, posSecond = 0.0, negFirst = 0.0, negSecond = DBL_MAX * -1.0;
+    for (size_t p = 0; p < total; ++p) {
+        const double s = v[p];
+        if (s > (double)0.000001f) {
+            posFirst = std::min(s, posFirst);
+            posSecond = std::max(s, posSecond);
+        } else {
+            negFirst = std::min(s, negFirst);
+            negSecond = std::max(s, negSecond);
+        }
+    }
+    for (size_t p = 0; p < total; ++p) {
+        const float u = (float)v[p];
+        uint8_t* px = rgb + 3 * p;
+        if (u > 0.0f) {
+            px[0] = 0, px[1] = f64ToU8(255 * ((double)u - posSecond) / (posFirst - posSecond)), px[2] = 0;
+        } else {
+            px[0] = 0, px[1] = 0, px[2] = f64ToU8(255 * ((double)u - negFirst) / (negSecond - negFirst));
+        }
+    }
+    return HPSDF_OK;
+    HPSDF_CATCH
+}
+
 // ---------------------------------------------------------------------------- build
 int hpsdf_build_begin(const hpsdf_config* cfg, const hpsdf_build_opts* opts, hpsdf_build** out) {
     HPSDF_TRY
@@ -773,13 +893,54 @@ int hpsdf_create(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* fie
     }
     if (!rc && stats) hpsdf_build_get_stats(b, stats);
     t1 = now();
+    std::memset(&g_lastContinuity, 0, sizeof g_lastContinuity);
+    if (!rc && cfg->continuity_enforce) {  // Octree.cpp:341-344
+        std::string err;
+        rc = continuityPostProcess(*block, *size, 0.0, 0, 0, &g_lastContinuity, err);
+        if (rc) {
+            setError(err);
+            std::free(*block);
+            *block = nullptr;
+            *size = 0;
+        }
+    }
+    const double tCont = now() - t1;
+    t1 = now();
     delete b;
     if (trace)
         std::fprintf(stderr, "[hpsdf_create] us: begin %.0f select %.0f compute(host+launch) %.0f results(wait+D2H) %.0f apply %.0f "
-                             "layout %.0f pack %.0f assemble %.0f destroy %.0f total %.0f\n",
-                     tBegin, tSel, tCmp, tRes, tApp, tLay, tPack, tAsm, now() - t1, now() - t0);
+                             "layout %.0f pack %.0f assemble %.0f continuity %.0f destroy %.0f total %.0f\n",
+                     tBegin, tSel, tCmp, tRes, tApp, tLay, tPack, tAsm, tCont, now() - t1, now() - t0);
     return rc;
     HPSDF_CATCH
+}
+
+// ---------------------------------------------------------------------------- continuity (host)
+int hpsdf_continuity_post_process(void* block, size_t size, double tol, int maxIter, uint64_t threads,
+                                  hpsdf_continuity_stats* stats) {
+    HPSDF_TRY
+    std::string err;
+    const int rc = continuityPostProcess(block, size, tol, maxIter, threads, stats, err);
+    if (rc) return fail(rc, err);
+    return HPSDF_OK;
+    HPSDF_CATCH
+}
+
+int hpsdf_continuity_matrix(const void* block, size_t size, uint64_t threads, uint64_t** rowPtr, uint64_t** col,
+                            double** val, hpsdf_continuity_stats* stats) {
+    HPSDF_TRY
+    if (!rowPtr || !col || !val) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null output");
+    std::string err;
+    const int rc = continuityMatrix(block, size, threads, rowPtr, col, val, stats, err);
+    if (rc) return fail(rc, err);
+    return HPSDF_OK;
+    HPSDF_CATCH
+}
+
+int hpsdf_continuity_last_stats(hpsdf_continuity_stats* out) {
+    if (!out) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null out");
+    *out = g_lastContinuity;
+    return HPSDF_OK;
 }
 
 // ---------------------------------------------------------------------------- micro-benchmark

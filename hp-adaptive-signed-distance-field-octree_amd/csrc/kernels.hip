@@ -709,6 +709,87 @@ __global__ __launch_bounds__(256) void query_grad_kernel(TreeDev t, const Device
     }
 }
 
+// Octree::QueryRay (Octree.cpp:705-746) over Ray / Ray::IntersectAABB (Source/HP/Ray.cpp:5-68): sphere tracing,
+// at most 200 Query steps per ray, one lane per ray.  The reference's behaviour is kept statement by statement,
+// including what looks unintended: the origin is mapped to the unit cube but the direction is not (:711); for an
+// origin outside the root `intMin` is what IntersectAABB leaves in its first output -- the entry parameter in x,
+// per-axis slab parameters in y and z -- not a point (:717); Query maps its argument through the root transform
+// again (:726 -> :665); and on a hit t_ receives the field value (:730).  t of a miss is left untouched.
+__global__ __launch_bounds__(256) void query_ray_kernel(TreeDev t, const DeviceTables* __restrict__ T,
+                                                        const double* __restrict__ origins,
+                                                        const double* __restrict__ dirs, const double* __restrict__ tMax,
+                                                        size_t n, uint8_t* __restrict__ hit, double* __restrict__ tOut) {
+    __shared__ double sNl[13 * 11];
+    __shared__ double sRec[26];
+    stageQueryTables(T, sNl, sRec);
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double o[3], d[3], inv[3];
+        int sgn[3];
+        for (int a = 0; a < 3; ++a) {
+            o[a] = (origins[3 * i + a] - t.rootCentre[a]) * t.rootInvSizes[a];  // :711
+            d[a] = dirs[3 * i + a];
+            inv[a] = 1.0 / d[a];  // Ray.cpp:10 cwiseInverse
+            sgn[a] = inv[a] < 0.0 ? 1 : 0;
+        }
+        double im[3] = {o[0], o[1], o[2]};  // intMin
+        const float fx = (float)o[0], fy = (float)o[1], fz = (float)o[2];
+        const bool inside = fx >= -0.5f && fx <= 0.5f && fy >= -0.5f && fy <= 0.5f && fz >= -0.5f && fz <= 0.5f;
+        bool miss = false;
+        if (!inside) {  // Ray::IntersectAABB on [-0.5,0.5]^3, Ray.cpp:18-68
+            double a0 = ((sgn[0] ? 0.5 : -0.5) - o[0]) * inv[0], b0 = ((sgn[0] ? -0.5 : 0.5) - o[0]) * inv[0];
+            const double a1 = ((sgn[1] ? 0.5 : -0.5) - o[1]) * inv[1], b1 = ((sgn[1] ? -0.5 : 0.5) - o[1]) * inv[1];
+            if ((a0 > b1) || (a1 > b0)) {
+                miss = true;
+            } else {
+                if (a1 > a0) a0 = a1;
+                if (b1 < b0) b0 = b1;
+                const double a2 = ((sgn[2] ? 0.5 : -0.5) - o[2]) * inv[2], b2 = ((sgn[2] ? -0.5 : 0.5) - o[2]) * inv[2];
+                if ((a0 > b2) || (a2 > b0)) {
+                    miss = true;
+                } else {
+                    if (a2 > a0) a0 = a2;
+                    im[0] = a0, im[1] = a1, im[2] = a2;
+                }
+            }
+        }
+        uint8_t h = 0;
+        if (!miss) {
+            const double eps = 0.0001, minStep = 0.0001, lim = tMax[i];
+            double dist = 0.0;
+            for (int s = 0; s < 200; ++s) {
+                const double v = queryPoint<12>(t, im[0] + dist * d[0], im[1] + dist * d[1], im[2] + dist * d[2], sNl, sRec);
+                if (v < eps) {
+                    tOut[i] = v;  // :730
+                    h = 1;
+                    break;
+                }
+                dist = dist + (v * 0.95 + minStep);  // :736
+                if (dist > lim) break;
+            }
+        }
+        hit[i] = h;
+    }
+}
+
+// Sample values of Octree::OutputFunctionSlice (Octree.cpp:1144-1170): pixel (i, j) queries
+// (min.x + (f32)j*step, min.y + (f32)i*step, c), step = (max.x - min.x) / nSamples in f32.
+__global__ __launch_bounds__(256) void slice_kernel(TreeDev t, const DeviceTables* __restrict__ T, double c, float minX,
+                                                    float minY, float step, uint32_t nSamples, double* __restrict__ out) {
+    __shared__ double sNl[13 * 11];
+    __shared__ double sRec[26];
+    stageQueryTables(T, sNl, sRec);
+    __syncthreads();
+    const size_t total = (size_t)nSamples * nSamples, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += stride) {
+        const uint32_t i = (uint32_t)(p / nSamples), j = (uint32_t)(p - (size_t)i * nSamples);
+        const double x = (double)minX + (double)((float)j * step);
+        const double y = (double)minY + (double)((float)i * step);
+        out[p] = queryPoint<12>(t, x, y, c, sNl, sRec);
+    }
+}
+
 // F at a world-space point, with the optional CSG wrapper of Octree.cpp:355-400
 template <int KIND, bool CSG>
 __device__ __forceinline__ double fieldEvalWorld(const FieldDev& f, double x, double y, double z, uint64_t sampleIdx,
@@ -1176,6 +1257,22 @@ hipError_t launchQueryGrad(hipStream_t stream, const TreeDev& t, const DeviceTab
                            size_t n, double* dOut, double* dGrad) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(query_grad_kernel, dim3(gridFor(n)), dim3(256), 0, stream, t, dTables, dXyz, n, dOut, dGrad);
+    return hipGetLastError();
+}
+
+hipError_t launchQueryRay(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dOrigins,
+                          const double* dDirs, const double* dTMax, size_t n, uint8_t* dHit, double* dT) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(query_ray_kernel, dim3(gridFor(n)), dim3(256), 0, stream, t, dTables, dOrigins, dDirs, dTMax, n,
+                       dHit, dT);
+    return hipGetLastError();
+}
+
+hipError_t launchSlice(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, double c, float minX,
+                       float minY, float step, uint32_t nSamples, double* dOut) {
+    if (nSamples == 0) return hipSuccess;
+    hipLaunchKernelGGL(slice_kernel, dim3(gridFor((size_t)nSamples * nSamples)), dim3(256), 0, stream, t, dTables, c,
+                       minX, minY, step, nSamples, dOut);
     return hipGetLastError();
 }
 

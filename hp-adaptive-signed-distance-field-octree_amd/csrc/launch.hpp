@@ -30,6 +30,10 @@ hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables*
                        double* dOut, uint32_t* dDeferCount, uint32_t* dDeferIdx, bool allInline);
 hipError_t launchQueryGrad(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dXyz,
                            size_t n, double* dOut, double* dGrad);
+hipError_t launchQueryRay(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dOrigins,
+                          const double* dDirs, const double* dTMax, size_t n, uint8_t* dHit, double* dT);
+hipError_t launchSlice(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, double c, float minX,
+                       float minY, float step, uint32_t nSamples, double* dOut);
 hipError_t launchFieldEval(hipStream_t stream, const FieldDev& f, const DeviceTables* dTables, const double* dXyz,
                            size_t n, double* dOut);
 hipError_t launchPack(hipStream_t stream, const PackItem* dItems, uint32_t nItems, const double* dArena, double* dOut);

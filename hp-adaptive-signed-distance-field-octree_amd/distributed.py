@@ -9,6 +9,10 @@ Create
     applies identical headers in identical order, so the MemoryBlock is byte-identical for any
     world size (tests/test_distributed_gloo.py, tests/test_gpu_create.py).
 
+Continuity (config.continuity.enforce)
+    The host-side post-process runs on every rank on its identical copy of the assembled block; its
+    reductions are thread-count independent, so the ranks stay byte-identical without a collective.
+
 Query
     The tree is replicated (<= a few MB); points are split contiguously; no collective.
 
@@ -22,7 +26,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import Build, JOB_HEADER_DOUBLES
+from . import Build, JOB_HEADER_DOUBLES, continuity_post_process
 
 
 class _DevPtr:
@@ -89,6 +93,11 @@ def create_distributed(ctx, config, field, K=0, group=None, compute=None):
     block = b.assemble(packs)
     stats = b.stats()
     b.close()
+    if b.pod.continuity_enforce:
+        # Octree.cpp:341-344: host-side post-process; deterministic, so every rank computes the same block
+        # from its identical copy and no exchange is needed
+        block, cstats = continuity_post_process(block)
+        stats["continuity"] = cstats
     return block, stats
 
 

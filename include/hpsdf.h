@@ -161,6 +161,24 @@ HPSDF_API int hpsdf_query_gradient_device(hpsdf_ctx* ctx, const hpsdf_tree* t, c
 HPSDF_API int hpsdf_query_gradient_host(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* xyz, size_t n, double* out,
                                         double* grad);
 
+/* Octree::QueryRay (Octree.cpp:705-746; Ray: Include/HP/Ray.h, Source/HP/Ray.cpp:5-68) for n rays: sphere
+ * tracing, <= 200 Query steps each.  hit[i] = 1/0; t[i] is written only on a hit (the reference leaves t_
+ * untouched otherwise) and receives what the reference stores there -- the field value at the stopping point
+ * (Octree.cpp:730).  origins/dirs: xyz interleaved, world coordinates; dirs are used as given. */
+HPSDF_API int hpsdf_query_ray_device(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* d_origins,
+                                     const double* d_dirs, const double* d_tmax, size_t n, uint8_t* d_hit,
+                                     double* d_t);
+HPSDF_API int hpsdf_query_ray_host(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* origins, const double* dirs,
+                                   const double* tmax, size_t n, uint8_t* hit, double* t_out);
+
+/* Octree::OutputFunctionSlice (Octree.cpp:1131-1206) up to the byte image: n_samples^2 Query() calls on the
+ * plane z = c over [view_min.xy, view_min.xy + (view_max.x - view_min.x)) (the reference steps both axes by
+ * the x extent), then its green/blue normalisation.  rgb: n_samples^2 * 3 bytes, row i = y index (host);
+ * values: the n_samples^2 Query results (host, may be NULL).  The reference uses n_samples = 2048 and hands
+ * the bytes to stb_image_write (not a dependency here; include/hpsdf_octree.hpp writes the BMP itself). */
+HPSDF_API int hpsdf_function_slice(hpsdf_ctx* ctx, const hpsdf_tree* t, double c, const float* view_min,
+                                   const float* view_max, uint64_t n_samples, uint8_t* rgb, double* values);
+
 /* ---- Create: Octree::Create under the canonical round schedule ---------------
  * (Octree.cpp:312-352, 194-309, 558-659, 804-856, 1007-1093; schedule: DESIGN.md)
  *
@@ -224,7 +242,34 @@ HPSDF_API int hpsdf_build_pack_host(hpsdf_build* b, hpsdf_ctx* ctx, double* out)
 HPSDF_API int hpsdf_build_assemble(hpsdf_build* b, const double* const* packs, void** block, size_t* size);
 HPSDF_API int hpsdf_build_get_stats(const hpsdf_build* b, hpsdf_build_stats* out);
 
-/* whole Create on one GPU: begin .. assemble.  *block is malloc'd (caller frees). */
+/* ---- continuity post-process: Octree::PerformContinuityPostProcess (Octree.cpp:1717-1762) ------------
+ * Host side, as the reference's (which hands the system to Eigen): enumerate the face-adjacent leaf pairs
+ * (NodeProc/FaceProc, :1549-1612), assemble the jump-energy matrix M (analytic integrals for equal depths
+ * :1459-1546, Gauss-Legendre ones otherwise :1250-1456), solve (M + strength I) x = strength c by
+ * preconditioned CG from the guess strength c until |r| < tol |b| (the reference: tol = EPSILON_F32 with
+ * Eigen's IncompleteCholesky; here Jacobi -- same solution to solver tolerance), overwrite the coefficients.
+ * Deterministic for any thread count. */
+typedef struct hpsdf_continuity_stats {
+    uint64_t n_pairs, n_pairs_analytic, n_pairs_numeric, nnz, iterations;
+    double residual;    /* |b - A x| / |b| at exit */
+    double jump_before; /* c^T M c: jump energy of the fitted coefficients */
+    double jump_after;  /* x^T M x */
+    double assemble_ms, solve_ms;
+} hpsdf_continuity_stats;
+/* In place on a serialised block in host memory (the layout hpsdf_tree_upload takes); strength is read from
+ * the block's Config.  tol <= 0: EPSILON_F32 (1e-6, Octree.cpp:1754); max_iter <= 0: 2n (Eigen's default);
+ * threads 0: the block's config.thread_count (capped to the machine). */
+HPSDF_API int hpsdf_continuity_post_process(void* block, size_t size, double tol, int max_iter, uint64_t threads,
+                                            hpsdf_continuity_stats* stats);
+/* M itself (without the regularisation), CSR with duplicates summed; the three arrays are malloc'd, the
+ * caller frees them.  Test / diagnostic hook. */
+HPSDF_API int hpsdf_continuity_matrix(const void* block, size_t size, uint64_t threads, uint64_t** row_ptr,
+                                      uint64_t** col, double** val, hpsdf_continuity_stats* stats);
+/* stats of the last post-process hpsdf_create ran on this thread (zeros if it ran none) */
+HPSDF_API int hpsdf_continuity_last_stats(hpsdf_continuity_stats* out);
+
+/* whole Create on one GPU: begin .. assemble, then the continuity post-process when
+ * cfg->continuity_enforce is set (Octree.cpp:341-344).  *block is malloc'd (caller frees). */
 HPSDF_API int hpsdf_create(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* field,
                            uint64_t max_jobs_per_round, void** block, size_t* size, hpsdf_build_stats* stats);
 

@@ -16,12 +16,13 @@
 //     samples the callback with config.threadCount host threads per round.
 //   * errors: the reference asserts; here a failed call throws SDF::Error carrying
 //     hpsdf_last_error() (Query outside the root still returns DBL_MAX).
-//   * QueryRay / OutputFunctionSlice are not part of the hot path and are not
-//     provided yet.
+//   * QueryRay(origins, dirs, tMax, n, hit, t) -- batched sphere tracing on the GPU; QueryRay(ray, tMax, t)
+//     is the same path with n = 1.  OutputFunctionSlice needs no stb: the BMP is written here.
 #pragma once
 
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -74,17 +75,22 @@ struct HpsdfVec3 {
 };
 typedef HpsdfVec3<double> Vector3d;
 typedef HpsdfVec3<float> Vector3f;
-struct AlignedBox3f {
-    Vector3f lo, hi;
-    AlignedBox3f() : lo(FLT_MAX, FLT_MAX, FLT_MAX), hi(-FLT_MAX, -FLT_MAX, -FLT_MAX) {}
-    AlignedBox3f(const Vector3f& a, const Vector3f& b) : lo(a), hi(b) {}
-    Vector3f& min() { return lo; }
-    Vector3f& max() { return hi; }
-    const Vector3f& min() const { return lo; }
-    const Vector3f& max() const { return hi; }
-    Vector3f sizes() const { return hi - lo; }
-    float volume() const { return (hi.x() - lo.x()) * (hi.y() - lo.y()) * (hi.z() - lo.z()); }
+template <typename T>
+struct HpsdfBox3 {
+    HpsdfVec3<T> lo, hi;
+    HpsdfBox3()
+        : lo(std::numeric_limits<T>::max(), std::numeric_limits<T>::max(), std::numeric_limits<T>::max()),
+          hi(std::numeric_limits<T>::lowest(), std::numeric_limits<T>::lowest(), std::numeric_limits<T>::lowest()) {}
+    HpsdfBox3(const HpsdfVec3<T>& a, const HpsdfVec3<T>& b) : lo(a), hi(b) {}
+    HpsdfVec3<T>& min() { return lo; }
+    HpsdfVec3<T>& max() { return hi; }
+    const HpsdfVec3<T>& min() const { return lo; }
+    const HpsdfVec3<T>& max() const { return hi; }
+    HpsdfVec3<T> sizes() const { return hi - lo; }
+    T volume() const { return (hi.x() - lo.x()) * (hi.y() - lo.y()) * (hi.z() - lo.z()); }
 };
+typedef HpsdfBox3<float> AlignedBox3f;
+typedef HpsdfBox3<double> AlignedBox3d;
 }  // namespace Eigen
 #endif
 
@@ -161,6 +167,39 @@ struct Config {
         threadCount = (u32)d.thread_count;
         root = Eigen::AlignedBox3f(Eigen::Vector3f(d.root_min[0], d.root_min[1], d.root_min[2]),
                                    Eigen::Vector3f(d.root_max[0], d.root_max[1], d.root_max[2]));
+    }
+};
+
+/// Defines a line R(t) = O + t * D, where ||D||_2 = 1   (Include/HP/Ray.h:8-22, Source/HP/Ray.cpp:5-15)
+struct Ray {
+    Ray(const Eigen::Vector3d& origin_, const Eigen::Vector3d& direction_) : origin(origin_), direction(direction_) {
+        for (int a = 0; a < 3; ++a) {
+            invDirection(a) = 1.0 / direction_(a);
+            sign[a] = invDirection(a) < 0.0;
+        }
+    }
+    Eigen::Vector3d origin;
+    Eigen::Vector3d direction;
+    Eigen::Vector3d invDirection;
+    int sign[3];
+
+    /// Returns whether the ray intersects the box and, if so, stores the slab parameters in a_ and b_
+    /// (Source/HP/Ray.cpp:18-68; host-side helper, the batched QueryRay does the same on the GPU)
+    bool IntersectAABB(const Eigen::AlignedBox3d& aabb_, Eigen::Vector3d& a_, Eigen::Vector3d& b_) const {
+        const Eigen::Vector3d bounds[2] = {aabb_.min(), aabb_.max()};
+        a_(0) = (bounds[sign[0]](0) - origin(0)) * invDirection(0);
+        b_(0) = (bounds[1 - sign[0]](0) - origin(0)) * invDirection(0);
+        a_(1) = (bounds[sign[1]](1) - origin(1)) * invDirection(1);
+        b_(1) = (bounds[1 - sign[1]](1) - origin(1)) * invDirection(1);
+        if ((a_(0) > b_(1)) || (a_(1) > b_(0))) return false;
+        if (a_(1) > a_(0)) a_(0) = a_(1);
+        if (b_(1) < b_(0)) b_(0) = b_(1);
+        a_(2) = (bounds[sign[2]](2) - origin(2)) * invDirection(2);
+        b_(2) = (bounds[1 - sign[2]](2) - origin(2)) * invDirection(2);
+        if ((a_(0) > b_(2)) || (a_(2) > b_(0))) return false;
+        if (a_(2) > a_(0)) a_(0) = a_(2);
+        if (b_(2) < b_(0)) b_(0) = b_(2);
+        return true;
     }
 };
 
@@ -310,6 +349,55 @@ class Octree {
     void QueryWithGradient(const double* xyz, usize n, double* out, double* grad) const {
         if (!tree_) throw Error(HPSDF_ERR_STATE, "Query on an empty octree");
         check(hpsdf_query_gradient_host(ctx_, tree_, xyz, n, out, grad));
+    }
+
+    /// Sphere tracing along ray_ (<= 200 Query steps).  As in the reference (Octree.cpp:705-746), t_ receives
+    /// the field value at the stopping point on a hit and is left untouched otherwise   (Octree.h:75)
+    bool QueryRay(const Ray& ray_, const f64 tMax_, f64& t_) const {
+        const double o[3] = {ray_.origin(0), ray_.origin(1), ray_.origin(2)};
+        const double d[3] = {ray_.direction(0), ray_.direction(1), ray_.direction(2)};
+        uint8_t hit = 0;
+        double t = t_;
+        QueryRay(o, d, &tMax_, 1, &hit, &t);
+        if (hit) t_ = t;
+        return hit != 0;
+    }
+    /// Batched form over host arrays; t rows of misses are left untouched
+    void QueryRay(const double* origins, const double* dirs, const double* tMax, usize n, uint8_t* hit, double* t) const {
+        if (!tree_) throw Error(HPSDF_ERR_STATE, "Query on an empty octree");
+        check(hpsdf_query_ray_host(ctx_, tree_, origins, dirs, tMax, n, hit, t));
+    }
+
+    /// Outputs an image of the z = c_ slice over viewArea_ to <fName_>.bmp   (Octree.h:83-86, Octree.cpp:1131-1206;
+    /// the reference needs stb_image_write for this, here the 24-bit BMP is written directly)
+    void OutputFunctionSlice(const char* fName_, const f64 c_, const Eigen::AlignedBox3f& viewArea_) const {
+        if (!tree_) throw Error(HPSDF_ERR_STATE, "Query on an empty octree");
+        const uint64_t n = 2048;
+        std::vector<uint8_t> rgb(n * n * 3);
+        const float vmin[3] = {viewArea_.min()(0), viewArea_.min()(1), viewArea_.min()(2)};
+        const float vmax[3] = {viewArea_.max()(0), viewArea_.max()(1), viewArea_.max()(2)};
+        check(hpsdf_function_slice(ctx_, tree_, c_, vmin, vmax, n, rgb.data(), nullptr));
+        const std::string path = std::string(fName_) + ".bmp";
+        std::FILE* fh = std::fopen(path.c_str(), "wb");
+        if (!fh) throw Error(HPSDF_ERR_STATE, "cannot open " + path);
+        const uint32_t rowBytes = (uint32_t)(3 * n), pad = (4 - rowBytes % 4) % 4;
+        const uint32_t fileSize = 14 + 40 + (rowBytes + pad) * (uint32_t)n;
+        uint8_t hdr[54] = {0};
+        auto put32 = [&](int off, uint32_t v) { std::memcpy(hdr + off, &v, 4); };
+        auto put16 = [&](int off, uint16_t v) { std::memcpy(hdr + off, &v, 2); };
+        hdr[0] = 'B', hdr[1] = 'M';
+        put32(2, fileSize), put32(10, 54), put32(14, 40), put32(18, (uint32_t)n), put32(22, (uint32_t)n);
+        put16(26, 1), put16(28, 24);
+        std::fwrite(hdr, 1, sizeof hdr, fh);
+        std::vector<uint8_t> row(rowBytes + pad, 0);
+        for (uint64_t i = n; i-- > 0;) {  // bottom-up rows, BGR
+            for (uint64_t j = 0; j < n; ++j) {
+                const uint8_t* px = &rgb[3 * (i * n + j)];
+                row[3 * j] = px[2], row[3 * j + 1] = px[1], row[3 * j + 2] = px[0];
+            }
+            std::fwrite(row.data(), 1, row.size(), fh);
+        }
+        std::fclose(fh);
     }
 
     /// Returns the aabb of the root node   (Octree.h:81)

@@ -186,6 +186,33 @@ double ora_fapprox_with_gradient(const double* coeffs, int degree, const float b
 double ora_query_with_gradient(const ora_tree* t, const double pt[3], double grad[3]);
 void ora_query_gradient_batch(const ora_tree* t, const double* xyz, size_t n, double* out, double* grad);
 
+/* ---- query-side helpers on top of Query -- see hp_oracle_ray.c.  Parity unpinned: the
+ * reference has no test of either and OutputFunctionSlice needs stb (absent). */
+/* Octree::QueryRay, Octree.cpp:705-746 (Ray, Source/HP/Ray.cpp).  1 = hit (*t_out written) */
+int ora_query_ray(const ora_tree* t, const double origin[3], const double direction[3], double t_max, double* t_out);
+void ora_query_ray_batch(const ora_tree* t, const double* origins, const double* directions, const double* t_max,
+                         size_t n, uint8_t* hit, double* t_out);
+/* Octree::OutputFunctionSlice, Octree.cpp:1131-1206, up to the RGB byte image */
+void ora_function_slice(const ora_tree* t, double c, const float view_min[3], const float view_max[3],
+                        uint64_t n_samples, uint8_t* rgb, double* values);
+uint8_t ora_f64_to_u8(double q);
+
+/* ---- continuity post-process -- see hp_oracle_continuity.c ---
+ * Octree::PerformContinuityPostProcess, Octree.cpp:1250-1762: face-pair enumeration, jump-energy matrix,
+ * (M + strength I) x = strength c solved by preconditioned CG to relative residual `tol` (reference:
+ * EPSILON_F32 = 1e-6 with Eigen's IncompleteCholesky; here Jacobi -- the solver is unpinned Eigen arithmetic,
+ * so parity is to solver tolerance only).  Overwrites t->coeff_store.  Returns CG iterations, < 0 on error. */
+typedef struct {
+    uint64_t n_pairs, n_pairs_analytic, n_pairs_numeric, nnz, iterations;
+    double residual;     /* |b - A x| / |b| at exit */
+    double jump_before;  /* c^T M c   (jump energy of the input coefficients) */
+    double jump_after;   /* x^T M x */
+} ora_continuity_stats;
+int ora_continuity_post_process(ora_tree* t, double tol, int max_iter, ora_continuity_stats* stats);
+/* the assembled matrix (without the regularisation) in CSR, duplicates summed; caller frees the three arrays */
+int ora_continuity_matrix(const ora_tree* t, uint64_t** row_ptr, uint64_t** col, double** val,
+                          ora_continuity_stats* stats);
+
 /* ---- mesh field (Source/Meshing) -- see hp_oracle_mesh.c ---------------- */
 typedef struct ora_mesh ora_mesh;
 ora_mesh* ora_mesh_create(const float* verts, uint64_t nverts, const uint64_t* tris, uint64_t ntris);

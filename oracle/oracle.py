@@ -60,6 +60,12 @@ class JobResult(C.Structure):
                 ("refine_p", C.c_int32), ("refine_h", C.c_int32), ("coarse", C.c_int32)]
 
 
+class ContinuityStats(C.Structure):
+    _fields_ = [("n_pairs", C.c_uint64), ("n_pairs_analytic", C.c_uint64), ("n_pairs_numeric", C.c_uint64),
+                ("nnz", C.c_uint64), ("iterations", C.c_uint64), ("residual", C.c_double),
+                ("jump_before", C.c_double), ("jump_after", C.c_double)]
+
+
 class BuildStats(C.Structure):
     _fields_ = [("rounds", C.c_uint64), ("jobs", C.c_uint64), ("p_refines", C.c_uint64), ("h_refines", C.c_uint64),
                 ("dropped", C.c_uint64), ("fits", C.c_uint64), ("total_error", C.c_double)]
@@ -68,7 +74,8 @@ class BuildStats(C.Structure):
 def build(force=False):
     """Compile oracle/liboracle.so (and oracle/_ref when /root/reference exists)."""
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("hp_oracle.c", "hp_oracle_mesh.c", "hp_oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("hp_oracle.c", "hp_oracle_mesh.c", "hp_oracle_ray.c", "hp_oracle_continuity.c",
+                                            "hp_oracle.h", "Makefile")]
     stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if stale:
         subprocess.run(["make", "-C", _HERE, "liboracle.so"], check=True, capture_output=True)
@@ -112,6 +119,13 @@ def lib():
     L.ora_query.argtypes = [C.c_void_p, dp]
     L.ora_query_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.ora_query_gradient_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.ora_query_ray_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.ora_function_slice.argtypes = [C.c_void_p, C.c_double, fp, fp, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.ora_continuity_post_process.restype = C.c_int
+    L.ora_continuity_post_process.argtypes = [C.c_void_p, C.c_double, C.c_int, C.POINTER(ContinuityStats)]
+    L.ora_continuity_matrix.restype = C.c_int
+    L.ora_continuity_matrix.argtypes = [C.c_void_p, C.POINTER(u64p), C.POINTER(u64p), C.POINTER(dp),
+                                        C.POINTER(ContinuityStats)]
     L.ora_mesh_create.restype = C.c_void_p
     L.ora_mesh_create.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
     L.ora_mesh_free.argtypes = [C.c_void_p]
@@ -334,6 +348,53 @@ class Tree:
         lib().ora_query_gradient_batch(self.handle, pts.ctypes.data_as(C.c_void_p), len(pts),
                                        out.ctypes.data_as(C.c_void_p), grad.ctypes.data_as(C.c_void_p))
         return out, grad
+
+    def query_ray(self, origins, directions, t_max, t_init=None):
+        """Octree::QueryRay per row: (hit u8, t) -- t rows of misses keep t_init."""
+        o = np.ascontiguousarray(origins, np.float64).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, np.float64).reshape(-1, 3)
+        n = len(o)
+        tm = np.ascontiguousarray(np.broadcast_to(np.asarray(t_max, np.float64), (n,)))
+        hit = np.zeros(n, np.uint8)
+        t = np.zeros(n) if t_init is None else np.array(t_init, np.float64).reshape(n).copy()
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        lib().ora_query_ray_batch(self.handle, vp(o), vp(d), vp(tm), n, vp(hit), vp(t))
+        return hit, t
+
+    def function_slice(self, c, view_min, view_max, n_samples=2048):
+        """Octree::OutputFunctionSlice up to the byte image: (rgb [n,n,3] u8, values [n,n] f64)."""
+        n = int(n_samples)
+        rgb = np.zeros((n, n, 3), np.uint8)
+        vals = np.zeros((n, n))
+        lib().ora_function_slice(self.handle, float(c), _f3(view_min), _f3(view_max), n,
+                                 rgb.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p))
+        return rgb, vals
+
+    def continuity_post_process(self, tol=1e-6, max_iter=0):
+        """Octree::PerformContinuityPostProcess in place; returns the stats dict."""
+        st = ContinuityStats()
+        rc = lib().ora_continuity_post_process(self.handle, tol, max_iter, C.byref(st))
+        if rc < 0:
+            raise RuntimeError("continuity failed")
+        return {k: getattr(st, k) for k, _ in ContinuityStats._fields_}
+
+    def continuity_matrix(self):
+        """(row_ptr, col, val) CSR of the jump-energy matrix M (no regularisation), duplicates summed."""
+        L = lib()
+        dp, u64p = C.POINTER(C.c_double), C.POINTER(C.c_uint64)
+        rp, ci, v = u64p(), u64p(), dp()
+        st = ContinuityStats()
+        L.ora_continuity_matrix(self.handle, C.byref(rp), C.byref(ci), C.byref(v), C.byref(st))
+        n = len(parse_block(self.to_block())["coeffs"])
+        row_ptr = np.ctypeslib.as_array(rp, shape=(n + 1,)).copy()
+        nnz = int(row_ptr[-1])
+        col = np.ctypeslib.as_array(ci, shape=(max(nnz, 1),))[:nnz].copy()
+        val = np.ctypeslib.as_array(v, shape=(max(nnz, 1),))[:nnz].copy()
+        libc = C.CDLL(None)
+        libc.free.argtypes = [C.c_void_p]
+        for p in (rp, ci, v):
+            libc.free(C.cast(p, C.c_void_p))
+        return row_ptr, col, val, {k: getattr(st, k) for k, _ in ContinuityStats._fields_}
 
     def __del__(self):
         if getattr(self, "handle", None):

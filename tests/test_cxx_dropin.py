@@ -11,8 +11,10 @@ from conftest import ROOT
 
 SRC = r'''
 #include "HP/Octree.h"   // the reference's include path (Include/HP/Octree.h)
+#include "HP/Ray.h"
 #include <cstdio>
 #include <cmath>
+#include <string>
 #include <vector>
 int main(int argc, char** argv) {
     try {
@@ -52,6 +54,21 @@ int main(int argc, char** argv) {
         if (qg != q0 || std::fabs(nrm.norm() - 1.0) > 1e-12) { printf("QueryWithGradient\n"); return 8; }
         const Eigen::Vector3d tn((p.x() - 0.25), p.y(), p.z());
         if ((nrm.x() * tn.x() + nrm.y() * tn.y() + nrm.z() * tn.z()) / tn.norm() < 0.9) { printf("gradient direction\n"); return 9; }
+        // QueryRay (Include/HP/Octree.h:75): marching from outside the sphere towards it hits, t = field value there
+        f64 t = -1.0;
+        if (!hpOctree.QueryRay(SDF::Ray(Eigen::Vector3d(-0.45, 0, 0), Eigen::Vector3d(1, 0, 0)), 5.0, t) || !(t >= 0.0 && t < 1e-4)) { printf("QueryRay hit\n"); return 10; }
+        t = -1.0;
+        if (hpOctree.QueryRay(SDF::Ray(Eigen::Vector3d(-0.45, 0, 0), Eigen::Vector3d(-1, 0, 0)), 5.0, t) || t != -1.0) { printf("QueryRay miss\n"); return 11; }
+        Eigen::Vector3d ia, ib;
+        if (!SDF::Ray(Eigen::Vector3d(-2, 0, 0), Eigen::Vector3d(1, 0, 0)).IntersectAABB(Eigen::AlignedBox3d(Eigen::Vector3d(-.5,-.5,-.5), Eigen::Vector3d(.5,.5,.5)), ia, ib) || ia(0) != 1.5 || ib(0) != 2.5) { printf("IntersectAABB\n"); return 12; }
+        if (argc > 2) {   // OutputFunctionSlice (Include/HP/Octree.h:83-86) -> <name>.bmp
+            hpOctree.OutputFunctionSlice(argv[2], 0.0, hpOctree.GetRootAABB());
+            FILE* bmp = fopen((std::string(argv[2]) + ".bmp").c_str(), "rb");
+            if (!bmp) { printf("no bmp\n"); return 13; }
+            fseek(bmp, 0, SEEK_END);
+            if (ftell(bmp) != 54 + 2048L * 2048L * 3L) { printf("bmp size\n"); return 14; }
+            fclose(bmp);
+        }
         free(a.ptr); free(b.ptr);
         printf("OK %zu\n", a.size);
         return 0;
@@ -87,7 +104,7 @@ def test_dropin_compiles_and_fails_loudly_without_gpu(H, tmp_path):
 def test_dropin_reproduces_oracle_block(H, golden, tmp_path):
     exe = build_prog(H, str(tmp_path))
     out = tmp_path / "blk.bin"
-    r = subprocess.run([exe, str(out)], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([exe, str(out), str(tmp_path / "slice")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     blk = bytearray(open(out, "rb").read())
     g = golden["blocks"]["C1_sphere_1e-4"]

@@ -395,3 +395,52 @@ def test_capi_argument_checks(H, ctx):
     with pytest.raises(H.HpsdfError) as e:
         f.eval(ctx, np.zeros((4, 3)))
     assert e.value.status == H.ERR_UNSUPPORTED
+
+
+# ------------------------------------------------------------------ QueryRay / OutputFunctionSlice
+def _ray_set(rng, n):
+    o = rng.uniform(-0.6, 0.6, (n, 3))           # most inside the root, some outside
+    o[: n // 8] = rng.uniform(-3.0, 3.0, (n // 8, 3))  # far outside: IntersectAABB path
+    d = rng.standard_normal((n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[n // 8: n // 8 + 16, 1] = 0.0              # axis-parallel components: infinite slab parameters
+    d[n // 8 + 16: n // 8 + 32] = [1.0, 0.0, 0.0]
+    tmax = rng.uniform(0.05, 3.0, n)
+    return o, d, tmax
+
+
+@pytest.mark.parametrize("case", ["C1_sphere_1e-4", "A1_union3_1e-7_K1024", "D1_sphere075_customroot_1e-6"])
+def test_query_ray_bitwise(H, O, ctx, golden, case):
+    g = golden["blocks"][case]
+    blk = O.Tree.create(O.default_config(g["target"], g["root_min"], g["root_max"]), oracle_field(O, g["field"]), g["K"]).to_block()
+    o, d, tmax = _ray_set(np.random.default_rng(11), 20000)
+    lo, hi = np.array(g["root_min"]), np.array(g["root_max"])
+    o = (o + 0.5) * (hi - lo) + lo
+    init = np.full(len(o), -123.0)
+    hit, t = H.DeviceTree(ctx, blk).query_ray(o, d, tmax, t_init=init)
+    whit, wt = O.Tree.from_block(blk).query_ray(o, d, tmax, t_init=init)
+    assert np.array_equal(hit, whit)
+    assert np.array_equal(bits(t), bits(wt))
+    assert 0 < hit.sum() < len(hit)
+    assert np.all(t[hit == 0] == -123.0)  # t_ untouched on a miss (Octree.cpp:705-746)
+
+
+def test_function_slice_bitwise(H, O, ctx, golden, tmp_path):
+    g = golden["blocks"]["C2_union3_1e-5"]
+    blk = O.Tree.create(O.default_config(g["target"]), oracle_field(O, g["field"]), g["K"]).to_block()
+    dt, ot = H.DeviceTree(ctx, blk), O.Tree.from_block(blk)
+    for c, vmin, vmax, n in ((0.1, (-0.5, -0.5, -0.5), (0.5, 0.5, 0.5), 256),
+                             (-0.2, (-0.7, -0.3, 0.0), (0.4, 0.9, 0.0), 200)):  # partly outside the root
+        rgb, vals = dt.function_slice(c, vmin, vmax, n)
+        wrgb, wvals = ot.function_slice(c, vmin, vmax, n)
+        assert np.array_equal(bits(vals), bits(wvals))
+        assert np.array_equal(rgb, wrgb)
+    # the reference's 2048^2 image through the Octree mirror, written as a BMP
+    oc = H.Octree()
+    oc.FromMemoryBlock(blk)
+    rgb = oc.OutputFunctionSlice(str(tmp_path / "slice"), 0.1, (-0.5, -0.5, -0.5), (0.5, 0.5, 0.5))
+    raw = open(str(tmp_path / "slice.bmp"), "rb").read()
+    assert raw[:2] == b"BM" and len(raw) == 54 + 2048 * 2048 * 3
+    assert rgb.shape == (2048, 2048, 3) and rgb[..., 1].max() == 255 and rgb[..., 2].max() == 255
+    # bottom-up BGR rows: the file's first pixel is image row 2047, column 0
+    assert raw[54:57] == bytes(rgb[2047, 0, ::-1])
