@@ -404,6 +404,7 @@ class Octree {
     Eigen::AlignedBox3f GetRootAABB() const { return config_.root; }
 
     const hpsdf_build_stats& LastBuildStats() const { return stats_; }
+    const hpsdf_continuity_stats& LastContinuityStats() const { return continuity_; }
     const Config& GetConfig() const { return config_; }
 
    private:
@@ -449,8 +450,9 @@ class Octree {
         size_ = sz;
         config_ = config;
         uploadTree();
-        // continuity.enforce: the reference's host-side Eigen CG post-process (Octree.cpp:341-344)
-        // is outside the GPU hot path and not applied here.
+        // continuity.enforce: hpsdf_create has already run the host-side post-process (Octree.cpp:341-344)
+        // on the block; LastContinuityStats() reports it.
+        hpsdf_continuity_last_stats(&continuity_);
     }
     void csg(int op, const hpsdf_field* inner) {
         if (!tree_) throw Error(HPSDF_ERR_STATE, "CSG on an empty octree");
@@ -505,6 +507,7 @@ class Octree {
     size_t size_ = 0;
     Config config_;
     hpsdf_build_stats stats_{};
+    hpsdf_continuity_stats continuity_{};
 };
 
 }  // namespace SDF
