@@ -103,6 +103,8 @@ _SIGNATURES = {
     "hpsdf_field_create_callback": (C.c_int, [CALLBACK, C.c_void_p, C.POINTER(C.c_void_p)]),
     "hpsdf_field_create_mesh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                           C.POINTER(C.c_void_p)]),
+    "hpsdf_obj_load": (C.c_int, [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint64),
+                                 C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint64)]),
     "hpsdf_field_create_tree_csg": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "hpsdf_field_destroy": (C.c_int, [C.c_void_p]),
     "hpsdf_field_eval_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -682,18 +684,13 @@ def write_bmp(path, rgb):
 
 
 def load_obj(path):
-    """Minimal OBJ reader for the mesh field: `v x y z` and triangular `f a b c` / `a/t/n` / `a//n` records
-    (the three face formats Source/Meshing/ObjParser.cpp:11-164 accepts).  Returns (verts f32 [n,3], tris u64 [m,3]),
-    0-based.  One-off host preprocessing, not part of the hot path."""
-    verts, tris = [], []
-    with open(path) as fh:
-        for line in fh:
-            if line.startswith("v "):
-                p = line.split()
-                verts.append((float(p[1]), float(p[2]), float(p[3])))
-            elif line.startswith("f "):
-                idx = [int(tok.split("/")[0]) for tok in line.split()[1:]]
-                if len(idx) != 3:
-                    raise ValueError("only triangles are supported: " + line.strip())
-                tris.append([i - 1 if i > 0 else len(verts) + i for i in idx])
-    return np.asarray(verts, np.float32), np.asarray(tris, np.uint64)
+    """Meshing::ObjParser::Load (Source/Meshing/ObjParser.cpp:11-164) through the native reader:
+    (verts f32 [n,3], tris u64 [m,3]), zero-based."""
+    v, t = C.POINTER(C.c_float)(), C.POINTER(C.c_uint64)()
+    nv, nt = C.c_uint64(), C.c_uint64()
+    check(lib().hpsdf_obj_load(os.fsencode(path), C.byref(v), C.byref(nv), C.byref(t), C.byref(nt)))
+    verts = np.ctypeslib.as_array(v, shape=(nv.value, 3)).copy()
+    tris = np.ctypeslib.as_array(t, shape=(nt.value, 3)).copy()
+    lib()._libc.free(C.cast(v, C.c_void_p))
+    lib()._libc.free(C.cast(t, C.c_void_p))
+    return verts, tris

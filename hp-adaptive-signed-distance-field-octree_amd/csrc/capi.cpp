@@ -21,6 +21,8 @@ using namespace hpsdf;
 
 namespace hpsdf {
 
+int loadObj(const char* path, std::vector<float>& verts, std::vector<uint64_t>& tris, std::string& err);  // obj.cpp
+
 static thread_local std::string g_lastError;
 static thread_local hpsdf_continuity_stats g_lastContinuity = {};
 
@@ -264,6 +266,30 @@ int hpsdf_field_create_mesh(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts,
         return hipFail(e, "mesh upload");
     }
     *out = f;
+    return HPSDF_OK;
+    HPSDF_CATCH
+}
+
+int hpsdf_obj_load(const char* path, float** verts, uint64_t* nVerts, uint64_t** tris, uint64_t* nTris) {
+    HPSDF_TRY
+    if (!path || !verts || !nVerts || !tris || !nTris) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    *verts = nullptr, *tris = nullptr, *nVerts = 0, *nTris = 0;
+    std::vector<float> v;
+    std::vector<uint64_t> t;
+    std::string err;
+    const int rc = loadObj(path, v, t, err);
+    if (rc) return fail(rc, err);
+    *verts = (float*)std::malloc(v.size() * sizeof(float));
+    *tris = (uint64_t*)std::malloc(t.size() * sizeof(uint64_t));
+    if (!*verts || !*tris) {
+        std::free(*verts), std::free(*tris);
+        *verts = nullptr, *tris = nullptr;
+        return fail(HPSDF_ERR_OUT_OF_MEMORY, "malloc failed");
+    }
+    std::memcpy(*verts, v.data(), v.size() * sizeof(float));
+    std::memcpy(*tris, t.data(), t.size() * sizeof(uint64_t));
+    *nVerts = v.size() / 3;
+    *nTris = t.size() / 3;
     return HPSDF_OK;
     HPSDF_CATCH
 }

@@ -9,6 +9,7 @@
 #include <cfloat>
 #include <cstring>
 #include <numeric>
+#include <thread>
 
 #include "runtime.hpp"
 
@@ -68,11 +69,13 @@ struct Builder {
     std::vector<float> triBox;  // 6 per triangle
     std::vector<float> cen;     // 3 per triangle
     std::vector<uint32_t> ids;
-    std::vector<BvhNode>& nodes;
+    std::vector<BvhNode>& nodes;  // preallocated: a subtree over m triangles owns m - 1 consecutive nodes (preorder)
 
-    // median split on the longest centroid axis; returns the child reference (node index, or ~triangle for a
-    // leaf) and the box of the subtree
-    int32_t build(size_t lo, size_t hi, float* bmin, float* bmax) {
+    // Median split on the longest centroid axis.  `node` is the preorder index of this subtree's root, so the
+    // layout is fixed before anything is built and the upper levels can hand their right halves to other threads
+    // (the result is the sequential build's, byte for byte).  Returns the child reference (node index, or
+    // ~triangle for a leaf) and the box of the subtree.
+    int32_t build(size_t lo, size_t hi, int32_t node, int spawnDepth, float* bmin, float* bmax) {
         if (hi - lo == 1) {
             const uint32_t t = ids[lo];
             for (int a = 0; a < 3; ++a) {
@@ -81,8 +84,6 @@ struct Builder {
             }
             return ~(int32_t)t;
         }
-        const int32_t node = (int32_t)nodes.size();
-        nodes.emplace_back();
         float cmin[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, cmax[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
         for (size_t i = lo; i < hi; ++i)
             for (int a = 0; a < 3; ++a) {
@@ -98,8 +99,16 @@ struct Builder {
             return cx < cy || (cx == cy && x < y);
         });
         float l0[3], h0[3], l1[3], h1[3];
-        const int32_t c0 = build(lo, mid, l0, h0);
-        const int32_t c1 = build(mid, hi, l1, h1);
+        int32_t c0, c1;
+        const int32_t leftNode = node + 1, rightNode = node + (int32_t)(mid - lo);  // left subtree: mid - lo - 1 nodes
+        if (spawnDepth > 0 && hi - lo > 4096) {
+            std::thread right([&] { c1 = build(mid, hi, rightNode, spawnDepth - 1, l1, h1); });
+            c0 = build(lo, mid, leftNode, spawnDepth - 1, l0, h0);
+            right.join();
+        } else {
+            c0 = build(lo, mid, leftNode, 0, l0, h0);
+            c1 = build(mid, hi, rightNode, 0, l1, h1);
+        }
         BvhNode& n = nodes[node];
         std::memset(&n, 0, sizeof n);
         for (int a = 0; a < 3; ++a) {
@@ -123,8 +132,7 @@ bool prepareMesh(const float* verts, uint64_t nVerts, const uint64_t* tris, uint
         out->tris[i] = (uint32_t)tris[i];
     }
     if (!twinHalfEdges(out->tris, out->halfEdges)) return false;
-    out->bvh.clear();
-    out->bvh.reserve(nTris);
+    out->bvh.assign(nTris > 1 ? nTris - 1 : 1, BvhNode{});
     Builder b{{}, {}, {}, out->bvh};
     b.triBox.resize(6 * nTris);
     b.cen.resize(3 * nTris);
@@ -147,11 +155,14 @@ bool prepareMesh(const float* verts, uint64_t nVerts, const uint64_t* tris, uint
             n.hi0[a] = n.hi1[a] = b.triBox[3 + a];
         }
         n.c0 = n.c1 = ~0;
-        out->bvh.push_back(n);
+        out->bvh[0] = n;
         return true;
     }
     float bmin[3], bmax[3];
-    b.build(0, nTris, bmin, bmax);
+    unsigned hc = std::thread::hardware_concurrency();
+    int spawnDepth = 0;  // 2^spawnDepth concurrent subtrees, at most 16
+    while (spawnDepth < 4 && (2u << spawnDepth) <= (hc ? hc : 1)) ++spawnDepth;
+    b.build(0, nTris, 0, spawnDepth, bmin, bmax);
     return true;
 }
 

@@ -132,6 +132,10 @@ HPSDF_API int hpsdf_field_create_callback(hpsdf_callback cb, void* user, hpsdf_f
  * over a device BVH.  tris: 3 vertex indices per triangle, CCW. */
 HPSDF_API int hpsdf_field_create_mesh(hpsdf_ctx* ctx, const float* verts, uint64_t n_verts, const uint64_t* tris,
                                       uint64_t n_tris, hpsdf_field** out);
+/* Meshing::ObjParser::Load (Source/Meshing/ObjParser.cpp:11-164): `v` records and triangular `f` records in
+ * the spellings a, a/t, a//n, a/t/n.  *verts (3 floats per vertex) and *tris (3 zero-based indices per
+ * triangle) are malloc'd; the caller frees them.  Host-only: needs no device. */
+HPSDF_API int hpsdf_obj_load(const char* path, float** verts, uint64_t* n_verts, uint64_t** tris, uint64_t* n_tris);
 /* F'(p) = op(old.Query(p), inner(p)): Octree::UnionSDF/SubtractSDF/IntersectSDF, Octree.cpp:355-400.
  * op: HPSDF_OP_UNION -> min(old,F); HPSDF_OP_SUBTRACT -> max(-old,F); HPSDF_OP_INTERSECT -> max(old,F). */
 HPSDF_API int hpsdf_field_create_tree_csg(const hpsdf_tree* old_tree, int op, const hpsdf_field* inner,

@@ -277,6 +277,11 @@ class Octree {
     }
     /// Same, with a field evaluated on the GPU.
     void Create(const Config& config_, const DeviceField& F_) { createFrom(config_, F_.f_); }
+    /// Same, with a field handle of the C ABI (e.g. Meshing::BVH::Field()); the handle stays the caller's
+    void Create(const Config& config_, const hpsdf_field* F_) {
+        if (!F_) throw Error(HPSDF_ERR_INVALID_ARGUMENT, "null field");
+        createFrom(config_, F_);
+    }
 
     /// Resultant SDF = Min(oldF, F_)   (Octree.h:53, Octree.cpp:355-374)
     void UnionSDF(Func F_) { csg(HPSDF_OP_UNION, std::move(F_)); }

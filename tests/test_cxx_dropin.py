@@ -113,3 +113,88 @@ def test_dropin_reproduces_oracle_block(H, golden, tmp_path):
     import numpy as np
     blk[-80 + 48:-80 + 56] = np.array([1], np.uint64).tobytes()
     assert hashlib.sha256(bytes(blk)).hexdigest() == g["block_sha256"]
+
+
+MESH_SRC = r'''
+#include "Meshing/Mesh.h"     // the reference's include paths (Include/Meshing/*.h, Include/HP/Octree.h)
+#include "Meshing/BVH.h"
+#include "Meshing/ObjParser.h"
+#include "HP/Octree.h"
+#include <cstdio>
+#include <cmath>
+#include <vector>
+int main(int argc, char** argv) {
+    try {
+        Meshing::ObjParser parser;
+        if (!parser.Load(argv[1])) { printf("ObjParser::Load\n"); return 2; }
+        if (parser.GetVertices().size() != 642 || parser.GetTriIndices().size() != 3 * 1280) { printf("counts\n"); return 3; }
+        const Eigen::Vector3f n0 = parser.GetVertexNormals()[0], v0 = parser.GetVertices()[0];
+        if (std::fabs(n0.norm() - 1.0f) > 1e-5f || (n0.x() * v0.x() + n0.y() * v0.y() + n0.z() * v0.z()) / v0.norm() < 0.99f) { printf("vertex normals\n"); return 4; }
+        Meshing::Mesh mesh;                                   // as Source/Tests/MeshingUnitTests.cpp:92-138
+        if (!mesh.CreateFromObj(argv[1])) { printf("CreateFromObj\n"); return 5; }
+        const Eigen::AlignedBox3f box = mesh.CalculateMeshAABB();
+        if (std::fabs(box.min().x() + 0.35f) > 1e-3f || std::fabs(box.max().z() - 0.35f) > 1e-2f) { printf("aabb\n"); return 6; }
+        Meshing::BVH bvh;
+        if (!bvh.Create(mesh)) { printf("BVH::Create: %s\n", hpsdf_last_error()); return hpsdf_last_error()[0] ? 42 : 7; }
+        std::vector<float> xyz, out(2000);
+        for (int i = 0; i < 2000; ++i) for (int a = 0; a < 3; ++a) xyz.push_back(-0.5f + ((i * 7919 + a * 104729) % 1000) / 1000.0f);
+        mesh.SignedDistanceAtPt(xyz.data(), 2000, out.data(), bvh);
+        for (int i = 0; i < 2000; ++i) {
+            const float r = std::sqrt(xyz[3*i]*xyz[3*i] + xyz[3*i+1]*xyz[3*i+1] + xyz[3*i+2]*xyz[3*i+2]);
+            if (std::fabs(out[i] - (r - 0.35f)) > 4e-3f) { printf("distance %d: %g vs %g\n", i, out[i], r - 0.35f); return 8; }
+        }
+        const Eigen::Vector3f p(0.1f, 0.2f, -0.3f);
+        if (mesh.SignedDistanceAtPt(p, bvh, 0) != mesh.SignedDistanceAtPt(p, bvh, 3)) { printf("single point\n"); return 9; }
+        SDF::Config cfg;
+        cfg.targetErrorThreshold = 1e-5;
+        cfg.continuity.enforce = false;
+        cfg.root = box;                                        // root = mesh AABB (SURVEY 8d C3)
+        SDF::Octree oct;
+        oct.Create(cfg, bvh.Field());                          // the mesh is sampled on the GPU inside the fit kernel
+        const double q = oct.Query(Eigen::Vector3d(0.1, 0.05, -0.02));
+        const double want = std::sqrt(0.1 * 0.1 + 0.05 * 0.05 + 0.02 * 0.02) - 0.35;
+        if (std::fabs(q - want) > 1e-2) { printf("octree over mesh: %g vs %g\n", q, want); return 10; }
+        printf("OK\n");
+        return 0;
+    } catch (const SDF::Error& e) {
+        printf("SDF::Error %d: %s\n", e.status, e.what());
+        return e.status == HPSDF_ERR_NO_DEVICE ? 42 : 1;
+    }
+}
+'''
+
+
+def build_mesh_prog(H, tmp):
+    import numpy as np
+    from helpers import icosphere
+    src, exe, obj = os.path.join(tmp, "mesh.cpp"), os.path.join(tmp, "mesh"), os.path.join(tmp, "ico.obj")
+    open(src, "w").write(MESH_SRC)
+    v, t = icosphere(3, 0.35)
+    with open(obj, "w") as fh:
+        fh.write("# icosphere level 3\n")
+        for p in v:
+            fh.write("v %.9g %.9g %.9g\n" % tuple(p))
+        fh.write("vn 0 0 1\n")
+        for a, b, c in t:
+            fh.write("f %d//1 %d//1 %d//1\n" % (a + 1, b + 1, c + 1))
+    libdir = os.path.dirname(H.LIB_PATH)
+    cmd = ["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), src, "-o", exe, "-L", libdir,
+           "-lhpsdf", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-pthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe, obj
+
+
+def test_meshing_dropin_compiles_and_fails_loudly_without_gpu(H, tmp_path):
+    exe, obj = build_mesh_prog(H, str(tmp_path))
+    r = subprocess.run([exe, obj], capture_output=True, text=True, timeout=300)
+    if r.returncode == 0:
+        pytest.skip("a GPU is present: covered by the gpu test")
+    assert r.returncode == 42, r.stdout + r.stderr  # parsing and normals ran on the host, BVH::Create needs the GPU
+
+
+@pytest.mark.gpu
+def test_meshing_dropin_on_gpu(H, tmp_path):
+    exe, obj = build_mesh_prog(H, str(tmp_path))
+    r = subprocess.run([exe, obj], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
