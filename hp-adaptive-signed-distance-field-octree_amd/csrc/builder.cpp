@@ -284,7 +284,7 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
         const int deg = c / kDepths / 2;
         const bool incr = (c / kDepths) & 1;
         const int nrows = incr ? (int)(T.coeffCount[deg] - T.coeffCount[deg - 1]) : (int)T.coeffCount[deg];
-        classShape[c] = fitShape(deg, nrows, classCount[c], b->weighted);
+        classShape[c] = fitShape(deg, nrows, classCount[c], b->weighted, innermost(field)->kind == kHostMesh);
         nBlocks += (classCount[c] + classShape[c].cells - 1) / classShape[c].cells;
     }
     classBlockFirst[kClasses] = nBlocks;

@@ -405,7 +405,7 @@ int hpsdf_tree_upload(hpsdf_ctx* ctx, const void* block, size_t size, hpsdf_tree
             return fail(HPSDF_ERR_UNSUPPORTED, "internal root box must be [-0.5,0.5]^3 (Octree.cpp:798)");
     std::vector<uint64_t> stack{0};
     std::vector<double> padded;
-    padded.reserve(nCoeffs + nNodes);
+    padded.reserve(nCoeffs + 16 * nNodes);
     uint64_t leaves = 0;
     int maxDeg = 0, maxDepth = 0, minLeafDepth = kMaxDepth + 1;
     std::vector<uint8_t> depthOf(nNodes, 0);
@@ -432,10 +432,11 @@ int hpsdf_tree_upload(hpsdf_ctx* ctx, const void* block, size_t size, hpsdf_tree
             if (n.degree > kMaxDegree) return fail(HPSDF_ERR_BAD_BLOCK, "leaf degree out of range");
             if (n.coeffs_start + T.coeffCount[n.degree] > nCoeffs) return fail(HPSDF_ERR_BAD_BLOCK, "leaf coefficients out of range");
             if (n.depth != depthOf[i]) return fail(HPSDF_ERR_BAD_BLOCK, "stored depth does not match tree depth");
-            // device mirror: every leaf's block starts on a 16-byte boundary
+            // device mirror: every leaf's block starts on a 128-byte line (the wave-cooperative fetch of
+            // query_general_kernel moves whole lines; a degree-2 leaf is one line, a degree-3 leaf two)
             recs[i] = NodeRec{(uint32_t)padded.size(), (uint32_t)n.degree};
             padded.insert(padded.end(), coeffs + n.coeffs_start, coeffs + n.coeffs_start + T.coeffCount[n.degree]);
-            if (padded.size() & 1) padded.push_back(0.0);
+            padded.resize((padded.size() + 15) & ~(size_t)15, 0.0);
             ++leaves;
             maxDeg = std::max(maxDeg, (int)n.degree);
             maxDepth = std::max(maxDepth, (int)depthOf[i]);
@@ -446,6 +447,7 @@ int hpsdf_tree_upload(hpsdf_ctx* ctx, const void* block, size_t size, hpsdf_tree
     // dense table of the deepest complete level (<= 5): table[path] = node reached by that octant path
     const int topDepth = std::max(1, std::min(5, minLeafDepth));
     std::vector<TopEntry> top((size_t)1 << (3 * topDepth));
+    std::vector<NodeRec> topRec(top.size());
     for (size_t code = 0; code < top.size(); ++code) {  // code = x + side * (y + side * z), cell coordinates at topDepth
         const size_t mask = ((size_t)1 << topDepth) - 1;
         const size_t kx = code & mask, ky = (code >> topDepth) & mask, kz = code >> (2 * topDepth);
@@ -456,6 +458,7 @@ int hpsdf_tree_upload(hpsdf_ctx* ctx, const void* block, size_t size, hpsdf_tree
         std::memset(&te, 0, sizeof te);
         te.a = recs[cur].a;
         te.b = recs[cur].b;
+        topRec[code] = recs[cur];
         if (te.b <= 2u)  // small leaf: coefficients ride in the same line
             std::memcpy(te.c, coeffs + nodes[cur].coeffs_start, sizeof(double) * T.coeffCount[te.b]);
     }
@@ -472,6 +475,8 @@ int hpsdf_tree_upload(hpsdf_ctx* ctx, const void* block, size_t size, hpsdf_tree
     hipError_t e = hipMalloc((void**)&t->dNodes, nNodes * sizeof(NodeRec));
     if (e == hipSuccess) e = hipMalloc((void**)&t->dCoeffs, std::max<size_t>(2, padded.size()) * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&t->dTop, top.size() * sizeof(TopEntry));
+    if (e == hipSuccess) e = hipMalloc((void**)&t->dTopRec, topRec.size() * sizeof(NodeRec));
+    if (e == hipSuccess) e = hipMemcpy(t->dTopRec, topRec.data(), topRec.size() * sizeof(NodeRec), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(t->dNodes, recs.data(), nNodes * sizeof(NodeRec), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(t->dTop, top.data(), top.size() * sizeof(TopEntry), hipMemcpyHostToDevice);
     if (e == hipSuccess && !padded.empty())
@@ -482,6 +487,7 @@ int hpsdf_tree_upload(hpsdf_ctx* ctx, const void* block, size_t size, hpsdf_tree
     }
     t->dev.nodes = t->dNodes;
     t->dev.top = t->dTop;
+    t->dev.topRec = t->dTopRec;
     t->dev.coeffs = t->dCoeffs;
     t->dev.topDepth = topDepth;
     t->dev.maxDegree = maxDeg;
@@ -500,6 +506,7 @@ int hpsdf_tree_destroy(hpsdf_tree* t) {
     (void)hipSetDevice(t->device);
     if (t->dNodes) (void)hipFree(t->dNodes);
     if (t->dTop) (void)hipFree(t->dTop);
+    if (t->dTopRec) (void)hipFree(t->dTopRec);
     if (t->dCoeffs) (void)hipFree(t->dCoeffs);
     delete t;
     return HPSDF_OK;
@@ -522,19 +529,22 @@ int hpsdf_query_device(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* dXyz, 
     if (!t || (!dXyz && n) || (!dOut && n)) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
     if (t->device != ctx->device) return fail(HPSDF_ERR_INVALID_ARGUMENT, "tree lives on another device");
     HPSDF_HIP(hipSetDevice(ctx->device));
-    if (!ctx->dDeferCount) HPSDF_HIP(hipMalloc((void**)&ctx->dDeferCount, sizeof(uint32_t)));
     const size_t kChunk = (size_t)1 << 31;  // deferred indices are 32-bit
     for (size_t off = 0; off < n; off += kChunk) {
         const size_t m = std::min(kChunk, n - off);
-        if (!t->allInline && ctx->deferCap < m) {
-            if (ctx->dDefer) HPSDF_HIP(hipFree(ctx->dDefer));
-            ctx->dDefer = nullptr;
-            ctx->deferCap = 0;
-            HPSDF_HIP(hipMalloc((void**)&ctx->dDefer, m * sizeof(uint32_t)));
-            ctx->deferCap = m;
+        if (t->maxDegree > 3) {
+            if (!ctx->dDeferCount) HPSDF_HIP(hipMalloc((void**)&ctx->dDeferCount, kQueryMaxGrid * sizeof(uint32_t)));
+            const size_t need = m + (size_t)256 * kQueryMaxGrid;
+            if (ctx->deferCap < need) {
+                if (ctx->dDefer) HPSDF_HIP(hipFree(ctx->dDefer));
+                ctx->dDefer = nullptr;
+                ctx->deferCap = 0;
+                HPSDF_HIP(hipMalloc((void**)&ctx->dDefer, need * sizeof(uint32_t)));
+                ctx->deferCap = need;
+            }
         }
-        HPSDF_HIP(launchQuery(ctx->stream, t->dev, ctx->dTables, dXyz + 3 * off, m, dOut + off, ctx->dDeferCount, ctx->dDefer,
-                              t->allInline));
+        HPSDF_HIP(launchQuery(ctx->stream, t->dev, ctx->dTables, dXyz + 3 * off, m, dOut + off, t->allInline, ctx->dDeferCount,
+                              ctx->dDefer));
     }
     return HPSDF_OK;
     HPSDF_CATCH

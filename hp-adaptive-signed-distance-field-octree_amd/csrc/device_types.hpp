@@ -21,7 +21,8 @@ struct DeviceTables {
 // node (Include/HP/Node.h:10-33) is not needed on the device: cell boxes are
 // exact dyadics recomputed during the descent, the depth is the descent count.
 //   interior: a = index of first child, b = 0xFFFFFFFF
-//   leaf:     a = offset of its coefficients in the device mirror (doubles, even => 16-byte aligned), b = degree
+//   leaf:     a = offset of its coefficients in the device mirror (doubles; a multiple of 16: every leaf's
+//             block starts on a 128-byte line), b = degree
 struct NodeRec {
     uint32_t a, b;
 };
@@ -39,7 +40,8 @@ static_assert(sizeof(TopEntry) == 128, "one line per entry");
 struct TreeDev {
     const NodeRec* nodes;
     const TopEntry* top;     // dense table of the nodes at depth topDepth, indexed by cell: x + side*(y + side*z)
-    const double* coeffs;    // per-leaf blocks padded to an even count
+    const NodeRec* topRec;   // the same table, records only (8 bytes per cell)
+    const double* coeffs;    // per-leaf blocks, each padded to whole 128-byte lines
     int32_t topDepth;        // every node above this depth is interior (1..5)
     int32_t maxDegree;
     double nlTop[3];         // NormalisedLengths[j][topDepth], j <= 2 (degrees of the inline leaves)

@@ -468,92 +468,63 @@ __device__ __forceinline__ void stageQueryTables(const DeviceTables* T, double* 
     for (int i = threadIdx.x; i < 26; i += blockDim.x) sRec[i] = (&T->rec[0][0])[i];
 }
 
-// Batched Query.  Random points share nothing, so per point the tree costs one 128-byte top-table line
-// out of L2; fetched lane-by-lane that is 6 divergent 16-byte requests per point and the texture
-// addresser becomes the limit.  Here the wave fetches cooperatively: in step k the 8 lanes of every
+// Cell of the complete top level that holds p (unit-cube coordinates), per axis: index k and cell centre c.
+// The comparison chain "p >= mid-plane" of Octree.cpp:674-701, level by level, selects the cell k with
+// lo_k <= p < lo_k + h (h = 2^-topDepth, lo_k = -0.5 + k h, all exact dyadics; k clamped to the grid because the
+// containment test ran on the f32 cast).  k is computed directly -- floor((p+0.5)/h) can be off by one when
+// p + 0.5 rounds across a cell boundary, so it is corrected by the same exact comparisons the chain would make.
+__device__ __forceinline__ void topCell(const double (&p3)[3], int topDepth, int (&k3)[3], double (&c3)[3]) {
+    const int side = 1 << topDepth;
+    const double h = 1.0 / (double)side, fside = (double)side;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        int k = (int)floor((p3[a] + 0.5) * fside);
+        k = k < 0 ? 0 : (k > side - 1 ? side - 1 : k);
+        double lo = -0.5 + (double)k * h;
+        if (p3[a] < lo && k > 0) {
+            --k;
+            lo = lo - h;
+        } else if (p3[a] >= lo + h && k < side - 1) {
+            ++k;
+            lo = lo + h;
+        }
+        k3[a] = k;
+        c3[a] = lo + 0.5 * h;
+    }
+}
+
+// Batched Query, trees whose leaves ALL sit in the top table with degree <= 2 (what the BASELINE thresholds
+// produce: 4096 depth-4 leaves of degree 2).  Random points share nothing, so per point the tree costs one
+// 128-byte top-table line out of L2; fetched lane-by-lane that is 6 divergent 16-byte requests per point and the
+// texture addresser becomes the limit.  Here the wave fetches cooperatively: in step k the 8 lanes of every
 // group read the 8 consecutive 16-byte chunks of the line of the group's k-th point, straight into LDS
 // (global_load_lds_dwordx4: lane-linear destination, per-lane source), i.e. 8 whole lines per
 // wave-instruction instead of 64 fragments; afterwards every lane reads back its own point's row.
-// Points whose table entry is not an inline leaf (interior node, or a leaf of degree > 2) are not finished
-// here: their indices go to a deferred list that query_deep_kernel walks lane-by-lane.  Keeping that path out
-// of this kernel is what keeps it at ~64 VGPRs (8 waves/SIMD) -- inlined or called, it doubles the registers.
-// STAGED: the wave's 64 points (1536 contiguous bytes) also come in through LDS-DMA -- two wave-instructions
-// instead of three 24-byte-strided ones; the texture addresser is the busiest unit of this kernel (measured
-// ~75 %), so its instruction count is what matters.  Needs a 16-byte aligned point array.
-template <int TOPD, bool STAGED>
-__global__ __launch_bounds__(256, 7) void query_kernel(TreeDev t, const DeviceTables* __restrict__ T,
-                                                    const double* __restrict__ xyz, size_t n, double* __restrict__ out,
-                                                    uint32_t* __restrict__ deferCount, uint32_t* __restrict__ deferIdx) {
+// Every other tree goes through query_general_kernel below.
+template <int TOPD>
+__global__ __launch_bounds__(256, 7) void query_kernel(TreeDev t, const double* __restrict__ xyz, size_t n,
+                                                    double* __restrict__ out) {
     // per wave: 4 steps x 64 lanes x 16 B (two passes; less LDS = more waves).  Each step's kilobyte is followed by
     // 32 bytes of padding: a lane reads row (sub & 3), so without it the four lanes of a group hit the same banks
     // one kilobyte apart (measured: 70 % of the LDS cycles were bank conflicts).
     __shared__ double2 sRows[4][4][66];
-    (void)T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane & ~7, sub = lane & 7;
     for (size_t base = (size_t)blockIdx.x * 256; base < n; base += (size_t)gridDim.x * 256) {
         const size_t i = base + threadIdx.x;
         const bool valid = i < n;
         const size_t il = valid ? i : n - 1;
-        double x, y, z;
-        const size_t waveBase = base + (size_t)wave * 64;
-        if (STAGED && waveBase + 64 <= n) {  // wave-uniform
-            const char* src = reinterpret_cast<const char*>(xyz + 3 * waveBase) + lane * 16;
-            char* win = reinterpret_cast<char*>(&sRows[wave][0][0]);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)win, 16, 0, 0);
-            if (lane < 32)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 1024),
-                                                 (__attribute__((address_space(3))) void*)(win + 1024), 16, 0, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            const double* pp = reinterpret_cast<const double*>(win) + 3 * lane;
-            x = pp[0], y = pp[1], z = pp[2];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();  // the window is reused for the table rows below
-        } else {
-            x = xyz[3 * il], y = xyz[3 * il + 1], z = xyz[3 * il + 2];
-        }
+        const double x = xyz[3 * il], y = xyz[3 * il + 1], z = xyz[3 * il + 2];
         // Octree.cpp:665
-        const double px = (x - t.rootCentre[0]) * t.rootInvSizes[0];
-        const double py = (y - t.rootCentre[1]) * t.rootInvSizes[1];
-        const double pz = (z - t.rootCentre[2]) * t.rootInvSizes[2];
+        const double p3[3] = {(x - t.rootCentre[0]) * t.rootInvSizes[0], (y - t.rootCentre[1]) * t.rootInvSizes[1],
+                              (z - t.rootCentre[2]) * t.rootInvSizes[2]};
         // :668 containment on the f32 cast, both ends inclusive; NaN fails
-        const float fx = (float)px, fy = (float)py, fz = (float)pz;
+        const float fx = (float)p3[0], fy = (float)p3[1], fz = (float)p3[2];
         const bool inside = fx >= -0.5f && fx <= 0.5f && fy >= -0.5f && fy <= 0.5f && fz >= -0.5f && fz <= 0.5f;
-        // :674-701 for the complete top levels.  The comparison chain "p >= mid-plane" level by level selects the
-        // cell k with lo_k <= p < lo_k + h (h = 2^-topDepth, lo_k = -0.5 + k h, all exact dyadics; k clamped to the
-        // grid because the containment test above ran on the f32 cast).  k is computed directly -- floor((p+0.5)/h)
-        // can be off by one when p + 0.5 rounds across a cell boundary, so it is corrected by the same exact
-        // comparisons the chain would make.
         const int topDepth = TOPD > 0 ? TOPD : t.topDepth;
-        const int side = 1 << topDepth;
-        const double h = 1.0 / (double)side, fside = (double)side;
-        int kx, ky, kz;
-        double cx, cy, cz;
-        {
-            const double p3[3] = {px, py, pz};
-            int k3[3];
-            double c3[3];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                int k = (int)floor((p3[a] + 0.5) * fside);
-                k = k < 0 ? 0 : (k > side - 1 ? side - 1 : k);
-                double lo = -0.5 + (double)k * h;
-                if (p3[a] < lo && k > 0) {
-                    --k;
-                    lo = lo - h;
-                } else if (p3[a] >= lo + h && k < side - 1) {
-                    ++k;
-                    lo = lo + h;
-                }
-                k3[a] = k;
-                c3[a] = lo + 0.5 * h;
-            }
-            kx = k3[0], ky = k3[1], kz = k3[2];
-            cx = c3[0], cy = c3[1], cz = c3[2];
-        }
-        const int depth = topDepth;
-        uint32_t code = (uint32_t)(kx + ((ky + (kz << topDepth)) << topDepth));
+        int k3[3];
+        double c3[3];
+        topCell(p3, topDepth, k3, c3);
+        uint32_t code = (uint32_t)(k3[0] + ((k3[1] + (k3[2] << topDepth)) << topDepth));
         if (!inside) code = 0;  // any valid line; the result is DBL_MAX
         // lane (group g, sub k) owns the row that step k writes at lanes 8g..8g+7: [record][c0 c1]..[c8 c9].
         // Two passes of four steps through a 4 KB per-wave window (measured: 110 vs 121 us for one 8 KB pass).
@@ -585,48 +556,179 @@ __global__ __launch_bounds__(256, 7) void query_kernel(TreeDev t, const DeviceTa
             __builtin_amdgcn_wave_barrier();  // the window is rewritten by the next pass / tile
         }
         double r = DBL_MAX;  // :668-671 outside the root
-        bool defer = false;
         if (inside) {
-            if (hdr.y <= 2u) {
-                // :862  unitPt = (pt - centre) * (2 << depth)
-                const double s = (double)(2 << depth);
-                const double ux = (px - cx) * s, uy = (py - cy) * s, uz = (pz - cz) * s;
-                if (hdr.y == 2u)
-                    r = evalLeafTop<2>(cv, ux, uy, uz, t.nlTop);
-                else if (hdr.y == 1u)
-                    r = evalLeafTop<1>(cv, ux, uy, uz, t.nlTop);
-                else
-                    r = evalLeafTop<0>(cv, ux, uy, uz, t.nlTop);
-            } else {
-                defer = valid;
-            }
+            // :862  unitPt = (pt - centre) * (2 << depth)
+            const double s = (double)(2 << topDepth);
+            const double ux = (p3[0] - c3[0]) * s, uy = (p3[1] - c3[1]) * s, uz = (p3[2] - c3[2]) * s;
+            if (hdr.y == 2u)
+                r = evalLeafTop<2>(cv, ux, uy, uz, t.nlTop);
+            else if (hdr.y == 1u)
+                r = evalLeafTop<1>(cv, ux, uy, uz, t.nlTop);
+            else
+                r = evalLeafTop<0>(cv, ux, uy, uz, t.nlTop);
         }
-        // one atomic per wave reserves the deferred slots
-        const unsigned long long dmask = __ballot(defer);
-        if (dmask) {
-            uint32_t base = 0;
-            const int leader = __ffsll((long long)dmask) - 1;
-            if (lane == leader) base = atomicAdd(deferCount, (uint32_t)__popcll(dmask));
-            base = __shfl(base, leader, 64);
-            if (defer) deferIdx[base + (uint32_t)__popcll(dmask & ((1ull << lane) - 1ull))] = (uint32_t)i;
-        }
-        if (valid && !defer) out[i] = r;
+        if (valid) out[i] = r;
     }
 }
 
-// Second pass of Query: the deferred points, one lane each, any depth and degree.
+// 16-byte chunks a leaf of degree d occupies in the device mirror (blocks are 128-byte aligned there)
+__device__ __forceinline__ uint32_t leafChunks(uint32_t degree) { return ((uint32_t)coeffCount((int)degree) + 1u) >> 1; }
+
+// Batched Query, any tree.  Per lane: the top cell by arithmetic, its 8-byte record from the thin top table
+// (32 KB at depth 4: L1/L2 traffic only), then the walk down to the leaf (Octree.cpp:674-701).  The leaves'
+// coefficients are then fetched by the wave as a whole, as in query_kernel, straight from the coefficient mirror
+// (every leaf block starts on a 128-byte line there): in step k the 8 lanes of a group fetch chunks 0..7 of the
+// leaf of the group's k-th point -- a whole degree-2 leaf, the first line of a degree-3 one -- and one extra step
+// per pass brings chunks 8..9 of four degree-3 leaves at a time (two lanes each).  Two passes of 4 + 1 steps
+// through a 5 KB per-wave window, i.e. two L2 round trips per tile whatever the mix of degrees <= 3.
+// Leaves of degree > 3 are rare at the thresholds in use (a few dozen among thousands): DEFER appends their points to
+// the workgroup's own run of deferIdx (an LDS counter, no global atomic -- one global atomic per wave serialised
+// the first version of this at 2 ms per 10 M points) and query_deep_kernel finishes them lane by lane; keeping
+// that code out of this kernel keeps it at ~100 VGPRs.
+template <int TOPD, bool DEFER>
+__global__ __launch_bounds__(256) void query_general_kernel(TreeDev t, const DeviceTables* __restrict__ T,
+                                                            const double* __restrict__ xyz, size_t n,
+                                                            double* __restrict__ out, uint32_t tilesPerWg,
+                                                            uint32_t* __restrict__ deferCount,
+                                                            uint32_t* __restrict__ deferIdx) {
+    __shared__ double2 sRows[4][5][66];
+    __shared__ uint32_t sInfo[4][64];
+    __shared__ double sNl[13 * 11];
+    __shared__ double sRec[26];
+    __shared__ uint32_t sDeferred;
+    stageQueryTables(T, sNl, sRec);
+    if (threadIdx.x == 0) sDeferred = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane & ~7, sub = lane & 7;
+    const size_t segStart = (size_t)blockIdx.x * tilesPerWg * 256;  // this workgroup's run of deferIdx
+    for (size_t base = (size_t)blockIdx.x * 256; base < n; base += (size_t)gridDim.x * 256) {
+        const size_t i = base + threadIdx.x;
+        const bool valid = i < n;
+        const size_t il = valid ? i : n - 1;
+        const double x = xyz[3 * il], y = xyz[3 * il + 1], z = xyz[3 * il + 2];
+        const double p3[3] = {(x - t.rootCentre[0]) * t.rootInvSizes[0], (y - t.rootCentre[1]) * t.rootInvSizes[1],
+                              (z - t.rootCentre[2]) * t.rootInvSizes[2]};  // Octree.cpp:665
+        const float fx = (float)p3[0], fy = (float)p3[1], fz = (float)p3[2];
+        const bool inside = fx >= -0.5f && fx <= 0.5f && fy >= -0.5f && fy <= 0.5f && fz >= -0.5f && fz <= 0.5f;  // :668
+        const int topDepth = TOPD > 0 ? TOPD : t.topDepth;
+        int k3[3];
+        double c3[3];
+        topCell(p3, topDepth, k3, c3);
+        uint32_t code = (uint32_t)(k3[0] + ((k3[1] + (k3[2] << topDepth)) << topDepth));
+        if (!inside) code = 0;
+        NodeRec rec = t.topRec[code];
+        int depth = topDepth;
+        double q = 0.25 / (double)(1 << topDepth);  // a quarter of the cell size: from a centre to its children's
+        while (rec.b == kInteriorTag) {              // :674-701 below the complete levels
+            const bool ux = p3[0] >= c3[0], uy = p3[1] >= c3[1], uz = p3[2] >= c3[2];
+            const uint32_t idx = rec.a + (ux ? 1u : 0u) + (uy ? 2u : 0u) + (uz ? 4u : 0u);
+            c3[0] = ux ? c3[0] + q : c3[0] - q;
+            c3[1] = uy ? c3[1] + q : c3[1] - q;
+            c3[2] = uz ? c3[2] + q : c3[2] - q;
+            q = q * 0.5;
+            ++depth;
+            rec = t.nodes[idx];
+        }
+        const uint32_t degree = rec.b;
+        const bool coop = inside && degree <= 3u;
+        // what the fetching lanes need to know about this lane's leaf: block offset (a multiple of 16 doubles, so its
+        // low four bits are free) and chunk count (0 = nothing to fetch)
+        sInfo[wave][lane] = rec.a | (coop ? leafChunks(degree) : 0u);
+        __builtin_amdgcn_wave_barrier();
+        uint32_t info[8];
+        {
+            const uint4 i0 = *reinterpret_cast<const uint4*>(&sInfo[wave][grp]);
+            const uint4 i1 = *reinterpret_cast<const uint4*>(&sInfo[wave][grp + 4]);
+            info[0] = i0.x, info[1] = i0.y, info[2] = i0.z, info[3] = i0.w;
+            info[4] = i1.x, info[5] = i1.y, info[6] = i1.z, info[7] = i1.w;
+        }
+        const bool second = __any(coop && degree == 3u);  // wave-uniform: somebody needs chunks 8..9
+        double cv[20];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {  // chunks 0..7 of the leaf of point (group, 4 pass + k)
+                const uint32_t inf = info[pass * 4 + k];
+                const char* src = reinterpret_cast<const char*>(t.coeffs) + (size_t)(inf & ~15u) * 8u + (uint32_t)sub * 16u;
+                if ((uint32_t)sub < (inf & 15u))
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)&sRows[wave][k][0], 16, 0, 0);
+            }
+            if (second) {  // chunks 8..9 of the leaves of points (group, 4 pass + 0..3): two lanes each
+                const uint32_t inf = sInfo[wave][grp + 4 * pass + (sub >> 1)];
+                const char* src = reinterpret_cast<const char*>(t.coeffs) + (size_t)(inf & ~15u) * 8u + (8u + (uint32_t)(sub & 1)) * 16u;
+                if ((inf & 15u) > 8u)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)&sRows[wave][4][0], 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if ((sub >> 2) == pass) {
+                const double2* row = &sRows[wave][sub & 3][grp];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const double2 v = row[c];
+                    cv[2 * c] = v.x;
+                    cv[2 * c + 1] = v.y;
+                }
+                const double2* tail = &sRows[wave][4][grp + 2 * (sub & 3)];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const double2 v = tail[c];
+                    cv[16 + 2 * c] = v.x;
+                    cv[16 + 2 * c + 1] = v.y;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();  // the window is rewritten by the next pass / tile
+        }
+        double r = DBL_MAX;  // :668-671
+        bool defer = false;
+        if (inside) {
+            const double s = (double)(2 << depth);  // :862
+            const double ux = (p3[0] - c3[0]) * s, uy = (p3[1] - c3[1]) * s, uz = (p3[2] - c3[2]) * s;
+            switch (degree) {
+                case 0: r = evalLeafVals<0>(cv, ux, uy, uz, depth, sNl, sRec); break;
+                case 1: r = evalLeafVals<1>(cv, ux, uy, uz, depth, sNl, sRec); break;
+                case 2: r = evalLeafVals<2>(cv, ux, uy, uz, depth, sNl, sRec); break;
+                case 3: r = evalLeafVals<3>(cv, ux, uy, uz, depth, sNl, sRec); break;
+                default: defer = valid; break;
+            }
+        }
+        if constexpr (DEFER) {
+            const unsigned long long dmask = __ballot(defer);
+            if (dmask) {  // one LDS atomic per wave reserves the slots
+                uint32_t slot = 0;
+                const int leader = __ffsll((long long)dmask) - 1;
+                if (lane == leader) slot = atomicAdd(&sDeferred, (uint32_t)__popcll(dmask));
+                slot = __shfl(slot, leader, 64);
+                if (defer) deferIdx[segStart + slot + (uint32_t)__popcll(dmask & ((1ull << lane) - 1ull))] = (uint32_t)i;
+            }
+        }
+        if (valid && !defer) out[i] = r;
+    }
+    if constexpr (DEFER) {
+        __syncthreads();
+        if (threadIdx.x == 0) deferCount[blockIdx.x] = sDeferred;
+    }
+}
+
+// Second pass of Query for the points query_general_kernel deferred (leaves of degree > 3), one lane each.
+// Workgroup b walks the list the first kernel's workgroup b left in its run of deferIdx.
 template <int MAXP>
 __global__ __launch_bounds__(256) void query_deep_kernel(TreeDev t, const DeviceTables* __restrict__ T,
                                                          const double* __restrict__ xyz, double* __restrict__ out,
-                                                         const uint32_t* __restrict__ deferCount,
+                                                         uint32_t tilesPerWg, const uint32_t* __restrict__ deferCount,
                                                          const uint32_t* __restrict__ deferIdx) {
     __shared__ double sNl[13 * 11];
     __shared__ double sRec[26];
+    const uint32_t count = deferCount[blockIdx.x];
+    if (count == 0) return;  // workgroup-uniform
     stageQueryTables(T, sNl, sRec);
     __syncthreads();
-    const uint32_t count = *deferCount;
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < count; j += gridDim.x * blockDim.x) {
-        const size_t i = deferIdx[j];
+    const size_t segStart = (size_t)blockIdx.x * tilesPerWg * 256;
+    for (uint32_t j = threadIdx.x; j < count; j += blockDim.x) {
+        const size_t i = deferIdx[segStart + j];
         out[i] = queryPoint<MAXP>(t, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], sNl, sRec);
     }
 }
@@ -1115,7 +1217,7 @@ size_t fitLdsBytes(int degree, int nTasks, int planes) {
 }
 
 // Shape of the workgroups of one class: `count` fits of `nrows` coefficient rows at `degree`.
-FitShape fitShape(int degree, int nrows, uint32_t count, bool weighted) {
+FitShape fitShape(int degree, int nrows, uint32_t count, bool weighted, bool latencyBound) {
     FitShape sh;
     const int slots = nrows > kFitThreads ? 1 : kFitThreads / nrows;
     // Cell blocking (4 cells per thread sharing each basis product) is implemented in the kernel but measured
@@ -1133,6 +1235,10 @@ FitShape fitShape(int degree, int nrows, uint32_t count, bool weighted) {
     // enough workgroups to cover the chip twice before cells are stacked into one workgroup
     int g = sh.cellsPerThread > 1 ? gmax
                                   : (int)std::min<uint32_t>((uint32_t)gmax, std::max<uint32_t>(1, (count + 511) / 512));
+    // Mesh fields: phase 1 is a chain of dependent BVH-node gathers per sample (measured on a 1.3 M-triangle mesh,
+    // 4096 coarse cells: 206 ms with 8 cells per workgroup, 176 / 151 / 128 ms with 4 / 2 / 1) -- many small
+    // workgroups keep more waves in flight and shorten the wait for the slowest lane of a chunk.
+    if (latencyBound) g = 1;
     if (const char* e = std::getenv("HPSDF_FIT_G")) {  // tuning knobs
         sh.cellsPerThread = 1;
         g = std::max(1, std::min(slots, std::atoi(e)));
@@ -1212,43 +1318,46 @@ hipError_t launchFit(hipStream_t stream, int degree, int cellsPerThread, const F
 
 static unsigned gridFor(size_t n) {
     size_t blocks = (n + 255) / 256;
-    const size_t cap = 256 * 8 * 4;  // grid-stride beyond this
+    const size_t cap = kQueryMaxGrid;  // grid-stride beyond this
     return (unsigned)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
 }
 
-// Points are processed in launches of at most 2^31 so that deferred indices fit 32 bits.
+// dDeferCount: kQueryMaxGrid counters; dDeferIdx: n + 256 * kQueryMaxGrid slots (both only for trees with leaves of
+// degree > 3).  n < 2^32 (the caller splits larger batches).
 hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dXyz, size_t n,
-                       double* dOut, uint32_t* dDeferCount, uint32_t* dDeferIdx, bool allInline) {
+                       double* dOut, bool allInline, uint32_t* dDeferCount, uint32_t* dDeferIdx) {
     if (n == 0) return hipSuccess;
     const dim3 grid(gridFor(n)), block(256);
-    if (!allInline) {
-        hipError_t e = hipMemsetAsync(dDeferCount, 0, sizeof(uint32_t), stream);
-        if (e != hipSuccess) return e;
+    if (allInline) {
+        if (t.topDepth == 4)
+            hipLaunchKernelGGL((query_kernel<4>), grid, block, 0, stream, t, dXyz, n, dOut);
+        else
+            hipLaunchKernelGGL((query_kernel<0>), grid, block, 0, stream, t, dXyz, n, dOut);
+        return hipGetLastError();
     }
-    // measured: staging the points through LDS-DMA is not faster (114 us either way, slower on sorted points)
-    const bool staged = false;
-#define HPSDF_QUERY(TOPD, ST) \
-    hipLaunchKernelGGL((query_kernel<TOPD, ST>), grid, block, 0, stream, t, dTables, dXyz, n, dOut, dDeferCount, dDeferIdx)
+    const size_t nTiles = (n + 255) / 256;
+    const uint32_t tilesPerWg = (uint32_t)((nTiles + grid.x - 1) / grid.x);  // tiles b, b + G, ... of workgroup b
+    const bool defer = t.maxDegree > 3;
+#define HPSDF_QUERY_GENERAL(TOPD, DF)                                                                                 \
+    hipLaunchKernelGGL((query_general_kernel<TOPD, DF>), grid, block, 0, stream, t, dTables, dXyz, n, dOut, tilesPerWg, \
+                       dDeferCount, dDeferIdx)
     if (t.topDepth == 4) {
-        if (staged)
-            HPSDF_QUERY(4, true);
+        if (defer)
+            HPSDF_QUERY_GENERAL(4, true);
         else
-            HPSDF_QUERY(4, false);
+            HPSDF_QUERY_GENERAL(4, false);
     } else {
-        if (staged)
-            HPSDF_QUERY(0, true);
+        if (defer)
+            HPSDF_QUERY_GENERAL(0, true);
         else
-            HPSDF_QUERY(0, false);
+            HPSDF_QUERY_GENERAL(0, false);
     }
-#undef HPSDF_QUERY
-    if (!allInline) {
-        const dim3 dgrid(std::min<unsigned>(gridFor(n), 4096u));
-        if (t.maxDegree <= 3)
-            hipLaunchKernelGGL((query_deep_kernel<3>), dgrid, block, 0, stream, t, dTables, dXyz, dOut, dDeferCount, dDeferIdx);
-        else if (t.maxDegree <= 5)
-            hipLaunchKernelGGL((query_deep_kernel<5>), dgrid, block, 0, stream, t, dTables, dXyz, dOut, dDeferCount, dDeferIdx);
+#undef HPSDF_QUERY_GENERAL
+    if (defer) {
+        if (t.maxDegree <= 5)
+            hipLaunchKernelGGL((query_deep_kernel<5>), grid, block, 0, stream, t, dTables, dXyz, dOut, tilesPerWg, dDeferCount, dDeferIdx);
         else
-            hipLaunchKernelGGL((query_deep_kernel<12>), dgrid, block, 0, stream, t, dTables, dXyz, dOut, dDeferCount, dDeferIdx);
+            hipLaunchKernelGGL((query_deep_kernel<12>), grid, block, 0, stream, t, dTables, dXyz, dOut, tilesPerWg, dDeferCount, dDeferIdx);
     }
     return hipGetLastError();
 }

@@ -11,6 +11,7 @@ namespace hpsdf {
 
 constexpr size_t kFitMaxLdsBytes = 60 * 1024;  // stays under the 64 KiB default dynamic-LDS limit
 constexpr int kFitBlockThreads = 256;
+constexpr unsigned kQueryMaxGrid = 256 * 8 * 4;  // workgroups of one Query launch (grid-stride beyond)
 
 constexpr size_t kFitChunkLdsBytes = 40 * 1024;  // sample planes staged per chunk (keeps >= 3 workgroups per CU)
 size_t fitLdsBytes(int degree, int nTasks, int planes);
@@ -20,14 +21,15 @@ struct FitShape {
     int planes;          // i-planes staged per chunk
     size_t ldsBytes;
 };
-FitShape fitShape(int degree, int nrows, uint32_t count, bool weighted);
+// latencyBound: the field is a BVH traversal (mesh): one cell per workgroup, occupancy hides the gathers
+FitShape fitShape(int degree, int nrows, uint32_t count, bool weighted, bool latencyBound = false);
 
 
 hipError_t launchFit(hipStream_t stream, int degree, int cellsPerThread, const FitBlock* dBlocks, uint32_t nBlocks, size_t ldsBytes,
                      const FitTask* dTasks, double* dArena, double* dErrs, double* dMeans,
                      const DeviceTables* dTables, const FieldDev& field, const RootMap& rm);
 hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dXyz, size_t n,
-                       double* dOut, uint32_t* dDeferCount, uint32_t* dDeferIdx, bool allInline);
+                       double* dOut, bool allInline, uint32_t* dDeferCount, uint32_t* dDeferIdx);
 hipError_t launchQueryGrad(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dXyz,
                            size_t n, double* dOut, double* dGrad);
 hipError_t launchQueryRay(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dOrigins,

@@ -70,7 +70,7 @@ struct hpsdf_ctx {
     bool ownsStream = false;
     hpsdf::DeviceTables* dTables = nullptr;
     hpsdf::Workspace ws;
-    // Query scratch: indices of the points that need the lane-by-lane pass (+ their count)
+    // Query scratch for trees with leaves of degree > 3: per-workgroup lists of the points finished lane by lane
     uint32_t* dDefer = nullptr;
     uint64_t deferCap = 0;
     uint32_t* dDeferCount = nullptr;
@@ -80,11 +80,12 @@ struct hpsdf_tree {
     int device = 0;
     hpsdf::NodeRec* dNodes = nullptr;
     hpsdf::TopEntry* dTop = nullptr;
+    hpsdf::NodeRec* dTopRec = nullptr;
     double* dCoeffs = nullptr;
     hpsdf::TreeDev dev{};
     uint64_t nNodes = 0, nCoeffs = 0, nLeaves = 0;
     int maxDegree = 0, maxDepth = 0;
-    bool allInline = false;  // every leaf sits in the top table with degree <= 2: Query is one kernel
+    bool allInline = false;  // every leaf sits in the top table with degree <= 2: query_kernel serves it
     hpsdf_config config{};
 };
 

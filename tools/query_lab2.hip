@@ -1,0 +1,316 @@
+// Development lab #2 (not part of the product): instruction-count and request-shape variants of the cooperative
+// LDS-DMA Query kernel, on the same synthetic uniform depth-4 / degree-2 tree as tools/query_lab.hip.
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/query_lab2.hip -o /tmp/query_lab2 && /tmp/query_lab2
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x)                                                                                     \
+    do {                                                                                          \
+        hipError_t e_ = (x);                                                                      \
+        if (e_ != hipSuccess) {                                                                   \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__);         \
+            exit(1);                                                                              \
+        }                                                                                         \
+    } while (0)
+
+struct alignas(128) Fat {
+    uint32_t a, b, pad[2];
+    double c[14];
+};
+struct alignas(128) Row80 {  // coefficients first, no header
+    double c[16];
+};
+struct Args {
+    const Fat* fat;
+    const Row80* r80;
+    double nl[3];
+};
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+__device__ __forceinline__ void descend4(double px, double py, double pz, uint32_t& code, double& cx, double& cy, double& cz) {
+    cx = cy = cz = 0.0;
+    double q = 0.25;
+    uint32_t ix = 0, iy = 0, iz = 0;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        const bool ux = px >= cx, uy = py >= cy, uz = pz >= cz;
+        ix = ix * 2u + (ux ? 1u : 0u), iy = iy * 2u + (uy ? 1u : 0u), iz = iz * 2u + (uz ? 1u : 0u);
+        cx = ux ? cx + q : cx - q;
+        cy = uy ? cy + q : cy - q;
+        cz = uz ? cz + q : cz - q;
+        q = q * 0.5;
+    }
+    code = ix + 16u * (iy + 16u * iz);
+}
+
+// cell of p along one axis on the 16-cell grid over [-0.5, 0.5]: k = clamp(floor(16 p) + 8, 0, 15) -- 16 p and its floor
+// are exact, so this is the comparison chain's answer; centre = (k - 7.5) / 16 exactly.
+__device__ __forceinline__ void cellOf(double p, int& k, double& c) {
+    double kf = floor(p * 16.0);
+    kf = fmin(fmax(kf, -8.0), 7.0);
+    k = (int)kf + 8;
+    c = (kf + 0.5) * 0.0625;
+}
+
+__device__ __forceinline__ double eval2(const double (&cv)[10], double ux, double uy, double uz, const double* nl) {
+    double tx[3], ty[3], tz[3];
+    tx[0] = ty[0] = tz[0] = nl[0];
+    tx[1] = ux * nl[1], ty[1] = uy * nl[1], tz[1] = uz * nl[1];
+    tx[2] = (1.5 * ux * ux - 0.5) * nl[2], ty[2] = (1.5 * uy * uy - 0.5) * nl[2], tz[2] = (1.5 * uz * uz - 0.5) * nl[2];
+    const int I[10][3] = {{0, 0, 0}, {0, 0, 1}, {0, 1, 0}, {1, 0, 0}, {0, 0, 2}, {0, 1, 1}, {0, 2, 0}, {1, 0, 1}, {1, 1, 0}, {2, 0, 0}};
+    double f = 0;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        double lp = tx[I[i][0]];
+        lp = lp * ty[I[i][1]];
+        lp = lp * tz[I[i][2]];
+        f = f + cv[i] * lp;
+    }
+    return f;
+}
+
+// IDX 0: select chain, 1: floor.  CODES 0: shfl, 1: LDS.  PF: prefetch next tile's points -- BROKEN as written (the
+// asm loads are still in flight when the compiler reuses their registers: memory fault at n = 10 M); not run.
+template <int IDX, int CODES, int PF>
+__global__ __launch_bounds__(256, 7) void lab8(Args a, const double* __restrict__ xyz, size_t n, double* __restrict__ out) {
+    __shared__ double2 sd[4][4][66];
+    __shared__ uint32_t sCode[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, grp = lane & ~7, j = lane & 7;
+    const size_t step = (size_t)gridDim.x * 256;
+    size_t base = (size_t)blockIdx.x * 256;
+    if (base >= n) return;
+    double nx = 0, ny = 0, nz = 0;
+    if (PF) {
+        const size_t i = base + threadIdx.x < n ? base + threadIdx.x : n - 1;
+        nx = xyz[3 * i], ny = xyz[3 * i + 1], nz = xyz[3 * i + 2];
+    }
+    const uint32_t subOff = (uint32_t)j * 16u;
+    for (; base < n; base += step) {
+        double px, py, pz;
+        if (PF) {
+            px = nx, py = ny, pz = nz;
+        } else {
+            const size_t i = base + threadIdx.x < n ? base + threadIdx.x : n - 1;
+            px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+        }
+        uint32_t code;
+        double cx, cy, cz;
+        if (IDX == 0) {
+            descend4(px, py, pz, code, cx, cy, cz);
+        } else {
+            int kx, ky, kz;
+            cellOf(px, kx, cx), cellOf(py, ky, cy), cellOf(pz, kz, cz);
+            code = (uint32_t)(kx + 16 * (ky + 16 * kz));
+        }
+        uint32_t ck[8];
+        if (CODES == 1) {
+            sCode[w][lane] = code;
+            __builtin_amdgcn_wave_barrier();
+            const uint4 c0 = *reinterpret_cast<const uint4*>(&sCode[w][grp]);
+            const uint4 c1 = *reinterpret_cast<const uint4*>(&sCode[w][grp + 4]);
+            ck[0] = c0.x, ck[1] = c0.y, ck[2] = c0.z, ck[3] = c0.w, ck[4] = c1.x, ck[5] = c1.y, ck[6] = c1.z, ck[7] = c1.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ck[k] = __shfl(code, grp | k, 64);
+        }
+        const double* np = nullptr;
+        if (PF) {
+            const size_t nb = base + step;
+            const size_t ni = (nb + threadIdx.x < n) ? nb + threadIdx.x : n - 1;
+            np = xyz + 3 * ni;
+        }
+        double cv[10];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t off = (ck[half * 4 + k] << 7) + subOff;
+                const char* src = reinterpret_cast<const char*>(a.fat) + off;
+                if (j < 6)
+                    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src, (LDS_AS void*)&sd[w][k][0], 16, 0, 0);
+            }
+            if (PF && half == 1) {
+                asm volatile("global_load_dwordx2 %0, %3, off\n\tglobal_load_dwordx2 %1, %3, off offset:8\n\tglobal_load_dwordx2 %2, %3, off offset:16"
+                             : "=&v"(nx), "=&v"(ny), "=&v"(nz) : "v"(np) : "memory");
+                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_wave_barrier();
+            if ((j >> 2) == half) {
+                const double2* row = &sd[w][j & 3][grp];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    const double2 v = row[1 + q];
+                    cv[2 * q] = v.x, cv[2 * q + 1] = v.y;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        const double r = eval2(cv, (px - cx) * 32.0, (py - cy) * 32.0, (pz - cz) * 32.0, a.nl);
+        if (base + threadIdx.x < n) out[base + threadIdx.x] = r;
+    }
+}
+
+// 80-byte rows, 5 lanes per row, 12 rows per DMA instruction, 6 instructions per 64 points (one pass, 6.2 KB/wave)
+// or two passes of 3 (3.1 KB/wave).
+template <int PASSES, int PF>
+__global__ __launch_bounds__(256, 7) void lab5(Args a, const double* __restrict__ xyz, size_t n, double* __restrict__ out) {
+    constexpr int SPP = 6 / PASSES;  // steps per pass
+    __shared__ double2 sd[4][SPP][66];
+    __shared__ uint32_t sCode[4][72];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int rowInStep = lane / 5, chunk = lane - rowInStep * 5;  // lanes 60..63: rowInStep 12 (idle)
+    const bool fetcher = lane < 60;
+    const int myStep = lane / 12, myRow = lane - myStep * 12;      // where this lane's own row lands
+    const size_t step = (size_t)gridDim.x * 256;
+    size_t base = (size_t)blockIdx.x * 256;
+    if (base >= n) return;
+    double nx = 0, ny = 0, nz = 0;
+    if (PF) {
+        const size_t i = base + threadIdx.x < n ? base + threadIdx.x : n - 1;
+        nx = xyz[3 * i], ny = xyz[3 * i + 1], nz = xyz[3 * i + 2];
+    }
+    if (lane < 8) sCode[w][64 + lane] = 0;  // steps read past point 63
+    for (; base < n; base += step) {
+        double px, py, pz;
+        if (PF) {
+            px = nx, py = ny, pz = nz;
+        } else {
+            const size_t i = base + threadIdx.x < n ? base + threadIdx.x : n - 1;
+            px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+        }
+        int kx, ky, kz;
+        double cx, cy, cz;
+        cellOf(px, kx, cx), cellOf(py, ky, cy), cellOf(pz, kz, cz);
+        sCode[w][lane] = (uint32_t)(kx + 16 * (ky + 16 * kz));
+        __builtin_amdgcn_wave_barrier();
+        uint32_t ck[6];
+#pragma unroll
+        for (int s = 0; s < 6; ++s) ck[s] = sCode[w][rowInStep + 12 * s];  // lanes 60..63 read row 12: harmless
+        const double* np = nullptr;
+        if (PF) {
+            const size_t nb = base + step;
+            const size_t ni = (nb + threadIdx.x < n) ? nb + threadIdx.x : n - 1;
+            np = xyz + 3 * ni;
+        }
+        double cv[10];
+#pragma unroll
+        for (int pass = 0; pass < PASSES; ++pass) {
+#pragma unroll
+            for (int s = 0; s < SPP; ++s) {
+                const uint32_t off = (ck[pass * SPP + s] << 7) + (uint32_t)chunk * 16u;
+                const char* src = reinterpret_cast<const char*>(a.r80) + off;
+                if (fetcher)
+                    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src, (LDS_AS void*)&sd[w][s][0], 16, 0, 0);
+            }
+            if (PF && pass == PASSES - 1) {
+                asm volatile("global_load_dwordx2 %0, %3, off\n\tglobal_load_dwordx2 %1, %3, off offset:8\n\tglobal_load_dwordx2 %2, %3, off offset:16"
+                             : "=&v"(nx), "=&v"(ny), "=&v"(nz) : "v"(np) : "memory");
+                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (myStep / SPP == pass) {
+                const double2* row = &sd[w][myStep % SPP][myRow * 5];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    const double2 v = row[q];
+                    cv[2 * q] = v.x, cv[2 * q + 1] = v.y;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        const double r = eval2(cv, (px - cx) * 32.0, (py - cy) * 32.0, (pz - cz) * 32.0, a.nl);
+        if (base + threadIdx.x < n) out[base + threadIdx.x] = r;
+    }
+}
+
+template <typename K>
+float timeIt(K launch, int reps) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) launch();
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) launch();
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / reps;
+}
+
+int main(int argc, char** argv) {
+    const size_t n = argc > 1 ? atol(argv[1]) : 10000000;
+    std::vector<double> pts(3 * n);
+    uint64_t s = 12345;
+    for (auto& v : pts) {
+        s += 0x9E3779B97F4A7C15ull;
+        uint64_t z = s;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        v = (double)(z >> 11) * 0x1p-53 - 0.5;
+    }
+    // a few points on cell boundaries / root faces: the floor index must agree with the comparison chain
+    for (int i = 0; i < 3000 && (size_t)i < 3 * n; ++i) pts[i] = ((i * 7) % 17 - 8) / 16.0;
+    std::vector<Fat> fat(4096);
+    std::vector<Row80> r80(4096);
+    for (int i = 0; i < 4096; ++i) {
+        fat[i].a = i, fat[i].b = 2;
+        for (int k = 0; k < 10; ++k) {
+            const double c = std::sin(i * 0.37 + k);
+            fat[i].c[k] = c, r80[i].c[k] = c;
+        }
+    }
+    Args a;
+    for (int j = 0; j < 3; ++j) a.nl[j] = std::sqrt((2.0 * j + 1.0) * 16.0);
+    double *dx, *dout;
+    Fat* dfat;
+    Row80* dr80;
+    CK(hipMalloc(&dx, pts.size() * 8));
+    CK(hipMalloc(&dout, n * 8));
+    CK(hipMalloc(&dfat, fat.size() * sizeof(Fat)));
+    CK(hipMalloc(&dr80, r80.size() * sizeof(Row80)));
+    CK(hipMemcpy(dx, pts.data(), pts.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dfat, fat.data(), fat.size() * sizeof(Fat), hipMemcpyHostToDevice));
+    CK(hipMemcpy(dr80, r80.data(), r80.size() * sizeof(Row80), hipMemcpyHostToDevice));
+    a.fat = dfat, a.r80 = dr80;
+    std::vector<double> h(n), ref;
+    auto check = [&](const char* name, float ms, int grid) {
+        CK(hipMemcpy(h.data(), dout, n * 8, hipMemcpyDeviceToHost));
+        size_t bad = 0;
+        if (ref.empty()) ref = h;
+        for (size_t i = 0; i < n; ++i) bad += (h[i] != ref[i]);
+        printf("%-58s grid %6d : %7.1f us  %7.1f GB/s alg  mismatches %zu\n", name, grid, ms * 1e3, 32.0 * n / ms / 1e6, bad);
+        fflush(stdout);
+    };
+#define RUN8(I, C, P, g) check("8-lane rows  idx=" #I " codes=" #C " pf=" #P, timeIt([&] { hipLaunchKernelGGL((lab8<I, C, P>), dim3(g), dim3(256), 0, 0, a, dx, n, dout); }, 10), g)
+#define RUN5(PS, P, g) check("5-lane rows (80 B)  passes=" #PS " pf=" #P, timeIt([&] { hipLaunchKernelGGL((lab5<PS, P>), dim3(g), dim3(256), 0, 0, a, dx, n, dout); }, 10), g)
+    const char* only = argc > 2 ? argv[2] : "";
+    (void)only;
+    for (int g : {4096, 8192, 16384}) {
+        printf("grid %d\n", g);
+        fflush(stdout);
+        RUN8(0, 0, 0, g);
+        RUN8(1, 0, 0, g);
+        RUN8(0, 1, 0, g);
+        RUN8(1, 1, 0, g);
+        RUN5(1, 0, g);
+        RUN5(2, 0, g);
+        printf("\n");
+    }
+    return 0;
+}
