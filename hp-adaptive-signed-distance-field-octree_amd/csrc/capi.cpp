@@ -523,10 +523,8 @@ int hpsdf_tree_info(const hpsdf_tree* t, uint64_t* nNodes, uint64_t* nCoeffs, ui
     return HPSDF_OK;
 }
 
-int hpsdf_query_device(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* dXyz, size_t n, double* dOut) {
-    HPSDF_TRY
-    if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "a device context is required");
-    if (!t || (!dXyz && n) || (!dOut && n)) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+// Query / QueryWithGradient over device arrays (dGrad == nullptr: values only)
+static int queryDevice(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* dXyz, size_t n, double* dOut, double* dGrad) {
     if (t->device != ctx->device) return fail(HPSDF_ERR_INVALID_ARGUMENT, "tree lives on another device");
     HPSDF_HIP(hipSetDevice(ctx->device));
     const size_t kChunk = (size_t)1 << 31;  // deferred indices are 32-bit
@@ -543,10 +541,17 @@ int hpsdf_query_device(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* dXyz, 
                 ctx->deferCap = need;
             }
         }
-        HPSDF_HIP(launchQuery(ctx->stream, t->dev, ctx->dTables, dXyz + 3 * off, m, dOut + off, t->allInline, ctx->dDeferCount,
-                              ctx->dDefer));
+        HPSDF_HIP(launchQuery(ctx->stream, t->dev, ctx->dTables, dXyz + 3 * off, m, dOut + off, dGrad ? dGrad + 3 * off : nullptr,
+                              t->allInline, ctx->dDeferCount, ctx->dDefer));
     }
     return HPSDF_OK;
+}
+
+int hpsdf_query_device(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* dXyz, size_t n, double* dOut) {
+    HPSDF_TRY
+    if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "a device context is required");
+    if (!t || (!dXyz && n) || (!dOut && n)) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    return queryDevice(ctx, t, dXyz, n, dOut, nullptr);
     HPSDF_CATCH
 }
 
@@ -568,10 +573,7 @@ int hpsdf_query_gradient_device(hpsdf_ctx* ctx, const hpsdf_tree* t, const doubl
     HPSDF_TRY
     if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "a device context is required");
     if (!t || (n && (!dXyz || !dOut || !dGrad))) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
-    if (t->device != ctx->device) return fail(HPSDF_ERR_INVALID_ARGUMENT, "tree lives on another device");
-    HPSDF_HIP(hipSetDevice(ctx->device));
-    HPSDF_HIP(launchQueryGrad(ctx->stream, t->dev, ctx->dTables, dXyz, n, dOut, dGrad));
-    return HPSDF_OK;
+    return queryDevice(ctx, t, dXyz, n, dOut, dGrad);
     HPSDF_CATCH
 }
 

@@ -296,6 +296,55 @@ __device__ __forceinline__ double evalLeafVals(const double (&cv)[NV], double ux
     return f;
 }
 
+// Octree::FApproxWithGradient (Octree.cpp:904-985) for a compile-time degree: the value as FApprox, the "gradient"
+// as the reference forms it -- per axis k the central difference of sum_r c_r * Lhat_{idx[r][k]}(u_k +- eps), i.e. with
+// the other two axes' factors left out (:956-968) -- then normalised.  Same statements, same order as
+// query_grad_kernel's any-degree loop (and as the oracle), with the tables in registers.
+template <int P, int NV>
+__device__ __forceinline__ double evalLeafGradVals(const double (&cv)[NV], const double (&u)[3], int depth, const double* sNl,
+                                                   const double* sRec, double (&g)[3]) {
+    constexpr int N = coeffCount(P);
+    static_assert(NV >= N, "coefficient registers");
+    const double eps = 0.0001;
+    double L0[3][P + 1];  // normalised Legendre values at u, per axis: the value's factors
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        double Lp[P + 1], Lm[P + 1];
+        L0[k][0] = Lp[0] = Lm[0] = sNl[depth];
+        double a2 = 0.0, a1 = 1.0, b2 = 0.0, b1 = 1.0, c2 = 0.0, c1 = 1.0;
+#pragma unroll
+        for (int j = 1; j <= P; ++j) {
+            const double r0 = sRec[2 * j], r1 = sRec[2 * j + 1], nl = sNl[j * 11 + depth];
+            const double a0 = r0 * u[k] * a1 - r1 * a2;          // :937
+            const double b0 = r0 * (u[k] + eps) * b1 - r1 * b2;  // :941
+            const double c0 = r0 * (u[k] - eps) * c1 - r1 * c2;  // :945
+            a2 = a1, a1 = a0, b2 = b1, b1 = b0, c2 = c1, c1 = c0;
+            L0[k][j] = a0 * nl, Lp[j] = b0 * nl, Lm[j] = c0 * nl;
+        }
+        double p1 = 0.0, m1 = 0.0;
+#pragma unroll
+        for (int r = 0; r < N; ++r) {  // :956-968
+            p1 = p1 + cv[r] * Lp[kBasis.v[r][k]];
+            m1 = m1 + cv[r] * Lm[kBasis.v[r][k]];
+        }
+        g[k] = (p1 - m1) / (2.0 * eps);
+    }
+    const double z = g[0] * g[0] + (g[1] * g[1] + g[2] * g[2]);  // Eigen normalize()
+    if (z > 0.0) {
+        const double nrm = sqrt(z);
+        g[0] = g[0] / nrm, g[1] = g[1] / nrm, g[2] = g[2] / nrm;
+    }
+    double f = 0.0;  // :972-984
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+        double lp = L0[0][kBasis.v[r][0]];
+        lp = lp * L0[1][kBasis.v[r][1]];
+        lp = lp * L0[2][kBasis.v[r][2]];
+        f = f + cv[r] * lp;
+    }
+    return f;
+}
+
 // Legendre recurrence constants (2j-1)/j and (j-1)/j (Include/HP/Utility.h:112-127): IEEE divisions of small
 // integers, so the compile-time values are the table's values.
 __host__ __device__ constexpr double recA(int j) { return j == 0 ? 0.0 : (2.0 * j - 1.0) / j; }
@@ -585,11 +634,13 @@ __device__ __forceinline__ uint32_t leafChunks(uint32_t degree) { return ((uint3
 // the workgroup's own run of deferIdx (an LDS counter, no global atomic -- one global atomic per wave serialised
 // the first version of this at 2 ms per 10 M points) and query_deep_kernel finishes them lane by lane; keeping
 // that code out of this kernel keeps it at ~100 VGPRs.
-template <int TOPD, bool DEFER>
+// GRAD: QueryWithGradient (Octree.cpp:749-789) -- the same walk and fetch, value and "gradient" evaluated together;
+// rows of grad for points outside the root are left untouched, as the reference leaves its output argument.
+template <int TOPD, bool DEFER, bool GRAD>
 __global__ __launch_bounds__(256) void query_general_kernel(TreeDev t, const DeviceTables* __restrict__ T,
                                                             const double* __restrict__ xyz, size_t n,
-                                                            double* __restrict__ out, uint32_t tilesPerWg,
-                                                            uint32_t* __restrict__ deferCount,
+                                                            double* __restrict__ out, double* __restrict__ grad,
+                                                            uint32_t tilesPerWg, uint32_t* __restrict__ deferCount,
                                                             uint32_t* __restrict__ deferIdx) {
     __shared__ double2 sRows[4][5][66];
     __shared__ uint32_t sInfo[4][64];
@@ -683,16 +734,27 @@ __global__ __launch_bounds__(256) void query_general_kernel(TreeDev t, const Dev
             __builtin_amdgcn_wave_barrier();  // the window is rewritten by the next pass / tile
         }
         double r = DBL_MAX;  // :668-671
+        double g[3] = {0.0, 0.0, 0.0};
         bool defer = false;
         if (inside) {
-            const double s = (double)(2 << depth);  // :862
-            const double ux = (p3[0] - c3[0]) * s, uy = (p3[1] - c3[1]) * s, uz = (p3[2] - c3[2]) * s;
-            switch (degree) {
-                case 0: r = evalLeafVals<0>(cv, ux, uy, uz, depth, sNl, sRec); break;
-                case 1: r = evalLeafVals<1>(cv, ux, uy, uz, depth, sNl, sRec); break;
-                case 2: r = evalLeafVals<2>(cv, ux, uy, uz, depth, sNl, sRec); break;
-                case 3: r = evalLeafVals<3>(cv, ux, uy, uz, depth, sNl, sRec); break;
-                default: defer = valid; break;
+            const double s = (double)(2 << depth);  // :862 / :907
+            const double u[3] = {(p3[0] - c3[0]) * s, (p3[1] - c3[1]) * s, (p3[2] - c3[2]) * s};
+            if constexpr (GRAD) {
+                switch (degree) {
+                    case 0: r = evalLeafGradVals<0>(cv, u, depth, sNl, sRec, g); break;
+                    case 1: r = evalLeafGradVals<1>(cv, u, depth, sNl, sRec, g); break;
+                    case 2: r = evalLeafGradVals<2>(cv, u, depth, sNl, sRec, g); break;
+                    case 3: r = evalLeafGradVals<3>(cv, u, depth, sNl, sRec, g); break;
+                    default: defer = valid; break;
+                }
+            } else {
+                switch (degree) {
+                    case 0: r = evalLeafVals<0>(cv, u[0], u[1], u[2], depth, sNl, sRec); break;
+                    case 1: r = evalLeafVals<1>(cv, u[0], u[1], u[2], depth, sNl, sRec); break;
+                    case 2: r = evalLeafVals<2>(cv, u[0], u[1], u[2], depth, sNl, sRec); break;
+                    case 3: r = evalLeafVals<3>(cv, u[0], u[1], u[2], depth, sNl, sRec); break;
+                    default: defer = valid; break;
+                }
             }
         }
         if constexpr (DEFER) {
@@ -705,7 +767,12 @@ __global__ __launch_bounds__(256) void query_general_kernel(TreeDev t, const Dev
                 if (defer) deferIdx[segStart + slot + (uint32_t)__popcll(dmask & ((1ull << lane) - 1ull))] = (uint32_t)i;
             }
         }
-        if (valid && !defer) out[i] = r;
+        if (valid && !defer) {
+            out[i] = r;
+            if constexpr (GRAD) {
+                if (inside) grad[3 * i] = g[0], grad[3 * i + 1] = g[1], grad[3 * i + 2] = g[2];
+            }
+        }
     }
     if constexpr (DEFER) {
         __syncthreads();
@@ -733,18 +800,23 @@ __global__ __launch_bounds__(256) void query_deep_kernel(TreeDev t, const Device
     }
 }
 
-// Octree::QueryWithGradient + FApproxWithGradient (Octree.cpp:749-789, 904-985): value as Query; the
-// "gradient" is the reference's central difference of the per-axis basis factor, normalised.  One lane per
-// point; grad of a point outside the root is left untouched, as the reference leaves its output argument.
-__global__ __launch_bounds__(256) void query_grad_kernel(TreeDev t, const DeviceTables* __restrict__ T,
-                                                         const double* __restrict__ xyz, size_t n,
-                                                         double* __restrict__ out, double* __restrict__ grad) {
+// Octree::QueryWithGradient + FApproxWithGradient (Octree.cpp:749-789, 904-985), any degree, one lane per point:
+// the second pass of the gradient query for the points query_general_kernel<.., GRAD> deferred (leaves of degree > 3).
+// Workgroup b walks the list the first kernel's workgroup b left in its run of deferIdx.
+__global__ __launch_bounds__(256) void query_grad_deep_kernel(TreeDev t, const DeviceTables* __restrict__ T,
+                                                              const double* __restrict__ xyz, double* __restrict__ out,
+                                                              double* __restrict__ grad, uint32_t tilesPerWg,
+                                                              const uint32_t* __restrict__ deferCount,
+                                                              const uint32_t* __restrict__ deferIdx) {
     __shared__ double sNl[13 * 11];
     __shared__ double sRec[26];
+    const uint32_t count = deferCount[blockIdx.x];
+    if (count == 0) return;  // workgroup-uniform
     stageQueryTables(T, sNl, sRec);
     __syncthreads();
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const size_t segStart = (size_t)blockIdx.x * tilesPerWg * 256;
+    for (uint32_t jj = threadIdx.x; jj < count; jj += blockDim.x) {
+        const size_t i = deferIdx[segStart + jj];
         const double p[3] = {(xyz[3 * i] - t.rootCentre[0]) * t.rootInvSizes[0],
                              (xyz[3 * i + 1] - t.rootCentre[1]) * t.rootInvSizes[1],
                              (xyz[3 * i + 2] - t.rootCentre[2]) * t.rootInvSizes[2]};
@@ -1322,13 +1394,14 @@ static unsigned gridFor(size_t n) {
     return (unsigned)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
 }
 
-// dDeferCount: kQueryMaxGrid counters; dDeferIdx: n + 256 * kQueryMaxGrid slots (both only for trees with leaves of
-// degree > 3).  n < 2^32 (the caller splits larger batches).
+// Query (dGrad == nullptr) or QueryWithGradient.  dDeferCount: kQueryMaxGrid counters; dDeferIdx: n + 256 *
+// kQueryMaxGrid slots (both only touched for trees with leaves of degree > 3).  n < 2^32 (the caller splits larger
+// batches).
 hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dXyz, size_t n,
-                       double* dOut, bool allInline, uint32_t* dDeferCount, uint32_t* dDeferIdx) {
+                       double* dOut, double* dGrad, bool allInline, uint32_t* dDeferCount, uint32_t* dDeferIdx) {
     if (n == 0) return hipSuccess;
     const dim3 grid(gridFor(n)), block(256);
-    if (allInline) {
+    if (allInline && !dGrad) {
         if (t.topDepth == 4)
             hipLaunchKernelGGL((query_kernel<4>), grid, block, 0, stream, t, dXyz, n, dOut);
         else
@@ -1338,34 +1411,38 @@ hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables*
     const size_t nTiles = (n + 255) / 256;
     const uint32_t tilesPerWg = (uint32_t)((nTiles + grid.x - 1) / grid.x);  // tiles b, b + G, ... of workgroup b
     const bool defer = t.maxDegree > 3;
-#define HPSDF_QUERY_GENERAL(TOPD, DF)                                                                                 \
-    hipLaunchKernelGGL((query_general_kernel<TOPD, DF>), grid, block, 0, stream, t, dTables, dXyz, n, dOut, tilesPerWg, \
-                       dDeferCount, dDeferIdx)
-    if (t.topDepth == 4) {
-        if (defer)
-            HPSDF_QUERY_GENERAL(4, true);
-        else
-            HPSDF_QUERY_GENERAL(4, false);
-    } else {
-        if (defer)
-            HPSDF_QUERY_GENERAL(0, true);
-        else
-            HPSDF_QUERY_GENERAL(0, false);
-    }
+#define HPSDF_QUERY_GENERAL(TOPD, DF, GR)                                                                            \
+    hipLaunchKernelGGL((query_general_kernel<TOPD, DF, GR>), grid, block, 0, stream, t, dTables, dXyz, n, dOut, dGrad, \
+                       tilesPerWg, dDeferCount, dDeferIdx)
+#define HPSDF_QUERY_GENERAL_T(TOPD)          \
+    do {                                     \
+        if (dGrad) {                         \
+            if (defer)                       \
+                HPSDF_QUERY_GENERAL(TOPD, true, true);   \
+            else                             \
+                HPSDF_QUERY_GENERAL(TOPD, false, true);  \
+        } else {                             \
+            if (defer)                       \
+                HPSDF_QUERY_GENERAL(TOPD, true, false);  \
+            else                             \
+                HPSDF_QUERY_GENERAL(TOPD, false, false); \
+        }                                    \
+    } while (0)
+    if (t.topDepth == 4)
+        HPSDF_QUERY_GENERAL_T(4);
+    else
+        HPSDF_QUERY_GENERAL_T(0);
+#undef HPSDF_QUERY_GENERAL_T
 #undef HPSDF_QUERY_GENERAL
     if (defer) {
-        if (t.maxDegree <= 5)
+        if (dGrad)
+            hipLaunchKernelGGL(query_grad_deep_kernel, grid, block, 0, stream, t, dTables, dXyz, dOut, dGrad, tilesPerWg,
+                               dDeferCount, dDeferIdx);
+        else if (t.maxDegree <= 5)
             hipLaunchKernelGGL((query_deep_kernel<5>), grid, block, 0, stream, t, dTables, dXyz, dOut, tilesPerWg, dDeferCount, dDeferIdx);
         else
             hipLaunchKernelGGL((query_deep_kernel<12>), grid, block, 0, stream, t, dTables, dXyz, dOut, tilesPerWg, dDeferCount, dDeferIdx);
     }
-    return hipGetLastError();
-}
-
-hipError_t launchQueryGrad(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dXyz,
-                           size_t n, double* dOut, double* dGrad) {
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(query_grad_kernel, dim3(gridFor(n)), dim3(256), 0, stream, t, dTables, dXyz, n, dOut, dGrad);
     return hipGetLastError();
 }
 

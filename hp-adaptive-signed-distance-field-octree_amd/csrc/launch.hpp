@@ -29,9 +29,7 @@ hipError_t launchFit(hipStream_t stream, int degree, int cellsPerThread, const F
                      const FitTask* dTasks, double* dArena, double* dErrs, double* dMeans,
                      const DeviceTables* dTables, const FieldDev& field, const RootMap& rm);
 hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dXyz, size_t n,
-                       double* dOut, bool allInline, uint32_t* dDeferCount, uint32_t* dDeferIdx);
-hipError_t launchQueryGrad(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dXyz,
-                           size_t n, double* dOut, double* dGrad);
+                       double* dOut, double* dGrad, bool allInline, uint32_t* dDeferCount, uint32_t* dDeferIdx);
 hipError_t launchQueryRay(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dOrigins,
                           const double* dDirs, const double* dTMax, size_t n, uint8_t* dHit, double* dT);
 hipError_t launchSlice(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, double c, float minX,

@@ -475,3 +475,22 @@ def test_create_with_continuity_matches_oracle(H, O, ctx, field, target, rmin, r
         pts = O.splitmix64_points(300000, seed=9)
         true = np.linalg.norm(pts - np.array([0.25, 0, 0]), axis=1) - 0.5
         assert np.abs(H.DeviceTree(ctx, blk).query(pts) - true).max() <= 1e-2
+
+
+@pytest.mark.parametrize("case", ["A1_union3_1e-7_K1024", "A2_sphere_1e-8_K1024"])
+def test_query_refined_trees_many_points_bitwise(H, O, ctx, golden, case):
+    """The wave-cooperative general kernel over many workgroups and a ragged last tile: leaves of degree 2 and 3 at
+    depths 4-6 fetched by the wave, leaves of degree 4 through the per-workgroup deferred lists (no global atomics)."""
+    g = golden["blocks"][case]
+    ot = O.Tree.create(O.default_config(g["target"]), oracle_field(O, g["field"]), g["K"])
+    tree = H.DeviceTree(ctx, ot.to_block())
+    assert tree.info()["max_degree"] == 4
+    n = 2_100_003
+    pts = O.splitmix64_points(n, seed=77)
+    pts[::1000] *= 2.5  # some outside the root
+    got, want = tree.query(pts), ot.query(pts)
+    assert np.array_equal(bits(got), bits(want))
+    assert (got == DBL_MAX).sum() > 100
+    gv, gg = tree.query_with_gradient(pts[:700_001])
+    wv, wg = ot.query_with_gradient(pts[:700_001])
+    assert np.array_equal(bits(gv), bits(wv)) and np.array_equal(bits(gg), bits(wg))

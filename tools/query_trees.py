@@ -36,3 +36,20 @@ with torch.cuda.stream(stream):
         print("%-16s create %7.2f ms  nodes %6d leaves %6d max depth %d degrees %s | query %7.1f us = %6.1f Gpts/s (%.2f of HBM peak)"
               % (name, tc, info["n_nodes"], info["n_leaves"], info["max_depth"], hist, ms * 1e3, n / ms / 1e6, 32 * n / ms / 1e6 / 8000),
               flush=True)
+    # QueryWithGradient on the last two kinds of tree (the reference's 8 M-point gradient benchmark, HPBenchmarks.cpp:169-203)
+    import ctypes as C
+    for name, field, target in (("C2 union3 1e-5", H.Field.union3(), 1e-5), ("A2 sphere 1e-8", H.Field.sphere(), 1e-8)):
+        blk, st = H.create_block(ctx, H.make_config(target), field, 1024)
+        tree = H.DeviceTree(ctx, blk)
+        L = H.lib()
+        call = lambda: H.check(L.hpsdf_query_gradient_device(ctx.handle, tree.handle, C.c_void_p(pts.data_ptr()), n,
+                                                             C.c_void_p(out.data_ptr()), C.c_void_p(grad.data_ptr())))
+        call()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(5):
+            call()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        print("%-16s QueryWithGradient %8.1f us = %6.1f Gpts/s (56 B/pt: %.2f of HBM peak)" % (name, ms * 1e3, n / ms / 1e6, 56 * n / ms / 1e6 / 8000), flush=True)
