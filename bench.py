@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--points", type=int, default=N_POINTS, help="query points per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fit-bench", action="store_true", help="also run the steady-state fit micro-benchmark")
+    ap.add_argument("--no-refined", action="store_true",
+                    help="skip the extra Query / QueryWithGradient timings on the refined tree (union3 @ 1e-7)")
     ap.add_argument("--sorted-ceiling", action="store_true",
                     help="also time Query on the same points sorted by depth-4 cell (locality ceiling, SURVEY 8d)")
     args = ap.parse_args()
@@ -152,6 +154,50 @@ def main():
             assert torch.equal(d_out2, d_out[order]), "sorted-point Query differs from the unsorted one"
             del d_sorted, d_out2, order, cell
 
+        # Beyond the headline config: the same points against a tree the hp-refinement has actually worked on
+        # (union3 @ 1e-7: ~12 k nodes, degrees 2-4, depths 4-6) -- Query goes through
+        # query_general_kernel there -- and QueryWithGradient (reference benchmark HPBenchmarks.cpp:169-203).
+        refined = None
+        if rank == 0 and not args.no_refined:
+            import ctypes as C
+            blk_r, st_r = H.create_block(ctx, H.make_config(1e-7), field, JOBS_PER_ROUND)
+            t0 = time.perf_counter()
+            blk_r, st_r = H.create_block(ctx, H.make_config(1e-7), field, JOBS_PER_ROUND)
+            torch.cuda.synchronize()
+            create_r_ms = (time.perf_counter() - t0) * 1e3
+            tree_r = H.DeviceTree(ctx, blk_r)
+            d_grad = torch.empty(3 * n, dtype=torch.float64, device="cuda")
+            d_out2 = torch.empty_like(d_out)
+            L = H.lib()
+
+            def timed(fn, reps=5):
+                fn()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(stream)
+                for _ in range(reps):
+                    fn()
+                b.record(stream)
+                torch.cuda.synchronize()
+                return a.elapsed_time(b) / reps
+
+            q_ms = timed(lambda: tree_r.query_device(d_xyz.data_ptr(), n, d_out2.data_ptr()))
+            got_r = d_out2[:: max(1, n // 2000)].cpu().numpy()
+            g_ms = timed(lambda: H.check(L.hpsdf_query_gradient_device(ctx.handle, tree_r.handle, C.c_void_p(d_xyz.data_ptr()), n,
+                                                                      C.c_void_p(d_out2.data_ptr()), C.c_void_p(d_grad.data_ptr()))))
+            gc_ms = timed(lambda: H.check(L.hpsdf_query_gradient_device(ctx.handle, tree.handle, C.c_void_p(d_xyz.data_ptr()), n,
+                                                                       C.c_void_p(d_out2.data_ptr()), C.c_void_p(d_grad.data_ptr()))))
+            refined = {"tree": "union3 @ 1e-7, K=%d: %d nodes, %d leaves, %d coeffs, max degree %d, max depth %d"
+                               % (JOBS_PER_ROUND, st_r["n_nodes"], st_r["n_leaves"], st_r["n_coeffs"], tree_r.info()["max_degree"],
+                                  tree_r.info()["max_depth"]),
+                       "create_ms": create_r_ms, "create_jobs": st_r["jobs"], "create_rounds": st_r["rounds"],
+                       "query_ms": q_ms, "query_mpts_per_s": n / q_ms / 1e3, "query_frac_hbm_peak": 32.0 * n / (q_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "query_with_gradient_ms": g_ms, "query_with_gradient_mpts_per_s": n / g_ms / 1e3,
+                       "query_with_gradient_frac_hbm_peak": 56.0 * n / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "headline_tree_query_with_gradient_ms": gc_ms}
+            refined["_blk"] = blk_r
+            refined["_got"] = got_r
+            del d_grad, d_out2
+
         fit = None
         if args.fit_bench and rank == 0:
             fit = {}
@@ -204,6 +250,10 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": 32 * n,
                      "avg_launch_ms": kernel_ms},
     }
+    if refined is not None:
+        want_r = O.Tree.from_block(refined.pop("_blk")).query(pts[:: max(1, n // 2000)])
+        assert np.array_equal(refined.pop("_got"), want_r), "timed Query output on the refined tree differs from the oracle"
+        out["refined_tree"] = refined
     if sorted_ms is not None:
         out["query_cell_sorted_points"] = {"avg_launch_ms": sorted_ms, "mpts_per_s": n / sorted_ms / 1e3,
                                            "frac_hbm_peak": 32.0 * n / (sorted_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}

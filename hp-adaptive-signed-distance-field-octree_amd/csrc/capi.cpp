@@ -531,7 +531,7 @@ static int queryDevice(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* dXyz, 
     for (size_t off = 0; off < n; off += kChunk) {
         const size_t m = std::min(kChunk, n - off);
         if (t->maxDegree > 3) {
-            if (!ctx->dDeferCount) HPSDF_HIP(hipMalloc((void**)&ctx->dDeferCount, kQueryMaxGrid * sizeof(uint32_t)));
+            if (!ctx->dDeferCount) HPSDF_HIP(hipMalloc((void**)&ctx->dDeferCount, (2 * kQueryMaxGrid + 1) * sizeof(uint32_t)));
             const size_t need = m + (size_t)256 * kQueryMaxGrid;
             if (ctx->deferCap < need) {
                 if (ctx->dDefer) HPSDF_HIP(hipFree(ctx->dDefer));

@@ -621,8 +621,9 @@ int continuityPostProcess(void* block, size_t size, double tol, int maxIter, uin
         assemble(b, asmPool, M, st);
     }
     const double t1 = nowMs();
-    // a CG region over a few hundred thousand non-zeros lasts tens of microseconds: one thread per ~0.5 M non-zeros
-    Pool pool((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nThreads, st.nnz / 500000)));
+    // a CG region over a few hundred thousand non-zeros lasts tens of microseconds: one thread per ~0.25 M non-zeros
+    // (a per-leaf dense block preconditioner was tried: 106 -> 88 iterations on sphere@1e-8, not worth its triangular solves)
+    Pool pool((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nThreads, st.nnz / 250000)));
     const uint64_t n = b.nCoeffs;
     const double lambda = b.cfg.continuity_strength;
     std::vector<double> rhs(n), x(n), r(n), p(n), z(n), tmp(n), dinv(n), c(n);

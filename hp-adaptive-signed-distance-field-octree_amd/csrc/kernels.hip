@@ -780,43 +780,88 @@ __global__ __launch_bounds__(256) void query_general_kernel(TreeDev t, const Dev
     }
 }
 
-// Second pass of Query for the points query_general_kernel deferred (leaves of degree > 3), one lane each.
-// Workgroup b walks the list the first kernel's workgroup b left in its run of deferIdx.
+// Exclusive scan of the per-workgroup deferred counts (nWg <= 8192): offsets[b] = points deferred by workgroups
+// < b, offsets[nWg] = their total.  One workgroup of 1024 threads, eight counts each.
+__global__ __launch_bounds__(1024) void defer_scan_kernel(const uint32_t* __restrict__ counts, uint32_t nWg,
+                                                          uint32_t* __restrict__ offsets) {
+    __shared__ uint32_t sSum[1024];
+    const uint32_t tid = threadIdx.x;
+    uint32_t local[8], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t b = tid * 8 + k;
+        local[k] = b < nWg ? counts[b] : 0u;
+        sum += local[k];
+    }
+    sSum[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {  // inclusive Hillis-Steele scan
+        const uint32_t v = tid >= d ? sSum[tid - d] : 0u;
+        __syncthreads();
+        sSum[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = sSum[tid] - sum;  // exclusive prefix of this thread's eight
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t b = tid * 8 + k;
+        if (b < nWg) offsets[b] = run;
+        run += local[k];
+    }
+    if (tid == 1023) offsets[nWg] = sSum[1023];
+}
+
+// j-th deferred point overall -> its index: the workgroup whose run holds it (binary search in the scanned counts),
+// then the slot inside that run.
+__device__ __forceinline__ size_t deferredPoint(uint32_t j, const uint32_t* __restrict__ offsets, uint32_t nWg,
+                                                uint32_t tilesPerWg, const uint32_t* __restrict__ deferIdx) {
+    uint32_t lo = 0, hi = nWg;  // offsets[lo] <= j < offsets[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (offsets[mid] <= j)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return deferIdx[(size_t)lo * tilesPerWg * 256 + (j - offsets[lo])];
+}
+
+// Second pass of Query for the points query_general_kernel deferred (leaves of degree > 3), one lane each, dense
+// over the concatenation of the per-workgroup lists.
 template <int MAXP>
 __global__ __launch_bounds__(256) void query_deep_kernel(TreeDev t, const DeviceTables* __restrict__ T,
                                                          const double* __restrict__ xyz, double* __restrict__ out,
-                                                         uint32_t tilesPerWg, const uint32_t* __restrict__ deferCount,
+                                                         uint32_t tilesPerWg, uint32_t nWg,
+                                                         const uint32_t* __restrict__ offsets,
                                                          const uint32_t* __restrict__ deferIdx) {
     __shared__ double sNl[13 * 11];
     __shared__ double sRec[26];
-    const uint32_t count = deferCount[blockIdx.x];
-    if (count == 0) return;  // workgroup-uniform
+    const uint32_t total = offsets[nWg];
+    if ((uint32_t)(blockIdx.x * blockDim.x) >= total) return;  // workgroup-uniform
     stageQueryTables(T, sNl, sRec);
     __syncthreads();
-    const size_t segStart = (size_t)blockIdx.x * tilesPerWg * 256;
-    for (uint32_t j = threadIdx.x; j < count; j += blockDim.x) {
-        const size_t i = deferIdx[segStart + j];
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
+        const size_t i = deferredPoint(j, offsets, nWg, tilesPerWg, deferIdx);
         out[i] = queryPoint<MAXP>(t, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], sNl, sRec);
     }
 }
 
 // Octree::QueryWithGradient + FApproxWithGradient (Octree.cpp:749-789, 904-985), any degree, one lane per point:
 // the second pass of the gradient query for the points query_general_kernel<.., GRAD> deferred (leaves of degree > 3).
-// Workgroup b walks the list the first kernel's workgroup b left in its run of deferIdx.
+// Dense over the concatenation of the per-workgroup lists, like query_deep_kernel.
 __global__ __launch_bounds__(256) void query_grad_deep_kernel(TreeDev t, const DeviceTables* __restrict__ T,
                                                               const double* __restrict__ xyz, double* __restrict__ out,
-                                                              double* __restrict__ grad, uint32_t tilesPerWg,
-                                                              const uint32_t* __restrict__ deferCount,
+                                                              double* __restrict__ grad, uint32_t tilesPerWg, uint32_t nWg,
+                                                              const uint32_t* __restrict__ offsets,
                                                               const uint32_t* __restrict__ deferIdx) {
     __shared__ double sNl[13 * 11];
     __shared__ double sRec[26];
-    const uint32_t count = deferCount[blockIdx.x];
-    if (count == 0) return;  // workgroup-uniform
+    const uint32_t total = offsets[nWg];
+    if ((uint32_t)(blockIdx.x * blockDim.x) >= total) return;  // workgroup-uniform
     stageQueryTables(T, sNl, sRec);
     __syncthreads();
-    const size_t segStart = (size_t)blockIdx.x * tilesPerWg * 256;
-    for (uint32_t jj = threadIdx.x; jj < count; jj += blockDim.x) {
-        const size_t i = deferIdx[segStart + jj];
+    for (uint32_t jj = blockIdx.x * blockDim.x + threadIdx.x; jj < total; jj += gridDim.x * blockDim.x) {
+        const size_t i = deferredPoint(jj, offsets, nWg, tilesPerWg, deferIdx);
         const double p[3] = {(xyz[3 * i] - t.rootCentre[0]) * t.rootInvSizes[0],
                              (xyz[3 * i + 1] - t.rootCentre[1]) * t.rootInvSizes[1],
                              (xyz[3 * i + 2] - t.rootCentre[2]) * t.rootInvSizes[2]};
@@ -1394,7 +1439,7 @@ static unsigned gridFor(size_t n) {
     return (unsigned)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
 }
 
-// Query (dGrad == nullptr) or QueryWithGradient.  dDeferCount: kQueryMaxGrid counters; dDeferIdx: n + 256 *
+// Query (dGrad == nullptr) or QueryWithGradient.  dDeferCount: 2 * kQueryMaxGrid + 1 words (counts, then their scan); dDeferIdx: n + 256 *
 // kQueryMaxGrid slots (both only touched for trees with leaves of degree > 3).  n < 2^32 (the caller splits larger
 // batches).
 hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dXyz, size_t n,
@@ -1435,13 +1480,17 @@ hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables*
 #undef HPSDF_QUERY_GENERAL_T
 #undef HPSDF_QUERY_GENERAL
     if (defer) {
+        // the per-workgroup lists are short and ragged: scan their lengths, then walk their concatenation densely
+        uint32_t* dOffsets = dDeferCount + kQueryMaxGrid;
+        hipLaunchKernelGGL(defer_scan_kernel, dim3(1), dim3(1024), 0, stream, dDeferCount, grid.x, dOffsets);
+        const dim3 dgrid(std::min<unsigned>(grid.x, 1024u));
         if (dGrad)
-            hipLaunchKernelGGL(query_grad_deep_kernel, grid, block, 0, stream, t, dTables, dXyz, dOut, dGrad, tilesPerWg,
-                               dDeferCount, dDeferIdx);
+            hipLaunchKernelGGL(query_grad_deep_kernel, dgrid, block, 0, stream, t, dTables, dXyz, dOut, dGrad, tilesPerWg, grid.x,
+                               dOffsets, dDeferIdx);
         else if (t.maxDegree <= 5)
-            hipLaunchKernelGGL((query_deep_kernel<5>), grid, block, 0, stream, t, dTables, dXyz, dOut, tilesPerWg, dDeferCount, dDeferIdx);
+            hipLaunchKernelGGL((query_deep_kernel<5>), dgrid, block, 0, stream, t, dTables, dXyz, dOut, tilesPerWg, grid.x, dOffsets, dDeferIdx);
         else
-            hipLaunchKernelGGL((query_deep_kernel<12>), grid, block, 0, stream, t, dTables, dXyz, dOut, tilesPerWg, dDeferCount, dDeferIdx);
+            hipLaunchKernelGGL((query_deep_kernel<12>), dgrid, block, 0, stream, t, dTables, dXyz, dOut, tilesPerWg, grid.x, dOffsets, dDeferIdx);
     }
     return hipGetLastError();
 }
