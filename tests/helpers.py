@@ -142,3 +142,57 @@ def icosphere(level=1, radius=0.35, centre=(0.0, 0.0, 0.0)):
         f = nf
     verts = (np.array(v) * radius + np.array(centre)).astype(np.float32)
     return verts, np.array(f, np.uint64)
+
+
+def deep_chain_block(rng, max_depth=10, degrees=(2, 3, 1, 0, 4, 3, 2, 5)):
+    """A MemoryBlock whose octant 7 is split again and again down to `max_depth` (TREE_MAX_DEPTH = 10): at every level
+    seven leaves (degrees cycling through `degrees`) and one interior child; the last level holds eight leaves."""
+    nodes, coeffs = [], []
+    leaf = np.uint64(0xFFFFFFFFFFFFFFFF)
+    cur = [0]
+
+    def node(child, bmin, bmax, start, degree, dep):
+        b = np.zeros(56, np.uint8)
+        b[0:8] = np.array([child], np.uint64).view(np.uint8)
+        b[8:32] = np.array(list(bmin) + list(bmax), np.float32).view(np.uint8)
+        b[32:40] = np.array([start], np.uint64).view(np.uint8)
+        b[40] = degree
+        b[48] = dep
+        return b
+
+    def corner(bmin, bmax, i):
+        lo, hi = list(bmin), list(bmax)
+        for d in range(3):
+            mid = (np.float32(bmax[d]) + np.float32(bmin[d])) * np.float32(0.5)
+            if (i >> d) & 1:
+                lo[d] = mid
+            else:
+                hi[d] = mid
+        return lo, hi
+
+    box = ([-0.5] * 3, [0.5] * 3)
+    nodes.append(node(1, box[0], box[1], 0, 13, 0))
+    k = 0
+    for dep in range(1, max_depth + 1):
+        first = len(nodes)
+        nxt = None
+        for i in range(8):
+            lo, hi = corner(box[0], box[1], i)
+            if i == 7 and dep < max_depth:
+                nodes.append(node(first + 8, lo, hi, 0, 13, dep))
+                nxt = (lo, hi)
+            else:
+                deg = degrees[k % len(degrees)]
+                k += 1
+                c = rng.standard_normal(NCOEF[deg])
+                nodes.append(node(leaf, lo, hi, cur[0], deg, dep))
+                coeffs.append(c)
+                cur[0] += len(c)
+        box = nxt
+    coeffs = np.concatenate(coeffs)
+    cfg = np.zeros(80, np.uint8)
+    cfg[40:48] = np.array([1e-10], np.float64).view(np.uint8)
+    cfg[48:56] = np.array([1], np.uint64).view(np.uint8)
+    cfg[56:80] = np.array([-0.5] * 3 + [0.5] * 3, np.float32).view(np.uint8)
+    return (np.array([len(coeffs)], np.uint64).tobytes() + coeffs.tobytes() + np.array([len(nodes)], np.uint64).tobytes()
+            + np.concatenate(nodes).tobytes() + cfg.tobytes())

@@ -27,7 +27,7 @@ dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 f = oracle_field(O, case["field"])
 ocfg = O.default_config(case["target"], case["root_min"], case["root_max"])
-cfg = H.make_config(case["target"], case["root_min"], case["root_max"])
+cfg = H.make_config(case["target"], case["root_min"], case["root_max"], continuity=bool(case.get("continuity")))
 def compute(b, jobs, first, count):
     hdr = np.zeros((count, 9))
     for j in range(first, first + count):
@@ -44,9 +44,10 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("case", ["C1_sphere_1e-4", "A2_sphere_1e-8_K1024"])
+@pytest.mark.parametrize("case", ["C1_sphere_1e-4", "A2_sphere_1e-8_K1024", "C1_sphere_1e-4+continuity"])
 def test_world2_gloo_block_identical(golden, case, O, H):
-    g = golden["blocks"][case]
+    continuity = case.endswith("+continuity")
+    g = dict(golden["blocks"][case.split("+")[0]], continuity=continuity)
     with tempfile.TemporaryDirectory() as td:
         wpath = os.path.join(td, "worker.py")
         open(wpath, "w").write(WORKER)
@@ -57,7 +58,14 @@ def test_world2_gloo_block_identical(golden, case, O, H):
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
         res = [json.load(open(out + ".%d" % k)) for k in range(2)]
+    want = g["block_sha256"]
+    if continuity:  # the host-side post-process of the same block, run in this process: every rank must reproduce it
+        from helpers import oracle_field
+        ocfg = O.default_config(g["target"], g["root_min"], g["root_max"], continuity=True)
+        raw = O.Tree.create(ocfg, oracle_field(O, g["field"]), g["K"]).to_block()
+        want = hashlib.sha256(H.continuity_post_process(raw)[0]).hexdigest()
+        assert want != g["block_sha256"]
     for k in range(2):
-        assert res[k]["sha"] == g["block_sha256"]
+        assert res[k]["sha"] == want
         assert res[k]["stats"]["n_nodes"] == g["n_nodes"] and res[k]["stats"]["jobs"] == g["stats"]["jobs"]
     assert res[0]["shard"] == [0, 500] and res[1]["shard"] == [500, 1000]

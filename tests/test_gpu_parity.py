@@ -494,3 +494,46 @@ def test_query_refined_trees_many_points_bitwise(H, O, ctx, golden, case):
     gv, gg = tree.query_with_gradient(pts[:700_001])
     wv, wg = ot.query_with_gradient(pts[:700_001])
     assert np.array_equal(bits(gv), bits(wv)) and np.array_equal(bits(gg), bits(wg))
+
+
+def test_query_down_to_max_depth_bitwise(H, O, ctx):
+    """TREE_MAX_DEPTH = 10 (Consts.h:8): a chain of splits towards the (+,+,+) corner, leaves of degree 0-5 at every
+    depth 1..10 -- the walk below the (here 1-level) top table, cooperative and deferred leaves side by side."""
+    from helpers import deep_chain_block
+    rng = np.random.default_rng(10)
+    blk = deep_chain_block(rng)
+    tree, ot = H.DeviceTree(ctx, blk), O.Tree.from_block(blk)
+    assert tree.info()["max_depth"] == 10 and tree.info()["max_degree"] == 5
+    pts = rng.uniform(-0.5, 0.5, (300000, 3))
+    pts[:200000] = 0.5 - rng.uniform(0, 1, (200000, 3)) * 2.0 ** -rng.integers(0, 11, (200000, 1))  # crowd the deep corner
+    pts[:64] = 0.5                                                                                  # the corner itself
+    got, want = tree.query(pts), ot.query(pts)
+    assert np.array_equal(bits(got), bits(want))
+    gv, gg = tree.query_with_gradient(pts[:100000])
+    wv, wg = ot.query_with_gradient(pts[:100000])
+    assert np.array_equal(bits(gv), bits(wv)) and np.array_equal(bits(gg), bits(wg))
+    o = rng.uniform(-0.5, 0.5, (4000, 3))
+    d = rng.standard_normal((4000, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    h1, t1 = tree.query_ray(o, d, 1.0)
+    h2, t2 = ot.query_ray(o, d, 1.0)
+    assert np.array_equal(h1, h2) and np.array_equal(bits(t1), bits(t2))
+
+
+def test_capi_argument_checks_query_side(H, ctx):
+    import ctypes as C
+    L = H.lib()
+    blk, _ = H.create_block(ctx, H.make_config(1e-4), H.Field.sphere(), 0)
+    tree = H.DeviceTree(ctx, blk)
+    assert L.hpsdf_query_ray_host(None, tree.handle, None, None, None, 0, None, None) == H.ERR_NO_DEVICE
+    assert L.hpsdf_query_ray_host(ctx.handle, tree.handle, None, None, None, 3, None, None) == 1
+    assert L.hpsdf_query_ray_host(ctx.handle, tree.handle, None, None, None, 0, None, None) == 0  # empty batch
+    assert L.hpsdf_query_gradient_host(ctx.handle, tree.handle, None, 0, None, None) == 0
+    f3 = (C.c_float * 3)(0, 0, 0)
+    assert L.hpsdf_function_slice(ctx.handle, tree.handle, 0.0, f3, f3, 0, None, None) == 1
+    buf = (C.c_uint8 * 12)()
+    assert L.hpsdf_function_slice(ctx.handle, tree.handle, 0.0, f3, f3, 0, buf, None) == 1       # n_samples = 0
+    hit, t = tree.query_ray(np.zeros((0, 3)), np.zeros((0, 3)), 1.0)
+    assert hit.shape == (0,) and t.shape == (0,)
+    rgb, vals = tree.function_slice(0.0, (-0.5,) * 3, (0.5,) * 3, 1)
+    assert rgb.shape == (1, 1, 3) and vals.shape == (1, 1)
