@@ -54,6 +54,13 @@ def create_distributed(ctx, config, field, K=0, group=None, compute=None):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     on_gpu = compute is None
+    pod = config.to_pod() if hasattr(config, "to_pod") else config
+    if world > 1 and pod.weighting_type != 0 and on_gpu:
+        # Nearness-weighted fits keep one full coefficient array per node and an incremental fit reads the node's
+        # previous rows, which live in the arena of whichever rank fitted them: such builds are not sharded.
+        # Every rank builds the whole tree (deterministic, so the blocks are identical): replicas, no exchange.
+        from . import create_block
+        return create_block(ctx, config, field, K)
     dev = torch.device("cuda", ctx.device) if on_gpu else torch.device("cpu")
     b = Build(config, K, rank, world)
     while True:
