@@ -637,11 +637,10 @@ __device__ __forceinline__ uint32_t leafChunks(uint32_t degree) { return ((uint3
 // GRAD: QueryWithGradient (Octree.cpp:749-789) -- the same walk and fetch, value and "gradient" evaluated together;
 // rows of grad for points outside the root are left untouched, as the reference leaves its output argument.
 template <int TOPD, bool DEFER, bool GRAD>
-__global__ __launch_bounds__(256) void query_general_kernel(TreeDev t, const DeviceTables* __restrict__ T,
-                                                            const double* __restrict__ xyz, size_t n,
-                                                            double* __restrict__ out, double* __restrict__ grad,
-                                                            uint32_t tilesPerWg, uint32_t* __restrict__ deferCount,
-                                                            uint32_t* __restrict__ deferIdx) {
+__device__ __forceinline__ void queryGeneralBody(const TreeDev& t, const DeviceTables* __restrict__ T,
+                                                 const double* __restrict__ xyz, size_t n, double* __restrict__ out,
+                                                 double* __restrict__ grad, uint32_t tilesPerWg,
+                                                 uint32_t* __restrict__ deferCount, uint32_t* __restrict__ deferIdx) {
     __shared__ double2 sRows[4][5][66];
     __shared__ uint32_t sInfo[4][64];
     __shared__ double sNl[13 * 11];
@@ -682,24 +681,21 @@ __global__ __launch_bounds__(256) void query_general_kernel(TreeDev t, const Dev
         }
         const uint32_t degree = rec.b;
         const bool coop = inside && degree <= 3u;
+        // :862 / :907  unitPt = (pt - centre) * (2 << depth) -- formed now, so that the point and the centre need no
+        // registers across the fetch
+        const double sc = (double)(2 << depth);
+        const double u[3] = {(p3[0] - c3[0]) * sc, (p3[1] - c3[1]) * sc, (p3[2] - c3[2]) * sc};
         // what the fetching lanes need to know about this lane's leaf: block offset (a multiple of 16 doubles, so its
         // low four bits are free) and chunk count (0 = nothing to fetch)
         sInfo[wave][lane] = rec.a | (coop ? leafChunks(degree) : 0u);
         __builtin_amdgcn_wave_barrier();
-        uint32_t info[8];
-        {
-            const uint4 i0 = *reinterpret_cast<const uint4*>(&sInfo[wave][grp]);
-            const uint4 i1 = *reinterpret_cast<const uint4*>(&sInfo[wave][grp + 4]);
-            info[0] = i0.x, info[1] = i0.y, info[2] = i0.z, info[3] = i0.w;
-            info[4] = i1.x, info[5] = i1.y, info[6] = i1.z, info[7] = i1.w;
-        }
         const bool second = __any(coop && degree == 3u);  // wave-uniform: somebody needs chunks 8..9
         double cv[20];
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {  // chunks 0..7 of the leaf of point (group, 4 pass + k)
-                const uint32_t inf = info[pass * 4 + k];
+                const uint32_t inf = sInfo[wave][grp + pass * 4 + k];
                 const char* src = reinterpret_cast<const char*>(t.coeffs) + (size_t)(inf & ~15u) * 8u + (uint32_t)sub * 16u;
                 if ((uint32_t)sub < (inf & 15u))
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -737,8 +733,6 @@ __global__ __launch_bounds__(256) void query_general_kernel(TreeDev t, const Dev
         double g[3] = {0.0, 0.0, 0.0};
         bool defer = false;
         if (inside) {
-            const double s = (double)(2 << depth);  // :862 / :907
-            const double u[3] = {(p3[0] - c3[0]) * s, (p3[1] - c3[1]) * s, (p3[2] - c3[2]) * s};
             if constexpr (GRAD) {
                 switch (degree) {
                     case 0: r = evalLeafGradVals<0>(cv, u, depth, sNl, sRec, g); break;
@@ -778,6 +772,25 @@ __global__ __launch_bounds__(256) void query_general_kernel(TreeDev t, const Dev
         __syncthreads();
         if (threadIdx.x == 0) deferCount[blockIdx.x] = sDeferred;
     }
+}
+
+// Values only: ~104 VGPRs, 4 waves per SIMD (forcing 5 spills: measured 223 -> 338 us on union3@1e-7); with the
+// gradient ~140 VGPRs, 3 waves.
+template <int TOPD, bool DEFER>
+__global__ __launch_bounds__(256) void query_general_kernel(TreeDev t, const DeviceTables* __restrict__ T,
+                                                               const double* __restrict__ xyz, size_t n,
+                                                               double* __restrict__ out, uint32_t tilesPerWg,
+                                                               uint32_t* __restrict__ deferCount,
+                                                               uint32_t* __restrict__ deferIdx) {
+    queryGeneralBody<TOPD, DEFER, false>(t, T, xyz, n, out, nullptr, tilesPerWg, deferCount, deferIdx);
+}
+template <int TOPD, bool DEFER>
+__global__ __launch_bounds__(256, 3) void query_general_grad_kernel(TreeDev t, const DeviceTables* __restrict__ T,
+                                                                    const double* __restrict__ xyz, size_t n,
+                                                                    double* __restrict__ out, double* __restrict__ grad,
+                                                                    uint32_t tilesPerWg, uint32_t* __restrict__ deferCount,
+                                                                    uint32_t* __restrict__ deferIdx) {
+    queryGeneralBody<TOPD, DEFER, true>(t, T, xyz, n, out, grad, tilesPerWg, deferCount, deferIdx);
 }
 
 // Exclusive scan of the per-workgroup deferred counts (nWg <= 8192): offsets[b] = points deferred by workgroups
@@ -1456,22 +1469,21 @@ hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables*
     const size_t nTiles = (n + 255) / 256;
     const uint32_t tilesPerWg = (uint32_t)((nTiles + grid.x - 1) / grid.x);  // tiles b, b + G, ... of workgroup b
     const bool defer = t.maxDegree > 3;
-#define HPSDF_QUERY_GENERAL(TOPD, DF, GR)                                                                            \
-    hipLaunchKernelGGL((query_general_kernel<TOPD, DF, GR>), grid, block, 0, stream, t, dTables, dXyz, n, dOut, dGrad, \
-                       tilesPerWg, dDeferCount, dDeferIdx)
-#define HPSDF_QUERY_GENERAL_T(TOPD)          \
-    do {                                     \
-        if (dGrad) {                         \
-            if (defer)                       \
-                HPSDF_QUERY_GENERAL(TOPD, true, true);   \
-            else                             \
-                HPSDF_QUERY_GENERAL(TOPD, false, true);  \
-        } else {                             \
-            if (defer)                       \
-                HPSDF_QUERY_GENERAL(TOPD, true, false);  \
-            else                             \
-                HPSDF_QUERY_GENERAL(TOPD, false, false); \
-        }                                    \
+#define HPSDF_QUERY_GENERAL(TOPD, DF)                                                                               \
+    do {                                                                                                            \
+        if (dGrad)                                                                                                  \
+            hipLaunchKernelGGL((query_general_grad_kernel<TOPD, DF>), grid, block, 0, stream, t, dTables, dXyz, n, dOut, \
+                               dGrad, tilesPerWg, dDeferCount, dDeferIdx);                                          \
+        else                                                                                                        \
+            hipLaunchKernelGGL((query_general_kernel<TOPD, DF>), grid, block, 0, stream, t, dTables, dXyz, n, dOut,  \
+                               tilesPerWg, dDeferCount, dDeferIdx);                                                 \
+    } while (0)
+#define HPSDF_QUERY_GENERAL_T(TOPD)         \
+    do {                                    \
+        if (defer)                          \
+            HPSDF_QUERY_GENERAL(TOPD, true);  \
+        else                                \
+            HPSDF_QUERY_GENERAL(TOPD, false); \
     } while (0)
     if (t.topDepth == 4)
         HPSDF_QUERY_GENERAL_T(4);
