@@ -629,7 +629,8 @@ __device__ __forceinline__ uint32_t leafChunks(uint32_t degree) { return ((uint3
 // (every leaf block starts on a 128-byte line there): in step k the 8 lanes of a group fetch chunks 0..7 of the
 // leaf of the group's k-th point -- a whole degree-2 leaf, the first line of a degree-3 one -- and one extra step
 // per pass brings chunks 8..9 of four degree-3 leaves at a time (two lanes each).  Two passes of 4 + 1 steps
-// through a 5 KB per-wave window, i.e. two L2 round trips per tile whatever the mix of degrees <= 3.
+// through a 5 KB per-wave window, i.e. two L2 round trips per tile whatever the mix of degrees <= 3 (one pass of
+// 8 + 2 steps through a 10 KB window measured 3 % slower: fewer workgroups per CU).
 // Leaves of degree > 3 are rare at the thresholds in use (a few dozen among thousands): DEFER appends their points to
 // the workgroup's own run of deferIdx (an LDS counter, no global atomic -- one global atomic per wave serialised
 // the first version of this at 2 ms per 10 M points) and query_deep_kernel finishes them lane by lane; keeping
