@@ -79,6 +79,87 @@ int makeFieldDev(const hpsdf_field* f, const double* dSamples, FieldDev* out) {
 
 }  // namespace hpsdf
 
+// ---- host-array entry points: cached device + pinned scratch ---------------------------------------------
+namespace {
+constexpr size_t kPinnedPathBytes = 1u << 20;  // below this, user memory is staged through the pinned buffer
+inline size_t alignUp(size_t b) { return (b + 255) & ~(size_t)255; }
+
+int ensureHostScratch(hpsdf_ctx* ctx, size_t devBytes, size_t pinBytes) {
+    if (ctx->hostDevCap < devBytes) {
+        if (ctx->hostDev) HPSDF_HIP(hipFree(ctx->hostDev));
+        ctx->hostDev = nullptr;
+        ctx->hostDevCap = 0;
+        size_t cap = 1u << 16;
+        while (cap < devBytes) cap *= 2;
+        HPSDF_HIP(hipMalloc((void**)&ctx->hostDev, cap));
+        ctx->hostDevCap = cap;
+    }
+    if (ctx->hostPinCap < pinBytes) {
+        if (ctx->hostPin) HPSDF_HIP(hipHostFree(ctx->hostPin));
+        ctx->hostPin = nullptr;
+        ctx->hostPinCap = 0;
+        size_t cap = 1u << 16;
+        while (cap < pinBytes) cap *= 2;
+        HPSDF_HIP(hipHostMalloc((void**)&ctx->hostPin, cap, hipHostMallocDefault));
+        ctx->hostPinCap = cap;
+    }
+    return HPSDF_OK;
+}
+
+// One host call: `ins` are copied to the device, `run` launches on the context stream, `outs` come back.
+// inout arrays are both (rows the kernel leaves untouched keep the caller's values).
+struct HostArray {
+    const void* src;  // host source (nullptr: output only)
+    void* dst;        // host destination (nullptr: input only)
+    size_t bytes;
+    char* dev = nullptr;
+};
+template <typename Run>
+int hostCall(hpsdf_ctx* ctx, HostArray* arrays, int nArrays, Run&& run) {
+    std::lock_guard<std::mutex> guard(ctx->hostLock);
+    HPSDF_HIP(hipSetDevice(ctx->device));
+    size_t total = 0;
+    for (int a = 0; a < nArrays; ++a) total += alignUp(arrays[a].bytes);
+    const bool staged = total <= kPinnedPathBytes;
+    int rc = ensureHostScratch(ctx, total, staged ? total : 0);
+    if (rc) return rc;
+    size_t off = 0;
+    for (int a = 0; a < nArrays; ++a) {
+        arrays[a].dev = ctx->hostDev + off;
+        if (arrays[a].src) {
+            const void* from = arrays[a].src;
+            if (staged) {
+                std::memcpy(ctx->hostPin + off, arrays[a].src, arrays[a].bytes);
+                from = ctx->hostPin + off;
+            }
+            HPSDF_HIP(hipMemcpyAsync(arrays[a].dev, from, arrays[a].bytes, hipMemcpyHostToDevice, ctx->stream));
+        }
+        off += alignUp(arrays[a].bytes);
+    }
+    rc = run();
+    if (rc) {
+        (void)hipStreamSynchronize(ctx->stream);
+        return rc;
+    }
+    off = 0;
+    for (int a = 0; a < nArrays; ++a) {
+        if (arrays[a].dst)
+            HPSDF_HIP(hipMemcpyAsync(staged ? (void*)(ctx->hostPin + off) : arrays[a].dst, arrays[a].dev, arrays[a].bytes,
+                                     hipMemcpyDeviceToHost, ctx->stream));
+        off += alignUp(arrays[a].bytes);
+    }
+    HPSDF_HIP(hipStreamSynchronize(ctx->stream));
+    if (staged) {
+        off = 0;
+        for (int a = 0; a < nArrays; ++a) {
+            if (arrays[a].dst) std::memcpy(arrays[a].dst, ctx->hostPin + off, arrays[a].bytes);
+            off += alignUp(arrays[a].bytes);
+        }
+    }
+    return HPSDF_OK;
+}
+}  // namespace
+
 #define HPSDF_TRY                                                            \
     try {
 #define HPSDF_CATCH                                                          \
@@ -180,6 +261,8 @@ int hpsdf_ctx_destroy(hpsdf_ctx* c) {
     if (!c) return HPSDF_OK;
     (void)hipSetDevice(c->device);
     if (c->dTables) (void)hipFree(c->dTables);
+    if (c->hostDev) (void)hipFree(c->hostDev);
+    if (c->hostPin) (void)hipHostFree(c->hostPin);
     if (c->dDefer) (void)hipFree(c->dDefer);
     if (c->dDeferCount) (void)hipFree(c->dDeferCount);
     c->ws.release();
@@ -339,26 +422,8 @@ int hpsdf_field_eval_device(hpsdf_ctx* ctx, const hpsdf_field* f, const double* 
 static int hostRoundTrip(hpsdf_ctx* ctx, const double* xyz, size_t n, double* out,
                          int (*run)(hpsdf_ctx*, const void*, const double*, size_t, double*), const void* obj) {
     if (n == 0) return HPSDF_OK;
-    HPSDF_HIP(hipSetDevice(ctx->device));
-    double *dIn = nullptr, *dOut = nullptr;
-    HPSDF_HIP(hipMalloc((void**)&dIn, n * 3 * sizeof(double)));
-    hipError_t e = hipMalloc((void**)&dOut, n * sizeof(double));
-    if (e != hipSuccess) {
-        (void)hipFree(dIn);
-        return hipFail(e, "hipMalloc");
-    }
-    int rc = HPSDF_OK;
-    e = hipMemcpyAsync(dIn, xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) {
-        rc = run(ctx, obj, dIn, n, dOut);
-        if (rc == HPSDF_OK) e = hipMemcpyAsync(out, dOut, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(dIn);
-    (void)hipFree(dOut);
-    if (rc) return rc;
-    if (e != hipSuccess) return hipFail(e, "host round trip");
-    return HPSDF_OK;
+    HostArray arr[2] = {{xyz, nullptr, n * 3 * sizeof(double)}, {nullptr, out, n * sizeof(double)}};
+    return hostCall(ctx, arr, 2, [&] { return run(ctx, obj, (const double*)arr[0].dev, n, (double*)arr[1].dev); });
 }
 
 int hpsdf_field_eval_host(hpsdf_ctx* ctx, const hpsdf_field* f, const double* xyz, size_t n, double* out) {
@@ -583,24 +648,11 @@ int hpsdf_query_gradient_host(hpsdf_ctx* ctx, const hpsdf_tree* t, const double*
     if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "a device context is required");
     if (!t || (n && (!xyz || !out || !grad))) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
     if (n == 0) return HPSDF_OK;
-    HPSDF_HIP(hipSetDevice(ctx->device));
-    double *dIn = nullptr, *dOut = nullptr, *dGrad = nullptr;
-    hipError_t e = hipMalloc((void**)&dIn, n * 3 * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&dOut, n * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&dGrad, n * 3 * sizeof(double));
-    int rc = HPSDF_OK;
-    if (e == hipSuccess) e = hipMemcpyAsync(dIn, xyz, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
     // rows of points outside the root keep what the caller passed in (the reference leaves its output untouched)
-    if (e == hipSuccess) e = hipMemcpyAsync(dGrad, grad, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) rc = hpsdf_query_gradient_device(ctx, t, dIn, n, dOut, dGrad);
-    if (e == hipSuccess && rc == HPSDF_OK) e = hipMemcpyAsync(out, dOut, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess && rc == HPSDF_OK) e = hipMemcpyAsync(grad, dGrad, n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(dIn);
-    (void)hipFree(dOut);
-    (void)hipFree(dGrad);
-    if (rc) return rc;
-    if (e != hipSuccess) return hipFail(e, "query_gradient_host");
+    HostArray arr[3] = {{xyz, nullptr, n * 3 * sizeof(double)}, {nullptr, out, n * sizeof(double)}, {grad, grad, n * 3 * sizeof(double)}};
+    return hostCall(ctx, arr, 3, [&] {
+        return hpsdf_query_gradient_device(ctx, t, (const double*)arr[0].dev, n, (double*)arr[1].dev, (double*)arr[2].dev);
+    });
     return HPSDF_OK;
     HPSDF_CATCH
 }
@@ -639,29 +691,14 @@ int hpsdf_query_ray_host(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* orig
     if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "a device context is required");
     if (!t || (n && (!origins || !dirs || !tMax || !hit || !tOut))) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
     if (n == 0) return HPSDF_OK;
-    HPSDF_HIP(hipSetDevice(ctx->device));
-    DevBufs bufs;
-    double *dO = nullptr, *dD = nullptr, *dM = nullptr, *dT = nullptr;
-    uint8_t* dH = nullptr;
-    HPSDF_HIP(bufs.alloc((void**)&dO, n * 3 * sizeof(double)));
-    HPSDF_HIP(bufs.alloc((void**)&dD, n * 3 * sizeof(double)));
-    HPSDF_HIP(bufs.alloc((void**)&dM, n * sizeof(double)));
-    HPSDF_HIP(bufs.alloc((void**)&dT, n * sizeof(double)));
-    HPSDF_HIP(bufs.alloc((void**)&dH, n));
-    HPSDF_HIP(hipMemcpyAsync(dO, origins, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HPSDF_HIP(hipMemcpyAsync(dD, dirs, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HPSDF_HIP(hipMemcpyAsync(dM, tMax, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     // t of a miss keeps the caller's value (the reference leaves t_ untouched)
-    HPSDF_HIP(hipMemcpyAsync(dT, tOut, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    int rc = hpsdf_query_ray_device(ctx, t, dO, dD, dM, n, dH, dT);
-    if (rc) {
-        (void)hipStreamSynchronize(ctx->stream);
-        return rc;
-    }
-    HPSDF_HIP(hipMemcpyAsync(hit, dH, n, hipMemcpyDeviceToHost, ctx->stream));
-    HPSDF_HIP(hipMemcpyAsync(tOut, dT, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HPSDF_HIP(hipStreamSynchronize(ctx->stream));
-    return HPSDF_OK;
+    HostArray arr[5] = {{origins, nullptr, n * 3 * sizeof(double)}, {dirs, nullptr, n * 3 * sizeof(double)},
+                        {tMax, nullptr, n * sizeof(double)},        {tOut, tOut, n * sizeof(double)},
+                        {nullptr, hit, n}};
+    return hostCall(ctx, arr, 5, [&] {
+        return hpsdf_query_ray_device(ctx, t, (const double*)arr[0].dev, (const double*)arr[1].dev, (const double*)arr[2].dev, n,
+                                      (uint8_t*)arr[4].dev, (double*)arr[3].dev);
+    });
     HPSDF_CATCH
 }
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstdint>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -70,6 +71,15 @@ struct hpsdf_ctx {
     bool ownsStream = false;
     hpsdf::DeviceTables* dTables = nullptr;
     hpsdf::Workspace ws;
+    // Scratch of the *_host entry points (host arrays in, host arrays out): one device buffer and one pinned buffer,
+    // kept across calls -- a scalar Query(pt) through the C++ drop-in must not pay two hipMalloc/hipFree pairs.
+    // hostLock serialises those entry points per context (Octree::Query* is const and callable from many threads in
+    // the reference, Octree.h:71-78).
+    char* hostDev = nullptr;
+    size_t hostDevCap = 0;
+    char* hostPin = nullptr;
+    size_t hostPinCap = 0;
+    std::mutex hostLock;
     // Query scratch for trees with leaves of degree > 3: per-workgroup lists of the points finished lane by lane
     uint32_t* dDefer = nullptr;
     uint64_t deferCap = 0;
