@@ -550,7 +550,7 @@ __device__ __forceinline__ void topCell(const double (&p3)[3], int topDepth, int
 // (global_load_lds_dwordx4: lane-linear destination, per-lane source), i.e. 8 whole lines per
 // wave-instruction instead of 64 fragments; afterwards every lane reads back its own point's row.
 // Every other tree goes through query_general_kernel below.
-template <int TOPD>
+template <int TOPD, bool DEDUPE>
 __global__ __launch_bounds__(256, 7) void query_kernel(TreeDev t, const double* __restrict__ xyz, size_t n,
                                                     double* __restrict__ out) {
     // per wave: 4 steps x 64 lanes x 16 B (two passes; less LDS = more waves).  Each step's kilobyte is followed by
@@ -577,22 +577,44 @@ __global__ __launch_bounds__(256, 7) void query_kernel(TreeDev t, const double* 
         if (!inside) code = 0;  // any valid line; the result is DBL_MAX
         // lane (group g, sub k) owns the row that step k writes at lanes 8g..8g+7: [record][c0 c1]..[c8 c9].
         // Two passes of four steps through a 4 KB per-wave window (measured: 110 vs 121 us for one 8 KB pass).
+        // Points of a group that fall into the same cell share one fetch: step k runs for a group only if its k-th
+        // point is the first of the group in its cell, and every lane reads the row of the first point of its own cell
+        // (coherent point sets -- grids, slices, rays -- move a fraction of the lines; random points lose nothing but a
+        // few compares: the kernel is bound by the L2 -> CU line traffic).
+        uint32_t ck[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ck[k] = __shfl(code, grp | k, 64);
+        int firstOfMine = sub;  // first point of the group in this lane's cell
+        uint32_t needMask = 0xFFu;  // bit k: point k is the first of its cell in the group
+        // wave-uniform gate: on random points (almost) no wave has two neighbouring lanes in one cell and the
+        // bookkeeping below is skipped; on ordered point sets (almost) every wave has
+        if (DEDUPE && __any(__shfl_xor(code, 1, 64) == code)) {
+#pragma unroll
+            for (int k = 7; k >= 0; --k) firstOfMine = ck[k] == code ? k : firstOfMine;
+            needMask = 1u;
+#pragma unroll
+            for (int k = 1; k < 8; ++k) {
+                bool seen = false;
+#pragma unroll
+                for (int j = 0; j < k; ++j) seen = seen || (ck[j] == ck[k]);
+                needMask |= seen ? 0u : (1u << k);
+            }
+        }
         uint2 hdr = make_uint2(0u, 0u);
         double cv[10];
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const uint32_t ck = __shfl(code, grp | (pass * 4 + k), 64);
-                const char* src = reinterpret_cast<const char*>(t.top + ck) + sub * 16;
-                if (sub < 6)  // bytes 96..127 of an entry are padding
+                const char* src = reinterpret_cast<const char*>(t.top + ck[pass * 4 + k]) + sub * 16;
+                if (sub < 6 && ((needMask >> (pass * 4 + k)) & 1u))  // bytes 96..127 of an entry are padding
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                      (__attribute__((address_space(3))) void*)&sRows[wave][k][0], 16, 0, 0);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            if ((sub >> 2) == pass) {
-                const double2* row = &sRows[wave][sub & 3][grp];
+            if ((firstOfMine >> 2) == pass) {
+                const double2* row = &sRows[wave][firstOfMine & 3][grp];
                 hdr = *reinterpret_cast<const uint2*>(row);
 #pragma unroll
                 for (int c = 0; c < 5; ++c) {
@@ -1461,10 +1483,19 @@ hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables*
     if (n == 0) return hipSuccess;
     const dim3 grid(gridFor(n)), block(256);
     if (allInline && !dGrad) {
-        if (t.topDepth == 4)
-            hipLaunchKernelGGL((query_kernel<4>), grid, block, 0, stream, t, dXyz, n, dOut);
-        else
-            hipLaunchKernelGGL((query_kernel<0>), grid, block, 0, stream, t, dXyz, n, dOut);
+        const char* e = std::getenv("HPSDF_QUERY_DEDUPE");  // tuning knob; default on
+        const bool dedupe = !(e && e[0] == '0');
+        if (t.topDepth == 4) {
+            if (dedupe)
+                hipLaunchKernelGGL((query_kernel<4, true>), grid, block, 0, stream, t, dXyz, n, dOut);
+            else
+                hipLaunchKernelGGL((query_kernel<4, false>), grid, block, 0, stream, t, dXyz, n, dOut);
+        } else {
+            if (dedupe)
+                hipLaunchKernelGGL((query_kernel<0, true>), grid, block, 0, stream, t, dXyz, n, dOut);
+            else
+                hipLaunchKernelGGL((query_kernel<0, false>), grid, block, 0, stream, t, dXyz, n, dOut);
+        }
         return hipGetLastError();
     }
     const size_t nTiles = (n + 255) / 256;
