@@ -702,6 +702,8 @@ int hpsdf_query_ray_host(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* orig
     HPSDF_CATCH
 }
 
+static int queryDevice(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* dXyz, size_t n, double* dOut, double* dGrad);
+
 // (u8)f64 as the reference's x86-64 build performs it: truncating conversion to a 32-bit integer
 // (out of range and NaN give INT_MIN), then the low byte
 static uint8_t f64ToU8(double q) {
@@ -723,10 +725,15 @@ int hpsdf_function_slice(hpsdf_ctx* ctx, const hpsdf_tree* t, double c, const fl
     HPSDF_HIP(hipSetDevice(ctx->device));
     const size_t total = (size_t)nSamples * nSamples;
     DevBufs bufs;
-    double* dV = nullptr;
+    double *dV = nullptr, *dP = nullptr;
     HPSDF_HIP(bufs.alloc((void**)&dV, total * sizeof(double)));
+    HPSDF_HIP(bufs.alloc((void**)&dP, total * 3 * sizeof(double)));
     const float step = (viewMax[0] - viewMin[0]) / (float)nSamples;  // Octree.cpp:1149
-    HPSDF_HIP(launchSlice(ctx->stream, t->dev, ctx->dTables, c, viewMin[0], viewMin[1], step, (uint32_t)nSamples, dV));
+    HPSDF_HIP(launchSlicePoints(ctx->stream, c, viewMin[0], viewMin[1], step, (uint32_t)nSamples, dP));
+    {
+        const int rc = queryDevice(ctx, t, dP, total, dV, nullptr);
+        if (rc) return rc;
+    }
     std::vector<double> own;
     double* v = values;
     if (!v) {

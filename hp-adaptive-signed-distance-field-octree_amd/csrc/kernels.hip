@@ -798,7 +798,8 @@ __device__ __forceinline__ void queryGeneralBody(const TreeDev& t, const DeviceT
 }
 
 // Values only: ~104 VGPRs, 4 waves per SIMD (forcing 5 spills: measured 223 -> 338 us on union3@1e-7); with the
-// gradient ~140 VGPRs, 3 waves.
+// gradient ~140 VGPRs, 3 waves.  (Sharing one fetch between the points of a group that land in the same leaf, as
+// query_kernel does, measured slower here on grids and sorted points alike: this kernel is latency-, not traffic-bound.)
 template <int TOPD, bool DEFER>
 __global__ __launch_bounds__(256) void query_general_kernel(TreeDev t, const DeviceTables* __restrict__ T,
                                                                const double* __restrict__ xyz, size_t n,
@@ -1028,20 +1029,17 @@ __global__ __launch_bounds__(256) void query_ray_kernel(TreeDev t, const DeviceT
     }
 }
 
-// Sample values of Octree::OutputFunctionSlice (Octree.cpp:1144-1170): pixel (i, j) queries
-// (min.x + (f32)j*step, min.y + (f32)i*step, c), step = (max.x - min.x) / nSamples in f32.
-__global__ __launch_bounds__(256) void slice_kernel(TreeDev t, const DeviceTables* __restrict__ T, double c, float minX,
-                                                    float minY, float step, uint32_t nSamples, double* __restrict__ out) {
-    __shared__ double sNl[13 * 11];
-    __shared__ double sRec[26];
-    stageQueryTables(T, sNl, sRec);
-    __syncthreads();
+// Sample points of Octree::OutputFunctionSlice (Octree.cpp:1144-1170): pixel (i, j) queries
+// (min.x + (f32)j*step, min.y + (f32)i*step, c), step = (max.x - min.x) / nSamples in f32.  The points then go
+// through the batched Query kernels (a row of pixels is a coherent run of points).
+__global__ __launch_bounds__(256) void slice_points_kernel(double c, float minX, float minY, float step, uint32_t nSamples,
+                                                           double* __restrict__ xyz) {
     const size_t total = (size_t)nSamples * nSamples, stride = (size_t)gridDim.x * blockDim.x;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += stride) {
         const uint32_t i = (uint32_t)(p / nSamples), j = (uint32_t)(p - (size_t)i * nSamples);
-        const double x = (double)minX + (double)((float)j * step);
-        const double y = (double)minY + (double)((float)i * step);
-        out[p] = queryPoint<12>(t, x, y, c, sNl, sRec);
+        xyz[3 * p] = (double)minX + (double)((float)j * step);
+        xyz[3 * p + 1] = (double)minY + (double)((float)i * step);
+        xyz[3 * p + 2] = c;
     }
 }
 
@@ -1547,11 +1545,11 @@ hipError_t launchQueryRay(hipStream_t stream, const TreeDev& t, const DeviceTabl
     return hipGetLastError();
 }
 
-hipError_t launchSlice(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, double c, float minX,
-                       float minY, float step, uint32_t nSamples, double* dOut) {
+hipError_t launchSlicePoints(hipStream_t stream, double c, float minX, float minY, float step, uint32_t nSamples,
+                             double* dXyz) {
     if (nSamples == 0) return hipSuccess;
-    hipLaunchKernelGGL(slice_kernel, dim3(gridFor((size_t)nSamples * nSamples)), dim3(256), 0, stream, t, dTables, c,
-                       minX, minY, step, nSamples, dOut);
+    hipLaunchKernelGGL(slice_points_kernel, dim3(gridFor((size_t)nSamples * nSamples)), dim3(256), 0, stream, c, minX, minY,
+                       step, nSamples, dXyz);
     return hipGetLastError();
 }
 

@@ -32,8 +32,8 @@ hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables*
                        double* dOut, double* dGrad, bool allInline, uint32_t* dDeferCount, uint32_t* dDeferIdx);
 hipError_t launchQueryRay(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dOrigins,
                           const double* dDirs, const double* dTMax, size_t n, uint8_t* dHit, double* dT);
-hipError_t launchSlice(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, double c, float minX,
-                       float minY, float step, uint32_t nSamples, double* dOut);
+hipError_t launchSlicePoints(hipStream_t stream, double c, float minX, float minY, float step, uint32_t nSamples,
+                             double* dXyz);
 hipError_t launchFieldEval(hipStream_t stream, const FieldDev& f, const DeviceTables* dTables, const double* dXyz,
                            size_t n, double* dOut);
 hipError_t launchPack(hipStream_t stream, const PackItem* dItems, uint32_t nItems, const double* dArena, double* dOut);

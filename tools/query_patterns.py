@@ -1,4 +1,5 @@
-"""Query on the headline tree for three point orders: random, 200^3 grid (z fastest), cell-sorted."""
+"""Query for three point orders: random, 230^3 grid (z fastest), cell-sorted -- 12 M points each, so that points +
+results (384 MB) do not fit the 256 MB Infinity Cache (8 M-point sets are served from it between launches)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -12,13 +13,13 @@ with torch.cuda.stream(stream):
     for name, target in (("C2 union3 1e-5", 1e-5), ("A1 union3 1e-7", 1e-7)):
         blk, _ = H.create_block(ctx, H.make_config(target), H.Field.union3(), 1024)
         tree = H.DeviceTree(ctx, blk)
-        n = 8_000_000
+        n = 12_000_000
         rnd = torch.from_numpy(O.splitmix64_points(n)).cuda()
-        g = torch.linspace(-0.5, 0.5, 200, dtype=torch.float64, device="cuda")
+        g = torch.linspace(-0.5, 0.5, 230, dtype=torch.float64, device="cuda")
         grid = torch.stack(torch.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3).contiguous()
         cell = ((rnd + 0.5) * 16.0).floor().clamp_(0, 15).to(torch.int64)
         srt = rnd[torch.argsort(cell[:, 0] * 256 + cell[:, 1] * 16 + cell[:, 2])].contiguous()
-        for pname, pts in (("random", rnd), ("200^3 grid", grid), ("cell-sorted", srt)):
+        for pname, pts in (("random", rnd), ("230^3 grid", grid), ("cell-sorted", srt)):
             m = len(pts)
             out = torch.empty(m, dtype=torch.float64, device="cuda")
             torch.cuda.synchronize()
