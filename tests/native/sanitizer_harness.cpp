@@ -1,0 +1,144 @@
+// Sanitizer harness (tests/test_sanitizers.py): the host-side native code of libhpsdf.so -- continuity post-process,
+// OBJ reader, mesh preparation, round scheduler -- built with g++ -fsanitize=address,undefined and run without a GPU.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "builder.hpp"
+#include "continuity.hpp"
+#include "launch.hpp"
+#include "runtime.hpp"
+namespace hpsdf {
+int loadObj(const char* path, std::vector<float>& verts, std::vector<uint64_t>& tris, std::string& err);
+void setError(const std::string&) {}
+int fail(int code, const std::string& msg) {
+    fprintf(stderr, "fail(%d): %s\n", code, msg.c_str());
+    return code;
+}
+int hipFail(hipError_t, const char*) { return HPSDF_ERR_HIP; }
+const hpsdf_field* innermost(const hpsdf_field* f) { return f; }
+int makeFieldDev(const hpsdf_field*, const double*, FieldDev*) { return HPSDF_ERR_UNSUPPORTED; }
+// the GPU legs are not exercised here (no device): link-time stand-ins for the launch wrappers of kernels.hip
+size_t fitLdsBytes(int, int, int) { return 0; }
+FitShape fitShape(int, int, uint32_t, bool, bool) { return FitShape{1, 1, 1, 0}; }
+hipError_t launchFit(hipStream_t, int, int, const FitBlock*, uint32_t, size_t, const FitTask*, double*, double*, double*,
+                     const DeviceTables*, const FieldDev&, const RootMap&) { return hipErrorNoDevice; }
+hipError_t launchPack(hipStream_t, const PackItem*, uint32_t, const double*, double*) { return hipErrorNoDevice; }
+}
+
+// The host round scheduler (builder.cpp) driven through its injection hook: two simulated ranks, synthetic errors that
+// make both P- and H-refinements occur, random coefficients; the two ranks must assemble identical blocks.
+static int schedulerRun() {
+    using namespace hpsdf;
+    const Tables& T = tables();
+    hpsdf_config cfg;
+    std::memset(&cfg, 0, sizeof cfg);
+    cfg.target_error_threshold = 1e-3;
+    cfg.thread_count = 1;
+    for (int a = 0; a < 3; ++a) cfg.root_min[a] = -0.5f, cfg.root_max[a] = 0.5f;
+    std::vector<std::vector<char>> blocks;
+    const int world = 2;
+    hpsdf_build* b[world];
+    for (int r = 0; r < world; ++r) {
+        b[r] = new hpsdf_build();
+        hpsdf_build_opts o{256, r, world, {0, 0}};
+        if (builderBegin(b[r], &cfg, &o)) return 20;
+    }
+    uint64_t rng = 12345;
+    auto next = [&] { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return (double)(rng >> 11) * 0x1p-53; };
+    for (int round = 0; round < 12; ++round) {
+        uint64_t n0 = 0, n1 = 0;
+        if (builderSelect(b[0], &n0) || builderSelect(b[1], &n1) || n0 != n1) return 21;
+        if (n0 == 0) break;
+        std::vector<hpsdf_job> jobs(n0);
+        builderJobs(b[0], jobs.data());
+        std::vector<double> headers(n0 * HPSDF_JOB_HEADER_DOUBLES);
+        std::vector<double> pc(kMaxCoeffs), hc(8 * kMaxCoeffs);
+        for (auto& v : pc) v = next();
+        for (auto& v : hc) v = next();
+        for (uint64_t j = 0; j < n0; ++j) {
+            const double e = jobs[j].coarse ? 1.0 : jobs[j].err;
+            const double mode = next();  // < 0.5: P wins, < 0.9: H wins, else neither improves
+            headers[9 * j] = mode < 0.5 ? e * 0.013 : e * 7.3;  // never exactly 100: that value marks a coarse job (Octree.cpp:806)
+            for (int c = 0; c < 8; ++c) headers[9 * j + 1 + c] = mode >= 0.5 && mode < 0.9 ? e * 0.0017 : e * 7.3;
+            for (int r = 0; r < world; ++r) {
+                const hpsdf_build::Slice sl = b[r]->slices[r];
+                if (j >= sl.first && j < sl.first + sl.count && builderInject(b[r], j, pc.data(), hc.data())) return 22;
+            }
+        }
+        if (builderApply(b[0], headers.data()) || builderApply(b[1], headers.data())) return 23;
+    }
+    for (int r = 0; r < world; ++r)
+        if (builderLayout(b[r])) {
+            for (size_t n = 0; n < b[r]->nodes.size(); ++n) {
+                if (b[r]->nodes[n].child_idx != ~0ull) continue;
+                uint32_t row = 0;
+                bool bad = false;
+                for (int64_t sg = b[r]->segHead[n]; sg >= 0; sg = b[r]->segs[sg].next) {
+                    if (b[r]->segs[sg].rowStart != row) bad = true;
+                    row = b[r]->segs[sg].rowEnd;
+                }
+                if (bad) {
+                    fprintf(stderr, "rank %d node %zu degree %d depth %d segs:", r, n, b[r]->nodes[n].degree, b[r]->nodes[n].depth);
+                    for (int64_t sg = b[r]->segHead[n]; sg >= 0; sg = b[r]->segs[sg].next)
+                        fprintf(stderr, " [%u,%u) owner %d", b[r]->segs[sg].rowStart, b[r]->segs[sg].rowEnd, b[r]->segs[sg].owner);
+                    fprintf(stderr, "\n");
+                    break;
+                }
+            }
+            return 24;
+        }
+    std::vector<std::vector<double>> packs(world);
+    for (int r = 0; r < world; ++r) {
+        packs[r].resize(std::max<uint64_t>(1, b[r]->packCounts[r]));
+        if (builderPackHost(b[r], nullptr, packs[r].data())) return 25;
+    }
+    const double* pp[world] = {packs[0].data(), packs[1].data()};
+    for (int r = 0; r < world; ++r) {
+        void* blk = nullptr;
+        size_t size = 0;
+        if (builderAssemble(b[r], pp, &blk, &size)) return 26;
+        blocks.emplace_back((char*)blk, (char*)blk + size);
+        std::free(blk);
+    }
+    printf("scheduler: %llu nodes, %llu coefficients, p %llu h %llu dropped %llu\n", (unsigned long long)b[0]->stats.n_nodes,
+           (unsigned long long)b[0]->nCoeffsTotal, (unsigned long long)b[0]->stats.p_refines,
+           (unsigned long long)b[0]->stats.h_refines, (unsigned long long)b[0]->stats.dropped);
+    const bool exercised = b[0]->stats.p_refines > 1000 && b[0]->stats.h_refines > 100;
+    for (int r = 0; r < world; ++r) delete b[r];
+    (void)T;
+    if (blocks[0] != blocks[1]) return 27;
+    return exercised ? 0 : 28;
+}
+int main(int argc, char** argv) {
+    FILE* f = fopen(argv[1], "rb");
+    fseek(f, 0, SEEK_END); long sz = ftell(f); fseek(f, 0, SEEK_SET);
+    std::vector<char> blk(sz); if (fread(blk.data(), 1, sz, f) != (size_t)sz) return 2; fclose(f);
+    std::string err;
+    for (int thr : {1, 3, 8}) {
+        std::vector<char> b = blk;
+        hpsdf_continuity_stats st;
+        int rc = hpsdf::continuityPostProcess(b.data(), b.size(), 0.0, 0, thr, &st, err);
+        printf("continuity threads %d rc %d its %llu\n", thr, rc, (unsigned long long)st.iterations);
+        if (rc) return 3;
+    }
+    { std::vector<char> b(blk.begin(), blk.end() - 8); hpsdf_continuity_stats st; if (!hpsdf::continuityPostProcess(b.data(), b.size(), 0, 0, 1, &st, err)) return 4; }
+    std::vector<float> v; std::vector<uint64_t> t;
+    int rc = hpsdf::loadObj(argv[2], v, t, err);
+    printf("obj rc %d verts %zu tris %zu\n", rc, v.size() / 3, t.size() / 3);
+    if (rc) return 5;
+    hpsdf::HostMesh hm;
+    bool ok = hpsdf::prepareMesh(v.data(), v.size() / 3, t.data(), t.size() / 3, &hm);
+    printf("prepareMesh closed=%d bvh nodes %zu\n", (int)ok, hm.bvh.size());
+    if (!ok) return 6;
+    t.resize(t.size() - 3);
+    if (hpsdf::prepareMesh(v.data(), v.size() / 3, t.data(), t.size() / 3, &hm)) return 7;  // open mesh must be rejected
+    for (const char* bad : {"v 1 2\nf 1 2 3\n", "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 9\n", "v 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\nf 1 2 3 4\n", ""}) {
+        FILE* g = fopen(argv[3], "wb"); fputs(bad, g); fclose(g);
+        if (hpsdf::loadObj(argv[3], v, t, err) == 0) { printf("malformed OBJ accepted\n"); return 8; }
+    }
+    if (int rc = schedulerRun()) { printf("scheduler rc %d\n", rc); return rc; }
+    printf("OK\n");
+    return 0;
+}

@@ -1,0 +1,39 @@
+"""The host-side native code of libhpsdf.so under AddressSanitizer + UndefinedBehaviorSanitizer (CPU build only: GPU
+sanitizers are not available on the pool).  tests/native/sanitizer_harness.cpp drives the continuity post-process
+(1/3/8 threads, truncated block), the OBJ reader (good and malformed files), the mesh preparation (closed and open
+mesh) and the round scheduler (two simulated ranks through the injection hook) in one binary built with g++."""
+import os
+import subprocess
+
+import numpy as np
+
+from conftest import ROOT
+from helpers import icosphere, oracle_field
+
+CSRC = os.path.join(ROOT, "hp-adaptive-signed-distance-field-octree_amd", "csrc")
+
+
+def test_host_native_code_is_clean_under_asan_ubsan(O, tmp_path):
+    exe = str(tmp_path / "harness")
+    srcs = [os.path.join(ROOT, "tests", "native", "sanitizer_harness.cpp")] + \
+           [os.path.join(CSRC, f) for f in ("continuity.cpp", "tables.cpp", "obj.cpp", "mesh.cpp", "builder.cpp")]
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=all",
+           "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I", CSRC, "-I", os.path.join(ROOT, "include")] + srcs + \
+          ["-o", exe, "-pthread", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    cfg = O.default_config(1e-7, continuity=True)
+    blk = O.Tree.create(cfg, oracle_field(O, "union3"), 1024).to_block()   # depths 4-6: analytic and numeric face integrals
+    (tmp_path / "blk.bin").write_bytes(blk)
+    v, t = icosphere(3, 0.35)
+    with open(tmp_path / "ico.obj", "w") as fh:
+        for p in v:
+            fh.write("v %.9g %.9g %.9g\n" % tuple(p))
+        fh.write("vt 0 0\nvn 0 0 1\n")
+        for a, b, c in t:
+            fh.write("f %d/1/1 %d/1/1 %d/1/1\n" % (a + 1, b + 1, c + 1))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe, str(tmp_path / "blk.bin"), str(tmp_path / "ico.obj"), str(tmp_path / "bad.obj")],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-2000:] + r.stderr[-4000:]
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
