@@ -237,6 +237,61 @@ __global__ __launch_bounds__(256, 7) void lab5(Args a, const double* __restrict_
     }
 }
 
+// 64-byte rows (c0..c7: one L2 sector) fetched by 4 lanes each, 16 rows per DMA instruction, 4 instructions per 64
+// points in one pass; c8, c9 of every cell live in a 64 KB LDS table shared by the workgroup's 16 waves.
+struct alignas(64) Row64 {
+    double c[8];
+};
+struct Args64 {
+    const Row64* r64;
+    const double2* tails;  // [4096] (c8, c9)
+    double nl[3];
+};
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void lab64(Args64 a, const double* __restrict__ xyz, size_t n, double* __restrict__ out) {
+    extern __shared__ double2 smem[];
+    double2* sTail = smem;                                      // [4096]
+    double2* sWin = smem + 4096;                                // [WAVES][4][66]
+    uint32_t* sCode = reinterpret_cast<uint32_t*>(sWin + WAVES * 4 * 66);  // [WAVES][64]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 4096; i += WAVES * 64) sTail[i] = a.tails[i];
+    __syncthreads();
+    const int rowInStep = lane >> 2, chunk = lane & 3;  // 16 rows per step
+    const int myStep = lane >> 4, myRow = lane & 15;
+    const size_t step = (size_t)gridDim.x * WAVES * 64;
+    for (size_t base = (size_t)blockIdx.x * WAVES * 64; base < n; base += step) {
+        const size_t i = base + threadIdx.x < n ? base + threadIdx.x : n - 1;
+        const double px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+        int kx, ky, kz;
+        double cx, cy, cz;
+        cellOf(px, kx, cx), cellOf(py, ky, cy), cellOf(pz, kz, cz);
+        const uint32_t code = (uint32_t)(kx + 16 * (ky + 16 * kz));
+        sCode[w * 64 + lane] = code;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const uint32_t ck = sCode[w * 64 + rowInStep + 16 * s];
+            const char* src = reinterpret_cast<const char*>(a.r64) + (ck << 6) + (uint32_t)chunk * 16u;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src, (LDS_AS void*)&sWin[(w * 4 + s) * 66], 16, 0, 0);
+        }
+        const double2 tail = sTail[code];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        double cv[10];
+        const double2* row = &sWin[(w * 4 + myStep) * 66 + myRow * 4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double2 v = row[q];
+            cv[2 * q] = v.x, cv[2 * q + 1] = v.y;
+        }
+        cv[8] = tail.x, cv[9] = tail.y;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const double r = eval2(cv, (px - cx) * 32.0, (py - cy) * 32.0, (pz - cz) * 32.0, a.nl);
+        if (base + threadIdx.x < n) out[base + threadIdx.x] = r;
+    }
+}
+
 template <typename K>
 float timeIt(K launch, int reps) {
     hipEvent_t e0, e1;
@@ -288,6 +343,24 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dfat, fat.data(), fat.size() * sizeof(Fat), hipMemcpyHostToDevice));
     CK(hipMemcpy(dr80, r80.data(), r80.size() * sizeof(Row80), hipMemcpyHostToDevice));
     a.fat = dfat, a.r80 = dr80;
+    std::vector<Row64> r64(4096);
+    std::vector<double2> tails(4096);
+    for (int i = 0; i < 4096; ++i) {
+        for (int k = 0; k < 8; ++k) r64[i].c[k] = fat[i].c[k];
+        tails[i] = double2{fat[i].c[8], fat[i].c[9]};
+    }
+    Row64* dr64;
+    double2* dtails;
+    CK(hipMalloc(&dr64, r64.size() * sizeof(Row64)));
+    CK(hipMalloc(&dtails, tails.size() * sizeof(double2)));
+    CK(hipMemcpy(dr64, r64.data(), r64.size() * sizeof(Row64), hipMemcpyHostToDevice));
+    CK(hipMemcpy(dtails, tails.data(), tails.size() * sizeof(double2), hipMemcpyHostToDevice));
+    Args64 a64;
+    a64.r64 = dr64, a64.tails = dtails;
+    for (int j = 0; j < 3; ++j) a64.nl[j] = a.nl[j];
+    CK(hipFuncSetAttribute((const void*)lab64<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void*)lab64<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void*)lab64<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     std::vector<double> h(n), ref;
     auto check = [&](const char* name, float ms, int grid) {
         CK(hipMemcpy(h.data(), dout, n * 8, hipMemcpyDeviceToHost));
@@ -308,6 +381,13 @@ int main(int argc, char** argv) {
         RUN8(1, 0, 0, g);
         RUN8(0, 1, 0, g);
         RUN8(1, 1, 0, g);
+#define RUN64(W, blocks) check("64-B rows + LDS tails, waves/WG=" #W, timeIt([&] { hipLaunchKernelGGL((lab64<W>), dim3(blocks), dim3(W * 64), (4096 + W * 4 * 66) * 16 + W * 64 * 4, 0, a64, dx, n, dout); }, 10), blocks)
+        RUN64(16, g / 4);
+        RUN64(8, g / 2);
+        RUN64(4, g);
+        RUN64(16, 256);
+        RUN64(16, 512);
+        RUN64(8, 512);
         RUN5(1, 0, g);
         RUN5(2, 0, g);
         printf("\n");
