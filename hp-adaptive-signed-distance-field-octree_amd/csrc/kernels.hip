@@ -799,7 +799,9 @@ __device__ __forceinline__ void queryGeneralBody(const TreeDev& t, const DeviceT
 
 // Values only: ~104 VGPRs, 4 waves per SIMD (forcing 5 spills: measured 223 -> 338 us on union3@1e-7); with the
 // gradient ~140 VGPRs, 3 waves.  (Sharing one fetch between the points of a group that land in the same leaf, as
-// query_kernel does, measured slower here on grids and sorted points alike: this kernel is latency-, not traffic-bound.)
+// query_kernel does, measured slower here on grids and sorted points alike: this kernel is latency-, not traffic-bound.
+// Evaluating every lane of a mixed wave with the degree-3 code over zero-padded rows -- one pass instead of the
+// degree-2 and degree-3 passes -- is bit-identical but needs whole lines for degree-2 leaves: 229 -> 247 us.)
 template <int TOPD, bool DEFER>
 __global__ __launch_bounds__(256) void query_general_kernel(TreeDev t, const DeviceTables* __restrict__ T,
                                                                const double* __restrict__ xyz, size_t n,

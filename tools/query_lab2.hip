@@ -292,6 +292,53 @@ __global__ __launch_bounds__(WAVES * 64) void lab64(Args64 a, const double* __re
     }
 }
 
+// 64-byte rows as above, the (c8, c9) tails fetched by a fifth DMA step from a compact 64 KB global table (one lane
+// per point): two L2 sectors per point as today, but five DMA instructions, one wait, 5.2 KB of LDS per wave.
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void lab64t(Args64 a, const double* __restrict__ xyz, size_t n, double* __restrict__ out) {
+    __shared__ double2 sWin[4][5][66];
+    __shared__ uint32_t sCode[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int rowInStep = lane >> 2, chunk = lane & 3;
+    const int myStep = lane >> 4, myRow = lane & 15;
+    const size_t step = (size_t)gridDim.x * 256;
+    for (size_t base = (size_t)blockIdx.x * 256; base < n; base += step) {
+        const size_t i = base + threadIdx.x < n ? base + threadIdx.x : n - 1;
+        const double px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+        int kx, ky, kz;
+        double cx, cy, cz;
+        cellOf(px, kx, cx), cellOf(py, ky, cy), cellOf(pz, kz, cz);
+        const uint32_t code = (uint32_t)(kx + 16 * (ky + 16 * kz));
+        sCode[w][lane] = code;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const uint32_t ck = sCode[w][rowInStep + 16 * s];
+            const char* src = reinterpret_cast<const char*>(a.r64) + (ck << 6) + (uint32_t)chunk * 16u;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src, (LDS_AS void*)&sWin[w][s][0], 16, 0, 0);
+        }
+        {
+            const char* src = reinterpret_cast<const char*>(a.tails) + (code << 4);
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src, (LDS_AS void*)&sWin[w][4][0], 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        double cv[10];
+        const double2* row = &sWin[w][myStep][myRow * 4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double2 v = row[q];
+            cv[2 * q] = v.x, cv[2 * q + 1] = v.y;
+        }
+        const double2 tail = sWin[w][4][lane];
+        cv[8] = tail.x, cv[9] = tail.y;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const double r = eval2(cv, (px - cx) * 32.0, (py - cy) * 32.0, (pz - cz) * 32.0, a.nl);
+        if (base + threadIdx.x < n) out[base + threadIdx.x] = r;
+    }
+}
+
 template <typename K>
 float timeIt(K launch, int reps) {
     hipEvent_t e0, e1;
@@ -382,12 +429,12 @@ int main(int argc, char** argv) {
         RUN8(0, 1, 0, g);
         RUN8(1, 1, 0, g);
 #define RUN64(W, blocks) check("64-B rows + LDS tails, waves/WG=" #W, timeIt([&] { hipLaunchKernelGGL((lab64<W>), dim3(blocks), dim3(W * 64), (4096 + W * 4 * 66) * 16 + W * 64 * 4, 0, a64, dx, n, dout); }, 10), blocks)
+#define RUN64T(MW, blocks) check("64-B rows + tail step (5 DMA, 1 wait), min waves/SIMD=" #MW, timeIt([&] { hipLaunchKernelGGL((lab64t<MW>), dim3(blocks), dim3(256), 0, 0, a64, dx, n, dout); }, 10), blocks)
+        RUN64T(7, g);
+        RUN64T(8, g);
+        RUN64T(6, g);
         RUN64(16, g / 4);
-        RUN64(8, g / 2);
-        RUN64(4, g);
         RUN64(16, 256);
-        RUN64(16, 512);
-        RUN64(8, 512);
         RUN5(1, 0, g);
         RUN5(2, 0, g);
         printf("\n");
