@@ -597,7 +597,7 @@ static int queryDevice(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* dXyz, 
         const size_t m = std::min(kChunk, n - off);
         if (t->maxDegree > 3) {
             if (!ctx->dDeferCount) HPSDF_HIP(hipMalloc((void**)&ctx->dDeferCount, (2 * kQueryMaxGrid + 1) * sizeof(uint32_t)));
-            const size_t need = m + (size_t)256 * kQueryMaxGrid;
+            const size_t need = m + (size_t)256 * kQueryMaxGrid + 4096;  // every workgroup's run is whole tiles
             if (ctx->deferCap < need) {
                 if (ctx->dDefer) HPSDF_HIP(hipFree(ctx->dDefer));
                 ctx->dDefer = nullptr;

@@ -659,22 +659,36 @@ __device__ __forceinline__ uint32_t leafChunks(uint32_t degree) { return ((uint3
 // that code out of this kernel keeps it at ~100 VGPRs.
 // GRAD: QueryWithGradient (Octree.cpp:749-789) -- the same walk and fetch, value and "gradient" evaluated together;
 // rows of grad for points outside the root are left untouched, as the reference leaves its output argument.
-template <int TOPD, bool DEFER, bool GRAD>
+// WAVES: waves per workgroup (tile = 64 WAVES points).  LDSTOP (depth-4 top level only): the thin top table, 32 KB,
+// sits in LDS -- the kernel runs at 4 waves per SIMD for its registers anyway, so one 16-wave workgroup per CU with
+// ~120 KB of LDS costs no occupancy and takes the record lookup (an L2 round trip and 64 scattered 8-byte requests
+// per wave) off the dependent chain.
+constexpr size_t queryGeneralLdsBytes(int waves, bool ldsTop) {
+    return (size_t)waves * 5 * 66 * sizeof(double2) + (size_t)waves * 64 * sizeof(uint32_t) + (ldsTop ? 4096 * sizeof(NodeRec) : 0);
+}
+template <int TOPD, bool DEFER, bool GRAD, int WAVES, bool LDSTOP>
 __device__ __forceinline__ void queryGeneralBody(const TreeDev& t, const DeviceTables* __restrict__ T,
                                                  const double* __restrict__ xyz, size_t n, double* __restrict__ out,
                                                  double* __restrict__ grad, uint32_t tilesPerWg,
                                                  uint32_t* __restrict__ deferCount, uint32_t* __restrict__ deferIdx) {
-    __shared__ double2 sRows[4][5][66];
-    __shared__ uint32_t sInfo[4][64];
+    static_assert(!LDSTOP || TOPD == 4, "the LDS copy of the thin table is sized for depth 4");
+    constexpr int TILE = WAVES * 64;
+    extern __shared__ double2 sDyn[];
+    double2(*sRows)[5][66] = reinterpret_cast<double2(*)[5][66]>(sDyn);           // [WAVES][5][66]
+    uint32_t(*sInfo)[64] = reinterpret_cast<uint32_t(*)[64]>(sDyn + WAVES * 5 * 66);  // [WAVES][64]
+    NodeRec* sTop = reinterpret_cast<NodeRec*>(&sInfo[WAVES][0]);                  // [4096] when LDSTOP
     __shared__ double sNl[13 * 11];
     __shared__ double sRec[26];
     __shared__ uint32_t sDeferred;
     stageQueryTables(T, sNl, sRec);
+    if constexpr (LDSTOP) {
+        for (int q = threadIdx.x; q < 4096; q += TILE) sTop[q] = t.topRec[q];
+    }
     if (threadIdx.x == 0) sDeferred = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane & ~7, sub = lane & 7;
-    const size_t segStart = (size_t)blockIdx.x * tilesPerWg * 256;  // this workgroup's run of deferIdx
-    for (size_t base = (size_t)blockIdx.x * 256; base < n; base += (size_t)gridDim.x * 256) {
+    const size_t segStart = (size_t)blockIdx.x * tilesPerWg * TILE;  // this workgroup's run of deferIdx
+    for (size_t base = (size_t)blockIdx.x * TILE; base < n; base += (size_t)gridDim.x * TILE) {
         const size_t i = base + threadIdx.x;
         const bool valid = i < n;
         const size_t il = valid ? i : n - 1;
@@ -689,7 +703,7 @@ __device__ __forceinline__ void queryGeneralBody(const TreeDev& t, const DeviceT
         topCell(p3, topDepth, k3, c3);
         uint32_t code = (uint32_t)(k3[0] + ((k3[1] + (k3[2] << topDepth)) << topDepth));
         if (!inside) code = 0;
-        NodeRec rec = t.topRec[code];
+        NodeRec rec = LDSTOP ? sTop[code] : t.topRec[code];
         int depth = topDepth;
         double q = 0.25 / (double)(1 << topDepth);  // a quarter of the cell size: from a centre to its children's
         while (rec.b == kInteriorTag) {              // :674-701 below the complete levels
@@ -808,7 +822,16 @@ __global__ __launch_bounds__(256) void query_general_kernel(TreeDev t, const Dev
                                                                double* __restrict__ out, uint32_t tilesPerWg,
                                                                uint32_t* __restrict__ deferCount,
                                                                uint32_t* __restrict__ deferIdx) {
-    queryGeneralBody<TOPD, DEFER, false>(t, T, xyz, n, out, nullptr, tilesPerWg, deferCount, deferIdx);
+    queryGeneralBody<TOPD, DEFER, false, 4, false>(t, T, xyz, n, out, nullptr, tilesPerWg, deferCount, deferIdx);
+}
+// depth-4 top level: 16 waves per workgroup, thin table in LDS
+template <bool DEFER>
+__global__ __launch_bounds__(1024) void query_general_lds_kernel(TreeDev t, const DeviceTables* __restrict__ T,
+                                                                 const double* __restrict__ xyz, size_t n,
+                                                                 double* __restrict__ out, uint32_t tilesPerWg,
+                                                                 uint32_t* __restrict__ deferCount,
+                                                                 uint32_t* __restrict__ deferIdx) {
+    queryGeneralBody<4, DEFER, false, 16, true>(t, T, xyz, n, out, nullptr, tilesPerWg, deferCount, deferIdx);
 }
 template <int TOPD, bool DEFER>
 __global__ __launch_bounds__(256, 3) void query_general_grad_kernel(TreeDev t, const DeviceTables* __restrict__ T,
@@ -816,7 +839,7 @@ __global__ __launch_bounds__(256, 3) void query_general_grad_kernel(TreeDev t, c
                                                                     double* __restrict__ out, double* __restrict__ grad,
                                                                     uint32_t tilesPerWg, uint32_t* __restrict__ deferCount,
                                                                     uint32_t* __restrict__ deferIdx) {
-    queryGeneralBody<TOPD, DEFER, true>(t, T, xyz, n, out, grad, tilesPerWg, deferCount, deferIdx);
+    queryGeneralBody<TOPD, DEFER, true, 4, false>(t, T, xyz, n, out, grad, tilesPerWg, deferCount, deferIdx);
 }
 
 // Exclusive scan of the per-workgroup deferred counts (nWg <= 8192): offsets[b] = points deferred by workgroups
@@ -1498,16 +1521,31 @@ hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables*
         }
         return hipGetLastError();
     }
-    const size_t nTiles = (n + 255) / 256;
-    const uint32_t tilesPerWg = (uint32_t)((nTiles + grid.x - 1) / grid.x);  // tiles b, b + G, ... of workgroup b
     const bool defer = t.maxDegree > 3;
+    const bool big = !dGrad && t.topDepth == 4 && std::getenv("HPSDF_QUERY_NO_LDSTOP") == nullptr;
+    const unsigned tile = big ? 1024u : 256u;
+    const size_t nTiles = (n + tile - 1) / tile;
+    const unsigned nWg = (unsigned)std::min<size_t>(nTiles, big ? 2048u : kQueryMaxGrid);
+    const uint32_t tilesPerWg = (uint32_t)((nTiles + nWg - 1) / nWg);  // tiles b, b + G, ... of workgroup b
+    const dim3 ggrid(nWg);
+    const size_t lds = queryGeneralLdsBytes(big ? 16 : 4, big);
+    if (big) {
+        // > 64 KB of dynamic LDS is opt-in, per function and device
+        const void* fn = defer ? (const void*)query_general_lds_kernel<true> : (const void*)query_general_lds_kernel<false>;
+        const hipError_t ae = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ae != hipSuccess) return ae;
+        if (defer)
+            hipLaunchKernelGGL((query_general_lds_kernel<true>), ggrid, dim3(1024), lds, stream, t, dTables, dXyz, n, dOut, tilesPerWg, dDeferCount, dDeferIdx);
+        else
+            hipLaunchKernelGGL((query_general_lds_kernel<false>), ggrid, dim3(1024), lds, stream, t, dTables, dXyz, n, dOut, tilesPerWg, dDeferCount, dDeferIdx);
+    } else {
 #define HPSDF_QUERY_GENERAL(TOPD, DF)                                                                               \
     do {                                                                                                            \
         if (dGrad)                                                                                                  \
-            hipLaunchKernelGGL((query_general_grad_kernel<TOPD, DF>), grid, block, 0, stream, t, dTables, dXyz, n, dOut, \
+            hipLaunchKernelGGL((query_general_grad_kernel<TOPD, DF>), ggrid, block, lds, stream, t, dTables, dXyz, n, dOut, \
                                dGrad, tilesPerWg, dDeferCount, dDeferIdx);                                          \
         else                                                                                                        \
-            hipLaunchKernelGGL((query_general_kernel<TOPD, DF>), grid, block, 0, stream, t, dTables, dXyz, n, dOut,  \
+            hipLaunchKernelGGL((query_general_kernel<TOPD, DF>), ggrid, block, lds, stream, t, dTables, dXyz, n, dOut,  \
                                tilesPerWg, dDeferCount, dDeferIdx);                                                 \
     } while (0)
 #define HPSDF_QUERY_GENERAL_T(TOPD)         \
@@ -1517,24 +1555,26 @@ hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables*
         else                                \
             HPSDF_QUERY_GENERAL(TOPD, false); \
     } while (0)
-    if (t.topDepth == 4)
-        HPSDF_QUERY_GENERAL_T(4);
-    else
-        HPSDF_QUERY_GENERAL_T(0);
+        if (t.topDepth == 4)
+            HPSDF_QUERY_GENERAL_T(4);
+        else
+            HPSDF_QUERY_GENERAL_T(0);
 #undef HPSDF_QUERY_GENERAL_T
 #undef HPSDF_QUERY_GENERAL
+    }
     if (defer) {
         // the per-workgroup lists are short and ragged: scan their lengths, then walk their concatenation densely
         uint32_t* dOffsets = dDeferCount + kQueryMaxGrid;
-        hipLaunchKernelGGL(defer_scan_kernel, dim3(1), dim3(1024), 0, stream, dDeferCount, grid.x, dOffsets);
-        const dim3 dgrid(std::min<unsigned>(grid.x, 1024u));
+        hipLaunchKernelGGL(defer_scan_kernel, dim3(1), dim3(1024), 0, stream, dDeferCount, nWg, dOffsets);
+        const dim3 dgrid(std::min<unsigned>(nWg, 1024u));
+        const uint32_t slotsPerWg = tilesPerWg * (tile / 256u);  // deferredPoint() counts in runs of 256
         if (dGrad)
-            hipLaunchKernelGGL(query_grad_deep_kernel, dgrid, block, 0, stream, t, dTables, dXyz, dOut, dGrad, tilesPerWg, grid.x,
+            hipLaunchKernelGGL(query_grad_deep_kernel, dgrid, block, 0, stream, t, dTables, dXyz, dOut, dGrad, slotsPerWg, nWg,
                                dOffsets, dDeferIdx);
         else if (t.maxDegree <= 5)
-            hipLaunchKernelGGL((query_deep_kernel<5>), dgrid, block, 0, stream, t, dTables, dXyz, dOut, tilesPerWg, grid.x, dOffsets, dDeferIdx);
+            hipLaunchKernelGGL((query_deep_kernel<5>), dgrid, block, 0, stream, t, dTables, dXyz, dOut, slotsPerWg, nWg, dOffsets, dDeferIdx);
         else
-            hipLaunchKernelGGL((query_deep_kernel<12>), dgrid, block, 0, stream, t, dTables, dXyz, dOut, tilesPerWg, grid.x, dOffsets, dDeferIdx);
+            hipLaunchKernelGGL((query_deep_kernel<12>), dgrid, block, 0, stream, t, dTables, dXyz, dOut, slotsPerWg, nWg, dOffsets, dDeferIdx);
     }
     return hipGetLastError();
 }
