@@ -80,25 +80,35 @@ def main():
         field = H.Field.union3()
 
         # ---------------- Create(): sharded over the ranks, timed over a few repetitions
-        def create():
-            return D.create_distributed(ctx, cfg, field, JOBS_PER_ROUND) if world > 1 else \
-                H.create_block(ctx, cfg, field, JOBS_PER_ROUND)
-
-        block, stats = create()  # warm-up (also first hipMalloc of the arena)
-        create_times = []
-        for _ in range(5):
+        # N > 1: create_ms is the policy a user gets by default ("auto": an analytic field is cheap, so every rank
+        # builds the whole tree and nothing is exchanged); create_sharded_ms forces the sharded frontier with its
+        # all-gather per round (the mesh-field path), whose fixed costs exceed this 0.3 ms build.
+        def timed_create(policy):
+            def create():
+                return D.create_distributed(ctx, cfg, field, JOBS_PER_ROUND, policy=policy) if world > 1 else \
+                    H.create_block(ctx, cfg, field, JOBS_PER_ROUND)
+            blk, st = create()  # warm-up (also first hipMalloc of the arena)
+            times = []
+            for _ in range(5):
+                if world > 1:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                blk, st = create()
+                torch.cuda.synchronize()
+                times.append((time.perf_counter() - t0) * 1e3)
+            ms = float(np.median(times))
             if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            block, stats = create()
-            torch.cuda.synchronize()
-            create_times.append((time.perf_counter() - t0) * 1e3)
-        create_ms = float(np.median(create_times))
+                t = torch.tensor([ms], device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                ms = float(t.item())
+            return blk, st, ms, times
+
+        block, stats, create_ms, create_times = timed_create("auto")
+        create_sharded_ms = None
         if world > 1:
-            t = torch.tensor([create_ms], device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            create_ms = float(t.item())
+            block_s, _, create_sharded_ms, _ = timed_create("shard")
+            assert block_s == block, "sharded and replicated Create disagree"
 
         # ---------------- Query(): this rank's points, resident in HBM
         n = args.points
@@ -242,7 +252,7 @@ def main():
         "config": {"workload": "BASELINE configs[1]: union(sphere,box,torus) analytic SDF, targetError=1e-5, "
                                "continuity off, %d random Query() points per GPU" % n,
                    "jobs_per_round": JOBS_PER_ROUND, "points_per_gpu": n, "sharding": "replicated tree, points split"},
-        "create_ms": create_ms,
+        "create_ms": create_ms, "create_sharded_ms": create_sharded_ms,
         "create": {"nodes": stats["n_nodes"], "leaves": stats["n_leaves"], "coeffs": stats["n_coeffs"],
                    "rounds": stats["rounds"], "jobs": stats["jobs"], "fits": stats["fits"], "samples": stats["samples"],
                    "block_bytes": len(block), "ms_all": create_times},

@@ -276,9 +276,10 @@ class Context:
 
 
 class Field:
-    def __init__(self, handle, keep=()):
+    def __init__(self, handle, keep=(), kind=None):
         self.handle = handle
         self._keep = keep
+        self.kind = kind  # "analytic" | "callback" | "mesh" | "tree_csg"
 
     @staticmethod
     def analytic(spec):
@@ -290,7 +291,7 @@ class Field:
                 arr[i].p[j] = float(v)
         h = C.c_void_p()
         check(lib().hpsdf_field_create_analytic(arr, len(spec), C.byref(h)))
-        return Field(h)
+        return Field(h, kind="analytic")
 
     @staticmethod
     def sphere(centre=(0.25, 0.0, 0.0), radius=0.5):
@@ -313,7 +314,7 @@ class Field:
         cb = CALLBACK(tramp)
         h = C.c_void_p()
         check(lib().hpsdf_field_create_callback(cb, None, C.byref(h)))
-        return Field(h, keep=(cb, fn))
+        return Field(h, keep=(cb, fn), kind="callback")
 
     @staticmethod
     def mesh(ctx, verts, tris):
@@ -322,13 +323,13 @@ class Field:
         h = C.c_void_p()
         check(lib().hpsdf_field_create_mesh(ctx.handle, v.ctypes.data_as(C.c_void_p), len(v),
                                             t.ctypes.data_as(C.c_void_p), len(t), C.byref(h)))
-        return Field(h, keep=(ctx,))
+        return Field(h, keep=(ctx,), kind="mesh")
 
     @staticmethod
     def tree_csg(tree, op, inner):
         h = C.c_void_p()
         check(lib().hpsdf_field_create_tree_csg(tree.handle, op, inner.handle, C.byref(h)))
-        return Field(h, keep=(tree, inner))
+        return Field(h, keep=(tree, inner), kind="tree_csg")
 
     def eval(self, ctx, pts):
         pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)

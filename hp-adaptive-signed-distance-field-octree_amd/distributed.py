@@ -45,12 +45,23 @@ def _gather_padded(local, pad_to, group, world):
     return out.view(world, pad_to)
 
 
-def create_distributed(ctx, config, field, K=0, group=None, compute=None):
-    """Octree::Create sharded over the ranks of ``group``.  Returns (block bytes, stats) on every rank.
+def create_distributed(ctx, config, field, K=0, group=None, compute=None, policy="shard"):
+    """Octree::Create over the ranks of ``group``.  Returns (block bytes, stats) on every rank.
+
+    policy "shard": every round's jobs are split over the ranks and their errors all-gathered (what the
+    north_star asks for; pays when the field is expensive -- meshes, host callbacks).  "replicate": every rank
+    builds the whole tree by itself (deterministic, so the blocks are identical; no exchange) -- for analytic
+    fields a whole Create is a fraction of a millisecond and any exchange costs more than it saves.  "auto":
+    replicate for GPU-evaluated analytic fields, shard otherwise.
 
     compute(build, jobs, first, count) -> (headers [count,9] ndarray) may replace the GPU leg
     (test hook: it must also ``build.inject`` the coefficients of its jobs).
     """
+    if policy not in ("shard", "replicate", "auto"):
+        raise ValueError("policy must be shard, replicate or auto")
+    if compute is None and (policy == "replicate" or (policy == "auto" and getattr(field, "kind", None) == "analytic")):
+        from . import create_block
+        return create_block(ctx, config, field, K)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     on_gpu = compute is None
