@@ -75,6 +75,7 @@ struct HpsdfVec3 {
 };
 typedef HpsdfVec3<double> Vector3d;
 typedef HpsdfVec3<float> Vector3f;
+typedef HpsdfVec3<int> Vector3i;
 template <typename T>
 struct HpsdfBox3 {
     HpsdfVec3<T> lo, hi;
@@ -175,27 +176,27 @@ struct Ray {
     Ray(const Eigen::Vector3d& origin_, const Eigen::Vector3d& direction_) : origin(origin_), direction(direction_) {
         for (int a = 0; a < 3; ++a) {
             invDirection(a) = 1.0 / direction_(a);
-            sign[a] = invDirection(a) < 0.0;
+            sign(a) = invDirection(a) < 0.0;
         }
     }
     Eigen::Vector3d origin;
     Eigen::Vector3d direction;
     Eigen::Vector3d invDirection;
-    int sign[3];
+    Eigen::Vector3i sign;
 
     /// Returns whether the ray intersects the box and, if so, stores the slab parameters in a_ and b_
     /// (Source/HP/Ray.cpp:18-68; host-side helper, the batched QueryRay does the same on the GPU)
     bool IntersectAABB(const Eigen::AlignedBox3d& aabb_, Eigen::Vector3d& a_, Eigen::Vector3d& b_) const {
         const Eigen::Vector3d bounds[2] = {aabb_.min(), aabb_.max()};
-        a_(0) = (bounds[sign[0]](0) - origin(0)) * invDirection(0);
-        b_(0) = (bounds[1 - sign[0]](0) - origin(0)) * invDirection(0);
-        a_(1) = (bounds[sign[1]](1) - origin(1)) * invDirection(1);
-        b_(1) = (bounds[1 - sign[1]](1) - origin(1)) * invDirection(1);
+        a_(0) = (bounds[sign(0)](0) - origin(0)) * invDirection(0);
+        b_(0) = (bounds[1 - sign(0)](0) - origin(0)) * invDirection(0);
+        a_(1) = (bounds[sign(1)](1) - origin(1)) * invDirection(1);
+        b_(1) = (bounds[1 - sign(1)](1) - origin(1)) * invDirection(1);
         if ((a_(0) > b_(1)) || (a_(1) > b_(0))) return false;
         if (a_(1) > a_(0)) a_(0) = a_(1);
         if (b_(1) < b_(0)) b_(0) = b_(1);
-        a_(2) = (bounds[sign[2]](2) - origin(2)) * invDirection(2);
-        b_(2) = (bounds[1 - sign[2]](2) - origin(2)) * invDirection(2);
+        a_(2) = (bounds[sign(2)](2) - origin(2)) * invDirection(2);
+        b_(2) = (bounds[1 - sign(2)](2) - origin(2)) * invDirection(2);
         if ((a_(0) > b_(2)) || (a_(2) > b_(0))) return false;
         if (a_(2) > a_(0)) a_(0) = a_(2);
         if (b_(2) < b_(0)) b_(0) = b_(2);
