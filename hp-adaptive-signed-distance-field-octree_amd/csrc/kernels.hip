@@ -996,6 +996,7 @@ __global__ __launch_bounds__(256) void query_grad_deep_kernel(TreeDev t, const D
 // origin outside the root `intMin` is what IntersectAABB leaves in its first output -- the entry parameter in x,
 // per-axis slab parameters in y and z -- not a point (:717); Query maps its argument through the root transform
 // again (:726 -> :665); and on a hit t_ receives the field value (:730).  t of a miss is left untouched.
+template <int MAXP>
 __global__ __launch_bounds__(256) void query_ray_kernel(TreeDev t, const DeviceTables* __restrict__ T,
                                                         const double* __restrict__ origins,
                                                         const double* __restrict__ dirs, const double* __restrict__ tMax,
@@ -1040,7 +1041,7 @@ __global__ __launch_bounds__(256) void query_ray_kernel(TreeDev t, const DeviceT
             const double eps = 0.0001, minStep = 0.0001, lim = tMax[i];
             double dist = 0.0;
             for (int s = 0; s < 200; ++s) {
-                const double v = queryPoint<12>(t, im[0] + dist * d[0], im[1] + dist * d[1], im[2] + dist * d[2], sNl, sRec);
+                const double v = queryPoint<MAXP>(t, im[0] + dist * d[0], im[1] + dist * d[1], im[2] + dist * d[2], sNl, sRec);
                 if (v < eps) {
                     tOut[i] = v;  // :730
                     h = 1;
@@ -1582,8 +1583,13 @@ hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables*
 hipError_t launchQueryRay(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dOrigins,
                           const double* dDirs, const double* dTMax, size_t n, uint8_t* dHit, double* dT) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(query_ray_kernel, dim3(gridFor(n)), dim3(256), 0, stream, t, dTables, dOrigins, dDirs, dTMax, n,
-                       dHit, dT);
+    // the evaluation code for the degrees the tree does not contain is left out (registers, no scratch)
+    if (t.maxDegree <= 3)
+        hipLaunchKernelGGL((query_ray_kernel<3>), dim3(gridFor(n)), dim3(256), 0, stream, t, dTables, dOrigins, dDirs, dTMax, n, dHit, dT);
+    else if (t.maxDegree <= 5)
+        hipLaunchKernelGGL((query_ray_kernel<5>), dim3(gridFor(n)), dim3(256), 0, stream, t, dTables, dOrigins, dDirs, dTMax, n, dHit, dT);
+    else
+        hipLaunchKernelGGL((query_ray_kernel<12>), dim3(gridFor(n)), dim3(256), 0, stream, t, dTables, dOrigins, dDirs, dTMax, n, dHit, dT);
     return hipGetLastError();
 }
 
