@@ -241,6 +241,88 @@ __device__ float meshSignedDistance(const MeshDev& m, V3 pt, uint32_t& hint) {
     return sign * sqrtf(sqnorm(d));
 }
 
+// The same query for the 64 points of a wave at once (the samples of one cell's grid: a tight cluster).  The wave
+// walks ONE traversal: a node is visited if any lane still needs it, its 64 bytes are fetched once (every lane reads
+// the same address), every lane keeps its own best and tests a triangle only if its own bound asks for it -- so each
+// lane ends with exactly what its own traversal finds (pruning is per lane, ties go to the lower triangle index,
+// the visiting order does not matter), while the gathers that dominate the per-lane version (64 lanes x dozens of
+// scattered 64-byte nodes) become a few dozen uniform loads.  `stack` : kMeshStack ints of LDS owned by this wave (two entries per level of a BVH at most 31 levels deep).
+// Every lane of the wave must call this (inactive lanes with active = false).
+constexpr int kMeshStack = 128;
+__device__ float meshSignedDistanceWave(const MeshDev& m, V3 pt, bool active, uint32_t& hint, int32_t* stack) {
+    float best = FLT_MAX;
+    uint32_t bestTri = 0xFFFFFFFFu;
+    int bestCode = 8;
+    V3 bestQ = {0.0f, 0.0f, 0.0f};
+    auto visitTri = [&](uint32_t t) {
+        V3 q;
+        const int code =
+            closestSimplex(pt, meshVert(m, m.tris[3 * t]), meshVert(m, m.tris[3 * t + 1]), meshVert(m, m.tris[3 * t + 2]), q);
+        const float d = sqnorm(pt - q);
+        if (d < best || (d == best && t < bestTri)) {
+            best = d;
+            bestTri = t;
+            bestCode = code;
+            bestQ = q;
+        }
+    };
+    auto boxDist = [&](const float* lo, const float* hi) {
+        const float cx = fminf(fmaxf(pt.x, lo[0]), hi[0]);
+        const float cy = fminf(fmaxf(pt.y, lo[1]), hi[1]);
+        const float cz = fminf(fmaxf(pt.z, lo[2]), hi[2]);
+        return sqnorm(pt - V3{cx, cy, cz});
+    };
+    auto worthIt = [&](float d) { return active && !(d > best * 1.00001f + 1e-30f); };
+    if (active && hint < m.nTris) visitTri(hint);
+    const int lane = threadIdx.x & 63;
+    int sp = 1;  // wave-uniform
+    if (lane == 0) stack[0] = 0;
+    while (sp > 0) {
+        --sp;
+        const int32_t ni = __builtin_amdgcn_readfirstlane(stack[sp]);
+        const BvhNode n = m.bvh[ni];
+        const float d0 = boxDist(n.lo0, n.hi0), d1 = boxDist(n.lo1, n.hi1);
+        const bool w0 = worthIt(d0), w1 = worthIt(d1);
+        const unsigned long long b0 = __ballot(w0), b1 = __ballot(w1);
+        if ((b0 | b1) == 0ull) continue;
+        // leaves are resolved at once (they tighten the bounds); inner children are pushed, the one that is nearer
+        // for the first lane that wants it on top
+        if (n.c0 < 0) {
+            if (w0) visitTri((uint32_t)~n.c0);
+        }
+        if (n.c1 < 0) {
+            if (w1 && worthIt(d1)) visitTri((uint32_t)~n.c1);
+        }
+        const bool push0 = n.c0 >= 0 && b0 != 0ull, push1 = n.c1 >= 0 && b1 != 0ull;
+        if (push0 && push1) {
+            const int l0 = __ffsll((long long)b0) - 1;
+            const float a0 = __shfl(d0, l0, 64), a1 = __shfl(d1, l0, 64);
+            const bool firstIs1 = a1 < a0;  // visit the nearer one first: it goes on top
+            if (sp < kMeshStack - 2) {
+                if (lane == 0) {
+                    stack[sp] = firstIs1 ? n.c0 : n.c1;
+                    stack[sp + 1] = firstIs1 ? n.c1 : n.c0;
+                }
+                sp += 2;
+            }
+        } else if (push0 || push1) {
+            if (sp < kMeshStack - 1) {
+                if (lane == 0) stack[sp] = push0 ? n.c0 : n.c1;
+                sp += 1;
+            }
+        }
+    }
+    float r = 0.0f;
+    if (active) {
+        hint = bestTri;
+        const V3 nrm = pseudoNormal(m, bestTri, bestCode);
+        const V3 d = pt - bestQ;
+        const float sign = dot(nrm, d) > 0.0f ? 1.0f : -1.0f;
+        r = sign * sqrtf(sqnorm(d));
+    }
+    return r;
+}
+
 // ---------------------------------------------------------------------------
 // tree evaluation: Octree::Query (Octree.cpp:662-702) and FApprox (:859-901)
 // ---------------------------------------------------------------------------
@@ -1069,6 +1151,21 @@ __global__ __launch_bounds__(256) void slice_points_kernel(double c, float minX,
     }
 }
 
+// the CSG wrapper of Octree.cpp:355-400 around an inner field value v
+template <bool CSG>
+__device__ __forceinline__ double applyCsg(const FieldDev& f, double v, double x, double y, double z, const double* sNl,
+                                           const double* sRec) {
+    if constexpr (CSG) {
+        const double o = queryPoint<12>(f.oldTree, x, y, z, sNl, sRec);
+        switch (f.csgOp) {
+            case HPSDF_OP_UNION: v = o < v ? o : v; break;                   // std::min(old, F)
+            case HPSDF_OP_SUBTRACT: v = (o * -1.0) < v ? v : (o * -1.0); break;  // std::max(-old, F)
+            default: v = o < v ? v : o; break;                               // std::max(old, F)
+        }
+    }
+    return v;
+}
+
 // F at a world-space point, with the optional CSG wrapper of Octree.cpp:355-400
 template <int KIND, bool CSG>
 __device__ __forceinline__ double fieldEvalWorld(const FieldDev& f, double x, double y, double z, uint64_t sampleIdx,
@@ -1080,15 +1177,7 @@ __device__ __forceinline__ double fieldEvalWorld(const FieldDev& f, double x, do
         v = f.samples[sampleIdx];
     else  // SURVEY 3.4 user glue: (f64) mesh.SignedDistanceAtPt(p.cast<f32>())
         v = (double)meshSignedDistance(f.mesh, V3{(float)x, (float)y, (float)z}, meshHint);
-    if constexpr (CSG) {
-        const double o = queryPoint<12>(f.oldTree, x, y, z, sNl, sRec);
-        switch (f.csgOp) {
-            case HPSDF_OP_UNION: v = o < v ? o : v; break;                   // std::min(old, F)
-            case HPSDF_OP_SUBTRACT: v = (o * -1.0) < v ? v : (o * -1.0); break;  // std::max(-old, F)
-            default: v = o < v ? v : o; break;                               // std::max(old, F)
-        }
-    }
-    return v;
+    return applyCsg<CSG>(f, v, x, y, z, sNl, sRec);
 }
 
 template <int KIND, bool CSG>
@@ -1160,6 +1249,7 @@ __global__ __launch_bounds__(kFitThreads) void fit_kernel(const FitBlock* __rest
     extern __shared__ double lds[];
     __shared__ double sNl[13 * 11];
     __shared__ double sRec[26];
+    __shared__ int32_t sMeshStack[kFitThreads / 64][kMeshStack];  // per-wave traversal stacks (mesh fields)
     const FitBlock blk = blocks[blockIdx.x];
     const int tid = threadIdx.x;
     const int deg = DEG > 0 ? DEG : (int)blk.degree;
@@ -1239,10 +1329,13 @@ __global__ __launch_bounds__(kFitThreads) void fit_kernel(const FitBlock* __rest
         // ---- phase 1: F on planes [iBase, iBase+np) of every cell (:1035-1040)
         const int chunkSamples = np * nq2, total = G * chunkSamples;
         const float invChunk = 1.0f / (float)chunkSamples;
-        for (int s = tid; s < total; s += kFitThreads) {
+        for (int s0 = 0; s0 < total; s0 += kFitThreads) {  // every lane iterates (the mesh path works wave-wide)
+            const int s = s0 + tid;
+            const bool activeS = s < total;
+            const int sc = activeS ? s : total - 1;
             // s -> (cell g, sample rem) without an integer division by the run-time chunk size
-            int g = (int)(((float)s + 0.5f) * invChunk);
-            int rem = s - g * chunkSamples;
+            int g = (int)(((float)sc + 0.5f) * invChunk);
+            int rem = sc - g * chunkSamples;
             if (rem < 0) {
                 --g;
                 rem += chunkSamples;
@@ -1257,8 +1350,16 @@ __global__ __launch_bounds__(kFitThreads) void fit_kernel(const FitBlock* __rest
             const double wy = uy * rm.bounds[1] + rm.centre[1];
             const double wz = uz * rm.bounds[2] + rm.centre[2];
             const uint64_t sidx = (uint64_t)__double_as_longlong(c[7]) + (uint64_t)((i * nq + j) * nq + k);
-            const double fv = fieldEvalWorld<KIND, CSG>(field, wx, wy, wz, sidx, sNl, sRec, meshHint);
-            sF[g * cellStride + rem] = c[6] * (sW[i] * (sW[j] * sW[k])) * fv;  // :1040
+            double fv;
+            if constexpr (KIND == kFieldMesh) {
+                // SURVEY 3.4 user glue: (f64) mesh.SignedDistanceAtPt(p.cast<f32>()) -- one traversal per wave
+                const double mv = (double)meshSignedDistanceWave(field.mesh, V3{(float)wx, (float)wy, (float)wz}, activeS, meshHint,
+                                                                 sMeshStack[tid >> 6]);
+                fv = activeS ? applyCsg<CSG>(field, mv, wx, wy, wz, sNl, sRec) : 0.0;
+            } else {
+                fv = activeS ? fieldEvalWorld<KIND, CSG>(field, wx, wy, wz, sidx, sNl, sRec, meshHint) : 0.0;
+            }
+            if (activeS) sF[g * cellStride + rem] = c[6] * (sW[i] * (sW[j] * sW[k])) * fv;  // :1040
         }
         __syncthreads();
         // ---- phase 2: accumulate the chunk, planes ascending (:1043-1053)
