@@ -537,3 +537,26 @@ def test_capi_argument_checks_query_side(H, ctx):
     assert hit.shape == (0,) and t.shape == (0,)
     rgb, vals = tree.function_slice(0.0, (-0.5,) * 3, (0.5,) * 3, 1)
     assert rgb.shape == (1, 1, 3) and vals.shape == (1, 1)
+
+
+def test_mesh_create_with_continuity_config5_shape(H, O, ctx):
+    """BASELINE config 5 in miniature: mesh field, root = mesh box, targetError 1e-5, continuity.enforce -- GPU build,
+    host post-process.  The result must equal the host post-process of the continuity-free build (bit for bit) and stay
+    close to the mesh's own signed distance."""
+    verts, tris = icosphere(4, 0.35)
+    lo, hi = verts.min(0) - 0.03, verts.max(0) + 0.03
+    f = H.Field.mesh(ctx, verts, tris)
+    cfg = H.make_config(1e-5, tuple(lo), tuple(hi), continuity=True)
+    blk, st = H.create_block(ctx, cfg, f, 1024)
+    cs = H.continuity_last_stats()
+    assert cs["n_pairs"] >= 11520 and cs["residual"] < 1e-6 and cs["jump_after"] < cs["jump_before"]
+    cfg0 = H.make_config(1e-5, tuple(lo), tuple(hi), continuity=False)
+    blk0, _ = H.create_block(ctx, cfg0, f, 1024)
+    b0 = bytearray(blk0)
+    b0[-80 + 16] = 1
+    assert H.continuity_post_process(bytes(b0))[0] == blk
+    pts = np.random.default_rng(5).uniform(lo, hi, (50000, 3))
+    q = H.DeviceTree(ctx, blk).query(pts)
+    d = f.eval(ctx, pts)
+    # the reference's continuity tests run at 1e-8 with a 1e-2 bar (HPUnitTests.cpp:80-112); this config's 1e-5 is coarser
+    assert np.abs(q - d).max() <= 2e-2 and np.median(np.abs(q - d)) <= 1e-3
