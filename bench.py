@@ -132,10 +132,11 @@ def main():
         for _ in range(args.steps):
             step()
         e1.record(stream)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0  # this rank's K steps; the MAX over ranks is taken below, behind the closing barrier
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
-        wall = time.perf_counter() - t0
+            torch.cuda.synchronize()
         kernel_ms = e0.elapsed_time(e1) / args.steps  # average launch duration of query_kernel
         if world > 1:
             t = torch.tensor([wall], device="cuda", dtype=torch.float64)
