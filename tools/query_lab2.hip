@@ -339,6 +339,163 @@ __global__ __launch_bounds__(256, MINW) void lab64t(Args64 a, const double* __re
     }
 }
 
+// Two point sets in flight per wave: tile i is processed from set (i & 1); right after its second batch of DMAs the
+// points of tile i + 2 are requested into the same set (its values are already turned into code / local coordinates).
+// The wait for the second batch is vmcnt(3) (the three point loads are younger), the wait for the first batch of
+// the NEXT tile is vmcnt(0), which retires them -- by then they have been in flight for an evaluation, a store and a
+// whole DMA round trip.  vmcnt retires in order, so this is as far ahead as a wave can look.
+#define LAB_PIPE_BODY(SX, SY, SZ, TILE_BASE)                                                                         \
+    {                                                                                                                \
+        const size_t base_ = (TILE_BASE);                                                                            \
+        asm volatile("" : "+v"(SX), "+v"(SY), "+v"(SZ));                                                             \
+        const double px = SX, py = SY, pz = SZ;                                                                      \
+        uint32_t code;                                                                                               \
+        double cx, cy, cz;                                                                                           \
+        descend4(px, py, pz, code, cx, cy, cz);                                                                      \
+        const double ux = (px - cx) * 32.0, uy = (py - cy) * 32.0, uz = (pz - cz) * 32.0;                            \
+        double cv[10];                                                                                               \
+        _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                                     \
+            _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                          \
+                const uint32_t off = ((uint32_t)__shfl(code, grp | (half * 4 + k), 64) << 7) + (uint32_t)j * 16u;    \
+                const char* src = reinterpret_cast<const char*>(a.fat) + off;                                        \
+                if (j < 6) __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src, (LDS_AS void*)&sd[w][k][0], 16, 0, 0); \
+            }                                                                                                        \
+            if (half == 0) {                                                                                         \
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
+            } else {                                                                                                 \
+                const size_t nb = base_ + 2 * step;                                                                  \
+                const size_t ni = (nb + threadIdx.x < n) ? nb + threadIdx.x : n - 1;                                 \
+                const double* np = xyz + 3 * ni;                                                                     \
+                asm volatile("global_load_dwordx2 %0, %3, off\n\tglobal_load_dwordx2 %1, %3, off offset:8\n\tglobal_load_dwordx2 %2, %3, off offset:16" \
+                             : "=&v"(SX), "=&v"(SY), "=&v"(SZ) : "v"(np) : "memory");                                \
+                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                                     \
+            }                                                                                                        \
+            __builtin_amdgcn_wave_barrier();                                                                         \
+            if ((j >> 2) == half) {                                                                                  \
+                const double2* row = &sd[w][j & 3][grp];                                                             \
+                _Pragma("unroll") for (int q = 0; q < 5; ++q) {                                                      \
+                    const double2 v = row[1 + q];                                                                    \
+                    cv[2 * q] = v.x, cv[2 * q + 1] = v.y;                                                            \
+                }                                                                                                    \
+            }                                                                                                        \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
+            __builtin_amdgcn_wave_barrier();                                                                         \
+        }                                                                                                            \
+        const double r = eval2(cv, ux, uy, uz, a.nl);                                                                \
+        if (base_ + threadIdx.x < n) out[base_ + threadIdx.x] = r;                                                   \
+    }
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void labPipe(Args a, const double* __restrict__ xyz, size_t n, double* __restrict__ out) {
+    __shared__ double2 sd[4][4][66];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, grp = lane & ~7, j = lane & 7;
+    const size_t step = (size_t)gridDim.x * 256;
+    size_t base = (size_t)blockIdx.x * 256;
+    if (base >= n) return;
+    double ax, ay, az, bx, by, bz;
+    {
+        const size_t i0 = base + threadIdx.x < n ? base + threadIdx.x : n - 1;
+        const size_t i1 = base + step + threadIdx.x < n ? base + step + threadIdx.x : n - 1;
+        ax = xyz[3 * i0], ay = xyz[3 * i0 + 1], az = xyz[3 * i0 + 2];
+        bx = xyz[3 * i1], by = xyz[3 * i1 + 1], bz = xyz[3 * i1 + 2];
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ax), "+v"(ay), "+v"(az), "+v"(bx), "+v"(by), "+v"(bz)::"memory");
+    }
+    for (;;) {
+        LAB_PIPE_BODY(ax, ay, az, base)
+        base += step;
+        if (base >= n) break;
+        LAB_PIPE_BODY(bx, by, bz, base)
+        base += step;
+        if (base >= n) break;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last prefetches must land before the registers are released
+}
+
+// The product's structure (8-lane rows, two passes) with s_memtime stamps: where a wave-iteration's time goes.
+// acc[0..4]: cycles from loop top to points arrived / codes + DMA pass 0 issued & landed / pass 1 landed / evaluated /
+// stored; acc[5]: iterations.  Summed over waves with atomics (diagnostic build only).
+template <int PF>
+__global__ __launch_bounds__(256, 6) void labTimed(Args a, const double* __restrict__ xyz, size_t n, double* __restrict__ out,
+                                                   unsigned long long* __restrict__ acc) {
+    __shared__ double2 sd[4][4][66];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, grp = lane & ~7, j = lane & 7;
+    const size_t step = (size_t)gridDim.x * 256;
+    unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, iters = 0;
+    const bool timed = (blockIdx.x & 63) == 0 && w == 0;  // one wave in 256 carries the stamps: the others run undisturbed
+#define STAMP() (timed ? __builtin_amdgcn_s_memtime() : 0ull)
+    const unsigned long long r0 = timed ? __builtin_amdgcn_s_memrealtime() : 0ull, c0 = STAMP();
+    double nx = 0, ny = 0, nz = 0;
+    if (PF) {
+        const size_t b0 = (size_t)blockIdx.x * 256;
+        const size_t i = b0 + threadIdx.x < n ? b0 + threadIdx.x : n - 1;
+        nx = xyz[3 * i], ny = xyz[3 * i + 1], nz = xyz[3 * i + 2];
+    }
+    for (size_t base = (size_t)blockIdx.x * 256; base < n; base += step) {
+        const unsigned long long s0 = STAMP();
+        double px, py, pz;
+        if (PF) {
+            // the prefetch of this tile's points was issued behind the previous tile's first four DMAs
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(nx), "+v"(ny), "+v"(nz)::"memory");
+            px = nx, py = ny, pz = nz;
+        } else {
+            const size_t i = base + threadIdx.x < n ? base + threadIdx.x : n - 1;
+            px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(px), "+v"(py), "+v"(pz)::"memory");
+        }
+        const unsigned long long s1 = STAMP();
+        uint32_t code;
+        double cx, cy, cz;
+        descend4(px, py, pz, code, cx, cy, cz);
+        uint32_t ck[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ck[k] = __shfl(code, grp | k, 64);
+        double cv[10];
+        unsigned long long s2 = 0, s3 = 0;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t off = (ck[half * 4 + k] << 7) + (uint32_t)j * 16u;
+                const char* src = reinterpret_cast<const char*>(a.fat) + off;
+                if (j < 6) __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src, (LDS_AS void*)&sd[w][k][0], 16, 0, 0);
+            }
+            if (PF && half == 0) {
+                const size_t nb = base + step;
+                const size_t ni = (nb + threadIdx.x < n) ? nb + threadIdx.x : n - 1;
+                const double* np = xyz + 3 * ni;
+                asm volatile("global_load_dwordx2 %0, %3, off\n\tglobal_load_dwordx2 %1, %3, off offset:8\n\tglobal_load_dwordx2 %2, %3, off offset:16"
+                             : "=&v"(nx), "=&v"(ny), "=&v"(nz) : "v"(np) : "memory");
+                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(nx), "+v"(ny), "+v"(nz)::"memory");
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (half == 0) s2 = STAMP(); else s3 = STAMP();
+            if ((j >> 2) == half) {
+                const double2* row = &sd[w][j & 3][grp];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    const double2 v = row[1 + q];
+                    cv[2 * q] = v.x, cv[2 * q + 1] = v.y;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        double r = eval2(cv, (px - cx) * 32.0, (py - cy) * 32.0, (pz - cz) * 32.0, a.nl);
+        asm volatile("" : "+v"(r));
+        const unsigned long long s4 = STAMP();
+        if (base + threadIdx.x < n) out[base + threadIdx.x] = r;
+        const unsigned long long s5 = STAMP();
+        tA += s1 - s0, tB += s2 - s1, tC += s3 - s2, tD += s4 - s3, tE += s5 - s4, ++iters;
+    }
+    const unsigned long long r1 = timed ? __builtin_amdgcn_s_memrealtime() : 0ull, c1 = STAMP();
+#undef STAMP
+    if (lane == 0 && timed) {
+        atomicAdd(acc + 0, tA), atomicAdd(acc + 1, tB), atomicAdd(acc + 2, tC), atomicAdd(acc + 3, tD), atomicAdd(acc + 4, tE);
+        atomicAdd(acc + 5, iters), atomicAdd(acc + 6, c1 - c0), atomicAdd(acc + 7, r1 - r0);
+    }
+}
+
 template <typename K>
 float timeIt(K launch, int reps) {
     hipEvent_t e0, e1;
@@ -413,7 +570,13 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(h.data(), dout, n * 8, hipMemcpyDeviceToHost));
         size_t bad = 0;
         if (ref.empty()) ref = h;
-        for (size_t i = 0; i < n; ++i) bad += (h[i] != ref[i]);
+        size_t shown = 0;
+        for (size_t i = 0; i < n; ++i) {
+            if (h[i] != ref[i]) {
+                if (shown < 6) printf("   mismatch at %zu (tile %zu, lane %zu): %.6g vs %.6g\n", i, i / 256, i % 256, h[i], ref[i]), ++shown;
+                ++bad;
+            }
+        }
         printf("%-58s grid %6d : %7.1f us  %7.1f GB/s alg  mismatches %zu\n", name, grid, ms * 1e3, 32.0 * n / ms / 1e6, bad);
         fflush(stdout);
     };
@@ -421,9 +584,43 @@ int main(int argc, char** argv) {
 #define RUN5(PS, P, g) check("5-lane rows (80 B)  passes=" #PS " pf=" #P, timeIt([&] { hipLaunchKernelGGL((lab5<PS, P>), dim3(g), dim3(256), 0, 0, a, dx, n, dout); }, 10), g)
     const char* only = argc > 2 ? argv[2] : "";
     (void)only;
-    for (int g : {4096, 8192, 16384}) {
+    {
+        unsigned long long* dacc;
+        CK(hipMalloc(&dacc, 8 * sizeof(unsigned long long)));
+        for (int gi = 0; gi < 6; ++gi) {
+            const int g = gi < 2 ? 8192 : (gi < 4 ? 8192 : 2048), pf = gi & 1;
+            CK(hipMemset(dacc, 0, 8 * sizeof(unsigned long long)));
+            hipEvent_t ev0, ev1;
+            CK(hipEventCreate(&ev0));
+            CK(hipEventCreate(&ev1));
+            CK(hipEventRecord(ev0));
+            if (pf)
+                hipLaunchKernelGGL(labTimed<1>, dim3(g), dim3(256), 0, 0, a, dx, n, dout, dacc);
+            else
+                hipLaunchKernelGGL(labTimed<0>, dim3(g), dim3(256), 0, 0, a, dx, n, dout, dacc);
+            CK(hipEventRecord(ev1));
+            CK(hipDeviceSynchronize());
+            float kms = 0;
+            CK(hipEventElapsedTime(&kms, ev0, ev1));
+            unsigned long long h8[8];
+            CK(hipMemcpy(h8, dacc, sizeof h8, hipMemcpyDeviceToHost));
+            const double it = (double)h8[5], mhz = (double)h8[6] / (double)h8[7] * 100.0;
+            printf("timed structure pf=%d, grid %d: clock %.0f MHz; per wave-iteration (cycles): points %.0f | pass 0 (codes, issue, wait) %.0f | pass 1 %.0f | "
+                   "LDS read + eval %.0f | store issue %.0f | total %.0f = %.2f us\n",
+                   pf, g, mhz, h8[0] / it, h8[1] / it, h8[2] / it, h8[3] / it, h8[4] / it, (h8[0] + h8[1] + h8[2] + h8[3] + h8[4]) / it,
+                   (h8[0] + h8[1] + h8[2] + h8[3] + h8[4]) / it / mhz);
+            const double tw = (g + 63) / 64;  // timed waves
+            printf("   kernel %.1f us by events; timed waves %.0f, iterations per wave %.2f, s_memtime ticks per wave %.0f (%.1f us)\n", kms * 1e3, tw,
+                   it / tw, (double)h8[6] / tw, (double)h8[6] / tw / mhz);
+        }
+        fflush(stdout);
+    }
+    for (int g : {8192}) {
         printf("grid %d\n", g);
         fflush(stdout);
+        RUN8(0, 0, 0, g);
+#define RUNP(MW, blocks) check("two point sets in flight (prefetch distance 2), min waves/SIMD=" #MW, timeIt([&] { hipLaunchKernelGGL((labPipe<MW>), dim3(blocks), dim3(256), 0, 0, a, dx, n, dout); }, 10), blocks)
+        RUNP(4, g);
         RUN8(0, 0, 0, g);
         RUN8(1, 0, 0, g);
         RUN8(0, 1, 0, g);
