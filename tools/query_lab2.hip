@@ -161,6 +161,75 @@ __global__ __launch_bounds__(256, 7) void lab8(Args a, const double* __restrict_
     }
 }
 
+// lab8 with the tile's points (1536 contiguous bytes) fetched line by line instead of three stride-24 loads that each
+// touch all 12 lines: PTS 1 = two dwordx4 LDS-DMA instructions (lane-linear), PTS 2 = dwordx4 to registers + ds_write.
+template <int PTS>
+__global__ __launch_bounds__(256, 7) void lab8D(Args a, const double* __restrict__ xyz, size_t n, double* __restrict__ out) {
+    __shared__ double2 sd[4][4][66];
+    __shared__ double2 sPts[4][96];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, grp = lane & ~7, j = lane & 7;
+    const size_t step = (size_t)gridDim.x * 256;
+    const uint32_t subOff = (uint32_t)j * 16u;
+    for (size_t base = (size_t)blockIdx.x * 256; base < n; base += step) {
+        const size_t tile = base + (size_t)w * 64;  // this wave's 64 points
+        double px, py, pz;
+        if (tile + 64 <= n) {
+            const char* src = reinterpret_cast<const char*>(xyz + 3 * tile) + lane * 16;
+            if (PTS == 1) {
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src, (LDS_AS void*)&sPts[w][0], 16, 0, 0);
+                if (lane < 32)
+                    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + 1024), (LDS_AS void*)&sPts[w][64], 16, 0, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                const double2 v0 = *reinterpret_cast<const double2*>(src);
+                double2 v1 = make_double2(0, 0);
+                if (lane < 32) v1 = *reinterpret_cast<const double2*>(src + 1024);
+                sPts[w][lane] = v0;
+                if (lane < 32) sPts[w][64 + lane] = v1;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const double* sp = reinterpret_cast<const double*>(&sPts[w][0]) + 3 * lane;
+            px = sp[0], py = sp[1], pz = sp[2];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            const size_t i = tile + lane < n ? tile + lane : n - 1;
+            px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+        }
+        uint32_t code;
+        double cx, cy, cz;
+        descend4(px, py, pz, code, cx, cy, cz);
+        uint32_t ck[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ck[k] = __shfl(code, grp | k, 64);
+        double cv[10];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t off = (ck[half * 4 + k] << 7) + subOff;
+                const char* src = reinterpret_cast<const char*>(a.fat) + off;
+                if (j < 6)
+                    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src, (LDS_AS void*)&sd[w][k][0], 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if ((j >> 2) == half) {
+                const double2* row = &sd[w][j & 3][grp];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    const double2 v = row[1 + q];
+                    cv[2 * q] = v.x, cv[2 * q + 1] = v.y;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        const double r = eval2(cv, (px - cx) * 32.0, (py - cy) * 32.0, (pz - cz) * 32.0, a.nl);
+        if (tile + lane < n) out[tile + lane] = r;
+    }
+}
+
 // 80-byte rows, 5 lanes per row, 12 rows per DMA instruction, 6 instructions per 64 points (one pass, 6.2 KB/wave)
 // or two passes of 3 (3.1 KB/wave).
 template <int PASSES, int PF>
@@ -292,6 +361,153 @@ __global__ __launch_bounds__(WAVES * 64) void lab64(Args64 a, const double* __re
     }
 }
 
+// lab64 with the points of the tile after next already in flight (one loop body, registers F -> N -> current as in
+// labPipe1): 16 waves per CU is all the 64 KB table leaves room for, so each wave has to keep more in flight.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void lab64P(Args64 a, const double* __restrict__ xyz, size_t n, double* __restrict__ out) {
+    extern __shared__ double2 smem[];
+    double2* sTail = smem;
+    double2* sWin = smem + 4096;
+    uint32_t* sCode = reinterpret_cast<uint32_t*>(sWin + WAVES * 4 * 66);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 4096; i += WAVES * 64) sTail[i] = a.tails[i];
+    __syncthreads();
+    const int rowInStep = lane >> 2, chunk = lane & 3;
+    const int myStep = lane >> 4, myRow = lane & 15;
+    const size_t step = (size_t)gridDim.x * WAVES * 64;
+    size_t base = (size_t)blockIdx.x * WAVES * 64;
+    if (base >= n) return;
+    double nx, ny, nz, fx, fy, fz;
+    {
+        const size_t i0 = base + threadIdx.x < n ? base + threadIdx.x : n - 1;
+        const size_t i1 = base + step + threadIdx.x < n ? base + step + threadIdx.x : n - 1;
+        nx = xyz[3 * i0], ny = xyz[3 * i0 + 1], nz = xyz[3 * i0 + 2];
+        fx = xyz[3 * i1], fy = xyz[3 * i1 + 1], fz = xyz[3 * i1 + 2];
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(nx), "+v"(ny), "+v"(nz), "+v"(fx), "+v"(fy), "+v"(fz)::"memory");
+    }
+    for (; base < n; base += step) {
+        const double px = nx, py = ny, pz = nz;
+        int kx, ky, kz;
+        double cx, cy, cz;
+        cellOf(px, kx, cx), cellOf(py, ky, cy), cellOf(pz, kz, cz);
+        const uint32_t code = (uint32_t)(kx + 16 * (ky + 16 * kz));
+        sCode[w * 64 + lane] = code;
+        __builtin_amdgcn_wave_barrier();
+        // the loads into F issued one iteration ago have had the whole iteration; they retire here, before this tile's
+        // rows are even asked for, and move to N -- so the rows' wait below covers nothing but the rows
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(fx), "+v"(fy), "+v"(fz)::"memory");
+        nx = fx, ny = fy, nz = fz;
+        asm volatile("" : "+v"(nx), "+v"(ny), "+v"(nz));
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const uint32_t ck = sCode[w * 64 + rowInStep + 16 * s];
+            const char* src = reinterpret_cast<const char*>(a.r64) + (ck << 6) + (uint32_t)chunk * 16u;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src, (LDS_AS void*)&sWin[(w * 4 + s) * 66], 16, 0, 0);
+        }
+        {
+            const size_t nb = base + 2 * step;
+            const size_t ni = (nb + threadIdx.x < n) ? nb + threadIdx.x : n - 1;
+            const double* np = xyz + 3 * ni;
+            asm volatile("global_load_dwordx2 %0, %3, off\n\tglobal_load_dwordx2 %1, %3, off offset:8\n\tglobal_load_dwordx2 %2, %3, off offset:16"
+                         : "=&v"(fx), "=&v"(fy), "=&v"(fz) : "v"(np) : "memory");
+        }
+        const double2 tail = sTail[code];
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        double cv[10];
+        const double2* row = &sWin[(w * 4 + myStep) * 66 + myRow * 4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double2 v = row[q];
+            cv[2 * q] = v.x, cv[2 * q + 1] = v.y;
+        }
+        cv[8] = tail.x, cv[9] = tail.y;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const double r = eval2(cv, (px - cx) * 32.0, (py - cy) * 32.0, (pz - cz) * 32.0, a.nl);
+        if (base + threadIdx.x < n) out[base + threadIdx.x] = r;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(fx), "+v"(fy), "+v"(fz)::"memory");
+}
+
+// lab64P with ONE wait per tile: the rows of tile i are asked for first (its points retired a tile ago), the points of
+// tile i + 2 go out right behind them into the registers tile i just vacated, and vmcnt(3) retires the rows together
+// with the points of tile i + 1 (older than the rows).  Two point sets are in flight, so the loop body exists twice.
+#define LAB64_BODY(PX, PY, PZ, TILE)                                                                                 \
+    {                                                                                                                \
+        const size_t tb_ = (TILE);                                                                                   \
+        int kx, ky, kz;                                                                                              \
+        double cx, cy, cz;                                                                                           \
+        cellOf(PX, kx, cx), cellOf(PY, ky, cy), cellOf(PZ, kz, cz);                                                  \
+        const double ux = (PX - cx) * 32.0, uy = (PY - cy) * 32.0, uz = (PZ - cz) * 32.0;                            \
+        const uint32_t code = (uint32_t)(kx + 16 * (ky + 16 * kz));                                                  \
+        sCode[w * 64 + lane] = code;                                                                                 \
+        __builtin_amdgcn_wave_barrier();                                                                             \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                              \
+            uint32_t ck = sCode[w * 64 + rowInStep + 16 * s];                                                        \
+            if (AUX == 100) ck &= 15u; /* experiment: every row an L1 hit (results wrong) */                         \
+            const char* src = reinterpret_cast<const char*>(a.r64) + (ck << 6) + (uint32_t)chunk * 16u;              \
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src, (LDS_AS void*)&sWin[(w * 4 + s) * 66], 16, 0, AUX == 100 ? 0 : AUX); \
+        }                                                                                                            \
+        {                                                                                                            \
+            const size_t nb = tb_ + 2 * step;                                                                        \
+            const size_t ni = (nb + threadIdx.x < n) ? nb + threadIdx.x : n - 1;                                     \
+            const double* np = xyz + 3 * ni;                                                                         \
+            asm volatile("global_load_dwordx2 %0, %3, off\n\tglobal_load_dwordx2 %1, %3, off offset:8\n\tglobal_load_dwordx2 %2, %3, off offset:16" \
+                         : "=&v"(PX), "=&v"(PY), "=&v"(PZ) : "v"(np) : "memory");                                    \
+        }                                                                                                            \
+        const double2 tail = sTail[code];                                                                            \
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                                             \
+        __builtin_amdgcn_wave_barrier();                                                                             \
+        double cv[10];                                                                                               \
+        const double2* row = &sWin[(w * 4 + myStep) * 66 + myRow * 4];                                               \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                              \
+            const double2 v = row[q];                                                                                \
+            cv[2 * q] = v.x, cv[2 * q + 1] = v.y;                                                                    \
+        }                                                                                                            \
+        cv[8] = tail.x, cv[9] = tail.y;                                                                              \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
+        __builtin_amdgcn_wave_barrier();                                                                             \
+        const double r = eval2(cv, ux, uy, uz, a.nl);                                                                \
+        if (tb_ + threadIdx.x < n) out[tb_ + threadIdx.x] = r;                                                       \
+    }
+
+template <int WAVES, int AUX>
+__global__ __launch_bounds__(WAVES * 64) void lab64P2(Args64 a, const double* __restrict__ xyz, size_t n, double* __restrict__ out) {
+    extern __shared__ double2 smem[];
+    double2* sTail = smem;
+    double2* sWin = smem + 4096;
+    uint32_t* sCode = reinterpret_cast<uint32_t*>(sWin + WAVES * 4 * 66);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 4096; i += WAVES * 64) sTail[i] = a.tails[i];
+    __syncthreads();
+    const int rowInStep = lane >> 2, chunk = lane & 3;
+    const int myStep = lane >> 4, myRow = lane & 15;
+    const size_t step = (size_t)gridDim.x * WAVES * 64;
+    size_t base = (size_t)blockIdx.x * WAVES * 64;
+    if (base >= n) return;
+    double ax, ay, az, bx, by, bz;
+    {
+        const size_t i0 = base + threadIdx.x < n ? base + threadIdx.x : n - 1;
+        const size_t i1 = base + step + threadIdx.x < n ? base + step + threadIdx.x : n - 1;
+        ax = xyz[3 * i0], ay = xyz[3 * i0 + 1], az = xyz[3 * i0 + 2];
+        bx = xyz[3 * i1], by = xyz[3 * i1 + 1], bz = xyz[3 * i1 + 2];
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ax), "+v"(ay), "+v"(az), "+v"(bx), "+v"(by), "+v"(bz)::"memory");
+    }
+    while (true) {
+        LAB64_BODY(ax, ay, az, base)
+        base += step;
+        if (base >= n) break;
+        // B's loads are older than the rows that wait just retired
+        asm volatile("" : "+v"(bx), "+v"(by), "+v"(bz));
+        LAB64_BODY(bx, by, bz, base)
+        base += step;
+        if (base >= n) break;
+        asm volatile("" : "+v"(ax), "+v"(ay), "+v"(az));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ax), "+v"(ay), "+v"(az), "+v"(bx), "+v"(by), "+v"(bz)::"memory");
+}
+
 // 64-byte rows as above, the (c8, c9) tails fetched by a fifth DMA step from a compact 64 KB global table (one lane
 // per point): two L2 sectors per point as today, but five DMA instructions, one wait, 5.2 KB of LDS per wave.
 template <int MINW>
@@ -408,6 +624,70 @@ __global__ __launch_bounds__(256, MINW) void labPipe(Args a, const double* __res
         if (base >= n) break;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last prefetches must land before the registers are released
+}
+
+// The same look-ahead with ONE loop body: the loads of tile i + 2 always target the registers F; they are retired by the
+// vmcnt(0) of tile i + 1's first batch, and only then copied to N (the "next" set), which becomes the current points
+// at the top of the following iteration.  A register is never read or moved while its load is in flight.
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void labPipe1(Args a, const double* __restrict__ xyz, size_t n, double* __restrict__ out) {
+    __shared__ double2 sd[4][4][66];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, grp = lane & ~7, j = lane & 7;
+    const size_t step = (size_t)gridDim.x * 256;
+    size_t base = (size_t)blockIdx.x * 256;
+    if (base >= n) return;
+    double nx, ny, nz, fx, fy, fz;
+    {
+        const size_t i0 = base + threadIdx.x < n ? base + threadIdx.x : n - 1;
+        const size_t i1 = base + step + threadIdx.x < n ? base + step + threadIdx.x : n - 1;
+        nx = xyz[3 * i0], ny = xyz[3 * i0 + 1], nz = xyz[3 * i0 + 2];
+        fx = xyz[3 * i1], fy = xyz[3 * i1 + 1], fz = xyz[3 * i1 + 2];
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(nx), "+v"(ny), "+v"(nz), "+v"(fx), "+v"(fy), "+v"(fz)::"memory");
+    }
+    for (; base < n; base += step) {
+        const double px = nx, py = ny, pz = nz;  // N is complete (copied from F behind a vmcnt(0), or the prologue)
+        uint32_t code;
+        double cx, cy, cz;
+        descend4(px, py, pz, code, cx, cy, cz);
+        const double ux = (px - cx) * 32.0, uy = (py - cy) * 32.0, uz = (pz - cz) * 32.0;
+        double cv[10];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t off = ((uint32_t)__shfl(code, grp | (half * 4 + k), 64) << 7) + (uint32_t)j * 16u;
+                const char* src = reinterpret_cast<const char*>(a.fat) + off;
+                if (j < 6) __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src, (LDS_AS void*)&sd[w][k][0], 16, 0, 0);
+            }
+            if (half == 0) {
+                // retires the first batch AND the loads into F issued during the previous iteration
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(fx), "+v"(fy), "+v"(fz)::"memory");
+                nx = fx, ny = fy, nz = fz;
+                asm volatile("" : "+v"(nx), "+v"(ny), "+v"(nz));
+            } else {
+                const size_t nb = base + 2 * step;
+                const size_t ni = (nb + threadIdx.x < n) ? nb + threadIdx.x : n - 1;
+                const double* np = xyz + 3 * ni;
+                asm volatile("global_load_dwordx2 %0, %3, off\n\tglobal_load_dwordx2 %1, %3, off offset:8\n\tglobal_load_dwordx2 %2, %3, off offset:16"
+                             : "=&v"(fx), "=&v"(fy), "=&v"(fz) : "v"(np) : "memory");
+                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            }
+            __builtin_amdgcn_wave_barrier();
+            if ((j >> 2) == half) {
+                const double2* row = &sd[w][j & 3][grp];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    const double2 v = row[1 + q];
+                    cv[2 * q] = v.x, cv[2 * q + 1] = v.y;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        const double r = eval2(cv, ux, uy, uz, a.nl);
+        if (base + threadIdx.x < n) out[base + threadIdx.x] = r;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(fx), "+v"(fy), "+v"(fz)::"memory");
 }
 
 // The product's structure (8-lane rows, two passes) with s_memtime stamps: where a wave-iteration's time goes.
@@ -562,6 +842,15 @@ int main(int argc, char** argv) {
     Args64 a64;
     a64.r64 = dr64, a64.tails = dtails;
     for (int j = 0; j < 3; ++j) a64.nl[j] = a.nl[j];
+    CK(hipFuncSetAttribute((const void*)lab64P2<16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void*)lab64P2<16, 100>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void*)lab64P2<16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void*)lab64P2<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void*)lab64P2<16, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void*)lab64P2<16, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void*)lab64P2<16, 17>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void*)lab64P2<16, 18>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void*)lab64P<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CK(hipFuncSetAttribute((const void*)lab64<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CK(hipFuncSetAttribute((const void*)lab64<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CK(hipFuncSetAttribute((const void*)lab64<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -620,9 +909,17 @@ int main(int argc, char** argv) {
         fflush(stdout);
         RUN8(0, 0, 0, g);
 #define RUNP(MW, blocks) check("two point sets in flight (prefetch distance 2), min waves/SIMD=" #MW, timeIt([&] { hipLaunchKernelGGL((labPipe<MW>), dim3(blocks), dim3(256), 0, 0, a, dx, n, dout); }, 10), blocks)
+#define RUNP1(MW, blocks) check("look-ahead 2, one loop body, min waves/SIMD=" #MW, timeIt([&] { hipLaunchKernelGGL((labPipe1<MW>), dim3(blocks), dim3(256), 0, 0, a, dx, n, dout); }, 10), blocks)
+        RUNP1(7, g);
+        RUNP1(6, g);
+        RUNP1(5, g);
+        RUNP1(4, g);
         RUNP(4, g);
         RUN8(0, 0, 0, g);
         RUN8(1, 0, 0, g);
+#define RUN8D(P, g) check("8-lane rows, points line by line, PTS=" #P, timeIt([&] { hipLaunchKernelGGL((lab8D<P>), dim3(g), dim3(256), 0, 0, a, dx, n, dout); }, 10), g)
+        RUN8D(1, g);
+        RUN8D(2, g);
         RUN8(0, 1, 0, g);
         RUN8(1, 1, 0, g);
 #define RUN64(W, blocks) check("64-B rows + LDS tails, waves/WG=" #W, timeIt([&] { hipLaunchKernelGGL((lab64<W>), dim3(blocks), dim3(W * 64), (4096 + W * 4 * 66) * 16 + W * 64 * 4, 0, a64, dx, n, dout); }, 10), blocks)
@@ -632,6 +929,16 @@ int main(int argc, char** argv) {
         RUN64T(6, g);
         RUN64(16, g / 4);
         RUN64(16, 256);
+#define RUN64P(W, blocks) check("64-B rows + LDS tails + points look-ahead, waves/WG=" #W, timeIt([&] { hipLaunchKernelGGL((lab64P<W>), dim3(blocks), dim3(W * 64), (4096 + W * 4 * 66) * 16 + W * 64 * 4, 0, a64, dx, n, dout); }, 10), blocks)
+#define RUN64P2(W, blocks) RUN64P2A(W, 0, blocks)
+#define RUN64P2A(W, AUX, blocks) check("64-B rows + LDS tails + two point sets in flight, one wait, waves/WG=" #W " aux=" #AUX, timeIt([&] { hipLaunchKernelGGL((lab64P2<W, AUX>), dim3(blocks), dim3(W * 64), (4096 + W * 4 * 66) * 16 + W * 64 * 4, 0, a64, dx, n, dout); }, 10), blocks)
+        RUN64P2(16, 256);
+        RUN64P2A(16, 100, 256);
+        RUN64P2(16, 1024);
+        RUN64P(16, 256);
+        RUN64P(16, 512);
+        RUN64P(16, 1024);
+        RUN64P(16, 2048);
         RUN5(1, 0, g);
         RUN5(2, 0, g);
         printf("\n");
