@@ -107,6 +107,7 @@ _SIGNATURES = {
                                  C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint64)]),
     "hpsdf_field_create_tree_csg": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "hpsdf_field_destroy": (C.c_int, [C.c_void_p]),
+    "hpsdf_field_mesh_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]),
     "hpsdf_field_eval_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hpsdf_field_eval_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hpsdf_tree_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -337,6 +338,12 @@ class Field:
         check(lib().hpsdf_field_eval_host(ctx.handle, self.handle, pts.ctypes.data_as(C.c_void_p), len(pts),
                                           out.ctypes.data_as(C.c_void_p)))
         return out
+
+    def mesh_stats(self, reset=True):
+        """BVH traversal counters (mesh fields created under HPSDF_MESH_STATS=1): queries, nodes, tri tests, lanes."""
+        out = (C.c_uint64 * 4)()
+        check(lib().hpsdf_field_mesh_stats(self.handle, out, 1 if reset else 0))
+        return dict(zip(("wave_queries", "node_visits", "tri_tests", "tri_test_lanes"), (int(v) for v in out)))
 
     def close(self):
         if self.handle:

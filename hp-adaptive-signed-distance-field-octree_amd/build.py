@@ -21,6 +21,8 @@ PUBLIC_HEADERS = ["hpsdf.h", "hpsdf_octree.hpp"]
 # -ffp-contract=off: no multiply-add is fused anywhere (bit parity with the x86-64 reference path)
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "--offload-arch=gfx950",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-I", INCLUDE]
+# diagnostic builds: HPSDF_EXTRA_FLAGS="-DHPSDF_MESH_STATS_BUILD" python build.py --force
+FLAGS += os.environ.get("HPSDF_EXTRA_FLAGS", "").split()
 
 
 def hipcc():

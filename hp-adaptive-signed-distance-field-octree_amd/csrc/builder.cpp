@@ -253,6 +253,10 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
     const Tables& T = tables();
     const hpsdf_build::Slice sl = b->slices[b->rank];
     const bool sampled = innermost(field)->kind == kHostCallback;
+    // Mesh fields are sampled by their own kernel, wave by wave, and fitted from the samples like a callback field;
+    // past kMeshSampleCap samples in one round the fit kernel samples for itself (one workgroup per cell).
+    constexpr uint64_t kMeshSampleCap = 1ull << 30;  // 8 GB of f64
+    bool meshSampled = innermost(field)->kind == kHostMesh;
 
     // ---- pass 1: count the fits of every shape.  A class = (degree, from-scratch | incremental, depth):
     //      all cells of a workgroup share these, so the kernel forms each basis product once.
@@ -273,6 +277,15 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
     std::vector<uint32_t> classFirst(kClasses + 1, 0);
     for (int c = 0; c < kClasses; ++c) classFirst[c + 1] = classFirst[c] + classCount[c];
     const uint32_t nTasks = classFirst[kClasses];
+    if (meshSampled) {
+        uint64_t need = 0;
+        for (int c = 0; c < kClasses; ++c) {
+            const uint64_t nq = 4 * (uint64_t)(c / kDepths / 2) + 1;
+            need += classCount[c] * nq * nq * nq;
+        }
+        meshSampled = need <= kMeshSampleCap;
+    }
+    const bool meshFused = innermost(field)->kind == kHostMesh && !meshSampled;
 
     // ---- workgroup table
     uint32_t nBlocks = 0;
@@ -284,7 +297,7 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
         const int deg = c / kDepths / 2;
         const bool incr = (c / kDepths) & 1;
         const int nrows = incr ? (int)(T.coeffCount[deg] - T.coeffCount[deg - 1]) : (int)T.coeffCount[deg];
-        classShape[c] = fitShape(deg, nrows, classCount[c], b->weighted, innermost(field)->kind == kHostMesh);
+        classShape[c] = fitShape(deg, nrows, classCount[c], b->weighted, meshFused);
         nBlocks += (classCount[c] + classShape[c].cells - 1) / classShape[c].cells;
     }
     classBlockFirst[kClasses] = nBlocks;
@@ -448,6 +461,26 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
     if (nTasks) {
         HPSDF_HIP(hipMemcpyAsync(ws.tasks.dev, ws.tasks.host, nTasks * sizeof(FitTask), hipMemcpyHostToDevice, ctx->stream));
         HPSDF_HIP(hipMemcpyAsync(ws.blocks.dev, ws.blocks.host, nBlocks * sizeof(FitBlock), hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (meshSampled && nTasks) {
+        if (sampleNeed > ws.meshSamplesCap) {
+            uint64_t nc = std::max<uint64_t>(ws.meshSamplesCap * 2, 1ull << 22);
+            while (nc < sampleNeed) nc *= 2;
+            HPSDF_HIP(hipStreamSynchronize(ctx->stream));  // an earlier round's kernels may still read the old buffer
+            if (ws.meshSamples) HPSDF_HIP(hipFree(ws.meshSamples));
+            ws.meshSamples = nullptr, ws.meshSamplesCap = 0;
+            HPSDF_HIP(hipMalloc((void**)&ws.meshSamples, nc * sizeof(double)));
+            ws.meshSamplesCap = nc;
+        }
+        // the tasks of one degree are contiguous (classes are ordered degree-major)
+        for (int deg = 0; deg <= kMaxDegree; ++deg) {
+            const uint32_t first = classFirst[classOf(deg, false, 0)];
+            const uint32_t last = deg == kMaxDegree ? nTasks : classFirst[classOf(deg + 1, false, 0)];
+            if (last > first)
+                HPSDF_HIP(launchMeshSample(ctx->stream, ws.tasks.dev + first, last - first, deg, ctx->dTables, fd, rm, ws.meshSamples));
+        }
+        fd.kind = kFieldSamples;  // the fit reads what the sampler wrote (a csg wrapper still applies on top)
+        fd.samples = ws.meshSamples;
     }
     HPSDF_HIP(hipMemsetAsync(ws.errs.dev, 0, (b->weighted ? 2 : 1) * nSlots * sizeof(double), ctx->stream));
     // one launch per shape class: the degree is a compile-time constant of the kernel

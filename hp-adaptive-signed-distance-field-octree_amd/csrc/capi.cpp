@@ -67,9 +67,11 @@ int makeFieldDev(const hpsdf_field* f, const double* dSamples, FieldDev* out) {
             out->mesh.verts = f->dVerts;
             out->mesh.tris = f->dTris;
             out->mesh.halfEdges = f->dHalfEdges;
+            out->mesh.triPos = f->dTriPos;
             out->mesh.bvh = f->dBvh;
             out->mesh.nTris = f->nTris;
             out->mesh.nNodes = f->nBvhNodes;
+            out->mesh.stats = f->dStats;
             break;
         default:
             return fail(HPSDF_ERR_INVALID_ARGUMENT, "unknown field kind");
@@ -342,8 +344,19 @@ int hpsdf_field_create_mesh(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts,
     };
     hipError_t e = up((void**)&f->dVerts, hm.verts.data(), hm.verts.size() * sizeof(float));
     if (e == hipSuccess) e = up((void**)&f->dTris, hm.tris.data(), hm.tris.size() * sizeof(uint32_t));
+    if (e == hipSuccess) {
+        std::vector<float> triPos(hm.tris.size() * 3);
+        for (size_t i = 0; i < hm.tris.size(); ++i) std::memcpy(&triPos[3 * i], &hm.verts[3 * (size_t)hm.tris[i]], 3 * sizeof(float));
+        e = up((void**)&f->dTriPos, triPos.data(), triPos.size() * sizeof(float));
+    }
     if (e == hipSuccess) e = up((void**)&f->dHalfEdges, hm.halfEdges.data(), hm.halfEdges.size() * sizeof(uint32_t));
     if (e == hipSuccess) e = up((void**)&f->dBvh, hm.bvh.data(), hm.bvh.size() * sizeof(BvhNode));
+#ifdef HPSDF_MESH_STATS_BUILD
+    if (e == hipSuccess && std::getenv("HPSDF_MESH_STATS")) {
+        e = hipMalloc((void**)&f->dStats, 4 * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMemset(f->dStats, 0, 4 * sizeof(unsigned long long));
+    }
+#endif
     if (e != hipSuccess) {
         hpsdf_field_destroy(f);
         return hipFail(e, "mesh upload");
@@ -398,11 +411,25 @@ int hpsdf_field_destroy(hpsdf_field* f) {
         (void)hipSetDevice(f->device);
         if (f->dVerts) (void)hipFree(f->dVerts);
         if (f->dTris) (void)hipFree(f->dTris);
+        if (f->dTriPos) (void)hipFree(f->dTriPos);
         if (f->dHalfEdges) (void)hipFree(f->dHalfEdges);
         if (f->dBvh) (void)hipFree(f->dBvh);
+        if (f->dStats) (void)hipFree(f->dStats);
     }
     delete f;
     return HPSDF_OK;
+}
+
+int hpsdf_field_mesh_stats(const hpsdf_field* f, uint64_t out[4], int reset) {
+    HPSDF_TRY
+    if (!f || !out || f->kind != kHostMesh) return fail(HPSDF_ERR_INVALID_ARGUMENT, "not a mesh field");
+    if (!f->dStats) return fail(HPSDF_ERR_UNSUPPORTED, "traversal counters need a diagnostic build (-DHPSDF_MESH_STATS_BUILD) and HPSDF_MESH_STATS=1");
+    HPSDF_HIP(hipSetDevice(f->device));
+    HPSDF_HIP(hipDeviceSynchronize());
+    HPSDF_HIP(hipMemcpy(out, f->dStats, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (reset) HPSDF_HIP(hipMemset(f->dStats, 0, 4 * sizeof(uint64_t)));
+    return HPSDF_OK;
+    HPSDF_CATCH
 }
 
 int hpsdf_field_eval_device(hpsdf_ctx* ctx, const hpsdf_field* f, const double* dXyz, size_t n, double* dOut) {

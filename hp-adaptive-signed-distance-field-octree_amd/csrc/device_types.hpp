@@ -65,9 +65,14 @@ static_assert(sizeof(BvhNode) == 64, "one line per node");
 struct MeshDev {
     const float* verts;        // xyz per vertex
     const uint32_t* tris;      // 3 vertex ids per triangle
+    const float* triPos;       // the 9 vertex coordinates of every triangle, gathered: a closest-point test is ONE
+                               // fetch instead of a chain of index -> vertex fetches (same values, same arithmetic)
     const uint32_t* halfEdges; // twin half-edge per half-edge (Mesh.h:74)
     const BvhNode* bvh;        // node 0 is the root
     uint32_t nTris, nNodes;
+    // traversal statistics (diagnostic builds, -DHPSDF_MESH_STATS_BUILD, and the field created under HPSDF_MESH_STATS=1):
+    // [0] wave-wide queries, [1] nodes visited by them, [2] triangle tests issued (wave level), [3] lanes that ran one
+    unsigned long long* stats;
 };
 
 // What the fit kernel evaluates at a sample point (world coordinates).

@@ -182,8 +182,8 @@ __device__ float meshSignedDistance(const MeshDev& m, V3 pt, uint32_t& hint) {
     V3 bestQ = {0.0f, 0.0f, 0.0f};
     auto visitTri = [&](uint32_t t) {
         V3 q;
-        const int code =
-            closestSimplex(pt, meshVert(m, m.tris[3 * t]), meshVert(m, m.tris[3 * t + 1]), meshVert(m, m.tris[3 * t + 2]), q);
+        const float* tp = m.triPos + 9 * (size_t)t;
+        const int code = closestSimplex(pt, V3{tp[0], tp[1], tp[2]}, V3{tp[3], tp[4], tp[5]}, V3{tp[6], tp[7], tp[8]}, q);
         const float d = sqnorm(pt - q);
         if (d < best || (d == best && t < bestTri)) {
             best = d;
@@ -256,8 +256,8 @@ __device__ float meshSignedDistanceWave(const MeshDev& m, V3 pt, bool active, ui
     V3 bestQ = {0.0f, 0.0f, 0.0f};
     auto visitTri = [&](uint32_t t) {
         V3 q;
-        const int code =
-            closestSimplex(pt, meshVert(m, m.tris[3 * t]), meshVert(m, m.tris[3 * t + 1]), meshVert(m, m.tris[3 * t + 2]), q);
+        const float* tp = m.triPos + 9 * (size_t)t;
+        const int code = closestSimplex(pt, V3{tp[0], tp[1], tp[2]}, V3{tp[3], tp[4], tp[5]}, V3{tp[6], tp[7], tp[8]}, q);
         const float d = sqnorm(pt - q);
         if (d < best || (d == best && t < bestTri)) {
             best = d;
@@ -277,10 +277,16 @@ __device__ float meshSignedDistanceWave(const MeshDev& m, V3 pt, bool active, ui
     const int lane = threadIdx.x & 63;
     int sp = 1;  // wave-uniform
     if (lane == 0) stack[0] = 0;
+#ifdef HPSDF_MESH_STATS_BUILD
+    unsigned nVisits = 0, nTriInstr = 0, nTriLanes = 0;
+#endif
     while (sp > 0) {
         --sp;
         const int32_t ni = __builtin_amdgcn_readfirstlane(stack[sp]);
         const BvhNode n = m.bvh[ni];
+#ifdef HPSDF_MESH_STATS_BUILD
+        ++nVisits;
+#endif
         const float d0 = boxDist(n.lo0, n.hi0), d1 = boxDist(n.lo1, n.hi1);
         const bool w0 = worthIt(d0), w1 = worthIt(d1);
         const unsigned long long b0 = __ballot(w0), b1 = __ballot(w1);
@@ -289,9 +295,15 @@ __device__ float meshSignedDistanceWave(const MeshDev& m, V3 pt, bool active, ui
         // for the first lane that wants it on top
         if (n.c0 < 0) {
             if (w0) visitTri((uint32_t)~n.c0);
+#ifdef HPSDF_MESH_STATS_BUILD
+            if (m.stats && b0) ++nTriInstr, nTriLanes += (unsigned)__popcll(b0);
+#endif
         }
         if (n.c1 < 0) {
             if (w1 && worthIt(d1)) visitTri((uint32_t)~n.c1);
+#ifdef HPSDF_MESH_STATS_BUILD
+            if (m.stats && b1) ++nTriInstr, nTriLanes += (unsigned)__popcll(b1);
+#endif
         }
         const bool push0 = n.c0 >= 0 && b0 != 0ull, push1 = n.c1 >= 0 && b1 != 0ull;
         if (push0 && push1) {
@@ -312,6 +324,12 @@ __device__ float meshSignedDistanceWave(const MeshDev& m, V3 pt, bool active, ui
             }
         }
     }
+#ifdef HPSDF_MESH_STATS_BUILD  // a global atomic in the kernel makes every BVH fetch a vector load: diagnostic builds only
+    if (m.stats && lane == 0) {
+        atomicAdd(m.stats + 0, 1ull), atomicAdd(m.stats + 1, (unsigned long long)nVisits);
+        atomicAdd(m.stats + 2, (unsigned long long)nTriInstr), atomicAdd(m.stats + 3, (unsigned long long)nTriLanes);
+    }
+#endif
     float r = 0.0f;
     if (active) {
         hint = bestTri;
@@ -1214,6 +1232,31 @@ __global__ __launch_bounds__(256) void field_kernel(FieldDev f, const DeviceTabl
 
 constexpr int kFitThreads = 256;
 
+// Mesh fields: the order in which the np x nq x nq samples of a chunk are handed to the lanes.  A wave answers its 64
+// closest-triangle queries with ONE traversal whose cost is the union of what its lanes need, so the 64 samples should
+// sit close together: the chunk is cut into 4 x 4 x 4 blocks (smaller at the upper edges), blocks in (i, j, k) order,
+// samples inside a block likewise -- in SPACE, not in index: the Gauss-Legendre tables list their roots as 0, -a, +a, ...
+// (Legendre.h), so posI / posJK map a position along the axis (ascending coordinate) to the root's index (posI: among
+// the chunk's np planes).  Returns the sample (il * nq + j) * nq + k that position r of that order holds.
+// Every sample's value is independent of its companions (pruning is per lane), so this is a pure scheduling choice.
+__device__ __forceinline__ int meshSampleOrder(int r, int np, int nq, const unsigned char* posI, const unsigned char* posJK) {
+    const int nq2 = nq * nq;
+    const int nbi = (np + 3) >> 2, nbj = (nq + 3) >> 2;
+    int bi = min(r / (4 * nq2), nbi - 1);
+    r -= bi * 4 * nq2;
+    const int di = min(4, np - 4 * bi);
+    const int strip = di * 4 * nq;
+    int bj = min(r / strip, nbj - 1);
+    r -= bj * strip;
+    const int dj = min(4, nq - 4 * bj);
+    const int blk = di * dj * 4;
+    int bk = min(r / blk, nbj - 1);
+    r -= bk * blk;
+    const int dk = min(4, nq - 4 * bk);
+    const int a = r / (dj * dk), rest = r - a * (dj * dk), b = rest / dk, c = rest - b * dk;
+    return ((int)posI[4 * bi + a] * nq + (int)posJK[4 * bj + b]) * nq + (int)posJK[4 * bk + c];
+}
+
 __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -1250,6 +1293,7 @@ __global__ __launch_bounds__(kFitThreads) void fit_kernel(const FitBlock* __rest
     __shared__ double sNl[13 * 11];
     __shared__ double sRec[26];
     __shared__ int32_t sMeshStack[kFitThreads / 64][kMeshStack];  // per-wave traversal stacks (mesh fields)
+    __shared__ unsigned char sPosI[KIND == kFieldMesh ? 64 : 4], sPosJK[KIND == kFieldMesh ? 64 : 4];  // meshSampleOrder
     const FitBlock blk = blocks[blockIdx.x];
     const int tid = threadIdx.x;
     const int deg = DEG > 0 ? DEG : (int)blk.degree;
@@ -1327,6 +1371,20 @@ __global__ __launch_bounds__(kFitThreads) void fit_kernel(const FitBlock* __rest
     for (int iBase = 0; iBase < nq; iBase += planes) {
         const int np = min(planes, nq - iBase);
         // ---- phase 1: F on planes [iBase, iBase+np) of every cell (:1035-1040)
+        if constexpr (KIND == kFieldMesh) {  // position -> root index by rank (roots are distinct), nq <= 49
+            if (tid < nq) {
+                int rank = 0;
+                for (int b = 0; b < nq; ++b) rank += sR[b] < sR[tid] ? 1 : 0;
+                sPosJK[rank] = (unsigned char)tid;
+            }
+            if (tid >= 64 && tid < 64 + np) {
+                const int a = tid - 64;
+                int rank = 0;
+                for (int b = 0; b < np; ++b) rank += sR[iBase + b] < sR[iBase + a] ? 1 : 0;
+                sPosI[rank] = (unsigned char)a;
+            }
+            __syncthreads();
+        }
         const int chunkSamples = np * nq2, total = G * chunkSamples;
         const float invChunk = 1.0f / (float)chunkSamples;
         for (int s0 = 0; s0 < total; s0 += kFitThreads) {  // every lane iterates (the mesh path works wave-wide)
@@ -1343,6 +1401,7 @@ __global__ __launch_bounds__(kFitThreads) void fit_kernel(const FitBlock* __rest
                 ++g;
                 rem -= chunkSamples;
             }
+            if constexpr (KIND == kFieldMesh) rem = meshSampleOrder(rem, np, nq, sPosI, sPosJK);
             const double* c = sC + 8 * g;
             const int il = rem / nq2, jk = rem - il * nq2, j = jk / nq, k = jk - j * nq, i = iBase + il;
             const double ux = sR[i] * c[0] + c[3], uy = sR[j] * c[1] + c[4], uz = sR[k] * c[2] + c[5];
@@ -1537,6 +1596,60 @@ FitShape fitShape(int degree, int nrows, uint32_t count, bool weighted, bool lat
         sh.ldsBytes = fitLdsBytes(degree, sh.cells, sh.planes);
     }
     return sh;
+}
+
+// Mesh fields, first half of a round: F at every sample of every fit, written where fit_kernel<kFieldSamples> reads it
+// (FitTask::sampleOff + (i nq + j) nq + k).  A closest-triangle traversal costs anything between a few dozen and tens
+// of thousands of steps depending on where the cell lies, so sampling inside the fit kernel (one workgroup per cell)
+// left the chip a quarter full behind the expensive cells; here the unit of work is one wave = 64 samples that sit
+// next to each other (meshSampleOrder over the whole grid), a workgroup is four of them, the hardware deals them out,
+// and without the fit's accumulators twice as many waves fit on a CU.  grid = (ceil(nq^3 / 256), tasks of one degree).
+__global__ __launch_bounds__(256) void mesh_sample_kernel(const FitTask* __restrict__ tasks, int degree,
+                                                          const DeviceTables* __restrict__ T, MeshDev mesh, RootMap rm,
+                                                          double* __restrict__ samples) {
+    __shared__ int32_t sStack[4][kMeshStack];
+    __shared__ double sR[64];
+    __shared__ unsigned char sPos[64];
+    const int tid = threadIdx.x, nq = 4 * degree + 1, gl = nq * (nq - 1) / 2, total = nq * nq * nq;
+    if (tid < nq) sR[tid] = T->roots[gl + tid];
+    __syncthreads();
+    if (tid < nq) {
+        int rank = 0;
+        for (int b = 0; b < nq; ++b) rank += sR[b] < sR[tid] ? 1 : 0;
+        sPos[rank] = (unsigned char)tid;
+    }
+    __syncthreads();
+    const FitTask& tk = tasks[blockIdx.y];
+    const int r = (int)blockIdx.x * 256 + tid;
+    const bool active = r < total;
+    const int rem = meshSampleOrder(active ? r : total - 1, nq, nq, sPos, sPos);
+    const int i = rem / (nq * nq), jk = rem - i * nq * nq, j = jk / nq, k = jk - j * nq;
+    double w[3];
+    const int idx[3] = {i, j, k};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double sc = (double)(tk.bmax[a] - tk.bmin[a]) * 0.5;       // Octree.cpp:1020 sizes() in f32
+        const double ce = (double)((tk.bmin[a] + tk.bmax[a]) / 2.0f);     // :1021 center() in f32
+        const double u = sR[idx[a]] * sc + ce;                            // :1035-1037
+        w[a] = u * rm.bounds[a] + rm.centre[a];                           // :327
+    }
+    uint32_t hint = 0xFFFFFFFFu;
+    const float mv = meshSignedDistanceWave(mesh, V3{(float)w[0], (float)w[1], (float)w[2]}, active, hint, sStack[tid >> 6]);
+    if (active) samples[tk.sampleOff + (uint64_t)rem] = (double)mv;
+}
+
+hipError_t launchMeshSample(hipStream_t stream, const FitTask* dTasks, uint32_t nTasks, int degree, const DeviceTables* dTables,
+                            const FieldDev& field, const RootMap& rm, double* dSamples) {
+    if (nTasks == 0) return hipSuccess;
+    if (degree < 1 || degree > 12 || field.kind != kFieldMesh) return hipErrorInvalidValue;
+    const int nq = 4 * degree + 1;
+    const unsigned gx = (unsigned)((nq * nq * nq + 255) / 256);
+    for (uint32_t first = 0; first < nTasks; first += 65535u) {
+        const uint32_t n = nTasks - first < 65535u ? nTasks - first : 65535u;
+        hipLaunchKernelGGL(mesh_sample_kernel, dim3(gx, n), dim3(256), 0, stream, dTasks + first, degree, dTables, field.mesh, rm,
+                           dSamples);
+    }
+    return hipGetLastError();
 }
 
 template <int KIND, bool CSG>

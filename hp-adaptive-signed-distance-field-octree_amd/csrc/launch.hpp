@@ -36,6 +36,9 @@ hipError_t launchSlicePoints(hipStream_t stream, double c, float minX, float min
                              double* dXyz);
 hipError_t launchFieldEval(hipStream_t stream, const FieldDev& f, const DeviceTables* dTables, const double* dXyz,
                            size_t n, double* dOut);
+// mesh fields: F at every sample of nTasks fits of one degree -> dSamples[FitTask::sampleOff + sample]
+hipError_t launchMeshSample(hipStream_t stream, const FitTask* dTasks, uint32_t nTasks, int degree, const DeviceTables* dTables,
+                            const FieldDev& field, const RootMap& rm, double* dSamples);
 hipError_t launchPack(hipStream_t stream, const PackItem* dItems, uint32_t nItems, const double* dArena, double* dOut);
 
 }  // namespace hpsdf

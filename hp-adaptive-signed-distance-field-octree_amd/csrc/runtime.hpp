@@ -47,6 +47,8 @@ struct Workspace {
     Staged<FitBlock> blocks;
     Staged<double> errs;
     Staged<double> samples;
+    double* meshSamples = nullptr;  // mesh fields: the round's F values (device only)
+    uint64_t meshSamplesCap = 0;
     Staged<double> pack;
     Staged<PackItem> items;
     void release() {
@@ -58,6 +60,9 @@ struct Workspace {
         blocks.release();
         errs.release();
         samples.release();
+        if (meshSamples) (void)hipFree(meshSamples);
+        meshSamples = nullptr;
+        meshSamplesCap = 0;
         pack.release();
         items.release();
     }
@@ -110,9 +115,11 @@ struct hpsdf_field {
     int device = -1;
     float* dVerts = nullptr;
     uint32_t* dTris = nullptr;
+    float* dTriPos = nullptr;
     uint32_t* dHalfEdges = nullptr;
     hpsdf::BvhNode* dBvh = nullptr;
     uint32_t nTris = 0, nVerts = 0, nBvhNodes = 0;
+    unsigned long long* dStats = nullptr;  // 4 counters, only under HPSDF_MESH_STATS=1
     // csg wrapper
     const hpsdf_tree* oldTree = nullptr;
     int csgOp = -1;

@@ -145,6 +145,11 @@ HPSDF_API int hpsdf_field_destroy(hpsdf_field* f);
 HPSDF_API int hpsdf_field_eval_device(hpsdf_ctx* ctx, const hpsdf_field* f, const double* d_xyz, size_t n,
                                       double* d_out);
 HPSDF_API int hpsdf_field_eval_host(hpsdf_ctx* ctx, const hpsdf_field* f, const double* xyz, size_t n, double* out);
+/* Diagnostics (no reference counterpart; HPSDF_ERR_UNSUPPORTED unless the library was built with
+ * -DHPSDF_MESH_STATS_BUILD): BVH traversal counters of a mesh field created while the environment
+ * variable HPSDF_MESH_STATS was set -- out[0] wave-wide closest-triangle queries, [1] BVH nodes they visited,
+ * [2] triangle tests issued, [3] lanes that ran one.  Synchronises the device; reset != 0 zeroes the counters. */
+HPSDF_API int hpsdf_field_mesh_stats(const hpsdf_field* f, uint64_t out[4], int reset);
 
 /* ---- Query: Octree::FromMemoryBlock + Octree::Query (Octree.cpp:403-421, 662-702, 859-901) */
 /* block layout: [u64 nCoeffs][f64 x nCoeffs][u64 nNodes][hpsdf_node x nNodes][hpsdf_config] */

@@ -1,0 +1,27 @@
+#!/bin/bash
+# SQ counters of the mesh-field fit kernel (tools/mesh_probe.py <level>).  Usage: bash tools/mesh_pmc.sh <tag> <level>
+TAG=${1:-mesh}; LEVEL=${2:-8}
+OUT=$PWD/gpurun_out/pmcm_$TAG
+mkdir -p $OUT
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+cd /tmp && export TMPDIR=/tmp
+i=0
+for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY" \
+         "SQ_WAIT_ANY SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE SQ_THREAD_CYCLES_VALU"; do
+  i=$((i+1))
+  rocprofv3 --pmc $C --output-format csv -d $OUT/p$i -- python3 $REPO/tools/mesh_probe.py $LEVEL > $OUT/log$i.txt 2>&1
+done
+cd $REPO && python3 - "$OUT" <<'PY'
+import csv, glob, os, sys
+out = sys.argv[1]
+acc = {}
+for f in glob.glob(os.path.join(out, "**/*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "fit_kernel<2" not in r["Kernel_Name"]:
+            continue
+        acc.setdefault((r["Kernel_Name"][:40], r["Counter_Name"]), []).append(float(r["Counter_Value"]))
+for k in sorted(acc):
+    v = acc[k]
+    print("%-42s %-26s n=%d avg %.4g max %.4g" % (k[0], k[1], len(v), sum(v) / len(v), max(v)))
+PY
+tail -2 $OUT/log1.txt

@@ -16,7 +16,14 @@ for level in (int(a) for a in sys.argv[1:] or ["5", "7", "8"]):
     t2 = time.time(); f = H.Field.mesh(ctx, verts, tris); t3 = time.time()
     cfg = H.make_config(1e-5, tuple(lo), tuple(hi))
     blk, st = H.create_block(ctx, cfg, f, 1024); t4 = time.time()
+    if os.environ.get("HPSDF_MESH_STATS"):
+        f.mesh_stats()
     blk, st = H.create_block(ctx, cfg, f, 1024); t5 = time.time()
+    if os.environ.get("HPSDF_MESH_STATS"):
+        ms = f.mesh_stats()
+        q = max(1, ms["wave_queries"])
+        print("   traversal: %d wave queries, %.0f nodes, %.0f triangle tests (%.1f lanes each) per query"
+              % (q, ms["node_visits"] / q, ms["tri_tests"] / q, ms["tri_test_lanes"] / max(1, ms["tri_tests"])))
     pts = np.random.default_rng(1).uniform(lo, hi, (1_000_000, 3))
     t6 = time.time(); v = f.eval(ctx, pts); t7 = time.time()
     print("icosphere L%d: %d tris | gen %.1fs | prepare (half-edges+BVH+upload) %.2fs | Create 1e-5: %.1f ms (first %.1f ms) "
