@@ -256,7 +256,12 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
     // Mesh fields are sampled by their own kernel, wave by wave, and fitted from the samples like a callback field;
     // past kMeshSampleCap samples in one round the fit kernel samples for itself (one workgroup per cell).
     constexpr uint64_t kMeshSampleCap = 1ull << 30;  // 8 GB of f64
+    // (HPSDF_MESH_FUSED=1 forces that path: the two must build identical trees, tests/test_gpu_parity.py)
     bool meshSampled = innermost(field)->kind == kHostMesh;
+    if (meshSampled) {
+        const char* e = std::getenv("HPSDF_MESH_FUSED");
+        if (e && e[0] == '1') meshSampled = false;
+    }
 
     // ---- pass 1: count the fits of every shape.  A class = (degree, from-scratch | incremental, depth):
     //      all cells of a workgroup share these, so the kernel forms each basis product once.

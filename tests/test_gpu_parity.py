@@ -309,6 +309,24 @@ def test_create_on_reference_mesh(H, ctx):
     assert blk2 == t.ToMemoryBlock()  # run-to-run deterministic
 
 
+def test_mesh_sampling_paths_build_identical_trees(H, ctx, monkeypatch):
+    """Mesh fields are sampled by mesh_sample_kernel and fitted from the samples; past 2^30 samples per round the fit
+    kernel samples for itself (HPSDF_MESH_FUSED=1 forces that).  Same samples, same fit: byte-identical blocks,
+    with refinement rounds (1e-7: 11 rounds, H and P fits of degrees 2-3) and with a csg wrapper on top."""
+    verts, tris = icosphere(3, 0.3)
+    f = H.Field.mesh(ctx, verts, tris)
+    cfg = H.make_config(1e-7)
+    blk_a, st_a = H.create_block(ctx, cfg, f, 256)
+    base = H.DeviceTree(ctx, H.create_block(ctx, H.make_config(1e-4), H.Field.union3(), 1024)[0])
+    csg = H.Field.tree_csg(base, H.OP_UNION, f)
+    blk_c, _ = H.create_block(ctx, H.make_config(1e-5), csg, 1024)
+    monkeypatch.setenv("HPSDF_MESH_FUSED", "1")
+    blk_b, st_b = H.create_block(ctx, cfg, f, 256)
+    blk_d, _ = H.create_block(ctx, H.make_config(1e-5), csg, 1024)
+    assert st_a["rounds"] > 1 and st_a["jobs"] == st_b["jobs"]
+    assert blk_a == blk_b and blk_c == blk_d
+
+
 # ------------------------------------------------------------------ nearness weighting (SURVEY 8 a-W)
 @pytest.mark.parametrize("wtype,target", [(1, 1e-8), (2, 1e-10)])
 def test_weighted_create_matches_oracle(H, O, ctx, wtype, target):
