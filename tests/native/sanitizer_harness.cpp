@@ -25,6 +25,9 @@ FitShape fitShape(int, int, uint32_t, bool, bool) { return FitShape{1, 1, 1, 0};
 hipError_t launchFit(hipStream_t, int, int, const FitBlock*, uint32_t, size_t, const FitTask*, double*, double*, double*,
                      const DeviceTables*, const FieldDev&, const RootMap&) { return hipErrorNoDevice; }
 hipError_t launchPack(hipStream_t, const PackItem*, uint32_t, const double*, double*) { return hipErrorNoDevice; }
+hipError_t launchMeshSample(hipStream_t, const FitTask*, uint32_t, int, const DeviceTables*, const FieldDev&, const RootMap&, double*) {
+    return hipErrorNoDevice;
+}
 }
 
 // The host round scheduler (builder.cpp) driven through its injection hook: two simulated ranks, synthetic errors that
