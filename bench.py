@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--fit-bench", action="store_true", help="also run the steady-state fit micro-benchmark")
     ap.add_argument("--no-refined", action="store_true",
                     help="skip the extra Query / QueryWithGradient timings on the refined tree (union3 @ 1e-7)")
+    ap.add_argument("--mesh-level", type=int, default=7,
+                    help="also time Create() on a mesh field (BASELINE configs 3-5 shape): bumpy icosphere of this "
+                         "subdivision level (7 = 327 680 triangles); 0 = skip")
     ap.add_argument("--sorted-ceiling", action="store_true",
                     help="also time Query on the same points sorted by depth-4 cell (locality ceiling, SURVEY 8d)")
     args = ap.parse_args()
@@ -209,6 +212,34 @@ def main():
             refined["_got"] = got_r
             del d_grad, d_out2
 
+        mesh = None
+        if args.mesh_level > 0 and rank == 0:
+            # BASELINE configs 3-5 in shape: a closed triangle mesh as the field, root = mesh box, targetError 1e-5.
+            # dragon.obj / Ramesses.obj are not in the reference mount: a procedural bumpy icosphere stands in.
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from helpers import icosphere
+            verts, tris = icosphere(args.mesh_level, 0.4)
+            dirs = verts / np.linalg.norm(verts, axis=1, keepdims=True)
+            verts = (verts * (1.0 + 0.08 * np.sin(9 * dirs[:, 0]) * np.cos(7 * dirs[:, 1])
+                              + 0.05 * np.sin(11 * dirs[:, 2]))[:, None]).astype(np.float32)
+            lo, hi = verts.min(0) - 0.02, verts.max(0) + 0.02
+            t0 = time.perf_counter()
+            mfield = H.Field.mesh(ctx, verts, tris)
+            prep_ms = (time.perf_counter() - t0) * 1e3
+            mcfg = H.make_config(TARGET, tuple(lo), tuple(hi))
+            H.create_block(ctx, mcfg, mfield, JOBS_PER_ROUND)
+            mt = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                mblk, mst = H.create_block(ctx, mcfg, mfield, JOBS_PER_ROUND)
+                torch.cuda.synchronize()
+                mt.append((time.perf_counter() - t0) * 1e3)
+            mesh = {"mesh": "bumpy icosphere, level %d" % args.mesh_level, "triangles": int(len(tris)),
+                    "prepare_ms": prep_ms, "create_ms": float(np.median(mt)), "nodes": mst["n_nodes"],
+                    "samples": mst["samples"], "msamples_per_s": mst["samples"] / float(np.median(mt)) / 1e3}
+            del mfield
+
         fit = None
         if args.fit_bench and rank == 0:
             fit = {}
@@ -268,6 +299,8 @@ def main():
     if sorted_ms is not None:
         out["query_cell_sorted_points"] = {"avg_launch_ms": sorted_ms, "mpts_per_s": n / sorted_ms / 1e3,
                                            "frac_hbm_peak": 32.0 * n / (sorted_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    if mesh:
+        out["mesh_create"] = mesh
     if fit:
         out["fit_microbench"] = fit
     if world == 1 and not args.no_cpu_baseline:
