@@ -143,6 +143,8 @@ _SIGNATURES = {
     "hpsdf_build_get_stats": (C.c_int, [C.c_void_p, C.POINTER(BuildStats)]),
     "hpsdf_continuity_post_process": (C.c_int, [C.c_void_p, C.c_size_t, C.c_double, C.c_int, C.c_uint64,
                                                 C.POINTER(ContinuityStats)]),
+    "hpsdf_continuity_post_process_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_int, C.c_uint64,
+                                                       C.POINTER(ContinuityStats)]),
     "hpsdf_continuity_matrix": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64, C.POINTER(C.POINTER(C.c_uint64)),
                                           C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(C.c_double)),
                                           C.POINTER(ContinuityStats)]),
@@ -534,12 +536,16 @@ def create_block(ctx, config, field, K=0):
     return data, st.as_dict()
 
 
-def continuity_post_process(block, tol=0.0, max_iter=0, threads=0):
-    """Octree::PerformContinuityPostProcess (Octree.cpp:1717-1762) on a serialised block, host side.
+def continuity_post_process(block, tol=0.0, max_iter=0, threads=0, ctx=None):
+    """Octree::PerformContinuityPostProcess (Octree.cpp:1717-1762) on a serialised block.  ctx=None: everything on
+    the host; with a Context the conjugate-gradient loop runs on its device (bit-identical result).
     Returns (new block bytes, stats dict).  tol 0 = the reference's EPSILON_F32."""
     buf = C.create_string_buffer(bytes(block), len(block))
     st = ContinuityStats()
-    check(lib().hpsdf_continuity_post_process(buf, len(block), tol, max_iter, threads, C.byref(st)))
+    if ctx is None:
+        check(lib().hpsdf_continuity_post_process(buf, len(block), tol, max_iter, threads, C.byref(st)))
+    else:
+        check(lib().hpsdf_continuity_post_process_device(ctx.handle, buf, len(block), tol, max_iter, threads, C.byref(st)))
     return buf.raw, st.as_dict()
 
 

@@ -14,7 +14,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libhpsdf.so")
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
 
-SOURCES = ["kernels.hip", "tables.cpp", "builder.cpp", "mesh.cpp", "obj.cpp", "continuity.cpp", "capi.cpp"]
+SOURCES = ["kernels.hip", "cg.hip", "tables.cpp", "builder.cpp", "mesh.cpp", "obj.cpp", "continuity.cpp", "capi.cpp"]
 HEADERS = ["tables.hpp", "device_types.hpp", "launch.hpp", "runtime.hpp", "builder.hpp", "continuity.hpp"]
 PUBLIC_HEADERS = ["hpsdf.h", "hpsdf_octree.hpp"]
 

@@ -1005,7 +1005,7 @@ int hpsdf_create(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* fie
     std::memset(&g_lastContinuity, 0, sizeof g_lastContinuity);
     if (!rc && cfg->continuity_enforce) {  // Octree.cpp:341-344
         std::string err;
-        rc = continuityPostProcess(*block, *size, 0.0, 0, 0, &g_lastContinuity, err);
+        rc = continuityPostProcess(*block, *size, 0.0, 0, 0, &g_lastContinuity, err, ctx);
         if (rc) {
             setError(err);
             std::free(*block);
@@ -1030,6 +1030,17 @@ int hpsdf_continuity_post_process(void* block, size_t size, double tol, int maxI
     HPSDF_TRY
     std::string err;
     const int rc = continuityPostProcess(block, size, tol, maxIter, threads, stats, err);
+    if (rc) return fail(rc, err);
+    return HPSDF_OK;
+    HPSDF_CATCH
+}
+
+int hpsdf_continuity_post_process_device(hpsdf_ctx* ctx, void* block, size_t size, double tol, int maxIter, uint64_t threads,
+                                         hpsdf_continuity_stats* stats) {
+    HPSDF_TRY
+    if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "a device context is required (hpsdf_continuity_post_process solves on the host)");
+    std::string err;
+    const int rc = continuityPostProcess(block, size, tol, maxIter, threads, stats, err, ctx);
     if (rc) return fail(rc, err);
     return HPSDF_OK;
     HPSDF_CATCH

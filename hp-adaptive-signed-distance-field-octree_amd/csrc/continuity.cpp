@@ -27,6 +27,7 @@
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -35,6 +36,8 @@
 #include <vector>
 
 #include "continuity.hpp"
+#include "launch.hpp"
+#include "runtime.hpp"
 #include "tables.hpp"
 
 namespace hpsdf {
@@ -526,7 +529,7 @@ void assemble(const ParsedBlock& b, Pool& pool, Csr& M, hpsdf_continuity_stats& 
 }
 
 // ---- vector kernels over fixed chunks (deterministic for any thread count) ---------------------------------
-constexpr uint64_t kVecChunk = 4096;
+constexpr uint64_t kVecChunk = kCgChunk;  // launch.hpp: the device solve sums over the same chunks
 
 struct Vec {
     Pool& pool;
@@ -539,9 +542,10 @@ struct Vec {
     }
     double dot(const double* a, const double* b) {
         pool.forEach(nChunks, [&](uint64_t c) {
-            double s = 0.0;
-            for (uint64_t i = c * kVecChunk, e = std::min(n, (c + 1) * kVecChunk); i < e; ++i) s += a[i] * b[i];
-            partial[c] = s;
+            double prod[kVecChunk];
+            const uint64_t lo = c * kVecChunk, cnt = std::min(n, lo + kVecChunk) - lo;
+            for (uint64_t i = 0; i < cnt; ++i) prod[i] = a[lo + i] * b[lo + i];
+            partial[c] = cgChunkSum(prod, cnt);
         });
         double s = 0.0;
         for (uint64_t c = 0; c < nChunks; ++c) s += partial[c];
@@ -601,8 +605,101 @@ int continuityMatrix(const void* block, size_t size, uint64_t threads, uint64_t*
 }
 
 // Octree::PerformContinuityPostProcess, :1717-1762, in place on the serialised block
+// The CG loop on the device: uploads the system and the state the host set up, runs batches of iterations until the
+// stop flag is up, brings x back.  Returns 0 or an HPSDF_ERR code (err filled).
+static int solveOnDevice(hpsdf_ctx* ctx, const Csr& M, double lambda, double threshold, int maxIter, double absNew,
+                         const std::vector<double>& dinv, std::vector<double>& x, const std::vector<double>& r,
+                         const std::vector<double>& p, int* iterations, double* resNorm2, std::string& err) {
+    const uint64_t n = M.n, nChunks = (n + kCgChunk - 1) / kCgChunk;
+    if (n >= 0xFFFFFFFFull) {
+        err = "continuity system too large for 32-bit column indices";
+        return HPSDF_ERR_UNSUPPORTED;
+    }
+    const bool trace = std::getenv("HPSDF_TRACE") != nullptr;
+    const double tt0 = nowMs();
+    auto al = [](uint64_t b) { return (b + 255) & ~255ull; };
+    // sliced ELL: every chunk of 256 rows is four slices of 64 (rows past n are empty); the host only sizes the
+    // slices, cg_ell_kernel moves the entries
+    const uint64_t nSlices = 4 * nChunks, nnz = M.rowPtr[n];
+    std::vector<uint64_t> sliceOff(nSlices + 1, 0);
+    for (uint64_t sl = 0; sl < nSlices; ++sl) {
+        uint64_t w = 0;
+        for (uint64_t r0 = sl * 64; r0 < std::min(n, sl * 64 + 64); ++r0) w = std::max(w, M.rowPtr[r0 + 1] - M.rowPtr[r0]);
+        sliceOff[sl + 1] = sliceOff[sl] + 64 * w;
+    }
+    const uint64_t ell = sliceOff[nSlices];
+    std::vector<uint32_t> col32(nnz ? nnz : 1);
+    for (uint64_t q = 0; q < nnz; ++q) col32[q] = (uint32_t)M.col[q];
+    const double tt1 = nowMs();
+    const uint64_t vecB = al(n * 8), partB = al(nChunks * 8);
+    const uint64_t total = al((nSlices + 1) * 8) + al(n * 4) + al(ell * 4 + 4) + al(ell * 8 + 8) + 7 * vecB + 2 * partB + 256 +
+                           al((n + 1) * 8) + al(nnz * 4 + 4) + al(nnz * 8 + 8);
+    char* base = nullptr;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e == hipSuccess) e = hipMalloc((void**)&base, total);
+    if (e != hipSuccess) {
+        err = std::string("continuity solve: ") + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? HPSDF_ERR_OUT_OF_MEMORY : HPSDF_ERR_HIP;
+    }
+    char* cur = base;
+    auto take = [&](uint64_t bytes) {
+        char* q = cur;
+        cur += al(bytes);
+        return q;
+    };
+    CgDev d;
+    d.n = n, d.nChunks = nChunks;
+    uint64_t* dSlice = (uint64_t*)take((nSlices + 1) * 8);
+    uint32_t* dLen = (uint32_t*)take(n * 4);
+    uint32_t* dCol = (uint32_t*)take(ell * 4 + 4);
+    double* dVal = (double*)take(ell * 8 + 8);
+    double* dDinv = (double*)take(n * 8);
+    d.sliceOff = dSlice, d.rowLen = dLen, d.col = dCol, d.val = dVal, d.dinv = dDinv;
+    d.x = (double*)take(n * 8), d.r = (double*)take(n * 8), d.p = (double*)take(n * 8), d.z = (double*)take(n * 8);
+    d.tmp = (double*)take(n * 8);
+    d.partA = (double*)take(nChunks * 8), d.partB = (double*)take(nChunks * 8);
+    d.s = (CgScalars*)take(sizeof(CgScalars));
+    uint64_t* dRowPtr = (uint64_t*)take((n + 1) * 8);
+    uint32_t* dCsrCol = (uint32_t*)take(nnz * 4 + 4);
+    double* dCsrVal = (double*)take(nnz * 8 + 8);
+    CgScalars s;
+    std::memset(&s, 0, sizeof s);
+    s.absNew = absNew, s.threshold = threshold, s.lambda = lambda, s.maxIter = maxIter;
+    hipStream_t st = ctx->stream;
+    auto up = [&](void* dst, const void* src, uint64_t bytes) {
+        if (e == hipSuccess && bytes) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+    };
+    up(dSlice, sliceOff.data(), (nSlices + 1) * 8), up(dRowPtr, M.rowPtr.data(), (n + 1) * 8);
+    up(dCsrCol, col32.data(), nnz * 4), up(dCsrVal, M.val.data(), nnz * 8);
+    if (e == hipSuccess) e = launchCgLayout(st, n, dRowPtr, dCsrCol, dCsrVal, d);
+    up(dDinv, dinv.data(), n * 8), up(d.x, x.data(), n * 8), up(d.r, r.data(), n * 8), up(d.p, p.data(), n * 8);
+    up(d.s, &s, sizeof s);
+    if (e == hipSuccess && trace) e = hipStreamSynchronize(st);
+    const double tt2 = nowMs();
+    while (e == hipSuccess) {
+        e = launchCgIterations(st, d, 16);
+        if (e == hipSuccess) e = hipMemcpyAsync(&s, d.s, sizeof s, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess || s.done) break;
+    }
+    const double tt3 = nowMs();
+    if (e == hipSuccess) e = hipMemcpyAsync(x.data(), d.x, n * 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(base);
+    if (trace)
+        std::fprintf(stderr, "[continuity solve] n %llu, ELL entries %llu: layout %.2f ms, malloc + upload %.2f, %d iterations %.2f, download + free %.2f\n",
+                     (unsigned long long)n, (unsigned long long)ell, tt1 - tt0, tt2 - tt1, (int)s.it, tt3 - tt2, nowMs() - tt3);
+    if (e != hipSuccess) {
+        err = std::string("continuity solve: ") + hipGetErrorString(e);
+        return HPSDF_ERR_HIP;
+    }
+    *iterations = s.it;
+    *resNorm2 = s.resNorm2;
+    return HPSDF_OK;
+}
+
 int continuityPostProcess(void* block, size_t size, double tol, int maxIter, uint64_t threads,
-                          hpsdf_continuity_stats* stats, std::string& err) {
+                          hpsdf_continuity_stats* stats, std::string& err, hpsdf_ctx* ctx) {
     ParsedBlock b;
     int rc = parseBlock(block, size, b, err);
     if (rc) return rc;
@@ -661,33 +758,39 @@ int continuityPostProcess(void* block, size_t size, double tol, int maxIter, uin
             });
             double absNew = V.dot(r.data(), p.data());
             std::vector<double> part2(V.nChunks ? V.nChunks : 1);
-            while (it < maxIter) {
+            if (ctx) {
+                rc = solveOnDevice(ctx, M, lambda, threshold, maxIter, absNew, dinv, x, r, p, &it, &resNorm2, err);
+                if (rc) return rc;
+            }
+            while (!ctx && it < maxIter) {
                 // region 1: tmp = A p and the partial sums of p . tmp
                 pool.forEach(V.nChunks, [&](uint64_t c) {
-                    double acc = 0.0;
-                    for (uint64_t i = c * kVecChunk, e = std::min(n, (c + 1) * kVecChunk); i < e; ++i) {
+                    double prod[kVecChunk];
+                    const uint64_t lo = c * kVecChunk, cnt = std::min(n, lo + kVecChunk) - lo;
+                    for (uint64_t i = lo; i < lo + cnt; ++i) {
                         double sacc = lambda * p[i];
                         for (uint64_t q = M.rowPtr[i]; q < M.rowPtr[i + 1]; ++q) sacc += M.val[q] * p[M.col[q]];
                         tmp[i] = sacc;
-                        acc += p[i] * sacc;
+                        prod[i - lo] = p[i] * sacc;
                     }
-                    V.partial[c] = acc;
+                    V.partial[c] = cgChunkSum(prod, cnt);
                 });
                 double pAp = 0.0;
                 for (uint64_t c = 0; c < V.nChunks; ++c) pAp += V.partial[c];
                 const double alpha = absNew / pAp;
                 // region 2: x, r, z updates and the partial sums of r . r and r . z
                 pool.forEach(V.nChunks, [&](uint64_t c) {
-                    double rr = 0.0, rz = 0.0;
-                    for (uint64_t i = c * kVecChunk, e = std::min(n, (c + 1) * kVecChunk); i < e; ++i) {
+                    double rr[kVecChunk], rz[kVecChunk];
+                    const uint64_t lo = c * kVecChunk, cnt = std::min(n, lo + kVecChunk) - lo;
+                    for (uint64_t i = lo; i < lo + cnt; ++i) {
                         x[i] += alpha * p[i];
                         r[i] -= alpha * tmp[i];
                         z[i] = dinv[i] * r[i];
-                        rr += r[i] * r[i];
-                        rz += r[i] * z[i];
+                        rr[i - lo] = r[i] * r[i];
+                        rz[i - lo] = r[i] * z[i];
                     }
-                    V.partial[c] = rr;
-                    part2[c] = rz;
+                    V.partial[c] = cgChunkSum(rr, cnt);
+                    part2[c] = cgChunkSum(rz, cnt);
                 });
                 resNorm2 = 0.0;
                 double rz = 0.0;
@@ -711,6 +814,9 @@ int continuityPostProcess(void* block, size_t size, double tol, int maxIter, uin
     std::memcpy(b.coeffs, x.data(), sizeof(double) * n);  // :1756
     st.assemble_ms = t1 - t0;
     st.solve_ms = nowMs() - t1;
+    if (std::getenv("HPSDF_TRACE"))
+        std::fprintf(stderr, "[continuity] assemble %.2f ms, solve %.2f ms (%s), pool %u threads\n", st.assemble_ms, st.solve_ms,
+                     ctx ? "device" : "host", pool.size());
     if (stats) *stats = st;
     return HPSDF_OK;
 }

@@ -39,6 +39,40 @@ hipError_t launchFieldEval(hipStream_t stream, const FieldDev& f, const DeviceTa
 // mesh fields: F at every sample of nTasks fits of one degree -> dSamples[FitTask::sampleOff + sample]
 hipError_t launchMeshSample(hipStream_t stream, const FitTask* dTasks, uint32_t nTasks, int degree, const DeviceTables* dTables,
                             const FieldDev& field, const RootMap& rm, double* dSamples);
+// ---- continuity solve on the device (cg.hip); the arithmetic is continuity.cpp's
+constexpr uint64_t kCgChunk = 256;  // dot products are summed chunk by chunk (one workgroup's rows), then over the chunks
+// The canonical sum of one chunk, e[0..count) with count <= 256 (missing elements count as +0.0): lane l of 64 adds
+// e[l], e[l+64], e[l+128], e[l+192] in that order, then the lanes fold as a shuffle tree (l += l+32, l+16, ... l+1).
+// Host and device both sum dot products this way, which is what makes their solves bit-identical.
+inline double cgChunkSum(const double* e, uint64_t count) {
+    double v[64];
+    for (uint64_t l = 0; l < 64; ++l) {
+        auto at = [&](uint64_t i) { return i < count ? e[i] : 0.0; };
+        v[l] = ((at(l) + at(64 + l)) + at(128 + l)) + at(192 + l);
+    }
+    for (int off = 32; off >= 1; off >>= 1)
+        for (int l = 0; l < off; ++l) v[l] = v[l] + v[l + off];
+    return v[0];
+}
+struct CgScalars {
+    double absNew, alpha, beta, resNorm2, threshold, lambda;
+    int32_t it, maxIter, done, pad;
+};
+struct CgDev {
+    uint64_t n, nChunks;
+    // M as sliced ELL: slice s = rows 64 s .. 64 s + 63, entry k of row r at sliceOff[s] + 64 k + (r & 63)
+    const uint64_t* sliceOff;  // 4 nChunks + 1 (every chunk has four slices, rows past n are empty)
+    const uint32_t* rowLen;    // n
+    const uint32_t* col;
+    const double* val;
+    const double* dinv;
+    double *x, *r, *p, *z, *tmp, *partA, *partB;
+    CgScalars* s;
+};
+// fills d.rowLen / d.col / d.val (sliced ELL, d.sliceOff already uploaded) from the CSR arrays in HBM
+hipError_t launchCgLayout(hipStream_t stream, uint64_t n, const uint64_t* dRowPtr, const uint32_t* dCsrCol, const double* dCsrVal,
+                          const CgDev& d);
+hipError_t launchCgIterations(hipStream_t stream, const CgDev& d, int iterations);
 hipError_t launchPack(hipStream_t stream, const PackItem* dItems, uint32_t nItems, const double* dArena, double* dOut);
 
 }  // namespace hpsdf

@@ -114,7 +114,7 @@ def create_distributed(ctx, config, field, K=0, group=None, compute=None, policy
     if b.pod.continuity_enforce:
         # Octree.cpp:341-344: host-side post-process; deterministic, so every rank computes the same block
         # from its identical copy and no exchange is needed
-        block, cstats = continuity_post_process(block)
+        block, cstats = continuity_post_process(block, ctx=ctx if on_gpu else None)
         stats["continuity"] = cstats
     return block, stats
 

@@ -270,6 +270,11 @@ typedef struct hpsdf_continuity_stats {
  * threads 0: the block's config.thread_count (capped to the machine). */
 HPSDF_API int hpsdf_continuity_post_process(void* block, size_t size, double tol, int max_iter, uint64_t threads,
                                             hpsdf_continuity_stats* stats);
+/* The same with the conjugate-gradient loop on ctx's device (what hpsdf_create runs): the assembly stays on the
+ * host, the system and the solver state go to HBM, every sum is taken in the host solve's order -- the block comes
+ * back bit-identical to hpsdf_continuity_post_process's. */
+HPSDF_API int hpsdf_continuity_post_process_device(hpsdf_ctx* ctx, void* block, size_t size, double tol, int max_iter,
+                                                   uint64_t threads, hpsdf_continuity_stats* stats);
 /* M itself (without the regularisation), CSR with duplicates summed; the three arrays are malloc'd, the
  * caller frees them.  Test / diagnostic hook. */
 HPSDF_API int hpsdf_continuity_matrix(const void* block, size_t size, uint64_t threads, uint64_t** row_ptr,

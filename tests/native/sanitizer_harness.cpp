@@ -25,6 +25,8 @@ FitShape fitShape(int, int, uint32_t, bool, bool) { return FitShape{1, 1, 1, 0};
 hipError_t launchFit(hipStream_t, int, int, const FitBlock*, uint32_t, size_t, const FitTask*, double*, double*, double*,
                      const DeviceTables*, const FieldDev&, const RootMap&) { return hipErrorNoDevice; }
 hipError_t launchPack(hipStream_t, const PackItem*, uint32_t, const double*, double*) { return hipErrorNoDevice; }
+hipError_t launchCgIterations(hipStream_t, const CgDev&, int) { return hipErrorNoDevice; }
+hipError_t launchCgLayout(hipStream_t, uint64_t, const uint64_t*, const uint32_t*, const double*, const CgDev&) { return hipErrorNoDevice; }
 hipError_t launchMeshSample(hipStream_t, const FitTask*, uint32_t, int, const DeviceTables*, const FieldDev&, const RootMap&, double*) {
     return hipErrorNoDevice;
 }

@@ -557,6 +557,20 @@ def test_capi_argument_checks_query_side(H, ctx):
     assert rgb.shape == (1, 1, 3) and vals.shape == (1, 1)
 
 
+@pytest.mark.parametrize("tol,max_iter", [(0.0, 0), (1e-12, 0), (0.0, 3), (1e-30, 40)])
+def test_continuity_device_solve_equals_host_solve(H, ctx, tol, max_iter):
+    """cg.hip runs continuity.cpp's conjugate-gradient loop with the same sums in the same order: same block, same
+    iteration count, same residual -- also when the loop ends on the iteration cap instead of the tolerance."""
+    cfg0 = H.make_config(1e-8, continuity=False)
+    cfg0.continuity_strength = 8.0
+    b0, _ = H.create_block(ctx, cfg0, H.Field.sphere((0.25, 0.0, 0.0), 0.5), 1024)
+    host, sh = H.continuity_post_process(bytes(b0), tol, max_iter)
+    dev, sd = H.continuity_post_process(bytes(b0), tol, max_iter, ctx=ctx)
+    assert host == dev
+    assert sh["iterations"] == sd["iterations"] and sh["residual"] == sd["residual"] and sh["jump_after"] == sd["jump_after"]
+    assert sd["iterations"] > 0 and (max_iter == 0 or sd["iterations"] <= max_iter)
+
+
 def test_mesh_create_with_continuity_config5_shape(H, O, ctx):
     """BASELINE config 5 in miniature: mesh field, root = mesh box, targetError 1e-5, continuity.enforce -- GPU build,
     host post-process.  The result must equal the host post-process of the continuity-free build (bit for bit) and stay
