@@ -344,11 +344,9 @@ int hpsdf_field_create_mesh(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts,
     };
     hipError_t e = up((void**)&f->dVerts, hm.verts.data(), hm.verts.size() * sizeof(float));
     if (e == hipSuccess) e = up((void**)&f->dTris, hm.tris.data(), hm.tris.size() * sizeof(uint32_t));
-    if (e == hipSuccess) {
-        std::vector<float> triPos(hm.tris.size() * 3);
-        for (size_t i = 0; i < hm.tris.size(); ++i) std::memcpy(&triPos[3 * i], &hm.verts[3 * (size_t)hm.tris[i]], 3 * sizeof(float));
-        e = up((void**)&f->dTriPos, triPos.data(), triPos.size() * sizeof(float));
-    }
+    if (e == hipSuccess) e = hipMalloc((void**)&f->dTriPos, hm.tris.size() * 3 * sizeof(float));
+    if (e == hipSuccess) e = launchMeshTriPos(ctx->stream, f->dVerts, f->dTris, nTris, f->dTriPos);  // after the blocking uploads
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = up((void**)&f->dHalfEdges, hm.halfEdges.data(), hm.halfEdges.size() * sizeof(uint32_t));
     if (e == hipSuccess) e = up((void**)&f->dBvh, hm.bvh.data(), hm.bvh.size() * sizeof(BvhNode));
 #ifdef HPSDF_MESH_STATS_BUILD

@@ -1638,6 +1638,23 @@ __global__ __launch_bounds__(256) void mesh_sample_kernel(const FitTask* __restr
     if (active) samples[tk.sampleOff + (uint64_t)rem] = (double)mv;
 }
 
+// MeshDev::triPos: the nine coordinates of every triangle, gathered once per mesh
+__global__ __launch_bounds__(256) void mesh_tripos_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ tris,
+                                                          uint64_t nCorners, float* __restrict__ triPos) {
+    const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;  // corner = 3 * triangle + k
+    if (c >= nCorners) return;
+    const uint64_t v = tris[c];
+    triPos[3 * c] = verts[3 * v], triPos[3 * c + 1] = verts[3 * v + 1], triPos[3 * c + 2] = verts[3 * v + 2];
+}
+
+hipError_t launchMeshTriPos(hipStream_t stream, const float* dVerts, const uint32_t* dTris, uint64_t nTris, float* dTriPos) {
+    if (nTris == 0) return hipSuccess;
+    const uint64_t nCorners = 3 * nTris;
+    hipLaunchKernelGGL(mesh_tripos_kernel, dim3((unsigned)((nCorners + 255) / 256)), dim3(256), 0, stream, dVerts, dTris, nCorners,
+                       dTriPos);
+    return hipGetLastError();
+}
+
 hipError_t launchMeshSample(hipStream_t stream, const FitTask* dTasks, uint32_t nTasks, int degree, const DeviceTables* dTables,
                             const FieldDev& field, const RootMap& rm, double* dSamples) {
     if (nTasks == 0) return hipSuccess;

@@ -92,10 +92,10 @@ bool twinHalfEdges(const std::vector<uint32_t>& tris, std::vector<uint32_t>& he)
 }
 
 struct Builder {
-    std::vector<float> triBox;  // 6 per triangle
-    std::vector<float> cen;     // 3 per triangle
-    std::vector<uint32_t> ids;
-    std::vector<BvhNode>& nodes;  // preallocated: a subtree over m triangles owns m - 1 consecutive nodes (preorder)
+    RawVector<float> triBox;  // 6 per triangle
+    RawVector<float> cen;     // 3 per triangle
+    RawVector<uint32_t> ids;
+    RawVector<BvhNode>& nodes;  // preallocated: a subtree over m triangles owns m - 1 consecutive nodes (preorder)
 
     // Median split on the longest centroid axis.  `node` is the preorder index of this subtree's root, so the
     // layout is fixed before anything is built and the upper levels can hand their right halves to other threads
@@ -163,15 +163,15 @@ bool prepareMesh(const float* verts, uint64_t nVerts, const uint64_t* tris, uint
     const double t1 = now();
     if (!twinHalfEdges(out->tris, out->halfEdges)) return false;
     const double t2 = now();
-    out->bvh.assign(nTris > 1 ? nTris - 1 : 1, BvhNode{});
+    out->bvh.resize(nTris > 1 ? nTris - 1 : 1);  // uninitialised: every node is written by the build
     Builder b{{}, {}, {}, out->bvh};
     b.triBox.resize(6 * nTris);
     b.cen.resize(3 * nTris);
     b.ids.resize(nTris);
-    std::iota(b.ids.begin(), b.ids.end(), 0u);
     const unsigned workers = nTris < (1u << 16) ? 1 : workerCount();
     parallelFor(workers, [&](unsigned w) {
-        for (uint64_t t = nTris * w / workers, end = nTris * (w + 1) / workers; t < end; ++t)
+        for (uint64_t t = nTris * w / workers, end = nTris * (w + 1) / workers; t < end; ++t) {
+            b.ids[t] = (uint32_t)t;
             for (int a = 0; a < 3; ++a) {
                 const float v0 = out->verts[3 * out->tris[3 * t] + a], v1 = out->verts[3 * out->tris[3 * t + 1] + a],
                             v2 = out->verts[3 * out->tris[3 * t + 2] + a];
@@ -180,6 +180,7 @@ bool prepareMesh(const float* verts, uint64_t nVerts, const uint64_t* tris, uint
                 b.triBox[6 * t + 3 + a] = hi;
                 b.cen[3 * t + a] = 0.5f * (lo + hi);
             }
+        }
     });
     if (nTris == 1) {  // degenerate: a root with the single triangle on both sides
         BvhNode n;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstdint>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -143,11 +144,30 @@ const hpsdf_field* innermost(const hpsdf_field* f);
 int makeFieldDev(const hpsdf_field* f, const double* dSamples, FieldDev* out);
 
 // host mesh preparation (mesh.cpp)
+// std::allocator that leaves trivially constructible elements uninitialised on resize(): the big mesh arrays are
+// written in full by parallel workers right after they are sized, and zero-filling them first costs more than that
+template <typename T>
+struct DefaultInit : std::allocator<T> {
+    template <typename U>
+    struct rebind {
+        using other = DefaultInit<U>;
+    };
+    template <typename U, typename... A>
+    void construct(U* p, A&&... a) {
+        if constexpr (sizeof...(A) == 0)
+            ::new ((void*)p) U;
+        else
+            ::new ((void*)p) U(std::forward<A>(a)...);
+    }
+};
+template <typename T>
+using RawVector = std::vector<T, DefaultInit<T>>;
+
 struct HostMesh {
     std::vector<float> verts;
     std::vector<uint32_t> tris;
     std::vector<uint32_t> halfEdges;
-    std::vector<BvhNode> bvh;
+    RawVector<BvhNode> bvh;
 };
 // returns false when the mesh is not closed (Mesh::CreateHalfEdges, Mesh.cpp:87-131)
 bool prepareMesh(const float* verts, uint64_t nVerts, const uint64_t* tris, uint64_t nTris, HostMesh* out);
