@@ -290,7 +290,12 @@ def main():
                    "block_bytes": len(block), "ms_all": create_times},
         "roofline": {"kernel": "query_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": 32 * n,
-                     "avg_launch_ms": kernel_ms},
+                     "avg_launch_ms": kernel_ms,
+                     # what actually limits the kernel: every random point pulls one 128-byte
+                     # top-table line out of L2 besides its 24 + 8 streamed bytes; MI355X_MICROARCH.md measures 66-73
+                     # GB/s per CU for rows gathered from an XCD's L2
+                     "l2_to_l1_fill": {"bytes_per_point": 160, "achieved_gbps_per_cu": 160.0 * n / (kernel_ms * 1e-3) / 1e9 / 256,
+                                       "measured_ceiling_gbps_per_cu": [66, 73]}},
     }
     if refined is not None:
         want_r = O.Tree.from_block(refined.pop("_blk")).query(pts[:: max(1, n // 2000)])
