@@ -251,6 +251,7 @@ __device__ float meshSignedDistance(const MeshDev& m, V3 pt, uint32_t& hint) {
 constexpr int kMeshStack = 128;
 __device__ float meshSignedDistanceWave(const MeshDev& m, V3 pt, bool active, uint32_t& hint, int32_t* stack) {
     float best = FLT_MAX;
+    float bound = __builtin_inff();  // best * 1.00001f + 1e-30f, kept beside best: what a box distance is compared with
     uint32_t bestTri = 0xFFFFFFFFu;
     int bestCode = 8;
     V3 bestQ = {0.0f, 0.0f, 0.0f};
@@ -261,18 +262,19 @@ __device__ float meshSignedDistanceWave(const MeshDev& m, V3 pt, bool active, ui
         const float d = sqnorm(pt - q);
         if (d < best || (d == best && t < bestTri)) {
             best = d;
+            bound = d * 1.00001f + 1e-30f;
             bestTri = t;
             bestCode = code;
             bestQ = q;
         }
     };
-    auto boxDist = [&](const float* lo, const float* hi) {
-        const float cx = fminf(fmaxf(pt.x, lo[0]), hi[0]);
-        const float cy = fminf(fmaxf(pt.y, lo[1]), hi[1]);
-        const float cz = fminf(fmaxf(pt.z, lo[2]), hi[2]);
+    auto boxDist = [&](const float* lo, const float* hi) {  // clamp = median of (p, lo, hi): lo <= hi in every box
+        const float cx = __builtin_amdgcn_fmed3f(pt.x, lo[0], hi[0]);
+        const float cy = __builtin_amdgcn_fmed3f(pt.y, lo[1], hi[1]);
+        const float cz = __builtin_amdgcn_fmed3f(pt.z, lo[2], hi[2]);
         return sqnorm(pt - V3{cx, cy, cz});
     };
-    auto worthIt = [&](float d) { return active && !(d > best * 1.00001f + 1e-30f); };
+    auto worthIt = [&](float d) { return active && !(d > bound); };
     if (active && hint < m.nTris) visitTri(hint);
     const int lane = threadIdx.x & 63;
     int sp = 1;  // wave-uniform
