@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters of the mesh-field fit kernel (tools/mesh_probe.py <level>).  Usage: bash tools/mesh_pmc.sh <tag> <level>
+# SQ counters of the mesh sampling kernel (and of the fused mesh fit kernel under HPSDF_MESH_FUSED=1) (tools/mesh_probe.py <level>).  Usage: bash tools/mesh_pmc.sh <tag> <level>
 TAG=${1:-mesh}; LEVEL=${2:-8}
 OUT=$PWD/gpurun_out/pmcm_$TAG
 mkdir -p $OUT
@@ -17,7 +17,7 @@ out = sys.argv[1]
 acc = {}
 for f in glob.glob(os.path.join(out, "**/*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "fit_kernel<2" not in r["Kernel_Name"]:
+        if "fit_kernel<2" not in r["Kernel_Name"] and "mesh_sample_kernel" not in r["Kernel_Name"]:
             continue
         acc.setdefault((r["Kernel_Name"][:40], r["Counter_Name"]), []).append(float(r["Counter_Value"]))
 for k in sorted(acc):
