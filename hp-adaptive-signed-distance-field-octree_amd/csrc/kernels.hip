@@ -277,54 +277,61 @@ __device__ float meshSignedDistanceWave(const MeshDev& m, V3 pt, bool active, ui
     auto worthIt = [&](float d) { return active && !(d > bound); };
     if (active && hint < m.nTris) visitTri(hint);
     const int lane = threadIdx.x & 63;
-    int sp = 1;  // wave-uniform
-    if (lane == 0) stack[0] = 0;
+    // The node being processed lives in registers, the stack only holds the deferred siblings.  Which node comes next is
+    // known as soon as the two box tests are in -- the nearer wanted child, else the top of the stack -- so its 64 bytes
+    // are asked for BEFORE this node's triangle tests run and arrive behind them (same visiting order as a plain
+    // push-both / pop loop; the winner does not depend on the order anyway).
+    int sp = 0;  // wave-uniform
 #ifdef HPSDF_MESH_STATS_BUILD
     unsigned nVisits = 0, nTriInstr = 0, nTriLanes = 0;
 #endif
-    while (sp > 0) {
-        --sp;
-        const int32_t ni = __builtin_amdgcn_readfirstlane(stack[sp]);
-        const BvhNode n = m.bvh[ni];
+    BvhNode n = m.bvh[0];
+    for (;;) {
 #ifdef HPSDF_MESH_STATS_BUILD
         ++nVisits;
 #endif
         const float d0 = boxDist(n.lo0, n.hi0), d1 = boxDist(n.lo1, n.hi1);
         const bool w0 = worthIt(d0), w1 = worthIt(d1);
         const unsigned long long b0 = __ballot(w0), b1 = __ballot(w1);
-        if ((b0 | b1) == 0ull) continue;
-        // leaves are resolved at once (they tighten the bounds); inner children are pushed, the one that is nearer
-        // for the first lane that wants it on top
-        if (n.c0 < 0) {
-            if (w0) visitTri((uint32_t)~n.c0);
-#ifdef HPSDF_MESH_STATS_BUILD
-            if (m.stats && b0) ++nTriInstr, nTriLanes += (unsigned)__popcll(b0);
-#endif
-        }
-        if (n.c1 < 0) {
-            if (w1 && worthIt(d1)) visitTri((uint32_t)~n.c1);
-#ifdef HPSDF_MESH_STATS_BUILD
-            if (m.stats && b1) ++nTriInstr, nTriLanes += (unsigned)__popcll(b1);
-#endif
-        }
-        const bool push0 = n.c0 >= 0 && b0 != 0ull, push1 = n.c1 >= 0 && b1 != 0ull;
+        const int32_t c0 = n.c0, c1 = n.c1;
+        int32_t next = -1;
+        const bool push0 = c0 >= 0 && b0 != 0ull, push1 = c1 >= 0 && b1 != 0ull;
         if (push0 && push1) {
+            // the one that is nearer for the first lane that wants child 0 goes first, its sibling waits on the stack
             const int l0 = __ffsll((long long)b0) - 1;
             const float a0 = __shfl(d0, l0, 64), a1 = __shfl(d1, l0, 64);
-            const bool firstIs1 = a1 < a0;  // visit the nearer one first: it goes on top
-            if (sp < kMeshStack - 2) {
-                if (lane == 0) {
-                    stack[sp] = firstIs1 ? n.c0 : n.c1;
-                    stack[sp + 1] = firstIs1 ? n.c1 : n.c0;
-                }
-                sp += 2;
+            const bool firstIs1 = __builtin_amdgcn_readfirstlane((int)(a1 < a0)) != 0;
+            next = firstIs1 ? c1 : c0;
+            if (sp < kMeshStack) {
+                if (lane == 0) stack[sp] = firstIs1 ? c0 : c1;
+                ++sp;
             }
         } else if (push0 || push1) {
-            if (sp < kMeshStack - 1) {
-                if (lane == 0) stack[sp] = push0 ? n.c0 : n.c1;
-                sp += 1;
-            }
+            next = push0 ? c0 : c1;
+        } else if (sp > 0) {
+            --sp;
+            next = __builtin_amdgcn_readfirstlane(stack[sp]);
         }
+        const BvhNode nn = m.bvh[next >= 0 ? next : 0];  // (the root again when the walk is over: never used)
+        // leaves are resolved at once (they tighten the bounds for everything still to come)
+        if (c0 < 0 && b0 != 0ull) {
+            if (w0) visitTri((uint32_t)~c0);
+#ifdef HPSDF_MESH_STATS_BUILD
+            if (m.stats) ++nTriInstr, nTriLanes += (unsigned)__popcll(b0);
+#endif
+        }
+        if (c1 < 0 && b1 != 0ull) {
+            if (w1 && worthIt(d1)) visitTri((uint32_t)~c1);
+#ifdef HPSDF_MESH_STATS_BUILD
+            if (m.stats) ++nTriInstr, nTriLanes += (unsigned)__popcll(b1);
+#endif
+        }
+        // The test on the two padding words (always zero, mesh.cpp) keeps all sixteen dwords of the prefetch live across
+        // the triangle tests: with them dead the register allocator reuses their SGPRs at once and has to wait for the
+        // load right where it was issued.  (An empty asm with "s" inputs would do too, but turns every BVH fetch of the
+        // kernel into a vector load.)
+        if (next < 0 || (nn.pad[0] & nn.pad[1]) == 0xFFFFFFFFu) break;
+        n = nn;
     }
 #ifdef HPSDF_MESH_STATS_BUILD  // a global atomic in the kernel makes every BVH fetch a vector load: diagnostic builds only
     if (m.stats && lane == 0) {
