@@ -244,8 +244,8 @@ def main():
         if args.fit_bench and rank == 0:
             fit = {}
             plane = H.Field.analytic([(H.PRIM_PLANE, H.OP_UNION, [0.3, -0.2, 0.5, 0.1])])  # F costs ~nothing: contraction only
-            for p in (2, 3, 4, 5):
-                cells = 65536 if p <= 3 else 16384
+            for p in (2, 3, 4, 5, 6, 7, 8):  # p in {2..8}; degrees > 5 run the any-degree kernel
+                cells = 65536 if p <= 3 else (16384 if p <= 5 else 4096)
                 flops = 2.0 * H.NCOEF[p] * (4 * p + 1) ** 3 * cells
                 ms = H.bench_fit(ctx, cfg, field, p, 5, cells, 3)
                 ms_c = H.bench_fit(ctx, cfg, plane, p, 5, cells, 3)
