@@ -196,3 +196,24 @@ def deep_chain_block(rng, max_depth=10, degrees=(2, 3, 1, 0, 4, 3, 2, 5)):
     cfg[56:80] = np.array([-0.5] * 3 + [0.5] * 3, np.float32).view(np.uint8)
     return (np.array([len(coeffs)], np.uint64).tobytes() + coeffs.tobytes() + np.array([len(nodes)], np.uint64).tobytes()
             + np.concatenate(nodes).tobytes() + cfg.tobytes())
+
+
+def displaced_torus(nu=1024, nv=1024, R=0.3, r=0.1, amp=0.02):
+    """Closed, consistently outward-oriented torus grid with a smooth radial displacement: 2 * nu * nv triangles
+    (1024 x 1024 -> 2 097 152, SURVEY 8(d)'s stand-in for the 2 M-triangle mesh of the north_star)."""
+    u = np.arange(nu) * (2.0 * np.pi / nu)
+    v = np.arange(nv) * (2.0 * np.pi / nv)
+    U, V = np.meshgrid(u, v, indexing="ij")
+    rr = r * (1.0 + amp / r * np.sin(7 * U) * np.cos(5 * V) + 0.5 * amp / r * np.sin(11 * V + 3 * U))
+    x = (R + rr * np.cos(V)) * np.cos(U)
+    y = (R + rr * np.cos(V)) * np.sin(U)
+    z = rr * np.sin(V)
+    verts = np.stack([x, y, z], -1).reshape(-1, 3).astype(np.float32)
+    i = np.arange(nu)[:, None]
+    j = np.arange(nv)[None, :]
+    a = (i * nv + j).ravel()
+    b = (((i + 1) % nu) * nv + j).ravel()
+    c = (((i + 1) % nu) * nv + (j + 1) % nv).ravel()
+    d = (i * nv + (j + 1) % nv).ravel()
+    tris = np.concatenate([np.stack([a, b, c], -1), np.stack([a, c, d], -1)]).astype(np.uint64)
+    return verts, tris

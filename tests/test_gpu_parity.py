@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from conftest import bits
-from helpers import (oracle_field, product_field, query_points, edge_points, synthetic_block, icosphere, sha)
+from helpers import (oracle_field, product_field, query_points, edge_points, synthetic_block, icosphere, displaced_torus, sha)
 
 pytestmark = pytest.mark.gpu
 DBL_MAX = np.finfo(np.float64).max
@@ -254,6 +254,26 @@ def test_mesh_field_matches_naive_oracle(H, O, ctx):
     assert set(np.unique(simp // 4)) == {0, 1, 2}  # vertex, edge and face regions all exercised
     r = np.linalg.norm(pts - np.array([0.05, -0.02, 0.01]), axis=1) - 0.35
     assert np.abs(got - r).max() < 0.02  # it is a sphere, to faceting error
+
+
+def test_torus_mesh_field_and_create_match_oracle(H, O, ctx):
+    """A genus-1 mesh with concave regions (the displaced torus that stands in for the north_star's 2 M-triangle mesh,
+    here 48 x 32 x 2 triangles): point values against the naive scan, and the tree built from it against the oracle's."""
+    verts, tris = displaced_torus(48, 32)
+    mf, of = H.Field.mesh(ctx, verts, tris), O.MeshField(verts, tris)
+    pts = O.splitmix64_points(20000, seed=21)
+    got = mf.eval(ctx, pts)
+    want, tri, simp = of.signed_distance(pts)
+    assert np.abs(got - want.astype(np.float64)).max() <= TOL
+    assert np.mean(np.sign(got) == np.sign(want)) > 0.999
+    assert np.mean(bits(got) == bits(want.astype(np.float64))) > 0.99
+    assert (got < 0).mean() > 0.02  # the tube's inside is seen
+    verts, tris = displaced_torus(16, 12)  # the oracle scans every triangle for every sample: keep it small
+    blk, st = H.create_block(ctx, H.make_config(1e-4), H.Field.mesh(ctx, verts, tris), 1024)
+    ot = O.Tree.create(O.default_config(1e-4), O.MeshField(verts, tris), 1024)
+    a, b = O.parse_block(blk), O.parse_block(ot.to_block())
+    assert np.array_equal(a["degree"], b["degree"]) and np.array_equal(a["childIdx"], b["childIdx"])
+    assert np.abs(a["coeffs"] - b["coeffs"]).max() <= TOL
 
 
 def test_mesh_open_mesh_rejected(H, ctx):

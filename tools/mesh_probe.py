@@ -4,14 +4,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import hpsdf_loader
-from helpers import icosphere
+from helpers import icosphere, displaced_torus
 H = hpsdf_loader.load()
 ctx = H.Context(0)
-for level in (int(a) for a in sys.argv[1:] or ["5", "7", "8"]):
-    t0 = time.time(); verts, tris = icosphere(level, 0.4); t1 = time.time()
-    # bumpy sphere so that the SDF is not trivially a sphere
-    d = verts / np.linalg.norm(verts, axis=1, keepdims=True)
-    verts = (verts * (1.0 + 0.08 * np.sin(9 * d[:, 0]) * np.cos(7 * d[:, 1]) + 0.05 * np.sin(11 * d[:, 2]))[:, None]).astype(np.float32)
+for level in (a for a in sys.argv[1:] or ["5", "7", "8"]):
+    t0 = time.time()
+    if level == "torus":  # 2 097 152 triangles
+        verts, tris = displaced_torus()
+        level = "displaced torus 1024x1024"
+    else:
+        level = int(level)
+        verts, tris = icosphere(level, 0.4)
+        # bumpy sphere so that the SDF is not trivially a sphere
+        d = verts / np.linalg.norm(verts, axis=1, keepdims=True)
+        verts = (verts * (1.0 + 0.08 * np.sin(9 * d[:, 0]) * np.cos(7 * d[:, 1]) + 0.05 * np.sin(11 * d[:, 2]))[:, None]).astype(np.float32)
+        level = "icosphere L%d" % level
+    t1 = time.time()
     lo, hi = verts.min(0) - 0.02, verts.max(0) + 0.02
     t2 = time.time(); f = H.Field.mesh(ctx, verts, tris); t3 = time.time()
     cfg = H.make_config(1e-5, tuple(lo), tuple(hi))
@@ -26,6 +34,6 @@ for level in (int(a) for a in sys.argv[1:] or ["5", "7", "8"]):
               % (q, ms["node_visits"] / q, ms["tri_tests"] / q, ms["tri_test_lanes"] / max(1, ms["tri_tests"])))
     pts = np.random.default_rng(1).uniform(lo, hi, (1_000_000, 3))
     t6 = time.time(); v = f.eval(ctx, pts); t7 = time.time()
-    print("icosphere L%d: %d tris | gen %.1fs | prepare (half-edges+BVH+upload) %.2fs | Create 1e-5: %.1f ms (first %.1f ms) "
+    print("%s: %d tris | gen %.1fs | prepare (half-edges+BVH+upload) %.2fs | Create 1e-5: %.1f ms (first %.1f ms) "
           "nodes %d samples %d | field eval 1M pts %.1f ms (incl. PCIe)" % (level, len(tris), t1 - t0, t3 - t2, (t5 - t4) * 1e3,
           (t4 - t3) * 1e3, st["n_nodes"], st["samples"], (t7 - t6) * 1e3))
