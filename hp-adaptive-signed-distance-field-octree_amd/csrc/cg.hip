@@ -44,42 +44,60 @@ __global__ __launch_bounds__(256) void cg_ell_kernel(uint64_t n, const uint64_t*
     }
 }
 
-// region 1 of an iteration: tmp = (M + lambda I) p and the chunk sums of p . tmp
-__global__ __launch_bounds__(256) void cg_spmv_kernel(CgDev d) {
-    __shared__ double sh[256];
+// region 1 of an iteration: tmp = (M + lambda I) p and the chunk sums of p . tmp.  One workgroup of 1024 threads per
+// chunk of 256 rows: four lanes share a row -- lane q of them fetches entries q, q + 4, ... of the current tile of 32 and
+// parks the products in LDS -- and the row's own lane (q = 0) then adds them strictly left to right.  The loads of a tile
+// are independent of every addition, so they are all in flight at once (a thread per row ran one dependent
+// load -> gather -> add chain per entry batch: 30 us per SpMV against 8 for the bytes alone).
+constexpr int kCgTile = 32;
+__global__ __launch_bounds__(1024) void cg_spmv_kernel(CgDev d) {
+    __shared__ double sProd[4][kCgTile][64];  // [slice of the chunk][entry in tile][row in slice]; reused for the chunk sum
     if (d.s->done) return;
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool live = i < d.n;
-    const uint64_t slice = i >> 6;
-    const uint64_t base = d.sliceOff[slice] + (threadIdx.x & 63);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sl = wave >> 2, q = wave & 3;
+    const uint64_t row = (uint64_t)blockIdx.x * 256 + sl * 64 + lane;
+    const bool live = row < d.n;
+    const uint64_t slice = (uint64_t)blockIdx.x * 4 + sl;
+    const uint64_t base = d.sliceOff[slice] + lane;
     const uint32_t width = (uint32_t)((d.sliceOff[slice + 1] - d.sliceOff[slice]) >> 6);  // wave-uniform
-    const uint32_t len = live ? d.rowLen[i] : 0u;
-    const double pi = live ? d.p[i] : 0.0;
+    uint32_t maxWidth = width;  // the workgroup's tile loop must be uniform over its four slices
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        const uint64_t so = (uint64_t)blockIdx.x * 4 + o;
+        const uint32_t w = (uint32_t)((d.sliceOff[so + 1] - d.sliceOff[so]) >> 6);
+        maxWidth = w > maxWidth ? w : maxWidth;
+    }
+    const uint32_t len = live ? d.rowLen[row] : 0u;
+    const double pi = live ? d.p[row] : 0.0;
     double acc = d.s->lambda * pi;
-    // sixteen entries' gathers in flight at a time, the next sixteen columns already on their way (padding slots hold
-    // column 0, value 0 and are never added); the additions stay strictly left to right
-    constexpr int B = 16;
-    uint32_t cn[B];
+    for (uint32_t k0 = 0; k0 < maxWidth; k0 += kCgTile) {
+        double v[kCgTile / 4], pv[kCgTile / 4];
 #pragma unroll
-    for (int j = 0; j < B; ++j) cn[j] = d.col[base + (uint64_t)((uint32_t)j < width ? j : (width ? width - 1 : 0)) * 64];
-    for (uint32_t k0 = 0; k0 < width; k0 += B) {
-        double v[B], pv[B];
-#pragma unroll
-        for (int j = 0; j < B; ++j) pv[j] = d.p[cn[j]];
-#pragma unroll
-        for (int j = 0; j < B; ++j) {
-            const uint32_t k = k0 + j < width ? k0 + j : width - 1;
-            v[j] = d.val[base + (uint64_t)k * 64];
-            const uint32_t kn = k0 + B + j < width ? k0 + B + j : width - 1;
-            cn[j] = d.col[base + (uint64_t)kn * 64];
+        for (int m = 0; m < kCgTile / 4; ++m) {
+            const uint32_t k = k0 + q + 4 * m;
+            const uint64_t idx = base + (uint64_t)(k < width ? k : (width ? width - 1 : 0)) * 64;
+            v[m] = width ? d.val[idx] : 0.0;
+            pv[m] = width ? d.p[d.col[idx]] : 0.0;
         }
 #pragma unroll
-        for (int j = 0; j < B; ++j)
-            if (k0 + j < len) acc += v[j] * pv[j];
+        for (int m = 0; m < kCgTile / 4; ++m) sProd[sl][q + 4 * m][lane] = v[m] * pv[m];
+        __syncthreads();
+        if (q == 0) {
+            const uint32_t end = len < k0 + kCgTile ? len : k0 + kCgTile;
+            for (uint32_t k = k0; k < end; ++k) acc += sProd[sl][k - k0][lane];
+        }
+        __syncthreads();
     }
-    if (live) d.tmp[i] = acc;
-    const double cs = blockChunkSum(live ? pi * acc : 0.0, sh);
-    if (threadIdx.x == 0) d.partA[blockIdx.x] = cs;
+    if (q == 0 && live) d.tmp[row] = acc;
+    // cgChunkSum over the chunk's 256 values p . tmp (rows past n hold 0.0): element e of the chunk = slice e / 64, lane e % 64
+    double* sh = &sProd[0][0][0];
+    if (q == 0) sh[sl * 64 + lane] = live ? pi * acc : 0.0;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        double s = ((sh[lane] + sh[64 + lane]) + sh[128 + lane]) + sh[192 + lane];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s = s + __shfl_down(s, off, 64);
+        if (lane == 0) d.partA[blockIdx.x] = s;
+    }
 }
 
 // the chunk sums left to right, by thread 0 out of LDS (tiles of 1024)
@@ -172,7 +190,7 @@ hipError_t launchCgIterations(hipStream_t stream, const CgDev& d, int iterations
     if (d.nChunks != (d.n + kCgChunk - 1) / kCgChunk) return hipErrorInvalidValue;
     const dim3 wide((unsigned)d.nChunks), one(1);
     for (int k = 0; k < iterations; ++k) {
-        hipLaunchKernelGGL(cg_spmv_kernel, wide, dim3(256), 0, stream, d);
+        hipLaunchKernelGGL(cg_spmv_kernel, wide, dim3(1024), 0, stream, d);
         hipLaunchKernelGGL(cg_alpha_kernel, one, dim3(1024), 0, stream, d);
         hipLaunchKernelGGL(cg_update_kernel, wide, dim3(256), 0, stream, d);
         hipLaunchKernelGGL(cg_beta_kernel, one, dim3(1024), 0, stream, d);
