@@ -198,3 +198,15 @@ def test_meshing_dropin_on_gpu(H, tmp_path):
     exe, obj = build_mesh_prog(H, str(tmp_path))
     r = subprocess.run([exe, obj], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_example_benchmark_program_compiles(H, tmp_path):
+    """examples/hp_benchmarks.cpp (the reference's benchmark workloads through the drop-in headers) builds with plain g++."""
+    exe = str(tmp_path / "hp_benchmarks")
+    libdir = os.path.dirname(H.LIB_PATH)
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wno-comment", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "hp_benchmarks.cpp"), "-o", exe, "-L", libdir, "-lhpsdf", "-Wl,-rpath," + libdir,
+           "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-pthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "warning" not in r.stderr, r.stderr[-3000:]
