@@ -84,6 +84,8 @@ int makeFieldDev(const hpsdf_field* f, const double* dSamples, FieldDev* out) {
 // ---- host-array entry points: cached device + pinned scratch ---------------------------------------------
 namespace {
 constexpr size_t kPinnedPathBytes = 1u << 20;  // below this, user memory is staged through the pinned buffer
+constexpr size_t kZeroCopyBytes = 4096;        // below this the kernel works on the pinned buffer itself: a scalar
+                                               // Query(pt) then costs a launch and a wait, not two copies as well
 inline size_t alignUp(size_t b) { return (b + 255) & ~(size_t)255; }
 
 int ensureHostScratch(hpsdf_ctx* ctx, size_t devBytes, size_t pinBytes) {
@@ -104,6 +106,8 @@ int ensureHostScratch(hpsdf_ctx* ctx, size_t devBytes, size_t pinBytes) {
         while (cap < pinBytes) cap *= 2;
         HPSDF_HIP(hipHostMalloc((void**)&ctx->hostPin, cap, hipHostMallocDefault));
         ctx->hostPinCap = cap;
+        void* dp = nullptr;
+        ctx->hostPinDev = hipHostGetDevicePointer(&dp, ctx->hostPin, 0) == hipSuccess ? (char*)dp : nullptr;
     }
     return HPSDF_OK;
 }
@@ -125,16 +129,18 @@ int hostCall(hpsdf_ctx* ctx, HostArray* arrays, int nArrays, Run&& run) {
     const bool staged = total <= kPinnedPathBytes;
     int rc = ensureHostScratch(ctx, total, staged ? total : 0);
     if (rc) return rc;
+    static const bool zeroCopyOff = std::getenv("HPSDF_NO_ZEROCOPY") != nullptr;  // measurement knob
+    const bool zeroCopy = total <= kZeroCopyBytes && ctx->hostPinDev != nullptr && !zeroCopyOff;
     size_t off = 0;
     for (int a = 0; a < nArrays; ++a) {
-        arrays[a].dev = ctx->hostDev + off;
+        arrays[a].dev = zeroCopy ? ctx->hostPinDev + off : ctx->hostDev + off;
         if (arrays[a].src) {
             const void* from = arrays[a].src;
             if (staged) {
                 std::memcpy(ctx->hostPin + off, arrays[a].src, arrays[a].bytes);
                 from = ctx->hostPin + off;
             }
-            HPSDF_HIP(hipMemcpyAsync(arrays[a].dev, from, arrays[a].bytes, hipMemcpyHostToDevice, ctx->stream));
+            if (!zeroCopy) HPSDF_HIP(hipMemcpyAsync(arrays[a].dev, from, arrays[a].bytes, hipMemcpyHostToDevice, ctx->stream));
         }
         off += alignUp(arrays[a].bytes);
     }
@@ -145,7 +151,7 @@ int hostCall(hpsdf_ctx* ctx, HostArray* arrays, int nArrays, Run&& run) {
     }
     off = 0;
     for (int a = 0; a < nArrays; ++a) {
-        if (arrays[a].dst)
+        if (arrays[a].dst && !zeroCopy)
             HPSDF_HIP(hipMemcpyAsync(staged ? (void*)(ctx->hostPin + off) : arrays[a].dst, arrays[a].dev, arrays[a].bytes,
                                      hipMemcpyDeviceToHost, ctx->stream));
         off += alignUp(arrays[a].bytes);

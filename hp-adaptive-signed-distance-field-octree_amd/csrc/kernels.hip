@@ -1017,6 +1017,20 @@ __global__ __launch_bounds__(256) void query_deep_kernel(TreeDev t, const Device
     }
 }
 
+// Query for a handful of points (what Octree::Query(pt) sends: n = 1): one lane per point, any tree, ONE launch -- the
+// batched kernels' tile machinery and, for trees with leaves of degree > 3, their scan + second pass are three more
+// launches that a scalar call would pay for nothing.  Same queryPoint as the deferred pass: same values.
+template <int MAXP>
+__global__ __launch_bounds__(64) void query_few_kernel(TreeDev t, const DeviceTables* __restrict__ T, const double* __restrict__ xyz,
+                                                       uint32_t n, double* __restrict__ out) {
+    __shared__ double sNl[13 * 11];
+    __shared__ double sRec[26];
+    stageQueryTables(T, sNl, sRec);
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i < n) out[i] = queryPoint<MAXP>(t, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], sNl, sRec);
+}
+
 // Octree::QueryWithGradient + FApproxWithGradient (Octree.cpp:749-789, 904-985), any degree, one lane per point:
 // the second pass of the gradient query for the points query_general_kernel<.., GRAD> deferred (leaves of degree > 3).
 // Dense over the concatenation of the per-workgroup lists, like query_deep_kernel.
@@ -1745,6 +1759,16 @@ static unsigned gridFor(size_t n) {
 hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dXyz, size_t n,
                        double* dOut, double* dGrad, bool allInline, uint32_t* dDeferCount, uint32_t* dDeferIdx) {
     if (n == 0) return hipSuccess;
+    if (!dGrad && n <= kQueryFewPoints) {
+        const dim3 fgrid((unsigned)((n + 63) / 64)), fblock(64);
+        if (t.maxDegree <= 3)
+            hipLaunchKernelGGL((query_few_kernel<3>), fgrid, fblock, 0, stream, t, dTables, dXyz, (uint32_t)n, dOut);
+        else if (t.maxDegree <= 5)
+            hipLaunchKernelGGL((query_few_kernel<5>), fgrid, fblock, 0, stream, t, dTables, dXyz, (uint32_t)n, dOut);
+        else
+            hipLaunchKernelGGL((query_few_kernel<12>), fgrid, fblock, 0, stream, t, dTables, dXyz, (uint32_t)n, dOut);
+        return hipGetLastError();
+    }
     const dim3 grid(gridFor(n)), block(256);
     if (allInline && !dGrad) {
         const char* e = std::getenv("HPSDF_QUERY_DEDUPE");  // tuning knob; default on

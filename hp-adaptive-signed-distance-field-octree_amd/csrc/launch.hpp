@@ -12,6 +12,7 @@ namespace hpsdf {
 constexpr size_t kFitMaxLdsBytes = 60 * 1024;  // stays under the 64 KiB default dynamic-LDS limit
 constexpr int kFitBlockThreads = 256;
 constexpr unsigned kQueryMaxGrid = 256 * 8 * 4;  // workgroups of one Query launch (grid-stride beyond)
+constexpr size_t kQueryFewPoints = 256;  // up to here Query is one launch of query_few_kernel (one lane per point)
 
 constexpr size_t kFitChunkLdsBytes = 40 * 1024;  // sample planes staged per chunk (keeps >= 3 workgroups per CU)
 size_t fitLdsBytes(int degree, int nTasks, int planes);

@@ -85,6 +85,7 @@ struct hpsdf_ctx {
     char* hostDev = nullptr;
     size_t hostDevCap = 0;
     char* hostPin = nullptr;
+    char* hostPinDev = nullptr;  // the pinned buffer as the device sees it (tiny calls run on it directly)
     size_t hostPinCap = 0;
     std::mutex hostLock;
     // Query scratch for trees with leaves of degree > 3: per-workgroup lists of the points finished lane by lane

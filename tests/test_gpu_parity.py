@@ -154,6 +154,22 @@ def test_query_all_degrees_and_depths_bitwise(H, O, ctx):
         assert np.array_equal(bits(got), bits(want))
 
 
+@pytest.mark.parametrize("case", ["C2_union3_1e-5", "A1_union3_1e-7_K1024", "A2_sphere_1e-8_K1024"])
+def test_query_few_points_bitwise(H, O, ctx, golden, case):
+    """Up to 256 points take the single-launch path (query_few_kernel; what a scalar Query(pt) sends): same values as
+    the batched kernels and the oracle, for n = 1, a ragged count, and on both sides of the switch."""
+    g = golden["blocks"][case]
+    blk, _ = H.create_block(ctx, H.make_config(g["target"], g["root_min"], g["root_max"]), product_field(H, g["field"]), g["K"])
+    tree, otree = H.DeviceTree(ctx, blk), O.Tree.from_block(blk)
+    pts = np.concatenate([O.splitmix64_points(300, seed=77), edge_points(np.random.default_rng(5))])
+    want = otree.query(pts)
+    big = tree.query(pts)
+    assert np.array_equal(bits(big), bits(want))
+    for n in (1, 2, 63, 64, 65, 255, 256, 257):
+        assert np.array_equal(bits(tree.query(pts[:n])), bits(want[:n])), n
+    assert np.array_equal(bits(tree.query(pts[-40:])), bits(want[-40:]))  # boundary / outside points
+
+
 def test_query_rejects_bad_blocks(H, ctx):
     for bad in (b"", b"\x00" * 50, np.array([1 << 40], np.uint64).tobytes() + b"\x00" * 300):
         with pytest.raises(H.HpsdfError):
