@@ -1031,6 +1031,85 @@ __global__ __launch_bounds__(64) void query_few_kernel(TreeDev t, const DeviceTa
     if (i < n) out[i] = queryPoint<MAXP>(t, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], sNl, sRec);
 }
 
+// Octree::QueryWithGradient + FApproxWithGradient (Octree.cpp:749-789, 904-985) for point i, any degree, one lane
+__device__ void queryPointWithGradient(const TreeDev& t, size_t i, const double* __restrict__ xyz, double* __restrict__ out,
+                                       double* __restrict__ grad, const double* sNl, const double* sRec) {
+    const double p[3] = {(xyz[3 * i] - t.rootCentre[0]) * t.rootInvSizes[0],
+                         (xyz[3 * i + 1] - t.rootCentre[1]) * t.rootInvSizes[1],
+                         (xyz[3 * i + 2] - t.rootCentre[2]) * t.rootInvSizes[2]};
+    const float fx = (float)p[0], fy = (float)p[1], fz = (float)p[2];
+    if (!(fx >= -0.5f && fx <= 0.5f && fy >= -0.5f && fy <= 0.5f && fz >= -0.5f && fz <= 0.5f)) {
+        out[i] = DBL_MAX;
+        return;
+    }
+    double c[3] = {0.0, 0.0, 0.0}, q = 0.25;
+    int depth = 0;
+    NodeRec rec = t.nodes[0];
+    while (rec.b == kInteriorTag) {
+        uint32_t idx = rec.a;
+        for (int a = 0; a < 3; ++a) {
+            const bool up = p[a] >= c[a];
+            idx += up ? (1u << a) : 0u;
+            c[a] = up ? c[a] + q : c[a] - q;
+        }
+        q = q * 0.5;
+        ++depth;
+        rec = t.nodes[idx];
+    }
+    const int degree = (int)rec.b;
+    const double* __restrict__ co = t.coeffs + rec.a;
+    const double eps = 0.0001, s = (double)(2 << depth);
+    double L[13][3][3];
+    for (int a = 0; a < 3; ++a) {
+        const double u = (p[a] - c[a]) * s;  // :907
+        L[0][a][0] = L[0][a][1] = L[0][a][2] = sNl[depth];
+        double a2 = 0.0, a1 = 1.0, b2 = 0.0, b1 = 1.0, c2 = 0.0, c1 = 1.0;
+        for (int j = 1; j <= degree; ++j) {
+            const double r0 = sRec[2 * j], r1 = sRec[2 * j + 1], nl = sNl[j * 11 + depth];
+            const double a0 = r0 * u * a1 - r1 * a2;          // :937
+            const double b0 = r0 * (u + eps) * b1 - r1 * b2;  // :941
+            const double c0 = r0 * (u - eps) * c1 - r1 * c2;  // :945
+            a2 = a1, a1 = a0, b2 = b1, b1 = b0, c2 = c1, c1 = c0;
+            L[j][a][0] = a0 * nl, L[j][a][1] = b0 * nl, L[j][a][2] = c0 * nl;
+        }
+    }
+    const int nc = coeffCount(degree);
+    double g[3];
+    for (int k = 0; k < 3; ++k) {  // :956-968
+        double p1 = 0.0, m1 = 0.0;
+        for (int r = 0; r < nc; ++r) {
+            p1 = p1 + co[r] * L[kBasis.v[r][k]][k][1];
+            m1 = m1 + co[r] * L[kBasis.v[r][k]][k][2];
+        }
+        g[k] = (p1 - m1) / (2.0 * eps);
+    }
+    const double z = g[0] * g[0] + (g[1] * g[1] + g[2] * g[2]);  // Eigen normalize()
+    if (z > 0.0) {
+        const double nrm = sqrt(z);
+        g[0] = g[0] / nrm, g[1] = g[1] / nrm, g[2] = g[2] / nrm;
+    }
+    double f = 0.0;  // :972-984
+    for (int r = 0; r < nc; ++r) {
+        double lp = L[kBasis.v[r][0]][0][0];
+        lp = lp * L[kBasis.v[r][1]][1][0];
+        lp = lp * L[kBasis.v[r][2]][2][0];
+        f = f + co[r] * lp;
+    }
+    out[i] = f;
+    grad[3 * i] = g[0], grad[3 * i + 1] = g[1], grad[3 * i + 2] = g[2];
+}
+
+// QueryWithGradient for a handful of points in one launch (the scalar call of the drop-in), like query_few_kernel
+__global__ __launch_bounds__(64) void query_grad_few_kernel(TreeDev t, const DeviceTables* __restrict__ T, const double* __restrict__ xyz,
+                                                            uint32_t n, double* __restrict__ out, double* __restrict__ grad) {
+    __shared__ double sNl[13 * 11];
+    __shared__ double sRec[26];
+    stageQueryTables(T, sNl, sRec);
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i < n) queryPointWithGradient(t, i, xyz, out, grad, sNl, sRec);
+}
+
 // Octree::QueryWithGradient + FApproxWithGradient (Octree.cpp:749-789, 904-985), any degree, one lane per point:
 // the second pass of the gradient query for the points query_general_kernel<.., GRAD> deferred (leaves of degree > 3).
 // Dense over the concatenation of the per-workgroup lists, like query_deep_kernel.
@@ -1047,69 +1126,7 @@ __global__ __launch_bounds__(256) void query_grad_deep_kernel(TreeDev t, const D
     __syncthreads();
     for (uint32_t jj = blockIdx.x * blockDim.x + threadIdx.x; jj < total; jj += gridDim.x * blockDim.x) {
         const size_t i = deferredPoint(jj, offsets, nWg, tilesPerWg, deferIdx);
-        const double p[3] = {(xyz[3 * i] - t.rootCentre[0]) * t.rootInvSizes[0],
-                             (xyz[3 * i + 1] - t.rootCentre[1]) * t.rootInvSizes[1],
-                             (xyz[3 * i + 2] - t.rootCentre[2]) * t.rootInvSizes[2]};
-        const float fx = (float)p[0], fy = (float)p[1], fz = (float)p[2];
-        if (!(fx >= -0.5f && fx <= 0.5f && fy >= -0.5f && fy <= 0.5f && fz >= -0.5f && fz <= 0.5f)) {
-            out[i] = DBL_MAX;
-            continue;
-        }
-        double c[3] = {0.0, 0.0, 0.0}, q = 0.25;
-        int depth = 0;
-        NodeRec rec = t.nodes[0];
-        while (rec.b == kInteriorTag) {
-            uint32_t idx = rec.a;
-            for (int a = 0; a < 3; ++a) {
-                const bool up = p[a] >= c[a];
-                idx += up ? (1u << a) : 0u;
-                c[a] = up ? c[a] + q : c[a] - q;
-            }
-            q = q * 0.5;
-            ++depth;
-            rec = t.nodes[idx];
-        }
-        const int degree = (int)rec.b;
-        const double* __restrict__ co = t.coeffs + rec.a;
-        const double eps = 0.0001, s = (double)(2 << depth);
-        double L[13][3][3];
-        for (int a = 0; a < 3; ++a) {
-            const double u = (p[a] - c[a]) * s;  // :907
-            L[0][a][0] = L[0][a][1] = L[0][a][2] = sNl[depth];
-            double a2 = 0.0, a1 = 1.0, b2 = 0.0, b1 = 1.0, c2 = 0.0, c1 = 1.0;
-            for (int j = 1; j <= degree; ++j) {
-                const double r0 = sRec[2 * j], r1 = sRec[2 * j + 1], nl = sNl[j * 11 + depth];
-                const double a0 = r0 * u * a1 - r1 * a2;          // :937
-                const double b0 = r0 * (u + eps) * b1 - r1 * b2;  // :941
-                const double c0 = r0 * (u - eps) * c1 - r1 * c2;  // :945
-                a2 = a1, a1 = a0, b2 = b1, b1 = b0, c2 = c1, c1 = c0;
-                L[j][a][0] = a0 * nl, L[j][a][1] = b0 * nl, L[j][a][2] = c0 * nl;
-            }
-        }
-        const int nc = coeffCount(degree);
-        double g[3];
-        for (int k = 0; k < 3; ++k) {  // :956-968
-            double p1 = 0.0, m1 = 0.0;
-            for (int r = 0; r < nc; ++r) {
-                p1 = p1 + co[r] * L[kBasis.v[r][k]][k][1];
-                m1 = m1 + co[r] * L[kBasis.v[r][k]][k][2];
-            }
-            g[k] = (p1 - m1) / (2.0 * eps);
-        }
-        const double z = g[0] * g[0] + (g[1] * g[1] + g[2] * g[2]);  // Eigen normalize()
-        if (z > 0.0) {
-            const double nrm = sqrt(z);
-            g[0] = g[0] / nrm, g[1] = g[1] / nrm, g[2] = g[2] / nrm;
-        }
-        double f = 0.0;  // :972-984
-        for (int r = 0; r < nc; ++r) {
-            double lp = L[kBasis.v[r][0]][0][0];
-            lp = lp * L[kBasis.v[r][1]][1][0];
-            lp = lp * L[kBasis.v[r][2]][2][0];
-            f = f + co[r] * lp;
-        }
-        out[i] = f;
-        grad[3 * i] = g[0], grad[3 * i + 1] = g[1], grad[3 * i + 2] = g[2];
+        queryPointWithGradient(t, i, xyz, out, grad, sNl, sRec);
     }
 }
 
@@ -1759,6 +1776,11 @@ static unsigned gridFor(size_t n) {
 hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dXyz, size_t n,
                        double* dOut, double* dGrad, bool allInline, uint32_t* dDeferCount, uint32_t* dDeferIdx) {
     if (n == 0) return hipSuccess;
+    if (dGrad && n <= kQueryFewPoints) {
+        hipLaunchKernelGGL(query_grad_few_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, t, dTables, dXyz, (uint32_t)n, dOut,
+                           dGrad);
+        return hipGetLastError();
+    }
     if (!dGrad && n <= kQueryFewPoints) {
         const dim3 fgrid((unsigned)((n + 63) / 64)), fblock(64);
         if (t.maxDegree <= 3)

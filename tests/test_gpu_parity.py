@@ -168,6 +168,15 @@ def test_query_few_points_bitwise(H, O, ctx, golden, case):
     for n in (1, 2, 63, 64, 65, 255, 256, 257):
         assert np.array_equal(bits(tree.query(pts[:n])), bits(want[:n])), n
     assert np.array_equal(bits(tree.query(pts[-40:])), bits(want[-40:]))  # boundary / outside points
+    # QueryWithGradient has the same switch (query_grad_few_kernel)
+    wv, wg = otree.query_with_gradient(pts)
+    init = np.full((len(pts), 3), 7.0)  # rows of outside points keep the caller's values
+    for n in (1, 64, 65, 256, 257, len(pts)):
+        gv, gg = tree.query_with_gradient(pts[:n], init[:n])
+        assert np.array_equal(bits(gv), bits(wv[:n])), n
+        inside = wv[:n] < 1e300
+        assert np.array_equal(bits(gg[inside]), bits(wg[:n][inside])), n
+        assert np.all(gg[~inside] == 7.0)
 
 
 def test_query_rejects_bad_blocks(H, ctx):
