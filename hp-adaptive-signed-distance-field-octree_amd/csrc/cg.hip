@@ -50,9 +50,10 @@ __global__ __launch_bounds__(256) void cg_ell_kernel(uint64_t n, const uint64_t*
 // are independent of every addition, so they are all in flight at once (a thread per row ran one dependent
 // load -> gather -> add chain per entry batch: 30 us per SpMV against 8 for the bytes alone).
 constexpr int kCgTile = 32;
-__global__ __launch_bounds__(1024) void cg_spmv_kernel(CgDev d) {
+// out = (M + shift I) in and the chunk sums of in . out -> part
+__device__ __forceinline__ void spmvChunk(const CgDev& d, const double* __restrict__ in, double shift, double* __restrict__ out,
+                                          double* __restrict__ part) {
     __shared__ double sProd[4][kCgTile][64];  // [slice of the chunk][entry in tile][row in slice]; reused for the chunk sum
-    if (d.s->done) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sl = wave >> 2, q = wave & 3;
     const uint64_t row = (uint64_t)blockIdx.x * 256 + sl * 64 + lane;
     const bool live = row < d.n;
@@ -67,8 +68,8 @@ __global__ __launch_bounds__(1024) void cg_spmv_kernel(CgDev d) {
         maxWidth = w > maxWidth ? w : maxWidth;
     }
     const uint32_t len = live ? d.rowLen[row] : 0u;
-    const double pi = live ? d.p[row] : 0.0;
-    double acc = d.s->lambda * pi;
+    const double pi = live ? in[row] : 0.0;
+    double acc = shift * pi;
     for (uint32_t k0 = 0; k0 < maxWidth; k0 += kCgTile) {
         double v[kCgTile / 4], pv[kCgTile / 4];
 #pragma unroll
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(1024) void cg_spmv_kernel(CgDev d) {
             const uint32_t k = k0 + q + 4 * m;
             const uint64_t idx = base + (uint64_t)(k < width ? k : (width ? width - 1 : 0)) * 64;
             v[m] = width ? d.val[idx] : 0.0;
-            pv[m] = width ? d.p[d.col[idx]] : 0.0;
+            pv[m] = width ? in[d.col[idx]] : 0.0;
         }
 #pragma unroll
         for (int m = 0; m < kCgTile / 4; ++m) sProd[sl][q + 4 * m][lane] = v[m] * pv[m];
@@ -87,8 +88,8 @@ __global__ __launch_bounds__(1024) void cg_spmv_kernel(CgDev d) {
         }
         __syncthreads();
     }
-    if (q == 0 && live) d.tmp[row] = acc;
-    // cgChunkSum over the chunk's 256 values p . tmp (rows past n hold 0.0): element e of the chunk = slice e / 64, lane e % 64
+    if (q == 0 && live) out[row] = acc;
+    // cgChunkSum over the chunk's 256 values in . out (rows past n hold 0.0): element e of the chunk = slice e / 64, lane e % 64
     double* sh = &sProd[0][0][0];
     if (q == 0) sh[sl * 64 + lane] = live ? pi * acc : 0.0;
     __syncthreads();
@@ -96,8 +97,53 @@ __global__ __launch_bounds__(1024) void cg_spmv_kernel(CgDev d) {
         double s = ((sh[lane] + sh[64 + lane]) + sh[128 + lane]) + sh[192 + lane];
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) s = s + __shfl_down(s, off, 64);
-        if (lane == 0) d.partA[blockIdx.x] = s;
+        if (lane == 0) part[blockIdx.x] = s;
     }
+}
+
+__global__ __launch_bounds__(1024) void cg_spmv_kernel(CgDev d) {  // region 1 of an iteration
+    if (d.s->done) return;
+    spmvChunk(d, d.p, d.s->lambda, d.tmp, d.partA);
+}
+
+// ---- the steps around the loop (continuity.cpp runs them on the host when it has no device): same arithmetic
+// which: 0  tmp = M c, chunk sums of c . tmp (jump energy before);  1  tmp = (M + lambda I) x (for the first residual);
+//        2  tmp = M x, chunk sums of x . tmp (jump energy after)
+__global__ __launch_bounds__(1024) void cg_spmv_aux_kernel(CgDev d, int which) {
+    spmvChunk(d, which == 0 ? d.c : d.x, which == 1 ? d.s->lambda : 0.0, d.tmp, d.partA);
+}
+
+// rhs = lambda c, x = rhs (solveWithGuess(old, old)), dinv = 1 / (lambda + diagonal entries of the row, in row order)
+__global__ __launch_bounds__(256) void cg_setup_kernel(CgDev d) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.n) return;
+    const double lambda = d.s->lambda;
+    const double rhs = d.c[i] * lambda;
+    d.rhs[i] = rhs;
+    d.x[i] = rhs;
+    const uint64_t base = d.sliceOff[i >> 6] + (i & 63);
+    double diag = lambda;
+    for (uint32_t k = 0, len = d.rowLen[i]; k < len; ++k)
+        if (d.col[base + (uint64_t)k * 64] == (uint32_t)i) diag += d.val[base + (uint64_t)k * 64];
+    d.dinv[i] = 1.0 / diag;
+}
+
+// r = rhs - tmp, p = dinv r, and the chunk sums of rhs . rhs, r . r, r . p
+__global__ __launch_bounds__(256) void cg_residual_kernel(CgDev d) {
+    __shared__ double sh[256];
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < d.n;
+    double bb = 0.0, rr = 0.0, rp = 0.0;
+    if (live) {
+        const double rhs = d.rhs[i], r = rhs - d.tmp[i], p = d.dinv[i] * r;
+        d.r[i] = r;
+        d.p[i] = p;
+        bb = rhs * rhs, rr = r * r, rp = r * p;
+    }
+    const double a = blockChunkSum(bb, sh);
+    const double b = blockChunkSum(rr, sh);
+    const double c = blockChunkSum(rp, sh);
+    if (threadIdx.x == 0) d.partA[blockIdx.x] = a, d.partB[blockIdx.x] = b, d.partC[blockIdx.x] = c;
 }
 
 // the chunk sums left to right, by thread 0 out of LDS (tiles of 1024)
@@ -118,6 +164,46 @@ __device__ __forceinline__ void sumChunks(const CgDev& d, double& sumA, double& 
             }
         }
         __syncthreads();
+    }
+}
+
+// which: 0  jumpBefore = sum of partA;  2  jumpAfter = sum of partA;
+//        1  |b|^2, |r|^2, r . p from partA / partB / partC -> threshold, absNew, and whether there is anything to iterate
+__global__ __launch_bounds__(1024) void cg_scalar_aux_kernel(CgDev d, int which) {
+    double a, b;
+    sumChunks<true>(d, a, b);
+    __shared__ double tc[1024];
+    double c = 0.0;
+    if (which == 1) {
+        for (uint64_t c0 = 0; c0 < d.nChunks; c0 += 1024) {
+            const uint64_t ci = c0 + threadIdx.x;
+            tc[threadIdx.x] = ci < d.nChunks ? d.partC[ci] : 0.0;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int m = (int)(d.nChunks - c0 < 1024 ? d.nChunks - c0 : 1024);
+                for (int j = 0; j < m; ++j) c += tc[j];
+            }
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x != 0) return;
+    CgScalars& s = *d.s;
+    if (which == 0) {
+        s.jumpBefore = a;
+    } else if (which == 2) {
+        s.jumpAfter = a;
+    } else {
+        s.rhsNorm2 = a;
+        s.resNorm2 = b;
+        s.absNew = c;
+        if (a == 0.0) {  // Eigen: a zero right-hand side has the zero solution
+            s.resNorm2 = 0.0;
+            s.done = 3;
+        } else {
+            const double t = s.tol * s.tol * a;
+            s.threshold = t > 2.2250738585072014e-308 ? t : 2.2250738585072014e-308;  // max(tol^2 |b|^2, DBL_MIN)
+            if (b < s.threshold) s.done = 1;
+        }
     }
 }
 
@@ -182,6 +268,27 @@ hipError_t launchCgLayout(hipStream_t stream, uint64_t n, const uint64_t* dRowPt
     if (d.n == 0) return hipSuccess;
     hipLaunchKernelGGL(cg_ell_kernel, dim3((unsigned)d.nChunks), dim3(256), 0, stream, n, dRowPtr, dCsrCol, dCsrVal, d.sliceOff,
                        const_cast<uint32_t*>(d.rowLen), const_cast<uint32_t*>(d.col), const_cast<double*>(d.val));
+    return hipGetLastError();
+}
+
+// everything before the loop: setup, jump energy of c, first residual, threshold
+hipError_t launchCgStart(hipStream_t stream, const CgDev& d) {
+    if (d.n == 0) return hipSuccess;
+    const dim3 wide((unsigned)d.nChunks), one(1);
+    hipLaunchKernelGGL(cg_setup_kernel, wide, dim3(256), 0, stream, d);
+    hipLaunchKernelGGL(cg_spmv_aux_kernel, wide, dim3(1024), 0, stream, d, 0);
+    hipLaunchKernelGGL(cg_scalar_aux_kernel, one, dim3(1024), 0, stream, d, 0);
+    hipLaunchKernelGGL(cg_spmv_aux_kernel, wide, dim3(1024), 0, stream, d, 1);
+    hipLaunchKernelGGL(cg_residual_kernel, wide, dim3(256), 0, stream, d);
+    hipLaunchKernelGGL(cg_scalar_aux_kernel, one, dim3(1024), 0, stream, d, 1);
+    return hipGetLastError();
+}
+
+// after the loop: the jump energy of x
+hipError_t launchCgFinish(hipStream_t stream, const CgDev& d) {
+    if (d.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(cg_spmv_aux_kernel, dim3((unsigned)d.nChunks), dim3(1024), 0, stream, d, 2);
+    hipLaunchKernelGGL(cg_scalar_aux_kernel, dim3(1), dim3(1024), 0, stream, d, 2);
     return hipGetLastError();
 }
 

@@ -605,11 +605,12 @@ int continuityMatrix(const void* block, size_t size, uint64_t threads, uint64_t*
 }
 
 // Octree::PerformContinuityPostProcess, :1717-1762, in place on the serialised block
-// The CG loop on the device: uploads the system and the state the host set up, runs batches of iterations until the
-// stop flag is up, brings x back.  Returns 0 or an HPSDF_ERR code (err filled).
-static int solveOnDevice(hpsdf_ctx* ctx, const Csr& M, double lambda, double threshold, int maxIter, double absNew,
-                         const std::vector<double>& dinv, std::vector<double>& x, const std::vector<double>& r,
-                         const std::vector<double>& p, int* iterations, double* resNorm2, std::string& err) {
+// The whole solve on the device: uploads the matrix and the block's coefficients, lets cg.hip set up the system
+// (right-hand side, initial guess, Jacobi diagonal, first residual, threshold -- the statements of the host path below,
+// same arithmetic), runs batches of iterations until the stop flag is up, brings x and the statistics back.
+// Returns 0 or an HPSDF_ERR code (err filled).
+static int solveOnDevice(hpsdf_ctx* ctx, const Csr& M, const double* coeffs, double lambda, double tol, int maxIter, double* xOut,
+                         hpsdf_continuity_stats& st, std::string& err) {
     const uint64_t n = M.n, nChunks = (n + kCgChunk - 1) / kCgChunk;
     if (n >= 0xFFFFFFFFull) {
         err = "continuity system too large for 32-bit column indices";
@@ -632,7 +633,7 @@ static int solveOnDevice(hpsdf_ctx* ctx, const Csr& M, double lambda, double thr
     for (uint64_t q = 0; q < nnz; ++q) col32[q] = (uint32_t)M.col[q];
     const double tt1 = nowMs();
     const uint64_t vecB = al(n * 8), partB = al(nChunks * 8);
-    const uint64_t total = al((nSlices + 1) * 8) + al(n * 4) + al(ell * 4 + 4) + al(ell * 8 + 8) + 7 * vecB + 2 * partB + 256 +
+    const uint64_t total = al((nSlices + 1) * 8) + al(n * 4) + al(ell * 4 + 4) + al(ell * 8 + 8) + 9 * vecB + 3 * partB + 256 +
                            al((n + 1) * 8) + al(nnz * 4 + 4) + al(nnz * 8 + 8);
     char* base = nullptr;
     hipError_t e = hipSetDevice(ctx->device);
@@ -653,48 +654,54 @@ static int solveOnDevice(hpsdf_ctx* ctx, const Csr& M, double lambda, double thr
     uint32_t* dLen = (uint32_t*)take(n * 4);
     uint32_t* dCol = (uint32_t*)take(ell * 4 + 4);
     double* dVal = (double*)take(ell * 8 + 8);
-    double* dDinv = (double*)take(n * 8);
-    d.sliceOff = dSlice, d.rowLen = dLen, d.col = dCol, d.val = dVal, d.dinv = dDinv;
+    double* dC = (double*)take(n * 8);
+    d.sliceOff = dSlice, d.rowLen = dLen, d.col = dCol, d.val = dVal, d.c = dC;
+    d.dinv = (double*)take(n * 8), d.rhs = (double*)take(n * 8);
     d.x = (double*)take(n * 8), d.r = (double*)take(n * 8), d.p = (double*)take(n * 8), d.z = (double*)take(n * 8);
     d.tmp = (double*)take(n * 8);
-    d.partA = (double*)take(nChunks * 8), d.partB = (double*)take(nChunks * 8);
+    d.partA = (double*)take(nChunks * 8), d.partB = (double*)take(nChunks * 8), d.partC = (double*)take(nChunks * 8);
     d.s = (CgScalars*)take(sizeof(CgScalars));
     uint64_t* dRowPtr = (uint64_t*)take((n + 1) * 8);
     uint32_t* dCsrCol = (uint32_t*)take(nnz * 4 + 4);
     double* dCsrVal = (double*)take(nnz * 8 + 8);
     CgScalars s;
     std::memset(&s, 0, sizeof s);
-    s.absNew = absNew, s.threshold = threshold, s.lambda = lambda, s.maxIter = maxIter;
-    hipStream_t st = ctx->stream;
+    s.lambda = lambda, s.tol = tol, s.maxIter = maxIter;
+    hipStream_t stm = ctx->stream;
     auto up = [&](void* dst, const void* src, uint64_t bytes) {
-        if (e == hipSuccess && bytes) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && bytes) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stm);
     };
     up(dSlice, sliceOff.data(), (nSlices + 1) * 8), up(dRowPtr, M.rowPtr.data(), (n + 1) * 8);
     up(dCsrCol, col32.data(), nnz * 4), up(dCsrVal, M.val.data(), nnz * 8);
-    if (e == hipSuccess) e = launchCgLayout(st, n, dRowPtr, dCsrCol, dCsrVal, d);
-    up(dDinv, dinv.data(), n * 8), up(d.x, x.data(), n * 8), up(d.r, r.data(), n * 8), up(d.p, p.data(), n * 8);
-    up(d.s, &s, sizeof s);
-    if (e == hipSuccess && trace) e = hipStreamSynchronize(st);
+    up(dC, coeffs, n * 8), up(d.s, &s, sizeof s);
+    if (e == hipSuccess) e = launchCgLayout(stm, n, dRowPtr, dCsrCol, dCsrVal, d);
+    if (e == hipSuccess) e = launchCgStart(stm, d);
+    if (e == hipSuccess && trace) e = hipStreamSynchronize(stm);
     const double tt2 = nowMs();
     while (e == hipSuccess) {
-        e = launchCgIterations(st, d, 16);
-        if (e == hipSuccess) e = hipMemcpyAsync(&s, d.s, sizeof s, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        e = launchCgIterations(stm, d, 16);
+        if (e == hipSuccess) e = hipMemcpyAsync(&s, d.s, sizeof s, hipMemcpyDeviceToHost, stm);
+        if (e == hipSuccess) e = hipStreamSynchronize(stm);
         if (e != hipSuccess || s.done) break;
     }
     const double tt3 = nowMs();
-    if (e == hipSuccess) e = hipMemcpyAsync(x.data(), d.x, n * 8, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = launchCgFinish(stm, d);
+    if (e == hipSuccess) e = hipMemcpyAsync(&s, d.s, sizeof s, hipMemcpyDeviceToHost, stm);
+    if (e == hipSuccess) e = hipMemcpyAsync(xOut, d.x, n * 8, hipMemcpyDeviceToHost, stm);
+    if (e == hipSuccess) e = hipStreamSynchronize(stm);
     (void)hipFree(base);
     if (trace)
-        std::fprintf(stderr, "[continuity solve] n %llu, ELL entries %llu: layout %.2f ms, malloc + upload %.2f, %d iterations %.2f, download + free %.2f\n",
+        std::fprintf(stderr, "[continuity solve] n %llu, ELL entries %llu: layout %.2f ms, malloc + upload + start %.2f, %d iterations %.2f, finish + download + free %.2f\n",
                      (unsigned long long)n, (unsigned long long)ell, tt1 - tt0, tt2 - tt1, (int)s.it, tt3 - tt2, nowMs() - tt3);
     if (e != hipSuccess) {
         err = std::string("continuity solve: ") + hipGetErrorString(e);
         return HPSDF_ERR_HIP;
     }
-    *iterations = s.it;
-    *resNorm2 = s.resNorm2;
+    if (s.done == 3) std::fill(xOut, xOut + n, 0.0);  // zero right-hand side: the zero solution (Eigen)
+    st.iterations = (uint64_t)s.it;
+    st.residual = s.rhsNorm2 > 0.0 ? std::sqrt(s.resNorm2 / s.rhsNorm2) : 0.0;
+    st.jump_before = s.jumpBefore;
+    st.jump_after = s.jumpAfter;
     return HPSDF_OK;
 }
 
@@ -734,6 +741,21 @@ int continuityPostProcess(void* block, size_t size, double tol, int maxIter, uin
         assemble(b, asmPool, M, st);
     }
     const double t1 = nowMs();
+    if (ctx) {  // the solve, all of it, on the device
+        if (maxIter <= 0) maxIter = (int)std::min<uint64_t>(2 * b.nCoeffs, 0x7FFFFFFF);  // Eigen's default 2n
+        std::vector<double>& xd = keep.v[0];
+        xd.resize(b.nCoeffs);
+        rc = solveOnDevice(ctx, M, b.coeffs, b.cfg.continuity_strength, tol, maxIter, xd.data(), st, err);
+        if (rc) return rc;
+        std::memcpy(b.coeffs, xd.data(), sizeof(double) * b.nCoeffs);  // :1756
+        st.assemble_ms = t1 - t0;
+        st.solve_ms = nowMs() - t1;
+        if (std::getenv("HPSDF_TRACE"))
+            std::fprintf(stderr, "[continuity] parse %.2f ms, assemble %.2f ms, solve %.2f ms (device)\n", t0 - tEntry, st.assemble_ms,
+                         st.solve_ms);
+        if (stats) *stats = st;
+        return HPSDF_OK;
+    }
     // a CG region over a few hundred thousand non-zeros lasts tens of microseconds: one thread per ~0.25 M non-zeros
     // (a per-leaf dense block preconditioner was tried: 106 -> 88 iterations on sphere@1e-8, not worth its triangular solves)
     Pool pool((unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nThreads, st.nnz / 250000)));
@@ -776,11 +798,7 @@ int continuityPostProcess(void* block, size_t size, double tol, int maxIter, uin
             });
             double absNew = V.dot(r.data(), p.data());
             std::vector<double> part2(V.nChunks ? V.nChunks : 1);
-            if (ctx) {
-                rc = solveOnDevice(ctx, M, lambda, threshold, maxIter, absNew, dinv, x, r, p, &it, &resNorm2, err);
-                if (rc) return rc;
-            }
-            while (!ctx && it < maxIter) {
+            while (it < maxIter) {
                 // region 1: tmp = A p and the partial sums of p . tmp
                 pool.forEach(V.nChunks, [&](uint64_t c) {
                     double prod[kVecChunk];

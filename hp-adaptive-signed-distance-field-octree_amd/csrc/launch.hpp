@@ -58,7 +58,8 @@ inline double cgChunkSum(const double* e, uint64_t count) {
 }
 struct CgScalars {
     double absNew, alpha, beta, resNorm2, threshold, lambda;
-    int32_t it, maxIter, done, pad;
+    double tol, rhsNorm2, jumpBefore, jumpAfter;
+    int32_t it, maxIter, done, pad;  // done: 0 iterating, 1 converged, 2 iteration cap, 3 zero right-hand side
 };
 struct CgDev {
     uint64_t n, nChunks;
@@ -67,14 +68,17 @@ struct CgDev {
     const uint32_t* rowLen;    // n
     const uint32_t* col;
     const double* val;
-    const double* dinv;
-    double *x, *r, *p, *z, *tmp, *partA, *partB;
+    const double* c;  // the block's coefficients (right-hand side / lambda, initial guess / lambda)
+    double *dinv, *rhs;
+    double *x, *r, *p, *z, *tmp, *partA, *partB, *partC;
     CgScalars* s;
 };
 // fills d.rowLen / d.col / d.val (sliced ELL, d.sliceOff already uploaded) from the CSR arrays in HBM
 hipError_t launchCgLayout(hipStream_t stream, uint64_t n, const uint64_t* dRowPtr, const uint32_t* dCsrCol, const double* dCsrVal,
                           const CgDev& d);
+hipError_t launchCgStart(hipStream_t stream, const CgDev& d);   // setup, jump energy before, first residual, threshold
 hipError_t launchCgIterations(hipStream_t stream, const CgDev& d, int iterations);
+hipError_t launchCgFinish(hipStream_t stream, const CgDev& d);  // jump energy after
 hipError_t launchPack(hipStream_t stream, const PackItem* dItems, uint32_t nItems, const double* dArena, double* dOut);
 
 }  // namespace hpsdf
