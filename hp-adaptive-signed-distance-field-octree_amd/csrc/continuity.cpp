@@ -605,12 +605,31 @@ int continuityMatrix(const void* block, size_t size, uint64_t threads, uint64_t*
 }
 
 // Octree::PerformContinuityPostProcess, :1717-1762, in place on the serialised block
+// What a context keeps between post-processes: the assembled matrix, the host solver's vectors and the device buffer
+// of the device solve.
+struct Keep {
+    Csr M;
+    std::vector<double> v[8];
+    std::vector<uint64_t> sliceOff;
+    std::vector<uint32_t> col32;
+    char* dBase = nullptr;
+    uint64_t dCap = 0;
+    int device = -1;
+    ~Keep() {
+        if (dBase) {
+            (void)hipSetDevice(device);
+            (void)hipFree(dBase);
+        }
+    }
+};
+
 // The whole solve on the device: uploads the matrix and the block's coefficients, lets cg.hip set up the system
 // (right-hand side, initial guess, Jacobi diagonal, first residual, threshold -- the statements of the host path below,
 // same arithmetic), runs batches of iterations until the stop flag is up, brings x and the statistics back.
 // Returns 0 or an HPSDF_ERR code (err filled).
-static int solveOnDevice(hpsdf_ctx* ctx, const Csr& M, const double* coeffs, double lambda, double tol, int maxIter, double* xOut,
+static int solveOnDevice(hpsdf_ctx* ctx, Keep& keep, const double* coeffs, double lambda, double tol, int maxIter, double* xOut,
                          hpsdf_continuity_stats& st, std::string& err) {
+    const Csr& M = keep.M;
     const uint64_t n = M.n, nChunks = (n + kCgChunk - 1) / kCgChunk;
     if (n >= 0xFFFFFFFFull) {
         err = "continuity system too large for 32-bit column indices";
@@ -622,26 +641,37 @@ static int solveOnDevice(hpsdf_ctx* ctx, const Csr& M, const double* coeffs, dou
     // sliced ELL: every chunk of 256 rows is four slices of 64 (rows past n are empty); the host only sizes the
     // slices, cg_ell_kernel moves the entries
     const uint64_t nSlices = 4 * nChunks, nnz = M.rowPtr[n];
-    std::vector<uint64_t> sliceOff(nSlices + 1, 0);
+    std::vector<uint64_t>& sliceOff = keep.sliceOff;
+    sliceOff.assign(nSlices + 1, 0);
     for (uint64_t sl = 0; sl < nSlices; ++sl) {
         uint64_t w = 0;
         for (uint64_t r0 = sl * 64; r0 < std::min(n, sl * 64 + 64); ++r0) w = std::max(w, M.rowPtr[r0 + 1] - M.rowPtr[r0]);
         sliceOff[sl + 1] = sliceOff[sl] + 64 * w;
     }
     const uint64_t ell = sliceOff[nSlices];
-    std::vector<uint32_t> col32(nnz ? nnz : 1);
+    std::vector<uint32_t>& col32 = keep.col32;
+    col32.resize(nnz ? nnz : 1);
     for (uint64_t q = 0; q < nnz; ++q) col32[q] = (uint32_t)M.col[q];
     const double tt1 = nowMs();
     const uint64_t vecB = al(n * 8), partB = al(nChunks * 8);
     const uint64_t total = al((nSlices + 1) * 8) + al(n * 4) + al(ell * 4 + 4) + al(ell * 8 + 8) + 9 * vecB + 3 * partB + 256 +
                            al((n + 1) * 8) + al(nnz * 4 + 4) + al(nnz * 8 + 8);
-    char* base = nullptr;
     hipError_t e = hipSetDevice(ctx->device);
-    if (e == hipSuccess) e = hipMalloc((void**)&base, total);
+    if (e == hipSuccess && (keep.dCap < total || keep.device != ctx->device)) {
+        if (keep.dBase) {
+            (void)hipSetDevice(keep.device);
+            (void)hipFree(keep.dBase);
+            (void)hipSetDevice(ctx->device);
+        }
+        keep.dBase = nullptr, keep.dCap = 0, keep.device = ctx->device;
+        e = hipMalloc((void**)&keep.dBase, total + total / 4);
+        if (e == hipSuccess) keep.dCap = total + total / 4;
+    }
     if (e != hipSuccess) {
         err = std::string("continuity solve: ") + hipGetErrorString(e);
         return e == hipErrorOutOfMemory ? HPSDF_ERR_OUT_OF_MEMORY : HPSDF_ERR_HIP;
     }
+    char* base = keep.dBase;
     char* cur = base;
     auto take = [&](uint64_t bytes) {
         char* q = cur;
@@ -689,9 +719,8 @@ static int solveOnDevice(hpsdf_ctx* ctx, const Csr& M, const double* coeffs, dou
     if (e == hipSuccess) e = hipMemcpyAsync(&s, d.s, sizeof s, hipMemcpyDeviceToHost, stm);
     if (e == hipSuccess) e = hipMemcpyAsync(xOut, d.x, n * 8, hipMemcpyDeviceToHost, stm);
     if (e == hipSuccess) e = hipStreamSynchronize(stm);
-    (void)hipFree(base);
     if (trace)
-        std::fprintf(stderr, "[continuity solve] n %llu, ELL entries %llu: layout %.2f ms, malloc + upload + start %.2f, %d iterations %.2f, finish + download + free %.2f\n",
+        std::fprintf(stderr, "[continuity solve] n %llu, ELL entries %llu: layout %.2f ms, upload + start %.2f, %d iterations %.2f, finish + download %.2f\n",
                      (unsigned long long)n, (unsigned long long)ell, tt1 - tt0, tt2 - tt1, (int)s.it, tt3 - tt2, nowMs() - tt3);
     if (e != hipSuccess) {
         err = std::string("continuity solve: ") + hipGetErrorString(e);
@@ -723,10 +752,6 @@ int continuityPostProcess(void* block, size_t size, double tol, int maxIter, uin
     // The matrix and the solver's vectors (some 60 MB on a 5 k-node tree) live in the context and are reused by the next
     // call: allocating, first-touching and unmapping them anew cost more than the assembly itself (7.8 -> 3.1 ms) and
     // another 3.5 ms behind the solve.  Without a context they are this call's own.
-    struct Keep {
-        Csr M;
-        std::vector<double> v[8];
-    };
     std::shared_ptr<Keep> own;
     if (ctx) {
         if (!ctx->continuityScratch) ctx->continuityScratch = std::make_shared<Keep>();
@@ -745,7 +770,7 @@ int continuityPostProcess(void* block, size_t size, double tol, int maxIter, uin
         if (maxIter <= 0) maxIter = (int)std::min<uint64_t>(2 * b.nCoeffs, 0x7FFFFFFF);  // Eigen's default 2n
         std::vector<double>& xd = keep.v[0];
         xd.resize(b.nCoeffs);
-        rc = solveOnDevice(ctx, M, b.coeffs, b.cfg.continuity_strength, tol, maxIter, xd.data(), st, err);
+        rc = solveOnDevice(ctx, keep, b.coeffs, b.cfg.continuity_strength, tol, maxIter, xd.data(), st, err);
         if (rc) return rc;
         std::memcpy(b.coeffs, xd.data(), sizeof(double) * b.nCoeffs);  // :1756
         st.assemble_ms = t1 - t0;
