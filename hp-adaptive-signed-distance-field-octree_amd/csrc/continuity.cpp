@@ -477,7 +477,14 @@ int parseBlock(void* block, size_t size, ParsedBlock& out, std::string& err) {
     return HPSDF_OK;
 }
 
-void assemble(const ParsedBlock& b, Pool& pool, Csr& M, hpsdf_continuity_stats& st) {
+// a chunk of leaves' rows before they are copied to their place in the CSR arrays
+struct Fragment {
+    std::vector<uint64_t> cols;
+    std::vector<double> vals;
+};
+
+// frags: scratch the caller may keep between calls (capacity is reused)
+void assemble(const ParsedBlock& b, Pool& pool, Csr& M, hpsdf_continuity_stats& st, std::vector<Fragment>& frags) {
     const Tables& T = tables();
     const View view{b.nodes.data(), b.nNodes};
     std::vector<Pair> pairs;
@@ -491,11 +498,8 @@ void assemble(const ParsedBlock& b, Pool& pool, Csr& M, hpsdf_continuity_stats& 
         if (b.nodes[i].child_idx == kLeafMarker) leaves.push_back(i);
     // leaves in chunks; every chunk builds a private CSR fragment
     const uint64_t chunk = 32, nChunks = (leaves.size() + chunk - 1) / chunk;
-    struct Fragment {
-        std::vector<uint64_t> cols;
-        std::vector<double> vals;
-    };
-    std::vector<Fragment> frags(nChunks);
+    if (frags.size() < nChunks) frags.resize(nChunks);
+    for (uint64_t c = 0; c < nChunks; ++c) frags[c].cols.clear(), frags[c].vals.clear();
     M.n = b.nCoeffs;
     M.rowPtr.assign(M.n + 1, 0);
     pool.forEach(nChunks, [&](uint64_t c) {
@@ -587,7 +591,8 @@ int continuityMatrix(const void* block, size_t size, uint64_t threads, uint64_t*
     Csr M;
     hpsdf_continuity_stats st;
     std::memset(&st, 0, sizeof st);
-    assemble(b, pool, M, st);
+    std::vector<Fragment> frags;
+    assemble(b, pool, M, st, frags);
     *rowPtr = (uint64_t*)std::malloc(sizeof(uint64_t) * (M.n + 1));
     *col = (uint64_t*)std::malloc(sizeof(uint64_t) * (M.col.size() ? M.col.size() : 1));
     *val = (double*)std::malloc(sizeof(double) * (M.val.size() ? M.val.size() : 1));
@@ -612,6 +617,8 @@ struct Keep {
     std::vector<double> v[8];
     std::vector<uint64_t> sliceOff;
     std::vector<uint32_t> col32;
+    std::vector<Fragment> frags;
+    std::unique_ptr<Pool> asmPool;  // the assembly's workers sleep between calls instead of being spawned and joined
     char* dBase = nullptr;
     uint64_t dCap = 0;
     int device = -1;
@@ -761,10 +768,8 @@ int continuityPostProcess(void* block, size_t size, double tol, int maxIter, uin
     }
     Keep& keep = *own;
     Csr& M = keep.M;
-    {
-        Pool asmPool(nThreads);
-        assemble(b, asmPool, M, st);
-    }
+    if (!keep.asmPool || keep.asmPool->size() != nThreads) keep.asmPool.reset(new Pool(nThreads));
+    assemble(b, *keep.asmPool, M, st, keep.frags);
     const double t1 = nowMs();
     if (ctx) {  // the solve, all of it, on the device
         if (maxIter <= 0) maxIter = (int)std::min<uint64_t>(2 * b.nCoeffs, 0x7FFFFFFF);  // Eigen's default 2n
