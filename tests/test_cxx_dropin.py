@@ -200,8 +200,7 @@ def test_meshing_dropin_on_gpu(H, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
-def test_example_benchmark_program_compiles(H, tmp_path):
-    """examples/hp_benchmarks.cpp (the reference's benchmark workloads through the drop-in headers) builds with plain g++."""
+def _build_example(H, tmp_path):
     exe = str(tmp_path / "hp_benchmarks")
     libdir = os.path.dirname(H.LIB_PATH)
     cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wno-comment", "-I", os.path.join(ROOT, "include"),
@@ -210,3 +209,20 @@ def test_example_benchmark_program_compiles(H, tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "warning" not in r.stderr, r.stderr[-3000:]
+    return exe
+
+
+def test_example_benchmark_program_compiles(H, tmp_path):
+    """examples/hp_benchmarks.cpp (the reference's benchmark workloads through the drop-in headers) builds with plain g++."""
+    _build_example(H, tmp_path)
+
+
+@pytest.mark.gpu
+def test_example_benchmark_program_runs(H, tmp_path):
+    r = subprocess.run([_build_example(H, tmp_path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for line in ("Creation (device field)", "Creation + continuity", "Query(pt), one call per point", "QueryWithGradient(8 M points",
+                 "UnionSDF (std::function field"):
+        assert line in r.stdout, r.stdout
+    got, exact = [float(x.strip(" ()")) for x in r.stdout.strip().splitlines()[-1].split(":")[1].replace("exact", "").split("(")]
+    assert abs(got - exact) < 1e-4  # the united tree against min(sphere, sphere)
