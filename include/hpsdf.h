@@ -98,7 +98,12 @@ HPSDF_API int hpsdf_tables_get(double* roots, double* weights, double* normalise
 
 /* ---- device context --------------------------------------------------------- */
 typedef struct hpsdf_ctx hpsdf_ctx;
-/* device: HIP ordinal; stream: hipStream_t to launch on (NULL = a stream owned by the context). */
+/* device: HIP ordinal; stream: hipStream_t to launch on (NULL = a stream owned by the context).
+ * A context owns the build's workspace (coefficient arena, per-round staging, the continuity post-process's matrix,
+ * vectors and worker threads -- all kept between calls): hpsdf_create, the hpsdf_build_* round calls and
+ * hpsdf_continuity_post_process_device use one context from one thread at a time.  The *_host query entry points
+ * serialise themselves per context (Octree::Query* is const and callable from many threads in the reference);
+ * use one context per thread for concurrent builds. */
 HPSDF_API int hpsdf_ctx_create(int device, void* stream, hpsdf_ctx** out);
 HPSDF_API int hpsdf_ctx_destroy(hpsdf_ctx* ctx);
 HPSDF_API int hpsdf_ctx_set_stream(hpsdf_ctx* ctx, void* stream);
