@@ -182,8 +182,25 @@ int builderSelect(hpsdf_build* b, uint64_t* nJobs) {
     }
     const uint64_t want = b->stats.rounds == 0 ? b->heap.size() : std::min<uint64_t>(b->K, b->heap.size());
     b->batch.resize(want);
+    bool sorted = false;
     if (want == b->heap.size()) {  // the whole frontier (always the case in round 0): no heap work needed
-        b->batch.assign(b->heap.begin(), b->heap.end());
+        if (b->stats.rounds == 0) {
+            // round 0 is every leaf of the uniformly refined tree with the initial error: listing them by node index
+            // gives the batch already in order (sorting 4096 heap-ordered entries was 12 % of a Create at 1e-5)
+            bool same = true;
+            for (uint64_t j = 0; j < want && same; ++j) same = std::fabs(b->heap[j].err - HPSDF_INITIAL_NODE_ERR) < DBL_EPSILON;
+            uint64_t k = 0;
+            for (uint64_t i = 0; i < b->nodes.size() && same; ++i)
+                if (b->nodes[i].child_idx == kNone) {
+                    same = k < want;
+                    if (same) {
+                        b->batch[k] = b->heap[0];  // (err, any other field) as pushed
+                        b->batch[k++].idx = i;
+                    }
+                }
+            sorted = same && k == want;
+        }
+        if (!sorted) b->batch.assign(b->heap.begin(), b->heap.end());
         b->heap.clear();
     } else {
         for (uint64_t i = 0; i < want; ++i) {
@@ -192,8 +209,9 @@ int builderSelect(hpsdf_build* b, uint64_t* nJobs) {
             b->heap.pop_back();
         }
     }
-    std::sort(b->batch.begin(), b->batch.end(),
-              [](const hpsdf_build::HeapEnt& x, const hpsdf_build::HeapEnt& y) { return x.idx < y.idx; });
+    if (!sorted)
+        std::sort(b->batch.begin(), b->batch.end(),
+                  [](const hpsdf_build::HeapEnt& x, const hpsdf_build::HeapEnt& y) { return x.idx < y.idx; });
     // contiguous cost-balanced slices, the same on every rank
     std::vector<uint64_t> prefix(want + 1, 0);
     for (uint64_t j = 0; j < want; ++j) {
