@@ -23,8 +23,13 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhpsdf.so")
 _LIB = None
 
 OK = 0
+ERR_INVALID_ARGUMENT = 1
 ERR_NO_DEVICE = 2
+ERR_HIP = 3
+ERR_BAD_BLOCK = 4
 ERR_UNSUPPORTED = 5
+ERR_STATE = 6
+ERR_OUT_OF_MEMORY = 7
 ERR_OPEN_MESH = 8
 PRIM_SPHERE, PRIM_BOX, PRIM_TORUS_Y, PRIM_PLANE = 0, 1, 2, 3
 OP_UNION, OP_INTERSECT, OP_SUBTRACT = 0, 1, 2

@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -14,6 +16,7 @@
 
 #include "builder.hpp"
 #include "continuity.hpp"
+#include "block_check.hpp"
 #include "launch.hpp"
 #include "runtime.hpp"
 
@@ -333,6 +336,10 @@ int hpsdf_field_create_mesh(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts,
     if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "mesh fields live in HBM: a device context is required");
     if (!verts || !tris || !out || nVerts == 0 || nTris == 0) return fail(HPSDF_ERR_INVALID_ARGUMENT, "empty mesh");
     if (nVerts > 0x7FFFFFFFull || nTris > 0x3FFFFFFFull) return fail(HPSDF_ERR_UNSUPPORTED, "mesh too large for 32-bit ids");
+    for (uint64_t i = 0; i < 3 * nTris; ++i)
+        if (tris[i] >= nVerts)
+            return fail(HPSDF_ERR_INVALID_ARGUMENT, "triangle " + std::to_string(i / 3) + " refers to vertex " + std::to_string(tris[i]) +
+                                                        " of " + std::to_string(nVerts));
     HostMesh hm;
     if (!prepareMesh(verts, nVerts, tris, nTris, &hm))
         return fail(HPSDF_ERR_OPEN_MESH, "mesh is not closed: an edge has no twin (Mesh::CreateHalfEdges)");
@@ -499,19 +506,20 @@ int hpsdf_tree_upload(hpsdf_ctx* ctx, const void* block, size_t size, hpsdf_tree
     for (int a = 0; a < 3; ++a)
         if (nodes[0].aabb_min[a] != -0.5f || nodes[0].aabb_max[a] != 0.5f)
             return fail(HPSDF_ERR_UNSUPPORTED, "internal root box must be [-0.5,0.5]^3 (Octree.cpp:798)");
-    std::vector<uint64_t> stack{0};
+    if (nNodes < 9) return fail(HPSDF_ERR_BAD_BLOCK, "an interior root needs its 8 children");
+    BlockTreeInfo walk;
+    {
+        std::string why;
+        const int vrc = checkBlockTree(nodes.data(), nNodes, nCoeffs, T.coeffCount, false, false, &walk, why);
+        if (vrc) return fail(vrc, why);
+    }
     std::vector<double> padded;
     padded.reserve(nCoeffs + 16 * nNodes);
-    uint64_t leaves = 0;
-    int maxDeg = 0, maxDepth = 0, minLeafDepth = kMaxDepth + 1;
-    std::vector<uint8_t> depthOf(nNodes, 0);
-    while (!stack.empty()) {
-        const uint64_t i = stack.back();
-        stack.pop_back();
+    const uint64_t leaves = walk.leaves;
+    const int maxDeg = walk.maxDegree, maxDepth = walk.maxDepth, minLeafDepth = walk.minLeafDepth;
+    for (const uint64_t i : walk.order) {
         const hpsdf_node& n = nodes[i];
         if (n.degree == kInteriorDegree) {
-            if (n.child_idx > nNodes - 8) return fail(HPSDF_ERR_BAD_BLOCK, "child index out of range");
-            if (depthOf[i] >= kMaxDepth + 1) return fail(HPSDF_ERR_BAD_BLOCK, "tree deeper than TREE_MAX_DEPTH + 1");
             recs[i] = NodeRec{(uint32_t)n.child_idx, kInteriorTag};
             for (unsigned c = 0; c < 8; ++c) {
                 const hpsdf_node& ch = nodes[n.child_idx + c];
@@ -521,22 +529,13 @@ int hpsdf_tree_upload(hpsdf_ctx* ctx, const void* block, size_t size, hpsdf_tree
                     if (ch.aabb_min[d] != emin || ch.aabb_max[d] != emax)
                         return fail(HPSDF_ERR_UNSUPPORTED, "child boxes are not midpoint octants of their parent");
                 }
-                depthOf[n.child_idx + c] = (uint8_t)(depthOf[i] + 1);
-                stack.push_back(n.child_idx + c);
             }
         } else {
-            if (n.degree > kMaxDegree) return fail(HPSDF_ERR_BAD_BLOCK, "leaf degree out of range");
-            if (n.coeffs_start + T.coeffCount[n.degree] > nCoeffs) return fail(HPSDF_ERR_BAD_BLOCK, "leaf coefficients out of range");
-            if (n.depth != depthOf[i]) return fail(HPSDF_ERR_BAD_BLOCK, "stored depth does not match tree depth");
             // device mirror: every leaf's block starts on a 128-byte line (the wave-cooperative fetch of
             // query_general_kernel moves whole lines; a degree-2 leaf is one line, a degree-3 leaf two)
             recs[i] = NodeRec{(uint32_t)padded.size(), (uint32_t)n.degree};
             padded.insert(padded.end(), coeffs + n.coeffs_start, coeffs + n.coeffs_start + T.coeffCount[n.degree]);
             padded.resize((padded.size() + 15) & ~(size_t)15, 0.0);
-            ++leaves;
-            maxDeg = std::max(maxDeg, (int)n.degree);
-            maxDepth = std::max(maxDepth, (int)depthOf[i]);
-            minLeafDepth = std::min(minLeafDepth, (int)depthOf[i]);
         }
     }
     if (padded.size() > 0xFFFFFFF0ull) return fail(HPSDF_ERR_UNSUPPORTED, "more than 2^32 coefficients");
@@ -626,7 +625,12 @@ static int queryDevice(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* dXyz, 
     const size_t kChunk = (size_t)1 << 31;  // deferred indices are 32-bit
     for (size_t off = 0; off < n; off += kChunk) {
         const size_t m = std::min(kChunk, n - off);
+        // Query* is const and callable from many threads in the reference (Octree.h:71-78): the deferred-point scratch is
+        // the one piece of context state these entry points touch -- grown and handed to the launch under one lock
+        // (launches on the context stream run in order, so sharing the buffer between them is safe)
+        std::unique_lock<std::mutex> guard(ctx->scratchLock, std::defer_lock);
         if (t->maxDegree > 3) {
+            guard.lock();
             if (!ctx->dDeferCount) HPSDF_HIP(hipMalloc((void**)&ctx->dDeferCount, (2 * kQueryMaxGrid + 1) * sizeof(uint32_t)));
             const size_t need = m + (size_t)256 * kQueryMaxGrid + 4096;  // every workgroup's run is whole tiles
             if (ctx->deferCap < need) {
@@ -971,6 +975,9 @@ int hpsdf_create(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* fie
     hpsdf_build* b = nullptr;
     int rc = hpsdf_build_begin(cfg, &o, &b);
     if (rc) return rc;
+    // whatever throws below (vector growth, std::thread creation in builderCompute ...), the build's destructor runs and
+    // hands the context's workspace back (ws->inUse)
+    std::unique_ptr<hpsdf_build> owner(b);
     const double tBegin = now() - t0;
     std::vector<double> headers;
     for (;;) {
@@ -1019,7 +1026,7 @@ int hpsdf_create(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* fie
     }
     const double tCont = now() - t1;
     t1 = now();
-    delete b;
+    owner.reset();
     if (trace)
         std::fprintf(stderr, "[hpsdf_create] us: begin %.0f select %.0f compute(host+launch) %.0f results(wait+D2H) %.0f apply %.0f "
                              "layout %.0f pack %.0f assemble %.0f continuity %.0f destroy %.0f total %.0f\n",

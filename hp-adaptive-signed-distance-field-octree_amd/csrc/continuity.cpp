@@ -35,6 +35,7 @@
 #include <thread>
 #include <vector>
 
+#include "block_check.hpp"
 #include "continuity.hpp"
 #include "launch.hpp"
 #include "runtime.hpp"
@@ -461,19 +462,22 @@ int parseBlock(void* block, size_t size, ParsedBlock& out, std::string& err) {
     out.nodes.resize(out.nNodes);
     std::memcpy(out.nodes.data(), p + 16 + 8 * out.nCoeffs, sizeof(hpsdf_node) * out.nNodes);
     std::memcpy(&out.cfg, p + 16 + 8 * out.nCoeffs + sizeof(hpsdf_node) * out.nNodes, sizeof out.cfg);
+    // untrusted bytes: walk from the root (block_check.hpp) -- children in range without wrap-around, no node reached
+    // twice (nodeProc recurses along child indices), depths consistent, leaf ranges inside the store and pairwise
+    // disjoint (the assembly writes one row block per leaf, in parallel)
     const Tables& T = tables();
-    for (uint64_t i = 0; i < out.nNodes; ++i) {
-        const hpsdf_node& n = out.nodes[i];
-        if (n.child_idx != kLeafMarker) {
-            if (n.child_idx == 0 || n.child_idx > out.nNodes - 8 || n.degree != kInteriorDegree) {
-                err = "malformed interior node";
-                return HPSDF_ERR_BAD_BLOCK;
-            }
-        } else if (n.degree > kMaxDegree || n.depth > kMaxDepth + 1 || n.coeffs_start + T.coeffCount[n.degree] > out.nCoeffs) {
-            err = "malformed leaf";
+    if (out.nodes[0].degree == kInteriorDegree && out.nNodes < 9) {
+        err = "an interior root needs its 8 children";
+        return HPSDF_ERR_BAD_BLOCK;
+    }
+    BlockTreeInfo walk;
+    const int vrc = checkBlockTree(out.nodes.data(), out.nNodes, out.nCoeffs, T.coeffCount, true, true, &walk, err);
+    if (vrc) return vrc;
+    for (uint64_t i = 0; i < out.nNodes; ++i)
+        if (!walk.reached[i]) {
+            err = "node not reachable from the root";
             return HPSDF_ERR_BAD_BLOCK;
         }
-    }
     return HPSDF_OK;
 }
 

@@ -88,6 +88,7 @@ struct hpsdf_ctx {
     char* hostPinDev = nullptr;  // the pinned buffer as the device sees it (tiny calls run on it directly)
     size_t hostPinCap = 0;
     std::mutex hostLock;
+    std::mutex scratchLock;  // growth of dDefer / dDeferCount below (the *_device query entry points)
     // Query scratch for trees with leaves of degree > 3: per-workgroup lists of the points finished lane by lane
     uint32_t* dDefer = nullptr;
     uint64_t deferCap = 0;

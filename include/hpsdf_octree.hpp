@@ -305,6 +305,8 @@ class Octree {
     /// Creates an octree from a previously serialised version; the block stays the caller's   (Octree.h:65)
     void FromMemoryBlock(MemoryBlock octBlock_) {
         if (!octBlock_.size || !octBlock_.ptr) throw Error(HPSDF_ERR_BAD_BLOCK, "empty MemoryBlock");
+        if (octBlock_.size < 16 + sizeof(hpsdf_config))  // two counts + Config: nothing smaller can be a block
+            throw Error(HPSDF_ERR_BAD_BLOCK, "MemoryBlock too small");
         Clear();
         block_ = std::malloc(octBlock_.size);
         if (!block_) throw Error(HPSDF_ERR_OUT_OF_MEMORY, "malloc failed");

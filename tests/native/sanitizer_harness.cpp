@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <functional>
 #include <vector>
 #include "builder.hpp"
 #include "continuity.hpp"
@@ -132,6 +133,47 @@ int main(int argc, char** argv) {
         if (rc) return 3;
     }
     { std::vector<char> b(blk.begin(), blk.end() - 8); hpsdf_continuity_stats st; if (!hpsdf::continuityPostProcess(b.data(), b.size(), 0, 0, 1, &st, err)) return 4; }
+    // malformed blocks (untrusted bytes): each must come back as an error, under ASAN/UBSAN, not crash
+    {
+        auto mutate = [&](const char* what, const std::function<void(std::vector<char>&, uint64_t, uint64_t, hpsdf_node*)>& edit) -> int {
+            std::vector<char> b = blk;
+            uint64_t nc, nn;
+            memcpy(&nc, b.data(), 8);
+            memcpy(&nn, b.data() + 8 + 8 * nc, 8);
+            edit(b, nc, nn, (hpsdf_node*)(b.data() + 16 + 8 * nc));
+            hpsdf_continuity_stats st;
+            const int rc = hpsdf::continuityPostProcess(b.data(), b.size(), 0, 0, 2, &st, err);
+            printf("malformed block (%s): rc %d (%s)\n", what, rc, err.c_str());
+            return rc == HPSDF_ERR_BAD_BLOCK ? 0 : 1;
+        };
+        int bad = 0;
+        bad += mutate("child index 1<<40", [](std::vector<char>&, uint64_t, uint64_t, hpsdf_node* n) { n[0].child_idx = 1ull << 40; });
+        bad += mutate("child index wraps", [](std::vector<char>&, uint64_t, uint64_t nn, hpsdf_node* n) { n[0].child_idx = nn - 3; });
+        bad += mutate("child points at the root", [](std::vector<char>&, uint64_t, uint64_t, hpsdf_node* n) { n[1].child_idx = 0; });
+        bad += mutate("child points at an ancestor", [](std::vector<char>&, uint64_t, uint64_t, hpsdf_node* n) { n[n[1].child_idx].child_idx = 1; });
+        bad += mutate("coefficient start wraps", [](std::vector<char>&, uint64_t, uint64_t nn, hpsdf_node* n) {
+            for (uint64_t i = 0; i < nn; ++i) if (n[i].child_idx == ~0ull) { n[i].coeffs_start = ~0ull - 3; break; } });
+        bad += mutate("coefficient start past the store", [](std::vector<char>&, uint64_t nc, uint64_t nn, hpsdf_node* n) {
+            for (uint64_t i = 0; i < nn; ++i) if (n[i].child_idx == ~0ull) { n[i].coeffs_start = nc - 1; break; } });
+        bad += mutate("two leaves share coefficients", [](std::vector<char>&, uint64_t, uint64_t nn, hpsdf_node* n) {
+            uint64_t first = ~0ull;
+            for (uint64_t i = 0; i < nn; ++i) if (n[i].child_idx == ~0ull) { if (first == ~0ull) first = i; else { n[i].coeffs_start = n[first].coeffs_start; break; } } });
+        bad += mutate("leaf degree 200", [](std::vector<char>&, uint64_t, uint64_t nn, hpsdf_node* n) {
+            for (uint64_t i = 0; i < nn; ++i) if (n[i].child_idx == ~0ull) { n[i].degree = 200; break; } });
+        bad += mutate("leaf depth lies", [](std::vector<char>&, uint64_t, uint64_t nn, hpsdf_node* n) {
+            for (uint64_t i = 0; i < nn; ++i) if (n[i].child_idx == ~0ull) { n[i].depth = 1; break; } });
+        if (bad) return 40;
+        // one interior root and nothing else: nNodes < 9
+        std::vector<char> tiny(16 + sizeof(hpsdf_node) + sizeof(hpsdf_config), 0);
+        const uint64_t one = 1;
+        memcpy(tiny.data() + 8, &one, 8);
+        hpsdf_node* root = (hpsdf_node*)(tiny.data() + 16);
+        root->child_idx = 1ull << 40;
+        root->degree = 13;
+        hpsdf_continuity_stats st;
+        if (hpsdf::continuityPostProcess(tiny.data(), tiny.size(), 0, 0, 1, &st, err) != HPSDF_ERR_BAD_BLOCK) return 41;
+        printf("malformed block (1-node interior root): %s\n", err.c_str());
+    }
     std::vector<float> v; std::vector<uint64_t> t;
     int rc = hpsdf::loadObj(argv[2], v, t, err);
     printf("obj rc %d verts %zu tris %zu\n", rc, v.size() / 3, t.size() / 3);

@@ -127,3 +127,44 @@ def test_bad_blocks_are_rejected(H, trees):
     bad[-80 + 24:-80 + 32] = np.array([0.0]).tobytes()  # continuity.strength = 0 (Config.cpp:28-31 asserts > 0)
     with pytest.raises(H.HpsdfError):
         H.continuity_post_process(bytes(bad))
+
+
+def test_malformed_blocks_return_bad_block_not_crash(H, trees):
+    """Deserialisation of untrusted bytes: child indices that wrap or cycle, coefficient ranges that wrap,
+    overlap or leave the store, a 1-node interior root -- every one is HPSDF_ERR_BAD_BLOCK, never a fault."""
+    blk = trees["sphere_uniform"]
+    nc = int(np.frombuffer(blk[:8], np.uint64)[0])
+    nn = int(np.frombuffer(blk[8 + 8 * nc:16 + 8 * nc], np.uint64)[0])
+    base = 16 + 8 * nc
+
+    def edit(node, off, value, dtype=np.uint64):
+        b = bytearray(blk)
+        raw = np.array([value], dtype).tobytes()
+        b[base + 56 * node + off:base + 56 * node + off + len(raw)] = raw
+        return bytes(b)
+
+    nodes = np.frombuffer(blk[base:base + 56 * nn], np.uint8).reshape(nn, 56)
+    child = nodes[:, :8].copy().view(np.uint64).ravel()
+    leaf = int(np.nonzero(child == np.uint64(0xFFFFFFFFFFFFFFFF))[0][0])
+    leaf2 = int(np.nonzero(child == np.uint64(0xFFFFFFFFFFFFFFFF))[0][1])
+    start1 = int(nodes[leaf, 32:40].copy().view(np.uint64)[0])
+    cases = {
+        "child index 1<<40": edit(0, 0, 1 << 40),
+        "children run past the end": edit(0, 0, nn - 3),
+        "child is the root": edit(1, 0, 0),
+        "child is an ancestor": edit(int(child[1]), 0, 1),
+        "coefficient start wraps": edit(leaf, 32, 0xFFFFFFFFFFFFFFFC),
+        "coefficient start past the store": edit(leaf, 32, nc - 1),
+        "leaves share coefficients": edit(leaf2, 32, start1),
+        "leaf degree 200": edit(leaf, 40, 200, np.uint8),
+        "leaf depth lies": edit(leaf, 48, 1, np.uint8),
+    }
+    tiny = bytearray(16 + 56 + 80)
+    tiny[8:16] = np.array([1], np.uint64).tobytes()
+    tiny[16:24] = np.array([1 << 40], np.uint64).tobytes()
+    tiny[16 + 40] = 13
+    cases["1-node interior root"] = bytes(tiny) [:16 + 56] + blk[-80:]
+    for name, b in cases.items():
+        with pytest.raises(H.HpsdfError) as e:
+            H.continuity_post_process(b)
+        assert e.value.status == H.ERR_BAD_BLOCK, name
