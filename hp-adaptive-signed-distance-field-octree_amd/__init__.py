@@ -115,6 +115,7 @@ _SIGNATURES = {
     "hpsdf_field_mesh_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]),
     "hpsdf_field_eval_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hpsdf_field_eval_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hpsdf_field_eval_naive_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hpsdf_tree_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "hpsdf_tree_destroy": (C.c_int, [C.c_void_p]),
     "hpsdf_tree_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
@@ -344,6 +345,14 @@ class Field:
         out = np.empty(len(pts))
         check(lib().hpsdf_field_eval_host(ctx.handle, self.handle, pts.ctypes.data_as(C.c_void_p), len(pts),
                                           out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def eval_naive(self, ctx, pts):
+        """Mesh fields: Mesh::SignedDistanceAtPt(pt) without the BVH -- the O(n) scan, on the GPU."""
+        pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)
+        out = np.empty(len(pts))
+        check(lib().hpsdf_field_eval_naive_host(ctx.handle, self.handle, pts.ctypes.data_as(C.c_void_p), len(pts),
+                                                out.ctypes.data_as(C.c_void_p)))
         return out
 
     def mesh_stats(self, reset=True):
@@ -637,6 +646,8 @@ class Octree:
     def FromMemoryBlock(self, block):
         if not block:
             raise HpsdfError(4, "empty MemoryBlock")
+        if len(block) < 16 + C.sizeof(PodConfig):
+            raise HpsdfError(4, "MemoryBlock too small")
         self.Clear()
         self.block = bytes(block)
         pod = PodConfig.from_buffer_copy(self.block[-C.sizeof(PodConfig):])

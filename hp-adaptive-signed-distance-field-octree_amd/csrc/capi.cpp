@@ -477,6 +477,26 @@ int hpsdf_field_eval_host(hpsdf_ctx* ctx, const hpsdf_field* f, const double* xy
     HPSDF_CATCH
 }
 
+static int meshNaiveDevice(hpsdf_ctx* ctx, const hpsdf_field* f, const double* dXyz, size_t n, double* dOut) {
+    if (f->kind != kHostMesh) return fail(HPSDF_ERR_INVALID_ARGUMENT, "the linear scan is defined for mesh fields");
+    HPSDF_HIP(hipSetDevice(ctx->device));
+    FieldDev fd;
+    int rc = makeFieldDev(f, nullptr, &fd);
+    if (rc) return rc;
+    HPSDF_HIP(launchMeshNaive(ctx->stream, fd, dXyz, n, dOut));
+    return HPSDF_OK;
+}
+
+int hpsdf_field_eval_naive_host(hpsdf_ctx* ctx, const hpsdf_field* f, const double* xyz, size_t n, double* out) {
+    HPSDF_TRY
+    if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "a device context is required");
+    if (!f || (!xyz && n) || (!out && n)) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    return hostRoundTrip(
+        ctx, xyz, n, out,
+        [](hpsdf_ctx* c, const void* o, const double* d, size_t m, double* r) { return meshNaiveDevice(c, (const hpsdf_field*)o, d, m, r); }, f);
+    HPSDF_CATCH
+}
+
 // ---------------------------------------------------------------------------- tree + query
 int hpsdf_tree_upload(hpsdf_ctx* ctx, const void* block, size_t size, hpsdf_tree** out) {
     HPSDF_TRY

@@ -1678,6 +1678,53 @@ __global__ __launch_bounds__(256) void mesh_sample_kernel(const FitTask* __restr
     if (active) samples[tk.sampleOff + (uint64_t)rem] = (double)mv;
 }
 
+// Mesh::SignedDistanceAtPt(pt) WITHOUT a BVH (Mesh.cpp:42-51 over the linear scan Mesh::ClosestTriangleToPt, :134-159):
+// one wave per point, lane l tests triangles l, l + 64, ... keeping the first strictly smaller squared distance (so the
+// lowest index among its own equals), then the lanes fold to the smallest distance, ties to the lower triangle index --
+// i.e. what the reference's `<` scan from triangle 0 upwards keeps.  The winner's lane forms the pseudo-normal sign.
+// It is the checker of the BVH path on the device (TestBVHQuerying, MeshingUnitTests.cpp:110-138) and O(n) per point.
+__global__ __launch_bounds__(256) void mesh_naive_kernel(MeshDev m, const double* __restrict__ xyz, size_t n, double* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;  // wave-uniform
+    const int lane = threadIdx.x & 63;
+    const V3 pt = {(float)xyz[3 * i], (float)xyz[3 * i + 1], (float)xyz[3 * i + 2]};
+    float best = FLT_MAX;
+    uint32_t bestTri = 0xFFFFFFFFu;
+    int bestCode = 8;
+    V3 bestQ = {0.0f, 0.0f, 0.0f};
+    for (uint32_t t = (uint32_t)lane; t < m.nTris; t += 64u) {
+        V3 q;
+        const float* tp = m.triPos + 9 * (size_t)t;
+        const int code = closestSimplex(pt, V3{tp[0], tp[1], tp[2]}, V3{tp[3], tp[4], tp[5]}, V3{tp[6], tp[7], tp[8]}, q);
+        const float d = sqnorm(pt - q);
+        if (d < best) best = d, bestTri = t, bestCode = code, bestQ = q;
+    }
+    float wd = best;
+    uint32_t wt = bestTri;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float od = __shfl_xor(wd, off, 64);
+        const uint32_t ot = __shfl_xor(wt, off, 64);
+        if (od < wd || (od == wd && ot < wt)) wd = od, wt = ot;
+    }
+    if (wt == bestTri && bestTri != 0xFFFFFFFFu) {  // exactly one lane owns the winning triangle
+        const V3 nrm = pseudoNormal(m, bestTri, bestCode);
+        const V3 d = pt - bestQ;
+        const float sign = dot(nrm, d) > 0.0f ? 1.0f : -1.0f;
+        out[i] = (double)(sign * sqrtf(sqnorm(d)));
+    }
+}
+
+hipError_t launchMeshNaive(hipStream_t stream, const FieldDev& f, const double* dXyz, size_t n, double* dOut) {
+    if (n == 0) return hipSuccess;
+    if (f.kind != kFieldMesh || f.csgOp >= 0) return hipErrorInvalidValue;
+    for (size_t first = 0; first < n; first += (size_t)1 << 30) {  // grid.x stays below 2^31
+        const size_t m = std::min<size_t>((size_t)1 << 30, n - first);
+        hipLaunchKernelGGL(mesh_naive_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, stream, f.mesh, dXyz + 3 * first, m, dOut + first);
+    }
+    return hipGetLastError();
+}
+
 // MeshDev::triPos: the nine coordinates of every triangle, gathered once per mesh
 __global__ __launch_bounds__(256) void mesh_tripos_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ tris,
                                                           uint64_t nCorners, float* __restrict__ triPos) {

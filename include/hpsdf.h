@@ -150,6 +150,10 @@ HPSDF_API int hpsdf_field_destroy(hpsdf_field* f);
 HPSDF_API int hpsdf_field_eval_device(hpsdf_ctx* ctx, const hpsdf_field* f, const double* d_xyz, size_t n,
                                       double* d_out);
 HPSDF_API int hpsdf_field_eval_host(hpsdf_ctx* ctx, const hpsdf_field* f, const double* xyz, size_t n, double* out);
+/* Mesh::SignedDistanceAtPt(pt) without a BVH (Source/Meshing/Mesh.cpp:42-51 over the O(n) scan :134-159), mesh fields
+ * only: every triangle is tested for every point (one wave per point).  What the reference's TestBVHQuerying
+ * (Source/Tests/MeshingUnitTests.cpp:110-138) compares the BVH answer with; same tie rule, so the two agree bit for bit. */
+HPSDF_API int hpsdf_field_eval_naive_host(hpsdf_ctx* ctx, const hpsdf_field* f, const double* xyz, size_t n, double* out);
 /* Diagnostics (no reference counterpart; HPSDF_ERR_UNSUPPORTED unless the library was built with
  * -DHPSDF_MESH_STATS_BUILD): BVH traversal counters of a mesh field created while the environment
  * variable HPSDF_MESH_STATS was set -- out[0] wave-wide closest-triangle queries, [1] BVH nodes they visited,

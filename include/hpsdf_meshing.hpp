@@ -17,6 +17,7 @@
 // details of its CPU BVH and have no counterpart: any BVH yields the same closest triangle.
 #pragma once
 
+#include <memory>
 #include <vector>
 
 #include "hpsdf_octree.hpp"
@@ -86,6 +87,7 @@ class Mesh {  // Include/Meshing/Mesh.h:45-77
         triIndices.clear();
         vertices.clear();
         vertexNormals.clear();
+        scan_.reset();
     }
     /// Creates a mesh from a .obj filepath   (Mesh.cpp:15-39).  Whether the mesh is closed -- the reference's
     /// CreateHalfEdges check (Mesh.cpp:87-131) -- is established when a BVH is created from it.
@@ -105,6 +107,11 @@ class Mesh {  // Include/Meshing/Mesh.h:45-77
         for (usize i = 0; i < nVerts; ++i) vertices[i] = Eigen::Vector3f(verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]);
         triIndices.assign(tris, tris + 3 * nTris);
     }
+    /// > 0 implies outside mesh, O(n) scan over every triangle   (Mesh.h:53, Mesh.cpp:42-51,134-159) -- on the GPU, one
+    /// wave per point; the mesh goes to HBM on the first call
+    inline f32 SignedDistanceAtPt(const Eigen::Vector3f& pt_);
+    /// Batched form of the O(n) scan (additive)
+    inline void SignedDistanceAtPt(const float* xyz, usize n, float* out);
     /// > 0 implies outside mesh   (Mesh.h:54, Mesh.cpp:54-63) -- one GPU launch per call; prefer the batched form
     inline f32 SignedDistanceAtPt(const Eigen::Vector3f& pt_, const BVH& bvh_, const u32 threadIdx_ = 0);
     /// Batched form: xyz interleaved f32 points in, f32 signed distances out (host arrays)
@@ -127,6 +134,7 @@ class Mesh {  // Include/Meshing/Mesh.h:45-77
     std::vector<u32> triIndices;
     std::vector<Eigen::Vector3f> vertexNormals;
     std::vector<Eigen::Vector3f> vertices;
+    std::shared_ptr<BVH> scan_;  // device copy of the mesh for the BVH-less overloads (made on first use)
 };
 
 class BVH {  // Include/Meshing/BVH.h:17-30
@@ -178,6 +186,23 @@ inline void Mesh::SignedDistanceAtPt(const float* xyz, usize n, float* out, cons
     for (usize i = 0; i < 3 * n; ++i) in[i] = (double)xyz[i];  // f32 -> f64 -> f32 is exact
     SDF::check(hpsdf_field_eval_host(bvh_.Context(), bvh_.Field(), in.data(), n, res.data()));
     for (usize i = 0; i < n; ++i) out[i] = (float)res[i];  // the field value is the f32 distance widened
+}
+inline void Mesh::SignedDistanceAtPt(const float* xyz, usize n, float* out) {
+    if (!scan_) {
+        auto b = std::make_shared<BVH>();
+        if (!b->Create(*this)) throw SDF::Error(HPSDF_ERR_STATE, hpsdf_last_error());
+        scan_ = b;
+    }
+    std::vector<double> in(3 * n), res(n);
+    for (usize i = 0; i < 3 * n; ++i) in[i] = (double)xyz[i];
+    SDF::check(hpsdf_field_eval_naive_host(scan_->Context(), scan_->Field(), in.data(), n, res.data()));
+    for (usize i = 0; i < n; ++i) out[i] = (float)res[i];
+}
+inline f32 Mesh::SignedDistanceAtPt(const Eigen::Vector3f& pt_) {
+    const float xyz[3] = {pt_(0), pt_(1), pt_(2)};
+    float out = 0.0f;
+    SignedDistanceAtPt(xyz, 1, &out);
+    return out;
 }
 inline f32 Mesh::SignedDistanceAtPt(const Eigen::Vector3f& pt_, const BVH& bvh_, const u32) {
     const float xyz[3] = {pt_(0), pt_(1), pt_(2)};

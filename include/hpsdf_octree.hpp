@@ -45,9 +45,15 @@
 // Literals.h of the reference: on LP64 Linux "u32" is 8 bytes wide
 typedef double f64;
 typedef float f32;
+typedef int i16;
+typedef long int i32;
 typedef unsigned char u8;
+typedef unsigned short u16;
 typedef long unsigned int u32;
+typedef long long unsigned int u64;
 typedef size_t usize;
+constexpr usize PATH_MAX_LEN = 1024;      // Literals.h:12
+constexpr f32 EPSILON_F32 = 0.000001f;    // Literals.h:13
 
 #ifndef HPSDF_HAVE_EIGEN
 // Just enough of the two Eigen types the public API mentions, for hosts without Eigen.
@@ -70,6 +76,9 @@ struct HpsdfVec3 {
     HpsdfVec3 operator+(const HpsdfVec3& o) const { return {T(v[0] + o.v[0]), T(v[1] + o.v[1]), T(v[2] + o.v[2])}; }
     HpsdfVec3 operator-(const HpsdfVec3& o) const { return {T(v[0] - o.v[0]), T(v[1] - o.v[1]), T(v[2] - o.v[2])}; }
     HpsdfVec3 operator*(T s) const { return {T(v[0] * s), T(v[1] * s), T(v[2] * s)}; }
+    HpsdfVec3 operator/(T s) const { return {T(v[0] / s), T(v[1] / s), T(v[2] / s)}; }
+    HpsdfVec3 cwiseProduct(const HpsdfVec3& o) const { return {T(v[0] * o.v[0]), T(v[1] * o.v[1]), T(v[2] * o.v[2])}; }
+    T dot(const HpsdfVec3& o) const { return v[0] * o.v[0] + (v[1] * o.v[1] + v[2] * o.v[2]); }
     T squaredNorm() const { return v[0] * v[0] + (v[1] * v[1] + v[2] * v[2]); }
     T norm() const { return std::sqrt(squaredNorm()); }
 };
@@ -88,6 +97,16 @@ struct HpsdfBox3 {
     const HpsdfVec3<T>& min() const { return lo; }
     const HpsdfVec3<T>& max() const { return hi; }
     HpsdfVec3<T> sizes() const { return hi - lo; }
+    HpsdfVec3<T> center() const { return (lo + hi) / T(2); }
+    bool contains(const HpsdfVec3<T>& p) const {  // both ends inclusive, as Eigen's
+        return lo.x() <= p.x() && p.x() <= hi.x() && lo.y() <= p.y() && p.y() <= hi.y() && lo.z() <= p.z() && p.z() <= hi.z();
+    }
+    /// uniform point of the box through std::rand, as Eigen's AlignedBox::sample() (internal::random<T>(0, 1))
+    HpsdfVec3<T> sample() const {
+        HpsdfVec3<T> r;
+        for (int d = 0; d < 3; ++d) r(d) = lo(d) + (hi(d) - lo(d)) * (T(0) + (T(1) - T(0)) * T(std::rand()) / T(RAND_MAX));
+        return r;
+    }
     T volume() const { return (hi.x() - lo.x()) * (hi.y() - lo.y()) * (hi.z() - lo.z()); }
 };
 typedef HpsdfBox3<float> AlignedBox3f;

@@ -208,7 +208,18 @@ void ora_config_default(ora_config* c) {
 
 /* Eigen's Vector3d::norm() reduces as x^2 + (y^2 + z^2); the reference test
  * fields are written with it (Source/Tests/HPUnitTests.cpp:48-51). */
-static double norm3(double x, double y, double z) { return sqrt(x * x + (y * y + z * z)); }
+/* Which way a 3-vector reduction (prod / squaredNorm / dot) associates is Eigen's choice, not the reference's: a + (b + c)
+ * (the default here and in the product) or (a + b) + c (ora_set_reduction_order(1): what an SSE2 build of Eigen 3.4 with
+ * unaligned vectorisation appears to do for a Vector3d).  Eigen is absent, so neither is verified; the switch exists so
+ * that the effect of the other choice on coefficients and topology is a measured number (tools/assoc_sensitivity.py,
+ * DESIGN.md section 2).  Sites: Vector3d::norm() in the test fields, aabbScale.prod() (:1022), unitWeights.prod() (:1040),
+ * grad.normalize() (:970). */
+static int g_leftAssoc = 0;
+void ora_set_reduction_order(int left_assoc) { g_leftAssoc = left_assoc != 0; }
+int ora_get_reduction_order(void) { return g_leftAssoc; }
+static double sum3(double a, double b, double c) { return g_leftAssoc ? (a + b) + c : a + (b + c); }
+static double prod3(double a, double b, double c) { return g_leftAssoc ? (a * b) * c : a * (b * c); }
+static double norm3(double x, double y, double z) { return sqrt(sum3(x * x, y * y, z * z)); }
 
 static double prim_eval(const ora_prim* pr, const double pt[3]) {
     const double* p = pr->p;
@@ -376,7 +387,7 @@ double ora_fit_polynomial(const ora_field* f, const ora_config* cfg, double* coe
         scale[a] = (double)(bmax[a] - bmin[a]) * 0.5;
         centre[a] = (double)((bmin[a] + bmax[a]) / 2.0f);
     }
-    const double scalesMult = scale[0] * (scale[1] * scale[2]); /* Eigen prod(): a*(b*c) */
+    const double scalesMult = prod3(scale[0], scale[1], scale[2]); /* Eigen prod(): a*(b*c) unless ora_set_reduction_order(1) */
     /* Octree.cpp:322,324 */
     double rootBounds[3], rootCentre[3];
     for (int a = 0; a < 3; ++a) {
@@ -397,7 +408,7 @@ double ora_fit_polynomial(const ora_field* f, const ora_config* cfg, double* coe
         for (uint64_t j = GQStart; j < GQEnd; ++j)
             for (uint64_t k = GQStart; k < GQEnd; ++k) {
                 const double us[3] = {g_roots[i], g_roots[j], g_roots[k]};
-                const double wprod = g_weights[i] * (g_weights[j] * g_weights[k]);
+                const double wprod = prod3(g_weights[i], g_weights[j], g_weights[k]);
                 double world[3];
                 for (int a = 0; a < 3; ++a) {
                     double s = us[a] * scale[a] + centre[a]; /* :1039 */
@@ -538,7 +549,7 @@ double ora_fapprox_with_gradient(const double* coeffs, int degree, const float b
         grad[k] = (p1 - m1) / (2.0 * eps);
     }
     { /* Eigen normalize(): divide by sqrt(squaredNorm) when > 0 */
-        const double z = grad[0] * grad[0] + (grad[1] * grad[1] + grad[2] * grad[2]);
+        const double z = sum3(grad[0] * grad[0], grad[1] * grad[1], grad[2] * grad[2]);
         if (z > 0.0) {
             const double n = sqrt(z);
             grad[0] /= n, grad[1] /= n, grad[2] /= n;

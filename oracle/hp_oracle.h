@@ -107,6 +107,9 @@ typedef struct ora_field {
 } ora_field;
 
 double ora_field_eval(const ora_field* f, const double pt[3]);
+/* 0 (default): 3-vector reductions associate as a + (b + c); 1: (a + b) + c -- sensitivity study only, see hp_oracle.c */
+void ora_set_reduction_order(int left_assoc);
+int ora_get_reduction_order(void);
 
 /* ---- per-node numerics --------------------------------------------------- */
 /* Octree::LpX, Octree.cpp:988-1004 */

@@ -200,11 +200,11 @@ def test_meshing_dropin_on_gpu(H, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
-def _build_example(H, tmp_path):
-    exe = str(tmp_path / "hp_benchmarks")
+def _build_example(H, tmp_path, name="hp_benchmarks"):
+    exe = str(tmp_path / name)
     libdir = os.path.dirname(H.LIB_PATH)
     cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wno-comment", "-I", os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "examples", "hp_benchmarks.cpp"), "-o", exe, "-L", libdir, "-lhpsdf", "-Wl,-rpath," + libdir,
+           os.path.join(ROOT, "examples", name + ".cpp"), "-o", exe, "-L", libdir, "-lhpsdf", "-Wl,-rpath," + libdir,
            "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-pthread"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -226,3 +226,34 @@ def test_example_benchmark_program_runs(H, tmp_path):
         assert line in r.stdout, r.stdout
     got, exact = [float(x.strip(" ()")) for x in r.stdout.strip().splitlines()[-1].split(":")[1].replace("exact", "").split("(")]
     assert abs(got - exact) < 1e-4  # the united tree against min(sphere, sphere)
+
+
+def test_reference_unit_tests_program_compiles_and_fails_loudly_without_gpu(H, tmp_path):
+    """examples/hp_unit_tests.cpp: the reference's six HP unit tests and its BVH test at their exact settings."""
+    exe = _build_example(H, tmp_path, "hp_unit_tests")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    if r.returncode == 0:
+        pytest.skip("a GPU is present: covered by the gpu test")
+    assert r.returncode == 42, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_reference_unit_tests_at_their_exact_settings(H, tmp_path):
+    """HPUnitTests.cpp:46-316 and MeshingUnitTests.cpp:110-138 through the C++ drop-in: targetError 1e-8, Polynomial(3)
+    weighting, continuity strength 8, root [-0.25,5]^3 with continuity, 1 000 000 samples per loop, copy constructor then
+    move assignment, Union/Intersect/Subtract at 1e-8, 50 naive-vs-BVH samples on the reference's own mesh."""
+    import numpy as np
+    exe = _build_example(H, tmp_path, "hp_unit_tests")
+    d = np.load(os.path.join(ROOT, "tests", "golden", "halfedge_fail_mesh.npz"))
+    obj = tmp_path / "halfedge_fail.obj"
+    with open(obj, "w") as fh:
+        for p in d["verts"]:
+            fh.write("v %.9g %.9g %.9g\n" % tuple(p))
+        for a, b, c in d["tris"]:
+            fh.write("f %d %d %d\n" % (a + 1, b + 1, c + 1))
+    r = subprocess.run([exe, str(obj)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "7 / 7 tests passed" in r.stdout, r.stdout
+    for name in ("TestOctreeCreation", "TestOctreeContinuity", "TestOctreeSerialisation", "TestOctreeCopying",
+                 "TestOctreeSDFOperations", "TestOctreeCustomDomains", "TestBVHQuerying"):
+        assert name + ": passed" in r.stdout, r.stdout

@@ -19,13 +19,13 @@ ROOT = sys.argv[1]; case = json.loads(sys.argv[2]); out = sys.argv[3]
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch, torch.distributed as dist
 import hpsdf_loader, oracle as O
-from helpers import oracle_field
+from helpers import oracle_field, displaced_torus
 H = hpsdf_loader.load()
 import importlib
 D = importlib.import_module("hpsdf_amd.distributed")
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-f = oracle_field(O, case["field"])
+f = O.MeshField(*displaced_torus(*case["torus"])) if case["field"] == "torus_mesh" else oracle_field(O, case["field"])
 ocfg = O.default_config(case["target"], case["root_min"], case["root_max"])
 cfg = H.make_config(case["target"], case["root_min"], case["root_max"], continuity=bool(case.get("continuity")))
 def compute(b, jobs, first, count):
@@ -69,3 +69,32 @@ def test_world2_gloo_block_identical(golden, case, O, H):
         assert res[k]["sha"] == want
         assert res[k]["stats"]["n_nodes"] == g["n_nodes"] and res[k]["stats"]["jobs"] == g["stats"]["jobs"]
     assert res[0]["shard"] == [0, 500] and res[1]["shard"] == [500, 1000]
+
+
+def test_world2_gloo_mesh_field_at_1e6(O, H):
+    """BASELINE configs[3] in shape on the N > 1 path: a mesh field at targetError 1e-6 (anisotropic root, K = 256:
+    several rounds with H and P refinement) through the product's exchange code over two gloo ranks -- every rank ends
+    with the block a single rank builds, byte for byte."""
+    from helpers import displaced_torus
+    case = {"field": "torus_mesh", "torus": [12, 8], "target": 1e-6, "root_min": [-0.45, -0.45, -0.2],
+            "root_max": [0.45, 0.45, 0.2], "K": 256}
+    with tempfile.TemporaryDirectory() as td:
+        wpath = os.path.join(td, "worker.py")
+        open(wpath, "w").write(WORKER)
+        out = os.path.join(td, "res")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+               "127.0.0.1", "--master-port", "29519", wpath, ROOT, json.dumps(case), out]
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+        # meanwhile: the single-rank tree of the same case, by the oracle
+        one = O.Tree.create(O.default_config(case["target"], case["root_min"], case["root_max"]),
+                            O.MeshField(*displaced_torus(*case["torus"])), case["K"])
+        so, se = p.communicate(timeout=900)
+        assert p.returncode == 0, so[-2000:] + se[-4000:]
+        res = [json.load(open(out + ".%d" % k)) for k in range(2)]
+    blk = one.to_block()
+    parsed = O.parse_block(blk)
+    assert parsed["depth"].max() >= 5 and parsed["degree"][parsed["degree"] != 13].max() >= 3
+    for k in range(2):
+        assert res[k]["sha"] == hashlib.sha256(blk).hexdigest()
+        assert res[k]["stats"]["rounds"] >= 3 and res[k]["stats"]["h_refines"] > 0

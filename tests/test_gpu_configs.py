@@ -1,0 +1,186 @@
+"""GPU tests for BASELINE configs[3] (mesh field at targetError 1e-6 through the sharded frontier) and for the
+deserialiser against blocks shaped like the reference's own, all through the C ABI."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import bits
+from helpers import displaced_torus, icosphere, synthetic_block
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6  # north_star: coefficients and Query() values within 1e-6 abs
+
+MESH_ROOT = ((-0.45, -0.45, -0.2), (0.45, 0.45, 0.2))  # anisotropic, like "root = mesh AABB" (Octree.cpp:322-328)
+MESH_K = 256                                            # several rounds, so the frontier exchange happens at all
+
+
+def _mesh():
+    return displaced_torus(12, 8)  # 192 triangles: the oracle scans every triangle for every sample
+
+
+@pytest.fixture(scope="module")
+def mesh_oracle_tree(O):
+    verts, tris = _mesh()
+    t = O.Tree.create(O.default_config(1e-6, *MESH_ROOT), O.MeshField(verts, tris), MESH_K)
+    return t
+
+
+def test_mesh_field_at_1e6_matches_oracle(H, O, ctx, mesh_oracle_tree):
+    """configs[3] in shape: mesh field, targetError 1e-6, root = (anisotropic) mesh box; several rounds with H- and
+    P-refinement.  Topology identical to the oracle's, coefficients and Query() within 1e-6 (the mesh path is f32)."""
+    verts, tris = _mesh()
+    blk, st = H.create_block(ctx, H.make_config(1e-6, *MESH_ROOT), H.Field.mesh(ctx, verts, tris), MESH_K)
+    assert st["rounds"] >= 3 and st["h_refines"] > 0 and st["p_refines"] > 4096
+    a, b = O.parse_block(blk), O.parse_block(mesh_oracle_tree.to_block())
+    assert len(a["degree"]) == len(b["degree"])
+    assert np.array_equal(a["degree"], b["degree"]) and np.array_equal(a["childIdx"], b["childIdx"])
+    assert np.array_equal(a["depth"], b["depth"])
+    leaf = a["degree"][a["degree"] != 13]
+    assert leaf.max() >= 3 and a["depth"].max() >= 5  # both kinds of refinement happened
+    assert np.abs(a["coeffs"] - b["coeffs"]).max() <= TOL
+    lo, hi = np.array(MESH_ROOT[0]), np.array(MESH_ROOT[1])
+    pts = (O.splitmix64_points(50000, seed=31) + 0.5) * (hi - lo) + lo
+    got = H.DeviceTree(ctx, blk).query(pts)
+    want = mesh_oracle_tree.query(pts)
+    assert np.abs(got - want).max() <= TOL
+    # and the tree of the device's block evaluated by the oracle agrees with the device bit for bit
+    assert np.array_equal(bits(got), bits(O.Tree.from_block(blk).query(pts)))
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_mesh_field_through_sharded_frontier_is_byte_identical(H, ctx, world):
+    """The same mesh build with the frontier sharded over `world` ranks (each rank's slice computed on this GPU, the
+    headers exchanged as the all-gather would): the block equals the single-rank block byte for byte."""
+    verts, tris = _mesh()
+    cfg = H.make_config(1e-6, *MESH_ROOT)
+    f = H.Field.mesh(ctx, verts, tris)
+    one, st1 = H.create_block(ctx, cfg, f, MESH_K)
+    builds = [H.Build(cfg, MESH_K, r, world) for r in range(world)]
+    rounds = 0
+    while True:
+        n = builds[0].select()
+        for b in builds[1:]:
+            assert b.select() == n
+        if n == 0:
+            break
+        rounds += 1
+        hdr = np.zeros((n, 9))
+        covered = 0
+        for b in builds:
+            b.compute(ctx, f)
+            first, count = b.slice()
+            assert first == covered
+            covered += count
+            hdr[first:first + count] = b.results_host(ctx).reshape(count, 9)
+        assert covered == n
+        for b in builds:
+            b.apply(hdr)
+    assert rounds == st1["rounds"]
+    lays = [b.layout() for b in builds]
+    packs = [builds[r].pack_host(ctx, lays[r][1][r]) for r in range(world)]
+    for b in builds:
+        assert b.assemble(packs) == one
+
+
+def test_mesh_bvh_equals_linear_scan_bitwise(H, O, ctx):
+    """TestBVHQuerying (MeshingUnitTests.cpp:110-138) on the device: the BVH traversal returns what the O(n) scan of
+    Mesh::ClosestTriangleToPt (Mesh.cpp:134-159) returns -- same triangle, same bits -- and both match the oracle."""
+    for verts, tris in (icosphere(3, 0.35, (0.02, 0.0, -0.01)), displaced_torus(48, 32)):
+        f = H.Field.mesh(ctx, verts, tris)
+        pts = O.splitmix64_points(4000, seed=3)
+        a, b = f.eval(ctx, pts), f.eval_naive(ctx, pts)
+        assert np.array_equal(bits(a), bits(b))
+        want, _, _ = O.MeshField(verts, tris).signed_distance(pts[:500])
+        assert np.abs(b[:500] - want.astype(np.float64)).max() <= TOL
+
+
+# ------------------------------------------------------------------ blocks shaped like the reference's
+def _reference_shaped(blk, rng):
+    """What Octree::ToMemoryBlock really emits: interior nodes keep a stale heap pointer in basis.coeffs
+    (Octree.cpp:267-268 frees but never clears the union), Node padding bytes 41-47 / 49-55 and Config padding bytes
+    1-7, 17-23, 33-39 are indeterminate."""
+    b = bytearray(blk)
+    nc = int(np.frombuffer(blk[:8], np.uint64)[0])
+    nn = int(np.frombuffer(blk[8 + 8 * nc:16 + 8 * nc], np.uint64)[0])
+    base = 16 + 8 * nc
+    for i in range(nn):
+        o = base + 56 * i
+        if b[o + 40] == 13:
+            b[o + 32:o + 40] = (0x00007F0000000000 + int(rng.integers(1 << 30)) * 16).to_bytes(8, "little")
+        b[o + 41:o + 48] = rng.integers(0, 256, 7, dtype=np.uint8).tobytes()
+        b[o + 49:o + 56] = rng.integers(0, 256, 7, dtype=np.uint8).tobytes()
+    c = len(b) - 80
+    for lo, hi in ((1, 8), (17, 24), (33, 40)):
+        b[c + lo:c + hi] = rng.integers(0, 256, hi - lo, dtype=np.uint8).tobytes()
+    return bytes(b)
+
+
+def test_upload_accepts_reference_shaped_block(H, O, ctx, golden):
+    rng = np.random.default_rng(5)
+    g = golden["blocks"]["A1_union3_1e-7_K1024"]
+    clean, _ = H.create_block(ctx, H.make_config(g["target"]), H.Field.union3(), g["K"])
+    dirty = _reference_shaped(clean, rng)
+    assert dirty != clean
+    pts = O.splitmix64_points(50000, seed=8)
+    a, b = H.DeviceTree(ctx, clean), H.DeviceTree(ctx, dirty)
+    assert a.info() == b.info()
+    assert np.array_equal(bits(a.query(pts)), bits(b.query(pts)))
+    va, ga = a.query_with_gradient(pts[:5000])
+    vb, gb = b.query_with_gradient(pts[:5000])
+    assert np.array_equal(bits(va), bits(vb)) and np.array_equal(bits(ga), bits(gb))
+    # the Python Octree mirror round-trips the dirty bytes untouched (FromMemoryBlock copies, ToMemoryBlock returns them)
+    t = H.Octree()
+    t.FromMemoryBlock(dirty)
+    assert t.ToMemoryBlock() == dirty
+    # the continuity post-process reads the same dirty block (host path) and changes only coefficients
+    cdirty = bytearray(dirty)
+    cdirty[-80 + 16] = 1
+    cdirty[-80 + 24:-80 + 32] = np.array([8.0]).tobytes()
+    cclean = bytearray(clean)
+    cclean[-80 + 16] = 1
+    cclean[-80 + 24:-80 + 32] = np.array([8.0]).tobytes()
+    pd, _ = H.continuity_post_process(bytes(cdirty))
+    pc, _ = H.continuity_post_process(bytes(cclean))
+    assert np.array_equal(O.parse_block(pd)["coeffs"], O.parse_block(pc)["coeffs"])
+
+
+def test_upload_rejects_malformed_blocks(H, ctx):
+    """hpsdf_tree_upload on untrusted bytes: wrap-around child indices, cycles, wrapping coefficient ranges,
+    an interior root without children -- HPSDF_ERR_BAD_BLOCK each, no fault."""
+    rng = np.random.default_rng(1)
+    blk = synthetic_block(rng, [2] * 8, depth=2)
+    nc = int(np.frombuffer(blk[:8], np.uint64)[0])
+    nn = int(np.frombuffer(blk[8 + 8 * nc:16 + 8 * nc], np.uint64)[0])
+    base = 16 + 8 * nc
+
+    def edit(node, off, value, dtype=np.uint64):
+        b = bytearray(blk)
+        raw = np.array([value], dtype).tobytes()
+        b[base + 56 * node + off:base + 56 * node + off + len(raw)] = raw
+        return bytes(b)
+
+    H.DeviceTree(ctx, blk)  # the unedited block is fine
+    cases = {
+        "child index 1<<40": edit(0, 0, 1 << 40),
+        "children run past the end": edit(0, 0, nn - 3),
+        "child is the root": edit(1, 0, 0),
+        "child is its own parent block": edit(1, 0, 1),
+        "coefficient start wraps": edit(2, 32, 0xFFFFFFFFFFFFFFFC),
+        "coefficient start past the store": edit(2, 32, nc - 1),
+        "leaf degree 200": edit(2, 40, 200, np.uint8),
+        "leaf depth lies": edit(2, 48, 3, np.uint8),
+    }
+    tiny = bytearray(16 + 56 + 80)
+    tiny[8:16] = np.array([1], np.uint64).tobytes()
+    tiny[16:24] = np.array([1 << 40], np.uint64).tobytes()
+    tiny[16 + 8:16 + 32] = np.array([-0.5] * 3 + [0.5] * 3, np.float32).tobytes()
+    tiny[16 + 40] = 13
+    cases["1-node interior root"] = bytes(tiny[:16 + 56]) + blk[-80:]
+    for name, b in cases.items():
+        with pytest.raises(H.HpsdfError) as e:
+            H.DeviceTree(ctx, b)
+        assert e.value.status == H.ERR_BAD_BLOCK, name
+    t = H.Octree()
+    with pytest.raises(H.HpsdfError):
+        t.FromMemoryBlock(b"\x00" * 40)  # smaller than two counts + Config
