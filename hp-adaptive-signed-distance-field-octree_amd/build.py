@@ -14,8 +14,8 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libhpsdf.so")
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
 
-SOURCES = ["kernels.hip", "cg.hip", "tables.cpp", "builder.cpp", "mesh.cpp", "obj.cpp", "continuity.cpp", "capi.cpp"]
-HEADERS = ["tables.hpp", "device_types.hpp", "launch.hpp", "runtime.hpp", "builder.hpp", "continuity.hpp", "block_check.hpp"]
+SOURCES = ["kernels.hip", "frontier.hip", "cg.hip", "tables.cpp", "builder.cpp", "mesh.cpp", "obj.cpp", "continuity.cpp", "capi.cpp"]
+HEADERS = ["tables.hpp", "device_types.hpp", "launch.hpp", "runtime.hpp", "builder.hpp", "continuity.hpp", "block_check.hpp", "frontier.hpp"]
 PUBLIC_HEADERS = ["hpsdf.h", "hpsdf_octree.hpp"]
 
 # -ffp-contract=off: no multiply-add is fused anywhere (bit parity with the x86-64 reference path)

@@ -16,6 +16,7 @@
 
 #include "builder.hpp"
 #include "continuity.hpp"
+#include "frontier.hpp"
 #include "block_check.hpp"
 #include "launch.hpp"
 #include "runtime.hpp"
@@ -984,6 +985,21 @@ int hpsdf_create(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* fie
     HPSDF_TRY
     if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "Create runs on the GPU: a device context is required");
     if (!cfg || !field || !block || !size) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    if (frontierEligible(cfg, field, K)) {  // frontier, decision and bookkeeping on the device (frontier.hip)
+        int frc = frontierCreate(ctx, cfg, field, K, block, size, stats);
+        std::memset(&g_lastContinuity, 0, sizeof g_lastContinuity);
+        if (!frc && cfg->continuity_enforce) {  // Octree.cpp:341-344
+            std::string err;
+            frc = continuityPostProcess(*block, *size, 0.0, 0, 0, &g_lastContinuity, err, ctx);
+            if (frc) {
+                setError(err);
+                std::free(*block);
+                *block = nullptr;
+                *size = 0;
+            }
+        }
+        return frc;
+    }
     hpsdf_build_opts o;
     std::memset(&o, 0, sizeof o);
     o.max_jobs_per_round = K;

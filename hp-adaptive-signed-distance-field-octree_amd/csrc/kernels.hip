@@ -1324,17 +1324,14 @@ __device__ __forceinline__ double fitRowAny(double acc, double a1, const double*
 // the cell (all cells of a workgroup share degree and depth), so it is formed once per sample and used
 // for R accumulators: 2 + 3/R multiply/add instructions per (cell, sample, row) instead of 5.
 template <int KIND, bool CSG, int DEG, int R>
-__global__ __launch_bounds__(kFitThreads) void fit_kernel(const FitBlock* __restrict__ blocks,
-                                                          const FitTask* __restrict__ tasks, double* __restrict__ arena,
-                                                          double* __restrict__ errs, double* __restrict__ means,
-                                                          const DeviceTables* __restrict__ T, FieldDev field, RootMap rm) {
+__device__ __forceinline__ void fitBlockBody(const FitBlock blk, const FitTask* __restrict__ tasks, double* __restrict__ arena,
+                                             double* __restrict__ errs, double* __restrict__ means,
+                                             const DeviceTables* __restrict__ T, const FieldDev& field, const RootMap& rm, double* lds) {
     static_assert(R == 1 || DEG > 0, "cell blocking needs a compile-time degree");
-    extern __shared__ double lds[];
     __shared__ double sNl[13 * 11];
     __shared__ double sRec[26];
     __shared__ int32_t sMeshStack[kFitThreads / 64][kMeshStack];  // per-wave traversal stacks (mesh fields)
     __shared__ unsigned char sPosI[KIND == kFieldMesh ? 64 : 4], sPosJK[KIND == kFieldMesh ? 64 : 4];  // meshSampleOrder
-    const FitBlock blk = blocks[blockIdx.x];
     const int tid = threadIdx.x;
     const int deg = DEG > 0 ? DEG : (int)blk.degree;
     const int nq = 4 * deg + 1, nq2 = nq * nq, G = blk.nTasks;
@@ -1572,6 +1569,25 @@ __global__ __launch_bounds__(kFitThreads) void fit_kernel(const FitBlock* __rest
     }
 }
 
+// range == nullptr: workgroup b fits blocks[b] (the host sized the grid).  Otherwise the grid is an upper bound and
+// workgroup b fits blocks[range[0] + b] if b < range[1]: the device-side frontier (frontier.hip) writes the round's block
+// list and its per-degree ranges itself, so the host never learns how many blocks a round has before it launches the fits
+// (a grid-stride loop over the range instead cost 37 more VGPRs at degree 3-4: one wave per SIMD less).
+template <int KIND, bool CSG, int DEG, int R>
+__global__ __launch_bounds__(kFitThreads) void fit_kernel(const FitBlock* __restrict__ blocks,
+                                                          const FitTask* __restrict__ tasks, double* __restrict__ arena,
+                                                          double* __restrict__ errs, double* __restrict__ means,
+                                                          const DeviceTables* __restrict__ T, FieldDev field, RootMap rm,
+                                                          const uint32_t* __restrict__ range) {
+    extern __shared__ double lds[];
+    uint32_t b = blockIdx.x;
+    if (range != nullptr) {
+        if (b >= range[1]) return;
+        b += range[0];
+    }
+    fitBlockBody<KIND, CSG, DEG, R>(blocks[b], tasks, arena, errs, means, T, field, rm, lds);
+}
+
 // ---------------------------------------------------------------------------
 // pack: Octree::ReallocCoeffs gather (Octree.cpp:510-552)
 // ---------------------------------------------------------------------------
@@ -1644,12 +1660,19 @@ FitShape fitShape(int degree, int nrows, uint32_t count, bool weighted, bool lat
 // left the chip a quarter full behind the expensive cells; here the unit of work is one wave = 64 samples that sit
 // next to each other (meshSampleOrder over the whole grid), a workgroup is four of them, the hardware deals them out,
 // and without the fit's accumulators twice as many waves fit on a CU.  grid = (ceil(nq^3 / 256), tasks of one degree).
+// range == nullptr: grid = (chunks of 256 samples, tasks).  Otherwise grid.y is an upper bound and row y samples task
+// range[0] + y if y < range[1] -- the device-side frontier's rounds (frontier.hip), whose task counts the host does not know.
 __global__ __launch_bounds__(256) void mesh_sample_kernel(const FitTask* __restrict__ tasks, int degree,
                                                           const DeviceTables* __restrict__ T, MeshDev mesh, RootMap rm,
-                                                          double* __restrict__ samples) {
+                                                          double* __restrict__ samples, const uint32_t* __restrict__ range) {
     __shared__ int32_t sStack[4][kMeshStack];
     __shared__ double sR[64];
     __shared__ unsigned char sPos[64];
+    uint32_t task = blockIdx.y;
+    if (range != nullptr) {
+        if (task >= range[1]) return;
+        task += range[0];
+    }
     const int tid = threadIdx.x, nq = 4 * degree + 1, gl = nq * (nq - 1) / 2, total = nq * nq * nq;
     if (tid < nq) sR[tid] = T->roots[gl + tid];
     __syncthreads();
@@ -1659,7 +1682,7 @@ __global__ __launch_bounds__(256) void mesh_sample_kernel(const FitTask* __restr
         sPos[rank] = (unsigned char)tid;
     }
     __syncthreads();
-    const FitTask& tk = tasks[blockIdx.y];
+    const FitTask& tk = tasks[task];
     const int r = (int)blockIdx.x * 256 + tid;
     const bool active = r < total;
     const int rem = meshSampleOrder(active ? r : total - 1, nq, nq, sPos, sPos);
@@ -1751,18 +1774,29 @@ hipError_t launchMeshSample(hipStream_t stream, const FitTask* dTasks, uint32_t 
     for (uint32_t first = 0; first < nTasks; first += 65535u) {
         const uint32_t n = nTasks - first < 65535u ? nTasks - first : 65535u;
         hipLaunchKernelGGL(mesh_sample_kernel, dim3(gx, n), dim3(256), 0, stream, dTasks + first, degree, dTables, field.mesh, rm,
-                           dSamples);
+                           dSamples, (const uint32_t*)nullptr);
     }
+    return hipGetLastError();
+}
+
+// the same over the device-written task range dRange = {first task, count} of dTasks; maxTasks bounds the count
+hipError_t launchMeshSampleRange(hipStream_t stream, const FitTask* dTasks, const uint32_t* dRange, uint32_t maxTasks, int degree,
+                                 const DeviceTables* dTables, const FieldDev& field, const RootMap& rm, double* dSamples) {
+    if (degree < 1 || degree > 12 || field.kind != kFieldMesh || maxTasks == 0 || maxTasks > 65535u) return hipErrorInvalidValue;
+    const int nq = 4 * degree + 1;
+    const unsigned gx = (unsigned)((nq * nq * nq + 255) / 256);
+    hipLaunchKernelGGL(mesh_sample_kernel, dim3(gx, maxTasks), dim3(256), 0, stream, dTasks, degree, dTables, field.mesh, rm, dSamples,
+                       dRange);
     return hipGetLastError();
 }
 
 template <int KIND, bool CSG>
 static void launchFitT(hipStream_t stream, int degree, int cellsPerThread, const FitBlock* dBlocks, uint32_t nBlocks,
                        size_t ldsBytes, const FitTask* dTasks, double* dArena, double* dErrs, double* dMeans,
-                       const DeviceTables* dTables, const FieldDev& field, const RootMap& rm) {
+                       const DeviceTables* dTables, const FieldDev& field, const RootMap& rm, const uint32_t* dRange) {
 #define HPSDF_FIT_LAUNCH(D, RR)                                                                                       \
     hipLaunchKernelGGL((fit_kernel<KIND, CSG, D, RR>), dim3(nBlocks), dim3(kFitThreads), ldsBytes, stream, dBlocks, \
-                       dTasks, dArena, dErrs, dMeans, dTables, field, rm)
+                       dTasks, dArena, dErrs, dMeans, dTables, field, rm, dRange)
 #define HPSDF_FIT_CASE(D)       \
     case D:                     \
         HPSDF_FIT_LAUNCH(D, 1); \
@@ -1803,11 +1837,11 @@ static void launchFitT(hipStream_t stream, int degree, int cellsPerThread, const
 // their own degree).
 hipError_t launchFit(hipStream_t stream, int degree, int cellsPerThread, const FitBlock* dBlocks, uint32_t nBlocks,
                      size_t ldsBytes, const FitTask* dTasks, double* dArena, double* dErrs, double* dMeans,
-                     const DeviceTables* dTables, const FieldDev& field, const RootMap& rm) {
+                     const DeviceTables* dTables, const FieldDev& field, const RootMap& rm, const uint32_t* dRange) {
     if (nBlocks == 0) return hipSuccess;
     if (ldsBytes > kFitMaxLdsBytes) return hipErrorInvalidValue;
     HPSDF_DISPATCH_FIELD(launchFitT, field, stream, degree, cellsPerThread, dBlocks, nBlocks, ldsBytes, dTasks, dArena,
-                         dErrs, dMeans, dTables, field, rm);
+                         dErrs, dMeans, dTables, field, rm, dRange);
     return hipGetLastError();
 }
 

@@ -28,7 +28,7 @@ FitShape fitShape(int degree, int nrows, uint32_t count, bool weighted, bool lat
 
 hipError_t launchFit(hipStream_t stream, int degree, int cellsPerThread, const FitBlock* dBlocks, uint32_t nBlocks, size_t ldsBytes,
                      const FitTask* dTasks, double* dArena, double* dErrs, double* dMeans,
-                     const DeviceTables* dTables, const FieldDev& field, const RootMap& rm);
+                     const DeviceTables* dTables, const FieldDev& field, const RootMap& rm, const uint32_t* dRange = nullptr);
 hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dXyz, size_t n,
                        double* dOut, double* dGrad, bool allInline, uint32_t* dDeferCount, uint32_t* dDeferIdx);
 hipError_t launchQueryRay(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dOrigins,
@@ -43,6 +43,8 @@ hipError_t launchMeshTriPos(hipStream_t stream, const float* dVerts, const uint3
 // mesh fields: F at every sample of nTasks fits of one degree -> dSamples[FitTask::sampleOff + sample]
 hipError_t launchMeshSample(hipStream_t stream, const FitTask* dTasks, uint32_t nTasks, int degree, const DeviceTables* dTables,
                             const FieldDev& field, const RootMap& rm, double* dSamples);
+hipError_t launchMeshSampleRange(hipStream_t stream, const FitTask* dTasks, const uint32_t* dRange, uint32_t maxTasks, int degree,
+                                 const DeviceTables* dTables, const FieldDev& field, const RootMap& rm, double* dSamples);
 // ---- continuity solve on the device (cg.hip); the arithmetic is continuity.cpp's
 constexpr uint64_t kCgChunk = 256;  // dot products are summed chunk by chunk (one workgroup's rows), then over the chunks
 // The canonical sum of one chunk, e[0..count) with count <= 256 (missing elements count as +0.0): lane l of 64 adds

@@ -81,6 +81,7 @@ struct hpsdf_ctx {
     // kept across calls -- a scalar Query(pt) through the C++ drop-in must not pay two hipMalloc/hipFree pairs.
     // hostLock serialises those entry points per context (Octree::Query* is const and callable from many threads in
     // the reference, Octree.h:71-78).
+    std::shared_ptr<void> frontierScratch;    // frontier.hip: the device-side frontier's buffers, kept between Creates
     std::shared_ptr<void> continuityScratch;  // continuity.cpp: matrix + solver vectors kept between post-processes
     char* hostDev = nullptr;
     size_t hostDevCap = 0;

@@ -24,7 +24,7 @@ int makeFieldDev(const hpsdf_field*, const double*, FieldDev*) { return HPSDF_ER
 size_t fitLdsBytes(int, int, int) { return 0; }
 FitShape fitShape(int, int, uint32_t, bool, bool) { return FitShape{1, 1, 1, 0}; }
 hipError_t launchFit(hipStream_t, int, int, const FitBlock*, uint32_t, size_t, const FitTask*, double*, double*, double*,
-                     const DeviceTables*, const FieldDev&, const RootMap&) { return hipErrorNoDevice; }
+                     const DeviceTables*, const FieldDev&, const RootMap&, const uint32_t*) { return hipErrorNoDevice; }
 hipError_t launchPack(hipStream_t, const PackItem*, uint32_t, const double*, double*) { return hipErrorNoDevice; }
 hipError_t launchCgIterations(hipStream_t, const CgDev&, int) { return hipErrorNoDevice; }
 hipError_t launchCgStart(hipStream_t, const CgDev&) { return hipErrorNoDevice; }
