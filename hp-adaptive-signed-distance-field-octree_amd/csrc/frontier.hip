@@ -10,23 +10,28 @@
 // the frontier), the parent index and up to 10 coefficient segments (a leaf of degree p that started at degree f owns rows
 // [0, ncoef(f)) from its first fit and one more run of rows per P-refinement: nothing is copied when a degree rises).
 //
-// A round:
+// A round (r >= 1):
 //   fr_select_kernel   top-K of the frontier by (error desc, node index asc) as an MSB radix select over the error's bit
-//                      pattern: level 0 (exponent, 2048 bins) against a histogram kept incrementally by the apply kernel,
-//                      everything strictly above the threshold bin is taken, the bin itself becomes the candidate list
+//                      pattern: level 0 (exponent, 2048 bins) against a histogram kept incrementally -- its threshold bin
+//                      is known since the previous round closed; everything strictly above the bin is taken, the bin
+//                      itself becomes the candidate list
 //   fr_batch_kernel    (one workgroup) refines the candidates digit by digit until <= 4096 remain, sorts those exactly,
-//                      sorts the taken nodes by index -> the batch; then emits the round's FitTask / FitBlock lists
-//                      grouped by shape, the per-degree launch ranges, arena and sample offsets
+//                      sorts the taken nodes by index -> the batch; counts the round's cell fits per shape class and
+//                      lays out task list, workgroup list, arena rows and sample slots by prefix sums
+//   fr_tasks_kernel    (grid) writes the FitTask / FitBlock lists
 //   mesh_sample_kernel / fit_kernel   (kernels.hip) over device-written ranges: grids are upper bounds
-//   fr_apply_kernel    (one workgroup) improvements (:814-825, :846-854), decision (:600-601), child creation, queue
-//                      updates, the running total in the reference's order (one lane, :253-290), stop rule (:216)
-//   fr_totals_kernel + fr_store_kernel   when the stop rule has fired: ReallocCoeffs -- subtree coefficient counts
-//                      bottom-up, every leaf's coeffsStart by walking up its ancestors, coefficients gathered into the
-//                      packed store
-// Round 0 (the 4096 coarse cells) skips the selection: its batch is the uniformly refined tree's leaves in index order.
+//   fr_decide_kernel   (one workgroup) improvements (:814-825, :846-854), decision (:600-601), first child of every split
+//   fr_update_kernel   (grid) child creation, queue, coefficient counts of the ancestors; workgroup 0 carries the running
+//                      total in the reference's order (:253-290); the last workgroup to finish applies the stop rule
+//                      (:216) and computes the next selection's threshold bin
+//   fr_store_kernel    when the stop rule has fired: ReallocCoeffs -- every leaf's coeffsStart by walking up its
+//                      ancestors, coefficients gathered into the packed store
+// Round 0 (the 4096 coarse cells) is the same for every build and comes from a template: no selection, no task emission,
+// and if the build stops there (the BASELINE thresholds do) the packed store is the arena itself.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cstddef>
 #include <chrono>
@@ -51,39 +56,63 @@ constexpr int kFrSegs = 10;         // degrees 2..11: the first fit and at most 
 constexpr int kFrDepths = kMaxDepth + 2;
 constexpr int kFrClasses = 2 * (kMaxDegree + 1) * kFrDepths;  // (degree, from scratch | incremental, depth)
 constexpr uint64_t kNotQueued = ~0ull;
-constexpr uint32_t kFrSort = 4096;  // exact sort capacity (LDS)
+constexpr uint32_t kFrSort = 4096;  // bitonic sort capacity (LDS): the fallback ordering of a batch
+constexpr uint32_t kFrExact = 64;   // candidates left when the digit-by-digit refinement hands over to exact ranking
 
 struct FrHdr {
     uint32_t nNodes, nQueued, nJobs, done;
     uint32_t round, maxDegree, maxDepth, overflow;
     uint32_t nTasks, nBlocks, takenCount, candCount;
-    uint32_t above;
-    int32_t t1;
-    uint32_t nLeaves, pad0;
+    uint32_t above;   // selection, level 0: queued nodes in the exponent bins above the threshold bin t1
+    int32_t t1;       // (-1: the whole frontier is the batch); both are left by the previous round's update kernel
+    uint32_t nLeaves, arrive;
     uint32_t degBlocks[13][2];  // {first block, count} per degree: the range a fit launch walks
     uint32_t degTasks[13][2];   // {first task, count} per degree: the range a mesh-sampler launch walks
     uint64_t arenaUsed, sampleUsed, nCoeffs, pad1;
     uint64_t jobs, pRefines, hRefines, dropped, fits, samples;
     double total, target;
-    uint32_t hist1[2048];  // queued nodes per exponent bin (kept by apply / batch)
+    // staging between the decide and update kernels of a round
+    uint32_t rP, rH, rD, rMaxDeg;
+    uint32_t rOps, rPad;
+    uint64_t dbg[24];  // phase time stamps (s_memtime) of the one-workgroup kernels, read under HPSDF_TRACE
+    int64_t rCoeffDelta;
+    double rTotal;
+    uint32_t hist1[2048];  // queued nodes per exponent bin (kept by update / batch)
     uint32_t hist2[2048];  // level-1 digits of the candidates of the current selection
+};
+constexpr size_t kFrHdrCopyBytes = offsetof(FrHdr, hist1);
+
+struct FrRound {  // shape classes of the current round (written by fr_batch_kernel, read by fr_tasks_kernel)
+    uint32_t cCount[kFrClasses], cFirst[kFrClasses], cCursor[kFrClasses], cBlockFirst[kFrClasses], cBlocks[kFrClasses];
+    uint64_t cArena[kFrClasses], cSample[kFrClasses];
+    uint8_t cG[kFrClasses], cPlanes[kFrClasses];
+    uint64_t arenaBase;
 };
 
 struct FrDev {
     FrHdr* hdr;
+    FrHdr* hostHdr;  // the header's mirror in pinned host memory, as the device addresses it
+    FrRound* rnd;
     hpsdf_node* nodes;
     uint64_t* qErr;     // bit pattern of the queued error; kNotQueued = not in the frontier
     uint32_t* parent;
     uint64_t* segOff;   // [node][kFrSegs] arena offsets (doubles)
     uint8_t* segFirst;  // degree of the node's first segment
-    uint32_t* sub;      // finalize: coefficients in the subtree
+    uint32_t* sub;      // coefficients below every interior node (kept incrementally from round 1 on)
     uint32_t* taken;    // selection: nodes taken so far (unordered)
     uint32_t* candA;
     uint32_t* candB;
-    uint32_t* batchIdx;
-    double* batchErr;
-    uint64_t* jobP;     // per job: arena offset of the P result / of the first H child
-    uint64_t* jobH;
+    const uint32_t* batchIdx;  // the round's jobs in node-index order (round 0: the template's)
+    const double* batchErr;
+    const uint64_t* jobP;      // per job: arena offset of the P result / of the first H child
+    const uint64_t* jobH;
+    uint32_t* wBatchIdx;       // the same buffers, writable (rounds > 0)
+    double* wBatchErr;
+    uint64_t* wJobP;
+    uint64_t* wJobH;
+    uint8_t* kind;             // per job: 0 dropped, 1 P, 2 H
+    uint32_t* base;            // per H job: index of its first child
+    double* ops;               // the round's additions to the running total, densely, in job order
     FitTask* tasks;
     FitBlock* blocks;
     double* errs;       // [jobs][9]
@@ -130,50 +159,49 @@ __device__ __forceinline__ uint32_t frDigit(int level, uint64_t bits, uint32_t i
 }
 
 // Threshold bin of a 2048-bin histogram in LDS for `need` entries taken from the top: the largest bin T with
-// count(bins > T) < need <= count(bins >= T); *above = count(bins > T).  All threads call; sTmp: blockDim.x words.
-__device__ void frThreshold(const uint32_t* hist, uint32_t need, uint32_t* sTmp, int* outT, uint32_t* outAbove) {
-    const int nt = (int)blockDim.x, per = 2048 / nt, tid = (int)threadIdx.x;
-    uint32_t s = 0;
-    for (int k = 0; k < per; ++k) s += hist[tid * per + k];
-    sTmp[tid] = s;
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t cum = 0;
-        int t = nt - 1;
-        for (; t > 0 && cum + sTmp[t] < need; --t) cum += sTmp[t];
-        int b = t * per + per - 1;
-        for (; b > t * per && cum + hist[b] < need; --b) cum += hist[b];
-        *outT = b;
-        *outAbove = cum;
+// count(bins > T) < need <= count(bins >= T); *above = count(bins > T).  All threads call (the histogram must be complete
+// and visible: the caller has synchronised); wave 0 works -- lane l owns bins 32 l .. 32 l + 31, a suffix scan over the
+// lanes finds the lane where the running count crosses `need`, that lane walks its 32 bins.
+__device__ void frThreshold(const uint32_t* hist, uint32_t need, uint32_t* /*sTmp*/, int* outT, uint32_t* outAbove) {
+    if (threadIdx.x < 64) {
+        const int lane = (int)threadIdx.x;
+        uint32_t own = 0;
+        for (int k = 0; k < 32; ++k) own += hist[lane * 32 + k];
+        uint32_t suf = own;  // inclusive suffix sum: bins of lanes >= this one
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_down(suf, off, 64);
+            if (lane + off < 64) suf += v;
+        }
+        const uint32_t aboveLane = suf - own;  // bins of the lanes above this one
+        const bool crossing = aboveLane < need && need <= suf;
+        const unsigned long long m = __ballot(crossing);
+        if (m == 0ull) {  // fewer than `need` entries in all: everything is taken
+            if (lane == 0) *outT = -1, *outAbove = suf;
+        } else if (crossing) {
+            uint32_t cum = aboveLane;
+            int bb = lane * 32 + 31;
+            for (; bb > lane * 32 && cum + hist[bb] < need; --bb) cum += hist[bb];
+            *outT = bb;
+            *outAbove = cum;
+        }
     }
     __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// selection, level 0
+// selection, level 0 (the threshold bin was computed when the previous round's updates completed)
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void fr_select_kernel(FrDev d) {
     FrHdr* h = d.hdr;
     if (h->done) return;
     __shared__ uint32_t sHist[2048];
-    __shared__ uint32_t sTmp[256];
-    __shared__ int sT;
-    __shared__ uint32_t sAbove;
-    const uint32_t nQ = h->nQueued, nNodes = h->nNodes;
-    for (int i = threadIdx.x; i < 2048; i += 256) sHist[i] = h->hist1[i];
-    __syncthreads();
-    if (nQ <= d.K) {  // the whole frontier is this round's batch
-        if (threadIdx.x == 0) sT = -1, sAbove = nQ;
-        __syncthreads();
-    } else {
-        frThreshold(sHist, d.K, sTmp, &sT, &sAbove);
-    }
-    const int T = sT;
-    __syncthreads();
+    const uint32_t nNodes = h->nNodes;
+    const int T = h->t1;
     for (int i = threadIdx.x; i < 2048; i += 256) sHist[i] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const uint32_t stride = gridDim.x * 256u;
+    bool anyCand = false;
     for (uint32_t base = blockIdx.x * 256u; base < nNodes; base += stride) {
         const uint32_t i = base + threadIdx.x;
         const uint64_t bits = i < nNodes ? d.qErr[i] : kNotQueued;
@@ -196,24 +224,24 @@ __global__ __launch_bounds__(256) void fr_select_kernel(FrDev d) {
             if (cand) {
                 d.candA[slot + (uint32_t)__popcll(mc & ((1ull << lane) - 1ull))] = i;
                 atomicAdd(&sHist[frDigit(1, bits, i)], 1u);
+                anyCand = true;
             }
         }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2048; i += 256)
-        if (sHist[i]) atomicAdd(&h->hist2[i], sHist[i]);
-    if (blockIdx.x == 0 && threadIdx.x == 0) h->t1 = T, h->above = sAbove;
+    if (__syncthreads_or(anyCand ? 1 : 0))
+        for (int i = threadIdx.x; i < 2048; i += 256)
+            if (sHist[i]) atomicAdd(&h->hist2[i], sHist[i]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// selection, remaining levels + exact sort; then the round's task and workgroup lists
+// selection, remaining levels + exact sort -> the batch; then the round's shape classes
 // ---------------------------------------------------------------------------------------------------------------------
-// In-place bitonic sort of n = 4096 (key, val) pairs in LDS by "key descending, then val ascending"; 1024 threads.
-__device__ void frBitonic(uint64_t* key, uint32_t* val) {
+// In-place bitonic sort of n (a power of two, <= 4096) (key, val) pairs in LDS by "key descending, then val ascending".
+__device__ void frBitonic(uint64_t* key, uint32_t* val, uint32_t n) {
     const uint32_t tid = threadIdx.x;
-    for (uint32_t k = 2; k <= kFrSort; k <<= 1) {
+    for (uint32_t k = 2; k <= n; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = tid; t < kFrSort / 2; t += blockDim.x) {
+            for (uint32_t t = tid; t < n / 2; t += blockDim.x) {
                 const uint32_t lo = ((t / j) * 2 * j) + (t % j), hi = lo + j;
                 const bool up = ((lo & k) == 0);  // this run sorts "first before second"
                 const uint64_t ka = key[lo], kb = key[hi];
@@ -228,288 +256,351 @@ __device__ void frBitonic(uint64_t* key, uint32_t* val) {
         }
     }
 }
+__device__ __forceinline__ uint32_t frPow2(uint32_t n) {
+    uint32_t p = 2;
+    while (p < n) p <<= 1;
+    return p;
+}
 
-struct FrBatchLds {  // carved out of dynamic LDS; the sort arrays are dead once the batch is written
-    uint64_t* key;    // [4096]
-    uint32_t* val;    // [4096]
-    uint32_t* hist;   // [2048]
-    uint32_t* tmp;    // [1024]
-    uint32_t* cCount;  // [kFrClasses] tasks per class
-    uint32_t* cFirst;  // first task
-    uint32_t* cCursor;
-    uint32_t* cBlockFirst;
-    uint32_t* cBlocks;
-    uint64_t* cArena;   // first arena row (relative to the round's base)
-    uint64_t* cSample;  // first sample
-    uint8_t* cG;
-    uint8_t* cPlanes;
-    uint8_t* jDeg;   // [4096] per job
-    uint8_t* jDepth;
-    uint8_t* jCoarse;
-};
-constexpr size_t kFrBatchLdsBytes = 4096 * 8 + 4096 * 4 + 2048 * 4 + 1024 * 4 + kFrClasses * (5 * 4 + 2 * 8 + 2) + 3 * 4096 + 64;
-
-__global__ __launch_bounds__(1024) void fr_batch_kernel(FrDev d, int skipSelect) {
+__global__ __launch_bounds__(1024) void fr_batch_kernel(FrDev d) {
     FrHdr* h = d.hdr;
+    FrRound* R = d.rnd;
+    const uint32_t tid = threadIdx.x;
     if (h->done) {
-        if (threadIdx.x == 0) {
-            h->nJobs = 0, h->nTasks = 0, h->nBlocks = 0;
-            for (int g = 0; g < 13; ++g) h->degBlocks[g][0] = h->degBlocks[g][1] = h->degTasks[g][0] = h->degTasks[g][1] = 0;
-        }
+        if (tid < 13) h->degBlocks[tid][0] = h->degBlocks[tid][1] = h->degTasks[tid][0] = h->degTasks[tid][1] = 0;
+        if (tid == 0) h->nJobs = 0, h->nTasks = 0, h->nBlocks = 0;
         return;
     }
-    extern __shared__ unsigned char frRaw[];
-    FrBatchLds L;
-    {
-        unsigned char* p = frRaw;
-        L.key = (uint64_t*)p, p += 4096 * 8;
-        L.cArena = (uint64_t*)p, p += kFrClasses * 8;
-        L.cSample = (uint64_t*)p, p += kFrClasses * 8;
-        L.val = (uint32_t*)p, p += 4096 * 4;
-        L.hist = (uint32_t*)p, p += 2048 * 4;
-        L.tmp = (uint32_t*)p, p += 1024 * 4;
-        L.cCount = (uint32_t*)p, p += kFrClasses * 4;
-        L.cFirst = (uint32_t*)p, p += kFrClasses * 4;
-        L.cCursor = (uint32_t*)p, p += kFrClasses * 4;
-        L.cBlockFirst = (uint32_t*)p, p += kFrClasses * 4;
-        L.cBlocks = (uint32_t*)p, p += kFrClasses * 4;
-        L.cG = p, p += kFrClasses;
-        L.cPlanes = p, p += kFrClasses;
-        L.jDeg = p, p += 4096;
-        L.jDepth = p, p += 4096;
-        L.jCoarse = p, p += 4096;
-    }
+    __shared__ uint64_t sKey[kFrSort];
+    __shared__ uint32_t sVal[kFrSort];
+    __shared__ uint32_t sHist[2048];
+    __shared__ uint32_t sTmp[1024];
+    __shared__ uint32_t sCount[kFrClasses];
     __shared__ int sT;
-    __shared__ uint32_t sAbove, sCount, sNext;
-    const uint32_t tid = threadIdx.x;
-    uint32_t nJobs;
-    if (skipSelect) {
-        nJobs = h->nJobs;  // batchIdx / batchErr were put there by the initialisation (round 0)
+    __shared__ uint32_t sAbove, sC, sNext;
+#define FR_STAMP(k) do { if (tid == 0) h->dbg[k] = __builtin_readcyclecounter(); } while (0)
+    FR_STAMP(0);
+    const uint32_t nQ = h->nQueued;
+    const uint32_t nJobs = nQ < d.K ? nQ : d.K;
+    uint32_t need = nJobs - h->above;  // still to come out of the candidates
+    uint32_t C = h->candCount;
+    uint32_t* cur = d.candA;
+    uint32_t* nxt = d.candB;
+    int level = 1;
+    if (C > kFrExact) {
+        for (uint32_t i = tid; i < 2048; i += 1024) sHist[i] = h->hist2[i];
+        __syncthreads();
+    }
+    uint32_t tk = h->takenCount;
+    while (C > kFrExact && level <= 8) {  // refine by the digit of `level` (its histogram is in sHist)
+        frThreshold(sHist, need, sTmp, &sT, &sAbove);
+        const int T = sT;
+        const uint32_t abv = sAbove;
+        if (tid == 0) sC = 0, sNext = tk;
+        __syncthreads();
+        for (uint32_t i = tid; i < 2048; i += 1024) sHist[i] = 0;
+        __syncthreads();
+        for (uint32_t base = 0; base < C; base += 1024) {
+            const uint32_t q = base + tid;
+            if (q < C) {
+                const uint32_t idx = cur[q];
+                const uint64_t bits = d.qErr[idx];
+                const int dg = (int)frDigit(level, bits, idx);
+                if (dg > T) {
+                    d.taken[atomicAdd(&sNext, 1u)] = idx;
+                } else if (dg == T) {
+                    nxt[atomicAdd(&sC, 1u)] = idx;
+                    if (level < 8) atomicAdd(&sHist[frDigit(level + 1, bits, idx)], 1u);
+                }
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        need -= abv;
+        C = sC;
+        tk = sNext;
+        __syncthreads();
+        uint32_t* t = cur;
+        cur = nxt, nxt = t;
+        ++level;
+    }
+    // exact order of what is left (<= 64 candidates, unique keys): a candidate's rank is the number of candidates before
+    // it in the frontier's order (error desc, index asc); ranks below `need` join the batch
+    FR_STAMP(1);
+    if (need && tid < 64) {
+        const bool have = tid < C;
+        const uint32_t idx = have ? cur[tid] : 0xFFFFFFFFu;
+        const uint64_t key = have ? d.qErr[idx] : 0ull;
+        uint32_t rank = 0;
+        for (int l = 0; l < 64; ++l) {
+            const uint64_t ok = (uint64_t)__shfl((long long)key, l, 64);
+            const uint32_t oi = __shfl(idx, l, 64);
+            rank += ((uint32_t)l < C && (ok > key || (ok == key && oi < idx))) ? 1u : 0u;
+        }
+        if (have && rank < need) d.taken[tk + rank] = idx;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // the batch in node-index order: a bitmap over the nodes (bit = taken), prefix population counts, every set bit's
+    // position is its rank (trees beyond 262144 nodes: bitonic sort of the indices)
+    FR_STAMP(2);
+    const uint32_t nNodes = h->nNodes;
+    if (nNodes <= 8192u * 32u) {
+        uint32_t* bm = reinterpret_cast<uint32_t*>(sKey);  // 8192 words
+        const uint32_t words = (nNodes + 31u) >> 5;
+        for (uint32_t w = tid; w < 8192u; w += 1024) bm[w] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < nJobs; i += 1024) {
+            const uint32_t idx = d.taken[i];
+            atomicOr(&bm[idx >> 5], 1u << (idx & 31u));
+        }
+        __syncthreads();
+        uint32_t own = 0;  // thread t owns words 8 t .. 8 t + 7
+        if (tid * 8u < words)
+            for (int k = 0; k < 8; ++k) own += (uint32_t)__popc(bm[tid * 8 + k]);
+        uint32_t inc = own;  // inclusive scan over the wave's lanes
+        const int lane = (int)(tid & 63);
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += v;
+        }
+        if (lane == 63) sTmp[tid >> 6] = inc;
+        __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < (tid >> 6); ++w) before += sTmp[w];
+        uint32_t pos = before + inc - own;
+        if (own)
+            for (int k = 0; k < 8; ++k) {
+                uint32_t bits = bm[tid * 8 + k];
+                while (bits) {
+                    const int bpos = __ffs((int)bits) - 1;
+                    bits &= bits - 1u;
+                    sVal[pos++] = (tid * 8u + (uint32_t)k) * 32u + (uint32_t)bpos;
+                }
+            }
+        __syncthreads();
     } else {
-        const uint32_t nQ = h->nQueued;
-        nJobs = nQ < d.K ? nQ : d.K;
-        uint32_t need = nJobs - h->above;  // still to come out of the candidates
-        uint32_t C = h->candCount;
-        uint32_t* cur = d.candA;
-        uint32_t* nxt = d.candB;
-        for (uint32_t i = tid; i < 2048; i += 1024) L.hist[i] = h->hist2[i];
-        __syncthreads();
-        int level = 1;
-        while (C > kFrSort && level <= 8) {  // refine by the digit of `level` (its histogram is in L.hist)
-            frThreshold(L.hist, need, L.tmp, &sT, &sAbove);
-            const int T = sT;
-            const uint32_t abv = sAbove;
-            if (tid == 0) sCount = 0, sNext = h->takenCount;
-            __syncthreads();
-            for (uint32_t i = tid; i < 2048; i += 1024) L.hist[i] = 0;
-            __syncthreads();
-            for (uint32_t base = 0; base < C; base += 1024) {
-                const uint32_t q = base + tid;
-                if (q < C) {
-                    const uint32_t idx = cur[q];
-                    const uint64_t bits = d.qErr[idx];
-                    const int dg = (int)frDigit(level, bits, idx);
-                    if (dg > T) {
-                        d.taken[atomicAdd(&sNext, 1u)] = idx;
-                    } else if (dg == T) {
-                        nxt[atomicAdd(&sCount, 1u)] = idx;
-                        if (level < 8) atomicAdd(&L.hist[frDigit(level + 1, bits, idx)], 1u);
-                    }
-                }
-            }
-            __syncthreads();
-            need -= abv;
-            C = sCount;
-            if (tid == 0) h->takenCount = sNext;
-            __syncthreads();
-            uint32_t* t = cur;
-            cur = nxt, nxt = t;
-            ++level;
-        }
-        // exact order of what is left (<= 4096 candidates; unique keys)
-        for (uint32_t i = tid; i < kFrSort; i += 1024) {
-            if (i < C) {
-                const uint32_t idx = cur[i];
-                L.key[i] = d.qErr[idx], L.val[i] = idx;
-            } else {
-                L.key[i] = 0, L.val[i] = 0xFFFFFFFFu;  // behind every real entry
-            }
+        const uint32_t n2 = frPow2(nJobs);
+        for (uint32_t i = tid; i < n2; i += 1024) {
+            sKey[i] = 0;
+            sVal[i] = i < nJobs ? d.taken[i] : 0xFFFFFFFFu;
         }
         __syncthreads();
-        if (C > 1) frBitonic(L.key, L.val);
-        const uint32_t tk = h->takenCount;
-        for (uint32_t i = tid; i < need; i += 1024) d.taken[tk + i] = L.val[i];
-        __syncthreads();
-        // the batch in node-index order
-        for (uint32_t i = tid; i < kFrSort; i += 1024) {
-            L.key[i] = 0;
-            L.val[i] = i < nJobs ? d.taken[i] : 0xFFFFFFFFu;
-        }
-        __syncthreads();
-        if (nJobs > 1) frBitonic(L.key, L.val);
-        for (uint32_t i = tid; i < 2048; i += 1024) L.hist[i] = 0;
-        __syncthreads();
-        for (uint32_t j = tid; j < nJobs; j += 1024) {
-            const uint32_t idx = L.val[j];
-            const uint64_t bits = d.qErr[idx];
-            d.batchIdx[j] = idx;
-            d.batchErr[j] = __longlong_as_double((long long)bits);
-            d.qErr[idx] = kNotQueued;
-            atomicAdd(&L.hist[frDigit(0, bits, idx)], 1u);
-        }
-        __syncthreads();
-        for (uint32_t i = tid; i < 2048; i += 1024)
-            if (L.hist[i]) h->hist1[i] -= L.hist[i];
-        __syncthreads();
+        if (nJobs > 1) frBitonic(sKey, sVal, n2);
     }
-
-    // ---- tasks: every job becomes 1 (coarse) or up to 9 cell fits, grouped by shape class
-    for (uint32_t c = tid; c < (uint32_t)kFrClasses; c += 1024) L.cCount[c] = 0;
+    FR_STAMP(3);
+    for (uint32_t i = tid; i < 2048; i += 1024) sHist[i] = 0;
+    for (uint32_t c = tid; c < (uint32_t)kFrClasses; c += 1024) sCount[c] = 0;
     __syncthreads();
+    // ---- the jobs leave the frontier; every job becomes 1 (coarse) or up to 9 cell fits: count them per shape class
     for (uint32_t j = tid; j < nJobs; j += 1024) {
-        const hpsdf_node& n = d.nodes[d.batchIdx[j]];
-        const double e = d.batchErr[j];
-        const bool coarse = fabs(e - HPSDF_INITIAL_NODE_ERR) < DBL_EPSILON;  // Octree.cpp:806,831
+        const uint32_t idx = sVal[j];
+        const uint64_t bits = d.qErr[idx];
+        const double e = __longlong_as_double((long long)bits);
+        d.wBatchIdx[j] = idx;
+        d.wBatchErr[j] = e;
+        d.qErr[idx] = kNotQueued;
+        atomicAdd(&sHist[frDigit(0, bits, idx)], 1u);
+        const hpsdf_node& n = d.nodes[idx];
         const int p = n.degree, dep = n.depth;
-        L.jDeg[j] = (uint8_t)p, L.jDepth[j] = (uint8_t)dep, L.jCoarse[j] = coarse ? 1 : 0;
-        if (coarse) {
-            atomicAdd(&L.cCount[frClass(2, false, dep)], 1u);  // :836-843
+        if (fabs(e - HPSDF_INITIAL_NODE_ERR) < DBL_EPSILON) {  // coarse, Octree.cpp:806,831
+            atomicAdd(&sCount[frClass(2, false, dep)], 1u);  // :836-843
         } else {
-            if (dep < kMaxDepth) atomicAdd(&L.cCount[frClass(p, false, dep + 1)], 8u);     // :814-822
-            if (p < kMaxDegree - 1) atomicAdd(&L.cCount[frClass(p + 1, true, dep)], 1u);  // :846-851
+            if (dep < kMaxDepth) atomicAdd(&sCount[frClass(p, false, dep + 1)], 8u);     // :814-822
+            if (p < kMaxDegree - 1) atomicAdd(&sCount[frClass(p + 1, true, dep)], 1u);  // :846-851
         }
     }
     __syncthreads();
-    for (uint32_t c = tid; c < (uint32_t)kFrClasses; c += 1024) {
-        int g = 1, pl = 1;
-        const int deg = (int)c / kFrDepths / 2;
-        const bool incr = ((int)c / kFrDepths) & 1;
-        if (L.cCount[c]) frShape(deg, incr, L.cCount[c], &g, &pl);
-        L.cG[c] = (uint8_t)g, L.cPlanes[c] = (uint8_t)pl;
-        L.cBlocks[c] = L.cCount[c] ? (L.cCount[c] + (uint32_t)g - 1u) / (uint32_t)g : 0u;
+    FR_STAMP(4);
+    for (uint32_t i = tid; i < 2048; i += 1024)
+        if (sHist[i]) h->hist1[i] -= sHist[i];
+    // ---- shapes, then prefix sums over the classes (degree-major): tasks, workgroups, arena rows, samples.
+    //      Thread c owns class c; the scan runs over 512 slots in LDS (sKey doubles as the 64-bit scan buffer).
+    uint32_t myCount = 0, myBlocks = 0;
+    uint64_t myRows = 0, mySamples = 0;
+    int g = 1, pl = 1;
+    if (tid < (uint32_t)kFrClasses) {
+        myCount = sCount[tid];
+        if (myCount) {
+            const int deg = (int)tid / kFrDepths / 2;
+            const bool incr = ((int)tid / kFrDepths) & 1;
+            frShape(deg, incr, myCount, &g, &pl);
+            myBlocks = (myCount + (uint32_t)g - 1u) / (uint32_t)g;
+            const uint64_t nq = 4 * (uint64_t)deg + 1;
+            myRows = (uint64_t)(incr ? frCoef(deg) - frCoef(deg - 1) : frCoef(deg)) * myCount;
+            mySamples = nq * nq * nq * myCount;
+        }
     }
     __syncthreads();
-    if (tid == 0) {  // prefix over the classes (degree-major): tasks, workgroups, arena rows, samples
-        uint32_t t = 0, b = 0;
-        uint64_t rows = 0, smp = 0;
-        for (int deg = 0; deg <= kMaxDegree; ++deg) {
-            const uint32_t t0 = t, b0 = b;
-            for (int v = 0; v < 2 * kFrDepths; ++v) {
-                const int c = deg * 2 * kFrDepths + v;
-                const uint32_t cnt = L.cCount[c];
-                L.cFirst[c] = t, L.cCursor[c] = 0, L.cBlockFirst[c] = b, L.cArena[c] = rows, L.cSample[c] = smp;
-                if (cnt) {
-                    const bool incr = v >= kFrDepths;
-                    const uint64_t r = incr ? frCoef(deg) - frCoef(deg - 1) : frCoef(deg);
-                    const uint64_t nq = 4 * (uint64_t)deg + 1;
-                    t += cnt, b += L.cBlocks[c], rows += r * cnt, smp += nq * nq * nq * cnt;
-                }
-            }
-            h->degTasks[deg][0] = t0, h->degTasks[deg][1] = t - t0;
-            h->degBlocks[deg][0] = b0, h->degBlocks[deg][1] = b - b0;
-        }
+    FR_STAMP(5);
+    // four inclusive scans over 512 slots: counts and blocks in sTmp / sVal (32 bit), rows and samples in sKey halves
+    uint64_t* sRows = sKey;
+    uint64_t* sSmp = sKey + 512;
+    uint32_t* sCnt = sTmp;
+    uint32_t* sBlk = sVal;
+    if (tid < 512) sCnt[tid] = myCount, sBlk[tid] = myBlocks, sRows[tid] = myRows, sSmp[tid] = mySamples;
+    __syncthreads();
+    for (uint32_t off = 1; off < 512; off <<= 1) {
+        uint32_t a = 0, b = 0;
+        uint64_t r = 0, sm = 0;
+        if (tid < 512 && tid >= off) a = sCnt[tid - off], b = sBlk[tid - off], r = sRows[tid - off], sm = sSmp[tid - off];
+        __syncthreads();
+        if (tid < 512) sCnt[tid] += a, sBlk[tid] += b, sRows[tid] += r, sSmp[tid] += sm;
+        __syncthreads();
+    }
+    FR_STAMP(6);
+    if (tid < (uint32_t)kFrClasses) {
+        R->cCount[tid] = myCount;
+        R->cFirst[tid] = sCnt[tid] - myCount;
+        R->cCursor[tid] = 0;
+        R->cBlockFirst[tid] = sBlk[tid] - myBlocks;
+        R->cBlocks[tid] = myBlocks;
+        R->cArena[tid] = sRows[tid] - myRows;
+        R->cSample[tid] = sSmp[tid] - mySamples;
+        R->cG[tid] = (uint8_t)g;
+        R->cPlanes[tid] = (uint8_t)pl;
+    }
+    if (tid < 13) {  // per degree: the classes [deg * 24, deg * 24 + 24)
+        const uint32_t lo = tid * 2 * kFrDepths, hi = lo + 2 * kFrDepths - 1;
+        const uint32_t t0 = lo ? sCnt[lo - 1] : 0u, b0 = lo ? sBlk[lo - 1] : 0u;
+        h->degTasks[tid][0] = t0, h->degTasks[tid][1] = sCnt[hi] - t0;
+        h->degBlocks[tid][0] = b0, h->degBlocks[tid][1] = sBlk[hi] - b0;
+    }
+    if (tid == 0) {
+        const uint32_t t = sCnt[kFrClasses - 1], b = sBlk[kFrClasses - 1];
+        const uint64_t rows = sRows[kFrClasses - 1], smp = sSmp[kFrClasses - 1];
         h->nJobs = nJobs, h->nTasks = t, h->nBlocks = b;
         h->sampleUsed = smp;
         h->fits += t, h->samples += smp;
-        sNext = 0;
-        // rows of this round start at the arena's current end
-        L.tmp[0] = (uint32_t)(rows & 0xFFFFFFFFu), L.tmp[1] = (uint32_t)(rows >> 32);
+        R->arenaBase = h->arenaUsed;
+        h->arenaUsed += rows;
     }
-    __syncthreads();
-    const uint64_t arenaBase = h->arenaUsed;
-    for (uint32_t j = tid; j < nJobs; j += 1024) {
-        const hpsdf_node& n = d.nodes[d.batchIdx[j]];
-        const int p = L.jDeg[j], dep = L.jDepth[j];
-        const uint32_t slot0 = j * HPSDF_JOB_HEADER_DOUBLES;
-        auto emit = [&](int deg, bool incr, const float* bmin, const float* bmax, int depth, uint32_t errSlot, uint32_t slot) -> uint64_t {
-            const int c = frClass(deg, incr, depth);
+    FR_STAMP(7);
+}
+
+// the round's FitTask / FitBlock lists, grouped by shape class.  Grid-wide: sixteen lanes per job -- lane k < 8 writes the
+// from-scratch fit of child k (EstimateHImprovement, :814-822), lane 8 the job's own fit (the coarse degree-2 fit :836-843
+// or the incremental one :846-851); lanes 0 and 8 reserve the slots of their class -- then one lane per workgroup record.
+__global__ __launch_bounds__(256) void fr_tasks_kernel(FrDev d) {
+    FrHdr* h = d.hdr;
+    if (h->done) return;
+    FrRound* R = d.rnd;
+    const uint32_t nJobs = h->nJobs, nBlocks = h->nBlocks;
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
+    const uint64_t arenaBase = R->arenaBase;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t base = (gid >> 4) - ((uint32_t)lane >> 4); base < nJobs; base += stride >> 4) {  // 4 jobs per wave, wave-uniform trip count
+        const uint32_t j = base + ((uint32_t)lane >> 4);
+        const int k = lane & 15;
+        const bool live = j < nJobs;
+        const hpsdf_node& n = d.nodes[d.batchIdx[live ? j : 0]];
+        const int p = n.degree, dep = n.depth;
+        const bool coarse = fabs(d.batchErr[live ? j : 0] - HPSDF_INITIAL_NODE_ERR) < DBL_EPSILON;
+        const bool hasH = live && !coarse && dep < kMaxDepth, hasP = live && (coarse || p < kMaxDegree - 1);
+        // this lane's fit, if any
+        const bool mine = (k < 8 && hasH) || (k == 8 && hasP);
+        const int deg = k < 8 ? p : (coarse ? 2 : p + 1);
+        const bool incr = k == 8 && !coarse;
+        const int depth = k < 8 ? dep + 1 : dep;
+        const int c = frClass(deg, incr, depth);
+        uint32_t slot = 0;
+        if (mine && (k == 0 || k == 8)) slot = atomicAdd(&R->cCursor[c], k == 0 ? 8u : 1u);
+        slot = __shfl(slot, (lane & ~15) | (k < 8 ? 0 : 8), 64) + (k < 8 ? (uint32_t)k : 0u);
+        uint64_t outOff = ~0ull;
+        if (mine) {
             const uint64_t rows = incr ? frCoef(deg) - frCoef(deg - 1) : frCoef(deg);
             const uint64_t nq = 4 * (uint64_t)deg + 1;
-            FitTask& t = d.tasks[L.cFirst[c] + slot];
-            for (int a = 0; a < 3; ++a) t.bmin[a] = bmin[a], t.bmax[a] = bmax[a];
-            t.outOff = arenaBase + L.cArena[c] + (uint64_t)slot * rows;
-            t.copyOff = ~0ull;
-            t.sampleOff = L.cSample[c] + (uint64_t)slot * nq * nq * nq;
-            t.errSlot = errSlot;
-            t.depth = (uint8_t)depth;
-            t.pad[0] = (uint8_t)deg, t.pad[1] = t.pad[2] = 0;
-            return t.outOff;
-        };
-        uint64_t pOff = ~0ull, hOff = ~0ull;
-        if (L.jCoarse[j]) {
-            const uint32_t s = atomicAdd(&L.cCursor[frClass(2, false, dep)], 1u);
-            pOff = emit(2, false, n.aabb_min, n.aabb_max, dep, slot0, s);
-        } else {
-            if (dep < kMaxDepth) {
-                const uint32_t s = atomicAdd(&L.cCursor[frClass(p, false, dep + 1)], 8u);
-                for (unsigned i = 0; i < 8; ++i) {
-                    float cmin[3], cmax[3];
-                    for (int a = 0; a < 3; ++a) {  // Octree::CornerAABB, :1096-1112
-                        const float mid = (n.aabb_max[a] + n.aabb_min[a]) * 0.5f;
-                        cmin[a] = (i >> a) & 1u ? mid : n.aabb_min[a];
-                        cmax[a] = (i >> a) & 1u ? n.aabb_max[a] : mid;
-                    }
-                    const uint64_t o = emit(p, false, cmin, cmax, dep + 1, slot0 + 1 + i, s + i);
-                    if (i == 0) hOff = o;
+            FitTask t;
+            for (int a = 0; a < 3; ++a) {
+                if (k < 8) {  // Octree::CornerAABB, :1096-1112
+                    const float mid = (n.aabb_max[a] + n.aabb_min[a]) * 0.5f;
+                    t.bmin[a] = (k >> a) & 1 ? mid : n.aabb_min[a];
+                    t.bmax[a] = (k >> a) & 1 ? n.aabb_max[a] : mid;
+                } else {
+                    t.bmin[a] = n.aabb_min[a], t.bmax[a] = n.aabb_max[a];
                 }
             }
-            if (p < kMaxDegree - 1) {
-                const uint32_t s = atomicAdd(&L.cCursor[frClass(p + 1, true, dep)], 1u);
-                pOff = emit(p + 1, true, n.aabb_min, n.aabb_max, dep, slot0, s);
-            }
+            outOff = arenaBase + R->cArena[c] + (uint64_t)slot * rows;
+            t.outOff = outOff;
+            t.copyOff = ~0ull;
+            t.sampleOff = R->cSample[c] + (uint64_t)slot * nq * nq * nq;
+            t.errSlot = j * HPSDF_JOB_HEADER_DOUBLES + (k < 8 ? 1u + (uint32_t)k : 0u);
+            t.depth = (uint8_t)depth;
+            t.pad[0] = (uint8_t)deg, t.pad[1] = t.pad[2] = 0;
+            d.tasks[R->cFirst[c] + slot] = t;
         }
-        d.jobP[j] = pOff, d.jobH[j] = hOff;
+        if (live && k == 0) d.wJobH[j] = outOff;
+        if (live && k == 8) d.wJobP[j] = outOff;
     }
-    for (int c = 0; c < kFrClasses; ++c) {
-        const uint32_t nb = L.cBlocks[c];
-        if (!nb) continue;
+    for (uint32_t b = gid; b < nBlocks; b += stride) {
+        int lo = 0, hi = kFrClasses;  // the last class whose first workgroup is <= b is the one that owns b
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (R->cBlockFirst[mid] <= b)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const int c = lo;
         const int deg = c / kFrDepths / 2;
         const bool incr = (c / kFrDepths) & 1;
-        for (uint32_t b = tid; b < nb; b += 1024) {
-            FitBlock fb;
-            fb.firstTask = L.cFirst[c] + b * L.cG[c];
-            const uint32_t left = L.cCount[c] - b * L.cG[c];
-            fb.nTasks = (uint16_t)(left < L.cG[c] ? left : L.cG[c]);
-            fb.degree = (uint8_t)deg;
-            fb.planesPerChunk = L.cPlanes[c];
-            fb.rowStart = (uint16_t)(incr ? frCoef(deg - 1) : 0);
-            fb.rowEnd = (uint16_t)frCoef(deg);
-            fb.depth = (uint8_t)(c % kFrDepths);
-            fb.weighted = 0;
-            fb.pad1[0] = fb.pad1[1] = 0;
-            d.blocks[L.cBlockFirst[c] + b] = fb;
-        }
+        const uint32_t local = b - R->cBlockFirst[c], g = R->cG[c];
+        FitBlock fb;
+        fb.firstTask = R->cFirst[c] + local * g;
+        const uint32_t left = R->cCount[c] - local * g;
+        fb.nTasks = (uint16_t)(left < g ? left : g);
+        fb.degree = (uint8_t)deg;
+        fb.planesPerChunk = R->cPlanes[c];
+        fb.rowStart = (uint16_t)(incr ? frCoef(deg - 1) : 0);
+        fb.rowEnd = (uint16_t)frCoef(deg);
+        fb.depth = (uint8_t)(c % kFrDepths);
+        fb.weighted = 0;
+        fb.pad1[0] = fb.pad1[1] = 0;
+        d.blocks[b] = fb;
     }
-    for (uint32_t i = tid; i < nJobs * HPSDF_JOB_HEADER_DOUBLES; i += 1024) d.errs[i] = 0.0;
-    __syncthreads();
-    if (tid == 0) h->arenaUsed = arenaBase + ((uint64_t)L.tmp[0] | ((uint64_t)L.tmp[1] << 32));
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// apply: Octree.cpp:594-601 (decision) and :243-299 (bookkeeping), jobs in node-index order
+// decide: Octree.cpp:594-601 per job, and the index of every splitting job's first child
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void fr_apply_kernel(FrDev d) {
+__global__ __launch_bounds__(1024) void fr_decide_kernel(FrDev d) {
     FrHdr* h = d.hdr;
     if (h->done) return;
-    __shared__ uint8_t sKind[kFrJobs];    // 0 dropped, 1 P, 2 H
-    __shared__ uint32_t sBase[kFrJobs];   // H: index of the first child
-    __shared__ uint32_t sHist[2048];
-    __shared__ uint32_t sScan[1024];
-    __shared__ double sOps[64 * 9];
-    __shared__ uint32_t sCnt[4];          // P, H, dropped, max degree
-    __shared__ double sTotal;
+    __shared__ uint32_t sScan[16];
+    __shared__ uint32_t sCnt[4];  // P, -, dropped, max degree
+    __shared__ int sDelta;
     const uint32_t tid = threadIdx.x, nJobs = h->nJobs, nNodes0 = h->nNodes;
-    for (uint32_t i = tid; i < 2048; i += 1024) sHist[i] = 0;
+    const bool round0 = h->round == 0;
+    FR_STAMP(8);
     if (tid < 4) sCnt[tid] = 0;
+    if (tid == 0) sDelta = 0;
     __syncthreads();
-    // ---- decisions
-    for (uint32_t j = tid; j < nJobs; j += 1024) {
+    // thread t owns jobs 4 t .. 4 t + 3 from the decision to the operand list: their errors stay in registers
+    uint32_t nP = 0, nD = 0, maxDeg = 0;
+    int delta = 0;
+    int kd[4];
+    double ev[4][9], be[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t j = tid * 4u + (uint32_t)q;
+        kd[q] = 0;
+        be[q] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) ev[q][i] = 0.0;
+        if (j >= nJobs) continue;
         const uint32_t idx = d.batchIdx[j];
         const double err = d.batchErr[j];
+        be[q] = err;
         const int p = d.nodes[idx].degree, dep = d.nodes[idx].depth;
         const double* e = d.errs + (size_t)j * HPSDF_JOB_HEADER_DOUBLES;
-        const double pErr = e[0];
         const bool coarse = fabs(err - HPSDF_INITIAL_NODE_ERR) < DBL_EPSILON;
+        const bool hasH = !coarse && dep < kMaxDepth, hasP = coarse || p < kMaxDegree - 1;
+        if (hasP) ev[q][0] = e[0];
+        if (hasH) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ev[q][1 + i] = e[1 + i];
+        }
+        const double pErr = ev[q][0];
         double pImp, hImp;
         if (coarse) {
             hImp = 0.0;   // :806-810
@@ -517,7 +608,8 @@ __global__ __launch_bounds__(1024) void fr_apply_kernel(FrDev d) {
         } else {
             if (dep < kMaxDepth) {
                 double maxNewErr = 0.0;
-                for (int i = 0; i < 8; ++i) maxNewErr = maxNewErr < e[1 + i] ? e[1 + i] : maxNewErr;  // std::max
+#pragma unroll
+                for (int i = 0; i < 8; ++i) maxNewErr = maxNewErr < ev[q][1 + i] ? ev[q][1 + i] : maxNewErr;  // std::max
                 hImp = (1.0 / (7.0 * (double)frCoef(p))) * (err - 8.0 * maxNewErr);  // :825
             } else {
                 hImp = 0.0;
@@ -530,88 +622,205 @@ __global__ __launch_bounds__(1024) void fr_apply_kernel(FrDev d) {
         bool refineP = p < (kMaxDegree - 1) && (dep == kMaxDepth || pImp > hImp);  // :600
         if (coarse) refineP = true;
         const bool refineH = dep < kMaxDepth && !refineP;  // :601
-        sKind[j] = refineP ? 1 : (refineH ? 2 : 0);
+        const int kind = refineP ? 1 : (refineH ? 2 : 0);
+        kd[q] = kind;
+        d.kind[j] = (uint8_t)kind;
+        if (kind == 1) {
+            const int np = coarse ? 2 : p + 1;
+            ++nP;
+            maxDeg = (uint32_t)np > maxDeg ? (uint32_t)np : maxDeg;
+            // coefficients gained (the template's subtree counts already stand for "every cell at degree 2")
+            delta += (int)frCoef(np) - (int)(round0 ? frCoef(2) : frCoef(p));
+        } else if (kind == 2) {
+            delta += 7 * (int)frCoef(p);
+        } else {
+            ++nD;
+        }
+    }
+    if (nP) atomicAdd(&sCnt[0], nP);
+    if (nD) atomicAdd(&sCnt[2], nD);
+    if (maxDeg) atomicMax(&sCnt[3], maxDeg);
+    if (delta) atomicAdd(&sDelta, delta);
+    FR_STAMP(9);
+    // first child of every H job: node count so far + 8 x (H jobs before it).  The same scan (H count in the high half,
+    // P count in the low half of one word) places every job's additions to the running total in a dense list: a P result
+    // adds (newErr - initialErr) (:255); an H result subtracts initialErr once (:268) and adds its 8 children's errors (:272).
+    uint32_t c = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c += kd[q] == 2 ? 0x10000u : (kd[q] == 1 ? 1u : 0u);
+    uint32_t inc = c;
+    const int lane = (int)(tid & 63);
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += v;
+    }
+    if (lane == 63) sScan[tid >> 6] = inc;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+    for (uint32_t w = 0; w < 16; ++w) {
+        if (w < (tid >> 6)) before += sScan[w];
+        all += sScan[w];
+    }
+    FR_STAMP(10);
+    uint32_t run = before + inc - c;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t j = tid * 4u + (uint32_t)q;
+        if (j >= nJobs) continue;
+        const uint32_t hBefore = run >> 16, pBefore = run & 0xFFFFu;
+        d.base[j] = nNodes0 + 8u * hBefore;
+        double* o = d.ops + (pBefore + 9u * hBefore);
+        if (kd[q] == 1) {
+            o[0] = ev[q][0] - be[q];
+            run += 1u;
+        } else if (kd[q] == 2) {
+            o[0] = be[q] * -1.0;  // total -= err  ==  total + (-err)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[1 + i] = ev[q][1 + i];
+            run += 0x10000u;
+        }
+    }
+    if (tid == 0) {
+        const uint32_t nH = all >> 16;
+        h->rP = sCnt[0], h->rH = nH, h->rD = sCnt[2], h->rMaxDeg = sCnt[3];
+        h->rOps = (all & 0xFFFFu) + 9u * nH;
+        h->dbg[11] = __builtin_readcyclecounter();
+        h->rCoeffDelta = (int64_t)sDelta;
+        h->arrive = 0;
+        if (nNodes0 + 8u * nH > d.nodeCap) h->overflow = 1, h->done = 1;  // cannot happen: the host sizes for 8 K new nodes
+    }
+}
+
+__device__ __forceinline__ double frReadLane(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// Whoever arrives last closes the round: counters, stop rule (Octree.cpp:216), the threshold bin of the next selection,
+// and the header's mirror in pinned host memory (the host waits for the stream and reads it there: no copy to launch).
+__device__ void frCloseRound(const FrDev& d, uint32_t nJobs, bool round0, uint32_t* sHist, uint32_t* sTmp) {
+    FrHdr* h = d.hdr;
+    __shared__ int sLast, sT;
+    __shared__ uint32_t sAbove;
+    const uint32_t tid = threadIdx.x;
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) sLast = atomicAdd(&h->arrive, 1u) == gridDim.x - 1u ? 1 : 0;
+    __syncthreads();
+    if (!sLast) return;
+    __threadfence();
+    const uint32_t nP = *(volatile uint32_t*)&h->rP, nH = *(volatile uint32_t*)&h->rH, nD = *(volatile uint32_t*)&h->rD;
+    const uint32_t nQ = h->nQueued - (round0 ? 0u : nJobs) + nP + 8u * nH;  // (round 0's batch never sat in the queue)
+    const double total = *(volatile double*)&h->rTotal;
+    const bool done = total < h->target || nQ == 0;  // Octree.cpp:216
+    for (uint32_t i = tid; i < 2048; i += 256) {
+        sHist[i] = *(volatile uint32_t*)&h->hist1[i];
+        h->hist2[i] = 0;
     }
     __syncthreads();
-    // ---- first child of every H job: node count so far + 8 x (H jobs before it); thread t scans jobs 4t..4t+3
-    {
-        uint32_t c = 0;
-        for (uint32_t j = tid * 4; j < tid * 4 + 4 && j < nJobs; ++j) c += sKind[j] == 2 ? 1u : 0u;
-        sScan[tid] = c;
-        __syncthreads();
-        for (uint32_t off = 1; off < 1024; off <<= 1) {
-            const uint32_t v = tid >= off ? sScan[tid - off] : 0u;
-            __syncthreads();
-            sScan[tid] += v;
-            __syncthreads();
-        }
-        uint32_t run = sScan[tid] - c;
-        for (uint32_t j = tid * 4; j < tid * 4 + 4 && j < nJobs; ++j) {
-            sBase[j] = nNodes0 + 8u * run;
-            run += sKind[j] == 2 ? 1u : 0u;
-        }
-    }
-    __syncthreads();
-    const uint32_t nH = sScan[1023];
-    if (nNodes0 + 8u * nH > d.nodeCap) {  // the host sizes the node arrays for 8 K new nodes per round: cannot happen
-        if (tid == 0) h->overflow = 1, h->done = 1;
-        return;
-    }
-    const int wave = tid >> 6, lane = tid & 63;
-    if (wave == 0) {
-        // ---- the running total, in the reference's order: one lane, one addition after the other.  A P result adds
-        //      (newErr - initialErr) (:255); an H result subtracts initialErr once (:268) and adds its 8 children's errors
-        //      (:272).  The other lanes stage the operands of 64 jobs at a time, densely, in LDS.
-        double total = h->total;
-        for (uint32_t base = 0; base < nJobs; base += 64) {
-            const uint32_t j = base + lane;
-            const int kind = j < nJobs ? sKind[j] : 0;
-            const uint32_t nOps = kind == 1 ? 1u : (kind == 2 ? 9u : 0u);
-            uint32_t pos = nOps;  // inclusive scan over the lanes
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t v = __shfl_up(pos, off, 64);
-                if (lane >= off) pos += v;
-            }
-            const uint32_t totalOps = __shfl(pos, 63, 64);
-            pos -= nOps;
-            if (kind == 1) {
-                sOps[pos] = d.errs[(size_t)j * 9] - d.batchErr[j];
-            } else if (kind == 2) {
-                sOps[pos] = d.batchErr[j] * -1.0;  // total -= err  ==  total + (-err)
-                for (int i = 0; i < 8; ++i) sOps[pos + 1 + i] = d.errs[(size_t)j * 9 + 1 + i];
-            }
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0)
-                for (uint32_t q = 0; q < totalOps; ++q) total = total + sOps[q];
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (lane == 0) sTotal = total;
+    if (!done && nQ > d.K) {
+        frThreshold(sHist, d.K, sTmp, &sT, &sAbove);
     } else {
-        // ---- tree and queue updates: lane group of 8 = one job (its 8 children when it splits)
-        const int sub = lane & 7;
-        uint32_t nP = 0, nD = 0, maxDeg = 0;
-        for (uint32_t j = (uint32_t)(wave - 1) * 8 + (uint32_t)(lane >> 3); j < nJobs; j += 15 * 8) {
+        if (tid == 0) sT = -1, sAbove = nQ;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        h->nQueued = nQ;
+        h->nNodes += 8u * nH;
+        h->total = total;
+        h->jobs += nJobs, h->pRefines += nP, h->hRefines += nH, h->dropped += nD;
+        h->nLeaves += 7u * nH;
+        h->nCoeffs = (uint64_t)((int64_t)h->nCoeffs + *(volatile int64_t*)&h->rCoeffDelta);
+        const uint32_t md = *(volatile uint32_t*)&h->rMaxDeg;
+        if (md > h->maxDegree) h->maxDegree = md;
+        h->round += 1;
+        h->takenCount = 0, h->candCount = 0, h->arrive = 0;
+        h->t1 = sT, h->above = sAbove;
+        if (done && h->nCoeffs > d.storeCap) h->overflow = 2;  // the host grows the store and runs fr_store_kernel again
+        h->done = done ? 1u : 0u;
+        __threadfence();
+    }
+    __syncthreads();
+    // the mirror: every word but the round number, a system-scope fence, then the round number -- the host watches that word
+    constexpr uint32_t kRoundWord = offsetof(FrHdr, round) / 4;
+    if (tid < kFrHdrCopyBytes / 4 && tid != kRoundWord)
+        reinterpret_cast<volatile uint32_t*>(d.hostHdr)[tid] = reinterpret_cast<volatile uint32_t*>(h)[tid];
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+        reinterpret_cast<volatile uint32_t*>(d.hostHdr)[kRoundWord] = reinterpret_cast<volatile uint32_t*>(h)[kRoundWord];
+        __threadfence_system();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// update: Octree.cpp:243-299 in node-index order.  Workgroup 0 carries the running total (one dependent addition after
+// the other, the reference's order); the others update tree and queue, eight lanes per job.  The workgroup that finishes
+// last closes the round: counters, stop rule (:216), the next selection's threshold bin.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fr_update_kernel(FrDev d) {
+    FrHdr* h = d.hdr;
+    if (h->done) return;  // (set by an earlier round, or by decide on overflow: uniform over the grid)
+    __shared__ uint32_t sHist[2048];
+    __shared__ uint32_t sTmp[256];
+    __shared__ double sOps[2][2048];  // workgroup 0: the running total's operands, double-buffered
+    const uint32_t tid = threadIdx.x, nJobs = h->nJobs;
+    const bool round0 = h->round == 0;
+    if (blockIdx.x == 0) {
+        // The running total: one dependent addition after the other, in the dense order fr_decide_kernel laid out.  Wave 0
+        // adds; waves 1..3 bring the next 2048 operands into the other half of the LDS buffer meanwhile (a lone wave
+        // loading its own operands waits out an L2 round trip every 64 jobs: 129 us for round 0's 4096 additions).
+        const uint32_t nOps = h->rOps;
+        double total = h->total;
+        for (uint32_t k = tid; k < 2048 && k < nOps; k += 256) sOps[0][k] = d.ops[k];
+        __syncthreads();
+        for (uint32_t c0 = 0, half = 0; c0 < nOps; c0 += 2048, half ^= 1u) {
+            const uint32_t n = nOps - c0 < 2048u ? nOps - c0 : 2048u;
+            if (tid >= 64) {
+                const uint32_t nx = c0 + 2048;
+                for (uint32_t k = tid - 64; k < 2048 && nx + k < nOps; k += 192) sOps[half ^ 1u][k] = d.ops[nx + k];
+            } else {
+                const double* src = sOps[half];
+                uint32_t q = 0;
+                for (; q + 16 <= n; q += 16) {
+                    double o[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) o[k] = src[q + k];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) total = total + o[k];
+                }
+                for (; q < n; ++q) total = total + src[q];
+            }
+            __syncthreads();
+        }
+        if (tid == 0) h->rTotal = total;
+    } else {
+        for (uint32_t i = tid; i < 2048; i += 256) sHist[i] = 0;
+        __syncthreads();
+        const int sub = (int)(tid & 7);
+        const uint32_t j = (blockIdx.x - 1u) * 32u + (tid >> 3);
+        if (j < nJobs) {
             const uint32_t idx = d.batchIdx[j];
-            const int kind = sKind[j];
-            const int p = d.nodes[idx].degree, dep = d.nodes[idx].depth;
+            const int kind = d.kind[j];
+            const hpsdf_node par = d.nodes[idx];
+            const int p = par.degree, dep = par.depth;
             const bool coarse = fabs(d.batchErr[j] - HPSDF_INITIAL_NODE_ERR) < DBL_EPSILON;
+            int delta = 0;
             if (kind == 1) {  // :253-260, :286-290
                 if (sub == 0) {
                     const int np = coarse ? 2 : p + 1;
+                    const int first = coarse ? 2 : (int)d.segFirst[idx];
                     if (coarse) d.segFirst[idx] = 2;
-                    d.segOff[(size_t)idx * kFrSegs + (np - d.segFirst[idx])] = d.jobP[j];
+                    d.segOff[(size_t)idx * kFrSegs + (np - first)] = d.jobP[j];
                     d.nodes[idx].degree = (uint8_t)np;
                     const double pErr = d.errs[(size_t)j * 9];
                     const uint64_t bits = (uint64_t)__double_as_longlong(pErr);
                     d.qErr[idx] = bits;
                     atomicAdd(&sHist[frDigit(0, bits, idx)], 1u);
-                    ++nP;
-                    maxDeg = (uint32_t)np > maxDeg ? (uint32_t)np : maxDeg;
+                    delta = (int)frCoef(np) - (int)(round0 ? frCoef(2) : frCoef(p));
                 }
             } else if (kind == 2) {  // :262-279, :286-290; Octree::Subdivide :1115-1128
-                const uint32_t c0 = sBase[j], ch = c0 + (uint32_t)sub;
-                const hpsdf_node par = d.nodes[idx];
+                const uint32_t c0 = d.base[j], ch = c0 + (uint32_t)sub;
                 hpsdf_node c;
                 c.child_idx = ~0ull;
                 for (int a = 0; a < 3; ++a) {  // CornerAABB
@@ -631,73 +840,92 @@ __global__ __launch_bounds__(1024) void fr_apply_kernel(FrDev d) {
                 const uint64_t bits = (uint64_t)__double_as_longlong(hErr);
                 d.qErr[ch] = bits;
                 atomicAdd(&sHist[frDigit(0, bits, ch)], 1u);
-                __builtin_amdgcn_wave_barrier();
-                if (sub == 0) {  // after the parent has been read by all eight lanes
+                if (sub == 0) {
                     d.nodes[idx].child_idx = c0;
                     d.nodes[idx].degree = kInteriorDegree;
                     d.nodes[idx].coeffs_start = 0;
+                    d.sub[idx] = 8u * frCoef(p);
+                    delta = 7 * (int)frCoef(p);
                 }
-            } else if (sub == 0) {
-                ++nD;  // :643-655: keeps its basis, never queued again
+            }
+            if (delta != 0) {  // coefficient counts of the ancestors (the root's is the header's nCoeffs)
+                uint32_t a = d.parent[idx];
+                while (a != 0) {
+                    atomicAdd(&d.sub[a], (uint32_t)delta);
+                    a = d.parent[a];
+                }
             }
         }
-        if (nP) atomicAdd(&sCnt[0], nP);
-        if (nD) atomicAdd(&sCnt[2], nD);
-        if (maxDeg) atomicMax(&sCnt[3], maxDeg);
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < 2048; i += 1024) {
-        if (sHist[i]) h->hist1[i] += sHist[i];
-        h->hist2[i] = 0;
-    }
-    if (tid == 0) {
-        const uint32_t nP = sCnt[0], nD = sCnt[2];
-        const uint32_t nQ = h->nQueued - (h->round == 0 ? 0u : nJobs) + nP + 8u * nH;
-        // (round 0's batch was never counted in nQueued: the initialisation hands it over directly)
-        h->nQueued = nQ;
-        h->nNodes = nNodes0 + 8u * nH;
-        h->total = sTotal;
-        h->jobs += nJobs, h->pRefines += nP, h->hRefines += nH, h->dropped += nD;
-        h->nLeaves += 7u * nH;
-        if (sCnt[3] > h->maxDegree) h->maxDegree = sCnt[3];
-        h->round += 1;
-        h->takenCount = 0, h->candCount = 0, h->above = 0, h->t1 = -1;
-        h->done = (sTotal < h->target || nQ == 0) ? 1u : 0u;  // Octree.cpp:216
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// ReallocCoeffs (Octree.cpp:474-555) once the stop rule has fired
-// ---------------------------------------------------------------------------------------------------------------------
-// coefficients below every interior node, level by level from the deepest (one workgroup; children sit at depth + 1)
-__global__ __launch_bounds__(1024) void fr_totals_kernel(FrDev d) {
-    FrHdr* h = d.hdr;
-    if (!h->done || h->overflow) return;
-    const uint32_t n = h->nNodes;
-    for (int dep = kMaxDepth; dep >= 0; --dep) {
-        for (uint32_t i = threadIdx.x; i < n; i += 1024) {
-            const hpsdf_node& nd = d.nodes[i];
-            if (nd.depth != dep || nd.degree != kInteriorDegree) continue;
-            uint32_t s = 0;
-            for (unsigned c = 0; c < 8; ++c) {
-                const hpsdf_node& ch = d.nodes[nd.child_idx + c];
-                s += ch.degree == kInteriorDegree ? d.sub[nd.child_idx + c] : frCoef(ch.degree);
-            }
-            d.sub[i] = s;
-        }
-        __threadfence_block();
         __syncthreads();
+        for (uint32_t i = tid; i < 2048; i += 256)
+            if (sHist[i]) atomicAdd(&h->hist1[i], sHist[i]);
     }
-    if (threadIdx.x == 0) {
-        const uint64_t total = d.sub[0];
-        h->nCoeffs = total;
-        if (total > d.storeCap) h->overflow = 2;  // the host grows the store and runs the two kernels again
-    }
+    frCloseRound(d, nJobs, round0, sHist, sTmp);
 }
 
-// One wave per node.  A leaf's coeffsStart = coefficients of everything the depth-first walk (children 0..7 from the
-// root) visits before it = over its ancestors-or-self a: the subtree sizes of a's earlier siblings.  Its rows are then
-// gathered from the arena, segment by segment.
+// Round 0 for itself: every job is a coarse cell that takes its degree-2 fit (:806-810, :836-843), so there is nothing to
+// decide and no child to place -- workgroup 0 sums (newErr - 100) in job order straight from the fit's error slots, the
+// others (one lane per cell) set degree, first segment and queued error.
+__global__ __launch_bounds__(256) void fr_round0_kernel(FrDev d) {
+    FrHdr* h = d.hdr;
+    __shared__ uint32_t sHist[2048];
+    __shared__ uint32_t sTmp[256];
+    __shared__ double sOps[2][2048];
+    const uint32_t tid = threadIdx.x, nJobs = h->nJobs;
+    if (blockIdx.x == 0) {
+        double total = h->total;
+        for (uint32_t k = tid; k < 2048 && k < nJobs; k += 256) sOps[0][k] = d.errs[(size_t)k * 9] - d.batchErr[k];
+        __syncthreads();
+        for (uint32_t c0 = 0, half = 0; c0 < nJobs; c0 += 2048, half ^= 1u) {
+            const uint32_t n = nJobs - c0 < 2048u ? nJobs - c0 : 2048u;
+            if (tid >= 64) {
+                const uint32_t nx = c0 + 2048;
+                for (uint32_t k = tid - 64; k < 2048 && nx + k < nJobs; k += 192)
+                    sOps[half ^ 1u][k] = d.errs[(size_t)(nx + k) * 9] - d.batchErr[nx + k];
+            } else {
+                const double* src = sOps[half];
+                uint32_t q = 0;
+                for (; q + 16 <= n; q += 16) {
+                    double o[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) o[k] = src[q + k];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) total = total + o[k];
+                }
+                for (; q < n; ++q) total = total + src[q];
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            h->rTotal = total;
+            h->rP = nJobs, h->rH = 0, h->rD = 0, h->rMaxDeg = 2, h->rCoeffDelta = 0;
+        }
+    } else {
+        for (uint32_t i = tid; i < 2048; i += 256) sHist[i] = 0;
+        __syncthreads();
+        const uint32_t j = (blockIdx.x - 1u) * 256u + tid;
+        if (j < nJobs) {
+            const uint32_t idx = d.batchIdx[j];
+            d.segFirst[idx] = 2;
+            d.segOff[(size_t)idx * kFrSegs] = d.jobP[j];
+            d.nodes[idx].degree = 2;
+            const uint64_t bits = (uint64_t)__double_as_longlong(d.errs[(size_t)j * 9]);
+            d.qErr[idx] = bits;
+            atomicAdd(&sHist[frDigit(0, bits, idx)], 1u);
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < 2048; i += 256)
+            if (sHist[i]) atomicAdd(&h->hist1[i], sHist[i]);
+    }
+    frCloseRound(d, nJobs, true, sHist, sTmp);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ReallocCoeffs (Octree.cpp:474-555) once the stop rule has fired.  One wave per node.  A leaf's coeffsStart =
+// coefficients of everything the depth-first walk (children 0..7 from the root) visits before it = over its
+// ancestors-or-self a: the subtree sizes of a's earlier siblings.  Its rows are then gathered from the arena, segment by
+// segment.
+// ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void fr_store_kernel(FrDev d) {
     FrHdr* h = d.hdr;
     if (!h->done || h->overflow) return;
@@ -731,33 +959,45 @@ __global__ __launch_bounds__(256) void fr_store_kernel(FrDev d) {
     }
 }
 
-// per-build initialisation: the uniformly refined tree (a copy of the context's template), the header, round 0's batch
-__global__ __launch_bounds__(256) void fr_init_kernel(FrDev d, const hpsdf_node* tmplNodes, const uint32_t* tmplParent,
-                                                      const uint32_t* tmplLeaves, uint32_t nTmpl, uint32_t nLeaves) {
+// per-build initialisation: the uniformly refined tree (a copy of the context's template) and the header.  Round 0's
+// batch, tasks and workgroups are the template's, used in place.
+struct FrTemplate {
+    const hpsdf_node* nodes;
+    const uint32_t* parent;
+    const uint32_t* sub;
+    uint32_t nNodes, nLeaves, nTasks, nBlocks;
+    uint64_t arenaRows, samples;
+};
+__global__ __launch_bounds__(256) void fr_init_kernel(FrDev d, FrTemplate t, double target) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < nTmpl) {
-        d.nodes[i] = tmplNodes[i];
-        d.parent[i] = tmplParent[i];
+    if (i < t.nNodes) {
+        d.nodes[i] = t.nodes[i];
+        d.parent[i] = t.parent[i];
+        d.sub[i] = t.sub[i];
         d.qErr[i] = kNotQueued;
         d.segFirst[i] = 2;
     }
-    if (i < nLeaves) {
-        d.batchIdx[i] = tmplLeaves[i];
-        d.batchErr[i] = HPSDF_INITIAL_NODE_ERR;
-    }
+    if (blockIdx.x != 0) return;
     uint32_t* hw = reinterpret_cast<uint32_t*>(d.hdr);
-    for (uint32_t w = i; w < sizeof(FrHdr) / 4; w += gridDim.x * 256u) hw[w] = 0;
-}
-// (a kernel of its own: the stores below must come after every workgroup's zeroing above)
-__global__ void fr_init_hdr_kernel(FrDev d, uint32_t nTmpl, uint32_t nLeaves, double target) {
-    FrHdr* h = d.hdr;
-    h->nNodes = nTmpl;
-    h->nJobs = nLeaves;
-    h->nLeaves = nLeaves;
-    h->t1 = -1;
-    h->total = 4096.0 * HPSDF_INITIAL_NODE_ERR;  // pow(8, 4) * INITIAL_NODE_ERR, Octree.cpp:212
-    h->target = target;
-    h->maxDegree = 2;
+    for (uint32_t w = threadIdx.x; w < sizeof(FrHdr) / 4; w += 256u) hw[w] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        FrHdr* h = d.hdr;
+        h->nNodes = t.nNodes;
+        h->nJobs = t.nLeaves;
+        h->nLeaves = t.nLeaves;
+        h->t1 = -1;
+        h->total = 4096.0 * HPSDF_INITIAL_NODE_ERR;  // pow(8, 4) * INITIAL_NODE_ERR, Octree.cpp:212
+        h->target = target;
+        h->maxDegree = 2;
+        h->nTasks = t.nTasks, h->nBlocks = t.nBlocks;
+        h->degTasks[2][0] = 0, h->degTasks[2][1] = t.nTasks;
+        h->degBlocks[2][0] = 0, h->degBlocks[2][1] = t.nBlocks;
+        h->arenaUsed = t.arenaRows;
+        h->sampleUsed = t.samples;
+        h->fits = t.nTasks, h->samples = t.samples;
+        h->nCoeffs = (uint64_t)t.nLeaves * frCoef(2);  // what the tree holds once round 0 has raised every cell to degree 2
+    }
 }
 
 }  // namespace
@@ -774,13 +1014,28 @@ struct FrontierWorkspace {
     uint64_t arenaCap = 0, sampleCap = 0, storeCap = 0;
     double* arena = nullptr;
     double* samples = nullptr;
-    // template of the uniformly refined tree (Octree::UniformlyRefine, :112-191)
+    // Template of the uniformly refined tree (Octree::UniformlyRefine, :112-191) and of round 0, which is the same for
+    // every build: the 4096 depth-4 cells in index order, one from-scratch degree-2 fit each, cell j's rows at arena
+    // offset 10 j (index order is the depth-first order of ReallocCoeffs, so a build that stops after round 0 finds
+    // its packed coefficient store already sitting at the start of the arena).
+    FrTemplate tmpl{};
     hpsdf_node* tmplNodes = nullptr;
     uint32_t* tmplParent = nullptr;
+    uint32_t* tmplSub = nullptr;
     uint32_t* tmplLeaves = nullptr;
-    uint32_t nTmpl = 0, nTmplLeaves = 0;
-    char* pinned = nullptr;  // staging of the finished block
+    double* tmplErr = nullptr;
+    uint64_t* tmplJobP = nullptr;
+    FitTask* tmplTasks = nullptr;
+    FitBlock* tmplBlocks = nullptr;
+    size_t tmplLds = 0;
+    std::vector<hpsdf_node> hostNodesAfterRound0;  // the node array of a tree that stops after round 0, serialised
+    char* pinned = nullptr;                        // staging of the finished block
     size_t pinnedCap = 0;
+    // A round's fits are one launch per degree, and none of them fills the chip (a few hundred workgroups of two per CU):
+    // degrees beyond the first go to side streams and run beside it
+    static constexpr int kSide = 3;
+    hipStream_t side[kSide] = {nullptr, nullptr, nullptr};
+    hipEvent_t forkEv = nullptr, joinEv[kSide] = {nullptr, nullptr, nullptr};
 
     template <typename T>
     static hipError_t grow(T** p, size_t oldCount, size_t newCount, hipStream_t s, bool keep) {
@@ -804,7 +1059,7 @@ struct FrontierWorkspace {
         if (e == hipSuccess) e = grow(&d.parent, nodeCap, nc, s, true);
         if (e == hipSuccess) e = grow(&d.segOff, (size_t)nodeCap * kFrSegs, (size_t)nc * kFrSegs, s, true);
         if (e == hipSuccess) e = grow(&d.segFirst, nodeCap, nc, s, true);
-        if (e == hipSuccess) e = grow(&d.sub, nodeCap, nc, s, false);
+        if (e == hipSuccess) e = grow(&d.sub, nodeCap, nc, s, true);
         if (e == hipSuccess) e = grow(&d.candA, nodeCap, nc, s, false);
         if (e == hipSuccess) e = grow(&d.candB, nodeCap, nc, s, false);
         if (e == hipSuccess) nodeCap = nc, d.nodeCap = nc;
@@ -844,57 +1099,124 @@ struct FrontierWorkspace {
         if (e == hipSuccess) pinnedCap = nc;
         return e;
     }
+    template <typename T>
+    static hipError_t upload(T** dst, const std::vector<T>& v) {
+        hipError_t e = hipMalloc((void**)dst, std::max<size_t>(1, v.size()) * sizeof(T));
+        if (e == hipSuccess && !v.empty()) e = hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+        return e;
+    }
     hipError_t init(int dev, hipStream_t s) {
         device = dev;
         hipError_t e = hipMalloc((void**)&d.hdr, sizeof(FrHdr));
+        if (e == hipSuccess) e = hipMalloc((void**)&d.rnd, sizeof(FrRound));
         if (e == hipSuccess) e = hipHostMalloc((void**)&hostHdr, sizeof(FrHdr), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&d.hostHdr, hostHdr, 0);
         if (e == hipSuccess) e = hipMalloc((void**)&d.taken, (kFrJobs + 64) * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc((void**)&d.batchIdx, kFrJobs * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc((void**)&d.batchErr, kFrJobs * sizeof(double));
-        if (e == hipSuccess) e = hipMalloc((void**)&d.jobP, kFrJobs * sizeof(uint64_t));
-        if (e == hipSuccess) e = hipMalloc((void**)&d.jobH, kFrJobs * sizeof(uint64_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&d.wBatchIdx, kFrJobs * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&d.wBatchErr, kFrJobs * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void**)&d.wJobP, kFrJobs * sizeof(uint64_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&d.wJobH, kFrJobs * sizeof(uint64_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&d.kind, kFrJobs);
+        if (e == hipSuccess) e = hipMalloc((void**)&d.base, kFrJobs * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&d.ops, (size_t)kFrJobs * 9 * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void**)&d.tasks, kFrTasks * sizeof(FitTask));
         if (e == hipSuccess) e = hipMalloc((void**)&d.blocks, kFrTasks * sizeof(FitBlock));
         if (e == hipSuccess) e = hipMalloc((void**)&d.errs, (size_t)kFrJobs * HPSDF_JOB_HEADER_DOUBLES * sizeof(double));
         if (e != hipSuccess) return e;
+        d.batchIdx = d.wBatchIdx, d.batchErr = d.wBatchErr, d.jobP = d.wJobP, d.jobH = d.wJobH;
         // the uniformly refined tree, from the host scheduler's own initialisation (builderBegin): identical indices
         hpsdf_build b;
         hpsdf_config cfg;
         hpsdf_config_default(&cfg);
         cfg.thread_count = 1;
         if (builderBegin(&b, &cfg, nullptr) != HPSDF_OK) return hipErrorUnknown;
-        nTmpl = (uint32_t)b.nodes.size();
-        std::vector<uint32_t> parent(nTmpl, 0), leaves;
-        for (uint32_t i = 0; i < nTmpl; ++i) {
+        const uint32_t nT = (uint32_t)b.nodes.size();
+        std::vector<uint32_t> parent(nT, 0), leaves, sub(nT, 0);
+        for (uint32_t i = 0; i < nT; ++i) {
             if (b.nodes[i].child_idx != ~0ull)
                 for (unsigned c = 0; c < 8; ++c) parent[b.nodes[i].child_idx + c] = i;
             else
                 leaves.push_back(i);
         }
-        nTmplLeaves = (uint32_t)leaves.size();
-        if (nTmplLeaves > kFrJobs) return hipErrorUnknown;
-        e = hipMalloc((void**)&tmplNodes, nTmpl * sizeof(hpsdf_node));
-        if (e == hipSuccess) e = hipMalloc((void**)&tmplParent, nTmpl * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc((void**)&tmplLeaves, nTmplLeaves * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMemcpy(tmplNodes, b.nodes.data(), nTmpl * sizeof(hpsdf_node), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(tmplParent, parent.data(), nTmpl * sizeof(uint32_t), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(tmplLeaves, leaves.data(), nTmplLeaves * sizeof(uint32_t), hipMemcpyHostToDevice);
+        const uint32_t nL = (uint32_t)leaves.size();
+        if (nL > kFrJobs) return hipErrorUnknown;
+        for (uint32_t i = nT; i-- > 1;) {  // children have larger indices than their parents
+            const uint32_t own = b.nodes[i].child_idx == ~0ull ? frCoef(2) : sub[i];
+            sub[parent[i]] += own;
+        }
+        // round 0: class (degree 2, from scratch, depth 4), slot j = job j
+        int g = 1, pl = 1;
+        frShape(2, false, nL, &g, &pl);
+        std::vector<FitTask> tasks(nL);
+        std::vector<uint64_t> jobP(nL);
+        std::vector<double> errs(nL, HPSDF_INITIAL_NODE_ERR);
+        for (uint32_t j = 0; j < nL; ++j) {
+            const hpsdf_node& n = b.nodes[leaves[j]];
+            FitTask& t = tasks[j];
+            std::memset(&t, 0, sizeof t);
+            for (int a = 0; a < 3; ++a) t.bmin[a] = n.aabb_min[a], t.bmax[a] = n.aabb_max[a];
+            t.outOff = (uint64_t)j * frCoef(2);
+            t.copyOff = ~0ull;
+            t.sampleOff = (uint64_t)j * 729;
+            t.errSlot = j * HPSDF_JOB_HEADER_DOUBLES;
+            t.depth = n.depth;
+            t.pad[0] = 2;
+            jobP[j] = t.outOff;
+        }
+        std::vector<FitBlock> blocks((nL + g - 1) / g);
+        for (uint32_t k = 0; k < blocks.size(); ++k) {
+            FitBlock& fb = blocks[k];
+            std::memset(&fb, 0, sizeof fb);
+            fb.firstTask = k * (uint32_t)g;
+            fb.nTasks = (uint16_t)std::min<uint32_t>((uint32_t)g, nL - k * (uint32_t)g);
+            fb.degree = 2;
+            fb.planesPerChunk = (uint8_t)pl;
+            fb.rowStart = 0, fb.rowEnd = (uint16_t)frCoef(2);
+            fb.depth = b.nodes[leaves[0]].depth;
+        }
+        tmplLds = frLds(2, g, pl);
+        hostNodesAfterRound0 = b.nodes;
+        for (uint32_t j = 0; j < nL; ++j) {
+            hostNodesAfterRound0[leaves[j]].degree = 2;
+            hostNodesAfterRound0[leaves[j]].coeffs_start = (uint64_t)j * frCoef(2);
+        }
+        e = upload(&tmplNodes, b.nodes);
+        if (e == hipSuccess) e = upload(&tmplParent, parent);
+        if (e == hipSuccess) e = upload(&tmplSub, sub);
+        if (e == hipSuccess) e = upload(&tmplLeaves, leaves);
+        if (e == hipSuccess) e = upload(&tmplErr, errs);
+        if (e == hipSuccess) e = upload(&tmplJobP, jobP);
+        if (e == hipSuccess) e = upload(&tmplTasks, tasks);
+        if (e == hipSuccess) e = upload(&tmplBlocks, blocks);
+        tmpl.nodes = tmplNodes, tmpl.parent = tmplParent, tmpl.sub = tmplSub;
+        tmpl.nNodes = nT, tmpl.nLeaves = nL, tmpl.nTasks = nL, tmpl.nBlocks = (uint32_t)blocks.size();
+        tmpl.arenaRows = (uint64_t)nL * frCoef(2), tmpl.samples = (uint64_t)nL * 729;
+        for (int k = 0; k < kSide && e == hipSuccess; ++k) {
+            e = hipStreamCreateWithFlags(&side[k], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&joinEv[k], hipEventDisableTiming);
+        }
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&forkEv, hipEventDisableTiming);
         if (e == hipSuccess) e = ensureNodes(65536, s);
         if (e == hipSuccess) e = ensureArena(1ull << 22, 0, s);
         if (e == hipSuccess) e = ensureStore(1ull << 20, s);
         if (e == hipSuccess) e = ensurePinned(4u << 20);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fr_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFrBatchLdsBytes);
         return e;
     }
     ~FrontierWorkspace() {
         if (device >= 0) (void)hipSetDevice(device);
-        for (void* p : {(void*)d.hdr, (void*)d.nodes, (void*)d.qErr, (void*)d.parent, (void*)d.segOff, (void*)d.segFirst, (void*)d.sub,
-                        (void*)d.taken, (void*)d.candA, (void*)d.candB, (void*)d.batchIdx, (void*)d.batchErr, (void*)d.jobP, (void*)d.jobH,
-                        (void*)d.tasks, (void*)d.blocks, (void*)d.errs, (void*)d.store, (void*)arena, (void*)samples, (void*)tmplNodes,
-                        (void*)tmplParent, (void*)tmplLeaves})
+        for (void* p : {(void*)d.hdr, (void*)d.rnd, (void*)d.nodes, (void*)d.qErr, (void*)d.parent, (void*)d.segOff, (void*)d.segFirst,
+                        (void*)d.sub, (void*)d.taken, (void*)d.candA, (void*)d.candB, (void*)d.wBatchIdx, (void*)d.wBatchErr, (void*)d.wJobP,
+                        (void*)d.wJobH, (void*)d.kind, (void*)d.base, (void*)d.ops, (void*)d.tasks, (void*)d.blocks, (void*)d.errs, (void*)d.store,
+                        (void*)arena, (void*)samples, (void*)tmplNodes, (void*)tmplParent, (void*)tmplSub, (void*)tmplLeaves, (void*)tmplErr,
+                        (void*)tmplJobP, (void*)tmplTasks, (void*)tmplBlocks})
             if (p) (void)hipFree(p);
         if (hostHdr) (void)hipHostFree(hostHdr);
         if (pinned) (void)hipHostFree(pinned);
+        for (int k = 0; k < kSide; ++k) {
+            if (side[k]) (void)hipStreamDestroy(side[k]);
+            if (joinEv[k]) (void)hipEventDestroy(joinEv[k]);
+        }
+        if (forkEv) (void)hipEventDestroy(forkEv);
     }
 };
 
@@ -932,7 +1254,6 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
     std::memset(cfg.pad2, 0, sizeof cfg.pad2);
     HPSDF_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    std::shared_ptr<FrontierWorkspace> wsKeep;
     if (!ctx->frontierScratch) {
         auto w = std::make_shared<FrontierWorkspace>();
         const hipError_t e = w->init(ctx->device, s);
@@ -959,22 +1280,20 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         rm.centre[a] = (double)((cfg.root_min[a] + cfg.root_max[a]) / 2.0f);  // Octree.cpp:322
     }
     // launch-time LDS of a fit launch of `deg`: the largest shape the device may pick
-    auto fitLds = [](int deg) {
-        size_t m = 0;
-        for (int incr = 0; incr < 2; ++incr) {
-            if (incr && deg == 0) continue;
-            for (uint32_t count : {1u, 512u, 1024u, 2048u, 4096u, 8192u, 16384u, 40000u}) {
+    static const auto fitLdsTable = [] {
+        std::vector<size_t> t(kMaxDegree + 1, 0);
+        for (int deg = 1; deg <= kMaxDegree; ++deg)
+            for (int incr = 0; incr < 2; ++incr) {
                 int g, pl;
-                frShape(deg, incr != 0, count, &g, &pl);
+                frShape(deg, incr != 0, 1u << 20, &g, &pl);  // g = the class's largest
                 for (int gg = 1; gg <= g; ++gg) {
                     int pp = 4 * deg + 1;
                     while (pp > 1 && frLds(deg, gg, pp) > kFitChunkLdsBytes) --pp;
-                    m = std::max(m, frLds(deg, gg, pp));
+                    t[deg] = std::max(t[deg], frLds(deg, gg, pp));
                 }
             }
-        }
-        return m;
-    };
+        return t;
+    }();
     auto rowsPerJob = [](int pmax) {  // arena rows one job can need when no leaf exceeds degree pmax
         const int p = std::min(pmax, kMaxDegree - 1);
         return (uint64_t)8 * frCoef(p) + frCoef(std::min(p + 1, kMaxDegree));
@@ -985,60 +1304,141 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
     };
 
     FrDev& d = ws->d;
-    hipLaunchKernelGGL(fr_init_kernel, dim3((ws->nTmpl + 255) / 256), dim3(256), 0, s, d, ws->tmplNodes, ws->tmplParent, ws->tmplLeaves,
-                       ws->nTmpl, ws->nTmplLeaves);
-    hipLaunchKernelGGL(fr_init_hdr_kernel, dim3(1), dim3(1), 0, s, d, ws->nTmpl, ws->nTmplLeaves, cfg.target_error_threshold);
-    uint32_t knownNodes = ws->nTmpl, knownMaxDeg = 2;
-    uint64_t knownArena = 0;
-    double tSync = 0;
-    int rounds = 0;
+    const FrTemplate& T = ws->tmpl;
     const FrHdr* hh = ws->hostHdr;
-    for (;; ++rounds) {
-        const uint32_t jobsBound = rounds == 0 ? ws->nTmplLeaves : Kj;
+    double tSync = 0;
+    uint8_t* early = nullptr;  // the block of a build that stops after round 0, begun before the device has finished
+    struct FreeEarly {
+        uint8_t** p;
+        ~FreeEarly() { std::free(*p); }
+    } freeEarly{&early};
+    // ---- round 0: every cell of the uniformly refined tree, straight from the template
+    {
+        hipError_t e = ws->ensureArena(T.arenaRows, 0, s);
+        if (e == hipSuccess && mesh) e = ws->ensureSamples(T.samples, s);
+        if (e != hipSuccess) return hipFail(e, "frontier buffers");
+        hipLaunchKernelGGL(fr_init_kernel, dim3((T.nNodes + 255) / 256), dim3(256), 0, s, d, T, cfg.target_error_threshold);
+        FieldDev fdr = fd;
+        if (mesh) {
+            HPSDF_HIP(launchMeshSample(s, ws->tmplTasks, T.nTasks, 2, ctx->dTables, fd, rm, ws->samples));
+            fdr.kind = kFieldSamples;
+            fdr.samples = ws->samples;
+        }
+        HPSDF_HIP(launchFit(s, 2, 1, ws->tmplBlocks, T.nBlocks, ws->tmplLds, ws->tmplTasks, ws->arena, d.errs, nullptr, ctx->dTables, fdr, rm));
+        FrDev d0 = d;
+        d0.batchIdx = ws->tmplLeaves, d0.batchErr = ws->tmplErr, d0.jobP = ws->tmplJobP, d0.jobH = ws->tmplJobP;
+        hipLaunchKernelGGL(fr_round0_kernel, dim3(1 + (T.nLeaves + 255) / 256), dim3(256), 0, s, d0);
+        // a build that stops here has its packed store at the start of the arena: fetch it right behind the round
+        HPSDF_HIP(hipMemcpyAsync(ws->pinned, ws->arena, T.arenaRows * sizeof(double), hipMemcpyDeviceToHost, s));
+        // ... and everything else of its block is known in advance: write that part while the device works
+        const uint64_t nc0 = T.arenaRows, nn0 = T.nNodes;
+        early = (uint8_t*)std::malloc(8 + 8 * (size_t)nc0 + 8 + sizeof(hpsdf_node) * (size_t)nn0 + sizeof(hpsdf_config));
+        if (early) {
+            std::memcpy(early, &nc0, 8);
+            std::memcpy(early + 8 + 8 * (size_t)nc0, &nn0, 8);
+            std::memcpy(early + 16 + 8 * (size_t)nc0, ws->hostNodesAfterRound0.data(), sizeof(hpsdf_node) * (size_t)nn0);
+            std::memcpy(early + 16 + 8 * (size_t)nc0 + sizeof(hpsdf_node) * (size_t)nn0, &cfg, sizeof cfg);
+        }
+        const double ts = now();
+        HPSDF_HIP(hipStreamSynchronize(s));
+        tSync += now() - ts;
+    }
+    int rounds = 1;
+    const bool stoppedAfterRound0 = hh->done && hh->overflow != 1;
+    if (stoppedAfterRound0 && early && hh->nCoeffs == T.arenaRows && hh->nNodes == T.nNodes) {
+        std::memcpy(early + 8, ws->pinned, 8 * (size_t)T.arenaRows);
+        *block = early;
+        *size = 8 + 8 * (size_t)T.arenaRows + 8 + sizeof(hpsdf_node) * (size_t)T.nNodes + sizeof(hpsdf_config);
+        early = nullptr;
+        if (stats) {
+            std::memset(stats, 0, sizeof *stats);
+            stats->rounds = hh->round, stats->jobs = hh->jobs, stats->p_refines = hh->pRefines, stats->h_refines = hh->hRefines;
+            stats->dropped = hh->dropped, stats->fits = hh->fits, stats->samples = hh->samples;
+            stats->n_nodes = hh->nNodes, stats->n_leaves = hh->nLeaves, stats->n_coeffs = hh->nCoeffs, stats->total_error = hh->total;
+        }
+        if (trace) std::fprintf(stderr, "[frontierCreate] us: total %.0f (waiting for the device %.0f, stopped after round 0)\n", now() - t0, tSync);
+        return HPSDF_OK;
+    }
+    std::free(early);
+    early = nullptr;
+    uint32_t knownNodes = hh->nNodes, knownMaxDeg = hh->maxDegree;
+    uint64_t knownArena = hh->arenaUsed;
+    while (!hh->done) {
         // capacities for this round (the device flags what the host failed to foresee; it cannot happen by these bounds)
-        hipError_t e = ws->ensureNodes(knownNodes + 8u * jobsBound, s);
-        if (e == hipSuccess) e = ws->ensureArena(knownArena + (uint64_t)jobsBound * rowsPerJob((int)knownMaxDeg), knownArena, s);
+        hipError_t e = ws->ensureNodes(knownNodes + 8u * Kj, s);
+        if (e == hipSuccess) e = ws->ensureArena(knownArena + (uint64_t)Kj * rowsPerJob((int)knownMaxDeg), knownArena, s);
         if (e == hipSuccess && mesh) {
-            const uint64_t need = (uint64_t)jobsBound * (rounds == 0 ? 729ull : samplesPerJob((int)knownMaxDeg));
+            const uint64_t need = (uint64_t)Kj * samplesPerJob((int)knownMaxDeg);
             if (need > (1ull << 31)) return fail(HPSDF_ERR_UNSUPPORTED, "round too large for the sampled mesh path");
             e = ws->ensureSamples(need, s);
         }
         if (e != hipSuccess) return hipFail(e, "frontier buffers");
-        if (rounds > 0) hipLaunchKernelGGL(fr_select_kernel, dim3(std::min<uint32_t>(1024u, (knownNodes + 8u * Kj + 255u) / 256u)), dim3(256), 0, s, d);
-        hipLaunchKernelGGL(fr_batch_kernel, dim3(1), dim3(1024), kFrBatchLdsBytes, s, d, rounds == 0 ? 1 : 0);
-        const int degLo = 2, degHi = rounds == 0 ? 2 : (int)std::min<uint32_t>(kMaxDegree, knownMaxDeg + 1);
-        const uint32_t taskBound = rounds == 0 ? ws->nTmplLeaves : 9u * Kj;
+        hipLaunchKernelGGL(fr_select_kernel, dim3(std::min<uint32_t>(512u, (knownNodes + 255u) / 256u)), dim3(256), 0, s, d);
+        hipLaunchKernelGGL(fr_batch_kernel, dim3(1), dim3(1024), 0, s, d);
+        hipLaunchKernelGGL(fr_tasks_kernel, dim3((16u * Kj + 255u) / 256u), dim3(256), 0, s, d);
+        const int degHi = (int)std::min<uint32_t>(kMaxDegree - 1, knownMaxDeg + 1);
+        const uint32_t taskBound = 9u * Kj;
         FieldDev fdr = fd;
         if (mesh) {
-            for (int deg = degLo; deg <= degHi; ++deg)
+            for (int deg = 2; deg <= degHi; ++deg)
                 HPSDF_HIP(launchMeshSampleRange(s, d.tasks, &d.hdr->degTasks[deg][0], std::min<uint32_t>(taskBound, 65535u), deg, ctx->dTables, fd,
                                                 rm, ws->samples));
             fdr.kind = kFieldSamples;
             fdr.samples = ws->samples;
         }
-        for (int deg = degLo; deg <= degHi; ++deg)
-            HPSDF_HIP(launchFit(s, deg <= 5 ? deg : 0, 1, d.blocks, taskBound, fitLds(deg), d.tasks, ws->arena, d.errs, nullptr, ctx->dTables, fdr,
-                                rm, &d.hdr->degBlocks[deg][0]));
-        hipLaunchKernelGGL(fr_apply_kernel, dim3(1), dim3(1024), 0, s, d);
-        hipLaunchKernelGGL(fr_totals_kernel, dim3(1), dim3(1024), 0, s, d);
-        hipLaunchKernelGGL(fr_store_kernel, dim3(std::min<uint32_t>(2048u, (knownNodes + 8u * jobsBound + 3u) / 4u)), dim3(256), 0, s, d);
-        HPSDF_HIP(hipMemcpyAsync(ws->hostHdr, d.hdr, offsetof(FrHdr, hist1), hipMemcpyDeviceToHost, s));
+        const bool fork = degHi > 2 && std::getenv("HPSDF_FRONTIER_ONE_STREAM") == nullptr;
+        if (fork) HPSDF_HIP(hipEventRecord(ws->forkEv, s));
+        bool used[FrontierWorkspace::kSide] = {false, false, false};
+        for (int deg = 2; deg <= degHi; ++deg) {
+            hipStream_t fs = s;
+            if (fork && deg > 2) {
+                const int k = (deg - 3) % FrontierWorkspace::kSide;
+                fs = ws->side[k];
+                if (!used[k]) HPSDF_HIP(hipStreamWaitEvent(fs, ws->forkEv, 0));
+                used[k] = true;
+            }
+            HPSDF_HIP(launchFit(fs, deg <= 5 ? deg : 0, 1, d.blocks, taskBound, fitLdsTable[deg], d.tasks, ws->arena, d.errs, nullptr, ctx->dTables,
+                                fdr, rm, &d.hdr->degBlocks[deg][0]));
+        }
+        for (int k = 0; k < FrontierWorkspace::kSide; ++k)
+            if (used[k]) {
+                HPSDF_HIP(hipEventRecord(ws->joinEv[k], ws->side[k]));
+                HPSDF_HIP(hipStreamWaitEvent(s, ws->joinEv[k], 0));
+            }
+        hipLaunchKernelGGL(fr_decide_kernel, dim3(1), dim3(1024), 0, s, d);
+        hipLaunchKernelGGL(fr_update_kernel, dim3(1 + (Kj + 31) / 32), dim3(256), 0, s, d);
+        hipLaunchKernelGGL(fr_store_kernel, dim3(std::min<uint32_t>(2048u, (knownNodes + 8u * Kj + 3u) / 4u)), dim3(256), 0, s, d);
+        // The round is over for the host when the header's mirror shows the next round number: the update kernel's last
+        // workgroup writes it into pinned memory behind a system-scope fence.  Watching that word costs ~3 us; waking up
+        // from hipStreamSynchronize ~20 (everything launched next is ordered behind this round on the stream anyway;
+        // the download of a finished build synchronises the stream itself).
         const double ts = now();
-        HPSDF_HIP(hipStreamSynchronize(s));
+        {
+            const volatile uint32_t* roundWord = &hh->round;
+            const uint32_t want = (uint32_t)rounds + 1u;
+            const double limit = ts + 2.0e6;  // two seconds of watching, then the ordinary wait
+            while (*roundWord != want && now() < limit) __builtin_ia32_pause();
+            if (*roundWord != want) HPSDF_HIP(hipStreamSynchronize(s));
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
         tSync += now() - ts;
-        if (hh->overflow == 1) return fail(HPSDF_ERR_STATE, "frontier: node capacity exceeded");
+        ++rounds;
         knownNodes = hh->nNodes, knownMaxDeg = hh->maxDegree, knownArena = hh->arenaUsed;
-        if (hh->done) break;
+        if (trace) {
+            std::fprintf(stderr, "[frontier round %d] batch phases (cycles):", rounds - 1);
+            for (int k = 1; k <= 7; ++k) std::fprintf(stderr, " %lld", (long long)(hh->dbg[k] - hh->dbg[k - 1]));
+            std::fprintf(stderr, " | decide:");
+            for (int k = 9; k <= 11; ++k) std::fprintf(stderr, " %lld", (long long)(hh->dbg[k] - hh->dbg[k - 1]));
+            std::fprintf(stderr, "\n");
+        }
     }
+    if (hh->overflow == 1) return fail(HPSDF_ERR_STATE, "frontier: node capacity exceeded");
     if (hh->overflow == 2) {  // the packed store was too small: grow, run ReallocCoeffs again
         hipError_t e = ws->ensureStore(hh->nCoeffs, s);
         if (e != hipSuccess) return hipFail(e, "coefficient store");
         HPSDF_HIP(hipMemsetAsync(&d.hdr->overflow, 0, sizeof(uint32_t), s));
-        hipLaunchKernelGGL(fr_totals_kernel, dim3(1), dim3(1024), 0, s, d);
         hipLaunchKernelGGL(fr_store_kernel, dim3(std::min<uint32_t>(2048u, (knownNodes + 3u) / 4u)), dim3(256), 0, s, d);
-        HPSDF_HIP(hipMemcpyAsync(ws->hostHdr, d.hdr, offsetof(FrHdr, hist1), hipMemcpyDeviceToHost, s));
         HPSDF_HIP(hipStreamSynchronize(s));
-        if (hh->overflow) return fail(HPSDF_ERR_STATE, "frontier: coefficient store overflow");
     }
     // Octree::ToMemoryBlock, Octree.cpp:424-456: [u64 nCoeffs][f64 x nCoeffs][u64 nNodes][Node x nNodes][Config]
     const uint64_t nc = hh->nCoeffs, nn = hh->nNodes;
@@ -1046,19 +1446,29 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
     uint8_t* p = (uint8_t*)std::malloc(bytes);
     if (!p) return fail(HPSDF_ERR_OUT_OF_MEMORY, "malloc of the memory block failed");
     const double tc = now();
-    hipError_t e = ws->ensurePinned(bytes);
-    if (e == hipSuccess && nc) e = hipMemcpyAsync(ws->pinned, d.store, 8 * (size_t)nc, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(ws->pinned + 8 * (size_t)nc, d.nodes, sizeof(hpsdf_node) * (size_t)nn, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) {
-        std::free(p);
-        return hipFail(e, "block download");
+    const hpsdf_node* nodesSrc;
+    if (stoppedAfterRound0) {
+        if (nc != T.arenaRows || nn != T.nNodes) {
+            std::free(p);
+            return fail(HPSDF_ERR_STATE, "frontier: round-0 tree does not match its template");
+        }
+        nodesSrc = ws->hostNodesAfterRound0.data();  // (its coefficients came with the header)
+    } else {
+        hipError_t e = ws->ensurePinned(8 * (size_t)nc + sizeof(hpsdf_node) * (size_t)nn);
+        if (e == hipSuccess && nc) e = hipMemcpyAsync(ws->pinned, d.store, 8 * (size_t)nc, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(ws->pinned + 8 * (size_t)nc, d.nodes, sizeof(hpsdf_node) * (size_t)nn, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) {
+            std::free(p);
+            return hipFail(e, "block download");
+        }
+        nodesSrc = reinterpret_cast<const hpsdf_node*>(ws->pinned + 8 * (size_t)nc);
     }
     const double tcopy = now() - tc;
     std::memcpy(p, &nc, 8);
     std::memcpy(p + 8, ws->pinned, 8 * (size_t)nc);
     std::memcpy(p + 8 + 8 * (size_t)nc, &nn, 8);
-    std::memcpy(p + 16 + 8 * (size_t)nc, ws->pinned + 8 * (size_t)nc, sizeof(hpsdf_node) * (size_t)nn);
+    std::memcpy(p + 16 + 8 * (size_t)nc, nodesSrc, sizeof(hpsdf_node) * (size_t)nn);
     std::memcpy(p + 16 + 8 * (size_t)nc + sizeof(hpsdf_node) * (size_t)nn, &cfg, sizeof cfg);
     *block = p;
     *size = bytes;
@@ -1070,7 +1480,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
     }
     if (trace)
         std::fprintf(stderr, "[frontierCreate] us: total %.0f (waiting for the device %.0f over %d rounds, block download %.0f)\n", now() - t0, tSync,
-                     rounds + 1, tcopy);
+                     rounds, tcopy);
     return HPSDF_OK;
 }
 

@@ -24,7 +24,7 @@ for which, label in ((11, "union3 @ 1e-5, 12th Create"), (23, "union3 @ 1e-7, 12
     prev_end = t0
     for r in rows[a:b]:
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-        name = r["Kernel_Name"].split("(")[0].replace("hpsdf::", "").replace("(anonymous namespace)::", "")[:60]
+        name = r["Kernel_Name"].replace("hpsdf::", "").replace("(anonymous namespace)::", "").split("(")[0][:60]
         print("  +%8.1f us  gap %6.1f  dur %7.1f us  grid %-8s %s" % ((s - t0) / 1e3, (s - prev_end) / 1e3, (e - s) / 1e3, r.get("Grid_Size", "?"), name))
         prev_end = e
     print("  span %.1f us" % ((prev_end - t0) / 1e3))
