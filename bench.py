@@ -43,14 +43,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=N_POINTS, help="query points per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fit-bench", action="store_true", help="also run the steady-state fit micro-benchmark")
+    ap.add_argument("--no-fit-bench", action="store_true", help="skip the steady-state fit micro-benchmark (fit_microbench)")
     ap.add_argument("--no-refined", action="store_true",
                     help="skip the extra Query / QueryWithGradient timings on the refined tree (union3 @ 1e-7)")
-    ap.add_argument("--mesh-level", type=int, default=7,
-                    help="also time Create() on a mesh field (BASELINE configs 3-5 shape): bumpy icosphere of this "
-                         "subdivision level (7 = 327 680 triangles); 0 = skip")
-    ap.add_argument("--sorted-ceiling", action="store_true",
-                    help="also time Query on the same points sorted by depth-4 cell (locality ceiling, SURVEY 8d)")
+    ap.add_argument("--mesh", default="torus",
+                    help="Create() on a mesh field (BASELINE configs 2-4 shape; dragon.obj / Ramesses.obj are not in the reference "
+                         "mount): 'torus' = displaced torus grid, 2 097 152 triangles (the north_star's 2 M-triangle mesh); "
+                         "an integer L = bumpy icosphere of subdivision level L (7 = 327 680, 8 = 1 310 720); 'none' = skip")
+    ap.add_argument("--no-sorted-ceiling", action="store_true",
+                    help="skip Query on the same points sorted by depth-4 cell (locality ceiling, SURVEY 8d)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -151,7 +152,7 @@ def main():
 
         # locality ceiling: the same points sorted by depth-4 cell, so neighbouring lanes share tree lines
         sorted_ms = None
-        if rank == 0 and args.sorted_ceiling:
+        if rank == 0 and not args.no_sorted_ceiling:
             cell = ((d_xyz + 0.5) * 16.0).floor().clamp_(0, 15).to(torch.int64)
             order = torch.argsort(cell[:, 0] * 256 + cell[:, 1] * 16 + cell[:, 2])
             d_sorted = d_xyz[order].contiguous()
@@ -213,35 +214,55 @@ def main():
             del d_grad, d_out2
 
         mesh = None
-        if args.mesh_level > 0 and rank == 0:
-            # BASELINE configs 3-5 in shape: a closed triangle mesh as the field, root = mesh box, targetError 1e-5.
-            # dragon.obj / Ramesses.obj are not in the reference mount: a procedural bumpy icosphere stands in.
+        if args.mesh != "none":
+            # BASELINE configs 2-4 in shape: a closed triangle mesh as the field, root = mesh box, targetError 1e-5 and
+            # 1e-6; with N > 1 ranks the frontier is sharded (one all-gather per round, hpsdf_create_distributed).
             sys.path.insert(0, os.path.join(ROOT, "tests"))
-            from helpers import icosphere
-            verts, tris = icosphere(args.mesh_level, 0.4)
-            dirs = verts / np.linalg.norm(verts, axis=1, keepdims=True)
-            verts = (verts * (1.0 + 0.08 * np.sin(9 * dirs[:, 0]) * np.cos(7 * dirs[:, 1])
-                              + 0.05 * np.sin(11 * dirs[:, 2]))[:, None]).astype(np.float32)
+            from helpers import icosphere, displaced_torus
+            if args.mesh == "torus":
+                verts, tris = displaced_torus()
+                mname = "displaced torus grid 1024 x 1024"
+            else:
+                verts, tris = icosphere(int(args.mesh), 0.4)
+                dirs = verts / np.linalg.norm(verts, axis=1, keepdims=True)
+                verts = (verts * (1.0 + 0.08 * np.sin(9 * dirs[:, 0]) * np.cos(7 * dirs[:, 1])
+                                  + 0.05 * np.sin(11 * dirs[:, 2]))[:, None]).astype(np.float32)
+                mname = "bumpy icosphere, level %s" % args.mesh
             lo, hi = verts.min(0) - 0.02, verts.max(0) + 0.02
             t0 = time.perf_counter()
             mfield = H.Field.mesh(ctx, verts, tris)
             prep_ms = (time.perf_counter() - t0) * 1e3
-            mcfg = H.make_config(TARGET, tuple(lo), tuple(hi))
-            H.create_block(ctx, mcfg, mfield, JOBS_PER_ROUND)
-            mt = []
-            for _ in range(3):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                mblk, mst = H.create_block(ctx, mcfg, mfield, JOBS_PER_ROUND)
-                torch.cuda.synchronize()
-                mt.append((time.perf_counter() - t0) * 1e3)
-            mesh = {"mesh": "bumpy icosphere, level %d" % args.mesh_level, "triangles": int(len(tris)),
-                    "prepare_ms": prep_ms, "create_ms": float(np.median(mt)), "nodes": mst["n_nodes"],
-                    "samples": mst["samples"], "msamples_per_s": mst["samples"] / float(np.median(mt)) / 1e3}
+            mesh = {"mesh": mname, "triangles": int(len(tris)), "prepare_ms": prep_ms, "n_gpus": world}
+            for tgt, key in ((1e-5, "1e-5"), (1e-6, "1e-6")):
+                mcfg = H.make_config(tgt, tuple(lo), tuple(hi))
+
+                def mcreate():
+                    if world > 1:
+                        return D.create_distributed(ctx, mcfg, mfield, JOBS_PER_ROUND, policy="shard")
+                    return H.create_block(ctx, mcfg, mfield, JOBS_PER_ROUND)
+                mcreate()
+                mt = []
+                for _ in range(3):
+                    if world > 1:
+                        dist.barrier()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    mblk, mst = mcreate()
+                    torch.cuda.synchronize()
+                    mt.append((time.perf_counter() - t0) * 1e3)
+                ms = float(np.median(mt))
+                if world > 1:
+                    t = torch.tensor([ms], device="cuda")
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    ms = float(t.item())
+                mesh["create_ms_" + key] = ms
+                mesh["tree_" + key] = {"nodes": mst["n_nodes"], "rounds": mst["rounds"], "samples": mst["samples"],
+                                       "msamples_per_s": mst["samples"] / ms / 1e3}
+            mesh["create_ms"] = mesh["create_ms_1e-5"]  # the north_star's "2 M-tri mesh at targetError 1e-5"
             del mfield
 
         fit = None
-        if args.fit_bench and rank == 0:
+        if not args.no_fit_bench and rank == 0:
             fit = {}
             plane = H.Field.analytic([(H.PRIM_PLANE, H.OP_UNION, [0.3, -0.2, 0.5, 0.1])])  # F costs ~nothing: contraction only
             for p in (2, 3, 4, 5, 6, 7, 8):  # p in {2..8}; degrees > 5 run the any-degree kernel
@@ -267,11 +288,25 @@ def main():
     want = otree.query(pts[:: max(1, n // 2000)])
     assert np.array_equal(got, want), "timed Query output differs from the oracle"
 
-    traffic = None
+    # roofline.traffic: HBM bytes per query_kernel launch from the PMC passes of tools/profile.sh (separate rocprofv3 --pmc
+    # runs of this very command; FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes).  Counters cannot be
+    # read from inside this process, so the figure is the one committed with the profile -- stamped with what it was taken
+    # from, and dropped (null) when the kernel source has changed since.
+    traffic, traffic_from = None, None
     pmc = os.path.join(ROOT, "profiles", "query_pmc.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            rec = json.load(open(pmc))
+            import hashlib
+            src = os.path.join(ROOT, "hp-adaptive-signed-distance-field-octree_amd", "csrc", "kernels.hip")
+            text = open(src).read()
+            a_ = text.index("template <int TOPD, bool DEDUPE>")
+            b_ = text.index("// 16-byte chunks a leaf of degree d occupies")
+            qsha = hashlib.sha256(text[a_:b_].encode()).hexdigest()[:16]
+            traffic_from = {"profile": rec.get("profile"), "query_kernel_sha16": rec.get("query_kernel_sha16"),
+                            "current_query_kernel_sha16": qsha}
+            if rec.get("query_kernel_sha16") in (None, qsha):
+                traffic = rec.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
 
@@ -289,7 +324,8 @@ def main():
                    "rounds": stats["rounds"], "jobs": stats["jobs"], "fits": stats["fits"], "samples": stats["samples"],
                    "block_bytes": len(block), "ms_all": create_times},
         "roofline": {"kernel": "query_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": 32 * n,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_measured_from": traffic_from,
+                     "algorithmic_bytes_per_launch": 32 * n,
                      "avg_launch_ms": kernel_ms,
                      # what actually limits the kernel: every random point pulls one 128-byte
                      # top-table line out of L2 besides its 24 + 8 streamed bytes; MI355X_MICROARCH.md measures 66-73
@@ -322,6 +358,24 @@ def main():
             t0 = time.perf_counter()
             O.Tree.create(O.default_config(TARGET), O.union3_field(), JOBS_PER_ROUND)
             tcs.append(time.perf_counter() - t0)
+        # the same Query on every host core (Octree::Query is const: the reference's own parallel use), ~5 s
+        from concurrent.futures import ThreadPoolExecutor
+        ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        chunks = np.array_split(np.arange(m), ncores * 4)
+
+        def qchunk(ix):
+            return otree.query(pts[ix[0]:ix[-1] + 1]) if len(ix) else None
+        with ThreadPoolExecutor(ncores) as pool:
+            list(pool.map(qchunk, chunks))  # warm the pool
+            tall, apasses = 0.0, 0
+            while tall < 4.0:
+                t0 = time.perf_counter()
+                list(pool.map(qchunk, chunks))
+                tall += time.perf_counter() - t0
+                apasses += 1
+        out["cpu_baseline_all_cores"] = {"value": apasses * m / tall / 1e6, "unit": "Mpts/s", "cores": ncores, "kind": "port",
+                                         "sample": "oracle Query() over the same %d points split over %d threads, %d whole passes (%.1f s)"
+                                                   % (m, ncores, apasses, tall)}
         out["cpu_baseline"] = {"value": passes * m / tq / 1e6, "unit": "Mpts/s", "cores": 1, "kind": "port",
                                "sample": "oracle Query() over the same %d points, %d whole passes (%.1f s); "
                                          "oracle Create() of the same config, median of 3" % (m, passes, tq),

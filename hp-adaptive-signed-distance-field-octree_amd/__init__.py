@@ -157,6 +157,8 @@ _SIGNATURES = {
     "hpsdf_continuity_last_stats": (C.c_int, [C.POINTER(ContinuityStats)]),
     "hpsdf_create": (C.c_int, [C.c_void_p, C.POINTER(PodConfig), C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p),
                                C.POINTER(C.c_size_t), C.POINTER(BuildStats)]),
+    "hpsdf_create_distributed": (C.c_int, [C.c_void_p, C.POINTER(PodConfig), C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p,
+                                           C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(BuildStats)]),
     "hpsdf_bench_fit": (C.c_int, [C.c_void_p, C.POINTER(PodConfig), C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int,
                                   C.POINTER(C.c_double)]),
 }
@@ -546,6 +548,36 @@ def create_block(ctx, config, field, K=0):
     check(lib().hpsdf_create(ctx.handle if ctx is not None else None, C.byref(pod), field.handle, K, C.byref(blk),
                              C.byref(sz), C.byref(st)))
     data = C.string_at(blk, sz.value)
+    lib()._libc.free(blk)
+    return data, st.as_dict()
+
+
+ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+def create_block_distributed(ctx, config, field, K, rank, world, gather):
+    """hpsdf_create_distributed: this rank's part of a Create sharded over `world` GPUs, frontier on the device.
+    gather(d_buf_ptr, bytes_per_rank, stream_ptr) -> None performs the in-place all-gather (rank r's part at
+    d_buf_ptr + r * bytes_per_rank); exceptions it raises fail the build.  Returns (block bytes, stats)."""
+    pod = config.to_pod() if hasattr(config, "to_pod") else config
+    failure = []
+
+    def _cb(_user, d_buf, nbytes, stream):
+        try:
+            gather(d_buf, nbytes, stream)
+            return 0
+        except BaseException as e:  # noqa: BLE001 -- must not propagate through the C frames
+            failure.append(e)
+            return 1
+
+    cb = ALLGATHER(_cb)
+    blk, size, st = C.c_void_p(), C.c_size_t(), BuildStats()
+    rc = lib().hpsdf_create_distributed(ctx.handle, C.byref(pod), field.handle, K, rank, world, C.cast(cb, C.c_void_p), None,
+                                        C.byref(blk), C.byref(size), C.byref(st))
+    if failure:
+        raise failure[0]
+    check(rc)
+    data = C.string_at(blk, size.value)
     lib()._libc.free(blk)
     return data, st.as_dict()
 

@@ -1071,6 +1071,32 @@ int hpsdf_create(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* fie
     HPSDF_CATCH
 }
 
+int hpsdf_create_distributed(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* field, uint64_t K, int rank, int world,
+                             hpsdf_allgather_fn gather, void* user, void** block, size_t* size, hpsdf_build_stats* stats) {
+    HPSDF_TRY
+    if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "Create runs on the GPU: a device context is required");
+    if (!cfg || !field || !block || !size) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    if (world == 1) return hpsdf_create(ctx, cfg, field, K, block, size, stats);
+    if (!frontierEligible(cfg, field, K))
+        return fail(HPSDF_ERR_UNSUPPORTED,
+                    "this build runs the host scheduler (host callback, nearness weighting, logging or K > 4096): shard it through the "
+                    "hpsdf_build_* round calls");
+    int rc = frontierCreate(ctx, cfg, field, K, block, size, stats, rank, world, gather, user);
+    std::memset(&g_lastContinuity, 0, sizeof g_lastContinuity);
+    if (!rc && cfg->continuity_enforce) {  // Octree.cpp:341-344: every rank on its identical copy (deterministic: no exchange)
+        std::string err;
+        rc = continuityPostProcess(*block, *size, 0.0, 0, 0, &g_lastContinuity, err, ctx);
+        if (rc) {
+            setError(err);
+            std::free(*block);
+            *block = nullptr;
+            *size = 0;
+        }
+    }
+    return rc;
+    HPSDF_CATCH
+}
+
 // ---------------------------------------------------------------------------- continuity (host)
 int hpsdf_continuity_post_process(void* block, size_t size, double tol, int maxIter, uint64_t threads,
                                   hpsdf_continuity_stats* stats) {

@@ -56,6 +56,7 @@ constexpr int kFrSegs = 10;         // degrees 2..11: the first fit and at most 
 constexpr int kFrDepths = kMaxDepth + 2;
 constexpr int kFrClasses = 2 * (kMaxDegree + 1) * kFrDepths;  // (degree, from scratch | incremental, depth)
 constexpr uint64_t kNotQueued = ~0ull;
+constexpr uint64_t kOffMask = (1ull << 56) - 1;  // a segment's arena offset; the bits above hold the rank that owns it
 constexpr uint32_t kFrSort = 4096;  // bitonic sort capacity (LDS): the fallback ordering of a batch
 constexpr uint32_t kFrExact = 64;   // candidates left when the digit-by-digit refinement hands over to exact ranking
 
@@ -74,6 +75,9 @@ struct FrHdr {
     // staging between the decide and update kernels of a round
     uint32_t rP, rH, rD, rMaxDeg;
     uint32_t rOps, rPad;
+    uint32_t sliceFirst[9];  // multi-rank: rank r computes jobs [sliceFirst[r], sliceFirst[r + 1]) of the round
+    uint32_t padS;
+    uint64_t packCount[8];   // multi-rank: coefficients rank r contributes to the packed store
     uint64_t dbg[24];  // phase time stamps (s_memtime) of the one-workgroup kernels, read under HPSDF_TRACE
     int64_t rCoeffDelta;
     double rTotal;
@@ -120,6 +124,13 @@ struct FrDev {
     const double* arena;
     uint64_t storeCap;
     uint32_t nodeCap, K;
+    // multi-rank builds (world > 1): this rank fits a cost-balanced slice of every round's jobs
+    int32_t rank, world;
+    uint32_t errStride;    // doubles per rank in errs: rank r's slice sits at errs + r * errStride (all-gathered in place)
+    uint8_t* jobOwner;     // per job: the rank that fits it
+    uint32_t* packPos;     // [node][kFrSegs]: where the segment sits in its owner's pack buffer
+    double* pack;          // [world][packStride] all-gathered pack buffers (this rank writes its own)
+    uint64_t packStride;
 };
 
 __host__ __device__ inline uint32_t frCoef(int p) { return p == 6 ? 83u : (uint32_t)((p + 1) * (p + 2) * (p + 3) / 6); }
@@ -141,6 +152,22 @@ __host__ __device__ inline void frShape(int degree, bool incr, uint32_t count, i
     while (pl > 1 && frLds(degree, g, pl) > kFitChunkLdsBytes) --pl;
     *cells = g;
     *planes = pl;
+}
+
+// where job j's 9 errors sit: in the slice of the rank that fitted it
+__device__ __forceinline__ size_t frErrSlot(const FrDev& d, const FrHdr* h, uint32_t j) {
+    if (d.world == 1) return (size_t)j * 9;
+    const uint32_t o = d.jobOwner[j];
+    return (size_t)o * d.errStride + (size_t)(j - h->sliceFirst[o]) * 9;
+}
+// flop-proportional cost of one job (builder.cpp jobCost): balances the ranks' slices
+__device__ __forceinline__ uint64_t frJobCost(int degree, int depth, bool coarse) {
+    auto cube = [](uint64_t n) { return n * n * n; };
+    if (coarse) return frCoef(2) * cube(9);
+    uint64_t c = 0;
+    if (depth < kMaxDepth) c += 8ull * frCoef(degree) * cube(4 * (uint64_t)degree + 1);
+    if (degree < kMaxDegree - 1) c += (uint64_t)(frCoef(degree + 1) - frCoef(degree)) * cube(4 * (uint64_t)degree + 5);
+    return c ? c : 1;
 }
 
 // digit `level` of the selection key (error bits, then ~index): larger key = earlier in the frontier's order
@@ -392,22 +419,105 @@ __global__ __launch_bounds__(1024) void fr_batch_kernel(FrDev d) {
     for (uint32_t i = tid; i < 2048; i += 1024) sHist[i] = 0;
     for (uint32_t c = tid; c < (uint32_t)kFrClasses; c += 1024) sCount[c] = 0;
     __syncthreads();
-    // ---- the jobs leave the frontier; every job becomes 1 (coarse) or up to 9 cell fits: count them per shape class
-    for (uint32_t j = tid; j < nJobs; j += 1024) {
-        const uint32_t idx = sVal[j];
-        const uint64_t bits = d.qErr[idx];
-        const double e = __longlong_as_double((long long)bits);
-        d.wBatchIdx[j] = idx;
-        d.wBatchErr[j] = e;
-        d.qErr[idx] = kNotQueued;
-        atomicAdd(&sHist[frDigit(0, bits, idx)], 1u);
-        const hpsdf_node& n = d.nodes[idx];
-        const int p = n.degree, dep = n.depth;
-        if (fabs(e - HPSDF_INITIAL_NODE_ERR) < DBL_EPSILON) {  // coarse, Octree.cpp:806,831
-            atomicAdd(&sCount[frClass(2, false, dep)], 1u);  // :836-843
-        } else {
-            if (dep < kMaxDepth) atomicAdd(&sCount[frClass(p, false, dep + 1)], 8u);     // :814-822
-            if (p < kMaxDegree - 1) atomicAdd(&sCount[frClass(p + 1, true, dep)], 1u);  // :846-851
+    // ---- the jobs leave the frontier; every job becomes 1 (coarse) or up to 9 cell fits: count them per shape class.
+    //      Thread t owns jobs 4 t .. 4 t + 3.  With several ranks every rank counts only the fits of its own slice: the
+    //      slices are contiguous job ranges of (nearly) equal cost, cut where the host scheduler cuts them (builderSelect).
+    uint64_t* sCost = sKey;  // (the bitmap is dead) inclusive prefix of the jobs' costs
+    {
+        uint32_t jIdx[4];
+        int jP[4], jDep[4];
+        bool jCoarse[4];
+        uint64_t own = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t j = tid * 4u + (uint32_t)q;
+            jIdx[q] = 0xFFFFFFFFu, jP[q] = 0, jDep[q] = 0, jCoarse[q] = false;
+            if (j >= nJobs) continue;
+            const uint32_t idx = sVal[j];
+            const uint64_t bits = d.qErr[idx];
+            const double e = __longlong_as_double((long long)bits);
+            d.wBatchIdx[j] = idx;
+            d.wBatchErr[j] = e;
+            d.qErr[idx] = kNotQueued;
+            atomicAdd(&sHist[frDigit(0, bits, idx)], 1u);
+            const hpsdf_node& n = d.nodes[idx];
+            jIdx[q] = idx, jP[q] = n.degree, jDep[q] = n.depth;
+            jCoarse[q] = fabs(e - HPSDF_INITIAL_NODE_ERR) < DBL_EPSILON;  // coarse, Octree.cpp:806,831
+            own += frJobCost(jP[q], jDep[q], jCoarse[q]);
+        }
+        if (d.world > 1) {
+            // inclusive scan of the costs (wave shuffles, then the 16 wave totals), slice ends by binary search
+            uint64_t inc = own;
+            const int lane = (int)(tid & 63);
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint64_t v = (uint64_t)__shfl_up((long long)inc, off, 64);
+                if (lane >= off) inc += v;
+            }
+            uint64_t* sWave = reinterpret_cast<uint64_t*>(sTmp);  // 16 totals (sTmp has 1024 words)
+            if (lane == 63) sWave[tid >> 6] = inc;
+            __syncthreads();
+            uint64_t before = 0, total = 0;
+            for (uint32_t w = 0; w < 16; ++w) {
+                if (w < (tid >> 6)) before += sWave[w];
+                total += sWave[w];
+            }
+            uint64_t run = before + inc - own;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t j = tid * 4u + (uint32_t)q;
+                if (j >= nJobs) continue;
+                run += frJobCost(jP[q], jDep[q], jCoarse[q]);
+                sCost[j] = run;  // cost of jobs 0..j
+            }
+            __syncthreads();
+            if (tid < (uint32_t)d.world - 1u) {  // end of rank tid's slice: the first i with cost(jobs < i) >= total (tid + 1) / world
+                const uint64_t target = total * (uint64_t)(tid + 1) / (uint64_t)d.world;
+                uint32_t lo = 0, hi = nJobs;  // answer in [0, nJobs]; cost(jobs < i) = i ? sCost[i - 1] : 0
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if ((mid ? sCost[mid - 1] : 0ull) >= target)
+                        hi = mid;
+                    else
+                        lo = mid + 1;
+                }
+                sTmp[64 + tid] = lo;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t start = 0;
+                h->sliceFirst[0] = 0;
+                for (int r = 0; r < d.world; ++r) {
+                    uint32_t end = nJobs;
+                    if (r + 1 < d.world) {
+                        end = sTmp[64 + r];
+                        end = end < start ? start : end;
+                        end = end > nJobs ? nJobs : end;
+                    }
+                    h->sliceFirst[r + 1] = end;
+                    sTmp[32 + r + 1] = end;
+                    start = end;
+                }
+                sTmp[32] = 0;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t j = tid * 4u + (uint32_t)q;
+            if (j >= nJobs) continue;
+            if (d.world > 1) {
+                uint32_t o = 0;
+                for (int r = 1; r < d.world; ++r) o += sTmp[32 + r] <= j ? 1u : 0u;
+                d.jobOwner[j] = (uint8_t)o;
+                if ((int)o != d.rank) continue;  // another rank's job: none of its fits here
+            }
+            const int p = jP[q], dep = jDep[q];
+            if (jCoarse[q]) {
+                atomicAdd(&sCount[frClass(2, false, dep)], 1u);  // :836-843
+            } else {
+                if (dep < kMaxDepth) atomicAdd(&sCount[frClass(p, false, dep + 1)], 8u);     // :814-822
+                if (p < kMaxDegree - 1) atomicAdd(&sCount[frClass(p + 1, true, dep)], 1u);  // :846-851
+            }
         }
     }
     __syncthreads();
@@ -496,7 +606,8 @@ __global__ __launch_bounds__(256) void fr_tasks_kernel(FrDev d) {
         const hpsdf_node& n = d.nodes[d.batchIdx[live ? j : 0]];
         const int p = n.degree, dep = n.depth;
         const bool coarse = fabs(d.batchErr[live ? j : 0] - HPSDF_INITIAL_NODE_ERR) < DBL_EPSILON;
-        const bool hasH = live && !coarse && dep < kMaxDepth, hasP = live && (coarse || p < kMaxDegree - 1);
+        const bool ours = live && (d.world == 1 || (int)d.jobOwner[j] == d.rank);
+        const bool hasH = ours && !coarse && dep < kMaxDepth, hasP = ours && (coarse || p < kMaxDegree - 1);
         // this lane's fit, if any
         const bool mine = (k < 8 && hasH) || (k == 8 && hasP);
         const int deg = k < 8 ? p : (coarse ? 2 : p + 1);
@@ -524,7 +635,7 @@ __global__ __launch_bounds__(256) void fr_tasks_kernel(FrDev d) {
             t.outOff = outOff;
             t.copyOff = ~0ull;
             t.sampleOff = R->cSample[c] + (uint64_t)slot * nq * nq * nq;
-            t.errSlot = j * HPSDF_JOB_HEADER_DOUBLES + (k < 8 ? 1u + (uint32_t)k : 0u);
+            t.errSlot = (uint32_t)frErrSlot(d, h, j) + (k < 8 ? 1u + (uint32_t)k : 0u);
             t.depth = (uint8_t)depth;
             t.pad[0] = (uint8_t)deg, t.pad[1] = t.pad[2] = 0;
             d.tasks[R->cFirst[c] + slot] = t;
@@ -592,7 +703,7 @@ __global__ __launch_bounds__(1024) void fr_decide_kernel(FrDev d) {
         const double err = d.batchErr[j];
         be[q] = err;
         const int p = d.nodes[idx].degree, dep = d.nodes[idx].depth;
-        const double* e = d.errs + (size_t)j * HPSDF_JOB_HEADER_DOUBLES;
+        const double* e = d.errs + frErrSlot(d, h, j);
         const bool coarse = fabs(err - HPSDF_INITIAL_NODE_ERR) < DBL_EPSILON;
         const bool hasH = !coarse && dep < kMaxDepth, hasP = coarse || p < kMaxDegree - 1;
         if (hasP) ev[q][0] = e[0];
@@ -811,9 +922,9 @@ __global__ __launch_bounds__(256) void fr_update_kernel(FrDev d) {
                     const int np = coarse ? 2 : p + 1;
                     const int first = coarse ? 2 : (int)d.segFirst[idx];
                     if (coarse) d.segFirst[idx] = 2;
-                    d.segOff[(size_t)idx * kFrSegs + (np - first)] = d.jobP[j];
+                    d.segOff[(size_t)idx * kFrSegs + (np - first)] = (d.jobP[j] & kOffMask) | ((uint64_t)(d.world == 1 ? 0 : d.jobOwner[j]) << 56);
                     d.nodes[idx].degree = (uint8_t)np;
-                    const double pErr = d.errs[(size_t)j * 9];
+                    const double pErr = d.errs[frErrSlot(d, h, j)];
                     const uint64_t bits = (uint64_t)__double_as_longlong(pErr);
                     d.qErr[idx] = bits;
                     atomicAdd(&sHist[frDigit(0, bits, idx)], 1u);
@@ -835,8 +946,8 @@ __global__ __launch_bounds__(256) void fr_update_kernel(FrDev d) {
                 d.nodes[ch] = c;
                 d.parent[ch] = idx;
                 d.segFirst[ch] = (uint8_t)p;
-                d.segOff[(size_t)ch * kFrSegs] = d.jobH[j] + (uint64_t)sub * frCoef(p);
-                const double hErr = d.errs[(size_t)j * 9 + 1 + sub];
+                d.segOff[(size_t)ch * kFrSegs] = ((d.jobH[j] + (uint64_t)sub * frCoef(p)) & kOffMask) | ((uint64_t)(d.world == 1 ? 0 : d.jobOwner[j]) << 56);
+                const double hErr = d.errs[frErrSlot(d, h, j) + 1 + sub];
                 const uint64_t bits = (uint64_t)__double_as_longlong(hErr);
                 d.qErr[ch] = bits;
                 atomicAdd(&sHist[frDigit(0, bits, ch)], 1u);
@@ -874,14 +985,14 @@ __global__ __launch_bounds__(256) void fr_round0_kernel(FrDev d) {
     const uint32_t tid = threadIdx.x, nJobs = h->nJobs;
     if (blockIdx.x == 0) {
         double total = h->total;
-        for (uint32_t k = tid; k < 2048 && k < nJobs; k += 256) sOps[0][k] = d.errs[(size_t)k * 9] - d.batchErr[k];
+        for (uint32_t k = tid; k < 2048 && k < nJobs; k += 256) sOps[0][k] = d.errs[frErrSlot(d, h, k)] - d.batchErr[k];
         __syncthreads();
         for (uint32_t c0 = 0, half = 0; c0 < nJobs; c0 += 2048, half ^= 1u) {
             const uint32_t n = nJobs - c0 < 2048u ? nJobs - c0 : 2048u;
             if (tid >= 64) {
                 const uint32_t nx = c0 + 2048;
                 for (uint32_t k = tid - 64; k < 2048 && nx + k < nJobs; k += 192)
-                    sOps[half ^ 1u][k] = d.errs[(size_t)(nx + k) * 9] - d.batchErr[nx + k];
+                    sOps[half ^ 1u][k] = d.errs[frErrSlot(d, h, nx + k)] - d.batchErr[nx + k];
             } else {
                 const double* src = sOps[half];
                 uint32_t q = 0;
@@ -907,9 +1018,9 @@ __global__ __launch_bounds__(256) void fr_round0_kernel(FrDev d) {
         if (j < nJobs) {
             const uint32_t idx = d.batchIdx[j];
             d.segFirst[idx] = 2;
-            d.segOff[(size_t)idx * kFrSegs] = d.jobP[j];
+            d.segOff[(size_t)idx * kFrSegs] = (d.jobP[j] & kOffMask) | ((uint64_t)(d.world == 1 ? 0 : d.jobOwner[j]) << 56);
             d.nodes[idx].degree = 2;
-            const uint64_t bits = (uint64_t)__double_as_longlong(d.errs[(size_t)j * 9]);
+            const uint64_t bits = (uint64_t)__double_as_longlong(d.errs[frErrSlot(d, h, j)]);
             d.qErr[idx] = bits;
             atomicAdd(&sHist[frDigit(0, bits, idx)], 1u);
         }
@@ -953,8 +1064,94 @@ __global__ __launch_bounds__(256) void fr_store_kernel(FrDev d) {
         const int first = d.segFirst[i];
         for (int s = 0; s <= (int)nd.degree - first; ++s) {
             const uint32_t r0 = s == 0 ? 0u : frCoef(first + s - 1), r1 = frCoef(first + s);
-            const double* src = d.arena + d.segOff[(size_t)i * kFrSegs + s];
+            const uint64_t so = d.segOff[(size_t)i * kFrSegs + s];
+            // one rank: straight from the arena; several: from the all-gathered pack buffers (fr_pack_kernel)
+            const double* src = d.world == 1 ? d.arena + (so & kOffMask)
+                                             : d.pack + (size_t)(so >> 56) * d.packStride + d.packPos[(size_t)i * kFrSegs + s];
             for (uint32_t r = r0 + (uint32_t)lane; r < r1; r += 64) d.store[(size_t)start + r] = src[r - r0];
+        }
+    }
+}
+
+// Several ranks: every rank holds the rows it fitted.  The packed store is reassembled from one all-gather of per-rank
+// pack buffers: a rank's segments in (node index, segment) order.  fr_packpos_kernel (one workgroup) numbers them --
+// thread t owns a contiguous run of nodes, per-rank running sums are scanned across the threads -- and leaves the
+// per-rank totals in the header; fr_pack_kernel copies this rank's own segments into its buffer.
+__global__ __launch_bounds__(1024) void fr_packpos_kernel(FrDev d) {
+    FrHdr* h = d.hdr;
+    if (!h->done || h->overflow) return;
+    __shared__ uint32_t sWave[16][8];
+    const uint32_t n = h->nNodes, tid = threadIdx.x;
+    const uint32_t per = (n + 1023u) / 1024u, lo = tid * per, hi = lo + per < n ? lo + per : n;
+    uint32_t own[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t i = lo; i < hi; ++i) {
+        const hpsdf_node& nd = d.nodes[i];
+        if (nd.degree == kInteriorDegree) continue;
+        const int first = d.segFirst[i];
+        for (int sg = 0; sg <= (int)nd.degree - first; ++sg) {
+            const uint32_t rows = frCoef(first + sg) - (sg == 0 ? 0u : frCoef(first + sg - 1));
+            own[(d.segOff[(size_t)i * kFrSegs + sg] >> 56) & 7u] += rows;
+        }
+    }
+    uint32_t inc[8];
+    const int lane = (int)(tid & 63);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        inc[r] = own[r];
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(inc[r], off, 64);
+            if (lane >= off) inc[r] += v;
+        }
+        if (lane == 63) sWave[tid >> 6][r] = inc[r];
+    }
+    __syncthreads();
+    uint32_t run[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        uint32_t before = 0, all = 0;
+        for (uint32_t w = 0; w < 16; ++w) {
+            if (w < (tid >> 6)) before += sWave[w][r];
+            all += sWave[w][r];
+        }
+        run[r] = before + inc[r] - own[r];
+        if (tid == 0) h->packCount[r] = all;
+    }
+    for (uint32_t i = lo; i < hi; ++i) {
+        const hpsdf_node& nd = d.nodes[i];
+        if (nd.degree == kInteriorDegree) continue;
+        const int first = d.segFirst[i];
+        for (int sg = 0; sg <= (int)nd.degree - first; ++sg) {
+            const uint32_t rows = frCoef(first + sg) - (sg == 0 ? 0u : frCoef(first + sg - 1));
+            const int o = (int)((d.segOff[(size_t)i * kFrSegs + sg] >> 56) & 7u);
+            uint32_t pos = 0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (r == o) pos = run[r], run[r] += rows;
+            d.packPos[(size_t)i * kFrSegs + sg] = pos;
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid < kFrHdrCopyBytes / 4) reinterpret_cast<volatile uint32_t*>(d.hostHdr)[tid] = reinterpret_cast<volatile uint32_t*>(h)[tid];
+    __threadfence_system();
+}
+__global__ __launch_bounds__(256) void fr_pack_kernel(FrDev d) {
+    FrHdr* h = d.hdr;
+    if (!h->done || h->overflow) return;
+    const uint32_t n = h->nNodes;
+    const int lane = threadIdx.x & 63;
+    double* mine = d.pack + (size_t)d.rank * d.packStride;
+    for (uint32_t i = (blockIdx.x * 256u + threadIdx.x) >> 6; i < n; i += gridDim.x * 4u) {
+        const hpsdf_node nd = d.nodes[i];
+        if (nd.degree == kInteriorDegree) continue;
+        const int first = d.segFirst[i];
+        for (int sg = 0; sg <= (int)nd.degree - first; ++sg) {
+            const uint64_t so = d.segOff[(size_t)i * kFrSegs + sg];
+            if ((int)(so >> 56) != d.rank) continue;
+            const uint32_t rows = frCoef(first + sg) - (sg == 0 ? 0u : frCoef(first + sg - 1));
+            const double* src = d.arena + (so & kOffMask);
+            double* dst = mine + d.packPos[(size_t)i * kFrSegs + sg];
+            for (uint32_t r = (uint32_t)lane; r < rows; r += 64) dst[r] = src[r];
         }
     }
 }
@@ -965,8 +1162,9 @@ struct FrTemplate {
     const hpsdf_node* nodes;
     const uint32_t* parent;
     const uint32_t* sub;
-    uint32_t nNodes, nLeaves, nTasks, nBlocks;
+    uint32_t nNodes, nLeaves, nTasks, nBlocks;  // nTasks / nBlocks / arenaRows / samples: this rank's share of round 0
     uint64_t arenaRows, samples;
+    uint32_t sliceFirst[9];
 };
 __global__ __launch_bounds__(256) void fr_init_kernel(FrDev d, FrTemplate t, double target) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -997,7 +1195,14 @@ __global__ __launch_bounds__(256) void fr_init_kernel(FrDev d, FrTemplate t, dou
         h->sampleUsed = t.samples;
         h->fits = t.nTasks, h->samples = t.samples;
         h->nCoeffs = (uint64_t)t.nLeaves * frCoef(2);  // what the tree holds once round 0 has raised every cell to degree 2
+        for (int r = 0; r < 9; ++r) h->sliceFirst[r] = t.sliceFirst[r];
     }
+    if (d.world > 1)  // round 0's owners: the slices are equal runs of cells
+        for (uint32_t j = threadIdx.x; j < t.nLeaves; j += 256u) {
+            uint32_t o = 0;
+            for (int r = 1; r < d.world; ++r) o += t.sliceFirst[r] <= j ? 1u : 0u;
+            d.jobOwner[j] = (uint8_t)o;
+        }
 }
 
 }  // namespace
@@ -1062,6 +1267,10 @@ struct FrontierWorkspace {
         if (e == hipSuccess) e = grow(&d.sub, nodeCap, nc, s, true);
         if (e == hipSuccess) e = grow(&d.candA, nodeCap, nc, s, false);
         if (e == hipSuccess) e = grow(&d.candB, nodeCap, nc, s, false);
+        if (e == hipSuccess && d.packPos) {
+            e = grow(&d.packPos, 0, (size_t)nc * kFrSegs, s, false);
+            if (e == hipSuccess) packPosCap = nc;
+        }
         if (e == hipSuccess) nodeCap = nc, d.nodeCap = nc;
         return e;
     }
@@ -1087,6 +1296,40 @@ struct FrontierWorkspace {
         while (nc < need) nc *= 2;
         hipError_t e = grow(&d.store, 0, nc, s, false);
         if (e == hipSuccess) storeCap = nc, d.storeCap = nc;
+        return e;
+    }
+    // multi-rank: errs is [world][4096 * 9], plus owners, pack positions, round-0 share
+    int ranksCap = 1;
+    uint64_t packCap = 0;
+    FitTask* r0Tasks = nullptr;
+    FitBlock* r0Blocks = nullptr;
+    uint64_t* r0JobP = nullptr;
+    std::vector<FitTask> hostTmplTasks, hostR0Tasks;
+    hipError_t ensureRanks(int world, hipStream_t s) {
+        hipError_t e = hipSuccess;
+        if (world > ranksCap) {
+            e = grow(&d.errs, 0, (size_t)world * kFrJobs * HPSDF_JOB_HEADER_DOUBLES, s, false);
+            if (e == hipSuccess) ranksCap = world;
+        }
+        if (e == hipSuccess && world > 1 && !d.jobOwner) {
+            e = hipMalloc((void**)&d.jobOwner, kFrJobs);
+            if (e == hipSuccess) e = hipMalloc((void**)&r0Tasks, kFrJobs * sizeof(FitTask));
+            if (e == hipSuccess) e = hipMalloc((void**)&r0Blocks, kFrJobs * sizeof(FitBlock));
+            if (e == hipSuccess) e = hipMalloc((void**)&r0JobP, kFrJobs * sizeof(uint64_t));
+        }
+        if (e == hipSuccess && world > 1 && packPosCap < nodeCap) {
+            e = grow(&d.packPos, 0, (size_t)nodeCap * kFrSegs, s, false);
+            if (e == hipSuccess) packPosCap = nodeCap;
+        }
+        return e;
+    }
+    uint32_t packPosCap = 0;
+    hipError_t ensurePack(uint64_t need, hipStream_t s) {
+        if (need <= packCap) return hipSuccess;
+        uint64_t nc = packCap ? packCap : (1ull << 20);
+        while (nc < need) nc *= 2;
+        hipError_t e = grow(&d.pack, 0, nc, s, false);
+        if (e == hipSuccess) packCap = nc;
         return e;
     }
     hipError_t ensurePinned(size_t need) {
@@ -1175,6 +1418,7 @@ struct FrontierWorkspace {
             fb.depth = b.nodes[leaves[0]].depth;
         }
         tmplLds = frLds(2, g, pl);
+        hostTmplTasks = tasks;
         hostNodesAfterRound0 = b.nodes;
         for (uint32_t j = 0; j < nL; ++j) {
             hostNodesAfterRound0[leaves[j]].degree = 2;
@@ -1208,7 +1452,8 @@ struct FrontierWorkspace {
                         (void*)d.sub, (void*)d.taken, (void*)d.candA, (void*)d.candB, (void*)d.wBatchIdx, (void*)d.wBatchErr, (void*)d.wJobP,
                         (void*)d.wJobH, (void*)d.kind, (void*)d.base, (void*)d.ops, (void*)d.tasks, (void*)d.blocks, (void*)d.errs, (void*)d.store,
                         (void*)arena, (void*)samples, (void*)tmplNodes, (void*)tmplParent, (void*)tmplSub, (void*)tmplLeaves, (void*)tmplErr,
-                        (void*)tmplJobP, (void*)tmplTasks, (void*)tmplBlocks})
+                        (void*)tmplJobP, (void*)tmplTasks, (void*)tmplBlocks, (void*)d.jobOwner, (void*)d.packPos, (void*)d.pack, (void*)r0Tasks,
+                        (void*)r0Blocks, (void*)r0JobP})
             if (p) (void)hipFree(p);
         if (hostHdr) (void)hipHostFree(hostHdr);
         if (pinned) (void)hipHostFree(pinned);
@@ -1236,7 +1481,9 @@ bool frontierEligible(const hpsdf_config* cfg, const hpsdf_field* field, uint64_
 }
 
 int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field* field, uint64_t K, void** block, size_t* size,
-                   hpsdf_build_stats* stats) {
+                   hpsdf_build_stats* stats, int rank, int world, hpsdf_allgather_fn gather, void* gatherUser) {
+    if (world < 1 || world > 8 || rank < 0 || rank >= world) return fail(HPSDF_ERR_INVALID_ARGUMENT, "bad rank/world (1..8 ranks)");
+    if (world > 1 && !gather) return fail(HPSDF_ERR_INVALID_ARGUMENT, "a multi-rank build needs an all-gather");
     const bool trace = std::getenv("HPSDF_TRACE") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
@@ -1269,7 +1516,19 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
     } release{ws};
     const uint32_t Kj = (uint32_t)(K ? K : HPSDF_DEFAULT_JOBS_PER_ROUND);
     ws->d.K = Kj;
+    ws->d.rank = rank, ws->d.world = world;
+    ws->d.errStride = kFrJobs * HPSDF_JOB_HEADER_DOUBLES;
+    {
+        const hipError_t e = ws->ensureRanks(world, s);
+        if (e != hipSuccess) return hipFail(e, "frontier buffers");
+    }
     const bool mesh = innermost(field)->kind == kHostMesh;
+    auto exchange = [&](void* dBuf, size_t bytesPerRank, const char* what) -> int {  // in place: rank r's part at r * bytesPerRank
+        if (world == 1) return HPSDF_OK;
+        const int grc = gather(gatherUser, dBuf, bytesPerRank, (void*)s);
+        if (grc != 0) return fail(HPSDF_ERR_STATE, std::string("the all-gather callback failed (") + what + ")");
+        return HPSDF_OK;
+    };
 
     FieldDev fd;
     int rc;
@@ -1313,38 +1572,95 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         ~FreeEarly() { std::free(*p); }
     } freeEarly{&early};
     // ---- round 0: every cell of the uniformly refined tree, straight from the template
+    FrTemplate T0 = T;  // (this rank's share when there are several)
+    const FitTask* r0Tasks = ws->tmplTasks;
+    const FitBlock* r0Blocks = ws->tmplBlocks;
+    const uint64_t* r0JobP = ws->tmplJobP;
+    size_t r0Lds = ws->tmplLds;
+    T0.sliceFirst[0] = 0;
+    for (int r = 1; r < 9; ++r) T0.sliceFirst[r] = T.nLeaves;
+    if (world > 1) {
+        // equal costs: slice ends where the scheduler's rule puts them (builderSelect: the first i with i c >= total (r + 1) / world)
+        const uint64_t c = (uint64_t)frCoef(2) * 729ull, total = c * T.nLeaves;
+        uint32_t start = 0;
+        for (int r = 0; r < world; ++r) {
+            uint32_t end = T.nLeaves;
+            if (r + 1 < world) {
+                const uint64_t target = total * (uint64_t)(r + 1) / (uint64_t)world;
+                end = (uint32_t)((target + c - 1) / c);
+                end = std::min(std::max(end, start), T.nLeaves);
+            }
+            T0.sliceFirst[r + 1] = end;
+            start = end;
+        }
+        const uint32_t first = T0.sliceFirst[rank], count = T0.sliceFirst[rank + 1] - first;
+        int g = 1, pl = 1;
+        frShape(2, false, std::max(1u, count), &g, &pl);
+        std::vector<FitTask>& tk = ws->hostR0Tasks;
+        tk.assign(ws->hostTmplTasks.begin() + first, ws->hostTmplTasks.begin() + first + count);
+        std::vector<uint64_t> jobP(T.nLeaves, ~0ull & kOffMask);
+        for (uint32_t q = 0; q < count; ++q) {
+            tk[q].outOff = (uint64_t)q * frCoef(2);
+            tk[q].sampleOff = (uint64_t)q * 729;
+            tk[q].errSlot = (uint32_t)rank * ws->d.errStride + q * HPSDF_JOB_HEADER_DOUBLES;
+            jobP[first + q] = tk[q].outOff;
+        }
+        std::vector<FitBlock> bl((count + g - 1) / g);
+        for (uint32_t k = 0; k < bl.size(); ++k) {
+            FitBlock& fb = bl[k];
+            std::memset(&fb, 0, sizeof fb);
+            fb.firstTask = k * (uint32_t)g;
+            fb.nTasks = (uint16_t)std::min<uint32_t>((uint32_t)g, count - k * (uint32_t)g);
+            fb.degree = 2;
+            fb.planesPerChunk = (uint8_t)pl;
+            fb.rowStart = 0, fb.rowEnd = (uint16_t)frCoef(2);
+            fb.depth = ws->hostTmplTasks[0].depth;
+        }
+        HPSDF_HIP(hipMemcpyAsync(ws->r0Tasks, tk.data(), count * sizeof(FitTask), hipMemcpyHostToDevice, s));
+        HPSDF_HIP(hipMemcpyAsync(ws->r0Blocks, bl.data(), bl.size() * sizeof(FitBlock), hipMemcpyHostToDevice, s));
+        HPSDF_HIP(hipMemcpyAsync(ws->r0JobP, jobP.data(), jobP.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+        HPSDF_HIP(hipStreamSynchronize(s));  // (pageable sources)
+        r0Tasks = ws->r0Tasks, r0Blocks = ws->r0Blocks, r0JobP = ws->r0JobP;
+        r0Lds = frLds(2, g, pl);
+        T0.nTasks = count, T0.nBlocks = (uint32_t)bl.size();
+        T0.arenaRows = (uint64_t)count * frCoef(2), T0.samples = (uint64_t)count * 729;
+    }
     {
-        hipError_t e = ws->ensureArena(T.arenaRows, 0, s);
-        if (e == hipSuccess && mesh) e = ws->ensureSamples(T.samples, s);
+        hipError_t e = ws->ensureArena(std::max<uint64_t>(1, T0.arenaRows), 0, s);
+        if (e == hipSuccess && mesh) e = ws->ensureSamples(std::max<uint64_t>(1, T0.samples), s);
         if (e != hipSuccess) return hipFail(e, "frontier buffers");
-        hipLaunchKernelGGL(fr_init_kernel, dim3((T.nNodes + 255) / 256), dim3(256), 0, s, d, T, cfg.target_error_threshold);
+        hipLaunchKernelGGL(fr_init_kernel, dim3((T.nNodes + 255) / 256), dim3(256), 0, s, d, T0, cfg.target_error_threshold);
         FieldDev fdr = fd;
         if (mesh) {
-            HPSDF_HIP(launchMeshSample(s, ws->tmplTasks, T.nTasks, 2, ctx->dTables, fd, rm, ws->samples));
+            HPSDF_HIP(launchMeshSample(s, r0Tasks, T0.nTasks, 2, ctx->dTables, fd, rm, ws->samples));
             fdr.kind = kFieldSamples;
             fdr.samples = ws->samples;
         }
-        HPSDF_HIP(launchFit(s, 2, 1, ws->tmplBlocks, T.nBlocks, ws->tmplLds, ws->tmplTasks, ws->arena, d.errs, nullptr, ctx->dTables, fdr, rm));
+        HPSDF_HIP(launchFit(s, 2, 1, r0Blocks, T0.nBlocks, r0Lds, r0Tasks, ws->arena, d.errs, nullptr, ctx->dTables, fdr, rm));
+        if ((rc = exchange(d.errs, (size_t)d.errStride * sizeof(double), "round 0"))) return rc;
         FrDev d0 = d;
-        d0.batchIdx = ws->tmplLeaves, d0.batchErr = ws->tmplErr, d0.jobP = ws->tmplJobP, d0.jobH = ws->tmplJobP;
+        d0.batchIdx = ws->tmplLeaves, d0.batchErr = ws->tmplErr, d0.jobP = r0JobP, d0.jobH = r0JobP;
         hipLaunchKernelGGL(fr_round0_kernel, dim3(1 + (T.nLeaves + 255) / 256), dim3(256), 0, s, d0);
-        // a build that stops here has its packed store at the start of the arena: fetch it right behind the round
-        HPSDF_HIP(hipMemcpyAsync(ws->pinned, ws->arena, T.arenaRows * sizeof(double), hipMemcpyDeviceToHost, s));
-        // ... and everything else of its block is known in advance: write that part while the device works
-        const uint64_t nc0 = T.arenaRows, nn0 = T.nNodes;
-        early = (uint8_t*)std::malloc(8 + 8 * (size_t)nc0 + 8 + sizeof(hpsdf_node) * (size_t)nn0 + sizeof(hpsdf_config));
-        if (early) {
-            std::memcpy(early, &nc0, 8);
-            std::memcpy(early + 8 + 8 * (size_t)nc0, &nn0, 8);
-            std::memcpy(early + 16 + 8 * (size_t)nc0, ws->hostNodesAfterRound0.data(), sizeof(hpsdf_node) * (size_t)nn0);
-            std::memcpy(early + 16 + 8 * (size_t)nc0 + sizeof(hpsdf_node) * (size_t)nn0, &cfg, sizeof cfg);
+        if (world == 1) {
+            // a build that stops here has its packed store at the start of the arena: fetch it right behind the round
+            HPSDF_HIP(hipMemcpyAsync(ws->pinned, ws->arena, T.arenaRows * sizeof(double), hipMemcpyDeviceToHost, s));
+            // ... and everything else of its block is known in advance: write that part while the device works
+            const uint64_t nc0 = T.arenaRows, nn0 = T.nNodes;
+            early = (uint8_t*)std::malloc(8 + 8 * (size_t)nc0 + 8 + sizeof(hpsdf_node) * (size_t)nn0 + sizeof(hpsdf_config));
+            if (early) {
+                std::memcpy(early, &nc0, 8);
+                std::memcpy(early + 8 + 8 * (size_t)nc0, &nn0, 8);
+                std::memcpy(early + 16 + 8 * (size_t)nc0, ws->hostNodesAfterRound0.data(), sizeof(hpsdf_node) * (size_t)nn0);
+                std::memcpy(early + 16 + 8 * (size_t)nc0 + sizeof(hpsdf_node) * (size_t)nn0, &cfg, sizeof cfg);
+            }
         }
         const double ts = now();
         HPSDF_HIP(hipStreamSynchronize(s));
         tSync += now() - ts;
     }
     int rounds = 1;
-    const bool stoppedAfterRound0 = hh->done && hh->overflow != 1;
+    d.errStride = Kj * HPSDF_JOB_HEADER_DOUBLES;  // later rounds have at most K jobs: smaller parts to all-gather
+    const bool stoppedAfterRound0 = world == 1 && hh->done && hh->overflow != 1;
     if (stoppedAfterRound0 && early && hh->nCoeffs == T.arenaRows && hh->nNodes == T.nNodes) {
         std::memcpy(early + 8, ws->pinned, 8 * (size_t)T.arenaRows);
         *block = early;
@@ -1405,9 +1721,10 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
                 HPSDF_HIP(hipEventRecord(ws->joinEv[k], ws->side[k]));
                 HPSDF_HIP(hipStreamWaitEvent(s, ws->joinEv[k], 0));
             }
+        if ((rc = exchange(d.errs, (size_t)d.errStride * sizeof(double), "a round's errors"))) return rc;
         hipLaunchKernelGGL(fr_decide_kernel, dim3(1), dim3(1024), 0, s, d);
         hipLaunchKernelGGL(fr_update_kernel, dim3(1 + (Kj + 31) / 32), dim3(256), 0, s, d);
-        hipLaunchKernelGGL(fr_store_kernel, dim3(std::min<uint32_t>(2048u, (knownNodes + 8u * Kj + 3u) / 4u)), dim3(256), 0, s, d);
+        if (world == 1) hipLaunchKernelGGL(fr_store_kernel, dim3(std::min<uint32_t>(2048u, (knownNodes + 8u * Kj + 3u) / 4u)), dim3(256), 0, s, d);
         // The round is over for the host when the header's mirror shows the next round number: the update kernel's last
         // workgroup writes it into pinned memory behind a system-scope fence.  Watching that word costs ~3 us; waking up
         // from hipStreamSynchronize ~20 (everything launched next is ordered behind this round on the stream anyway;
@@ -1433,7 +1750,24 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         }
     }
     if (hh->overflow == 1) return fail(HPSDF_ERR_STATE, "frontier: node capacity exceeded");
-    if (hh->overflow == 2) {  // the packed store was too small: grow, run ReallocCoeffs again
+    if (world > 1) {
+        // the packed store from one all-gather of the ranks' pack buffers (each rank's own segments in node order)
+        hipError_t e = ws->ensureStore(hh->nCoeffs, s);
+        if (e != hipSuccess) return hipFail(e, "coefficient store");
+        HPSDF_HIP(hipMemsetAsync(&d.hdr->overflow, 0, sizeof(uint32_t), s));
+        hipLaunchKernelGGL(fr_packpos_kernel, dim3(1), dim3(1024), 0, s, d);
+        HPSDF_HIP(hipStreamSynchronize(s));
+        uint64_t stride = 1;
+        for (int r = 0; r < world; ++r) stride = std::max<uint64_t>(stride, hh->packCount[r]);
+        stride = (stride + 15) & ~15ull;
+        e = ws->ensurePack((uint64_t)world * stride, s);
+        if (e != hipSuccess) return hipFail(e, "pack buffers");
+        d.packStride = stride;
+        hipLaunchKernelGGL(fr_pack_kernel, dim3(std::min<uint32_t>(2048u, (knownNodes + 3u) / 4u)), dim3(256), 0, s, d);
+        if ((rc = exchange(d.pack, (size_t)stride * sizeof(double), "the packed coefficients"))) return rc;
+        hipLaunchKernelGGL(fr_store_kernel, dim3(std::min<uint32_t>(2048u, (knownNodes + 3u) / 4u)), dim3(256), 0, s, d);
+        HPSDF_HIP(hipStreamSynchronize(s));
+    } else if (hh->overflow == 2) {  // the packed store was too small: grow, run ReallocCoeffs again
         hipError_t e = ws->ensureStore(hh->nCoeffs, s);
         if (e != hipSuccess) return hipFail(e, "coefficient store");
         HPSDF_HIP(hipMemsetAsync(&d.hdr->overflow, 0, sizeof(uint32_t), s));

@@ -11,7 +11,8 @@ namespace hpsdf {
 
 bool frontierEligible(const hpsdf_config* cfg, const hpsdf_field* field, uint64_t K);
 // the whole build up to the serialised block (malloc'd); the continuity post-process is the caller's
+// rank / world / gather: this rank's part of a build sharded over `world` ranks (hpsdf_create_distributed)
 int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* field, uint64_t K, void** block, size_t* size,
-                   hpsdf_build_stats* stats);
+                   hpsdf_build_stats* stats, int rank = 0, int world = 1, hpsdf_allgather_fn gather = nullptr, void* gatherUser = nullptr);
 
 }  // namespace hpsdf

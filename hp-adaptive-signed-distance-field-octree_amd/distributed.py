@@ -1,13 +1,19 @@
 """Multi-GPU Create/Query: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
 
 Create
-    The tree, the frontier heap and the field are replicated; every rank selects the same jobs and
+    The tree, the frontier and the field are replicated; every rank selects the same jobs and
     computes only its cost-balanced slice of each round on its GPU.  Per round the ranks exchange
-    the 9 errors of every job (72 B/job) with ONE all-gather of max-slice-padded buffers -- the
+    the 9 errors of every job (72 B/job) with ONE all-gather of equal (padded) parts -- the
     coefficients stay in the arena of the rank that fitted them.  After the last round one
-    all-gather (variable sizes, padded) reassembles the serialised tree on every rank.  Every rank
-    applies identical headers in identical order, so the MemoryBlock is byte-identical for any
-    world size (tests/test_distributed_gloo.py, tests/test_gpu_create.py).
+    all-gather reassembles the packed coefficients on every rank.  Every rank applies identical
+    results in identical order, so the MemoryBlock is byte-identical for any world size
+    (tests/test_distributed_gloo.py, tests/test_gpu_configs.py).
+
+    Fields the GPU evaluates itself (analytic, mesh, tree-CSG) without nearness weighting take the
+    device-side frontier (csrc/frontier.hip, hpsdf_create_distributed): selection, slicing, decision
+    and bookkeeping run on every rank's GPU and the two exchange points are all-gathers of device
+    buffers.  Host callbacks and weighted builds run the host scheduler through the stepwise C API
+    below (the per-round errors then pass through host memory).
 
 Continuity (config.continuity.enforce)
     The host-side post-process runs on every rank on its identical copy of the assembled block; its
@@ -21,6 +27,7 @@ for gloo (CPU tests inject oracle-computed job results through ``compute=``; the
 always computes on the GPU).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -45,6 +52,35 @@ def _gather_padded(local, pad_to, group, world):
     return out.view(world, pad_to)
 
 
+class _DevBytes:
+    """Raw HBM bytes for torch.as_tensor (no copy)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def device_allgather(ctx, group=None):
+    """The in-place all-gather hpsdf_create_distributed asks for, over torch.distributed: RCCL (backend nccl) on the
+    device buffer itself; gloo (CPU tests, one-GPU rehearsals) through host memory."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    on_device = dist.get_backend(group) == "nccl"
+
+    def gather(d_buf, nbytes, stream):
+        ctx.synchronize()  # this rank's part was written on the context's stream; the collective runs on torch's
+        buf = torch.as_tensor(_DevBytes(d_buf, nbytes * world), device=torch.device("cuda", ctx.device))
+        mine = buf[rank * nbytes:(rank + 1) * nbytes]
+        if on_device:
+            dist.all_gather_into_tensor(buf, mine.clone(), group=group)
+            torch.cuda.current_stream().synchronize()
+        else:
+            parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+            dist.all_gather(parts, mine.cpu(), group=group)
+            buf.copy_(torch.cat(parts))
+            torch.cuda.current_stream().synchronize()
+    return gather
+
+
 def create_distributed(ctx, config, field, K=0, group=None, compute=None, policy="shard"):
     """Octree::Create over the ranks of ``group``.  Returns (block bytes, stats) on every rank.
 
@@ -66,6 +102,14 @@ def create_distributed(ctx, config, field, K=0, group=None, compute=None, policy
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     on_gpu = compute is None
     pod = config.to_pod() if hasattr(config, "to_pod") else config
+    if on_gpu and world > 1 and getattr(field, "kind", None) in ("analytic", "mesh", "tree_csg") and pod.weighting_type == 0 \
+            and not pod.enable_logging and (K or 1024) <= 4096 and os.environ.get("HPSDF_HOST_FRONTIER") != "1":
+        from . import create_block_distributed, HpsdfError, ERR_UNSUPPORTED
+        try:
+            return create_block_distributed(ctx, config, field, K, rank, world, device_allgather(ctx, group))
+        except HpsdfError as e:  # e.g. a tree-CSG field around a host callback: the stepwise path below shards it
+            if e.status != ERR_UNSUPPORTED:
+                raise
     if world > 1 and pod.weighting_type != 0 and on_gpu:
         # Nearness-weighted fits keep one full coefficient array per node and an incremental fit reads the node's
         # previous rows, which live in the arena of whichever rank fitted them: such builds are not sharded.

@@ -296,6 +296,27 @@ HPSDF_API int hpsdf_continuity_last_stats(hpsdf_continuity_stats* out);
 HPSDF_API int hpsdf_create(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* field,
                            uint64_t max_jobs_per_round, void** block, size_t* size, hpsdf_build_stats* stats);
 
+/* ---- Create sharded over the GPUs of one node ---------------------------------------------------------------
+ * One process (or thread) per GPU, each with its own context, all calling this with the same config, field and K.
+ * Tree, frontier and field are replicated; every round's jobs are cut into `world` contiguous cost-balanced slices and
+ * rank r fits slice r on its GPU; the ranks then exchange the 9 errors per job -- ONE all-gather per round -- and every
+ * rank applies identical results in identical order; one more all-gather at the end reassembles the packed coefficient
+ * store.  The block is byte-identical on every rank and identical to what world = 1 builds.
+ * (Reference: there is no multi-process build; this is Octree::Create, Octree.cpp:312-352, with the job loop :194-309
+ * sharded.)
+ *
+ * gather: in-place all-gather of equal parts on device memory -- rank r's contribution sits at
+ * d_buf + r * bytes_per_rank when it is called; when the work it enqueues on `stream` (a hipStream_t) has run, every
+ * rank's d_buf must hold all `world` parts.  It returns 0 on success.  With RCCL this is one call,
+ *     ncclAllGather((char*)d_buf + rank * n, d_buf, n, ncclChar, comm, stream)      (include/hpsdf_rccl.hpp);
+ * the library itself does not link RCCL.
+ * Fields the device cannot evaluate (host callbacks) and nearness-weighted builds return HPSDF_ERR_UNSUPPORTED here:
+ * they are sharded through the stepwise hpsdf_build_* calls (hp-adaptive-..._amd/distributed.py). */
+typedef int (*hpsdf_allgather_fn)(void* user, void* d_buf, size_t bytes_per_rank, void* stream);
+HPSDF_API int hpsdf_create_distributed(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* field,
+                                       uint64_t max_jobs_per_round, int rank, int world, hpsdf_allgather_fn gather,
+                                       void* user, void** block, size_t* size, hpsdf_build_stats* stats);
+
 /* ---- steady-state micro-benchmark hook (bench.py / profiles) ------------------
  * n_cells from-scratch fits of `degree` at `depth` over a lattice of cells, results discarded. */
 HPSDF_API int hpsdf_bench_fit(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* field, int degree,

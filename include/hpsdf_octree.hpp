@@ -243,6 +243,18 @@ class DeviceField {
         p.p[0] = cx, p.p[1] = cy, p.p[2] = cz, p.p[3] = r;
         return Analytic({p});
     }
+    /// BASELINE configs[1]: union of a sphere, a box and a torus
+    static DeviceField Union3() {
+        hpsdf_prim p[3];
+        std::memset(p, 0, sizeof p);
+        p[0].kind = HPSDF_PRIM_SPHERE, p[0].op = HPSDF_OP_UNION;
+        p[0].p[0] = -0.2, p[0].p[1] = -0.15, p[0].p[2] = 0.1, p[0].p[3] = 0.18;
+        p[1].kind = HPSDF_PRIM_BOX, p[1].op = HPSDF_OP_UNION;
+        p[1].p[0] = 0.15, p[1].p[1] = 0.2, p[1].p[2] = -0.1, p[1].p[3] = 0.12, p[1].p[4] = 0.10, p[1].p[5] = 0.15;
+        p[2].kind = HPSDF_PRIM_TORUS_Y, p[2].op = HPSDF_OP_UNION;
+        p[2].p[0] = 0.0, p[2].p[1] = -0.2, p[2].p[2] = -0.2, p[2].p[3] = 0.15, p[2].p[4] = 0.05;
+        return Analytic({p[0], p[1], p[2]});
+    }
     const hpsdf_field* handle() const { return f_; }
 
    private:
@@ -286,6 +298,14 @@ class Octree {
     }
     /// Jobs per round of the canonical schedule (K); part of the result's definition.
     void SetJobsPerRound(uint64_t k) { jobsPerRound_ = k; }
+    /// Additive: Create() over `world` GPUs of one node -- one Octree per GPU (SetDevice), every rank calls Create with
+    /// the same config and field; `gather` is the in-place all-gather of hpsdf_create_distributed (for RCCL:
+    /// hpsdf_rccl::AllGather with an hpsdf_rccl::Comm as `user`, include/hpsdf_rccl.hpp).  Every rank ends with the
+    /// identical tree.  Fields given as std::function and nearness-weighted configs are not sharded this way (the call
+    /// throws HPSDF_ERR_UNSUPPORTED): they run the stepwise C API.
+    void SetRanks(int rank, int world, hpsdf_allgather_fn gather, void* user) {
+        rank_ = rank, world_ = world, gather_ = gather, gatherUser_ = user;
+    }
 
     /// Approximates F_ using the parameters in config_   (Octree.h:50)
     void Create(const Config& config_, Func F_) {
@@ -471,7 +491,10 @@ class Octree {
         const hpsdf_config pod = config.toPod();
         void* blk = nullptr;
         size_t sz = 0;
-        check(hpsdf_create(ctx_, &pod, f, jobsPerRound_, &blk, &sz, &stats_));
+        if (world_ > 1)  // one process / thread per GPU: this rank's part of the sharded build (SetRanks)
+            check(hpsdf_create_distributed(ctx_, &pod, f, jobsPerRound_, rank_, world_, gather_, gatherUser_, &blk, &sz, &stats_));
+        else
+            check(hpsdf_create(ctx_, &pod, f, jobsPerRound_, &blk, &sz, &stats_));
         Clear();  // Octree.cpp:315 (the old tree may have been the CSG operand until now)
         block_ = blk;
         size_ = sz;
@@ -528,6 +551,9 @@ class Octree {
     int device_ = 0;
     void* stream_ = nullptr;
     uint64_t jobsPerRound_ = 0;
+    int rank_ = 0, world_ = 1;
+    hpsdf_allgather_fn gather_ = nullptr;
+    void* gatherUser_ = nullptr;
     mutable hpsdf_ctx* ctx_ = nullptr;
     hpsdf_tree* tree_ = nullptr;
     void* block_ = nullptr;  // serialised tree: [nCoeffs][coeffs][nNodes][nodes][config]

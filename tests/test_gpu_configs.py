@@ -184,3 +184,95 @@ def test_upload_rejects_malformed_blocks(H, ctx):
     t = H.Octree()
     with pytest.raises(H.HpsdfError):
         t.FromMemoryBlock(b"\x00" * 40)  # smaller than two counts + Config
+
+
+# ------------------------------------------------------------------ the device-side frontier (csrc/frontier.hip)
+@pytest.mark.parametrize("name,target,K", [("union3", 1e-5, 1024), ("union3", 1e-7, 1024), ("union3", 1e-7, 256),
+                                           ("sphere", 1e-8, 1024), ("union3", 1e-8, 4096), ("sphere075", 1e-6, 64)])
+def test_device_frontier_equals_host_scheduler(H, ctx, monkeypatch, name, target, K):
+    """hpsdf_create runs selection, decision and bookkeeping on the device; HPSDF_HOST_FRONTIER=1 runs the host scheduler
+    (csrc/builder.cpp).  Same schedule, same arithmetic: the MemoryBlock and the statistics are identical."""
+    from helpers import product_field
+    root = ((-0.25,) * 3, (5.0,) * 3) if name == "sphere075" else ((-0.5,) * 3, (0.5,) * 3)
+    cfg = H.make_config(target, *root)
+    f = product_field(H, name)
+    monkeypatch.setenv("HPSDF_HOST_FRONTIER", "1")
+    want, swant = H.create_block(ctx, cfg, f, K)
+    monkeypatch.setenv("HPSDF_HOST_FRONTIER", "0")
+    got, sgot = H.create_block(ctx, cfg, f, K)
+    assert got == want
+    for k in ("rounds", "jobs", "p_refines", "h_refines", "dropped", "fits", "samples", "n_nodes", "n_leaves", "n_coeffs", "total_error"):
+        assert sgot[k] == swant[k], k
+
+
+class _DevBytes:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def _create_on_simulated_ranks(H, world, cfg, make_field, K):
+    """hpsdf_create_distributed on `world` threads of this process, one context each, all on this GPU; the all-gather is
+    a thread barrier plus device-to-device copies between the ranks' buffers."""
+    import threading
+    import torch
+    ctxs = [H.Context(0) for _ in range(world)]
+    fields = [make_field(c) for c in ctxs]
+    barrier = threading.Barrier(world)
+    bufs, out, errs = [None] * world, [None] * world, []
+
+    def gather_for(rank):
+        def gather(d_buf, nbytes, stream):
+            ctxs[rank].synchronize()
+            bufs[rank] = d_buf
+            barrier.wait()
+            mine = torch.as_tensor(_DevBytes(d_buf, nbytes * world), device="cuda")
+            for r in range(world):
+                if r != rank:
+                    other = torch.as_tensor(_DevBytes(bufs[r], nbytes * world), device="cuda")
+                    mine[r * nbytes:(r + 1) * nbytes].copy_(other[r * nbytes:(r + 1) * nbytes])
+            torch.cuda.synchronize()
+            barrier.wait()
+        return gather
+
+    def worker(rank):
+        try:
+            out[rank] = H.create_block_distributed(ctxs[rank], cfg, fields[rank], K, rank, world, gather_for(rank))
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+            barrier.abort()
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if errs:
+        raise errs[0]
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_create_distributed_device_frontier_byte_identical(H, ctx, world):
+    """The sharded build of the C ABI (hpsdf_create_distributed: slices cut on the device, one all-gather per round, one
+    for the packed coefficients) with 2 / 4 / 8 ranks: every rank's block equals the single-rank block.  configs[3] in
+    shape (mesh field, 1e-6, anisotropic root) and the refined analytic tree at two round sizes."""
+    verts, tris = _mesh()
+    cases = [(H.make_config(1e-6, *MESH_ROOT), lambda c: H.Field.mesh(c, verts, tris), MESH_K),
+             (H.make_config(1e-7), lambda c: H.Field.union3(), 256),
+             (H.make_config(1e-5), lambda c: H.Field.union3(), 1024)]
+    for cfg, make_field, K in cases:
+        one, st = H.create_block(ctx, cfg, make_field(ctx), K)
+        for blk, s in _create_on_simulated_ranks(H, world, cfg, make_field, K):
+            assert blk == one
+            assert s["rounds"] == st["rounds"] and s["n_nodes"] == st["n_nodes"] and s["jobs"] == st["jobs"]
+
+
+def test_create_distributed_refuses_what_the_host_scheduler_owns(H, ctx):
+    cfg = H.make_config(1e-6)
+    cfg.nearnessWeighting_type, cfg.nearnessWeighting_strength = 1, 3.0
+    with pytest.raises(H.HpsdfError) as e:
+        H.create_block_distributed(ctx, cfg, H.Field.sphere(), 1024, 0, 2, lambda *a: None)
+    assert e.value.status == H.ERR_UNSUPPORTED
+    with pytest.raises(H.HpsdfError) as e:
+        H.create_block_distributed(ctx, H.make_config(1e-6), H.Field.sphere(), 1024, 2, 2, lambda *a: None)
+    assert e.value.status == H.ERR_INVALID_ARGUMENT
