@@ -7,7 +7,8 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 i=0
 for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY" \
-         "SQ_WAIT_ANY SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE SQ_THREAD_CYCLES_VALU"; do
+         "SQ_WAIT_ANY SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE SQ_THREAD_CYCLES_VALU" \
+         "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   rocprofv3 --pmc $C --output-format csv -d $OUT/p$i -- python3 $REPO/tools/mesh_probe.py $LEVEL > $OUT/log$i.txt 2>&1
 done
@@ -23,5 +24,18 @@ for f in glob.glob(os.path.join(out, "**/*counter_collection.csv"), recursive=Tr
 for k in sorted(acc):
     v = acc[k]
     print("%-42s %-26s n=%d avg %.4g max %.4g" % (k[0], k[1], len(v), sum(v) / len(v), max(v)))
+def avg(name):
+    for k in acc:
+        if k[1] == name and "mesh_sample" in k[0]:
+            return sum(acc[k]) / len(acc[k])
+    return None
+tc, iv, w = avg("SQ_THREAD_CYCLES_VALU"), avg("SQ_INSTS_VALU"), avg("SQ_WAVES")
+if tc and iv:
+    print("mesh_sample_kernel lane utilisation SQ_THREAD_CYCLES_VALU / (SQ_INSTS_VALU * 256) = %.3f" % (tc / (iv * 256)))
+    print("mesh_sample_kernel VALU instructions per wave (64 samples): %.0f" % (iv / w))
+fs, ws = avg("FETCH_SIZE"), avg("WRITE_SIZE")
+if fs and w:
+    # FETCH_SIZE / WRITE_SIZE are in KB; gfx950 counts a 128-byte read request as 64 bytes (MI355X_MICROARCH.md): reads doubled
+    print("mesh_sample_kernel HBM traffic per sample: fetched %.1f B (counter x 2), written %.1f B" % (2 * fs * 1024 / (w * 64), (ws or 0) * 1024 / (w * 64)))
 PY
 tail -2 $OUT/log1.txt
