@@ -103,6 +103,7 @@ _SIGNATURES = {
     "hpsdf_ctx_destroy": (C.c_int, [C.c_void_p]),
     "hpsdf_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hpsdf_ctx_synchronize": (C.c_int, [C.c_void_p]),
+    "hpsdf_ctx_set_fast_fit": (C.c_int, [C.c_void_p, C.c_int]),
     "hpsdf_ctx_stream": (C.c_void_p, [C.c_void_p]),
     "hpsdf_field_create_analytic": (C.c_int, [C.POINTER(Prim), C.c_int, C.POINTER(C.c_void_p)]),
     "hpsdf_field_create_callback": (C.c_int, [CALLBACK, C.c_void_p, C.POINTER(C.c_void_p)]),
@@ -270,6 +271,10 @@ class Context:
 
     def set_stream(self, stream):
         check(lib().hpsdf_ctx_set_stream(self.handle, C.c_void_p(stream) if stream else None))
+
+    def set_fast_fit(self, on=True):
+        """Opt-in: cell fits of degree >= 4 on the matrix cores (not bit-identical to the default path)."""
+        check(lib().hpsdf_ctx_set_fast_fit(self.handle, 1 if on else 0))
 
     def synchronize(self):
         check(lib().hpsdf_ctx_synchronize(self.handle))

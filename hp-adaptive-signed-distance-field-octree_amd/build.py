@@ -14,8 +14,8 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libhpsdf.so")
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
 
-SOURCES = ["kernels.hip", "frontier.hip", "cg.hip", "tables.cpp", "builder.cpp", "mesh.cpp", "obj.cpp", "continuity.cpp", "capi.cpp"]
-HEADERS = ["tables.hpp", "device_types.hpp", "launch.hpp", "runtime.hpp", "builder.hpp", "continuity.hpp", "block_check.hpp", "frontier.hpp"]
+SOURCES = ["kernels.hip", "frontier.hip", "fit_mfma.hip", "cg.hip", "tables.cpp", "builder.cpp", "mesh.cpp", "obj.cpp", "continuity.cpp", "capi.cpp"]
+HEADERS = ["tables.hpp", "device_types.hpp", "launch.hpp", "runtime.hpp", "builder.hpp", "continuity.hpp", "block_check.hpp", "frontier.hpp", "field_eval.hpp"]
 PUBLIC_HEADERS = ["hpsdf.h", "hpsdf_octree.hpp"]
 
 # -ffp-contract=off: no multiply-add is fused anywhere (bit parity with the x86-64 reference path)
@@ -23,6 +23,10 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-I", INCLUDE]
 # diagnostic builds: HPSDF_EXTRA_FLAGS="-DHPSDF_MESH_STATS_BUILD" python build.py --force
 FLAGS += os.environ.get("HPSDF_EXTRA_FLAGS", "").split()
+# per-file flags.  fit_mfma.hip: keep the matrix instructions' accumulators in VGPRs -- left to its heuristics the
+# compiler gives them AGPR results and copies all of them to VGPRs and back around every step of the k-loop
+# (2 x 8 moves per tile and step, and a wait for each result)
+FILE_FLAGS = {"fit_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def hipcc():
@@ -58,7 +62,7 @@ def build(force=False, verbose=False):
                 and all(os.path.getmtime(obj) > os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
                 and all(os.path.getmtime(obj) > os.path.getmtime(os.path.join(INCLUDE, h)) for h in PUBLIC_HEADERS)):
             continue
-        cmd = [cc] + FLAGS + (["-x", "hip"] if s.endswith(".cpp") and False else []) + ["-c", src, "-o", obj]
+        cmd = [cc] + FLAGS + FILE_FLAGS.get(s, []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -309,6 +309,9 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
         meshSampled = need <= kMeshSampleCap;
     }
     const bool meshFused = innermost(field)->kind == kHostMesh && !meshSampled;
+    // opt-in fast fit (hpsdf_ctx_set_fast_fit): degrees >= 4 of unweighted, non-CSG fields go to the matrix cores
+    const bool fastOn = ctx->fastFit && !b->weighted && !meshFused && field->kind != kHostTreeCsg;
+    auto fastDeg = [&](int deg) { return fastOn && deg >= 4 && deg <= 9; };
 
     // ---- workgroup table
     uint32_t nBlocks = 0;
@@ -321,6 +324,7 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
         const bool incr = (c / kDepths) & 1;
         const int nrows = incr ? (int)(T.coeffCount[deg] - T.coeffCount[deg - 1]) : (int)T.coeffCount[deg];
         classShape[c] = fitShape(deg, nrows, classCount[c], b->weighted, meshFused);
+        if (fastDeg(deg)) classShape[c] = FitShape{kMfmaCells, 1, 1, 0};  // one workgroup = one 16-cell tile of the matrix-core fit
         nBlocks += (classCount[c] + classShape[c].cells - 1) / classShape[c].cells;
     }
     classBlockFirst[kClasses] = nBlocks;
@@ -521,8 +525,15 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
             if (classCount[e]) ldsBytes = std::max(ldsBytes, classShape[e].ldsBytes);
             ++e;
         }
-        HPSDF_HIP(launchFit(ctx->stream, deg, cpt, ws.blocks.dev + classBlockFirst[c], classBlockFirst[e] - classBlockFirst[c],
-                            ldsBytes, ws.tasks.dev, ws.arena, ws.errs.dev, ws.errs.dev + nSlots, ctx->dTables, fd, rm));
+        if (fastDeg(deg))
+            HPSDF_HIP(launchFitMfma(ctx->stream, deg, ws.blocks.dev + classBlockFirst[c], classBlockFirst[e] - classBlockFirst[c], ws.tasks.dev,
+                                    ws.arena, ws.errs.dev, ctx->dTables, fd, rm));
+        else
+            HPSDF_HIP(launchFit(ctx->stream, deg, cpt, ws.blocks.dev + classBlockFirst[c], classBlockFirst[e] - classBlockFirst[c],
+                                ldsBytes, ws.tasks.dev, ws.arena, ws.errs.dev, ws.errs.dev + nSlots, ctx->dTables, fd, rm));
+        if (b->weighted)  // Octree.cpp:1071-1092: the weight's |mean FApprox|, from the coefficients just written
+            HPSDF_HIP(launchFitWeight(ctx->stream, ws.blocks.dev + classBlockFirst[c], classBlockFirst[e] - classBlockFirst[c], ldsBytes,
+                                      ws.tasks.dev, ws.arena, ws.errs.dev + nSlots, ctx->dTables));
         c = e;
     }
     b->computed = true;

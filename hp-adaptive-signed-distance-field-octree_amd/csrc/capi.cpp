@@ -294,6 +294,12 @@ int hpsdf_ctx_set_stream(hpsdf_ctx* c, void* stream) {
     return HPSDF_OK;
 }
 
+int hpsdf_ctx_set_fast_fit(hpsdf_ctx* c, int on) {
+    if (!c) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null context");
+    c->fastFit = on != 0;
+    return HPSDF_OK;
+}
+
 int hpsdf_ctx_synchronize(hpsdf_ctx* c) {
     if (!c) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null ctx");
     HPSDF_HIP(hipSetDevice(c->device));
@@ -1149,7 +1155,13 @@ int hpsdf_bench_fit(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* 
     const Tables& T = tables();
     const uint64_t nc = T.coeffCount[degree];
     const int nrows = (int)nc;
-    const FitShape shape = fitShape(degree, nrows, (uint32_t)std::min<uint64_t>(nCells, 0xFFFFFFFFull), false);
+    FitShape shape = fitShape(degree, nrows, (uint32_t)std::min<uint64_t>(nCells, 0xFFFFFFFFull), false);
+    bool fast = false;
+    {
+        FieldDev probe;
+        if (ctx->fastFit && makeFieldDev(field, nullptr, &probe) == HPSDF_OK && fitMfmaSupports(degree, probe)) fast = true;
+    }
+    if (fast) shape = FitShape{kMfmaCells, 1, 1, 0};  // the matrix-core fit: one workgroup per 16-cell tile
     const int g = shape.cells, planes = shape.planes;
     std::vector<FitTask> tasks(nCells);
     const uint64_t side = 1ull << depth;
@@ -1201,10 +1213,13 @@ int hpsdf_bench_fit(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* 
     }
     const size_t lds = shape.ldsBytes;
     if (e == hipSuccess && rc == HPSDF_OK) {
-        e = launchFit(ctx->stream, degree, shape.cellsPerThread, dB, (uint32_t)blocks.size(), lds, dT, dA, dE, nullptr, ctx->dTables, fd, rm);  // warm-up
+        auto launch = [&]() {
+            return fast ? launchFitMfma(ctx->stream, degree, dB, (uint32_t)blocks.size(), dT, dA, dE, ctx->dTables, fd, rm)
+                        : launchFit(ctx->stream, degree, shape.cellsPerThread, dB, (uint32_t)blocks.size(), lds, dT, dA, dE, nullptr, ctx->dTables, fd, rm);
+        };
+        e = launch();  // warm-up
         if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
-        for (int r = 0; r < repeats && e == hipSuccess; ++r)
-            e = launchFit(ctx->stream, degree, shape.cellsPerThread, dB, (uint32_t)blocks.size(), lds, dT, dA, dE, nullptr, ctx->dTables, fd, rm);
+        for (int r = 0; r < repeats && e == hipSuccess; ++r) e = launch();
         if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
         if (e == hipSuccess) e = hipEventSynchronize(e1);
         float ms = 0.f;

@@ -131,6 +131,7 @@ struct FrDev {
     uint32_t* packPos;     // [node][kFrSegs]: where the segment sits in its owner's pack buffer
     double* pack;          // [world][packStride] all-gathered pack buffers (this rank writes its own)
     uint64_t packStride;
+    int32_t fastFit;       // degrees >= 4 fitted by fit_mfma.hip: 16 cells per workgroup
 };
 
 __host__ __device__ inline uint32_t frCoef(int p) { return p == 6 ? 83u : (uint32_t)((p + 1) * (p + 2) * (p + 3) / 6); }
@@ -140,7 +141,11 @@ __host__ __device__ inline size_t frLds(int degree, int g, int planes) {  // = f
     return ((size_t)(degree + 1) * nq + 2 * nq + 8 * (size_t)g + (size_t)g * planes * nq * nq) * sizeof(double);
 }
 // workgroup shape of `count` fits of one class: what fitShape (kernels.hip) gives an unweighted, sampled-or-analytic fit
-__host__ __device__ inline void frShape(int degree, bool incr, uint32_t count, int* cells, int* planes) {
+__host__ __device__ inline void frShape(int degree, bool incr, uint32_t count, int* cells, int* planes, bool fast = false) {
+    if (fast && degree >= 4 && degree <= 9) {  // the matrix-core fit: one workgroup = one tile of 16 cells
+        *cells = kMfmaCells, *planes = 1;
+        return;
+    }
     const int nrows = incr ? (int)(frCoef(degree) - frCoef(degree - 1)) : (int)frCoef(degree);
     int gmax = nrows > kFitBlockThreads ? 1 : kFitBlockThreads / nrows;
     while (gmax > 1 && frLds(degree, gmax, 1) > kFitMaxLdsBytes) --gmax;
@@ -534,7 +539,7 @@ __global__ __launch_bounds__(1024) void fr_batch_kernel(FrDev d) {
         if (myCount) {
             const int deg = (int)tid / kFrDepths / 2;
             const bool incr = ((int)tid / kFrDepths) & 1;
-            frShape(deg, incr, myCount, &g, &pl);
+            frShape(deg, incr, myCount, &g, &pl, d.fastFit != 0);
             myBlocks = (myCount + (uint32_t)g - 1u) / (uint32_t)g;
             const uint64_t nq = 4 * (uint64_t)deg + 1;
             myRows = (uint64_t)(incr ? frCoef(deg) - frCoef(deg - 1) : frCoef(deg)) * myCount;
@@ -1517,6 +1522,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
     const uint32_t Kj = (uint32_t)(K ? K : HPSDF_DEFAULT_JOBS_PER_ROUND);
     ws->d.K = Kj;
     ws->d.rank = rank, ws->d.world = world;
+    ws->d.fastFit = (ctx->fastFit && field->kind != kHostTreeCsg) ? 1 : 0;
     ws->d.errStride = kFrJobs * HPSDF_JOB_HEADER_DOUBLES;
     {
         const hipError_t e = ws->ensureRanks(world, s);
@@ -1713,8 +1719,11 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
                 if (!used[k]) HPSDF_HIP(hipStreamWaitEvent(fs, ws->forkEv, 0));
                 used[k] = true;
             }
-            HPSDF_HIP(launchFit(fs, deg <= 5 ? deg : 0, 1, d.blocks, taskBound, fitLdsTable[deg], d.tasks, ws->arena, d.errs, nullptr, ctx->dTables,
-                                fdr, rm, &d.hdr->degBlocks[deg][0]));
+            if (d.fastFit && deg >= 4 && deg <= 9)
+                HPSDF_HIP(launchFitMfma(fs, deg, d.blocks, taskBound, d.tasks, ws->arena, d.errs, ctx->dTables, fdr, rm, &d.hdr->degBlocks[deg][0]));
+            else
+                HPSDF_HIP(launchFit(fs, deg <= 5 ? deg : 0, 1, d.blocks, taskBound, fitLdsTable[deg], d.tasks, ws->arena, d.errs, nullptr,
+                                    ctx->dTables, fdr, rm, &d.hdr->degBlocks[deg][0]));
         }
         for (int k = 0; k < FrontierWorkspace::kSide; ++k)
             if (used[k]) {

@@ -22,54 +22,10 @@
 #include <cstdlib>
 
 #include "device_types.hpp"
+#include "field_eval.hpp"
 #include "launch.hpp"
 
 namespace hpsdf {
-
-// ---------------------------------------------------------------------------
-// field evaluation
-// ---------------------------------------------------------------------------
-
-// Eigen's Vector3d::norm(): sqrt(x^2 + (y^2 + z^2))
-__device__ __forceinline__ double norm3(double x, double y, double z) { return sqrt(x * x + (y * y + z * z)); }
-
-__device__ __forceinline__ double primEval(const hpsdf_prim& pr, double x, double y, double z) {
-    const double* p = pr.p;
-    switch (pr.kind) {
-        case HPSDF_PRIM_SPHERE:
-            return norm3(x - p[0], y - p[1], z - p[2]) - p[3];
-        case HPSDF_PRIM_BOX: {
-            const double qx = fabs(x - p[0]) - p[3];
-            const double qy = fabs(y - p[1]) - p[4];
-            const double qz = fabs(z - p[2]) - p[5];
-            const double outside = norm3(fmax(qx, 0.0), fmax(qy, 0.0), fmax(qz, 0.0));
-            const double inside = fmin(fmax(qx, fmax(qy, qz)), 0.0);
-            return outside + inside;
-        }
-        case HPSDF_PRIM_TORUS_Y: {
-            const double dx = x - p[0], dy = y - p[1], dz = z - p[2];
-            const double l = sqrt(dx * dx + dz * dz) - p[3];
-            return sqrt(l * l + dy * dy) - p[4];
-        }
-        case HPSDF_PRIM_PLANE:
-            return (p[0] * x + (p[1] * y + p[2] * z)) + p[3];
-        default:
-            return 0.0;
-    }
-}
-
-__device__ __forceinline__ double analyticEval(const FieldDev& f, double x, double y, double z) {
-    double acc = primEval(f.prims[0], x, y, z);
-    for (int i = 1; i < f.nPrims; ++i) {
-        const double d = primEval(f.prims[i], x, y, z);
-        switch (f.prims[i].op) {
-            case HPSDF_OP_UNION: acc = fmin(acc, d); break;
-            case HPSDF_OP_INTERSECT: acc = fmax(acc, d); break;
-            default: acc = fmax(acc, -d); break;
-        }
-    }
-    return acc;
-}
 
 // ---- mesh signed distance (all f32) ----------------------------------------
 // Source/Meshing/Utility.cpp:5-97, Source/Meshing/Mesh.cpp:54-63,162-242.
@@ -1379,6 +1335,11 @@ __global__ __launch_bounds__(256) void field_kernel(FieldDev f, const DeviceTabl
 // any-degree version (rows walked in groups of four, nq = 4p+1).
 
 constexpr int kFitThreads = 256;
+#ifndef HPSDF_FIT_MIN_WAVES
+#define HPSDF_FIT_MIN_WAVES 4  // waves per SIMD the register allocation must leave room for: <= 128 VGPRs.  Left alone the
+                               // degree-2 kernel takes 240 (two waves per SIMD); held to 128 it spills 448 bytes and is 37 % faster
+                               // (65 536 cells: 1.59 -> 2.18 TFLOP/s with the union3 field), degrees 4-5 gain 3-4 %
+#endif
 
 // Mesh fields: the order in which the np x nq x nq samples of a chunk are handed to the lanes.  A wave answers its 64
 // closest-triangle queries with ONE traversal whose cost is the union of what its lanes need, so the 64 samples should
@@ -1647,11 +1608,29 @@ __device__ __forceinline__ void fitBlockBody(const FitBlock blk, const FitTask* 
             }
         errs[tasks[blk.firstTask + g].errSlot] = e;
     }
-    if (!weighted) return;
-    // ---- nearness weighting, Octree.cpp:1209-1247: |mean of FApprox over 100 points of the cell|.  The points
-    //      come from a hash of (cell, sample, axis) instead of std::rand; the weight itself
-    //      (pow / exp) is applied by the host so that it matches the CPU path bit for bit.
-    double* sV = sF + G * stashStride;  // [G][100]
+}
+
+// Nearness weighting, Octree.cpp:1209-1247: |mean of FApprox over 100 points of the cell| for every fit of a weighted
+// build, from the full coefficient arrays fit_kernel has just written (a kernel of its own: its any-degree evaluation
+// keeps tables in private memory, and inside fit_kernel that put 320 bytes of scratch on every fit launch, weighted or
+// not).  The points come from a hash of (cell, sample, axis) instead of std::rand; the weight itself
+// (pow / exp) is applied by the host so that it matches the CPU path bit for bit.
+__global__ __launch_bounds__(kFitThreads) void fit_weight_kernel(const FitBlock* __restrict__ blocks, const FitTask* __restrict__ tasks,
+                                                                 const double* __restrict__ arena, double* __restrict__ means,
+                                                                 const DeviceTables* __restrict__ T) {
+    extern __shared__ double lds[];
+    __shared__ double sNl[13 * 11];
+    __shared__ double sRec[26];
+    const FitBlock blk = blocks[blockIdx.x];
+    const int tid = threadIdx.x, deg = blk.degree, depth = blk.depth, G = blk.nTasks, nc = blk.rowEnd;
+    stageQueryTables(T, sNl, sRec);
+    double* sCo = lds;           // [G][nc] coefficients
+    double* sV = lds + G * nc;   // [G][100]
+    for (int s = tid; s < G * nc; s += kFitThreads) {
+        const int g = s / nc, r = s - g * nc;
+        sCo[s] = arena[tasks[blk.firstTask + g].outOff + r];
+    }
+    __syncthreads();
     for (int s = tid; s < G * 100; s += kFitThreads) {
         const int g = s / 100, n = s - g * 100;
         const FitTask& tk = tasks[blk.firstTask + g];
@@ -1664,9 +1643,10 @@ __device__ __forceinline__ void fitBlockBody(const FitBlock blk, const FitTask* 
             const float r = (float)(splitmix64(key + ((uint64_t)n * 3 + (uint64_t)a) * 0x9E3779B97F4A7C15ull) >> 40) *
                             (1.0f / 16777216.0f);
             const double pt = (double)(tk.bmin[a] + (tk.bmax[a] - tk.bmin[a]) * r);  // AlignedBox3f::sample()
-            u[a] = (pt - sC[8 * g + 3 + a]) * (double)(2 << depth);                   // :862
+            const double centre = (double)((tk.bmin[a] + tk.bmax[a]) / 2.0f);        // :1021 center() in f32
+            u[a] = (pt - centre) * (double)(2 << depth);                             // :862
         }
-        sV[s] = evalLeafGeneric(sF + g * stashStride, deg, u[0], u[1], u[2], depth, sNl, sRec);
+        sV[s] = evalLeafGeneric(sCo + g * nc, deg, u[0], u[1], u[2], depth, sNl, sRec);
     }
     __syncthreads();
     for (int g = tid; g < G; g += kFitThreads) {
@@ -1682,7 +1662,7 @@ __device__ __forceinline__ void fitBlockBody(const FitBlock blk, const FitTask* 
 // list and its per-degree ranges itself, so the host never learns how many blocks a round has before it launches the fits
 // (a grid-stride loop over the range instead cost 37 more VGPRs at degree 3-4: one wave per SIMD less).
 template <int KIND, bool CSG, int DEG, int R>
-__global__ __launch_bounds__(kFitThreads) void fit_kernel(const FitBlock* __restrict__ blocks,
+__global__ __launch_bounds__(kFitThreads, HPSDF_FIT_MIN_WAVES) void fit_kernel(const FitBlock* __restrict__ blocks,
                                                           const FitTask* __restrict__ tasks, double* __restrict__ arena,
                                                           double* __restrict__ errs, double* __restrict__ means,
                                                           const DeviceTables* __restrict__ T, FieldDev field, RootMap rm,
@@ -1894,6 +1874,14 @@ hipError_t launchMeshSampleRange(hipStream_t stream, const FitTask* dTasks, cons
     const unsigned gx = (unsigned)((nq * nq * nq + 255) / 256);
     hipLaunchKernelGGL(mesh_sample_kernel, dim3(gx, maxTasks), dim3(256), 0, stream, dTasks, degree, dTables, field.mesh, rm, dSamples,
                        dRange);
+    return hipGetLastError();
+}
+
+// weighted builds: |mean FApprox| of every fit of the blocks (full coefficient arrays at FitTask::outOff)
+hipError_t launchFitWeight(hipStream_t stream, const FitBlock* dBlocks, uint32_t nBlocks, size_t ldsBytes, const FitTask* dTasks,
+                           const double* dArena, double* dMeans, const DeviceTables* dTables) {
+    if (nBlocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(fit_weight_kernel, dim3(nBlocks), dim3(kFitThreads), ldsBytes, stream, dBlocks, dTasks, dArena, dMeans, dTables);
     return hipGetLastError();
 }
 

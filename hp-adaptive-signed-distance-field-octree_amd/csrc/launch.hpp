@@ -29,6 +29,13 @@ FitShape fitShape(int degree, int nrows, uint32_t count, bool weighted, bool lat
 hipError_t launchFit(hipStream_t stream, int degree, int cellsPerThread, const FitBlock* dBlocks, uint32_t nBlocks, size_t ldsBytes,
                      const FitTask* dTasks, double* dArena, double* dErrs, double* dMeans,
                      const DeviceTables* dTables, const FieldDev& field, const RootMap& rm, const uint32_t* dRange = nullptr);
+hipError_t launchFitWeight(hipStream_t stream, const FitBlock* dBlocks, uint32_t nBlocks, size_t ldsBytes, const FitTask* dTasks,
+                           const double* dArena, double* dMeans, const DeviceTables* dTables);
+// opt-in fast fit of degrees 4..11 on the matrix cores (fit_mfma.hip): blocks of at most 16 fits, NOT bit-identical to launchFit
+constexpr int kMfmaCells = 16;
+bool fitMfmaSupports(int degree, const FieldDev& field);
+hipError_t launchFitMfma(hipStream_t stream, int degree, const FitBlock* dBlocks, uint32_t nBlocks, const FitTask* dTasks, double* dArena,
+                         double* dErrs, const DeviceTables* dTables, const FieldDev& field, const RootMap& rm, const uint32_t* dRange = nullptr);
 hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dXyz, size_t n,
                        double* dOut, double* dGrad, bool allInline, uint32_t* dDeferCount, uint32_t* dDeferIdx);
 hipError_t launchQueryRay(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dOrigins,

@@ -76,6 +76,7 @@ struct hpsdf_ctx {
     hipStream_t stream = nullptr;
     bool ownsStream = false;
     hpsdf::DeviceTables* dTables = nullptr;
+    bool fastFit = false;  // hpsdf_ctx_set_fast_fit: degrees >= 4 on the matrix cores (fit_mfma.hip), not bit-identical
     hpsdf::Workspace ws;
     // Scratch of the *_host entry points (host arrays in, host arrays out): one device buffer and one pinned buffer,
     // kept across calls -- a scalar Query(pt) through the C++ drop-in must not pay two hipMalloc/hipFree pairs.

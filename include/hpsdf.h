@@ -108,6 +108,13 @@ HPSDF_API int hpsdf_ctx_create(int device, void* stream, hpsdf_ctx** out);
 HPSDF_API int hpsdf_ctx_destroy(hpsdf_ctx* ctx);
 HPSDF_API int hpsdf_ctx_set_stream(hpsdf_ctx* ctx, void* stream);
 HPSDF_API int hpsdf_ctx_synchronize(hpsdf_ctx* ctx);
+/* Opt-in fast fit (default off).  on != 0: cell fits of degree >= 4 (Octree::FitPolynomial, Octree.cpp:1007-1093) run as
+ * a GEMM on the matrix cores (v_mfma_f64_16x16x4_f64; csrc/fit_mfma.hip) instead of the term-by-term kernel that
+ * reproduces the reference's summation order.  Coefficients then agree with the default path to ~1e-15 relative -- far
+ * inside 1e-6 -- but are NOT bit-identical to it, and refinement decisions that are exact ties in the default arithmetic
+ * may fall the other way.  Applies to unweighted builds of analytic, mesh and callback fields; everything
+ * else keeps the default kernel. */
+HPSDF_API int hpsdf_ctx_set_fast_fit(hpsdf_ctx* ctx, int on);
 HPSDF_API void* hpsdf_ctx_stream(hpsdf_ctx* ctx);
 
 /* ---- fields: the callback F of Octree::Create (Include/HP/Octree.h:50) ------ */

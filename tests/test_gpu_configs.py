@@ -276,3 +276,49 @@ def test_create_distributed_refuses_what_the_host_scheduler_owns(H, ctx):
     with pytest.raises(H.HpsdfError) as e:
         H.create_block_distributed(ctx, H.make_config(1e-6), H.Field.sphere(), 1024, 2, 2, lambda *a: None)
     assert e.value.status == H.ERR_INVALID_ARGUMENT
+
+
+# ------------------------------------------------------------------ the opt-in matrix-core fit (csrc/fit_mfma.hip)
+@pytest.mark.parametrize("name,target", [("union3", 1e-7), ("sphere", 1e-8), ("union3", 1e-8)])
+def test_fast_fit_within_tolerance_of_oracle(H, O, name, target):
+    """hpsdf_ctx_set_fast_fit: fits of degree >= 4 as a GEMM on v_mfma_f64_16x16x4_f64.  Not bit-identical by design;
+    the gate is the north_star's: topology identical to the CPU oracle's, coefficients and Query() within 1e-6."""
+    from helpers import oracle_field, product_field
+    fast = H.Context(0)
+    fast.set_fast_fit(True)
+    blk, st = H.create_block(fast, H.make_config(target), product_field(H, name), 1024)
+    want = O.Tree.create(O.default_config(target), oracle_field(O, name), 1024)
+    a, b = O.parse_block(blk), O.parse_block(want.to_block())
+    assert len(a["degree"]) == len(b["degree"])
+    assert np.array_equal(a["degree"], b["degree"]) and np.array_equal(a["childIdx"], b["childIdx"])
+    leaf = a["degree"][a["degree"] != 13]
+    assert leaf.max() >= 4  # the matrix-core kernel has actually produced leaves
+    assert np.abs(a["coeffs"] - b["coeffs"]).max() <= TOL
+    assert not np.array_equal(a["coeffs"], b["coeffs"])  # (and it is a different arithmetic: not the default kernel by accident)
+    pts = O.splitmix64_points(50000, seed=13)
+    assert np.abs(H.DeviceTree(fast, blk).query(pts) - want.query(pts)).max() <= TOL
+    fast.close()
+
+
+def test_fast_fit_mesh_and_callback_fields(H, O, ctx):
+    """The fast fit on sampled fields (mesh: samples from the BVH kernel; host callback: samples from host threads)."""
+    fast = H.Context(0)
+    fast.set_fast_fit(True)
+    verts, tris = _mesh()
+    cfg = H.make_config(1e-7, *MESH_ROOT)
+    want, _ = H.create_block(ctx, cfg, H.Field.mesh(ctx, verts, tris), 256)
+    got, st = H.create_block(fast, cfg, H.Field.mesh(fast, verts, tris), 256)
+    a, b = O.parse_block(got), O.parse_block(want)
+    assert np.array_equal(a["degree"], b["degree"]) and a["degree"][a["degree"] != 13].max() >= 4
+    assert np.abs(a["coeffs"] - b["coeffs"]).max() <= TOL
+
+    def sphere(p, _t):
+        dx, dy, dz = p[0] - 0.25, p[1], p[2]
+        return (dx * dx + (dy * dy + dz * dz)) ** 0.5 - 0.5
+    cfg = H.make_config(1e-9)
+    want, _ = H.create_block(ctx, cfg, H.Field.sphere(), 1024)
+    got, _ = H.create_block(fast, cfg, H.Field.callback(sphere), 1024)
+    a, b = O.parse_block(got), O.parse_block(want)
+    assert np.array_equal(a["degree"], b["degree"]) and a["degree"][a["degree"] != 13].max() >= 4
+    assert np.abs(a["coeffs"] - b["coeffs"]).max() <= TOL
+    fast.close()
