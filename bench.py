@@ -263,10 +263,17 @@ def main():
 
         fit = None
         if not args.no_fit_bench and rank == 0:
+            # Steady-state fit micro-benchmark: from-scratch fits of a lattice of depth-5 cells, per degree; the
+            # default bit-exact kernel and the opt-in matrix-core kernel (hpsdf_ctx_set_fast_fit, degrees 4..9), each with
+            # the headline field and with a field that costs nothing (contraction only).  Algorithmic flops:
+            # 2 ncoef(p) (4p+1)^3 per fit, against the FP64 peak (78.6 TFLOP/s, vector = matrix on this chip: measured
+            # 77.6 with back-to-back v_mfma_f64_16x16x4_f64, tools/mfma_f64_rate.hip).
             fit = {}
+            fast_ctx = H.Context(local, stream.cuda_stream)
+            fast_ctx.set_fast_fit(True)
             plane = H.Field.analytic([(H.PRIM_PLANE, H.OP_UNION, [0.3, -0.2, 0.5, 0.1])])  # F costs ~nothing: contraction only
-            for p in (2, 3, 4, 5, 6, 7, 8):  # p in {2..8}; degrees > 5 run the any-degree kernel
-                cells = 65536 if p <= 3 else (16384 if p <= 5 else 4096)
+            for p in (2, 3, 4, 5, 6, 7, 8):  # p in {2..8}; degrees > 5 run the any-degree kernel by default
+                cells = 65536 if p <= 3 else 16384
                 flops = 2.0 * H.NCOEF[p] * (4 * p + 1) ** 3 * cells
                 ms = H.bench_fit(ctx, cfg, field, p, 5, cells, 3)
                 ms_c = H.bench_fit(ctx, cfg, plane, p, 5, cells, 3)
@@ -274,6 +281,15 @@ def main():
                                   "frac_fp64_peak": flops / ms / 1e9 / FP64_PEAK_TFLOPS,
                                   "contraction_only_ms": ms_c, "contraction_only_tflops": flops / ms_c / 1e9,
                                   "contraction_only_frac_fp64_peak": flops / ms_c / 1e9 / FP64_PEAK_TFLOPS}
+                if p >= 4:
+                    fms = H.bench_fit(fast_ctx, cfg, field, p, 5, cells, 3)
+                    fms_c = H.bench_fit(fast_ctx, cfg, plane, p, 5, cells, 3)
+                    fit["p%d" % p]["fast_fit"] = {"kernel": "fit_mfma_kernel (v_mfma_f64_16x16x4_f64)", "ms": fms,
+                                                  "tflops_algorithmic": flops / fms / 1e9,
+                                                  "frac_fp64_peak": flops / fms / 1e9 / FP64_PEAK_TFLOPS,
+                                                  "contraction_only_ms": fms_c, "contraction_only_tflops": flops / fms_c / 1e9,
+                                                  "contraction_only_frac_fp64_peak": flops / fms_c / 1e9 / FP64_PEAK_TFLOPS}
+            fast_ctx.close()
 
     ms_per_step = wall * 1e3 / args.steps
     value = world * n * args.steps / wall / 1e6  # Mpts/s, whole job
