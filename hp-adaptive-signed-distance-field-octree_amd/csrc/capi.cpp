@@ -343,32 +343,52 @@ int hpsdf_field_create_mesh(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts,
     if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "mesh fields live in HBM: a device context is required");
     if (!verts || !tris || !out || nVerts == 0 || nTris == 0) return fail(HPSDF_ERR_INVALID_ARGUMENT, "empty mesh");
     if (nVerts > 0x7FFFFFFFull || nTris > 0x3FFFFFFFull) return fail(HPSDF_ERR_UNSUPPORTED, "mesh too large for 32-bit ids");
-    for (uint64_t i = 0; i < 3 * nTris; ++i)
-        if (tris[i] >= nVerts)
-            return fail(HPSDF_ERR_INVALID_ARGUMENT, "triangle " + std::to_string(i / 3) + " refers to vertex " + std::to_string(tris[i]) +
-                                                        " of " + std::to_string(nVerts));
-    HostMesh hm;
-    if (!prepareMesh(verts, nVerts, tris, nTris, &hm))
-        return fail(HPSDF_ERR_OPEN_MESH, "mesh is not closed: an edge has no twin (Mesh::CreateHalfEdges)");
     HPSDF_HIP(hipSetDevice(ctx->device));
     hpsdf_field* f = new hpsdf_field();
     f->kind = kHostMesh;
     f->device = ctx->device;
-    f->nVerts = (uint32_t)nVerts;
-    f->nTris = (uint32_t)nTris;
-    f->nBvhNodes = (uint32_t)hm.bvh.size();
-    auto up = [&](void** d, const void* h, size_t bytes) -> hipError_t {
-        hipError_t e = hipMalloc(d, bytes);
-        if (e != hipSuccess) return e;
-        return hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
-    };
-    hipError_t e = up((void**)&f->dVerts, hm.verts.data(), hm.verts.size() * sizeof(float));
-    if (e == hipSuccess) e = up((void**)&f->dTris, hm.tris.data(), hm.tris.size() * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void**)&f->dTriPos, hm.tris.size() * 3 * sizeof(float));
-    if (e == hipSuccess) e = launchMeshTriPos(ctx->stream, f->dVerts, f->dTris, nTris, f->dTriPos);  // after the blocking uploads
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess) e = up((void**)&f->dHalfEdges, hm.halfEdges.data(), hm.halfEdges.size() * sizeof(uint32_t));
-    if (e == hipSuccess) e = up((void**)&f->dBvh, hm.bvh.data(), hm.bvh.size() * sizeof(BvhNode));
+    hipError_t e = hipSuccess;
+    // half-edge twins and BVH on the device (mesh_build.hip); HPSDF_MESH_HOST_BUILD=1, non-manifold input and single
+    // triangles take the host preparation of mesh.cpp (same field values either way: any BVH gives the same distances)
+    int fallback = 1;
+    {
+        const char* hb = std::getenv("HPSDF_MESH_HOST_BUILD");
+        if (!(hb && hb[0] == '1')) {
+            const int brc = meshBuildDevice(ctx, verts, nVerts, tris, nTris, f, &fallback);
+            if (brc != HPSDF_OK) {
+                delete f;
+                return brc;
+            }
+        }
+    }
+    if (fallback) {
+        for (uint64_t i = 0; i < 3 * nTris; ++i)
+            if (tris[i] >= nVerts) {
+                delete f;
+                return fail(HPSDF_ERR_INVALID_ARGUMENT, "triangle " + std::to_string(i / 3) + " refers to vertex " + std::to_string(tris[i]) +
+                                                            " of " + std::to_string(nVerts));
+            }
+        HostMesh hm;
+        if (!prepareMesh(verts, nVerts, tris, nTris, &hm)) {
+            delete f;
+            return fail(HPSDF_ERR_OPEN_MESH, "mesh is not closed: an edge has no twin (Mesh::CreateHalfEdges)");
+        }
+        f->nVerts = (uint32_t)nVerts;
+        f->nTris = (uint32_t)nTris;
+        f->nBvhNodes = (uint32_t)hm.bvh.size();
+        auto up = [&](void** d, const void* h, size_t bytes) -> hipError_t {
+            hipError_t ue = hipMalloc(d, bytes);
+            if (ue != hipSuccess) return ue;
+            return hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
+        };
+        e = up((void**)&f->dVerts, hm.verts.data(), hm.verts.size() * sizeof(float));
+        if (e == hipSuccess) e = up((void**)&f->dTris, hm.tris.data(), hm.tris.size() * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&f->dTriPos, hm.tris.size() * 3 * sizeof(float));
+        if (e == hipSuccess) e = launchMeshTriPos(ctx->stream, f->dVerts, f->dTris, nTris, f->dTriPos);  // after the blocking uploads
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = up((void**)&f->dHalfEdges, hm.halfEdges.data(), hm.halfEdges.size() * sizeof(uint32_t));
+        if (e == hipSuccess) e = up((void**)&f->dBvh, hm.bvh.data(), hm.bvh.size() * sizeof(BvhNode));
+    }
 #ifdef HPSDF_MESH_STATS_BUILD
     if (e == hipSuccess && std::getenv("HPSDF_MESH_STATS")) {
         e = hipMalloc((void**)&f->dStats, 4 * sizeof(unsigned long long));
@@ -427,11 +447,15 @@ int hpsdf_field_destroy(hpsdf_field* f) {
     if (!f) return HPSDF_OK;
     if (f->kind == kHostMesh && f->device >= 0) {
         (void)hipSetDevice(f->device);
-        if (f->dVerts) (void)hipFree(f->dVerts);
-        if (f->dTris) (void)hipFree(f->dTris);
-        if (f->dTriPos) (void)hipFree(f->dTriPos);
-        if (f->dHalfEdges) (void)hipFree(f->dHalfEdges);
-        if (f->dBvh) (void)hipFree(f->dBvh);
+        if (f->dBlock) {
+            (void)hipFree(f->dBlock);
+        } else {
+            if (f->dVerts) (void)hipFree(f->dVerts);
+            if (f->dTris) (void)hipFree(f->dTris);
+            if (f->dTriPos) (void)hipFree(f->dTriPos);
+            if (f->dHalfEdges) (void)hipFree(f->dHalfEdges);
+            if (f->dBvh) (void)hipFree(f->dBvh);
+        }
         if (f->dStats) (void)hipFree(f->dStats);
     }
     delete f;

@@ -156,8 +156,10 @@ __device__ float meshSignedDistance(const MeshDev& m, V3 pt, uint32_t& hint) {
     };
     auto worthIt = [&](float d) { return !(d > best * 1.00001f + 1e-30f); };
     if (hint < m.nTris) visitTri(hint);
-    int32_t stack[48];
-    float stackD[48];
+    // one deferred sibling per level: the host's median-split tree is <= 31 levels deep, the device's linear BVH (63-bit
+    // Morton codes, equal codes split by position) at most 63 + 32
+    int32_t stack[96];
+    float stackD[96];
     int sp = 0;
     stack[sp] = 0;
     stackD[sp++] = 0.0f;
@@ -180,12 +182,12 @@ __device__ float meshSignedDistance(const MeshDev& m, V3 pt, uint32_t& hint) {
         if (worthIt(db)) {
             if (cb < 0)
                 visitTri((uint32_t)~cb);
-            else if (sp < 47) {
+            else if (sp < 95) {
                 stack[sp] = cb;
                 stackD[sp++] = db;
             }
         }
-        if (pushA >= 0 && sp < 48) {  // on top: popped next
+        if (pushA >= 0 && sp < 96) {  // on top: popped next
             stack[sp] = pushA;
             stackD[sp++] = da;
         }

@@ -1,0 +1,370 @@
+// Mesh preparation on the device: what Meshing::Mesh::CreateHalfEdges (Source/Meshing/Mesh.cpp:87-131) and
+// Meshing::BVH::Create (Source/Meshing/BVH.cpp:26-260) do on the CPU -- the twin of every half-edge, and a bounding
+// volume hierarchy over the triangles -- done where the mesh is going anyway.  mesh.cpp keeps the host versions (a
+// parallel median-split build): 0.15 s for 2.1 M triangles, ten times the Create that follows; this is a few ms.
+//
+// Twins.  A closed manifold mesh has every directed edge (a, b) exactly once and its reverse (b, a) exactly once.  All
+// directed edges go into an open-addressing table keyed by (a << 32 | b) (64-bit compare-and-swap); a second pass looks
+// (b, a) up.  For such meshes the result does not depend on insertion order, so it is what the reference's sequential
+// std::map pass gives.  A directed edge met twice (non-manifold) or a reverse that is missing (open mesh) is flagged;
+// the caller falls back to the host path for the first (whose sequential semantics it reproduces) and reports the
+// second as HPSDF_ERR_OPEN_MESH like the reference's `return false` (:121-128).
+//
+// BVH.  Any hierarchy gives the same distances (the traversal prunes only strictly farther boxes and breaks ties
+// towards the lower triangle index), so the reference's bottom-up pairing is not reproduced; this is a
+// linear BVH (Karras 2012): 63-bit Morton codes of the triangle-box centres, a stable radix sort (rocPRIM), every inner
+// node's range and split found independently from the sorted codes (equal codes ordered by position), boxes fitted
+// bottom-up by the second thread to reach a node.  Deterministic: the sort is stable, ranges and splits are pure
+// functions of the sorted keys, boxes are min / max.  Node layout as the traversal wants it: 64 bytes holding BOTH
+// children's boxes and references (>= 0 an inner node, < 0 the triangle ~c); node 0 is the root.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <chrono>
+#include <cstdlib>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "device_types.hpp"
+#include "launch.hpp"
+#include "runtime.hpp"
+
+namespace hpsdf {
+
+namespace {
+
+struct MeshBuildFlags {
+    unsigned long long badIndex;  // smallest corner (3 t + k) whose vertex index is out of range, or ~0
+    uint32_t nonManifold;         // a directed edge occurs twice
+    uint32_t open;                // a directed edge without its reverse
+    uint32_t boundsLo[3], boundsHi[3];  // scene box of the triangle-box centres, as order-preserving integers
+};
+
+__device__ __forceinline__ uint32_t orderedBits(float f) {  // monotone float -> uint
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float fromOrderedBits(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
+
+// u64 corner indices -> u32, range check
+__global__ __launch_bounds__(256) void mb_tris_kernel(const uint64_t* __restrict__ in, uint64_t nCorners, uint64_t nVerts,
+                                                      uint32_t* __restrict__ out, MeshBuildFlags* flags) {
+    const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= nCorners) return;
+    const uint64_t v = in[c];
+    if (v >= nVerts) {
+        atomicMin(&flags->badIndex, (unsigned long long)c);
+        out[c] = 0;
+    } else {
+        out[c] = (uint32_t)v;
+    }
+}
+
+// triangle boxes (as the host build: min / max of the three corners per axis), centres, scene bounds of the centres
+__global__ __launch_bounds__(256) void mb_boxes_kernel(const float* __restrict__ triPos, uint32_t nTris, float* __restrict__ triBox,
+                                                       MeshBuildFlags* flags) {
+    __shared__ uint32_t sLo[3], sHi[3];
+    if (threadIdx.x < 3) sLo[threadIdx.x] = 0xFFFFFFFFu, sHi[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t < nTris) {
+        const float* p = triPos + 9 * (size_t)t;
+        for (int a = 0; a < 3; ++a) {
+            const float lo = fminf(p[a], fminf(p[3 + a], p[6 + a])), hi = fmaxf(p[a], fmaxf(p[3 + a], p[6 + a]));
+            triBox[6 * (size_t)t + a] = lo;
+            triBox[6 * (size_t)t + 3 + a] = hi;
+            const uint32_t c = orderedBits(0.5f * (lo + hi));
+            atomicMin(&sLo[a], c);
+            atomicMax(&sHi[a], c);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        atomicMin(&flags->boundsLo[threadIdx.x], sLo[threadIdx.x]);
+        atomicMax(&flags->boundsHi[threadIdx.x], sHi[threadIdx.x]);
+    }
+}
+
+__device__ __forceinline__ uint64_t spread21(uint32_t v) {  // 21 bits -> every third bit
+    uint64_t x = v & 0x1FFFFFu;
+    x = (x | (x << 32)) & 0x1F00000000FFFFull;
+    x = (x | (x << 16)) & 0x1F0000FF0000FFull;
+    x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+    x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void mb_morton_kernel(const float* __restrict__ triBox, uint32_t nTris, const MeshBuildFlags* flags,
+                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ ids) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= nTris) return;
+    uint64_t code = 0;
+    for (int a = 0; a < 3; ++a) {
+        const float lo = fromOrderedBits(flags->boundsLo[a]), hi = fromOrderedBits(flags->boundsHi[a]);
+        const float c = 0.5f * (triBox[6 * (size_t)t + a] + triBox[6 * (size_t)t + 3 + a]);
+        const float ext = hi - lo;
+        float u = ext > 0.0f ? (c - lo) / ext : 0.0f;
+        u = fminf(fmaxf(u, 0.0f), 1.0f);
+        const uint32_t q = (uint32_t)fminf(u * 2097152.0f, 2097151.0f);
+        code |= spread21(q) << (2 - a);
+    }
+    keys[t] = code;
+    ids[t] = t;
+}
+
+// common-prefix length of sorted keys i and j (Karras): equal codes are told apart by their position
+__device__ __forceinline__ int mbDelta(const uint64_t* __restrict__ keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    const uint64_t a = keys[i], b = keys[j];
+    if (a != b) return __clzll((long long)(a ^ b));
+    return 64 + __clz(i ^ j);
+}
+
+// inner node i of n - 1: its range of sorted leaves and its split
+__global__ __launch_bounds__(256) void mb_hierarchy_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ ids, int n,
+                                                           BvhNode* __restrict__ nodes, int32_t* __restrict__ parent /* [2n - 1]: inner 0..n-2, leaves n-1.. */) {
+    const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (i >= n - 1) return;
+    const int d = mbDelta(keys, n, i, i + 1) - mbDelta(keys, n, i, i - 1) >= 0 ? 1 : -1;
+    const int dmin = mbDelta(keys, n, i, i - d);
+    int lmax = 2;
+    while (mbDelta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (mbDelta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = mbDelta(keys, n, i, j);
+    int s = 0;
+    for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
+        if (mbDelta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+        if (t == 1) break;
+    }
+    const int gamma = i + s * d + (d < 0 ? d : 0);
+    const int lo = d > 0 ? i : j, hi = d > 0 ? j : i;
+    const bool leaf0 = lo == gamma, leaf1 = hi == gamma + 1;
+    BvhNode& nd = nodes[i];
+    nd.c0 = leaf0 ? ~(int32_t)ids[gamma] : gamma;
+    nd.c1 = leaf1 ? ~(int32_t)ids[gamma + 1] : gamma + 1;
+    nd.pad[0] = nd.pad[1] = 0;
+    parent[leaf0 ? (n - 1) + gamma : gamma] = i * 2;          // (child slot in the low bit)
+    parent[leaf1 ? (n - 1) + gamma + 1 : gamma + 1] = i * 2 + 1;
+    if (i == 0) parent[0] = -1;
+}
+
+// boxes bottom-up: one thread per leaf; the second thread to reach a node owns it from there.  The hand-over between the
+// two threads (possibly on different XCDs, i.e. behind different L2s) goes through agent-scope atomic stores and loads of
+// the box (three 8-byte words) ordered against the arrival counter by a plain s_waitcnt: a __threadfence() per level
+// writes the XCD's L2 back each time and made this kernel 12 ms for 2 M triangles (now well under one).
+__global__ __launch_bounds__(256) void mb_fit_kernel(const uint32_t* __restrict__ ids, const float* __restrict__ triBox, int n,
+                                                     BvhNode* __restrict__ nodes, const int32_t* __restrict__ parent, uint32_t* __restrict__ arrived) {
+    const int leaf = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (leaf >= n) return;
+    const uint32_t t = ids[leaf];
+    union Box {
+        float f[6];  // lo xyz, hi xyz: the node's lo0[3] hi0[3] (or lo1 hi1) in memory order
+        unsigned long long w[3];
+    } box;
+    for (int a = 0; a < 6; ++a) box.f[a] = triBox[6 * (size_t)t + a];
+    int32_t p = parent[(n - 1) + leaf];
+    while (p >= 0) {
+        const int node = p >> 1, slot = p & 1;
+        BvhNode& nd = nodes[node];
+        unsigned long long* mine = reinterpret_cast<unsigned long long*>(slot ? nd.lo1 : nd.lo0);
+        unsigned long long* other = reinterpret_cast<unsigned long long*>(slot ? nd.lo0 : nd.lo1);
+        for (int k = 0; k < 3; ++k) __hip_atomic_store(mine + k, box.w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the box has reached the coherence point before the arrival does
+        if (__hip_atomic_fetch_add(&arrived[node], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;  // the sibling carries on
+        Box sib;
+        for (int k = 0; k < 3; ++k) sib.w[k] = __hip_atomic_load(other + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int a = 0; a < 3; ++a) {
+            box.f[a] = fminf(box.f[a], sib.f[a]);
+            box.f[3 + a] = fmaxf(box.f[3 + a], sib.f[3 + a]);
+        }
+        p = parent[node];
+    }
+}
+
+// ---- twins
+__device__ __forceinline__ uint64_t mbHash(uint64_t k) {
+    k *= 0x9E3779B97F4A7C15ull;
+    return k ^ (k >> 29);
+}
+__global__ __launch_bounds__(256) void mb_edges_insert_kernel(const uint32_t* __restrict__ tris, uint64_t nCorners, unsigned long long* __restrict__ tabKey,
+                                                              uint32_t* __restrict__ tabVal, uint64_t mask, MeshBuildFlags* flags) {
+    const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= nCorners) return;
+    const uint32_t a = tris[c], b = (c % 3 == 2) ? tris[c - 2] : tris[c + 1];  // Mesh.cpp:96-103
+    const unsigned long long key = ((unsigned long long)a << 32) | b;
+    uint64_t s = mbHash(key) & mask;
+    for (;;) {
+        const unsigned long long old = atomicCAS(&tabKey[s], ~0ull, key);
+        if (old == ~0ull) {
+            tabVal[s] = (uint32_t)c;
+            return;
+        }
+        if (old == key) {  // the same directed edge twice
+            atomicOr(&flags->nonManifold, 1u);
+            return;
+        }
+        s = (s + 1) & mask;
+    }
+}
+__global__ __launch_bounds__(256) void mb_edges_lookup_kernel(const uint32_t* __restrict__ tris, uint64_t nCorners, const unsigned long long* __restrict__ tabKey,
+                                                              const uint32_t* __restrict__ tabVal, uint64_t mask, uint32_t* __restrict__ halfEdges,
+                                                              MeshBuildFlags* flags) {
+    const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= nCorners) return;
+    const uint32_t a = tris[c], b = (c % 3 == 2) ? tris[c - 2] : tris[c + 1];
+    const unsigned long long rev = ((unsigned long long)b << 32) | a;
+    uint64_t s = mbHash(rev) & mask;
+    for (;;) {
+        const unsigned long long k = tabKey[s];
+        if (k == rev) {
+            halfEdges[c] = tabVal[s];
+            return;
+        }
+        if (k == ~0ull) {
+            halfEdges[c] = 0xFFFFFFFFu;
+            atomicOr(&flags->open, 1u);
+            return;
+        }
+        s = (s + 1) & mask;
+    }
+}
+
+}  // namespace
+
+// Everything a mesh field needs, from host arrays.  Returns HPSDF_OK and fills the device pointers, or an error / a
+// request to fall back: *fallback = 1 asks the caller to run the host preparation instead (non-manifold input, or a mesh
+// too small to be worth it); device buffers are released on any non-OK return.
+int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const uint64_t* tris, uint64_t nTris, hpsdf_field* f, int* fallback) {
+    *fallback = 0;
+    const bool trace = std::getenv("HPSDF_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    if (nTris < 2) {
+        *fallback = 1;
+        return HPSDF_OK;
+    }
+    hipStream_t s = ctx->stream;
+    const uint64_t nCorners = 3 * nTris;
+    const int n = (int)nTris;
+    uint64_t* dTris64 = nullptr;
+    float* dTriBox = nullptr;
+    uint64_t *dKeys = nullptr, *dKeysOut = nullptr;
+    uint32_t *dIds = nullptr, *dIdsOut = nullptr, *dArrived = nullptr, *dTabVal = nullptr;
+    unsigned long long* dTabKey = nullptr;
+    int32_t* dParent = nullptr;
+    MeshBuildFlags* dFlags = nullptr;
+    void* dSortTmp = nullptr;
+    size_t sortTmpBytes = 0;
+    uint64_t tabSize = 1;
+    while (tabSize < 2 * nCorners) tabSize <<= 1;
+    MeshBuildFlags hf;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, sortTmpBytes, dKeys, dKeysOut, dIds, dIdsOut, (size_t)nTris, 0, 63, s);
+    // two allocations in all (hipMalloc / hipFree cost ~0.1-0.3 ms apiece): the field's five arrays, and the temporaries
+    char* fieldBlock = nullptr;
+    char* tempBlock = nullptr;
+    {
+        auto carve = [](size_t& at, size_t bytes) {
+            const size_t o = at;
+            at = (at + bytes + 255) & ~(size_t)255;
+            return o;
+        };
+        size_t fb = 0;
+        const size_t oVerts = carve(fb, 3 * nVerts * sizeof(float)), oTris = carve(fb, nCorners * sizeof(uint32_t)),
+                     oTriPos = carve(fb, nCorners * 3 * sizeof(float)), oHe = carve(fb, nCorners * sizeof(uint32_t)),
+                     oBvh = carve(fb, (size_t)(n - 1) * sizeof(BvhNode));
+        size_t tb = 0;
+        const size_t oT64 = carve(tb, nCorners * sizeof(uint64_t)), oBox = carve(tb, 6 * nTris * sizeof(float)),
+                     oK = carve(tb, nTris * sizeof(uint64_t)), oK2 = carve(tb, nTris * sizeof(uint64_t)), oI = carve(tb, nTris * sizeof(uint32_t)),
+                     oI2 = carve(tb, nTris * sizeof(uint32_t)), oArr = carve(tb, nTris * sizeof(uint32_t)),
+                     oPar = carve(tb, 2 * nTris * sizeof(int32_t)), oTK = carve(tb, tabSize * sizeof(unsigned long long)),
+                     oTV = carve(tb, tabSize * sizeof(uint32_t)), oFl = carve(tb, sizeof(MeshBuildFlags)),
+                     oSort = carve(tb, sortTmpBytes ? sortTmpBytes : 16);
+        if (e == hipSuccess) e = hipMalloc((void**)&fieldBlock, fb);
+        if (e == hipSuccess) e = hipMalloc((void**)&tempBlock, tb);
+        if (e == hipSuccess) {
+            f->dBlock = fieldBlock;
+            f->dVerts = (float*)(fieldBlock + oVerts), f->dTris = (uint32_t*)(fieldBlock + oTris), f->dTriPos = (float*)(fieldBlock + oTriPos);
+            f->dHalfEdges = (uint32_t*)(fieldBlock + oHe), f->dBvh = (BvhNode*)(fieldBlock + oBvh);
+            dTris64 = (uint64_t*)(tempBlock + oT64), dTriBox = (float*)(tempBlock + oBox), dKeys = (uint64_t*)(tempBlock + oK);
+            dKeysOut = (uint64_t*)(tempBlock + oK2), dIds = (uint32_t*)(tempBlock + oI), dIdsOut = (uint32_t*)(tempBlock + oI2);
+            dArrived = (uint32_t*)(tempBlock + oArr), dParent = (int32_t*)(tempBlock + oPar), dTabKey = (unsigned long long*)(tempBlock + oTK);
+            dTabVal = (uint32_t*)(tempBlock + oTV), dFlags = (MeshBuildFlags*)(tempBlock + oFl), dSortTmp = tempBlock + oSort;
+        }
+    }
+    auto freeTemps = [&] {
+        if (tempBlock) (void)hipFree(tempBlock);
+        tempBlock = nullptr;
+    };
+    auto freeField = [&] {
+        if (fieldBlock) (void)hipFree(fieldBlock);
+        fieldBlock = nullptr;
+        f->dBlock = nullptr;
+        f->dVerts = nullptr, f->dTris = nullptr, f->dTriPos = nullptr, f->dHalfEdges = nullptr, f->dBvh = nullptr;
+    };
+    const double t1 = now();
+    if (e == hipSuccess) e = hipMemcpyAsync(f->dVerts, verts, 3 * nVerts * sizeof(float), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dTris64, tris, nCorners * sizeof(uint64_t), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        std::memset(&hf, 0, sizeof hf);
+        hf.badIndex = ~0ull;
+        for (int a = 0; a < 3; ++a) hf.boundsLo[a] = 0xFFFFFFFFu, hf.boundsHi[a] = 0u;
+        e = hipMemcpyAsync(dFlags, &hf, sizeof hf, hipMemcpyHostToDevice, s);
+    }
+    if (e == hipSuccess) e = hipMemsetAsync(dTabKey, 0xFF, tabSize * sizeof(unsigned long long), s);
+    if (e == hipSuccess) e = hipMemsetAsync(dArrived, 0, nTris * sizeof(uint32_t), s);
+    if (e != hipSuccess) {
+        freeTemps(), freeField();
+        return hipFail(e, "mesh preparation buffers");
+    }
+    const double t2 = now();
+    const unsigned gc = (unsigned)((nCorners + 255) / 256), gt = (unsigned)((nTris + 255) / 256);
+    hipLaunchKernelGGL(mb_tris_kernel, dim3(gc), dim3(256), 0, s, dTris64, nCorners, nVerts, f->dTris, dFlags);
+    e = launchMeshTriPos(s, f->dVerts, f->dTris, nTris, f->dTriPos);
+    hipLaunchKernelGGL(mb_boxes_kernel, dim3(gt), dim3(256), 0, s, f->dTriPos, (uint32_t)nTris, dTriBox, dFlags);
+    hipLaunchKernelGGL(mb_morton_kernel, dim3(gt), dim3(256), 0, s, dTriBox, (uint32_t)nTris, dFlags, dKeys, dIds);
+    if (e == hipSuccess) e = rocprim::radix_sort_pairs(dSortTmp, sortTmpBytes, dKeys, dKeysOut, dIds, dIdsOut, (size_t)nTris, 0, 63, s);
+    hipLaunchKernelGGL(mb_hierarchy_kernel, dim3(gt), dim3(256), 0, s, dKeysOut, dIdsOut, n, f->dBvh, dParent);
+    hipLaunchKernelGGL(mb_fit_kernel, dim3(gt), dim3(256), 0, s, dIdsOut, dTriBox, n, f->dBvh, dParent, dArrived);
+    hipLaunchKernelGGL(mb_edges_insert_kernel, dim3(gc), dim3(256), 0, s, f->dTris, nCorners, dTabKey, dTabVal, tabSize - 1, dFlags);
+    hipLaunchKernelGGL(mb_edges_lookup_kernel, dim3(gc), dim3(256), 0, s, f->dTris, nCorners, dTabKey, dTabVal, tabSize - 1, f->dHalfEdges, dFlags);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&hf, dFlags, sizeof hf, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    const double t3 = now();
+    freeTemps();
+    if (trace)
+        std::fprintf(stderr, "[meshBuildDevice] %llu triangles, ms: allocations %.2f, uploads (issue) %.2f, kernels + wait %.2f, frees %.2f\n",
+                     (unsigned long long)nTris, t1 - t0, t2 - t1, t3 - t2, now() - t3);
+    if (e != hipSuccess) {
+        freeField();
+        return hipFail(e, "mesh preparation");
+    }
+    if (hf.badIndex != ~0ull) {
+        freeField();
+        return fail(HPSDF_ERR_INVALID_ARGUMENT, "triangle " + std::to_string(hf.badIndex / 3) + " refers to a vertex beyond the " +
+                                                    std::to_string(nVerts) + " given");
+    }
+    if (hf.nonManifold) {  // the reference's sequential pairing decides such meshes: the host path reproduces it
+        freeField();
+        *fallback = 1;
+        return HPSDF_OK;
+    }
+    if (hf.open) {
+        freeField();
+        return fail(HPSDF_ERR_OPEN_MESH, "mesh is not closed: an edge has no twin (Mesh::CreateHalfEdges)");
+    }
+    f->nVerts = (uint32_t)nVerts;
+    f->nTris = (uint32_t)nTris;
+    f->nBvhNodes = (uint32_t)(nTris - 1);
+    return HPSDF_OK;
+}
+
+}  // namespace hpsdf

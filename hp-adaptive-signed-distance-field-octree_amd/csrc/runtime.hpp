@@ -119,6 +119,7 @@ struct hpsdf_field {
     void* user = nullptr;
     // mesh (device resident)
     int device = -1;
+    void* dBlock = nullptr;  // device-built meshes: ONE allocation holding the five arrays below (which then are not freed singly)
     float* dVerts = nullptr;
     uint32_t* dTris = nullptr;
     float* dTriPos = nullptr;
@@ -176,5 +177,7 @@ struct HostMesh {
 };
 // returns false when the mesh is not closed (Mesh::CreateHalfEdges, Mesh.cpp:87-131)
 bool prepareMesh(const float* verts, uint64_t nVerts, const uint64_t* tris, uint64_t nTris, HostMesh* out);
+// the same on the device (mesh_build.hip): fills f's device pointers; *fallback = 1 asks for prepareMesh instead
+int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const uint64_t* tris, uint64_t nTris, hpsdf_field* f, int* fallback);
 
 }  // namespace hpsdf
