@@ -71,7 +71,7 @@ int makeFieldDev(const hpsdf_field* f, const double* dSamples, FieldDev* out) {
             out->mesh.verts = f->dVerts;
             out->mesh.tris = f->dTris;
             out->mesh.halfEdges = f->dHalfEdges;
-            out->mesh.triPos = f->dTriPos;
+            out->mesh.triPos = reinterpret_cast<const float4*>(f->dTriPos);
             out->mesh.bvh = f->dBvh;
             out->mesh.nTris = f->nTris;
             out->mesh.nNodes = f->nBvhNodes;
@@ -383,7 +383,7 @@ int hpsdf_field_create_mesh(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts,
         };
         e = up((void**)&f->dVerts, hm.verts.data(), hm.verts.size() * sizeof(float));
         if (e == hipSuccess) e = up((void**)&f->dTris, hm.tris.data(), hm.tris.size() * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc((void**)&f->dTriPos, hm.tris.size() * 3 * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&f->dTriPos, (size_t)nTris * kTriRecordFloats * sizeof(float));
         if (e == hipSuccess) e = launchMeshTriPos(ctx->stream, f->dVerts, f->dTris, nTris, f->dTriPos);  // after the blocking uploads
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e == hipSuccess) e = up((void**)&f->dHalfEdges, hm.halfEdges.data(), hm.halfEdges.size() * sizeof(uint32_t));

@@ -1,5 +1,7 @@
 // Structures shared between the host runtime and the gfx950 kernels.
 #pragma once
+#include <hip/hip_vector_types.h>
+
 #include <cstdint>
 
 #include "../../include/hpsdf.h"
@@ -65,7 +67,7 @@ static_assert(sizeof(BvhNode) == 64, "one line per node");
 struct MeshDev {
     const float* verts;        // xyz per vertex
     const uint32_t* tris;      // 3 vertex ids per triangle
-    const float* triPos;       // the 9 vertex coordinates of every triangle, gathered: a closest-point test is ONE
+    const float4* triPos;      // 3 x float4 per triangle: its 9 vertex coordinates and its normal, gathered: a closest-point test is ONE
                                // fetch instead of a chain of index -> vertex fetches (same values, same arithmetic)
     const uint32_t* halfEdges; // twin half-edge per half-edge (Mesh.h:74)
     const BvhNode* bvh;        // node 0 is the root

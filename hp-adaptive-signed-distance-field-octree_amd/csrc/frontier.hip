@@ -149,9 +149,14 @@ __host__ __device__ inline void frShape(int degree, bool incr, uint32_t count, i
     const int nrows = incr ? (int)(frCoef(degree) - frCoef(degree - 1)) : (int)frCoef(degree);
     int gmax = nrows > kFitBlockThreads ? 1 : kFitBlockThreads / nrows;
     while (gmax > 1 && frLds(degree, gmax, 1) > kFitMaxLdsBytes) --gmax;
-    const uint32_t spread = (count + 511u) / 512u;
+    uint32_t spread = (count + 511u) / 512u;
+    int cap = gmax;
+    if (degree == 2) {  // as fitShape: measured best for degree 2
+        if (count <= 4096u) spread = (count + 1023u) / 1024u;
+        cap = gmax < 16 ? gmax : 16;
+    }
     int g = (int)(spread < 1u ? 1u : spread);
-    g = g < gmax ? g : gmax;
+    g = g < cap ? g : cap;
     const int nq = 4 * degree + 1;
     int pl = nq;
     while (pl > 1 && frLds(degree, g, pl) > kFitChunkLdsBytes) --pl;

@@ -55,7 +55,9 @@ __device__ __forceinline__ V3 meshVert(const MeshDev& m, uint32_t i) {
 constexpr float kEpsF32 = 0.000001f;  // Include/Utility/Literals.h:13
 
 // returns simplex*4 + simplexIdx; closest point in q
-__device__ int closestSimplex(V3 pt, V3 a, V3 b, V3 c, V3& q) {
+// (n: the triangle's unnormalised normal cross(b - a, c - a), precomputed per triangle by mesh_tripos_kernel with these very
+// operations -- the value the reference recomputes in every call, Utility.cpp:41)
+__device__ int closestSimplex(V3 pt, V3 a, V3 b, V3 c, V3 n, V3& q) {
     const V3 ab = b - a, ac = c - a, bc = c - b;
     const float snom = dot(pt - a, ab), sdenom = dot(pt - b, a - b);
     const float tnom = dot(pt - a, ac), tdenom = dot(pt - c, a - c);
@@ -72,7 +74,6 @@ __device__ int closestSimplex(V3 pt, V3 a, V3 b, V3 c, V3& q) {
         q = c;
         return 2;
     }
-    const V3 n = cross(b - a, c - a);
     const float vc = dot(n, cross(a - pt, b - pt));
     if (vc < kEpsF32 && snom > kEpsF32 && sdenom > kEpsF32) {
         q = a + (snom / (snom + sdenom)) * ab;
@@ -138,8 +139,8 @@ __device__ float meshSignedDistance(const MeshDev& m, V3 pt, uint32_t& hint) {
     V3 bestQ = {0.0f, 0.0f, 0.0f};
     auto visitTri = [&](uint32_t t) {
         V3 q;
-        const float* tp = m.triPos + 9 * (size_t)t;
-        const int code = closestSimplex(pt, V3{tp[0], tp[1], tp[2]}, V3{tp[3], tp[4], tp[5]}, V3{tp[6], tp[7], tp[8]}, q);
+        const float4 tp[3] = {m.triPos[3 * (size_t)t], m.triPos[3 * (size_t)t + 1], m.triPos[3 * (size_t)t + 2]};
+        const int code = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, q);
         const float d = sqnorm(pt - q);
         if (d < best || (d == best && t < bestTri)) {
             best = d;
@@ -215,8 +216,8 @@ __device__ float meshSignedDistanceWave(const MeshDev& m, V3 pt, bool active, ui
     V3 bestQ = {0.0f, 0.0f, 0.0f};
     auto visitTri = [&](uint32_t t) {
         V3 q;
-        const float* tp = m.triPos + 9 * (size_t)t;
-        const int code = closestSimplex(pt, V3{tp[0], tp[1], tp[2]}, V3{tp[3], tp[4], tp[5]}, V3{tp[6], tp[7], tp[8]}, q);
+        const float4 tp[3] = {m.triPos[3 * (size_t)t], m.triPos[3 * (size_t)t + 1], m.triPos[3 * (size_t)t + 2]};
+        const int code = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, q);
         const float d = sqnorm(pt - q);
         if (d < best || (d == best && t < bestTri)) {
             best = d;
@@ -338,8 +339,8 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool active, M
         const V3 p = {__shfl(pt.x, src, 64), __shfl(pt.y, src, 64), __shfl(pt.z, src, 64)};
         if (on) {
             V3 q;
-            const float* tp = m.triPos + 9 * (size_t)t;
-            closestSimplex(p, V3{tp[0], tp[1], tp[2]}, V3{tp[3], tp[4], tp[5]}, V3{tp[6], tp[7], tp[8]}, q);
+            const float4 tp[3] = {m.triPos[3 * (size_t)t], m.triPos[3 * (size_t)t + 1], m.triPos[3 * (size_t)t + 2]};
+            closestSimplex(p, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, q);
             const float d = sqnorm(p - q);
             atomicMin(&L.best[src], ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)t);
         }
@@ -406,8 +407,8 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool active, M
     if (active) {
         const uint32_t bestTri = (uint32_t)(L.best[lane] & 0xFFFFFFFFull);
         V3 bestQ;
-        const float* tp = m.triPos + 9 * (size_t)bestTri;
-        const int bestCode = closestSimplex(pt, V3{tp[0], tp[1], tp[2]}, V3{tp[3], tp[4], tp[5]}, V3{tp[6], tp[7], tp[8]}, bestQ);
+        const float4 tp[3] = {m.triPos[3 * (size_t)bestTri], m.triPos[3 * (size_t)bestTri + 1], m.triPos[3 * (size_t)bestTri + 2]};
+        const int bestCode = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, bestQ);
         const V3 nrm = pseudoNormal(m, bestTri, bestCode);
         const V3 d = pt - bestQ;
         const float sign = dot(nrm, d) > 0.0f ? 1.0f : -1.0f;
@@ -1718,6 +1719,10 @@ FitShape fitShape(int degree, int nrows, uint32_t count, bool weighted, bool lat
     // enough workgroups to cover the chip twice before cells are stacked into one workgroup
     int g = sh.cellsPerThread > 1 ? gmax
                                   : (int)std::min<uint32_t>((uint32_t)gmax, std::max<uint32_t>(1, (count + 511) / 512));
+    // degree 2 (25 cells fit a workgroup): a round-0-sized launch is fastest at 4 cells per workgroup, big ones at 16
+    // (tools/fit_shape_sweep.py: 4096 cells 53 -> 45 us; 32 768 cells 251 -> 211 us)
+    if (degree == 2 && sh.cellsPerThread == 1)
+        g = (int)std::min<uint32_t>(std::min(gmax, 16), std::max<uint32_t>(1, count <= 4096 ? (count + 1023) / 1024 : (count + 511) / 512));
     // Mesh fields: phase 1 is a chain of dependent BVH-node gathers per sample (measured on a 1.3 M-triangle mesh,
     // 4096 coarse cells: 206 ms with 8 cells per workgroup, 176 / 151 / 128 ms with 4 / 2 / 1) -- many small
     // workgroups keep more waves in flight and shorten the wait for the slowest lane of a chunk.
@@ -1806,8 +1811,8 @@ __global__ __launch_bounds__(256) void mesh_naive_kernel(MeshDev m, const double
     V3 bestQ = {0.0f, 0.0f, 0.0f};
     for (uint32_t t = (uint32_t)lane; t < m.nTris; t += 64u) {
         V3 q;
-        const float* tp = m.triPos + 9 * (size_t)t;
-        const int code = closestSimplex(pt, V3{tp[0], tp[1], tp[2]}, V3{tp[3], tp[4], tp[5]}, V3{tp[6], tp[7], tp[8]}, q);
+        const float4 tp[3] = {m.triPos[3 * (size_t)t], m.triPos[3 * (size_t)t + 1], m.triPos[3 * (size_t)t + 2]};
+        const int code = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, q);
         const float d = sqnorm(pt - q);
         if (d < best) best = d, bestTri = t, bestCode = code, bestQ = q;
     }
@@ -1837,20 +1842,26 @@ hipError_t launchMeshNaive(hipStream_t stream, const FieldDev& f, const double* 
     return hipGetLastError();
 }
 
-// MeshDev::triPos: the nine coordinates of every triangle, gathered once per mesh
+// MeshDev::triPos: per triangle one 48-byte record -- the nine vertex coordinates and the unnormalised normal
+// cross(b - a, c - a) -- gathered once per mesh: a closest-point test is three 16-byte loads instead of index -> vertex chains
 __global__ __launch_bounds__(256) void mesh_tripos_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ tris,
-                                                          uint64_t nCorners, float* __restrict__ triPos) {
-    const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;  // corner = 3 * triangle + k
-    if (c >= nCorners) return;
-    const uint64_t v = tris[c];
-    triPos[3 * c] = verts[3 * v], triPos[3 * c + 1] = verts[3 * v + 1], triPos[3 * c + 2] = verts[3 * v + 2];
+                                                          uint64_t nTris, float4* __restrict__ triPos) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nTris) return;
+    const uint32_t ia = tris[3 * t], ib = tris[3 * t + 1], ic = tris[3 * t + 2];
+    const V3 a = {verts[3 * (size_t)ia], verts[3 * (size_t)ia + 1], verts[3 * (size_t)ia + 2]};
+    const V3 b = {verts[3 * (size_t)ib], verts[3 * (size_t)ib + 1], verts[3 * (size_t)ib + 2]};
+    const V3 c = {verts[3 * (size_t)ic], verts[3 * (size_t)ic + 1], verts[3 * (size_t)ic + 2]};
+    const V3 n = cross(b - a, c - a);
+    triPos[3 * t] = make_float4(a.x, a.y, a.z, b.x);
+    triPos[3 * t + 1] = make_float4(b.y, b.z, c.x, c.y);
+    triPos[3 * t + 2] = make_float4(c.z, n.x, n.y, n.z);
 }
 
 hipError_t launchMeshTriPos(hipStream_t stream, const float* dVerts, const uint32_t* dTris, uint64_t nTris, float* dTriPos) {
     if (nTris == 0) return hipSuccess;
-    const uint64_t nCorners = 3 * nTris;
-    hipLaunchKernelGGL(mesh_tripos_kernel, dim3((unsigned)((nCorners + 255) / 256)), dim3(256), 0, stream, dVerts, dTris, nCorners,
-                       dTriPos);
+    hipLaunchKernelGGL(mesh_tripos_kernel, dim3((unsigned)((nTris + 255) / 256)), dim3(256), 0, stream, dVerts, dTris, nTris,
+                       reinterpret_cast<float4*>(dTriPos));
     return hipGetLastError();
 }
 

@@ -46,6 +46,7 @@ hipError_t launchFieldEval(hipStream_t stream, const FieldDev& f, const DeviceTa
                            size_t n, double* dOut);
 // mesh field, linear scan over all triangles (no BVH): Mesh::SignedDistanceAtPt(pt), Mesh.cpp:42-51,134-159
 hipError_t launchMeshNaive(hipStream_t stream, const FieldDev& f, const double* dXyz, size_t n, double* dOut);
+constexpr int kTriRecordFloats = 12;  // MeshDev::triPos: a, b, c, cross(b - a, c - a)
 hipError_t launchMeshTriPos(hipStream_t stream, const float* dVerts, const uint32_t* dTris, uint64_t nTris, float* dTriPos);
 // mesh fields: F at every sample of nTasks fits of one degree -> dSamples[FitTask::sampleOff + sample]
 hipError_t launchMeshSample(hipStream_t stream, const FitTask* dTasks, uint32_t nTasks, int degree, const DeviceTables* dTables,

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void mb_boxes_kernel(const float* __restrict__
     __syncthreads();
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t < nTris) {
-        const float* p = triPos + 9 * (size_t)t;
+        const float* p = triPos + (size_t)kTriRecordFloats * t;  // a xyz, b xyz, c xyz, normal
         for (int a = 0; a < 3; ++a) {
             const float lo = fminf(p[a], fminf(p[3 + a], p[6 + a])), hi = fmaxf(p[a], fmaxf(p[3 + a], p[6 + a]));
             triBox[6 * (size_t)t + a] = lo;
@@ -278,7 +278,7 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
         };
         size_t fb = 0;
         const size_t oVerts = carve(fb, 3 * nVerts * sizeof(float)), oTris = carve(fb, nCorners * sizeof(uint32_t)),
-                     oTriPos = carve(fb, nCorners * 3 * sizeof(float)), oHe = carve(fb, nCorners * sizeof(uint32_t)),
+                     oTriPos = carve(fb, (size_t)nTris * kTriRecordFloats * sizeof(float)), oHe = carve(fb, nCorners * sizeof(uint32_t)),
                      oBvh = carve(fb, (size_t)(n - 1) * sizeof(BvhNode));
         size_t tb = 0;
         const size_t oT64 = carve(tb, nCorners * sizeof(uint64_t)), oBox = carve(tb, 6 * nTris * sizeof(float)),
