@@ -50,3 +50,33 @@ for k, d in summary.get("pmc", {}).items():
                             "fetch_kb": d["FETCH_SIZE"], "write_kb": d["WRITE_SIZE"]}
         print("query_kernel HBM bytes/launch: raw %.0f, with the gfx950 x2 read correction %.0f" % (raw, corrected))
 json.dump(summary, open(os.path.join(out, "summary.json"), "w"), indent=1)
+# the headline kernel's launches inside bench.py's timed region (after the warm-up launches, before the cell-sorted ones),
+# from the trace's own timestamps: the figure bench.py's HIP-event average (roofline.avg_launch_ms) has to agree with
+try:
+    import csv, glob
+    line = [l for l in open(os.path.join(out, "bench_trace.log")) if l.startswith("{")][0]
+    b = json.loads(line)
+    tr = glob.glob(os.path.join(out, "trace", "*", "*_kernel_trace.csv"))[0]
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(tr))
+         if r["Kernel_Name"].startswith("void hpsdf::query_kernel<4, true>")]
+    timed = d[b["warmup"]:b["warmup"] + b["steps"]]
+    summary.setdefault("query", {}).update(timed_launches=len(timed), timed_avg_us=sum(timed) / len(timed),
+                                            bench_hip_event_avg_us=b["roofline"]["avg_launch_ms"] * 1e3)
+    print("query_kernel<4, true>: %d timed launches, trace average %.1f us; bench.py HIP events %.1f us"
+          % (len(timed), sum(timed) / len(timed), b["roofline"]["avg_launch_ms"] * 1e3))
+    json.dump(summary, open(os.path.join(out, "summary.json"), "w"), indent=1)
+except Exception as e:
+    print("timed-region average not computed:", e)
+
+# profiles/query_pmc.json: what bench.py reports as roofline.traffic, stamped with the source of the kernel it was measured on
+if "query" in summary:
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "hp-adaptive-signed-distance-field-octree_amd", "csrc", "kernels.hip")).read()
+    a, b = text.index("template <int TOPD, bool DEDUPE>"), text.index("// 16-byte chunks a leaf of degree d occupies")
+    rec = dict(summary["query"], kernel="query_kernel<4, true>", profile=os.path.basename(out.rstrip("/")),
+               query_kernel_sha16=hashlib.sha256(text[a:b].encode()).hexdigest()[:16],
+               note="FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B read requests at 64 B); WRITE_SIZE exact; "
+                    "separate --pmc passes of bench.py --steps 5 (tools/profile.sh)")
+    json.dump(rec, open(os.path.join(out, "query_pmc.json"), "w"), indent=1)
+    print("wrote", os.path.join(out, "query_pmc.json"))
