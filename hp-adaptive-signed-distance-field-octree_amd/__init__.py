@@ -117,6 +117,7 @@ _SIGNATURES = {
     "hpsdf_field_eval_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hpsdf_field_eval_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hpsdf_field_eval_naive_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hpsdf_field_eval_wave_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hpsdf_tree_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "hpsdf_tree_destroy": (C.c_int, [C.c_void_p]),
     "hpsdf_tree_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
@@ -362,8 +363,17 @@ class Field:
                                                 out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def eval_wave(self, ctx, pts):
+        """Mesh fields: the BVH query as Create's sampler runs it (64 consecutive points share one traversal)."""
+        pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)
+        out = np.empty(len(pts))
+        check(lib().hpsdf_field_eval_wave_host(ctx.handle, self.handle, pts.ctypes.data_as(C.c_void_p), len(pts),
+                                               out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def mesh_stats(self, reset=True):
-        """BVH traversal counters (mesh fields created under HPSDF_MESH_STATS=1): queries, nodes, tri tests, lanes."""
+        """BVH traversal counters (mesh fields created under HPSDF_MESH_STATS=1, diagnostic builds): wave queries, nodes
+        visited, pairs through the lower-bound test ("tri_tests"), pairs through the closest-point test ("tri_test_lanes")."""
         out = (C.c_uint64 * 4)()
         check(lib().hpsdf_field_mesh_stats(self.handle, out, 1 if reset else 0))
         return dict(zip(("wave_queries", "node_visits", "tri_tests", "tri_test_lanes"), (int(v) for v in out)))

@@ -72,6 +72,7 @@ int makeFieldDev(const hpsdf_field* f, const double* dSamples, FieldDev* out) {
             out->mesh.tris = f->dTris;
             out->mesh.halfEdges = f->dHalfEdges;
             out->mesh.triPos = reinterpret_cast<const float4*>(f->dTriPos);
+            out->mesh.triPre = reinterpret_cast<const float4*>(f->dTriPre);
             out->mesh.bvh = f->dBvh;
             out->mesh.nTris = f->nTris;
             out->mesh.nNodes = f->nBvhNodes;
@@ -342,7 +343,7 @@ int hpsdf_field_create_mesh(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts,
     HPSDF_TRY
     if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "mesh fields live in HBM: a device context is required");
     if (!verts || !tris || !out || nVerts == 0 || nTris == 0) return fail(HPSDF_ERR_INVALID_ARGUMENT, "empty mesh");
-    if (nVerts > 0x7FFFFFFFull || nTris > 0x3FFFFFFFull) return fail(HPSDF_ERR_UNSUPPORTED, "mesh too large for 32-bit ids");
+    if (nVerts > 0x7FFFFFFFull || nTris > kMeshMaxTris) return fail(HPSDF_ERR_UNSUPPORTED, "mesh too large: at most 2^27 - 1 triangles");
     HPSDF_HIP(hipSetDevice(ctx->device));
     hpsdf_field* f = new hpsdf_field();
     f->kind = kHostMesh;
@@ -384,7 +385,8 @@ int hpsdf_field_create_mesh(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts,
         e = up((void**)&f->dVerts, hm.verts.data(), hm.verts.size() * sizeof(float));
         if (e == hipSuccess) e = up((void**)&f->dTris, hm.tris.data(), hm.tris.size() * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc((void**)&f->dTriPos, (size_t)nTris * kTriRecordFloats * sizeof(float));
-        if (e == hipSuccess) e = launchMeshTriPos(ctx->stream, f->dVerts, f->dTris, nTris, f->dTriPos);  // after the blocking uploads
+        if (e == hipSuccess) e = hipMalloc((void**)&f->dTriPre, (size_t)nTris * kTriPreFloats * sizeof(float));
+        if (e == hipSuccess) e = launchMeshTriPos(ctx->stream, f->dVerts, f->dTris, nTris, f->dTriPos, nullptr, f->dTriPre);  // after the blocking uploads
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e == hipSuccess) e = up((void**)&f->dHalfEdges, hm.halfEdges.data(), hm.halfEdges.size() * sizeof(uint32_t));
         if (e == hipSuccess) e = up((void**)&f->dBvh, hm.bvh.data(), hm.bvh.size() * sizeof(BvhNode));
@@ -453,6 +455,7 @@ int hpsdf_field_destroy(hpsdf_field* f) {
             if (f->dVerts) (void)hipFree(f->dVerts);
             if (f->dTris) (void)hipFree(f->dTris);
             if (f->dTriPos) (void)hipFree(f->dTriPos);
+            if (f->dTriPre) (void)hipFree(f->dTriPre);
             if (f->dHalfEdges) (void)hipFree(f->dHalfEdges);
             if (f->dBvh) (void)hipFree(f->dBvh);
         }
@@ -516,6 +519,26 @@ static int meshNaiveDevice(hpsdf_ctx* ctx, const hpsdf_field* f, const double* d
     if (rc) return rc;
     HPSDF_HIP(launchMeshNaive(ctx->stream, fd, dXyz, n, dOut));
     return HPSDF_OK;
+}
+
+static int meshWaveDevice(hpsdf_ctx* ctx, const hpsdf_field* f, const double* dXyz, size_t n, double* dOut) {
+    if (f->kind != kHostMesh) return fail(HPSDF_ERR_INVALID_ARGUMENT, "the shared traversal is defined for mesh fields");
+    HPSDF_HIP(hipSetDevice(ctx->device));
+    FieldDev fd;
+    int rc = makeFieldDev(f, nullptr, &fd);
+    if (rc) return rc;
+    HPSDF_HIP(launchMeshEvalWave(ctx->stream, fd, dXyz, n, dOut));
+    return HPSDF_OK;
+}
+
+int hpsdf_field_eval_wave_host(hpsdf_ctx* ctx, const hpsdf_field* f, const double* xyz, size_t n, double* out) {
+    HPSDF_TRY
+    if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "a device context is required");
+    if (!f || (!xyz && n) || (!out && n)) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    return hostRoundTrip(
+        ctx, xyz, n, out,
+        [](hpsdf_ctx* c, const void* o, const double* d, size_t m, double* r) { return meshWaveDevice(c, (const hpsdf_field*)o, d, m, r); }, f);
+    HPSDF_CATCH
 }
 
 int hpsdf_field_eval_naive_host(hpsdf_ctx* ctx, const hpsdf_field* f, const double* xyz, size_t n, double* out) {

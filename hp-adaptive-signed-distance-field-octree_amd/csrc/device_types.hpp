@@ -55,7 +55,11 @@ enum FieldKind : int32_t { kFieldAnalytic = 0, kFieldSamples = 1, kFieldMesh = 2
 
 // Binary BVH node, one 64-byte line: the boxes of BOTH children (so a visit decides about both subtrees from
 // one load, and a leaf child is tested against its triangle's box before the triangle itself) and the child
-// references: >= 0 an inner node, < 0 the triangle ~c.
+// references: >= 0 an inner node, < 0 a leaf: ~c = first slot << kMeshLeafShift | (count - 1), i.e. 1..kMeshLeafMax
+// consecutive entries of MeshDev::triPre (the host build makes one-triangle leaves with slot = triangle; the device build
+// sorts the triangles along a Morton curve and closes every subtree of <= leafTris triangles into one leaf).
+constexpr uint32_t kMeshLeafShift = 4, kMeshLeafMax = 1u << kMeshLeafShift;
+constexpr uint64_t kMeshMaxTris = (1ull << (31 - kMeshLeafShift)) - 1;
 struct alignas(64) BvhNode {
     float lo0[3], hi0[3];
     float lo1[3], hi1[3];
@@ -69,6 +73,9 @@ struct MeshDev {
     const uint32_t* tris;      // 3 vertex ids per triangle
     const float4* triPos;      // 3 x float4 per triangle: its 9 vertex coordinates and its normal, gathered: a closest-point test is ONE
                                // fetch instead of a chain of index -> vertex fetches (same values, same arithmetic)
+    const float4* triPre;      // 2 x float4 per leaf SLOT: a point g of the triangle's plane and the radius of the in-plane circle
+                               // around it that holds the triangle, the unit normal, and the triangle's index (bits in .w of the
+                               // second): a lower bound of the distance in ~20 instructions, and the slot -> triangle map
     const uint32_t* halfEdges; // twin half-edge per half-edge (Mesh.h:74)
     const BvhNode* bvh;        // node 0 is the root
     uint32_t nTris, nNodes;

@@ -127,13 +127,50 @@ __device__ V3 pseudoNormal(const MeshDev& m, uint32_t t, int code) {
     return normalized(n);
 }
 
+// A leaf reference (BvhNode::c0 / c1 < 0): its first slot and how many, and the triangle a slot holds.
+__device__ __forceinline__ uint32_t leafFirst(int32_t c) { return (uint32_t)~c >> kMeshLeafShift; }
+__device__ __forceinline__ uint32_t leafCount(int32_t c) { return ((uint32_t)~c & (kMeshLeafMax - 1u)) + 1u; }
+__device__ __forceinline__ uint32_t slotTriangle(const MeshDev& m, uint32_t slot) { return __float_as_uint(m.triPre[2 * (size_t)slot + 1].w); }
+
+// The lower-bound test on a triPre record (g, rho | unit normal, index): the triangle lies in the plane through g across
+// the normal, inside the circle of radius rho around g, so with s = n.(p - g) its squared distance from p is at least
+// s^2 + max(0, sqrt(|p - g|^2 - s^2) - rho)^2 -- twenty instructions against the two hundred of the closest-point test.
+// A box only says "the triangle is somewhere in here": for a sample at distance D from a surface tessellated at size h every
+// triangle whose box dips into the ball passes the box test, a patch ~sqrt(2 D h) wide (~300 triangles per sample on a
+// 1.3 M-triangle sphere); the plane-and-circle bound leaves the ones within ~h.
+// A triangle is dropped only if the bound exceeds the best distance by `slack` = 2e-5 of the mesh's scale (its extent, or
+// its largest coordinate if that is larger: f32 positions round at that scale) -- two orders of magnitude above the f32
+// rounding of either computation (mesh_tripre_kernel builds normal and circle with margins of their own) and far below a
+// triangle's size -- so the winner is still exactly the exhaustive scan's (test_mesh_bvh_equals_linear_scan_bitwise, the
+// fuzzers).  rejectBound = what the bound is compared with; a NaN bound never drops anything.
+__device__ __forceinline__ float triLowerBound2(V3 p, float4 g, float4 nh) {
+    const V3 dx = p - V3{g.x, g.y, g.z};
+    const float sd = dot(V3{nh.x, nh.y, nh.z}, dx), s2 = sd * sd;
+    const float off = fmaxf(sqrtf(fmaxf(sqnorm(dx) - s2, 0.0f)) - g.w, 0.0f);
+    return s2 + off * off;
+}
+__device__ __forceinline__ float meshSlack(const BvhNode& root) {
+    float e2 = 0.0f, big = 0.0f;
+    for (int a = 0; a < 3; ++a) {
+        const float hi = fmaxf(root.hi0[a], root.hi1[a]), lo = fminf(root.lo0[a], root.lo1[a]);
+        e2 += (hi - lo) * (hi - lo);
+        big = fmaxf(big, fmaxf(fabsf(hi), fabsf(lo)));
+    }
+    return 2e-5f * fmaxf(sqrtf(e2), big);
+}
+__device__ __forceinline__ float rejectBound(float best, float slack) {
+    const float r = sqrtf(best) + slack;
+    return r * r * 1.00001f;
+}
+
 // Closest triangle by stack traversal of the device BVH, nearer child first.  Ties on squared distance go to
 // the lower triangle index, and a box is pruned only when it is strictly farther than the running best (with a
 // guard band for f32 rounding of the box distance), so the winner equals the linear scan of
 // Mesh::ClosestTriangleToPt (Mesh.cpp:134-159) whatever the visiting order.  `hint` (the winner of the
 // caller's previous, nearby query) is tested first so that the bound is tight from the start.
 __device__ float meshSignedDistance(const MeshDev& m, V3 pt, uint32_t& hint) {
-    float best = FLT_MAX;
+    float best = FLT_MAX, reject = __builtin_inff();
+    const float slack = meshSlack(m.bvh[0]);
     uint32_t bestTri = 0xFFFFFFFFu;
     int bestCode = 8;
     V3 bestQ = {0.0f, 0.0f, 0.0f};
@@ -144,9 +181,16 @@ __device__ float meshSignedDistance(const MeshDev& m, V3 pt, uint32_t& hint) {
         const float d = sqnorm(pt - q);
         if (d < best || (d == best && t < bestTri)) {
             best = d;
+            reject = rejectBound(d, slack);
             bestTri = t;
             bestCode = code;
             bestQ = q;
+        }
+    };
+    auto visitLeaf = [&](int32_t c) {
+        for (uint32_t k = 0, first = leafFirst(c), cnt = leafCount(c); k < cnt; ++k) {
+            const float4 g = m.triPre[2 * (size_t)(first + k)], nh = m.triPre[2 * (size_t)(first + k) + 1];
+            if (!(triLowerBound2(pt, g, nh) > reject)) visitTri(__float_as_uint(nh.w));
         }
     };
     auto boxDist = [&](const float* lo, const float* hi) {
@@ -176,13 +220,13 @@ __device__ float meshSignedDistance(const MeshDev& m, V3 pt, uint32_t& hint) {
         int32_t pushA = -1;
         if (worthIt(da)) {
             if (ca < 0)
-                visitTri((uint32_t)~ca);
+                visitLeaf(ca);
             else
                 pushA = ca;
         }
         if (worthIt(db)) {
             if (cb < 0)
-                visitTri((uint32_t)~cb);
+                visitLeaf(cb);
             else if (sp < 95) {
                 stack[sp] = cb;
                 stackD[sp++] = db;
@@ -211,6 +255,8 @@ constexpr int kMeshStack = 128;
 __device__ float meshSignedDistanceWave(const MeshDev& m, V3 pt, bool active, uint32_t& hint, int32_t* stack) {
     float best = FLT_MAX;
     float bound = __builtin_inff();  // best * 1.00001f + 1e-30f, kept beside best: what a box distance is compared with
+    float reject = __builtin_inff();  // what a triangle's lower bound is compared with (rejectBound)
+    const float slack = meshSlack(m.bvh[0]);
     uint32_t bestTri = 0xFFFFFFFFu;
     int bestCode = 8;
     V3 bestQ = {0.0f, 0.0f, 0.0f};
@@ -222,9 +268,16 @@ __device__ float meshSignedDistanceWave(const MeshDev& m, V3 pt, bool active, ui
         if (d < best || (d == best && t < bestTri)) {
             best = d;
             bound = d * 1.00001f + 1e-30f;
+            reject = rejectBound(d, slack);
             bestTri = t;
             bestCode = code;
             bestQ = q;
+        }
+    };
+    auto visitLeaf = [&](int32_t c) {
+        for (uint32_t k = 0, first = leafFirst(c), cnt = leafCount(c); k < cnt; ++k) {
+            const float4 g = m.triPre[2 * (size_t)(first + k)], nh = m.triPre[2 * (size_t)(first + k) + 1];
+            if (!(triLowerBound2(pt, g, nh) > reject)) visitTri(__float_as_uint(nh.w));
         }
     };
     auto boxDist = [&](const float* lo, const float* hi) {  // clamp = median of (p, lo, hi): lo <= hi in every box
@@ -274,13 +327,13 @@ __device__ float meshSignedDistanceWave(const MeshDev& m, V3 pt, bool active, ui
         const BvhNode nn = m.bvh[next >= 0 ? next : 0];  // (the root again when the walk is over: never used)
         // leaves are resolved at once (they tighten the bounds for everything still to come)
         if (c0 < 0 && b0 != 0ull) {
-            if (w0) visitTri((uint32_t)~c0);
+            if (w0) visitLeaf(c0);
 #ifdef HPSDF_MESH_STATS_BUILD
             if (m.stats) ++nTriInstr, nTriLanes += (unsigned)__popcll(b0);
 #endif
         }
         if (c1 < 0 && b1 != 0ull) {
-            if (w1 && worthIt(d1)) visitTri((uint32_t)~c1);
+            if (w1 && worthIt(d1)) visitLeaf(c1);
 #ifdef HPSDF_MESH_STATS_BUILD
             if (m.stats) ++nTriInstr, nTriLanes += (unsigned)__popcll(b1);
 #endif
@@ -309,33 +362,58 @@ __device__ float meshSignedDistanceWave(const MeshDev& m, V3 pt, bool active, ui
     return r;
 }
 
-// The same traversal with the triangle tests COMPACTED (what mesh_sample_kernel runs).  In meshSignedDistanceWave a leaf
-// is tested the moment it is met, by the lanes whose bound asks for it: ~13 of 64 on a smooth 1.3 M-triangle mesh, i.e. the
-// closest-point code -- 70 % of the kernel's instructions -- runs at a fifth of the machine's width.  Here a leaf only
-// appends its (lane, triangle) pairs to a ring in LDS; whenever 64 pairs are there, the wave tests 64 pairs at once --
-// lane l takes pair l: the point comes from its owner's registers by ds_bpermute, the triangle's 36 bytes by a per-lane
-// load -- and every result is merged into its owner's best with ONE 64-bit LDS atomic min on (distance bits << 32 |
-// triangle): smallest distance, ties to the lower index -- the linear scan's rule (Mesh.cpp:134-159), whatever the order.
-// Pruning works on bounds that are refreshed after every batch: a stale (looser) bound only adds pairs, never drops one,
-// so every lane still ends with exactly the triangle its own traversal finds.  The winner's closest point and simplex
-// are recomputed once at the end (same function, same bits).
+// A node fetched for the whole wave: the index is wave-uniform and nothing writes the BVH while a kernel walks it, so the
+// 64 bytes go through the scalar cache into SGPRs (one s_load_dwordx16) instead of 64 lanes asking the texture path for
+// the same line.  The compiler only does that for memory it knows to be invariant -- the constant address space says so;
+// through the generic pointer it falls back to four vector loads as soon as the kernel contains an LDS atomic.
+__device__ __forceinline__ BvhNode loadNodeUniform(const BvhNode* base, int32_t idx) {
+    typedef const __attribute__((address_space(4))) uint32_t* ConstWords;
+    const ConstWords w = (ConstWords)(uintptr_t)(base + idx);
+    BvhNode n;
+    n.lo0[0] = __uint_as_float(w[0]), n.lo0[1] = __uint_as_float(w[1]), n.lo0[2] = __uint_as_float(w[2]);
+    n.hi0[0] = __uint_as_float(w[3]), n.hi0[1] = __uint_as_float(w[4]), n.hi0[2] = __uint_as_float(w[5]);
+    n.lo1[0] = __uint_as_float(w[6]), n.lo1[1] = __uint_as_float(w[7]), n.lo1[2] = __uint_as_float(w[8]);
+    n.hi1[0] = __uint_as_float(w[9]), n.hi1[1] = __uint_as_float(w[10]), n.hi1[2] = __uint_as_float(w[11]);
+    n.c0 = (int32_t)w[12], n.c1 = (int32_t)w[13], n.pad[0] = w[14], n.pad[1] = w[15];
+    return n;
+}
+
+// The same traversal with the triangle tests COMPACTED and FILTERED (what mesh_sample_kernel runs).  In
+// meshSignedDistanceWave a leaf is tested the moment it is met, by the lanes whose bound asks for it: ~13 of 64 on a smooth
+// 1.3 M-triangle mesh, i.e. the closest-point code runs at a fifth of the machine's width.  Here a leaf only appends
+// (lane, slot) pairs to ring A in LDS.  Whenever 64 pairs are there the wave runs 64 lower-bound tests at once
+// (triLowerBound2; lane l takes pair l, the point comes from its owner's registers by ds_bpermute).  Survivors -- about one
+// pair in twelve -- go to ring B as (lane, triangle); whenever 64 are there the wave runs 64 closest-point tests at once and
+// merges every result into its owner's best with ONE 64-bit LDS atomic min on (distance bits << 32 | triangle): smallest
+// distance, ties to the lower index -- the linear scan's rule (Mesh.cpp:134-159), whatever the order.
+// Pruning works on bounds that are refreshed after every closest-point batch: a stale (looser) bound only adds pairs,
+// never drops one, so every lane still ends with exactly the triangle its own exhaustive scan finds.  The winner's closest
+// point and simplex are recomputed once at the end (same function, same bits).
 struct MeshWaveLds {
     unsigned long long best[64];
-    uint32_t qTri[256];
-    uint8_t qLane[256];
+    uint32_t aSlot[128];  // ring A: waiting for the lower-bound test
+    uint32_t bTri[128];   // ring B: waiting for the closest-point test
+    uint8_t aLane[128];
+    uint8_t bLane[128];
     int32_t stack[kMeshStack];
 };
 __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool active, MeshWaveLds& L) {
     const int lane = threadIdx.x & 63;
-    float bound = __builtin_inff();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    float bound = __builtin_inff();  // what a box distance is compared with: best * 1.00001f + 1e-30f
+    float reject = __builtin_inff(); // what a lower bound is compared with: (sqrt(best) + slack)^2
     L.best[lane] = ((unsigned long long)__float_as_uint(FLT_MAX) << 32) | 0xFFFFFFFFull;
-    uint32_t qHead = 0, qCount = 0;  // wave-uniform
-    bool seeded = false;
-    auto runBatch = [&](uint32_t n) {  // the first n (<= 64) pairs of the ring
-        const bool on = (uint32_t)lane < n;
-        const uint32_t slot = (qHead + (uint32_t)lane) & 255u;
-        const uint32_t t = on ? L.qTri[slot] : 0u;
-        const int src = on ? (int)L.qLane[slot] : lane;
+    uint32_t aHead = 0, aCount = 0, bHead = 0, bCount = 0;  // wave-uniform
+#ifdef HPSDF_MESH_STATS_BUILD
+    unsigned nVisits = 0, nBound = 0, nClosest = 0;  // [1] nodes, [2] pairs through the lower-bound test, [3] through the closest-point test
+#endif
+    BvhNode n = loadNodeUniform(m.bvh, 0);
+    const float slack = meshSlack(n);
+    auto closestBatch = [&](uint32_t cnt) {  // the first cnt (<= 64) pairs of ring B
+        const bool on = (uint32_t)lane < cnt;
+        const uint32_t at = (bHead + (uint32_t)lane) & 127u;
+        const uint32_t t = on ? L.bTri[at] : 0u;
+        const int src = on ? (int)L.bLane[at] : lane;
         const V3 p = {__shfl(pt.x, src, 64), __shfl(pt.y, src, 64), __shfl(pt.z, src, 64)};
         if (on) {
             V3 q;
@@ -345,9 +423,43 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool active, M
             atomicMin(&L.best[src], ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)t);
         }
         __builtin_amdgcn_wave_barrier();
-        bound = __uint_as_float((uint32_t)(L.best[lane] >> 32)) * 1.00001f + 1e-30f;
-        qHead = (qHead + n) & 255u;
-        qCount -= n;
+        const float best = __uint_as_float((uint32_t)(L.best[lane] >> 32));
+        bound = best * 1.00001f + 1e-30f;
+        reject = rejectBound(best, slack);
+        bHead = (bHead + cnt) & 127u;
+        bCount -= cnt;
+#ifdef HPSDF_MESH_STATS_BUILD
+        nClosest += cnt;
+#endif
+    };
+    auto boundBatch = [&](uint32_t cnt) {  // the first cnt (<= 64) pairs of ring A; ring B holds < 64 on entry
+        const bool on = (uint32_t)lane < cnt;
+        const uint32_t at = (aHead + (uint32_t)lane) & 127u;
+        const uint32_t slot = on ? L.aSlot[at] : 0u;
+        const int src = on ? (int)L.aLane[at] : lane;
+        const V3 p = {__shfl(pt.x, src, 64), __shfl(pt.y, src, 64), __shfl(pt.z, src, 64)};
+        const float rj = __shfl(reject, src, 64);
+        bool pass = false;
+        uint32_t tri = 0u;
+        if (on) {
+            const float4 g = m.triPre[2 * (size_t)slot], nh = m.triPre[2 * (size_t)slot + 1];
+            tri = __float_as_uint(nh.w);
+            pass = !(triLowerBound2(p, g, nh) > rj);  // (a NaN passes)
+        }
+        const unsigned long long pb = __ballot(pass);
+        if (pass) {
+            const uint32_t pos = (bHead + bCount + (uint32_t)__popcll(pb & below)) & 127u;
+            L.bTri[pos] = tri;
+            L.bLane[pos] = (uint8_t)src;
+        }
+        bCount += (uint32_t)__popcll(pb);
+        aHead = (aHead + cnt) & 127u;
+        aCount -= cnt;
+#ifdef HPSDF_MESH_STATS_BUILD
+        nBound += cnt;
+#endif
+        __builtin_amdgcn_wave_barrier();
+        while (bCount >= 64) closestBatch(64);
     };
     auto boxDist = [&](const float* lo, const float* hi) {  // clamp = median of (p, lo, hi): lo <= hi in every box
         const float cx = __builtin_amdgcn_fmed3f(pt.x, lo[0], hi[0]);
@@ -356,18 +468,50 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool active, M
         return sqnorm(pt - V3{cx, cy, cz});
     };
     auto worthIt = [&](float d) { return active && !(d > bound); };
-    auto enqueue = [&](unsigned long long b, bool w, uint32_t tri) {
-        if (w) {
-            const uint32_t pos = (qHead + qCount + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))) & 255u;
-            L.qTri[pos] = tri;
-            L.qLane[pos] = (uint8_t)lane;
+    auto enqueueLeaf = [&](unsigned long long b, bool w, int32_t c) {  // ring A holds < 64 on entry and on exit
+        const uint32_t first = leafFirst(c), cnt = leafCount(c), nb = (uint32_t)__popcll(b);
+        const uint32_t mine = (uint32_t)__popcll(b & below);
+        for (uint32_t k = 0; k < cnt; ++k) {
+            if (w) {
+                const uint32_t pos = (aHead + aCount + mine) & 127u;
+                L.aSlot[pos] = first + k;
+                L.aLane[pos] = (uint8_t)lane;
+            }
+            aCount += nb;
+            __builtin_amdgcn_wave_barrier();
+            if (aCount >= 64) boundBatch(64);
         }
-        qCount += (uint32_t)__popcll(b);
-        __builtin_amdgcn_wave_barrier();
     };
+    // Every lane first walks down to ONE leaf of its own, nearer child first, and tests its triangles: a bound within a
+    // triangle's size of the final distance before the shared traversal starts.  (Seeded from the first leaf the wave
+    // meets instead, the 64 samples -- spread over several triangle sizes -- start with bounds as loose as their spread
+    // and nine tenths of everything they queue passes the lower-bound test.)
+    if (active) {
+        int32_t c = 0;
+        do {
+            const BvhNode nd = m.bvh[c];
+            c = boxDist(nd.lo1, nd.hi1) < boxDist(nd.lo0, nd.hi0) ? nd.c1 : nd.c0;
+        } while (c >= 0);
+        float best = FLT_MAX;
+        uint32_t bestTri = 0xFFFFFFFFu;
+        for (uint32_t k = 0, first = leafFirst(c), cnt = leafCount(c); k < cnt; ++k) {
+            const uint32_t t = slotTriangle(m, first + k);
+            V3 q;
+            const float4 tp[3] = {m.triPos[3 * (size_t)t], m.triPos[3 * (size_t)t + 1], m.triPos[3 * (size_t)t + 2]};
+            closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, q);
+            const float d = sqnorm(pt - q);
+            if (d < best || (d == best && t < bestTri)) best = d, bestTri = t;
+        }
+        L.best[lane] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)bestTri;
+        bound = best * 1.00001f + 1e-30f;
+        reject = rejectBound(best, slack);
+    }
+    __builtin_amdgcn_wave_barrier();
     int sp = 0;  // wave-uniform
-    BvhNode n = m.bvh[0];
     for (;;) {
+#ifdef HPSDF_MESH_STATS_BUILD
+        ++nVisits;
+#endif
         const float d0 = boxDist(n.lo0, n.hi0), d1 = boxDist(n.lo1, n.hi1);
         const bool w0 = worthIt(d0), w1 = worthIt(d1);
         const unsigned long long b0 = __ballot(w0), b1 = __ballot(w1);
@@ -390,19 +534,20 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool active, M
             --sp;
             next = __builtin_amdgcn_readfirstlane(L.stack[sp]);
         }
-        const BvhNode nn = m.bvh[next >= 0 ? next : 0];  // (the root again when the walk is over: never used)
-        if (c0 < 0 && b0 != 0ull) enqueue(b0, w0, (uint32_t)~c0);
-        if (c1 < 0 && b1 != 0ull) enqueue(b1, w1, (uint32_t)~c1);
-        if (!seeded && qCount > 0) {  // the first triangles met give every lane a finite bound at once
-            while (qCount >= 64) runBatch(64);
-            if (qCount) runBatch(qCount);
-            seeded = true;
-        }
-        while (qCount >= 64) runBatch(64);
+        const BvhNode nn = loadNodeUniform(m.bvh, __builtin_amdgcn_readfirstlane(next >= 0 ? next : 0));  // (the root again when the walk is over: never used)
+        if (c0 < 0 && b0 != 0ull) enqueueLeaf(b0, w0, c0);
+        if (c1 < 0 && b1 != 0ull) enqueueLeaf(b1, w1, c1);
         if (next < 0 || (nn.pad[0] & nn.pad[1]) == 0xFFFFFFFFu) break;
         n = nn;
     }
-    if (qCount) runBatch(qCount);
+    if (aCount) boundBatch(aCount);
+    if (bCount) closestBatch(bCount);
+#ifdef HPSDF_MESH_STATS_BUILD
+    if (m.stats && lane == 0) {
+        atomicAdd(m.stats + 0, 1ull), atomicAdd(m.stats + 1, (unsigned long long)nVisits);
+        atomicAdd(m.stats + 2, (unsigned long long)nBound), atomicAdd(m.stats + 3, (unsigned long long)nClosest);
+    }
+#endif
     float r = 0.0f;
     if (active) {
         const uint32_t bestTri = (uint32_t)(L.best[lane] & 0xFFFFFFFFull);
@@ -1832,6 +1977,28 @@ __global__ __launch_bounds__(256) void mesh_naive_kernel(MeshDev m, const double
     }
 }
 
+// Mesh::SignedDistanceAtPt(pt, bvh) through the traversal the sampler uses: 64 consecutive points share one walk
+// (meshSignedDistanceWaveQ).  Correct for any points -- a wave visits the union of what its lanes need -- and fast when
+// neighbours in the array are neighbours in space.
+__global__ __launch_bounds__(256) void mesh_eval_wave_kernel(MeshDev m, const double* __restrict__ xyz, size_t n, double* __restrict__ out) {
+    __shared__ MeshWaveLds sWave[4];
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool active = i < n;
+    const size_t j = active ? i : n - 1;
+    const float v = meshSignedDistanceWaveQ(m, V3{(float)xyz[3 * j], (float)xyz[3 * j + 1], (float)xyz[3 * j + 2]}, active, sWave[threadIdx.x >> 6]);
+    if (active) out[i] = (double)v;
+}
+
+hipError_t launchMeshEvalWave(hipStream_t stream, const FieldDev& f, const double* dXyz, size_t n, double* dOut) {
+    if (n == 0) return hipSuccess;
+    if (f.kind != kFieldMesh || f.csgOp >= 0) return hipErrorInvalidValue;
+    for (size_t first = 0; first < n; first += (size_t)1 << 38) {  // grid.x stays below 2^31
+        const size_t m = std::min<size_t>((size_t)1 << 38, n - first);
+        hipLaunchKernelGGL(mesh_eval_wave_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, f.mesh, dXyz + 3 * first, m, dOut + first);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launchMeshNaive(hipStream_t stream, const FieldDev& f, const double* dXyz, size_t n, double* dOut) {
     if (n == 0) return hipSuccess;
     if (f.kind != kFieldMesh || f.csgOp >= 0) return hipErrorInvalidValue;
@@ -1858,10 +2025,50 @@ __global__ __launch_bounds__(256) void mesh_tripos_kernel(const float* __restric
     triPos[3 * t + 2] = make_float4(c.z, n.x, n.y, n.z);
 }
 
-hipError_t launchMeshTriPos(hipStream_t stream, const float* dVerts, const uint32_t* dTris, uint64_t nTris, float* dTriPos) {
+// MeshDev::triPre: per leaf slot the data of the lower-bound test (meshSignedDistanceWaveQ) and the triangle's index.
+// g = the centroid (any point near the triangle's plane would do), nh = the unit normal, rho = the largest distance of a
+// vertex from g, widened by its rounding.  The bound is valid for ANY unit nh as long as the vertices lie within e of the
+// plane through g across nh; e is measured here (the centroid is off the plane by the rounding of its coordinates), and when
+// it is not negligible (slivers, whose cross product cancels) nh is set to zero, which turns the test into the plain sphere
+// bound |p - g| - rho.  What is left of e (<= 2e-6 of the mesh's scale) and of |nh| - 1 is covered by the caller's slack
+// (2e-5 of that scale).
+__global__ __launch_bounds__(256) void mesh_tripre_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ tris,
+                                                          const uint32_t* __restrict__ slotTri, uint64_t nTris, float4* __restrict__ triPre) {
+    const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= nTris) return;
+    const uint32_t t = slotTri ? slotTri[s] : (uint32_t)s;
+    const uint32_t ia = tris[3 * (size_t)t], ib = tris[3 * (size_t)t + 1], ic = tris[3 * (size_t)t + 2];
+    const V3 a = {verts[3 * (size_t)ia], verts[3 * (size_t)ia + 1], verts[3 * (size_t)ia + 2]};
+    const V3 b = {verts[3 * (size_t)ib], verts[3 * (size_t)ib + 1], verts[3 * (size_t)ib + 2]};
+    const V3 c = {verts[3 * (size_t)ic], verts[3 * (size_t)ic + 1], verts[3 * (size_t)ic + 2]};
+    const float third = 1.0f / 3.0f;
+    const V3 g = third * (a + (b + c));
+    const float rho = sqrtf(fmaxf(sqnorm(a - g), fmaxf(sqnorm(b - g), sqnorm(c - g)))) * 1.00001f + 1e-30f;
+    // the scale the caller's slack is proportional to is at least this (the mesh's extent or its largest coordinate)
+    const float scale = fmaxf(rho, fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fabsf(g.z)));
+    const V3 n = cross(b - a, c - a);
+    const float len = sqrtf(sqnorm(n));
+    V3 nh = {0.0f, 0.0f, 0.0f};
+    if (len > 0.0f && len < __builtin_inff()) {
+        nh = (1.0f / len) * n;
+        const float e = fmaxf(fabsf(dot(nh, a - g)), fmaxf(fabsf(dot(nh, b - g)), fabsf(dot(nh, c - g))));
+        const float unit = fabsf(sqnorm(nh) - 1.0f);
+        if (!(e <= 2e-6f * scale) || !(unit <= 1e-5f)) nh = V3{0.0f, 0.0f, 0.0f};
+    }
+    if (!(rho < __builtin_inff())) nh = V3{0.0f, 0.0f, 0.0f};  // (non-finite input: the bound degenerates to "always passes" via NaN)
+    triPre[2 * s] = make_float4(g.x, g.y, g.z, rho);
+    triPre[2 * s + 1] = make_float4(nh.x, nh.y, nh.z, __uint_as_float(t));
+}
+
+hipError_t launchMeshTriPos(hipStream_t stream, const float* dVerts, const uint32_t* dTris, uint64_t nTris, float* dTriPos,
+                            const uint32_t* dSlotTri, float* dTriPre) {
     if (nTris == 0) return hipSuccess;
-    hipLaunchKernelGGL(mesh_tripos_kernel, dim3((unsigned)((nTris + 255) / 256)), dim3(256), 0, stream, dVerts, dTris, nTris,
-                       reinterpret_cast<float4*>(dTriPos));
+    if (dTriPos)
+        hipLaunchKernelGGL(mesh_tripos_kernel, dim3((unsigned)((nTris + 255) / 256)), dim3(256), 0, stream, dVerts, dTris, nTris,
+                           reinterpret_cast<float4*>(dTriPos));
+    if (dTriPre)
+        hipLaunchKernelGGL(mesh_tripre_kernel, dim3((unsigned)((nTris + 255) / 256)), dim3(256), 0, stream, dVerts, dTris, dSlotTri, nTris,
+                           reinterpret_cast<float4*>(dTriPre));
     return hipGetLastError();
 }
 

@@ -45,9 +45,13 @@ hipError_t launchSlicePoints(hipStream_t stream, double c, float minX, float min
 hipError_t launchFieldEval(hipStream_t stream, const FieldDev& f, const DeviceTables* dTables, const double* dXyz,
                            size_t n, double* dOut);
 // mesh field, linear scan over all triangles (no BVH): Mesh::SignedDistanceAtPt(pt), Mesh.cpp:42-51,134-159
+hipError_t launchMeshEvalWave(hipStream_t stream, const FieldDev& f, const double* dXyz, size_t n, double* dOut);
 hipError_t launchMeshNaive(hipStream_t stream, const FieldDev& f, const double* dXyz, size_t n, double* dOut);
 constexpr int kTriRecordFloats = 12;  // MeshDev::triPos: a, b, c, cross(b - a, c - a)
-hipError_t launchMeshTriPos(hipStream_t stream, const float* dVerts, const uint32_t* dTris, uint64_t nTris, float* dTriPos);
+constexpr int kTriPreFloats = 8;      // MeshDev::triPre: g, rho, unit normal, triangle index
+// dSlotTri: which triangle sits in leaf slot s (nullptr: slot s = triangle s); either output may be nullptr (skipped)
+hipError_t launchMeshTriPos(hipStream_t stream, const float* dVerts, const uint32_t* dTris, uint64_t nTris, float* dTriPos,
+                            const uint32_t* dSlotTri, float* dTriPre);
 // mesh fields: F at every sample of nTasks fits of one degree -> dSamples[FitTask::sampleOff + sample]
 hipError_t launchMeshSample(hipStream_t stream, const FitTask* dTasks, uint32_t nTasks, int degree, const DeviceTables* dTables,
                             const FieldDev& field, const RootMap& rm, double* dSamples);

@@ -108,7 +108,7 @@ struct Builder {
                 bmin[a] = triBox[6 * t + a];
                 bmax[a] = triBox[6 * t + 3 + a];
             }
-            return ~(int32_t)t;
+            return ~(int32_t)(t << kMeshLeafShift);  // a leaf of one triangle: slot = triangle (device_types.hpp)
         }
         float cmin[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, cmax[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
         for (size_t i = lo; i < hi; ++i)

@@ -16,7 +16,10 @@
 // node's range and split found independently from the sorted codes (equal codes ordered by position), boxes fitted
 // bottom-up by the second thread to reach a node.  Deterministic: the sort is stable, ranges and splits are pure
 // functions of the sorted keys, boxes are min / max.  Node layout as the traversal wants it: 64 bytes holding BOTH
-// children's boxes and references (>= 0 an inner node, < 0 the triangle ~c); node 0 is the root.
+// children's boxes and references (>= 0 an inner node, < 0 a leaf); node 0 is the root.  A leaf is a run of up to
+// `leafTris` triangles that are consecutive along the curve (= every subtree that small): the sorted order is the slot
+// order of MeshDev::triPre, so a leaf's lower-bound records are neighbours in memory, and the two bottom levels of the
+// binary tree -- three quarters of its nodes -- are never visited.
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
@@ -126,7 +129,7 @@ __device__ __forceinline__ int mbDelta(const uint64_t* __restrict__ keys, int n,
 }
 
 // inner node i of n - 1: its range of sorted leaves and its split
-__global__ __launch_bounds__(256) void mb_hierarchy_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ ids, int n,
+__global__ __launch_bounds__(256) void mb_hierarchy_kernel(const uint64_t* __restrict__ keys, int n, int leafTris,
                                                            BvhNode* __restrict__ nodes, int32_t* __restrict__ parent /* [2n - 1]: inner 0..n-2, leaves n-1.. */) {
     const int i = (int)(blockIdx.x * 256u + threadIdx.x);
     if (i >= n - 1) return;
@@ -148,8 +151,11 @@ __global__ __launch_bounds__(256) void mb_hierarchy_kernel(const uint64_t* __res
     const int lo = d > 0 ? i : j, hi = d > 0 ? j : i;
     const bool leaf0 = lo == gamma, leaf1 = hi == gamma + 1;
     BvhNode& nd = nodes[i];
-    nd.c0 = leaf0 ? ~(int32_t)ids[gamma] : gamma;
-    nd.c1 = leaf1 ? ~(int32_t)ids[gamma + 1] : gamma + 1;
+    // children as the traversal sees them: a subtree of <= leafTris sorted triangles is one leaf (slots lo..gamma, or
+    // gamma + 1..hi); the inner nodes below it still get their boxes (mb_fit_kernel climbs through them) but no reference
+    const int n0 = gamma - lo + 1, n1 = hi - gamma;
+    nd.c0 = n0 <= leafTris ? ~(int32_t)(((uint32_t)lo << kMeshLeafShift) | (uint32_t)(n0 - 1)) : gamma;
+    nd.c1 = n1 <= leafTris ? ~(int32_t)(((uint32_t)(gamma + 1) << kMeshLeafShift) | (uint32_t)(n1 - 1)) : gamma + 1;
     nd.pad[0] = nd.pad[1] = 0;
     parent[leaf0 ? (n - 1) + gamma : gamma] = i * 2;          // (child slot in the low bit)
     parent[leaf1 ? (n - 1) + gamma + 1 : gamma + 1] = i * 2 + 1;
@@ -252,6 +258,9 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
         return HPSDF_OK;
     }
     hipStream_t s = ctx->stream;
+    int leafTris = 8;  // triangles per leaf (1..kMeshLeafMax); HPSDF_MESH_LEAF_TRIS overrides (experiments)
+    if (const char* lt = std::getenv("HPSDF_MESH_LEAF_TRIS")) leafTris = std::atoi(lt);
+    leafTris = leafTris < 1 ? 1 : (leafTris > (int)kMeshLeafMax ? (int)kMeshLeafMax : leafTris);
     const uint64_t nCorners = 3 * nTris;
     const int n = (int)nTris;
     uint64_t* dTris64 = nullptr;
@@ -278,7 +287,8 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
         };
         size_t fb = 0;
         const size_t oVerts = carve(fb, 3 * nVerts * sizeof(float)), oTris = carve(fb, nCorners * sizeof(uint32_t)),
-                     oTriPos = carve(fb, (size_t)nTris * kTriRecordFloats * sizeof(float)), oHe = carve(fb, nCorners * sizeof(uint32_t)),
+                     oTriPos = carve(fb, (size_t)nTris * kTriRecordFloats * sizeof(float)),
+                     oTriPre = carve(fb, (size_t)nTris * kTriPreFloats * sizeof(float)), oHe = carve(fb, nCorners * sizeof(uint32_t)),
                      oBvh = carve(fb, (size_t)(n - 1) * sizeof(BvhNode));
         size_t tb = 0;
         const size_t oT64 = carve(tb, nCorners * sizeof(uint64_t)), oBox = carve(tb, 6 * nTris * sizeof(float)),
@@ -292,6 +302,7 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
         if (e == hipSuccess) {
             f->dBlock = fieldBlock;
             f->dVerts = (float*)(fieldBlock + oVerts), f->dTris = (uint32_t*)(fieldBlock + oTris), f->dTriPos = (float*)(fieldBlock + oTriPos);
+            f->dTriPre = (float*)(fieldBlock + oTriPre);
             f->dHalfEdges = (uint32_t*)(fieldBlock + oHe), f->dBvh = (BvhNode*)(fieldBlock + oBvh);
             dTris64 = (uint64_t*)(tempBlock + oT64), dTriBox = (float*)(tempBlock + oBox), dKeys = (uint64_t*)(tempBlock + oK);
             dKeysOut = (uint64_t*)(tempBlock + oK2), dIds = (uint32_t*)(tempBlock + oI), dIdsOut = (uint32_t*)(tempBlock + oI2);
@@ -307,7 +318,7 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
         if (fieldBlock) (void)hipFree(fieldBlock);
         fieldBlock = nullptr;
         f->dBlock = nullptr;
-        f->dVerts = nullptr, f->dTris = nullptr, f->dTriPos = nullptr, f->dHalfEdges = nullptr, f->dBvh = nullptr;
+        f->dVerts = nullptr, f->dTris = nullptr, f->dTriPos = nullptr, f->dTriPre = nullptr, f->dHalfEdges = nullptr, f->dBvh = nullptr;
     };
     const double t1 = now();
     if (e == hipSuccess) e = hipMemcpyAsync(f->dVerts, verts, 3 * nVerts * sizeof(float), hipMemcpyHostToDevice, s);
@@ -327,11 +338,12 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
     const double t2 = now();
     const unsigned gc = (unsigned)((nCorners + 255) / 256), gt = (unsigned)((nTris + 255) / 256);
     hipLaunchKernelGGL(mb_tris_kernel, dim3(gc), dim3(256), 0, s, dTris64, nCorners, nVerts, f->dTris, dFlags);
-    e = launchMeshTriPos(s, f->dVerts, f->dTris, nTris, f->dTriPos);
+    e = launchMeshTriPos(s, f->dVerts, f->dTris, nTris, f->dTriPos, nullptr, nullptr);
     hipLaunchKernelGGL(mb_boxes_kernel, dim3(gt), dim3(256), 0, s, f->dTriPos, (uint32_t)nTris, dTriBox, dFlags);
     hipLaunchKernelGGL(mb_morton_kernel, dim3(gt), dim3(256), 0, s, dTriBox, (uint32_t)nTris, dFlags, dKeys, dIds);
     if (e == hipSuccess) e = rocprim::radix_sort_pairs(dSortTmp, sortTmpBytes, dKeys, dKeysOut, dIds, dIdsOut, (size_t)nTris, 0, 63, s);
-    hipLaunchKernelGGL(mb_hierarchy_kernel, dim3(gt), dim3(256), 0, s, dKeysOut, dIdsOut, n, f->dBvh, dParent);
+    if (e == hipSuccess) e = launchMeshTriPos(s, f->dVerts, f->dTris, nTris, nullptr, dIdsOut, f->dTriPre);  // slot order = sorted order
+    hipLaunchKernelGGL(mb_hierarchy_kernel, dim3(gt), dim3(256), 0, s, dKeysOut, n, leafTris, f->dBvh, dParent);
     hipLaunchKernelGGL(mb_fit_kernel, dim3(gt), dim3(256), 0, s, dIdsOut, dTriBox, n, f->dBvh, dParent, dArrived);
     hipLaunchKernelGGL(mb_edges_insert_kernel, dim3(gc), dim3(256), 0, s, f->dTris, nCorners, dTabKey, dTabVal, tabSize - 1, dFlags);
     hipLaunchKernelGGL(mb_edges_lookup_kernel, dim3(gc), dim3(256), 0, s, f->dTris, nCorners, dTabKey, dTabVal, tabSize - 1, f->dHalfEdges, dFlags);

@@ -123,6 +123,7 @@ struct hpsdf_field {
     float* dVerts = nullptr;
     uint32_t* dTris = nullptr;
     float* dTriPos = nullptr;
+    float* dTriPre = nullptr;
     uint32_t* dHalfEdges = nullptr;
     hpsdf::BvhNode* dBvh = nullptr;
     uint32_t nTris = 0, nVerts = 0, nBvhNodes = 0;

@@ -161,10 +161,14 @@ HPSDF_API int hpsdf_field_eval_host(hpsdf_ctx* ctx, const hpsdf_field* f, const 
  * only: every triangle is tested for every point (one wave per point).  What the reference's TestBVHQuerying
  * (Source/Tests/MeshingUnitTests.cpp:110-138) compares the BVH answer with; same tie rule, so the two agree bit for bit. */
 HPSDF_API int hpsdf_field_eval_naive_host(hpsdf_ctx* ctx, const hpsdf_field* f, const double* xyz, size_t n, double* out);
+/* Mesh::SignedDistanceAtPt(pt, bvh, threadIdx) (Source/Meshing/Mesh.cpp:54-84) through the traversal Create's sampler
+ * uses: 64 consecutive points share one walk of the BVH.  Same values as hpsdf_field_eval_host bit for bit, whatever the
+ * order of the points; faster when neighbours in the array are neighbours in space.  Mesh fields only. */
+HPSDF_API int hpsdf_field_eval_wave_host(hpsdf_ctx* ctx, const hpsdf_field* f, const double* xyz, size_t n, double* out);
 /* Diagnostics (no reference counterpart; HPSDF_ERR_UNSUPPORTED unless the library was built with
  * -DHPSDF_MESH_STATS_BUILD): BVH traversal counters of a mesh field created while the environment
- * variable HPSDF_MESH_STATS was set -- out[0] wave-wide closest-triangle queries, [1] BVH nodes they visited,
- * [2] triangle tests issued, [3] lanes that ran one.  Synchronises the device; reset != 0 zeroes the counters. */
+ * variable HPSDF_MESH_STATS was set -- out[0] wave-wide closest-triangle queries (64 points each), [1] BVH nodes they visited,
+ * [2] (point, triangle) pairs that went through the lower-bound test, [3] pairs that went on to the closest-point test.  Synchronises the device; reset != 0 zeroes the counters. */
 HPSDF_API int hpsdf_field_mesh_stats(const hpsdf_field* f, uint64_t out[4], int reset);
 
 /* ---- Query: Octree::FromMemoryBlock + Octree::Query (Octree.cpp:403-421, 662-702, 859-901) */

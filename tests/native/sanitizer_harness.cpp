@@ -33,7 +33,7 @@ hipError_t launchCgIterations(hipStream_t, const CgDev&, int) { return hipErrorN
 hipError_t launchCgStart(hipStream_t, const CgDev&) { return hipErrorNoDevice; }
 hipError_t launchCgFinish(hipStream_t, const CgDev&) { return hipErrorNoDevice; }
 hipError_t launchCgLayout(hipStream_t, uint64_t, const uint64_t*, const uint32_t*, const double*, const CgDev&) { return hipErrorNoDevice; }
-hipError_t launchMeshTriPos(hipStream_t, const float*, const uint32_t*, uint64_t, float*) { return hipErrorNoDevice; }
+hipError_t launchMeshTriPos(hipStream_t, const float*, const uint32_t*, uint64_t, float*, const uint32_t*, float*) { return hipErrorNoDevice; }
 hipError_t launchMeshSample(hipStream_t, const FitTask*, uint32_t, int, const DeviceTables*, const FieldDev&, const RootMap&, double*) {
     return hipErrorNoDevice;
 }

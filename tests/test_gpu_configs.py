@@ -95,6 +95,58 @@ def test_mesh_bvh_equals_linear_scan_bitwise(H, O, ctx):
         assert np.abs(b[:500] - want.astype(np.float64)).max() <= TOL
 
 
+def _hard_meshes():
+    yield "icosphere L5", icosphere(5, 0.4)
+    yield "displaced torus", displaced_torus(160, 96)
+    v, t = icosphere(4, 0.3)
+    yield "far from the origin", ((v + np.float32([50.0, -30.0, 20.0])).astype(np.float32), t)
+    v, t = icosphere(4, 0.4)
+    yield "flattened (thin triangles)", ((v * np.float32([1.0, 0.01, 1.0])).astype(np.float32), t)
+    v, t = icosphere(3, 0.35)
+    v = v.copy()
+    for k in range(0, len(t), 7):  # slivers: a corner pulled to within 1e-6 of its neighbour (still closed and manifold)
+        a, b = int(t[k, 0]), int(t[k, 1])
+        v[b] = v[a] + np.float32(1e-6) * (v[b] - v[a])
+    yield "slivers", (v, t)
+
+
+def _hard_points(O, verts, tris, seed):
+    rng = np.random.default_rng(seed)
+    lo, hi = verts.min(0).astype(np.float64), verts.max(0).astype(np.float64)
+    ext = (hi - lo).max()
+    c = 0.5 * (lo + hi)
+    tri = verts[tris[rng.integers(0, len(tris), 600)]].astype(np.float64)
+    w = rng.dirichlet((1.0, 1.0, 1.0), 600)
+    return np.concatenate([
+        lo - 0.1 * ext + rng.random((3000, 3)) * (hi - lo + 0.2 * ext),        # around the mesh
+        verts[rng.integers(0, len(verts), 300)].astype(np.float64),             # on vertices
+        0.5 * (tri[:300, 0] + tri[:300, 1]),                                    # on edges
+        (tri * w[:, :, None]).sum(1),                                           # on faces
+        (tri * w[:, :, None]).sum(1) + 1e-4 * ext * rng.standard_normal((600, 3)),  # just off the surface
+        c + 1e-3 * ext * rng.standard_normal((300, 3)), c[None, :],             # the medial region: near-ties everywhere
+        c + 10.0 * ext * rng.standard_normal((200, 3)),                         # far away
+    ])
+
+
+@pytest.mark.parametrize("host_build", [False, True])
+def test_mesh_lower_bound_filter_keeps_the_scan_winner(H, O, ctx, monkeypatch, host_build):
+    """Leaves of several triangles and the plane-and-circle lower bound in front of the closest-point test (kernels.hip,
+    triLowerBound2) only skip work: per-lane traversal, the sampler's shared traversal and the O(n) scan return the same
+    bits -- on thin triangles, slivers, meshes far from the origin, points on the surface and in the medial region, with
+    the device-built LBVH and with the host-built tree."""
+    if host_build:
+        monkeypatch.setenv("HPSDF_MESH_HOST_BUILD", "1")
+    for seed, (name, (verts, tris)) in enumerate(_hard_meshes()):
+        f = H.Field.mesh(ctx, verts, tris)
+        pts = _hard_points(O, verts, tris, seed)
+        want = f.eval_naive(ctx, pts)
+        assert np.array_equal(bits(f.eval(ctx, pts)), bits(want)), name
+        assert np.array_equal(bits(f.eval_wave(ctx, pts)), bits(want)), name
+        perm = np.random.default_rng(seed).permutation(len(pts))
+        assert np.array_equal(bits(f.eval_wave(ctx, pts[perm])), bits(want[perm])), name
+        f.close()
+
+
 # ------------------------------------------------------------------ blocks shaped like the reference's (SURVEY H5)
 def _reference_shaped(blk, rng):
     """What Octree::ToMemoryBlock really emits: interior nodes keep a stale heap pointer in basis.coeffs

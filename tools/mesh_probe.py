@@ -30,8 +30,9 @@ for level in (a for a in sys.argv[1:] or ["5", "7", "8"]):
     if os.environ.get("HPSDF_MESH_STATS"):
         ms = f.mesh_stats()
         q = max(1, ms["wave_queries"])
-        print("   traversal: %d wave queries, %.0f nodes, %.0f triangle tests (%.1f lanes each) per query"
-              % (q, ms["node_visits"] / q, ms["tri_tests"] / q, ms["tri_test_lanes"] / max(1, ms["tri_tests"])))
+        print("   traversal: %d wave queries; per query of 64 samples: %.0f nodes visited, %.0f (lane, triangle) pairs through the "
+              "lower-bound test, %.0f through the closest-point test"
+              % (q, ms["node_visits"] / q, ms["tri_tests"] / q, ms["tri_test_lanes"] / q))
     pts = np.random.default_rng(1).uniform(lo, hi, (1_000_000, 3))
     t6 = time.time(); v = f.eval(ctx, pts); t7 = time.time()
     print("%s: %d tris | gen %.1fs | prepare (half-edges+BVH+upload) %.2fs | Create 1e-5: %.1f ms (first %.1f ms) "
