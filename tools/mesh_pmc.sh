@@ -18,7 +18,7 @@ out = sys.argv[1]
 acc = {}
 for f in glob.glob(os.path.join(out, "**/*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "fit_kernel<2" not in r["Kernel_Name"] and "mesh_sample_kernel" not in r["Kernel_Name"]:
+        if "fit_kernel<" not in r["Kernel_Name"] and "mesh_sample_kernel" not in r["Kernel_Name"]:
             continue
         acc.setdefault((r["Kernel_Name"][:40], r["Counter_Name"]), []).append(float(r["Counter_Value"]))
 for k in sorted(acc):
@@ -31,7 +31,15 @@ def avg(name):
     return None
 tc, iv, w = avg("SQ_THREAD_CYCLES_VALU"), avg("SQ_INSTS_VALU"), avg("SQ_WAVES")
 if tc and iv:
-    print("mesh_sample_kernel lane utilisation SQ_THREAD_CYCLES_VALU / (SQ_INSTS_VALU * 256) = %.3f" % (tc / (iv * 256)))
+    print("mesh_sample_kernel SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU = %.1f active lanes per VALU instruction" % (tc / iv))
+    print("mesh_sample_kernel lane utilisation SQ_THREAD_CYCLES_VALU / (SQ_INSTS_VALU * 64) = %.3f   [/ (... * 256) = %.3f]" % (tc / (iv * 64), tc / (iv * 256)))
+    # calibration of the counter's full scale: the fit kernel of the same run has every lane active in all but a few instructions
+    for k in sorted(acc):
+        if k[1] == "SQ_THREAD_CYCLES_VALU" and "fit_kernel<" in k[0]:
+            fi = acc.get((k[0], "SQ_INSTS_VALU"))
+            if fi:
+                print("calibration: %s SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU = %.1f (all lanes active: full scale is 64, not 256)"
+                      % (k[0], (sum(acc[k]) / len(acc[k])) / (sum(fi) / len(fi))))
     print("mesh_sample_kernel VALU instructions per wave (64 samples): %.0f" % (iv / w))
 fs, ws = avg("FETCH_SIZE"), avg("WRITE_SIZE")
 if fs and w:
