@@ -143,6 +143,10 @@ _SIGNATURES = {
     "hpsdf_build_round_results_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "hpsdf_build_round_apply": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hpsdf_build_round_inject": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "hpsdf_build_rows_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "hpsdf_build_rows_pack_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hpsdf_build_rows_unpack_host": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "hpsdf_build_node_rows_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]),
     "hpsdf_build_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "hpsdf_build_pack_device": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "hpsdf_build_pack_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -512,6 +516,31 @@ class Build:
         h = np.ascontiguousarray(h_coeffs, np.float64) if h_coeffs is not None else None
         check(lib().hpsdf_build_round_inject(self.handle, job, p.ctypes.data_as(C.c_void_p) if p is not None else None,
                                              h.ctypes.data_as(C.c_void_p) if h is not None else None))
+
+    def rows_counts(self):
+        """Weighted builds on N ranks: doubles every rank hands over after the round just applied (hpsdf.h)."""
+        counts = (C.c_uint64 * self.world)()
+        check(lib().hpsdf_build_rows_counts(self.handle, counts))
+        return list(counts)
+
+    def rows_pack_host(self, ctx, count):
+        out = np.zeros(max(1, count))
+        check(lib().hpsdf_build_rows_pack_host(self.handle, ctx.handle if ctx is not None else None, out.ctypes.data_as(C.c_void_p)))
+        return out[:count]
+
+    def rows_unpack_host(self, ctx, parts):
+        keep = [np.ascontiguousarray(p, np.float64) if len(p) else np.zeros(1) for p in parts]
+        arr = (C.c_void_p * len(keep))(*[k.ctypes.data_as(C.c_void_p).value for k in keep])
+        check(lib().hpsdf_build_rows_unpack_host(self.handle, ctx.handle if ctx is not None else None, arr))
+
+    def node_rows(self, ctx, node_idx):
+        """The coefficient rows node ``node_idx`` holds right now (its full array in a weighted build), if on this rank."""
+        n = C.c_uint64()
+        check(lib().hpsdf_build_node_rows_host(self.handle, ctx.handle if ctx is not None else None, node_idx, None, C.byref(n)))
+        out = np.zeros(max(1, n.value))
+        check(lib().hpsdf_build_node_rows_host(self.handle, ctx.handle if ctx is not None else None, node_idx,
+                                               out.ctypes.data_as(C.c_void_p), C.byref(n)))
+        return out[:n.value]
 
     def layout(self):
         tot = C.c_uint64()

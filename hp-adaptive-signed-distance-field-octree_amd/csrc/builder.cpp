@@ -138,9 +138,6 @@ int builderBegin(hpsdf_build* b, const hpsdf_config* cfg, const hpsdf_build_opts
     if (cfg->weighting_type > 2) return fail(HPSDF_ERR_INVALID_ARGUMENT, "unknown nearnessWeighting.type");
     if (cfg->weighting_type != 0) {
         if (!(cfg->weighting_strength > 0.0)) return fail(HPSDF_ERR_INVALID_ARGUMENT, "nearnessWeighting.strength must be > 0");
-        if (opts && opts->world > 1)
-            return fail(HPSDF_ERR_UNSUPPORTED,
-                        "nearness weighting needs every node's previous coefficients on the fitting rank: single-rank builds only");
     }
     b->weighted = cfg->weighting_type != 0;
     b->cfg = *cfg;
@@ -404,8 +401,9 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
             uint64_t prev = kNone;
             if (b->weighted) {
                 const int64_t sg = b->segHead[e.idx];
-                if (sg < 0 || b->segs[sg].hostStore || b->segs[sg].owner != b->rank)
-                    return fail(HPSDF_ERR_STATE, "weighted incremental fit without the node's previous coefficients in HBM");
+                if (sg < 0 || b->segs[sg].hostStore || (b->segs[sg].owner != b->rank && !b->segs[sg].local))
+                    return fail(HPSDF_ERR_STATE, "weighted incremental fit without the node's previous coefficients in HBM "
+                                                 "(on N ranks: exchange the accepted rows after every round, hpsdf_build_rows_*)");
                 prev = b->segs[sg].off;
             }
             jo.pOff = addTask(p + 1, true, n.aabb_min, n.aabb_max, d, slot0, prev);
@@ -567,6 +565,8 @@ int builderApply(hpsdf_build* b, const double* headers) {
     if (!b->roundOpen) return fail(HPSDF_ERR_STATE, "no open round");
     const Tables& T = tables();
     int owner = 0;
+    b->rowItems.clear();
+    const bool exchangeRows = b->weighted && b->world > 1;
     for (uint64_t j = 0; j < b->batch.size(); ++j) {
         while (owner + 1 < b->world && j >= b->slices[owner].first + b->slices[owner].count) ++owner;
         const bool mine = owner == b->rank;
@@ -610,6 +610,7 @@ int builderApply(hpsdf_build* b, const double* headers) {
             s.next = -1;
             if (mine && s.off == kNone) return fail(HPSDF_ERR_STATE, "P result of an owned job was never computed");
             appendSeg(b, idx, s);
+            if (exchangeRows) b->rowItems.push_back({(int64_t)b->segs.size() - 1, owner, s.rowEnd});
             b->nodes[idx].degree = (uint8_t)np;
             b->total += (pErr - err);
             b->heap.push_back({idx, pErr});
@@ -631,6 +632,7 @@ int builderApply(hpsdf_build* b, const double* headers) {
                 s.hostStore = mine ? jo->hHost : 0;
                 s.next = -1;
                 appendSeg(b, c0 + i, s);
+                if (exchangeRows) b->rowItems.push_back({(int64_t)b->segs.size() - 1, owner, s.rowEnd});
                 b->nodes[c0 + i].degree = (uint8_t)p;
                 b->total += h[1 + i];
                 b->heap.push_back({c0 + i, h[1 + i]});
@@ -646,6 +648,127 @@ int builderApply(hpsdf_build* b, const double* headers) {
     b->stats.rounds++;
     b->stats.total_error = b->total;
     b->roundOpen = false;
+    return HPSDF_OK;
+}
+
+// ---- weighted builds on N ranks: after every round the ranks hand each other the arrays that round accepted
+// (hpsdf.h: hpsdf_build_rows_*).  counts[r] = doubles rank r contributes, items in job order.
+int builderRowsCounts(const hpsdf_build* b, uint64_t* counts) {
+    if (b->roundOpen) return fail(HPSDF_ERR_STATE, "round still open: apply it first");
+    for (int r = 0; r < b->world; ++r) counts[r] = 0;
+    for (const auto& it : b->rowItems) counts[it.owner] += it.count;
+    return HPSDF_OK;
+}
+
+// this rank's accepted arrays of the last round, contiguous, in item order
+int builderRowsPackHost(hpsdf_build* b, hpsdf_ctx* ctx, double* out) {
+    if (b->roundOpen) return fail(HPSDF_ERR_STATE, "round still open: apply it first");
+    uint64_t pos = 0;
+    bool anyDevice = false;
+    for (const auto& it : b->rowItems) {
+        if (it.owner != b->rank) continue;
+        const hpsdf_build::Seg& sg = b->segs[it.seg];
+        if (sg.hostStore) {
+            std::memcpy(out + pos, b->hostStore.data() + sg.off, it.count * sizeof(double));
+        } else {
+            if (!ctx || !b->ws || !b->ws->arena) return fail(HPSDF_ERR_NO_DEVICE, "rows in HBM need the device context that computed them");
+            if (!anyDevice) HPSDF_HIP(hipSetDevice(ctx->device));
+            anyDevice = true;
+            HPSDF_HIP(hipMemcpyAsync(out + pos, b->ws->arena + sg.off, it.count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        }
+        pos += it.count;
+    }
+    if (anyDevice) HPSDF_HIP(hipStreamSynchronize(ctx->stream));
+    return HPSDF_OK;
+}
+
+// parts[r] = what rank r packed (parts[rank] is not read).  With a device context the rows go to this rank's arena
+// (one upload per rank), without one to the host store (CPU tests); either way the segments now have a local copy.
+int builderRowsUnpackHost(hpsdf_build* b, hpsdf_ctx* ctx, const double* const* parts) {
+    if (b->roundOpen) return fail(HPSDF_ERR_STATE, "round still open: apply it first");
+    std::vector<uint64_t> counts(b->world, 0), base(b->world, 0), cur(b->world, 0);
+    for (const auto& it : b->rowItems) counts[it.owner] += it.count;
+    uint64_t need = 0;
+    for (int r = 0; r < b->world; ++r)
+        if (r != b->rank) {
+            if (counts[r] && (!parts || !parts[r])) return fail(HPSDF_ERR_INVALID_ARGUMENT, "missing rows of a rank");
+            need += counts[r];
+        }
+    if (need == 0) {
+        b->rowItems.clear();
+        return HPSDF_OK;
+    }
+    if (ctx) {
+        HPSDF_HIP(hipSetDevice(ctx->device));
+        acquireWorkspace(b, ctx);
+        Workspace& ws = *b->ws;
+        if (b->arenaUsed + need > ws.arenaCap) {  // grow by reallocation, as builderCompute does
+            uint64_t nc = std::max<uint64_t>(ws.arenaCap * 2, 1ull << 22);
+            while (nc < b->arenaUsed + need) nc *= 2;
+            double* na = nullptr;
+            HPSDF_HIP(hipMalloc((void**)&na, nc * sizeof(double)));
+            if (ws.arena) {
+                if (b->arenaUsed)
+                    HPSDF_HIP(hipMemcpyAsync(na, ws.arena, b->arenaUsed * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+                HPSDF_HIP(hipStreamSynchronize(ctx->stream));
+                HPSDF_HIP(hipFree(ws.arena));
+            }
+            ws.arena = na;
+            ws.arenaCap = nc;
+        }
+        uint64_t at = b->arenaUsed;
+        for (int r = 0; r < b->world; ++r) {
+            if (r == b->rank || !counts[r]) continue;
+            base[r] = at;
+            HPSDF_HIP(hipMemcpyAsync(ws.arena + at, parts[r], counts[r] * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            at += counts[r];
+        }
+        HPSDF_HIP(hipStreamSynchronize(ctx->stream));  // the caller's buffers may go away
+        b->arenaUsed = at;
+    } else {
+        for (int r = 0; r < b->world; ++r) {
+            if (r == b->rank || !counts[r]) continue;
+            base[r] = b->hostStore.size();
+            b->hostStore.insert(b->hostStore.end(), parts[r], parts[r] + counts[r]);
+        }
+    }
+    for (const auto& it : b->rowItems) {
+        if (it.owner != b->rank) {
+            hpsdf_build::Seg& sg = b->segs[it.seg];
+            sg.off = base[it.owner] + cur[it.owner];
+            sg.hostStore = ctx ? 0 : 1;
+            sg.local = 1;
+        }
+        cur[it.owner] += it.count;
+    }
+    b->rowItems.clear();
+    return HPSDF_OK;
+}
+
+// the rows a node holds right now (its whole chain), if this rank has them: out[0 .. coeffCount[degree])
+int builderNodeRowsHost(hpsdf_build* b, hpsdf_ctx* ctx, uint64_t node, double* out, uint64_t* n) {
+    if (node >= b->nodes.size()) return fail(HPSDF_ERR_INVALID_ARGUMENT, "no such node");
+    uint64_t rows = 0;
+    bool anyDevice = false;
+    for (int64_t s = b->segHead[node]; s >= 0; s = b->segs[s].next) {
+        const hpsdf_build::Seg& sg = b->segs[s];
+        if (sg.rowStart != rows) return fail(HPSDF_ERR_STATE, "coefficient segments are not contiguous");
+        if (sg.owner != b->rank && !sg.local) return fail(HPSDF_ERR_STATE, "the node's rows live on another rank");
+        if (out) {
+            if (sg.hostStore) {
+                std::memcpy(out + sg.rowStart, b->hostStore.data() + sg.off, (sg.rowEnd - sg.rowStart) * sizeof(double));
+            } else {
+                if (!ctx || !b->ws || !b->ws->arena) return fail(HPSDF_ERR_NO_DEVICE, "rows in HBM need the device context that computed them");
+                if (!anyDevice) HPSDF_HIP(hipSetDevice(ctx->device));
+                anyDevice = true;
+                HPSDF_HIP(hipMemcpyAsync(out + sg.rowStart, b->ws->arena + sg.off, (sg.rowEnd - sg.rowStart) * sizeof(double), hipMemcpyDeviceToHost,
+                                         ctx->stream));
+            }
+        }
+        rows = sg.rowEnd;
+    }
+    if (anyDevice) HPSDF_HIP(hipStreamSynchronize(ctx->stream));
+    if (n) *n = rows;
     return HPSDF_OK;
 }
 

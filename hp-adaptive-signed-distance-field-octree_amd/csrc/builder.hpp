@@ -36,6 +36,7 @@ struct hpsdf_build {
         uint32_t rowStart, rowEnd;
         int32_t owner;
         int32_t hostStore;  // 1: off indexes hostStore (injected), 0: device arena
+        int32_t local = 0;  // a copy of another rank's rows lives HERE at off / hostStore (weighted builds on N ranks)
         int64_t next;       // next segment of the same node, -1 = end
     };
     std::vector<hpsdf_node> nodes;
@@ -62,6 +63,15 @@ struct hpsdf_build {
     };
     std::vector<JobOut> jobOut;  // indexed by job - slices[rank].first
     bool roundOpen = false, computed = false;
+    // weighted builds on N ranks: the arrays the round just applied has accepted, in job order (children 0..7 within
+    // a job) -- what the ranks hand each other after every round, because the next incremental fit of a node copies
+    // its previous rows (Octree.cpp:847) and may run on any rank
+    struct RowItem {
+        int64_t seg;
+        int32_t owner;
+        uint32_t count;
+    };
+    std::vector<RowItem> rowItems;
 
     // ---- device state of this rank: buffers borrowed from the context's workspace (or private ones
     //      when several builds share a context); the context must outlive the build
@@ -97,5 +107,9 @@ int builderLayout(hpsdf_build* b);
 int builderPackDevice(hpsdf_build* b, hpsdf_ctx* ctx, double** dPack, uint64_t* n);
 int builderPackHost(hpsdf_build* b, hpsdf_ctx* ctx, double* out);
 int builderAssemble(hpsdf_build* b, const double* const* packs, void** block, size_t* size);
+int builderRowsCounts(const hpsdf_build* b, uint64_t* counts);
+int builderRowsPackHost(hpsdf_build* b, hpsdf_ctx* ctx, double* out);
+int builderRowsUnpackHost(hpsdf_build* b, hpsdf_ctx* ctx, const double* const* parts);
+int builderNodeRowsHost(hpsdf_build* b, hpsdf_ctx* ctx, uint64_t node, double* out, uint64_t* n);
 
 }  // namespace hpsdf

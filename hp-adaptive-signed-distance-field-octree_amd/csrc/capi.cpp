@@ -985,6 +985,34 @@ int hpsdf_build_round_apply(hpsdf_build* b, const double* headers) {
     HPSDF_CATCH
 }
 
+int hpsdf_build_rows_counts(const hpsdf_build* b, uint64_t* counts_per_rank) {
+    HPSDF_TRY
+    if (!b || !counts_per_rank) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    return builderRowsCounts(b, counts_per_rank);
+    HPSDF_CATCH
+}
+
+int hpsdf_build_rows_pack_host(hpsdf_build* b, hpsdf_ctx* ctx, double* out) {
+    HPSDF_TRY
+    if (!b || !out) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    return builderRowsPackHost(b, ctx, out);
+    HPSDF_CATCH
+}
+
+int hpsdf_build_rows_unpack_host(hpsdf_build* b, hpsdf_ctx* ctx, const double* const* parts) {
+    HPSDF_TRY
+    if (!b) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null build");
+    return builderRowsUnpackHost(b, ctx, parts);
+    HPSDF_CATCH
+}
+
+int hpsdf_build_node_rows_host(hpsdf_build* b, hpsdf_ctx* ctx, uint64_t node_idx, double* out, uint64_t* n_rows) {
+    HPSDF_TRY
+    if (!b) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null build");
+    return builderNodeRowsHost(b, ctx, node_idx, out, n_rows);
+    HPSDF_CATCH
+}
+
 int hpsdf_build_round_inject(hpsdf_build* b, uint64_t job, const double* pCoeffs, const double* hCoeffs) {
     HPSDF_TRY
     if (!b) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null build");

@@ -13,7 +13,9 @@ Create
     device-side frontier (csrc/frontier.hip, hpsdf_create_distributed): selection, slicing, decision
     and bookkeeping run on every rank's GPU and the two exchange points are all-gathers of device
     buffers.  Host callbacks and weighted builds run the host scheduler through the stepwise C API
-    below (the per-round errors then pass through host memory).
+    below (the per-round errors then pass through host memory).  A weighted build also hands the arrays
+    each round accepted to every rank (one more all-gather per round): a weighted incremental fit copies
+    the node's previous rows and may run on any rank.
 
 Continuity (config.continuity.enforce)
     The host-side post-process runs on every rank on its identical copy of the assembled block; its
@@ -110,26 +112,29 @@ def create_distributed(ctx, config, field, K=0, group=None, compute=None, policy
         except HpsdfError as e:  # e.g. a tree-CSG field around a host callback: the stepwise path below shards it
             if e.status != ERR_UNSUPPORTED:
                 raise
-    if world > 1 and pod.weighting_type != 0 and on_gpu:
-        # Nearness-weighted fits keep one full coefficient array per node and an incremental fit reads the node's
-        # previous rows, which live in the arena of whichever rank fitted them: such builds are not sharded.
-        # Every rank builds the whole tree (deterministic, so the blocks are identical): replicas, no exchange.
-        from . import create_block
-        return create_block(ctx, config, field, K)
-    dev = torch.device("cuda", ctx.device) if on_gpu else torch.device("cpu")
+    # Nearness-weighted builds: the weight (pow / exp) is applied on the host (one libm for GPU path and oracle), so the
+    # per-round errors pass through host memory, and after every round the ranks hand each other the coefficient arrays
+    # that round accepted -- an incremental fit copies the node's previous rows and may run on any rank.
+    weighted = pod.weighting_type != 0
+    backend_dev = torch.device("cuda", ctx.device) if (ctx is not None and dist.is_initialized() and dist.get_backend(group) == "nccl") \
+        else torch.device("cpu")
+    dev = torch.device("cuda", ctx.device) if (on_gpu and not weighted) else (backend_dev if world > 1 else torch.device("cpu"))
     b = Build(config, K, rank, world)
     while True:
         n = b.select()
         if n == 0:
             break
         first, count = b.slice()
-        if on_gpu:
+        if on_gpu and not weighted:
             b.compute(ctx, field)
             ptr, nd = b.results_device()
             ctx.synchronize()  # the fit kernel ran on the context stream; the collective runs on torch's
             local = torch.as_tensor(_DevPtr(ptr, nd), device=dev) if nd else torch.empty(0, dtype=torch.float64, device=dev)
+        elif on_gpu:
+            b.compute(ctx, field)
+            local = torch.from_numpy(b.results_host(ctx)).to(dev)
         else:
-            local = torch.from_numpy(np.ascontiguousarray(compute(b, b.jobs(n), first, count), np.float64).reshape(-1))
+            local = torch.from_numpy(np.ascontiguousarray(compute(b, b.jobs(n), first, count), np.float64).reshape(-1)).to(dev)
         if world == 1:
             headers = local.cpu().numpy().reshape(n, JOB_HEADER_DOUBLES)
         else:
@@ -140,13 +145,18 @@ def create_distributed(ctx, config, field, K=0, group=None, compute=None, policy
                 f, c = b.slice(r)
                 headers[f:f + c] = gathered[r, : c * JOB_HEADER_DOUBLES].reshape(c, JOB_HEADER_DOUBLES)
         b.apply(headers)
+        if weighted and world > 1:
+            rc = b.rows_counts()
+            mine = torch.from_numpy(b.rows_pack_host(ctx if on_gpu else None, rc[rank])).to(dev)
+            g = _gather_padded(mine, max(1, max(rc)), group, world).cpu().numpy()
+            b.rows_unpack_host(ctx if on_gpu else None, [g[r, : rc[r]] for r in range(world)])
     _, counts = b.layout()
-    if on_gpu:
+    if on_gpu and dev.type == "cuda":
         ptr, nd = b.pack_device(ctx)
         ctx.synchronize()
         mine = torch.as_tensor(_DevPtr(ptr, nd), device=dev) if nd else torch.empty(0, dtype=torch.float64, device=dev)
     else:
-        mine = torch.from_numpy(b.pack_host(None, counts[rank]))
+        mine = torch.from_numpy(b.pack_host(ctx if on_gpu else None, counts[rank]))
     if world == 1:
         packs = [mine.cpu().numpy()]
     else:

@@ -261,6 +261,20 @@ HPSDF_API int hpsdf_build_round_apply(hpsdf_build* b, const double* headers);
 HPSDF_API int hpsdf_build_round_inject(hpsdf_build* b, uint64_t job, const double* p_coeffs,
                                        const double* h_coeffs);
 
+/* Nearness-weighted builds on N ranks (config.weighting_type != 0, opts.world > 1).  A weighted fit keeps ONE full
+ * coefficient array per node and an incremental fit copies the node's previous rows (Octree.cpp:847), so the rank
+ * that fits a node next needs what another rank accepted for it: after every hpsdf_build_round_apply the ranks hand
+ * each other the arrays that round accepted (a P refinement: the node's new array; an H refinement: its 8
+ * children's), in job order.  hpsdf_build_rows_counts: doubles each rank contributes (all zero for unweighted or
+ * single-rank builds); hpsdf_build_rows_pack_host: this rank's part, contiguous; after an all-gather,
+ * hpsdf_build_rows_unpack_host(parts[world]) stores the other ranks' parts in this rank's arena (ctx != NULL) or host
+ * store (ctx == NULL, CPU tests).  parts[own rank] is not read.  hpsdf_build_node_rows_host: the rows a node holds right
+ * now, if this rank has them (out may be NULL to ask for the count). */
+HPSDF_API int hpsdf_build_rows_counts(const hpsdf_build* b, uint64_t* counts_per_rank);
+HPSDF_API int hpsdf_build_rows_pack_host(hpsdf_build* b, hpsdf_ctx* ctx, double* out);
+HPSDF_API int hpsdf_build_rows_unpack_host(hpsdf_build* b, hpsdf_ctx* ctx, const double* const* parts);
+HPSDF_API int hpsdf_build_node_rows_host(hpsdf_build* b, hpsdf_ctx* ctx, uint64_t node_idx, double* out, uint64_t* n_rows);
+
 /* ReallocCoeffs (Octree.cpp:474-555): DFS layout, then gather.  counts[r] = doubles owned by rank r. */
 HPSDF_API int hpsdf_build_layout(hpsdf_build* b, uint64_t* n_coeffs_total, uint64_t* counts_per_rank);
 /* this rank's leaves' coefficients, in DFS order */

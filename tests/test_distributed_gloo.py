@@ -28,12 +28,17 @@ rank, world = dist.get_rank(), dist.get_world_size()
 f = O.MeshField(*displaced_torus(*case["torus"])) if case["field"] == "torus_mesh" else oracle_field(O, case["field"])
 ocfg = O.default_config(case["target"], case["root_min"], case["root_max"])
 cfg = H.make_config(case["target"], case["root_min"], case["root_max"], continuity=bool(case.get("continuity")))
+if case.get("weighting"):
+    ocfg.weighting_type, ocfg.weighting_strength = case["weighting"], 3.0
+    cfg.nearnessWeighting_type, cfg.nearnessWeighting_strength = case["weighting"], 3.0
 def compute(b, jobs, first, count):
     hdr = np.zeros((count, 9))
     for j in range(first, first + count):
         jb = jobs[j]
-        res, pc, hc = O.job(f, ocfg, tuple(jb.aabb_min), tuple(jb.aabb_max), jb.depth, jb.degree, jb.err,
-                            None if jb.coarse else np.zeros(O.NCOEF[jb.degree]))
+        # a weighted incremental fit copies the node's previous rows (Octree.cpp:847): they are on this rank because the
+        # ranks hand each other the accepted arrays after every round (an unweighted fit only forms the new rows)
+        prev = None if jb.coarse else (b.node_rows(None, jb.node_idx) if case.get("weighting") else np.zeros(O.NCOEF[jb.degree]))
+        res, pc, hc = O.job(f, ocfg, tuple(jb.aabb_min), tuple(jb.aabb_max), jb.depth, jb.degree, jb.err, prev)
         hdr[j - first, 0] = res.p_err; hdr[j - first, 1:] = list(res.h_err)
         b.inject(j, pc, hc.reshape(-1))
     return hdr
@@ -69,6 +74,32 @@ def test_world2_gloo_block_identical(golden, case, O, H):
         assert res[k]["sha"] == want
         assert res[k]["stats"]["n_nodes"] == g["n_nodes"] and res[k]["stats"]["jobs"] == g["stats"]["jobs"]
     assert res[0]["shard"] == [0, 500] and res[1]["shard"] == [500, 1000]
+
+
+def test_world2_gloo_weighted_build(O, H):
+    """A nearness-weighted build over two gloo ranks: the per-round hand-over of the accepted coefficient arrays
+    (distributed.py, hpsdf_build_rows_*) keeps every rank able to run any node's next incremental fit -- the hook below
+    reads the node's previous rows from the build on whichever rank the job lands -- and both ranks end with the
+    oracle's single-rank block."""
+    case = {"field": "sphere", "target": 1e-7, "root_min": [-0.5] * 3, "root_max": [0.5] * 3, "K": 256, "weighting": 1}
+    with tempfile.TemporaryDirectory() as td:
+        wpath = os.path.join(td, "worker.py")
+        open(wpath, "w").write(WORKER)
+        out = os.path.join(td, "res")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+               "127.0.0.1", "--master-port", "29521", wpath, ROOT, json.dumps(case), out]
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+        ocfg = O.default_config(case["target"])
+        ocfg.weighting_type, ocfg.weighting_strength = 1, 3.0
+        one = O.Tree.create(ocfg, O.sphere_field(), case["K"])
+        so, se = p.communicate(timeout=900)
+        assert p.returncode == 0, so[-2000:] + se[-4000:]
+        res = [json.load(open(out + ".%d" % k)) for k in range(2)]
+    assert one.stats["rounds"] >= 3 and one.stats["p_refines"] > 4096
+    for k in range(2):
+        assert res[k]["sha"] == hashlib.sha256(one.to_block()).hexdigest()
+        assert res[k]["stats"]["jobs"] == one.stats["jobs"]
 
 
 def test_world2_gloo_mesh_field_at_1e6(O, H):

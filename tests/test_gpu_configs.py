@@ -83,6 +83,47 @@ def test_mesh_field_through_sharded_frontier_is_byte_identical(H, ctx, world):
         assert b.assemble(packs) == one
 
 
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("wtype,target", [(1, 1e-8), (2, 1e-9)])
+def test_weighted_build_sharded_is_byte_identical(H, ctx, world, wtype, target):
+    """Nearness-weighted builds (what the reference's own tests and benchmarks switch on, HPUnitTests.cpp:53-58) with
+    the frontier sharded over `world` ranks: a weighted incremental fit copies the node's previous rows (Octree.cpp:847),
+    which another rank may have fitted -- after every round the ranks hand each other the arrays that round accepted
+    (hpsdf_build_rows_*).  Every rank ends with the single-rank block, byte for byte."""
+    cfg = H.make_config(target)
+    cfg.nearnessWeighting_type, cfg.nearnessWeighting_strength = wtype, 3.0
+    f = H.Field.sphere()
+    one, st1 = H.create_block(ctx, cfg, f, 256)
+    assert st1["p_refines"] > 4096 and st1["rounds"] >= 3  # incremental fits of nodes fitted in earlier rounds
+    builds = [H.Build(cfg, 256, r, world) for r in range(world)]
+    handed = 0
+    while True:
+        n = builds[0].select()
+        for b in builds[1:]:
+            assert b.select() == n
+        if n == 0:
+            break
+        hdr = np.zeros((n, 9))
+        for b in builds:
+            b.compute(ctx, f)
+            first, count = b.slice()
+            hdr[first:first + count] = b.results_host(ctx).reshape(count, 9)
+        for b in builds:
+            b.apply(hdr)
+        rc = builds[0].rows_counts()
+        assert all(b.rows_counts() == rc for b in builds)
+        parts = [builds[r].rows_pack_host(ctx, rc[r]) for r in range(world)]
+        handed += sum(rc)
+        for b in builds:
+            b.rows_unpack_host(ctx, parts)
+    assert handed > 0
+    lays = [b.layout() for b in builds]
+    packs = [builds[r].pack_host(ctx, lays[r][1][r]) for r in range(world)]
+    for b in builds:
+        assert b.assemble(packs) == one
+        assert b.stats()["jobs"] == st1["jobs"]
+
+
 def test_mesh_bvh_equals_linear_scan_bitwise(H, O, ctx):
     """TestBVHQuerying (MeshingUnitTests.cpp:110-138) on the device: the BVH traversal returns what the O(n) scan of
     Mesh::ClosestTriangleToPt (Mesh.cpp:134-159) returns -- same triangle, same bits -- and both match the oracle."""
