@@ -1,12 +1,21 @@
 // Continuity post-process, the solve (Octree::PerformContinuityPostProcess, Octree.cpp:1751-1756) on the device:
 // the Jacobi-preconditioned conjugate-gradient loop of continuity.cpp, a kernel per region, with the SAME arithmetic,
 // so the block it returns is bit-identical to the host solve's (tests/test_gpu_parity.py):
-//   * a matrix row is summed left to right in CSR order (stored here as sliced ELL, 64 rows per slice, so that a wave
-//     reads its 64 rows' k-th entries as one contiguous run);
+//   * a matrix row is summed left to right in CSR order (read from the CSR arrays as they are: 20 MB for the 83 k-unknown
+//     benchmark system, which stays in the L2s between iterations; the sliced-ELL copy of the first versions was 35 MB --
+//     three quarters padding, neighbouring rows differ a lot in length -- and streamed from HBM every iteration);
 //   * a dot product is summed in the order cgChunkSum (launch.hpp) fixes: chunks of 256 elements -- one workgroup's
-//     rows -- each as 64 lane sums of 4 and a shuffle tree, then the chunks left to right.
-// The loop's scalars (alpha, beta, |r|^2, the iteration count, the stop flag) live in HBM; the host launches batches
-// of iterations and looks at the flag in between; the kernels of iterations past the stop return at once.
+//     rows -- each as 64 lane sums of 4 and a shuffle tree, then the chunk sums the same way again (cgCombine).
+// The loop's scalars (|r|^2, r . z, the iteration count, the stop flag) live in HBM; the host launches batches of
+// iterations and looks at the flag in between; the kernels of iterations past the stop return at once.
+// An iteration is TWO kernels (five in the first version: 42 us per iteration of which 21 were launch gaps):
+//   step 1 (k): every workgroup sums the chunk sums of |r|^2 and r . z that step 2 (k - 1) left -- the same fixed order,
+//               so all of them get the same beta and the same verdict on the stop rule -- and then runs
+//               tmp = (M + lambda I) p with the new direction p = z + beta p_old formed on the fly, entry by entry,
+//               from z and the previous direction (two buffers, alternating; the products are the same bits);
+//   step 2 (k): every workgroup sums the chunk sums of p . tmp, alpha = (r . z) / (p . tmp), then x, r, z and the new
+//               chunk sums.
+// Only workgroup 0 writes scalars, and only into slots no workgroup of the same kernel reads.
 #include <hip/hip_runtime.h>
 
 #include "launch.hpp"
@@ -28,70 +37,66 @@ __device__ __forceinline__ double blockChunkSum(double v, double* sh) {
     return s;
 }
 
-// CSR (as assembled on the host) -> sliced ELL, one thread per row; padding slots get column 0 / value 0
-__global__ __launch_bounds__(256) void cg_ell_kernel(uint64_t n, const uint64_t* __restrict__ rowPtr, const uint32_t* __restrict__ csrCol,
-                                                     const double* __restrict__ csrVal, const uint64_t* __restrict__ sliceOff,
-                                                     uint32_t* __restrict__ rowLen, uint32_t* __restrict__ col, double* __restrict__ val) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;  // the grid covers whole slices
-    const uint64_t slice = i >> 6, base = sliceOff[slice] + (i & 63);
-    const uint32_t width = (uint32_t)((sliceOff[slice + 1] - sliceOff[slice]) >> 6);
-    const uint64_t first = i < n ? rowPtr[i] : 0;
-    const uint32_t len = i < n ? (uint32_t)(rowPtr[i + 1] - first) : 0u;
-    if (i < n) rowLen[i] = len;
-    for (uint32_t k = 0; k < width; ++k) {
-        col[base + (uint64_t)k * 64] = k < len ? csrCol[first + k] : 0u;
-        val[base + (uint64_t)k * 64] = k < len ? csrVal[first + k] : 0.0;
-    }
+// tmp = (M + shift I) in and the chunk sums of in . tmp.  One workgroup of 1024 threads per chunk of 256 rows, FOUR ADJACENT
+// LANES PER ROW: of every run of 32 entries lane q fetches entries 8 q .. 8 q + 7 (all loads of the run in flight at once)
+// and forms the products; the row's sum then runs strictly left to right in all four lanes at once -- step k adds the
+// product held by lane k / 8, handed round inside the quad by DPP (no LDS, no barrier; the additions are the only
+// dependent chain).  A wave owns 16 rows and never waits for another.  (First version: a thread per row, 30 us per SpMV;
+// second: four waves per 64 rows of a sliced-ELL copy, products parked in LDS, a barrier per 32 entries: 21-25 us.)
+// FUSED: in = z + beta * pOld, formed per entry (and written to pNew for the rows of this chunk); otherwise in is read
+// as it is.  sh: 256 doubles of LDS.
+constexpr int kCgBatch = 8;  // entries per lane in flight: 32 per row
+template <int J>
+__device__ __forceinline__ double quadBroadcast(double v) {  // the value lane J of every quad holds, in all four lanes
+    constexpr int ctrl = J | (J << 2) | (J << 4) | (J << 6);  // quad_perm: [J, J, J, J]
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, ctrl, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), ctrl, 0xF, 0xF, false);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
 }
-
-// region 1 of an iteration: tmp = (M + lambda I) p and the chunk sums of p . tmp.  One workgroup of 1024 threads per
-// chunk of 256 rows: four lanes share a row -- lane q of them fetches entries q, q + 4, ... of the current tile of 32 and
-// parks the products in LDS -- and the row's own lane (q = 0) then adds them strictly left to right.  The loads of a tile
-// are independent of every addition, so they are all in flight at once (a thread per row ran one dependent
-// load -> gather -> add chain per entry batch: 30 us per SpMV against 8 for the bytes alone).
-constexpr int kCgTile = 32;
-// out = (M + shift I) in and the chunk sums of in . out -> part
-__device__ __forceinline__ void spmvChunk(const CgDev& d, const double* __restrict__ in, double shift, double* __restrict__ out,
-                                          double* __restrict__ part) {
-    __shared__ double sProd[4][kCgTile][64];  // [slice of the chunk][entry in tile][row in slice]; reused for the chunk sum
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sl = wave >> 2, q = wave & 3;
-    const uint64_t row = (uint64_t)blockIdx.x * 256 + sl * 64 + lane;
-    const bool live = row < d.n;
-    const uint64_t slice = (uint64_t)blockIdx.x * 4 + sl;
-    const uint64_t base = d.sliceOff[slice] + lane;
-    const uint32_t width = (uint32_t)((d.sliceOff[slice + 1] - d.sliceOff[slice]) >> 6);  // wave-uniform
-    uint32_t maxWidth = width;  // the workgroup's tile loop must be uniform over its four slices
+template <int J>
+__device__ __forceinline__ double quadRun(double acc, const double (&prod)[kCgBatch], uint32_t k0, uint32_t len) {
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
-        const uint64_t so = (uint64_t)blockIdx.x * 4 + o;
-        const uint32_t w = (uint32_t)((d.sliceOff[so + 1] - d.sliceOff[so]) >> 6);
-        maxWidth = w > maxWidth ? w : maxWidth;
+    for (int j = 0; j < kCgBatch; ++j) {  // entries k0 + 8 J + j of the row, in order; past the row's length nothing is added
+        const double t = acc + quadBroadcast<J>(prod[j]);
+        acc = k0 + (uint32_t)(kCgBatch * J + j) < len ? t : acc;
     }
-    const uint32_t len = live ? d.rowLen[row] : 0u;
-    const double pi = live ? in[row] : 0.0;
+    return acc;
+}
+template <bool FUSED>
+__device__ __forceinline__ void spmvChunk(const CgDev& d, const double* __restrict__ in, const double* __restrict__ pOld, double beta,
+                                          double* __restrict__ pNew, double shift, double* __restrict__ out, double* __restrict__ part,
+                                          double* sh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane & 3;
+    const int rowInChunk = wave * 16 + (lane >> 2);
+    const uint64_t row = (uint64_t)blockIdx.x * 256 + rowInChunk;
+    const bool live = row < d.n;
+    const uint64_t first = live ? d.rowPtr[row] : 0;
+    const uint32_t len = live ? (uint32_t)(d.rowPtr[row + 1] - first) : 0u;
+    auto value = [&](uint64_t j) { return FUSED ? in[j] + beta * pOld[j] : in[j]; };
+    const double pi = live ? value(row) : 0.0;
+    if (FUSED && q == 0 && live) pNew[row] = pi;
     double acc = shift * pi;
-    for (uint32_t k0 = 0; k0 < maxWidth; k0 += kCgTile) {
-        double v[kCgTile / 4], pv[kCgTile / 4];
+    for (uint32_t k0 = 0; __any(k0 < len); k0 += 4 * kCgBatch) {
+        double prod[kCgBatch], v[kCgBatch];
+        uint32_t col[kCgBatch];
 #pragma unroll
-        for (int m = 0; m < kCgTile / 4; ++m) {
-            const uint32_t k = k0 + q + 4 * m;
-            const uint64_t idx = base + (uint64_t)(k < width ? k : (width ? width - 1 : 0)) * 64;
-            v[m] = width ? d.val[idx] : 0.0;
-            pv[m] = width ? in[d.col[idx]] : 0.0;
+        for (int j = 0; j < kCgBatch; ++j) {
+            const uint32_t k = k0 + (uint32_t)(kCgBatch * q + j);
+            const bool on = k < len;
+            v[j] = on ? d.val[first + k] : 0.0;
+            col[j] = on ? d.col[first + k] : (uint32_t)(live ? row : 0);
         }
 #pragma unroll
-        for (int m = 0; m < kCgTile / 4; ++m) sProd[sl][q + 4 * m][lane] = v[m] * pv[m];
-        __syncthreads();
-        if (q == 0) {
-            const uint32_t end = len < k0 + kCgTile ? len : k0 + kCgTile;
-            for (uint32_t k = k0; k < end; ++k) acc += sProd[sl][k - k0][lane];
-        }
-        __syncthreads();
+        for (int j = 0; j < kCgBatch; ++j) prod[j] = v[j] * value(col[j]);
+        acc = quadRun<0>(acc, prod, k0, len);
+        acc = quadRun<1>(acc, prod, k0, len);
+        acc = quadRun<2>(acc, prod, k0, len);
+        acc = quadRun<3>(acc, prod, k0, len);
     }
     if (q == 0 && live) out[row] = acc;
-    // cgChunkSum over the chunk's 256 values in . out (rows past n hold 0.0): element e of the chunk = slice e / 64, lane e % 64
-    double* sh = &sProd[0][0][0];
-    if (q == 0) sh[sl * 64 + lane] = live ? pi * acc : 0.0;
+    // cgChunkSum over the chunk's 256 values in . out (rows past n hold 0.0)
+    if (q == 0) sh[rowInChunk] = live ? pi * acc : 0.0;
     __syncthreads();
     if (threadIdx.x < 64) {
         double s = ((sh[lane] + sh[64 + lane]) + sh[128 + lane]) + sh[192 + lane];
@@ -101,16 +106,113 @@ __device__ __forceinline__ void spmvChunk(const CgDev& d, const double* __restri
     }
 }
 
-__global__ __launch_bounds__(1024) void cg_spmv_kernel(CgDev d) {  // region 1 of an iteration
+// cgChunkSum (launch.hpp) of e[0 .. cnt), cnt <= 256, by one wave; the result is valid in lane 0
+__device__ __forceinline__ double waveChunkSum(const double* e, uint64_t cnt, int lane) {
+    auto at = [&](uint64_t i) { return i < cnt ? e[i] : 0.0; };
+    double s = ((at((uint64_t)lane) + at(64 + (uint64_t)lane)) + at(128 + (uint64_t)lane)) + at(192 + (uint64_t)lane);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s = s + __shfl_down(s, off, 64);
+    return s;
+}
+
+// cgCombine (launch.hpp) of the chunk sums of one or two dot products, with the totals handed to every thread of the
+// workgroup: the waves share the groups of 256 chunk sums, wave 0 combines the group sums.  nChunks <= kCgMaxChunksOnDevice.
+// sh: 514 doubles of LDS.
+template <bool TWO>
+__device__ __forceinline__ void sumChunksAll(uint64_t nChunks, const double* __restrict__ pa, const double* __restrict__ pb, double* sh,
+                                             double& sumA, double& sumB) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nWaves = blockDim.x >> 6;
+    const uint64_t m = (nChunks + 255) / 256;
+    for (uint64_t g = (uint64_t)wave; g < m; g += (uint64_t)nWaves) {
+        const uint64_t cnt = nChunks - 256 * g < 256 ? nChunks - 256 * g : 256;
+        const double a = waveChunkSum(pa + 256 * g, cnt, lane);
+        if (lane == 0) sh[g] = a;
+        if (TWO) {
+            const double b = waveChunkSum(pb + 256 * g, cnt, lane);
+            if (lane == 0) sh[256 + g] = b;
+        }
+    }
+    __syncthreads();
+    if (m > 1) {
+        if (wave == 0) {
+            const double a = waveChunkSum(sh, m, lane);
+            const double b = TWO ? waveChunkSum(sh + 256, m, lane) : 0.0;
+            if (lane == 0) sh[512] = a, sh[513] = b;
+        }
+        __syncthreads();
+        sumA = sh[512], sumB = TWO ? sh[513] : 0.0;
+    } else {
+        sumA = sh[0], sumB = TWO ? sh[256] : 0.0;
+    }
+    __syncthreads();
+}
+
+// What ends iteration k - 1 and opens iteration k (the reference's order: |r|^2 against the threshold, then beta, then the
+// iteration count against the cap).  Every workgroup computes it for itself; `writer` also records it.  Returns false
+// when the loop is over.
+__device__ __forceinline__ bool cgOpenIteration(const CgDev& d, int k, double* tile, bool writer, double& beta) {
+    double rr, rz;
+    sumChunksAll<true>(d.nChunks, d.partB, d.partC, tile, rr, rz);
+    CgScalars& s = *d.s;
+    const bool converged = rr < s.threshold;
+    const bool capped = !converged && k >= s.maxIter;
+    beta = converged ? 0.0 : rz / s.absRing[(k - 1) & 1];
+    if (writer && threadIdx.x == 0) {
+        s.resNorm2 = rr;
+        if (converged) {
+            s.done = 1;
+        } else {
+            s.absRing[k & 1] = rz;
+            s.absNew = rz;
+            s.beta = beta;
+            s.it = k;
+            if (capped) s.done = 2;  // the direction of an iteration past the cap feeds nothing
+        }
+    }
+    return !(converged || capped);
+}
+
+// step 1 of iteration k
+__global__ __launch_bounds__(1024, 8) void cg_step1_kernel(CgDev d, int k) {
+    __shared__ double sh[514];
     if (d.s->done) return;
-    spmvChunk(d, d.p, d.s->lambda, d.tmp, d.partA);
+    double* const P[2] = {d.p, d.rhs};  // the direction of iteration k lives in P[k & 1] (rhs is free once the loop runs)
+    if (k == 0) {
+        spmvChunk<false>(d, d.p, nullptr, 0.0, nullptr, d.s->lambda, d.tmp, d.partA, sh);
+        return;
+    }
+    double beta;
+    if (!cgOpenIteration(d, k, sh, blockIdx.x == 0, beta)) return;
+    spmvChunk<true>(d, d.z, P[(k - 1) & 1], beta, P[k & 1], d.s->lambda, d.tmp, d.partA, sh);
+}
+
+// after the last iteration of a batch: has the loop ended?  (one workgroup; the next batch's first kernel would find out
+// the same, one launch and one host round trip later)
+__global__ __launch_bounds__(64) void cg_check_kernel(CgDev d, int k) {
+    __shared__ double tile[514];
+    if (d.s->done) return;
+    double rr, rz;
+    sumChunksAll<true>(d.nChunks, d.partB, d.partC, tile, rr, rz);
+    if (threadIdx.x != 0) return;
+    CgScalars& s = *d.s;
+    if (rr < s.threshold) {
+        s.resNorm2 = rr;
+        s.done = 1;
+    } else if (k >= s.maxIter) {
+        s.resNorm2 = rr;
+        s.absNew = rz;
+        s.beta = rz / s.absRing[(k - 1) & 1];
+        s.it = k;
+        s.done = 2;
+    }
 }
 
 // ---- the steps around the loop (continuity.cpp runs them on the host when it has no device): same arithmetic
 // which: 0  tmp = M c, chunk sums of c . tmp (jump energy before);  1  tmp = (M + lambda I) x (for the first residual);
 //        2  tmp = M x, chunk sums of x . tmp (jump energy after)
-__global__ __launch_bounds__(1024) void cg_spmv_aux_kernel(CgDev d, int which) {
-    spmvChunk(d, which == 0 ? d.c : d.x, which == 1 ? d.s->lambda : 0.0, d.tmp, d.partA);
+__global__ __launch_bounds__(1024, 8) void cg_spmv_aux_kernel(CgDev d, int which) {
+    __shared__ double sh[256];
+    spmvChunk<false>(d, which == 0 ? d.c : d.x, nullptr, 0.0, nullptr, which == 1 ? d.s->lambda : 0.0, d.tmp, d.partA, sh);
 }
 
 // rhs = lambda c, x = rhs (solveWithGuess(old, old)), dinv = 1 / (lambda + diagonal entries of the row, in row order)
@@ -121,10 +223,9 @@ __global__ __launch_bounds__(256) void cg_setup_kernel(CgDev d) {
     const double rhs = d.c[i] * lambda;
     d.rhs[i] = rhs;
     d.x[i] = rhs;
-    const uint64_t base = d.sliceOff[i >> 6] + (i & 63);
     double diag = lambda;
-    for (uint32_t k = 0, len = d.rowLen[i]; k < len; ++k)
-        if (d.col[base + (uint64_t)k * 64] == (uint32_t)i) diag += d.val[base + (uint64_t)k * 64];
+    for (uint64_t k = d.rowPtr[i], end = d.rowPtr[i + 1]; k < end; ++k)
+        if (d.col[k] == (uint32_t)i) diag += d.val[k];
     d.dinv[i] = 1.0 / diag;
 }
 
@@ -146,46 +247,13 @@ __global__ __launch_bounds__(256) void cg_residual_kernel(CgDev d) {
     if (threadIdx.x == 0) d.partA[blockIdx.x] = a, d.partB[blockIdx.x] = b, d.partC[blockIdx.x] = c;
 }
 
-// the chunk sums left to right, by thread 0 out of LDS (tiles of 1024)
-template <bool TWO>
-__device__ __forceinline__ void sumChunks(const CgDev& d, double& sumA, double& sumB) {
-    __shared__ double ta[1024], tb[1024];
-    sumA = sumB = 0.0;
-    for (uint64_t c0 = 0; c0 < d.nChunks; c0 += 1024) {
-        const uint64_t c = c0 + threadIdx.x;
-        ta[threadIdx.x] = c < d.nChunks ? d.partA[c] : 0.0;
-        if (TWO) tb[threadIdx.x] = c < d.nChunks ? d.partB[c] : 0.0;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const int m = (int)(d.nChunks - c0 < 1024 ? d.nChunks - c0 : 1024);
-            for (int j = 0; j < m; ++j) {
-                sumA += ta[j];
-                if (TWO) sumB += tb[j];
-            }
-        }
-        __syncthreads();
-    }
-}
-
 // which: 0  jumpBefore = sum of partA;  2  jumpAfter = sum of partA;
 //        1  |b|^2, |r|^2, r . p from partA / partB / partC -> threshold, absNew, and whether there is anything to iterate
-__global__ __launch_bounds__(1024) void cg_scalar_aux_kernel(CgDev d, int which) {
-    double a, b;
-    sumChunks<true>(d, a, b);
-    __shared__ double tc[1024];
-    double c = 0.0;
-    if (which == 1) {
-        for (uint64_t c0 = 0; c0 < d.nChunks; c0 += 1024) {
-            const uint64_t ci = c0 + threadIdx.x;
-            tc[threadIdx.x] = ci < d.nChunks ? d.partC[ci] : 0.0;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                const int m = (int)(d.nChunks - c0 < 1024 ? d.nChunks - c0 : 1024);
-                for (int j = 0; j < m; ++j) c += tc[j];
-            }
-            __syncthreads();
-        }
-    }
+__global__ __launch_bounds__(256) void cg_scalar_aux_kernel(CgDev d, int which) {
+    __shared__ double sh[514];
+    double a, b, c = 0.0, unused;
+    sumChunksAll<true>(d.nChunks, d.partA, d.partB, sh, a, b);
+    if (which == 1) sumChunksAll<false>(d.nChunks, d.partC, nullptr, sh, c, unused);
     if (threadIdx.x != 0) return;
     CgScalars& s = *d.s;
     if (which == 0) {
@@ -196,6 +264,7 @@ __global__ __launch_bounds__(1024) void cg_scalar_aux_kernel(CgDev d, int which)
         s.rhsNorm2 = a;
         s.resNorm2 = b;
         s.absNew = c;
+        s.absRing[0] = c;
         if (a == 0.0) {  // Eigen: a zero right-hand side has the zero solution
             s.resNorm2 = 0.0;
             s.done = 3;
@@ -207,23 +276,19 @@ __global__ __launch_bounds__(1024) void cg_scalar_aux_kernel(CgDev d, int which)
     }
 }
 
-__global__ __launch_bounds__(1024) void cg_alpha_kernel(CgDev d) {
+// step 2 of iteration k: alpha from the chunk sums of p . tmp, then x, r, z and the chunk sums of r . r and r . z
+__global__ __launch_bounds__(256) void cg_step2_kernel(CgDev d, int k) {
+    __shared__ double sh[514];
     if (d.s->done) return;
     double pAp, unused;
-    sumChunks<false>(d, pAp, unused);
-    if (threadIdx.x == 0) d.s->alpha = d.s->absNew / pAp;
-}
-
-// region 2: x, r, z and the chunk sums of r . r and r . z
-__global__ __launch_bounds__(256) void cg_update_kernel(CgDev d) {
-    __shared__ double sh[256];
-    if (d.s->done) return;
+    sumChunksAll<false>(d.nChunks, d.partA, nullptr, sh, pAp, unused);
+    const double alpha = d.s->absRing[k & 1] / pAp;
+    const double* p = (k & 1) ? d.rhs : d.p;
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const bool live = i < d.n;
     double rr = 0.0, rz = 0.0;
     if (live) {
-        const double alpha = d.s->alpha;
-        d.x[i] += alpha * d.p[i];
+        d.x[i] += alpha * p[i];
         const double r = d.r[i] - alpha * d.tmp[i];
         d.r[i] = r;
         const double z = d.dinv[i] * r;
@@ -233,42 +298,10 @@ __global__ __launch_bounds__(256) void cg_update_kernel(CgDev d) {
     }
     const double a = blockChunkSum(rr, sh);
     const double b = blockChunkSum(rz, sh);
-    if (threadIdx.x == 0) d.partA[blockIdx.x] = a, d.partB[blockIdx.x] = b;
-}
-
-__global__ __launch_bounds__(1024) void cg_beta_kernel(CgDev d) {
-    if (d.s->done) return;
-    double rr, rz;
-    sumChunks<true>(d, rr, rz);
     if (threadIdx.x == 0) {
-        CgScalars& s = *d.s;
-        s.resNorm2 = rr;
-        if (rr < s.threshold) {
-            s.done = 1;
-        } else {
-            const double absOld = s.absNew;
-            s.absNew = rz;
-            s.beta = rz / absOld;
-            s.it += 1;
-            if (s.it >= s.maxIter) s.done = 2;  // the p update of the last iteration feeds nothing
-        }
+        d.partB[blockIdx.x] = a, d.partC[blockIdx.x] = b;
+        if (blockIdx.x == 0) d.s->alpha = alpha;
     }
-}
-
-// region 3
-__global__ __launch_bounds__(256) void cg_direction_kernel(CgDev d) {
-    if (d.s->done) return;
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= d.n) return;
-    d.p[i] = d.z[i] + d.s->beta * d.p[i];
-}
-
-hipError_t launchCgLayout(hipStream_t stream, uint64_t n, const uint64_t* dRowPtr, const uint32_t* dCsrCol, const double* dCsrVal,
-                          const CgDev& d) {
-    if (d.n == 0) return hipSuccess;
-    hipLaunchKernelGGL(cg_ell_kernel, dim3((unsigned)d.nChunks), dim3(256), 0, stream, n, dRowPtr, dCsrCol, dCsrVal, d.sliceOff,
-                       const_cast<uint32_t*>(d.rowLen), const_cast<uint32_t*>(d.col), const_cast<double*>(d.val));
-    return hipGetLastError();
 }
 
 // everything before the loop: setup, jump energy of c, first residual, threshold
@@ -277,10 +310,10 @@ hipError_t launchCgStart(hipStream_t stream, const CgDev& d) {
     const dim3 wide((unsigned)d.nChunks), one(1);
     hipLaunchKernelGGL(cg_setup_kernel, wide, dim3(256), 0, stream, d);
     hipLaunchKernelGGL(cg_spmv_aux_kernel, wide, dim3(1024), 0, stream, d, 0);
-    hipLaunchKernelGGL(cg_scalar_aux_kernel, one, dim3(1024), 0, stream, d, 0);
+    hipLaunchKernelGGL(cg_scalar_aux_kernel, one, dim3(256), 0, stream, d, 0);
     hipLaunchKernelGGL(cg_spmv_aux_kernel, wide, dim3(1024), 0, stream, d, 1);
     hipLaunchKernelGGL(cg_residual_kernel, wide, dim3(256), 0, stream, d);
-    hipLaunchKernelGGL(cg_scalar_aux_kernel, one, dim3(1024), 0, stream, d, 1);
+    hipLaunchKernelGGL(cg_scalar_aux_kernel, one, dim3(256), 0, stream, d, 1);
     return hipGetLastError();
 }
 
@@ -288,21 +321,19 @@ hipError_t launchCgStart(hipStream_t stream, const CgDev& d) {
 hipError_t launchCgFinish(hipStream_t stream, const CgDev& d) {
     if (d.n == 0) return hipSuccess;
     hipLaunchKernelGGL(cg_spmv_aux_kernel, dim3((unsigned)d.nChunks), dim3(1024), 0, stream, d, 2);
-    hipLaunchKernelGGL(cg_scalar_aux_kernel, dim3(1), dim3(1024), 0, stream, d, 2);
+    hipLaunchKernelGGL(cg_scalar_aux_kernel, dim3(1), dim3(256), 0, stream, d, 2);
     return hipGetLastError();
 }
 
-hipError_t launchCgIterations(hipStream_t stream, const CgDev& d, int iterations) {
+hipError_t launchCgIterations(hipStream_t stream, const CgDev& d, int firstIteration, int iterations) {
     if (d.n == 0 || iterations <= 0) return hipSuccess;
     if (d.nChunks != (d.n + kCgChunk - 1) / kCgChunk) return hipErrorInvalidValue;
     const dim3 wide((unsigned)d.nChunks), one(1);
-    for (int k = 0; k < iterations; ++k) {
-        hipLaunchKernelGGL(cg_spmv_kernel, wide, dim3(1024), 0, stream, d);
-        hipLaunchKernelGGL(cg_alpha_kernel, one, dim3(1024), 0, stream, d);
-        hipLaunchKernelGGL(cg_update_kernel, wide, dim3(256), 0, stream, d);
-        hipLaunchKernelGGL(cg_beta_kernel, one, dim3(1024), 0, stream, d);
-        hipLaunchKernelGGL(cg_direction_kernel, wide, dim3(256), 0, stream, d);
+    for (int k = firstIteration; k < firstIteration + iterations; ++k) {
+        hipLaunchKernelGGL(cg_step1_kernel, wide, dim3(1024), 0, stream, d, k);
+        hipLaunchKernelGGL(cg_step2_kernel, wide, dim3(256), 0, stream, d, k);
     }
+    hipLaunchKernelGGL(cg_check_kernel, one, dim3(64), 0, stream, d, firstIteration + iterations);
     return hipGetLastError();
 }
 

@@ -555,9 +555,7 @@ struct Vec {
             for (uint64_t i = 0; i < cnt; ++i) prod[i] = a[lo + i] * b[lo + i];
             partial[c] = cgChunkSum(prod, cnt);
         });
-        double s = 0.0;
-        for (uint64_t c = 0; c < nChunks; ++c) s += partial[c];
-        return s;
+        return cgCombine(partial.data(), nChunks);
     }
     // y = (M + shift I) x
     void spmv(const Csr& M, double shift, const double* x, double* y) {
@@ -619,7 +617,6 @@ int continuityMatrix(const void* block, size_t size, uint64_t threads, uint64_t*
 struct Keep {
     Csr M;
     std::vector<double> v[8];
-    std::vector<uint64_t> sliceOff;
     std::vector<uint32_t> col32;
     std::vector<Fragment> frags;
     std::unique_ptr<Pool> asmPool;  // the assembly's workers sleep between calls instead of being spawned and joined
@@ -649,24 +646,13 @@ static int solveOnDevice(hpsdf_ctx* ctx, Keep& keep, const double* coeffs, doubl
     const bool trace = std::getenv("HPSDF_TRACE") != nullptr;
     const double tt0 = nowMs();
     auto al = [](uint64_t b) { return (b + 255) & ~255ull; };
-    // sliced ELL: every chunk of 256 rows is four slices of 64 (rows past n are empty); the host only sizes the
-    // slices, cg_ell_kernel moves the entries
-    const uint64_t nSlices = 4 * nChunks, nnz = M.rowPtr[n];
-    std::vector<uint64_t>& sliceOff = keep.sliceOff;
-    sliceOff.assign(nSlices + 1, 0);
-    for (uint64_t sl = 0; sl < nSlices; ++sl) {
-        uint64_t w = 0;
-        for (uint64_t r0 = sl * 64; r0 < std::min(n, sl * 64 + 64); ++r0) w = std::max(w, M.rowPtr[r0 + 1] - M.rowPtr[r0]);
-        sliceOff[sl + 1] = sliceOff[sl] + 64 * w;
-    }
-    const uint64_t ell = sliceOff[nSlices];
+    const uint64_t nnz = M.rowPtr[n];
     std::vector<uint32_t>& col32 = keep.col32;
     col32.resize(nnz ? nnz : 1);
     for (uint64_t q = 0; q < nnz; ++q) col32[q] = (uint32_t)M.col[q];
     const double tt1 = nowMs();
     const uint64_t vecB = al(n * 8), partB = al(nChunks * 8);
-    const uint64_t total = al((nSlices + 1) * 8) + al(n * 4) + al(ell * 4 + 4) + al(ell * 8 + 8) + 9 * vecB + 3 * partB + 256 +
-                           al((n + 1) * 8) + al(nnz * 4 + 4) + al(nnz * 8 + 8);
+    const uint64_t total = 9 * vecB + 3 * partB + 256 + al((n + 1) * 8) + al(nnz * 4 + 4) + al(nnz * 8 + 8);
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess && (keep.dCap < total || keep.device != ctx->device)) {
         if (keep.dBase) {
@@ -691,12 +677,8 @@ static int solveOnDevice(hpsdf_ctx* ctx, Keep& keep, const double* coeffs, doubl
     };
     CgDev d;
     d.n = n, d.nChunks = nChunks;
-    uint64_t* dSlice = (uint64_t*)take((nSlices + 1) * 8);
-    uint32_t* dLen = (uint32_t*)take(n * 4);
-    uint32_t* dCol = (uint32_t*)take(ell * 4 + 4);
-    double* dVal = (double*)take(ell * 8 + 8);
     double* dC = (double*)take(n * 8);
-    d.sliceOff = dSlice, d.rowLen = dLen, d.col = dCol, d.val = dVal, d.c = dC;
+    d.c = dC;
     d.dinv = (double*)take(n * 8), d.rhs = (double*)take(n * 8);
     d.x = (double*)take(n * 8), d.r = (double*)take(n * 8), d.p = (double*)take(n * 8), d.z = (double*)take(n * 8);
     d.tmp = (double*)take(n * 8);
@@ -705,6 +687,7 @@ static int solveOnDevice(hpsdf_ctx* ctx, Keep& keep, const double* coeffs, doubl
     uint64_t* dRowPtr = (uint64_t*)take((n + 1) * 8);
     uint32_t* dCsrCol = (uint32_t*)take(nnz * 4 + 4);
     double* dCsrVal = (double*)take(nnz * 8 + 8);
+    d.rowPtr = dRowPtr, d.col = dCsrCol, d.val = dCsrVal;
     CgScalars s;
     std::memset(&s, 0, sizeof s);
     s.lambda = lambda, s.tol = tol, s.maxIter = maxIter;
@@ -712,15 +695,14 @@ static int solveOnDevice(hpsdf_ctx* ctx, Keep& keep, const double* coeffs, doubl
     auto up = [&](void* dst, const void* src, uint64_t bytes) {
         if (e == hipSuccess && bytes) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stm);
     };
-    up(dSlice, sliceOff.data(), (nSlices + 1) * 8), up(dRowPtr, M.rowPtr.data(), (n + 1) * 8);
+    up(dRowPtr, M.rowPtr.data(), (n + 1) * 8);
     up(dCsrCol, col32.data(), nnz * 4), up(dCsrVal, M.val.data(), nnz * 8);
     up(dC, coeffs, n * 8), up(d.s, &s, sizeof s);
-    if (e == hipSuccess) e = launchCgLayout(stm, n, dRowPtr, dCsrCol, dCsrVal, d);
     if (e == hipSuccess) e = launchCgStart(stm, d);
     if (e == hipSuccess && trace) e = hipStreamSynchronize(stm);
     const double tt2 = nowMs();
-    while (e == hipSuccess) {
-        e = launchCgIterations(stm, d, 16);
+    for (int k0 = 0; e == hipSuccess; k0 += 16) {
+        e = launchCgIterations(stm, d, k0, 16);
         if (e == hipSuccess) e = hipMemcpyAsync(&s, d.s, sizeof s, hipMemcpyDeviceToHost, stm);
         if (e == hipSuccess) e = hipStreamSynchronize(stm);
         if (e != hipSuccess || s.done) break;
@@ -731,8 +713,8 @@ static int solveOnDevice(hpsdf_ctx* ctx, Keep& keep, const double* coeffs, doubl
     if (e == hipSuccess) e = hipMemcpyAsync(xOut, d.x, n * 8, hipMemcpyDeviceToHost, stm);
     if (e == hipSuccess) e = hipStreamSynchronize(stm);
     if (trace)
-        std::fprintf(stderr, "[continuity solve] n %llu, ELL entries %llu: layout %.2f ms, upload + start %.2f, %d iterations %.2f, finish + download %.2f\n",
-                     (unsigned long long)n, (unsigned long long)ell, tt1 - tt0, tt2 - tt1, (int)s.it, tt3 - tt2, nowMs() - tt3);
+        std::fprintf(stderr, "[continuity solve] n %llu, %llu non-zeros: 32-bit columns %.2f ms, upload + start %.2f, %d iterations %.2f, finish + download %.2f\n",
+                     (unsigned long long)n, (unsigned long long)nnz, tt1 - tt0, tt2 - tt1, (int)s.it, tt3 - tt2, nowMs() - tt3);
     if (e != hipSuccess) {
         err = std::string("continuity solve: ") + hipGetErrorString(e);
         return HPSDF_ERR_HIP;
@@ -775,7 +757,7 @@ int continuityPostProcess(void* block, size_t size, double tol, int maxIter, uin
     if (!keep.asmPool || keep.asmPool->size() != nThreads) keep.asmPool.reset(new Pool(nThreads));
     assemble(b, *keep.asmPool, M, st, keep.frags);
     const double t1 = nowMs();
-    if (ctx) {  // the solve, all of it, on the device
+    if (ctx && (b.nCoeffs + kCgChunk - 1) / kCgChunk <= kCgMaxChunksOnDevice) {  // the solve, all of it, on the device
         if (maxIter <= 0) maxIter = (int)std::min<uint64_t>(2 * b.nCoeffs, 0x7FFFFFFF);  // Eigen's default 2n
         std::vector<double>& xd = keep.v[0];
         xd.resize(b.nCoeffs);
@@ -845,8 +827,7 @@ int continuityPostProcess(void* block, size_t size, double tol, int maxIter, uin
                     }
                     V.partial[c] = cgChunkSum(prod, cnt);
                 });
-                double pAp = 0.0;
-                for (uint64_t c = 0; c < V.nChunks; ++c) pAp += V.partial[c];
+                const double pAp = cgCombine(V.partial.data(), V.nChunks);
                 const double alpha = absNew / pAp;
                 // region 2: x, r, z updates and the partial sums of r . r and r . z
                 pool.forEach(V.nChunks, [&](uint64_t c) {
@@ -862,9 +843,8 @@ int continuityPostProcess(void* block, size_t size, double tol, int maxIter, uin
                     V.partial[c] = cgChunkSum(rr, cnt);
                     part2[c] = cgChunkSum(rz, cnt);
                 });
-                resNorm2 = 0.0;
-                double rz = 0.0;
-                for (uint64_t c = 0; c < V.nChunks; ++c) resNorm2 += V.partial[c], rz += part2[c];
+                resNorm2 = cgCombine(V.partial.data(), V.nChunks);
+                const double rz = cgCombine(part2.data(), V.nChunks);
                 if (resNorm2 < threshold) break;
                 const double absOld = absNew;
                 absNew = rz;

@@ -1,5 +1,7 @@
 // Host-side launch wrappers of kernels.hip.
 #pragma once
+#include <algorithm>
+#include <vector>
 #include <hip/hip_runtime_api.h>
 
 #include <cstddef>
@@ -72,16 +74,32 @@ inline double cgChunkSum(const double* e, uint64_t count) {
         for (int l = 0; l < off; ++l) v[l] = v[l] + v[l + off];
     return v[0];
 }
+// The canonical total of n chunk sums: the same shape again, level by level -- groups of 256 consecutive values go through
+// cgChunkSum until one value is left (at least one level).  A wave does a level of <= 256 values in a dozen instructions;
+// added up left to right instead (rounds 1 and 2a) the 325 chunk sums of an 83 k-unknown system cost every kernel that
+// needed a scalar 5-6 us of one lane's dependent additions.
+inline double cgCombine(const double* part, uint64_t n) {
+    if (n == 0) return 0.0;
+    std::vector<double> a(part, part + n), b;
+    do {
+        b.resize((a.size() + 255) / 256);
+        for (uint64_t i = 0; i < b.size(); ++i) b[i] = cgChunkSum(a.data() + 256 * i, std::min<uint64_t>(256, a.size() - 256 * i));
+        a.swap(b);
+    } while (a.size() > 1);
+    return a[0];
+}
+constexpr uint64_t kCgMaxChunksOnDevice = 65536;  // two levels of cgCombine: 16.7 M unknowns
 struct CgScalars {
     double absNew, alpha, beta, resNorm2, threshold, lambda;
     double tol, rhsNorm2, jumpBefore, jumpAfter;
     int32_t it, maxIter, done, pad;  // done: 0 iterating, 1 converged, 2 iteration cap, 3 zero right-hand side
+    double absRing[2];               // r . z at the start of iteration k in absRing[k & 1] (read by workgroups of the kernel whose
+                                     // first workgroup writes the other slot)
 };
 struct CgDev {
     uint64_t n, nChunks;
-    // M as sliced ELL: slice s = rows 64 s .. 64 s + 63, entry k of row r at sliceOff[s] + 64 k + (r & 63)
-    const uint64_t* sliceOff;  // 4 nChunks + 1 (every chunk has four slices, rows past n are empty)
-    const uint32_t* rowLen;    // n
+    // M in CSR as the host assembles it: entries of row r at [rowPtr[r], rowPtr[r + 1]), columns ascending
+    const uint64_t* rowPtr;  // n + 1
     const uint32_t* col;
     const double* val;
     const double* c;  // the block's coefficients (right-hand side / lambda, initial guess / lambda)
@@ -89,11 +107,8 @@ struct CgDev {
     double *x, *r, *p, *z, *tmp, *partA, *partB, *partC;
     CgScalars* s;
 };
-// fills d.rowLen / d.col / d.val (sliced ELL, d.sliceOff already uploaded) from the CSR arrays in HBM
-hipError_t launchCgLayout(hipStream_t stream, uint64_t n, const uint64_t* dRowPtr, const uint32_t* dCsrCol, const double* dCsrVal,
-                          const CgDev& d);
 hipError_t launchCgStart(hipStream_t stream, const CgDev& d);   // setup, jump energy before, first residual, threshold
-hipError_t launchCgIterations(hipStream_t stream, const CgDev& d, int iterations);
+hipError_t launchCgIterations(hipStream_t stream, const CgDev& d, int firstIteration, int iterations);
 hipError_t launchCgFinish(hipStream_t stream, const CgDev& d);  // jump energy after
 hipError_t launchPack(hipStream_t stream, const PackItem* dItems, uint32_t nItems, const double* dArena, double* dOut);
 

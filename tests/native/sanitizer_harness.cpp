@@ -29,10 +29,9 @@ hipError_t launchPack(hipStream_t, const PackItem*, uint32_t, const double*, dou
 hipError_t launchFitWeight(hipStream_t, const FitBlock*, uint32_t, size_t, const FitTask*, const double*, double*, const DeviceTables*) { return hipErrorNoDevice; }
 hipError_t launchFitMfma(hipStream_t, int, const FitBlock*, uint32_t, const FitTask*, double*, double*, const DeviceTables*, const FieldDev&,
                          const RootMap&, const uint32_t*) { return hipErrorNoDevice; }
-hipError_t launchCgIterations(hipStream_t, const CgDev&, int) { return hipErrorNoDevice; }
+hipError_t launchCgIterations(hipStream_t, const CgDev&, int, int) { return hipErrorNoDevice; }
 hipError_t launchCgStart(hipStream_t, const CgDev&) { return hipErrorNoDevice; }
 hipError_t launchCgFinish(hipStream_t, const CgDev&) { return hipErrorNoDevice; }
-hipError_t launchCgLayout(hipStream_t, uint64_t, const uint64_t*, const uint32_t*, const double*, const CgDev&) { return hipErrorNoDevice; }
 hipError_t launchMeshTriPos(hipStream_t, const float*, const uint32_t*, uint64_t, float*, const uint32_t*, float*) { return hipErrorNoDevice; }
 hipError_t launchMeshSample(hipStream_t, const FitTask*, uint32_t, int, const DeviceTables*, const FieldDev&, const RootMap&, double*) {
     return hipErrorNoDevice;
