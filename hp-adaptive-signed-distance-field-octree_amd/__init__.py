@@ -160,6 +160,9 @@ _SIGNATURES = {
     "hpsdf_continuity_matrix": (C.c_int, [C.c_void_p, C.c_size_t, C.c_uint64, C.POINTER(C.POINTER(C.c_uint64)),
                                           C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(C.c_double)),
                                           C.POINTER(ContinuityStats)]),
+    "hpsdf_continuity_matrix_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.POINTER(C.c_uint64)),
+                                          C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(C.c_double)),
+                                          C.POINTER(ContinuityStats)]),
     "hpsdf_continuity_last_stats": (C.c_int, [C.POINTER(ContinuityStats)]),
     "hpsdf_create": (C.c_int, [C.c_void_p, C.POINTER(PodConfig), C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p),
                                C.POINTER(C.c_size_t), C.POINTER(BuildStats)]),
@@ -645,6 +648,22 @@ def continuity_matrix(block, threads=0):
     rp, ci, v = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)(), C.POINTER(C.c_double)()
     st = ContinuityStats()
     check(lib().hpsdf_continuity_matrix(b, len(b), threads, C.byref(rp), C.byref(ci), C.byref(v), C.byref(st)))
+    n = int(np.frombuffer(b[:8], np.uint64)[0])
+    row_ptr = np.ctypeslib.as_array(rp, shape=(n + 1,)).copy()
+    nnz = int(row_ptr[-1])
+    col = np.ctypeslib.as_array(ci, shape=(max(nnz, 1),))[:nnz].copy()
+    val = np.ctypeslib.as_array(v, shape=(max(nnz, 1),))[:nnz].copy()
+    for p in (rp, ci, v):
+        lib()._libc.free(C.cast(p, C.c_void_p))
+    return row_ptr, col, val, st.as_dict()
+
+
+def continuity_matrix_device(ctx, block):
+    """The same matrix assembled on the device (what Create uses) and copied back: (row_ptr, col, val, stats)."""
+    b = bytes(block)
+    rp, ci, v = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)(), C.POINTER(C.c_double)()
+    st = ContinuityStats()
+    check(lib().hpsdf_continuity_matrix_device(ctx.handle, b, len(b), C.byref(rp), C.byref(ci), C.byref(v), C.byref(st)))
     n = int(np.frombuffer(b[:8], np.uint64)[0])
     row_ptr = np.ctypeslib.as_array(rp, shape=(n + 1,)).copy()
     nnz = int(row_ptr[-1])

@@ -14,7 +14,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libhpsdf.so")
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
 
-SOURCES = ["kernels.hip", "frontier.hip", "fit_mfma.hip", "mesh_build.hip", "cg.hip", "tables.cpp", "builder.cpp", "mesh.cpp", "obj.cpp", "continuity.cpp", "capi.cpp"]
+SOURCES = ["kernels.hip", "frontier.hip", "fit_mfma.hip", "mesh_build.hip", "cg.hip", "continuity_asm.hip", "tables.cpp", "builder.cpp", "mesh.cpp", "obj.cpp", "continuity.cpp", "capi.cpp"]
 HEADERS = ["tables.hpp", "device_types.hpp", "launch.hpp", "runtime.hpp", "builder.hpp", "continuity.hpp", "block_check.hpp", "frontier.hpp", "field_eval.hpp"]
 PUBLIC_HEADERS = ["hpsdf.h", "hpsdf_octree.hpp"]
 

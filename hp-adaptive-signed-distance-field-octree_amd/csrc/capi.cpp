@@ -1211,6 +1211,18 @@ int hpsdf_continuity_matrix(const void* block, size_t size, uint64_t threads, ui
     HPSDF_CATCH
 }
 
+int hpsdf_continuity_matrix_device(hpsdf_ctx* ctx, const void* block, size_t size, uint64_t** rowPtr, uint64_t** col, double** val,
+                                   hpsdf_continuity_stats* stats) {
+    HPSDF_TRY
+    if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "a device context is required");
+    if (!block || !rowPtr || !col || !val) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    std::string err;
+    const int rc = continuityMatrixDevice(ctx, block, size, rowPtr, col, val, stats, err);
+    if (rc) return fail(rc, err);
+    return HPSDF_OK;
+    HPSDF_CATCH
+}
+
 int hpsdf_continuity_last_stats(hpsdf_continuity_stats* out) {
     if (!out) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null out");
     *out = g_lastContinuity;

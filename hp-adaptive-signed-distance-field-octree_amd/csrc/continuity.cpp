@@ -611,6 +611,46 @@ int continuityMatrix(const void* block, size_t size, uint64_t threads, uint64_t*
     return HPSDF_OK;
 }
 
+int continuityMatrixDevice(hpsdf_ctx* ctx, const void* block, size_t size, uint64_t** rowPtr, uint64_t** col, double** val,
+                           hpsdf_continuity_stats* stats, std::string& err) {
+    ParsedBlock b;
+    int rc = parseBlock(const_cast<void*>(block), size, b, err);
+    if (rc) return rc;
+    hpsdf_continuity_stats st;
+    std::memset(&st, 0, sizeof st);
+    ContinuityDeviceMatrix dm;
+    int fallback = 0;
+    rc = continuityAssembleDevice(ctx, b.nodes.data(), b.nNodes, b.nCoeffs, dm, st, &fallback, err);
+    if (rc) return rc;
+    if (fallback) {
+        err = "this tree is left to the host assembler";
+        return HPSDF_ERR_UNSUPPORTED;
+    }
+    std::vector<uint32_t> c32(dm.nnz ? dm.nnz : 1);
+    *rowPtr = (uint64_t*)std::malloc(sizeof(uint64_t) * (dm.n + 1));
+    *col = (uint64_t*)std::malloc(sizeof(uint64_t) * (dm.nnz ? dm.nnz : 1));
+    *val = (double*)std::malloc(sizeof(double) * (dm.nnz ? dm.nnz : 1));
+    if (!*rowPtr || !*col || !*val) {
+        std::free(*rowPtr), std::free(*col), std::free(*val);
+        *rowPtr = *col = nullptr, *val = nullptr;
+        err = "malloc failed";
+        return HPSDF_ERR_OUT_OF_MEMORY;
+    }
+    hipError_t e = hipStreamSynchronize(ctx->stream);  // the assembly's last kernel runs on the context's stream
+    if (e == hipSuccess) e = hipMemcpy(*rowPtr, dm.dRowPtr, sizeof(uint64_t) * (dm.n + 1), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && dm.nnz) e = hipMemcpy(c32.data(), dm.dCol, sizeof(uint32_t) * dm.nnz, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && dm.nnz) e = hipMemcpy(*val, dm.dVal, sizeof(double) * dm.nnz, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+        std::free(*rowPtr), std::free(*col), std::free(*val);
+        *rowPtr = *col = nullptr, *val = nullptr;
+        err = std::string("continuity matrix download: ") + hipGetErrorString(e);
+        return HPSDF_ERR_HIP;
+    }
+    for (uint64_t q = 0; q < dm.nnz; ++q) (*col)[q] = c32[q];
+    if (stats) *stats = st;
+    return HPSDF_OK;
+}
+
 // Octree::PerformContinuityPostProcess, :1717-1762, in place on the serialised block
 // What a context keeps between post-processes: the assembled matrix, the host solver's vectors and the device buffer
 // of the device solve.
@@ -620,6 +660,7 @@ struct Keep {
     std::vector<uint32_t> col32;
     std::vector<Fragment> frags;
     std::unique_ptr<Pool> asmPool;  // the assembly's workers sleep between calls instead of being spawned and joined
+    ContinuityDeviceMatrix dm;  // the matrix when it was assembled on the device (continuity_asm.hip)
     char* dBase = nullptr;
     uint64_t dCap = 0;
     int device = -1;
@@ -635,10 +676,10 @@ struct Keep {
 // (right-hand side, initial guess, Jacobi diagonal, first residual, threshold -- the statements of the host path below,
 // same arithmetic), runs batches of iterations until the stop flag is up, brings x and the statistics back.
 // Returns 0 or an HPSDF_ERR code (err filled).
-static int solveOnDevice(hpsdf_ctx* ctx, Keep& keep, const double* coeffs, double lambda, double tol, int maxIter, double* xOut,
-                         hpsdf_continuity_stats& st, std::string& err) {
-    const Csr& M = keep.M;
-    const uint64_t n = M.n, nChunks = (n + kCgChunk - 1) / kCgChunk;
+static int solveOnDevice(hpsdf_ctx* ctx, Keep& keep, const ContinuityDeviceMatrix* dm, const double* coeffs, double lambda, double tol,
+                         int maxIter, double* xOut, hpsdf_continuity_stats& st, std::string& err) {
+    const Csr& M = keep.M;  // (used when the host assembled: dm == nullptr)
+    const uint64_t n = dm ? dm->n : M.n, nChunks = (n + kCgChunk - 1) / kCgChunk;
     if (n >= 0xFFFFFFFFull) {
         err = "continuity system too large for 32-bit column indices";
         return HPSDF_ERR_UNSUPPORTED;
@@ -646,13 +687,15 @@ static int solveOnDevice(hpsdf_ctx* ctx, Keep& keep, const double* coeffs, doubl
     const bool trace = std::getenv("HPSDF_TRACE") != nullptr;
     const double tt0 = nowMs();
     auto al = [](uint64_t b) { return (b + 255) & ~255ull; };
-    const uint64_t nnz = M.rowPtr[n];
+    const uint64_t nnz = dm ? dm->nnz : M.rowPtr[n];
     std::vector<uint32_t>& col32 = keep.col32;
-    col32.resize(nnz ? nnz : 1);
-    for (uint64_t q = 0; q < nnz; ++q) col32[q] = (uint32_t)M.col[q];
+    if (!dm) {
+        col32.resize(nnz ? nnz : 1);
+        for (uint64_t q = 0; q < nnz; ++q) col32[q] = (uint32_t)M.col[q];
+    }
     const double tt1 = nowMs();
     const uint64_t vecB = al(n * 8), partB = al(nChunks * 8);
-    const uint64_t total = 9 * vecB + 3 * partB + 256 + al((n + 1) * 8) + al(nnz * 4 + 4) + al(nnz * 8 + 8);
+    const uint64_t total = 9 * vecB + 3 * partB + 256 + (dm ? 0 : al((n + 1) * 8) + al(nnz * 4 + 4) + al(nnz * 8 + 8));
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess && (keep.dCap < total || keep.device != ctx->device)) {
         if (keep.dBase) {
@@ -684,10 +727,17 @@ static int solveOnDevice(hpsdf_ctx* ctx, Keep& keep, const double* coeffs, doubl
     d.tmp = (double*)take(n * 8);
     d.partA = (double*)take(nChunks * 8), d.partB = (double*)take(nChunks * 8), d.partC = (double*)take(nChunks * 8);
     d.s = (CgScalars*)take(sizeof(CgScalars));
-    uint64_t* dRowPtr = (uint64_t*)take((n + 1) * 8);
-    uint32_t* dCsrCol = (uint32_t*)take(nnz * 4 + 4);
-    double* dCsrVal = (double*)take(nnz * 8 + 8);
-    d.rowPtr = dRowPtr, d.col = dCsrCol, d.val = dCsrVal;
+    uint64_t* dRowPtr = nullptr;
+    uint32_t* dCsrCol = nullptr;
+    double* dCsrVal = nullptr;
+    if (dm) {
+        d.rowPtr = dm->dRowPtr, d.col = dm->dCol, d.val = dm->dVal;
+    } else {
+        dRowPtr = (uint64_t*)take((n + 1) * 8);
+        dCsrCol = (uint32_t*)take(nnz * 4 + 4);
+        dCsrVal = (double*)take(nnz * 8 + 8);
+        d.rowPtr = dRowPtr, d.col = dCsrCol, d.val = dCsrVal;
+    }
     CgScalars s;
     std::memset(&s, 0, sizeof s);
     s.lambda = lambda, s.tol = tol, s.maxIter = maxIter;
@@ -695,8 +745,10 @@ static int solveOnDevice(hpsdf_ctx* ctx, Keep& keep, const double* coeffs, doubl
     auto up = [&](void* dst, const void* src, uint64_t bytes) {
         if (e == hipSuccess && bytes) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stm);
     };
-    up(dRowPtr, M.rowPtr.data(), (n + 1) * 8);
-    up(dCsrCol, col32.data(), nnz * 4), up(dCsrVal, M.val.data(), nnz * 8);
+    if (!dm) {
+        up(dRowPtr, M.rowPtr.data(), (n + 1) * 8);
+        up(dCsrCol, col32.data(), nnz * 4), up(dCsrVal, M.val.data(), nnz * 8);
+    }
     up(dC, coeffs, n * 8), up(d.s, &s, sizeof s);
     if (e == hipSuccess) e = launchCgStart(stm, d);
     if (e == hipSuccess && trace) e = hipStreamSynchronize(stm);
@@ -754,21 +806,37 @@ int continuityPostProcess(void* block, size_t size, double tol, int maxIter, uin
     }
     Keep& keep = *own;
     Csr& M = keep.M;
-    if (!keep.asmPool || keep.asmPool->size() != nThreads) keep.asmPool.reset(new Pool(nThreads));
-    assemble(b, *keep.asmPool, M, st, keep.frags);
+    const bool deviceSolve = ctx && (b.nCoeffs + kCgChunk - 1) / kCgChunk <= kCgMaxChunksOnDevice;
+    // The matrix is assembled where it is used: on the device when the solve runs there (continuity_asm.hip: the same
+    // entries bit for bit, and no 20 MB upload); HPSDF_CONTINUITY_HOST_ASSEMBLY=1, and trees the device assembly
+    // declines, take the host assembler.
+    bool onDevice = false;
+    if (deviceSolve) {
+        const char* ha = std::getenv("HPSDF_CONTINUITY_HOST_ASSEMBLY");
+        if (!(ha && ha[0] == '1')) {
+            int fallback = 0;
+            rc = continuityAssembleDevice(ctx, b.nodes.data(), b.nNodes, b.nCoeffs, keep.dm, st, &fallback, err);
+            if (rc) return rc;
+            onDevice = !fallback;
+        }
+    }
+    if (!onDevice) {
+        if (!keep.asmPool || keep.asmPool->size() != nThreads) keep.asmPool.reset(new Pool(nThreads));
+        assemble(b, *keep.asmPool, M, st, keep.frags);
+    }
     const double t1 = nowMs();
-    if (ctx && (b.nCoeffs + kCgChunk - 1) / kCgChunk <= kCgMaxChunksOnDevice) {  // the solve, all of it, on the device
+    if (deviceSolve) {  // the solve, all of it, on the device
         if (maxIter <= 0) maxIter = (int)std::min<uint64_t>(2 * b.nCoeffs, 0x7FFFFFFF);  // Eigen's default 2n
         std::vector<double>& xd = keep.v[0];
         xd.resize(b.nCoeffs);
-        rc = solveOnDevice(ctx, keep, b.coeffs, b.cfg.continuity_strength, tol, maxIter, xd.data(), st, err);
+        rc = solveOnDevice(ctx, keep, onDevice ? &keep.dm : nullptr, b.coeffs, b.cfg.continuity_strength, tol, maxIter, xd.data(), st, err);
         if (rc) return rc;
         std::memcpy(b.coeffs, xd.data(), sizeof(double) * b.nCoeffs);  // :1756
         st.assemble_ms = t1 - t0;
         st.solve_ms = nowMs() - t1;
         if (std::getenv("HPSDF_TRACE"))
-            std::fprintf(stderr, "[continuity] parse %.2f ms, assemble %.2f ms, solve %.2f ms (device)\n", t0 - tEntry, st.assemble_ms,
-                         st.solve_ms);
+            std::fprintf(stderr, "[continuity] parse %.2f ms, assemble %.2f ms (%s), solve %.2f ms (device)\n", t0 - tEntry, st.assemble_ms,
+                         onDevice ? "device" : "host", st.solve_ms);
         if (stats) *stats = st;
         return HPSDF_OK;
     }

@@ -304,15 +304,20 @@ typedef struct hpsdf_continuity_stats {
  * threads 0: the block's config.thread_count (capped to the machine). */
 HPSDF_API int hpsdf_continuity_post_process(void* block, size_t size, double tol, int max_iter, uint64_t threads,
                                             hpsdf_continuity_stats* stats);
-/* The same with the conjugate-gradient loop on ctx's device (what hpsdf_create runs): the assembly stays on the
- * host, the system and the solver state go to HBM, every sum is taken in the host solve's order -- the block comes
- * back bit-identical to hpsdf_continuity_post_process's. */
+/* The same on ctx's device (what hpsdf_create runs): assembly and conjugate-gradient loop in HBM, every entry and every
+ * sum formed in the host path's order -- the block comes back bit-identical to hpsdf_continuity_post_process's.
+ * (HPSDF_CONTINUITY_HOST_ASSEMBLY=1 in the environment keeps the assembly on the host.) */
 HPSDF_API int hpsdf_continuity_post_process_device(hpsdf_ctx* ctx, void* block, size_t size, double tol, int max_iter,
                                                    uint64_t threads, hpsdf_continuity_stats* stats);
 /* M itself (without the regularisation), CSR with duplicates summed; the three arrays are malloc'd, the
  * caller frees them.  Test / diagnostic hook. */
 HPSDF_API int hpsdf_continuity_matrix(const void* block, size_t size, uint64_t threads, uint64_t** row_ptr,
                                       uint64_t** col, double** val, hpsdf_continuity_stats* stats);
+/* The same matrix assembled on ctx's device (what hpsdf_create and hpsdf_continuity_post_process_device use) and copied
+ * back: identical to hpsdf_continuity_matrix's arrays bit for bit.  HPSDF_ERR_UNSUPPORTED for trees the device assembly
+ * leaves to the host (a leaf with more than 1024 face neighbours, own blocks beyond 2 GB). */
+HPSDF_API int hpsdf_continuity_matrix_device(hpsdf_ctx* ctx, const void* block, size_t size, uint64_t** row_ptr, uint64_t** col,
+                                             double** val, hpsdf_continuity_stats* stats);
 /* stats of the last post-process hpsdf_create ran on this thread (zeros if it ran none) */
 HPSDF_API int hpsdf_continuity_last_stats(hpsdf_continuity_stats* out);
 

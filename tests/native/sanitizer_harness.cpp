@@ -32,6 +32,12 @@ hipError_t launchFitMfma(hipStream_t, int, const FitBlock*, uint32_t, const FitT
 hipError_t launchCgIterations(hipStream_t, const CgDev&, int, int) { return hipErrorNoDevice; }
 hipError_t launchCgStart(hipStream_t, const CgDev&) { return hipErrorNoDevice; }
 hipError_t launchCgFinish(hipStream_t, const CgDev&) { return hipErrorNoDevice; }
+ContinuityDeviceMatrix::~ContinuityDeviceMatrix() {}
+int continuityAssembleDevice(hpsdf_ctx*, const hpsdf_node*, uint64_t, uint64_t, ContinuityDeviceMatrix&, hpsdf_continuity_stats&, int* fallback,
+                             std::string&) {
+    *fallback = 1;
+    return HPSDF_OK;
+}
 hipError_t launchMeshTriPos(hipStream_t, const float*, const uint32_t*, uint64_t, float*, const uint32_t*, float*) { return hipErrorNoDevice; }
 hipError_t launchMeshSample(hipStream_t, const FitTask*, uint32_t, int, const DeviceTables*, const FieldDev&, const RootMap&, double*) {
     return hipErrorNoDevice;

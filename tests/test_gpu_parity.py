@@ -616,6 +616,42 @@ def test_continuity_device_solve_equals_host_solve(H, ctx, tol, max_iter):
     assert sd["iterations"] > 0 and (max_iter == 0 or sd["iterations"] <= max_iter)
 
 
+@pytest.mark.parametrize("case", ["sphere@1e-8", "union3@1e-7 K=256", "offset sphere, custom root", "deep chain", "mixed degrees"])
+def test_continuity_matrix_assembled_on_device_equals_host(H, ctx, case):
+    """continuity_asm.hip against continuity.cpp: row pointer, columns and values of the jump-energy matrix bit for bit --
+    conforming faces (analytic integrals) and non-conforming ones (quadrature across depth differences of 1 and more),
+    own blocks that sum several faces, degrees 0..12."""
+    rng = np.random.default_rng(11)
+    if case == "sphere@1e-8":
+        blk, _ = H.create_block(ctx, H.make_config(1e-8), H.Field.sphere(), 1024)
+    elif case == "union3@1e-7 K=256":
+        blk, _ = H.create_block(ctx, H.make_config(1e-7), H.Field.union3(), 256)
+    elif case == "offset sphere, custom root":
+        blk, _ = H.create_block(ctx, H.make_config(3e-8, (-0.25, -0.3, -0.2), (0.6, 0.5, 0.7)), H.Field.sphere((0.25, 0.0, 0.0), 0.3), 1024)
+    elif case == "deep chain":
+        from helpers import deep_chain_block
+        blk = deep_chain_block(rng, max_depth=6)
+    else:
+        blk = synthetic_block(rng, [12, 0, 7, 3, 11, 2, 5, 9], depth=2)
+    rp, col, val, st = H.continuity_matrix(blk, 4)
+    drp, dcol, dval, dst = H.continuity_matrix_device(ctx, blk)
+    assert np.array_equal(rp, drp) and np.array_equal(col, dcol)
+    assert np.array_equal(bits(val), bits(dval))
+    for k in ("n_pairs", "n_pairs_analytic", "n_pairs_numeric", "nnz"):
+        assert st[k] == dst[k], k
+    if case in ("union3@1e-7 K=256", "deep chain"):
+        assert st["n_pairs_numeric"] > 0
+
+
+def test_continuity_device_assembly_equals_host_assembly_end_to_end(H, ctx, monkeypatch):
+    """hpsdf_create with continuity: matrix assembled on the device vs HPSDF_CONTINUITY_HOST_ASSEMBLY=1 -- same block."""
+    cfg = H.make_config(1e-7, continuity=True)
+    a, _ = H.create_block(ctx, cfg, H.Field.union3(), 1024)
+    monkeypatch.setenv("HPSDF_CONTINUITY_HOST_ASSEMBLY", "1")
+    b, _ = H.create_block(ctx, cfg, H.Field.union3(), 1024)
+    assert a == b
+
+
 def test_mesh_create_with_continuity_config5_shape(H, O, ctx):
     """BASELINE config 5 in miniature: mesh field, root = mesh box, targetError 1e-5, continuity.enforce -- GPU build,
     host post-process.  The result must equal the host post-process of the continuity-free build (bit for bit) and stay

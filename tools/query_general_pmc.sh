@@ -20,9 +20,9 @@ out = sys.argv[1]
 acc = {}
 for f in glob.glob(os.path.join(out, "**/*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "query_general_kernel" not in r["Kernel_Name"]:
+        if "query_general" not in r["Kernel_Name"] and "query_deep" not in r["Kernel_Name"] and "defer_scan" not in r["Kernel_Name"]:
             continue
-        acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        acc.setdefault(r["Kernel_Name"][:36] + " " + r["Counter_Name"], []).append(float(r["Counter_Value"]))
 for k in sorted(acc):
     v = acc[k]
     print("%-34s n=%d avg %.4g" % (k, len(v), sum(v) / len(v)))
