@@ -39,8 +39,8 @@ JOBS_PER_ROUND = 1024
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--points", type=int, default=N_POINTS, help="query points per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fit-bench", action="store_true", help="skip the steady-state fit micro-benchmark (fit_microbench)")
@@ -176,10 +176,14 @@ def main():
         if rank == 0 and not args.no_refined:
             import ctypes as C
             blk_r, st_r = H.create_block(ctx, H.make_config(1e-7), field, JOBS_PER_ROUND)
-            t0 = time.perf_counter()
-            blk_r, st_r = H.create_block(ctx, H.make_config(1e-7), field, JOBS_PER_ROUND)
-            torch.cuda.synchronize()
-            create_r_ms = (time.perf_counter() - t0) * 1e3
+            create_r_all = []
+            for _ in range(5):  # median of 5, like create_ms
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                blk_r, st_r = H.create_block(ctx, H.make_config(1e-7), field, JOBS_PER_ROUND)
+                torch.cuda.synchronize()
+                create_r_all.append((time.perf_counter() - t0) * 1e3)
+            create_r_ms = float(np.median(create_r_all))
             tree_r = H.DeviceTree(ctx, blk_r)
             d_grad = torch.empty(3 * n, dtype=torch.float64, device="cuda")
             d_out2 = torch.empty_like(d_out)
@@ -204,7 +208,7 @@ def main():
             refined = {"tree": "union3 @ 1e-7, K=%d: %d nodes, %d leaves, %d coeffs, max degree %d, max depth %d"
                                % (JOBS_PER_ROUND, st_r["n_nodes"], st_r["n_leaves"], st_r["n_coeffs"], tree_r.info()["max_degree"],
                                   tree_r.info()["max_depth"]),
-                       "create_ms": create_r_ms, "create_jobs": st_r["jobs"], "create_rounds": st_r["rounds"],
+                       "create_ms": create_r_ms, "create_ms_all": create_r_all, "create_jobs": st_r["jobs"], "create_rounds": st_r["rounds"],
                        "query_ms": q_ms, "query_mpts_per_s": n / q_ms / 1e3, "query_frac_hbm_peak": 32.0 * n / (q_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                        "query_with_gradient_ms": g_ms, "query_with_gradient_mpts_per_s": n / g_ms / 1e3,
                        "query_with_gradient_frac_hbm_peak": 56.0 * n / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
