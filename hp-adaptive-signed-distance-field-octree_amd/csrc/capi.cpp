@@ -1152,17 +1152,104 @@ int hpsdf_create(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* fie
     HPSDF_CATCH
 }
 
+// The sharded build for what the host scheduler owns (host callbacks, nearness weighting, logging, K > 4096): the round
+// loop of hp-adaptive-..._amd/distributed.py in C++, over the caller's all-gather.  The scheduler keeps its results in host
+// memory (the weight's pow / exp run there), so every exchange is staged through one device buffer: this rank's part up,
+// the in-place all-gather, everything down.  Per round: the 9 errors of every job; for weighted builds also the arrays the
+// round accepted (hpsdf_build_rows_*); at the end the packed coefficients.
+static int createShardedOnHostScheduler(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* field, uint64_t K, int rank, int world,
+                                        hpsdf_allgather_fn gather, void* user, void** block, size_t* size, hpsdf_build_stats* stats) {
+    hpsdf_build_opts o;
+    std::memset(&o, 0, sizeof o);
+    o.max_jobs_per_round = K;
+    o.rank = rank;
+    o.world = world;
+    hpsdf_build* b = nullptr;
+    int rc = hpsdf_build_begin(cfg, &o, &b);
+    if (rc) return rc;
+    std::unique_ptr<hpsdf_build> owner(b);
+    HPSDF_HIP(hipSetDevice(ctx->device));
+    struct Stage {
+        double* d = nullptr;
+        uint64_t cap = 0;
+        ~Stage() {
+            if (d) (void)hipFree(d);
+        }
+    } stage;
+    std::vector<double> all;
+    // every rank's `mine` (count doubles, padded to `pad`) -> all[world][pad]
+    auto exchange = [&](const double* mine, uint64_t count, uint64_t pad, const char* what) -> int {
+        const uint64_t total = (uint64_t)world * pad;
+        if (stage.cap < total) {
+            if (stage.d) (void)hipFree(stage.d);
+            stage.d = nullptr, stage.cap = 0;
+            HPSDF_HIP(hipMalloc((void**)&stage.d, (total + total / 2) * sizeof(double)));
+            stage.cap = total + total / 2;
+        }
+        if (count) HPSDF_HIP(hipMemcpyAsync(stage.d + (uint64_t)rank * pad, mine, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        const int grc = gather(user, stage.d, pad * sizeof(double), (void*)ctx->stream);
+        if (grc) return fail(HPSDF_ERR_STATE, std::string("the all-gather callback failed (") + what + "): " + std::to_string(grc));
+        all.resize(total);
+        HPSDF_HIP(hipMemcpyAsync(all.data(), stage.d, total * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HPSDF_HIP(hipStreamSynchronize(ctx->stream));
+        return HPSDF_OK;
+    };
+    std::vector<double> mine, headers;
+    std::vector<uint64_t> counts(world);
+    std::vector<const double*> parts(world);
+    for (;;) {
+        uint64_t n = 0;
+        if ((rc = builderSelect(b, &n))) return rc;
+        if (n == 0) break;
+        if ((rc = builderCompute(b, ctx, field))) return rc;
+        const uint64_t myCount = b->slices[rank].count * HPSDF_JOB_HEADER_DOUBLES;
+        uint64_t maxSlice = 0;
+        for (const auto& sl : b->slices) maxSlice = std::max(maxSlice, sl.count);
+        mine.resize(std::max<uint64_t>(1, myCount));
+        if ((rc = hpsdf_build_round_results_host(b, ctx, mine.data()))) return rc;
+        const uint64_t pad = maxSlice * HPSDF_JOB_HEADER_DOUBLES;
+        if ((rc = exchange(mine.data(), myCount, pad, "a round's errors"))) return rc;
+        headers.resize(n * HPSDF_JOB_HEADER_DOUBLES);
+        for (int r = 0; r < world; ++r)
+            if (b->slices[r].count)
+                std::memcpy(headers.data() + b->slices[r].first * HPSDF_JOB_HEADER_DOUBLES, all.data() + (uint64_t)r * pad,
+                            b->slices[r].count * HPSDF_JOB_HEADER_DOUBLES * sizeof(double));
+        if ((rc = builderApply(b, headers.data()))) return rc;
+        if (b->weighted) {  // the arrays this round accepted go to every rank (Octree.cpp:847 copies a node's previous rows)
+            if ((rc = builderRowsCounts(b, counts.data()))) return rc;
+            uint64_t rpad = 0;
+            for (uint64_t c : counts) rpad = std::max(rpad, c);
+            if (rpad) {
+                mine.resize(std::max<uint64_t>(1, counts[rank]));
+                if ((rc = builderRowsPackHost(b, ctx, mine.data()))) return rc;
+                if ((rc = exchange(mine.data(), counts[rank], rpad, "a round's accepted rows"))) return rc;
+                for (int r = 0; r < world; ++r) parts[r] = all.data() + (uint64_t)r * rpad;
+                if ((rc = builderRowsUnpackHost(b, ctx, parts.data()))) return rc;
+            }
+        }
+    }
+    if ((rc = builderLayout(b))) return rc;
+    uint64_t ppad = 1;
+    for (uint64_t c : b->packCounts) ppad = std::max(ppad, c);
+    mine.resize(std::max<uint64_t>(1, b->packCounts[rank]));
+    if ((rc = builderPackHost(b, ctx, mine.data()))) return rc;
+    if ((rc = exchange(mine.data(), b->packCounts[rank], ppad, "the packed coefficients"))) return rc;
+    for (int r = 0; r < world; ++r) parts[r] = all.data() + (uint64_t)r * ppad;
+    if ((rc = builderAssemble(b, parts.data(), block, size))) return rc;
+    if (stats) hpsdf_build_get_stats(b, stats);
+    return HPSDF_OK;
+}
+
 int hpsdf_create_distributed(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* field, uint64_t K, int rank, int world,
                              hpsdf_allgather_fn gather, void* user, void** block, size_t* size, hpsdf_build_stats* stats) {
     HPSDF_TRY
     if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "Create runs on the GPU: a device context is required");
     if (!cfg || !field || !block || !size) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
     if (world == 1) return hpsdf_create(ctx, cfg, field, K, block, size, stats);
-    if (!frontierEligible(cfg, field, K))
-        return fail(HPSDF_ERR_UNSUPPORTED,
-                    "this build runs the host scheduler (host callback, nearness weighting, logging or K > 4096): shard it through the "
-                    "hpsdf_build_* round calls");
-    int rc = frontierCreate(ctx, cfg, field, K, block, size, stats, rank, world, gather, user);
+    if (world < 1 || rank < 0 || rank >= world) return fail(HPSDF_ERR_INVALID_ARGUMENT, "rank outside [0, world)");
+    if (!gather) return fail(HPSDF_ERR_INVALID_ARGUMENT, "an all-gather callback is required for world > 1");
+    int rc = frontierEligible(cfg, field, K) ? frontierCreate(ctx, cfg, field, K, block, size, stats, rank, world, gather, user)
+                                             : createShardedOnHostScheduler(ctx, cfg, field, K, rank, world, gather, user, block, size, stats);
     std::memset(&g_lastContinuity, 0, sizeof g_lastContinuity);
     if (!rc && cfg->continuity_enforce) {  // Octree.cpp:341-344: every rank on its identical copy (deterministic: no exchange)
         std::string err;

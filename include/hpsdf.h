@@ -340,8 +340,11 @@ HPSDF_API int hpsdf_create(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_
  * rank's d_buf must hold all `world` parts.  It returns 0 on success.  With RCCL this is one call,
  *     ncclAllGather((char*)d_buf + rank * n, d_buf, n, ncclChar, comm, stream)      (include/hpsdf_rccl.hpp);
  * the library itself does not link RCCL.
- * Fields the device cannot evaluate (host callbacks) and nearness-weighted builds return HPSDF_ERR_UNSUPPORTED here:
- * they are sharded through the stepwise hpsdf_build_* calls (hp-adaptive-..._amd/distributed.py). */
+ * Fields the device evaluates itself, without nearness weighting, run the device-side frontier (slices cut, errors
+ * decided and the tree updated on every rank's GPU).  Host callbacks, nearness-weighted configs, logging and K > 4096 run
+ * the host scheduler's rounds, sharded the same way: the exchanges are staged through a device buffer for the same
+ * `gather`, and a weighted build also hands the arrays each round accepted to every rank (hpsdf_build_rows_*).
+ * The stepwise hpsdf_build_* calls expose the same loop to callers with a transport of their own. */
 typedef int (*hpsdf_allgather_fn)(void* user, void* d_buf, size_t bytes_per_rank, void* stream);
 HPSDF_API int hpsdf_create_distributed(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* field,
                                        uint64_t max_jobs_per_round, int rank, int world, hpsdf_allgather_fn gather,

@@ -360,12 +360,28 @@ def test_create_distributed_device_frontier_byte_identical(H, ctx, world):
             assert s["rounds"] == st["rounds"] and s["n_nodes"] == st["n_nodes"] and s["jobs"] == st["jobs"]
 
 
-def test_create_distributed_refuses_what_the_host_scheduler_owns(H, ctx):
-    cfg = H.make_config(1e-6)
-    cfg.nearnessWeighting_type, cfg.nearnessWeighting_strength = 1, 3.0
-    with pytest.raises(H.HpsdfError) as e:
-        H.create_block_distributed(ctx, cfg, H.Field.sphere(), 1024, 0, 2, lambda *a: None)
-    assert e.value.status == H.ERR_UNSUPPORTED
+@pytest.mark.parametrize("world", [2, 3])
+def test_create_distributed_shards_what_the_host_scheduler_owns(H, ctx, world):
+    """hpsdf_create_distributed on builds the device-side frontier does not take -- nearness weighting (the reference's
+    own test configuration, HPUnitTests.cpp:53-58) and fields given as host callbacks: the host scheduler's rounds,
+    sharded over the caller's all-gather (errors every round, the accepted rows of weighted builds, the packed
+    coefficients at the end).  Every rank ends with the single-rank block."""
+    import math
+    w = H.make_config(1e-8)
+    w.nearnessWeighting_type, w.nearnessWeighting_strength = 1, 3.0
+    one, st = H.create_block(ctx, w, H.Field.sphere(), 256)
+    for blk, s in _create_on_simulated_ranks(H, world, w, lambda c: H.Field.sphere(), 256):
+        assert blk == one and s["jobs"] == st["jobs"] and s["rounds"] == st["rounds"]
+    if world == 2:
+        def sphere(pt, thread_idx):
+            return math.sqrt((pt[0] - 0.1) ** 2 + pt[1] ** 2 + pt[2] ** 2) - 0.3
+        cfg = H.make_config(1e-3)
+        one, st = H.create_block(ctx, cfg, H.Field.callback(sphere), 1024)
+        for blk, s in _create_on_simulated_ranks(H, world, cfg, lambda c: H.Field.callback(sphere), 1024):
+            assert blk == one and s["jobs"] == st["jobs"]
+
+
+def test_create_distributed_argument_checks(H, ctx):
     with pytest.raises(H.HpsdfError) as e:
         H.create_block_distributed(ctx, H.make_config(1e-6), H.Field.sphere(), 1024, 2, 2, lambda *a: None)
     assert e.value.status == H.ERR_INVALID_ARGUMENT
