@@ -9,13 +9,16 @@ Create
     results in identical order, so the MemoryBlock is byte-identical for any world size
     (tests/test_distributed_gloo.py, tests/test_gpu_configs.py).
 
-    Fields the GPU evaluates itself (analytic, mesh, tree-CSG) without nearness weighting take the
-    device-side frontier (csrc/frontier.hip, hpsdf_create_distributed): selection, slicing, decision
-    and bookkeeping run on every rank's GPU and the two exchange points are all-gathers of device
-    buffers.  Host callbacks and weighted builds run the host scheduler through the stepwise C API
-    below (the per-round errors then pass through host memory).  A weighted build also hands the arrays
-    each round accepted to every rank (one more all-gather per round): a weighted incremental fit copies
-    the node's previous rows and may run on any rank.
+    On GPUs the whole loop sits behind the C ABI (hpsdf_create_distributed) and this module only supplies
+    the all-gather.  Fields the GPU evaluates itself (analytic, mesh, tree-CSG) without nearness
+    weighting take the device-side frontier (csrc/frontier.hip): selection, slicing, decision and
+    bookkeeping run on every rank's GPU and the two exchange points are all-gathers of device buffers.
+    Host callbacks and weighted builds run the host scheduler's rounds (the per-round errors then pass
+    through host memory, staged through a device buffer for the all-gather).  A weighted build also
+    hands the arrays each round accepted to every rank (one more all-gather per round): a weighted
+    incremental fit copies the node's previous rows and may run on any rank.  The Python round loop
+    below is the same algorithm over the stepwise C API: the CPU tests drive it (compute= hook), and
+    HPSDF_PYTHON_ROUND_LOOP=1 forces it on GPUs.
 
 Continuity (config.continuity.enforce)
     The host-side post-process runs on every rank on its identical copy of the assembled block; its
@@ -104,14 +107,11 @@ def create_distributed(ctx, config, field, K=0, group=None, compute=None, policy
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     on_gpu = compute is None
     pod = config.to_pod() if hasattr(config, "to_pod") else config
-    if on_gpu and world > 1 and getattr(field, "kind", None) in ("analytic", "mesh", "tree_csg") and pod.weighting_type == 0 \
-            and not pod.enable_logging and (K or 1024) <= 4096 and os.environ.get("HPSDF_HOST_FRONTIER") != "1":
-        from . import create_block_distributed, HpsdfError, ERR_UNSUPPORTED
-        try:
-            return create_block_distributed(ctx, config, field, K, rank, world, device_allgather(ctx, group))
-        except HpsdfError as e:  # e.g. a tree-CSG field around a host callback: the stepwise path below shards it
-            if e.status != ERR_UNSUPPORTED:
-                raise
+    if on_gpu and world > 1 and os.environ.get("HPSDF_PYTHON_ROUND_LOOP") != "1":
+        # the whole sharded build behind the C ABI (hpsdf_create_distributed): the device-side frontier for fields the GPU
+        # evaluates itself without nearness weighting, the host scheduler's rounds for the rest -- both over this all-gather
+        from . import create_block_distributed
+        return create_block_distributed(ctx, config, field, K, rank, world, device_allgather(ctx, group))
     # Nearness-weighted builds: the weight (pow / exp) is applied on the host (one libm for GPU path and oracle), so the
     # per-round errors pass through host memory, and after every round the ranks hand each other the coefficient arrays
     # that round accepted -- an incremental fit copies the node's previous rows and may run on any rank.

@@ -381,6 +381,28 @@ def test_create_distributed_shards_what_the_host_scheduler_owns(H, ctx, world):
             assert blk == one and s["jobs"] == st["jobs"]
 
 
+def test_bench_two_ranks_sharing_this_gpu():
+    """bench.py's N > 1 path end to end: two torch.distributed processes (gloo, both on this GPU: HPSDF_BENCH_SHARE_GPU=1)
+    -- sharded Create of the analytic field (asserted equal to the replicated one inside bench.py), the sharded mesh
+    leg, the weak-scaling Query -- and one JSON line with the contract's keys from rank 0."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, HPSDF_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--points", "400000",
+           "--mesh", "5", "--no-fit-bench", "--no-cpu-baseline", "--no-refined", "--no-sorted-ceiling"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["create_sharded_ms"] is not None and out["create_sharded_ms"] > 0
+    assert out["mesh_create"]["n_gpus"] == 2 and out["mesh_create"]["create_ms_1e-6"] > 0
+    for k in ("roofline", "config", "metric", "unit", "ms_per_step", "dtype"):
+        assert k in out
+
+
 def test_create_distributed_argument_checks(H, ctx):
     with pytest.raises(H.HpsdfError) as e:
         H.create_block_distributed(ctx, H.make_config(1e-6), H.Field.sphere(), 1024, 2, 2, lambda *a: None)
