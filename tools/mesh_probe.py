@@ -33,6 +33,12 @@ for level in (a for a in sys.argv[1:] or ["5", "7", "8"]):
         print("   traversal: %d wave queries; per query of 64 samples: %.0f nodes visited, %.0f (lane, triangle) pairs through the "
               "lower-bound test, %.0f through the closest-point test"
               % (q, ms["node_visits"] / q, ms["tri_tests"] / q, ms["tri_test_lanes"] / q))
+    for tgt in [float(x) for x in os.environ.get("MESH_PROBE_TARGETS", "").split(",") if x]:  # e.g. MESH_PROBE_TARGETS=1e-6,1e-7
+        c2 = H.make_config(tgt, tuple(lo), tuple(hi))
+        H.create_block(ctx, c2, f, 1024)
+        ta = time.time(); b2, s2 = H.create_block(ctx, c2, f, 1024); tb = time.time()
+        print("   Create %g: %.1f ms, %d rounds, %d nodes, %d samples = %.0f M samples/s"
+              % (tgt, (tb - ta) * 1e3, s2["rounds"], s2["n_nodes"], s2["samples"], s2["samples"] / (tb - ta) / 1e6))
     pts = np.random.default_rng(1).uniform(lo, hi, (1_000_000, 3))
     t6 = time.time(); v = f.eval(ctx, pts); t7 = time.time()
     print("%s: %d tris | gen %.1fs | prepare (half-edges+BVH+upload) %.2fs | Create 1e-5: %.1f ms (first %.1f ms) "
