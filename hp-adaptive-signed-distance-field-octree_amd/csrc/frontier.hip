@@ -1705,6 +1705,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         hipLaunchKernelGGL(fr_tasks_kernel, dim3((16u * Kj + 255u) / 256u), dim3(256), 0, s, d);
         const int degHi = (int)std::min<uint32_t>(kMaxDegree - 1, knownMaxDeg + 1);
         const uint32_t taskBound = 9u * Kj;
+        bool degHiDone = false;
         FieldDev fdr = fd;
         if (mesh) {
             for (int deg = 2; deg <= degHi; ++deg)
@@ -1713,10 +1714,19 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
             fdr.kind = kFieldSamples;
             fdr.samples = ws->samples;
         }
-        const bool fork = degHi > 2 && std::getenv("HPSDF_FRONTIER_ONE_STREAM") == nullptr;
+        // One launch for every degree of the round (kernels.hip fit_multi_kernel); the matrix-core fit and
+        // HPSDF_FRONTIER_SPLIT_FITS=1 keep one launch per degree, side by side on three streams.
+        static const bool splitFits = std::getenv("HPSDF_FRONTIER_SPLIT_FITS") != nullptr;
+        if (!d.fastFit && !splitFits) {
+            size_t lds = 0;
+            for (int deg = 2; deg <= degHi; ++deg) lds = std::max(lds, fitLdsTable[deg]);
+            HPSDF_HIP(launchFitMulti(s, d.blocks, taskBound, lds, d.tasks, ws->arena, d.errs, ctx->dTables, fdr, rm, &d.hdr->nBlocks));
+            degHiDone = true;
+        }
+        const bool fork = !degHiDone && degHi > 2 && std::getenv("HPSDF_FRONTIER_ONE_STREAM") == nullptr;
         if (fork) HPSDF_HIP(hipEventRecord(ws->forkEv, s));
         bool used[FrontierWorkspace::kSide] = {false, false, false};
-        for (int deg = 2; deg <= degHi; ++deg) {
+        for (int deg = 2; deg <= degHi && !degHiDone; ++deg) {
             hipStream_t fs = s;
             if (fork && deg > 2) {
                 const int k = (deg - 3) % FrontierWorkspace::kSide;

@@ -1758,6 +1758,29 @@ __device__ __forceinline__ void fitBlockBody(const FitBlock blk, const FitTask* 
     }
 }
 
+// All the fits of a round in ONE launch (the device-side frontier, frontier.hip): the round's blocks lie degree by degree in
+// one array and carry their degree, so a workgroup picks the compile-time-specialised body its block needs.  The blocks are
+// handed out from the END of the array -- highest degree, longest fits first -- and workgroups of every degree share the chip
+// at once, which is what the per-degree launches on side streams were for (their fork / join events cost 20-50 us a round).
+// count: the round's number of blocks, written by the device; the grid is an upper bound.
+template <int KIND, bool CSG>
+__global__ __launch_bounds__(kFitThreads, HPSDF_FIT_MIN_WAVES) void fit_multi_kernel(const FitBlock* __restrict__ blocks,
+                                                                const FitTask* __restrict__ tasks, double* __restrict__ arena,
+                                                                double* __restrict__ errs, const DeviceTables* __restrict__ T,
+                                                                FieldDev field, RootMap rm, const uint32_t* __restrict__ count) {
+    extern __shared__ double lds[];
+    const uint32_t n = *count;
+    if (blockIdx.x >= n) return;
+    const FitBlock blk = blocks[n - 1u - blockIdx.x];
+    switch (blk.degree) {
+        case 2: fitBlockBody<KIND, CSG, 2, 1>(blk, tasks, arena, errs, nullptr, T, field, rm, lds); break;
+        case 3: fitBlockBody<KIND, CSG, 3, 1>(blk, tasks, arena, errs, nullptr, T, field, rm, lds); break;
+        case 4: fitBlockBody<KIND, CSG, 4, 1>(blk, tasks, arena, errs, nullptr, T, field, rm, lds); break;
+        case 5: fitBlockBody<KIND, CSG, 5, 1>(blk, tasks, arena, errs, nullptr, T, field, rm, lds); break;
+        default: fitBlockBody<KIND, CSG, 0, 1>(blk, tasks, arena, errs, nullptr, T, field, rm, lds); break;
+    }
+}
+
 // Nearness weighting, Octree.cpp:1209-1247: |mean of FApprox over 100 points of the cell| for every fit of a weighted
 // build, from the full coefficient arrays fit_kernel has just written (a kernel of its own: its any-degree evaluation
 // keeps tables in private memory, and inside fit_kernel that put 320 bytes of scratch on every fit launch, weighted or
@@ -2150,6 +2173,23 @@ static void launchFitT(hipStream_t stream, int degree, int cellsPerThread, const
 
 // One launch per degree: `degree` selects the compile-time-specialised kernel (0 = any; the blocks then carry
 // their own degree).
+template <int KIND, bool CSG>
+static void launchFitMultiT(hipStream_t stream, const FitBlock* dBlocks, uint32_t maxBlocks, size_t ldsBytes, const FitTask* dTasks,
+                            double* dArena, double* dErrs, const DeviceTables* dTables, const FieldDev& field, const RootMap& rm,
+                            const uint32_t* dCount) {
+    hipLaunchKernelGGL((fit_multi_kernel<KIND, CSG>), dim3(maxBlocks), dim3(kFitThreads), ldsBytes, stream, dBlocks, dTasks, dArena, dErrs,
+                       dTables, field, rm, dCount);
+}
+// every block of dBlocks[0 .. *dCount), whatever its degree, in one launch; ldsBytes: the largest any of them needs
+hipError_t launchFitMulti(hipStream_t stream, const FitBlock* dBlocks, uint32_t maxBlocks, size_t ldsBytes, const FitTask* dTasks,
+                          double* dArena, double* dErrs, const DeviceTables* dTables, const FieldDev& field, const RootMap& rm,
+                          const uint32_t* dCount) {
+    if (maxBlocks == 0) return hipSuccess;
+    if (ldsBytes > kFitMaxLdsBytes) return hipErrorInvalidValue;
+    HPSDF_DISPATCH_FIELD(launchFitMultiT, field, stream, dBlocks, maxBlocks, ldsBytes, dTasks, dArena, dErrs, dTables, field, rm, dCount);
+    return hipGetLastError();
+}
+
 hipError_t launchFit(hipStream_t stream, int degree, int cellsPerThread, const FitBlock* dBlocks, uint32_t nBlocks,
                      size_t ldsBytes, const FitTask* dTasks, double* dArena, double* dErrs, double* dMeans,
                      const DeviceTables* dTables, const FieldDev& field, const RootMap& rm, const uint32_t* dRange) {

@@ -31,6 +31,9 @@ FitShape fitShape(int degree, int nrows, uint32_t count, bool weighted, bool lat
 hipError_t launchFit(hipStream_t stream, int degree, int cellsPerThread, const FitBlock* dBlocks, uint32_t nBlocks, size_t ldsBytes,
                      const FitTask* dTasks, double* dArena, double* dErrs, double* dMeans,
                      const DeviceTables* dTables, const FieldDev& field, const RootMap& rm, const uint32_t* dRange = nullptr);
+hipError_t launchFitMulti(hipStream_t stream, const FitBlock* dBlocks, uint32_t maxBlocks, size_t ldsBytes, const FitTask* dTasks,
+                          double* dArena, double* dErrs, const DeviceTables* dTables, const FieldDev& field, const RootMap& rm,
+                          const uint32_t* dCount);
 hipError_t launchFitWeight(hipStream_t stream, const FitBlock* dBlocks, uint32_t nBlocks, size_t ldsBytes, const FitTask* dTasks,
                            const double* dArena, double* dMeans, const DeviceTables* dTables);
 // opt-in fast fit of degrees 4..11 on the matrix cores (fit_mfma.hip): blocks of at most 16 fits, NOT bit-identical to launchFit
