@@ -511,7 +511,17 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
     // one launch per shape class: the degree is a compile-time constant of the kernel
     // the blocks of one degree are contiguous (classes are ordered degree-major) and carry their own rows and
     // depth, so one launch per (degree, cells-per-thread) run covers them
-    for (int c = 0; c < kClasses;) {
+    bool anyFast = false;
+    for (int deg = 0; deg <= kMaxDegree; ++deg) anyFast |= fastDeg(deg);
+    if (!anyFast && nBlocks) {  // every degree in one launch (kernels.hip fit_multi_kernel: longest fits first, all degrees share the chip)
+        size_t ldsAll = 0;
+        for (int c = 0; c < kClasses; ++c)
+            if (classCount[c]) ldsAll = std::max(ldsAll, classShape[c].ldsBytes);
+        HPSDF_HIP(launchFitMulti(ctx->stream, ws.blocks.dev, nBlocks, ldsAll, ws.tasks.dev, ws.arena, ws.errs.dev, ctx->dTables, fd, rm, nullptr));
+        if (b->weighted)  // Octree.cpp:1071-1092: the weight's |mean FApprox|, from the coefficients just written
+            HPSDF_HIP(launchFitWeight(ctx->stream, ws.blocks.dev, nBlocks, ldsAll, ws.tasks.dev, ws.arena, ws.errs.dev + nSlots, ctx->dTables));
+    }
+    for (int c = 0; c < kClasses && anyFast;) {
         if (!classCount[c]) {
             ++c;
             continue;

@@ -1767,9 +1767,10 @@ template <int KIND, bool CSG>
 __global__ __launch_bounds__(kFitThreads, HPSDF_FIT_MIN_WAVES) void fit_multi_kernel(const FitBlock* __restrict__ blocks,
                                                                 const FitTask* __restrict__ tasks, double* __restrict__ arena,
                                                                 double* __restrict__ errs, const DeviceTables* __restrict__ T,
-                                                                FieldDev field, RootMap rm, const uint32_t* __restrict__ count) {
+                                                                FieldDev field, RootMap rm, const uint32_t* __restrict__ count,
+                                                                uint32_t countValue) {
     extern __shared__ double lds[];
-    const uint32_t n = *count;
+    const uint32_t n = count ? *count : countValue;  // (the host scheduler knows the number, the device-side frontier writes it)
     if (blockIdx.x >= n) return;
     const FitBlock blk = blocks[n - 1u - blockIdx.x];
     switch (blk.degree) {
@@ -2178,9 +2179,10 @@ static void launchFitMultiT(hipStream_t stream, const FitBlock* dBlocks, uint32_
                             double* dArena, double* dErrs, const DeviceTables* dTables, const FieldDev& field, const RootMap& rm,
                             const uint32_t* dCount) {
     hipLaunchKernelGGL((fit_multi_kernel<KIND, CSG>), dim3(maxBlocks), dim3(kFitThreads), ldsBytes, stream, dBlocks, dTasks, dArena, dErrs,
-                       dTables, field, rm, dCount);
+                       dTables, field, rm, dCount, maxBlocks);
 }
-// every block of dBlocks[0 .. *dCount), whatever its degree, in one launch; ldsBytes: the largest any of them needs
+// every block of dBlocks[0 .. *dCount) -- or [0 .. maxBlocks) when dCount is null --, whatever its degree, in one launch;
+// ldsBytes: the largest any of them needs
 hipError_t launchFitMulti(hipStream_t stream, const FitBlock* dBlocks, uint32_t maxBlocks, size_t ldsBytes, const FitTask* dTasks,
                           double* dArena, double* dErrs, const DeviceTables* dTables, const FieldDev& field, const RootMap& rm,
                           const uint32_t* dCount) {
