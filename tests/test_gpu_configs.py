@@ -151,6 +151,24 @@ def _hard_meshes():
     yield "slivers", (v, t)
 
 
+def test_tiny_meshes_through_the_device_build(H, ctx):
+    """Four and eight triangles: fewer than one leaf holds -- the root's children are leaves, the LBVH has one or seven inner
+    nodes -- through the device build, the host build and the O(n) scan."""
+    tetra_v = np.float32([[0.3, 0.3, 0.3], [-0.3, -0.3, 0.3], [-0.3, 0.3, -0.3], [0.3, -0.3, -0.3]])
+    tetra_t = np.uint64([[0, 1, 2], [0, 3, 1], [0, 2, 3], [1, 3, 2]])
+    octa_v = np.float32([[0.3, 0, 0], [-0.3, 0, 0], [0, 0.25, 0], [0, -0.25, 0], [0, 0, 0.2], [0, 0, -0.2]])
+    octa_t = np.uint64([[0, 2, 4], [2, 1, 4], [1, 3, 4], [3, 0, 4], [2, 0, 5], [1, 2, 5], [3, 1, 5], [0, 3, 5]])
+    pts = np.random.default_rng(3).uniform(-0.5, 0.5, (3000, 3))
+    for verts, tris in ((tetra_v, tetra_t), (octa_v, octa_t)):
+        f = H.Field.mesh(ctx, verts, tris)
+        want = f.eval_naive(ctx, pts)
+        assert np.array_equal(bits(f.eval(ctx, pts)), bits(want)) and np.array_equal(bits(f.eval_wave(ctx, pts)), bits(want))
+        assert (want < 0).any() and (want > 0).any()
+        blk, st = H.create_block(ctx, H.make_config(1e-3), f, 1024)
+        assert st["n_nodes"] >= 4681
+        f.close()
+
+
 def _hard_points(O, verts, tris, seed):
     rng = np.random.default_rng(seed)
     lo, hi = verts.min(0).astype(np.float64), verts.max(0).astype(np.float64)

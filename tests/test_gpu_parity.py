@@ -616,7 +616,8 @@ def test_continuity_device_solve_equals_host_solve(H, ctx, tol, max_iter):
     assert sd["iterations"] > 0 and (max_iter == 0 or sd["iterations"] <= max_iter)
 
 
-@pytest.mark.parametrize("case", ["sphere@1e-8", "union3@1e-7 K=256", "offset sphere, custom root", "deep chain", "mixed degrees"])
+@pytest.mark.parametrize("case", ["sphere@1e-8", "union3@1e-7 K=256", "offset sphere, custom root", "deep chain", "mixed degrees",
+                                  "eight leaves"])
 def test_continuity_matrix_assembled_on_device_equals_host(H, ctx, case):
     """continuity_asm.hip against continuity.cpp: row pointer, columns and values of the jump-energy matrix bit for bit --
     conforming faces (analytic integrals) and non-conforming ones (quadrature across depth differences of 1 and more),
@@ -631,6 +632,8 @@ def test_continuity_matrix_assembled_on_device_equals_host(H, ctx, case):
     elif case == "deep chain":
         from helpers import deep_chain_block
         blk = deep_chain_block(rng, max_depth=6)
+    elif case == "eight leaves":
+        blk = synthetic_block(rng, [4, 1, 0, 6, 2, 2, 9, 3], depth=1)
     else:
         blk = synthetic_block(rng, [12, 0, 7, 3, 11, 2, 5, 9], depth=2)
     rp, col, val, st = H.continuity_matrix(blk, 4)
