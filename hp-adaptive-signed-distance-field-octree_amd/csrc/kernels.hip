@@ -1932,11 +1932,20 @@ __global__ __launch_bounds__(256) void mesh_sample_kernel(const FitTask* __restr
     __shared__ MeshWaveLds sWave[4];
     __shared__ double sR[64];
     __shared__ unsigned char sPos[64];
-    uint32_t task = blockIdx.y;
-    if (range != nullptr) {
-        if (task >= range[1]) return;
-        task += range[0];
-    }
+    // Which (task, chunk) this workgroup samples.  Workgroups are dealt round-robin over the 8 XCDs in dispatch order
+    // (blocks b and b + 8 share an XCD and its 4 MB L2: MI355X_MICROARCH.md, observed, a speed matter only), and the
+    // tasks lie in node order, i.e. along the octree's space-filling curve.  So the workgroups of one XCD take one
+    // CONTIGUOUS eighth of the (task, chunk) list -- an octant of the domain, whose part of the BVH and of the triangle
+    // records is all that XCD's L2 has to hold -- instead of every eighth cell chunk of the whole domain.
+    const uint32_t gx = gridDim.x, nTasks = range != nullptr ? range[1] : gridDim.y;
+    const uint32_t nwg = nTasks * gx, orig = blockIdx.y * gx + blockIdx.x;
+    if (orig >= ((nwg + 7u) & ~7u)) return;
+    const uint32_t xcd = orig & 7u, q8 = nwg >> 3, r8 = nwg & 7u;
+    const uint32_t wgid = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + (orig >> 3);
+    if ((orig >> 3) >= q8 + (xcd < r8 ? 1u : 0u)) return;  // (the padding of the last group of eight)
+    const uint32_t chunk = wgid % gx;
+    uint32_t task = wgid / gx;
+    if (range != nullptr) task += range[0];
     const int tid = threadIdx.x, nq = 4 * degree + 1, gl = nq * (nq - 1) / 2, total = nq * nq * nq;
     if (tid < nq) sR[tid] = T->roots[gl + tid];
     __syncthreads();
@@ -1947,7 +1956,7 @@ __global__ __launch_bounds__(256) void mesh_sample_kernel(const FitTask* __restr
     }
     __syncthreads();
     const FitTask& tk = tasks[task];
-    const int r = (int)blockIdx.x * 256 + tid;
+    const int r = (int)chunk * 256 + tid;
     const bool active = r < total;
     const int rem = meshSampleOrder(active ? r : total - 1, nq, nq, sPos, sPos);
     const int i = rem / (nq * nq), jk = rem - i * nq * nq, j = jk / nq, k = jk - j * nq;
