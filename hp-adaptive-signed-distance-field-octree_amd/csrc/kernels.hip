@@ -1926,23 +1926,35 @@ FitShape fitShape(int degree, int nrows, uint32_t count, bool weighted, bool lat
 // and without the fit's accumulators twice as many waves fit on a CU.  grid = (ceil(nq^3 / 256), tasks of one degree).
 // range == nullptr: grid = (chunks of 256 samples, tasks).  Otherwise grid.y is an upper bound and row y samples task
 // range[0] + y if y < range[1] -- the device-side frontier's rounds (frontier.hip), whose task counts the host does not know.
+constexpr uint32_t kMeshXcdRun = 32;  // 16-64 measure alike; 1 (plain order) and >= 256 lose 3-7 %
+static uint32_t meshXcdRun() {  // HPSDF_MESH_XCD_RUN overrides (experiments); 1 = plain dispatch order
+    static const uint32_t v = [] {
+        const char* e = std::getenv("HPSDF_MESH_XCD_RUN");
+        const long x = e ? std::atol(e) : (long)kMeshXcdRun;
+        return (uint32_t)(x < 1 ? 1 : (x > 4096 ? 4096 : x));
+    }();
+    return v;
+}
 __global__ __launch_bounds__(256) void mesh_sample_kernel(const FitTask* __restrict__ tasks, int degree,
                                                           const DeviceTables* __restrict__ T, MeshDev mesh, RootMap rm,
-                                                          double* __restrict__ samples, const uint32_t* __restrict__ range) {
+                                                          double* __restrict__ samples, const uint32_t* __restrict__ range,
+                                                          uint32_t nTasksArg, uint32_t xcdRun) {
     __shared__ MeshWaveLds sWave[4];
     __shared__ double sR[64];
     __shared__ unsigned char sPos[64];
     // Which (task, chunk) this workgroup samples.  Workgroups are dealt round-robin over the 8 XCDs in dispatch order
     // (blocks b and b + 8 share an XCD and its 4 MB L2: MI355X_MICROARCH.md, observed, a speed matter only), and the
-    // tasks lie in node order, i.e. along the octree's space-filling curve.  So the workgroups of one XCD take one
-    // CONTIGUOUS eighth of the (task, chunk) list -- an octant of the domain, whose part of the BVH and of the triangle
-    // records is all that XCD's L2 has to hold -- instead of every eighth cell chunk of the whole domain.
-    const uint32_t gx = gridDim.x, nTasks = range != nullptr ? range[1] : gridDim.y;
+    // tasks lie in node order, i.e. along the octree's space-filling curve.  The (task, chunk) list is cut into runs of
+    // kMeshXcdRun consecutive entries -- a few neighbouring cells -- and the runs are dealt round-robin over the XCDs:
+    // what an XCD has in flight at any time is a handful of compact regions, whose part of the BVH and of the triangle
+    // records is all its L2 has to hold (plain blockIdx order: every eighth chunk of an eight times longer stretch;
+    // one contiguous eighth of the list per XCD instead keeps the locality but not the balance -- cells far from the
+    // surface cost several times more than cells on it).
+    const uint32_t gx = gridDim.x, nTasks = range != nullptr ? range[1] : nTasksArg;
     const uint32_t nwg = nTasks * gx, orig = blockIdx.y * gx + blockIdx.x;
-    if (orig >= ((nwg + 7u) & ~7u)) return;
-    const uint32_t xcd = orig & 7u, q8 = nwg >> 3, r8 = nwg & 7u;
-    const uint32_t wgid = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + (orig >> 3);
-    if ((orig >> 3) >= q8 + (xcd < r8 ? 1u : 0u)) return;  // (the padding of the last group of eight)
+    const uint32_t inXcd = orig >> 3;  // position in the sequence of the workgroups that share this one's XCD
+    const uint32_t wgid = (((inXcd / xcdRun) << 3) + (orig & 7u)) * xcdRun + inXcd % xcdRun;
+    if (wgid >= nwg) return;  // (the grid is rounded up to whole groups of 8 runs, or an upper bound)
     const uint32_t chunk = wgid % gx;
     uint32_t task = wgid / gx;
     if (range != nullptr) task += range[0];
@@ -2113,8 +2125,10 @@ hipError_t launchMeshSample(hipStream_t stream, const FitTask* dTasks, uint32_t 
     const unsigned gx = (unsigned)((nq * nq * nq + 255) / 256);
     for (uint32_t first = 0; first < nTasks; first += 65535u) {
         const uint32_t n = nTasks - first < 65535u ? nTasks - first : 65535u;
-        hipLaunchKernelGGL(mesh_sample_kernel, dim3(gx, n), dim3(256), 0, stream, dTasks + first, degree, dTables, field.mesh, rm,
-                           dSamples, (const uint32_t*)nullptr);
+        // (grid rounded up to whole groups of 8 runs of the XCD interleave)
+        const uint32_t run = meshXcdRun(), wgs = (n * gx + 8u * run - 1u) / (8u * run) * (8u * run);
+        hipLaunchKernelGGL(mesh_sample_kernel, dim3(gx, (wgs + gx - 1u) / gx), dim3(256), 0, stream, dTasks + first, degree, dTables, field.mesh, rm,
+                           dSamples, (const uint32_t*)nullptr, n, run);
     }
     return hipGetLastError();
 }
@@ -2125,8 +2139,10 @@ hipError_t launchMeshSampleRange(hipStream_t stream, const FitTask* dTasks, cons
     if (degree < 1 || degree > 12 || field.kind != kFieldMesh || maxTasks == 0 || maxTasks > 65535u) return hipErrorInvalidValue;
     const int nq = 4 * degree + 1;
     const unsigned gx = (unsigned)((nq * nq * nq + 255) / 256);
-    hipLaunchKernelGGL(mesh_sample_kernel, dim3(gx, maxTasks), dim3(256), 0, stream, dTasks, degree, dTables, field.mesh, rm, dSamples,
-                       dRange);
+    const uint32_t run = meshXcdRun();
+    const unsigned gy = maxTasks + (8u * run + gx - 1u) / gx;  // whole groups of 8 runs of the XCD interleave past the last task
+    if (gy > 65535u) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mesh_sample_kernel, dim3(gx, gy), dim3(256), 0, stream, dTasks, degree, dTables, field.mesh, rm, dSamples, dRange, 0u, run);
     return hipGetLastError();
 }
 
