@@ -106,6 +106,70 @@ __device__ __forceinline__ void spmvChunk(const CgDev& d, const double* __restri
     }
 }
 
+// The same product with the work cut by ENTRIES instead of rows (what the loop runs; the row-owned version above stays for
+// matrices with a row longer than kCgRowTail).  Row lengths run from 1 to ~100 here and the row-owned kernel lasts as long
+// as its longest rows: every run of 32 entries is two more dependent fetches (entries, then the gathered vector) for that
+// wave, 21-30 us per launch when the bytes alone are 3.  Here workgroup w multiplies entries [w, w + 1) * 4096 (plus the
+// tail of its last row): every thread fetches its four or five entries at once and gathers -- two fetches deep whatever
+// the rows look like -- parks the products in LDS, and the rows whose first entry lies in that range are then summed from
+// LDS, a thread per row, strictly left to right: the same sums, bit for bit.  The chunk sums of in . out need all 256 rows
+// of a chunk, which no longer sit in one workgroup: cg_dot_kernel forms them afterwards.
+template <bool FUSED>
+__device__ __forceinline__ void spmvEntries(const CgDev& d, const double* __restrict__ in, const double* __restrict__ pOld, double beta,
+                                            double* __restrict__ pNew, double shift, double* __restrict__ out, double* sProd /* kCgEntriesPerWg + kCgRowTail */) {
+    const uint32_t w = blockIdx.x, tid = threadIdx.x;
+    const uint64_t e0 = (uint64_t)w * kCgEntriesPerWg, nnz = d.rowPtr[d.n];
+    auto value = [&](uint64_t j) { return FUSED ? in[j] + beta * pOld[j] : in[j]; };
+    constexpr int kPer = (int)((kCgEntriesPerWg + kCgRowTail) / 1024);
+    double v[kPer];
+    uint32_t c[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const uint64_t e = e0 + tid + (uint64_t)k * 1024;
+        const bool on = e < nnz;
+        v[k] = on ? d.val[e] : 0.0;
+        c[k] = on ? d.col[e] : 0u;
+    }
+    const uint32_t rs = d.wgRow[w], re = d.wgRow[w + 1];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) sProd[tid + k * 1024] = v[k] * value(c[k]);
+    __syncthreads();
+    for (uint32_t r = rs + tid; r < re; r += 1024u) {
+        const uint32_t a = (uint32_t)(d.rowPtr[r] - e0), b = (uint32_t)(d.rowPtr[r + 1] - e0);
+        const double pi = value(r);
+        if (FUSED) pNew[r] = pi;
+        double acc = shift * pi;
+        for (uint32_t k = a; k < b; ++k) acc += sProd[k];
+        out[r] = acc;
+    }
+}
+
+// partA[chunk] = cgChunkSum over the chunk's rows of a . b
+__global__ __launch_bounds__(256) void cg_dot_kernel(CgDev d, const double* __restrict__ a, const double* __restrict__ b, int checkDone) {
+    __shared__ double sh[256];
+    if (checkDone && d.s->done) return;
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const double s = blockChunkSum(i < d.n ? a[i] * b[i] : 0.0, sh);
+    if (threadIdx.x == 0) d.partA[blockIdx.x] = s;
+}
+
+// workgroup w of the entry-cut SpMV owns the rows whose first entry lies in [w, w + 1) * kCgEntriesPerWg
+__global__ __launch_bounds__(256) void cg_rows_kernel(CgDev d) {
+    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+    if (w <= d.nWg) {
+        uint32_t lo = 0, hi = (uint32_t)d.n;  // first row whose first entry is >= w * kCgEntriesPerWg (n if none)
+        const uint64_t key = (uint64_t)w * kCgEntriesPerWg;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (d.rowPtr[mid] < key)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        d.wgRow[w] = w == d.nWg ? (uint32_t)d.n : lo;
+    }
+}
+
 // cgChunkSum (launch.hpp) of e[0 .. cnt), cnt <= 256, by one wave; the result is valid in lane 0
 __device__ __forceinline__ double waveChunkSum(const double* e, uint64_t cnt, int lane) {
     auto at = [&](uint64_t i) { return i < cnt ? e[i] : 0.0; };
@@ -184,6 +248,24 @@ __global__ __launch_bounds__(1024, 8) void cg_step1_kernel(CgDev d, int k) {
     double beta;
     if (!cgOpenIteration(d, k, sh, blockIdx.x == 0, beta)) return;
     spmvChunk<true>(d, d.z, P[(k - 1) & 1], beta, P[k & 1], d.s->lambda, d.tmp, d.partA, sh);
+}
+
+// step 1 of iteration k with the SpMV cut by entries (grid = d.nWg); cg_dot_kernel follows
+__global__ __launch_bounds__(1024, 8) void cg_step1e_kernel(CgDev d, int k) {
+    __shared__ double sProd[kCgEntriesPerWg + kCgRowTail];
+    if (d.s->done) return;
+    double* const P[2] = {d.p, d.rhs};
+    if (k == 0) {
+        spmvEntries<false>(d, d.p, nullptr, 0.0, nullptr, d.s->lambda, d.tmp, sProd);
+        return;
+    }
+    double beta;
+    if (!cgOpenIteration(d, k, sProd, blockIdx.x == 0, beta)) return;
+    spmvEntries<true>(d, d.z, P[(k - 1) & 1], beta, P[k & 1], d.s->lambda, d.tmp, sProd);
+}
+__global__ __launch_bounds__(1024, 8) void cg_spmv_aux_e_kernel(CgDev d, int which) {
+    __shared__ double sProd[kCgEntriesPerWg + kCgRowTail];
+    spmvEntries<false>(d, which == 0 ? d.c : d.x, nullptr, 0.0, nullptr, which == 1 ? d.s->lambda : 0.0, d.tmp, sProd);
 }
 
 // after the last iteration of a batch: has the loop ended?  (one workgroup; the next batch's first kernel would find out
@@ -309,9 +391,18 @@ hipError_t launchCgStart(hipStream_t stream, const CgDev& d) {
     if (d.n == 0) return hipSuccess;
     const dim3 wide((unsigned)d.nChunks), one(1);
     hipLaunchKernelGGL(cg_setup_kernel, wide, dim3(256), 0, stream, d);
-    hipLaunchKernelGGL(cg_spmv_aux_kernel, wide, dim3(1024), 0, stream, d, 0);
+    if (d.nWg) hipLaunchKernelGGL(cg_rows_kernel, dim3((d.nWg + 256u) / 256u), dim3(256), 0, stream, d);
+    auto spmvAux = [&](int which, const double* in) {
+        if (d.nWg) {
+            hipLaunchKernelGGL(cg_spmv_aux_e_kernel, dim3(d.nWg), dim3(1024), 0, stream, d, which);
+            hipLaunchKernelGGL(cg_dot_kernel, wide, dim3(256), 0, stream, d, in, (const double*)d.tmp, 0);
+        } else {
+            hipLaunchKernelGGL(cg_spmv_aux_kernel, wide, dim3(1024), 0, stream, d, which);
+        }
+    };
+    spmvAux(0, d.c);
     hipLaunchKernelGGL(cg_scalar_aux_kernel, one, dim3(256), 0, stream, d, 0);
-    hipLaunchKernelGGL(cg_spmv_aux_kernel, wide, dim3(1024), 0, stream, d, 1);
+    spmvAux(1, d.x);
     hipLaunchKernelGGL(cg_residual_kernel, wide, dim3(256), 0, stream, d);
     hipLaunchKernelGGL(cg_scalar_aux_kernel, one, dim3(256), 0, stream, d, 1);
     return hipGetLastError();
@@ -320,7 +411,12 @@ hipError_t launchCgStart(hipStream_t stream, const CgDev& d) {
 // after the loop: the jump energy of x
 hipError_t launchCgFinish(hipStream_t stream, const CgDev& d) {
     if (d.n == 0) return hipSuccess;
-    hipLaunchKernelGGL(cg_spmv_aux_kernel, dim3((unsigned)d.nChunks), dim3(1024), 0, stream, d, 2);
+    if (d.nWg) {
+        hipLaunchKernelGGL(cg_spmv_aux_e_kernel, dim3(d.nWg), dim3(1024), 0, stream, d, 2);
+        hipLaunchKernelGGL(cg_dot_kernel, dim3((unsigned)d.nChunks), dim3(256), 0, stream, d, (const double*)d.x, (const double*)d.tmp, 0);
+    } else {
+        hipLaunchKernelGGL(cg_spmv_aux_kernel, dim3((unsigned)d.nChunks), dim3(1024), 0, stream, d, 2);
+    }
     hipLaunchKernelGGL(cg_scalar_aux_kernel, dim3(1), dim3(256), 0, stream, d, 2);
     return hipGetLastError();
 }
@@ -330,7 +426,12 @@ hipError_t launchCgIterations(hipStream_t stream, const CgDev& d, int firstItera
     if (d.nChunks != (d.n + kCgChunk - 1) / kCgChunk) return hipErrorInvalidValue;
     const dim3 wide((unsigned)d.nChunks), one(1);
     for (int k = firstIteration; k < firstIteration + iterations; ++k) {
-        hipLaunchKernelGGL(cg_step1_kernel, wide, dim3(1024), 0, stream, d, k);
+        if (d.nWg) {
+            hipLaunchKernelGGL(cg_step1e_kernel, dim3(d.nWg), dim3(1024), 0, stream, d, k);
+            hipLaunchKernelGGL(cg_dot_kernel, wide, dim3(256), 0, stream, d, (const double*)((k & 1) ? d.rhs : d.p), (const double*)d.tmp, 1);
+        } else {
+            hipLaunchKernelGGL(cg_step1_kernel, wide, dim3(1024), 0, stream, d, k);
+        }
         hipLaunchKernelGGL(cg_step2_kernel, wide, dim3(256), 0, stream, d, k);
     }
     hipLaunchKernelGGL(cg_check_kernel, one, dim3(64), 0, stream, d, firstIteration + iterations);

@@ -695,7 +695,12 @@ static int solveOnDevice(hpsdf_ctx* ctx, Keep& keep, const ContinuityDeviceMatri
     }
     const double tt1 = nowMs();
     const uint64_t vecB = al(n * 8), partB = al(nChunks * 8);
-    const uint64_t total = 9 * vecB + 3 * partB + 256 + (dm ? 0 : al((n + 1) * 8) + al(nnz * 4 + 4) + al(nnz * 8 + 8));
+    uint64_t maxRow = dm ? dm->maxRow : 0;
+    if (!dm)
+        for (uint64_t r = 0; r < n; ++r) maxRow = std::max<uint64_t>(maxRow, M.rowPtr[r + 1] - M.rowPtr[r]);
+    // the SpMV is cut by entries (cg.hip) unless a row is too long for a workgroup's tail or the counts outgrow 32 bits
+    const uint64_t nWg = (maxRow <= kCgRowTail && nnz < 0xFFFFFFFFull) ? std::max<uint64_t>(1, (nnz + kCgEntriesPerWg - 1) / kCgEntriesPerWg) : 0;
+    const uint64_t total = 9 * vecB + 3 * partB + 256 + al((nWg + 1) * 4) + (dm ? 0 : al((n + 1) * 8) + al(nnz * 4 + 4) + al(nnz * 8 + 8));
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess && (keep.dCap < total || keep.device != ctx->device)) {
         if (keep.dBase) {
@@ -727,6 +732,8 @@ static int solveOnDevice(hpsdf_ctx* ctx, Keep& keep, const ContinuityDeviceMatri
     d.tmp = (double*)take(n * 8);
     d.partA = (double*)take(nChunks * 8), d.partB = (double*)take(nChunks * 8), d.partC = (double*)take(nChunks * 8);
     d.s = (CgScalars*)take(sizeof(CgScalars));
+    d.wgRow = (uint32_t*)take((nWg + 1) * 4);
+    d.nWg = (uint32_t)nWg;
     uint64_t* dRowPtr = nullptr;
     uint32_t* dCsrCol = nullptr;
     double* dCsrVal = nullptr;

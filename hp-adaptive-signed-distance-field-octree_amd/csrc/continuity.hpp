@@ -30,7 +30,7 @@ struct ContinuityDeviceMatrix {
     void* scanTmp = nullptr;
     size_t scanCap = 0;
     int device = -1;
-    uint64_t n = 0, nnz = 0;
+    uint64_t n = 0, nnz = 0, maxRow = 0;  // maxRow: entries of the longest row
     const uint64_t* dRowPtr = nullptr;
     const uint32_t* dCol = nullptr;
     const double* dVal = nullptr;

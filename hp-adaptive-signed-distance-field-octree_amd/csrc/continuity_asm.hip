@@ -52,7 +52,7 @@ struct AsmDev {
     const DeviceTables* T;
     uint32_t* parent;    // [nNodes] parent * 8 + slot, root: 0xFFFFFFFF
     uint32_t* leaves;    // [nLeaves]
-    uint32_t* counters;  // [0] leaves listed, [1] fallback requested, [2] pairs x 2, [3] numeric pairs x 2
+    uint32_t* counters;  // [0] leaves listed, [1] fallback requested, [2] pairs x 2, [3] numeric pairs x 2, [4] longest row
     uint64_t* incCount;  // [nLeaves + 1] -> exclusive scan in place
     uint64_t* ownCount;  // [nLeaves + 1] rows^2 per leaf -> exclusive scan in place
     AsmIncident* inc;
@@ -424,7 +424,10 @@ __global__ __launch_bounds__(kAsmThreads) void ca_rows_kernel(AsmDev d) {
                 }
             if (in.numeric) __syncthreads();
         }
-        if (!WRITE && live) d.rowLen[nL.coeffs_start + i] = len;
+        if (!WRITE && live) {
+            d.rowLen[nL.coeffs_start + i] = len;
+            atomicMax(&d.counters[4], (uint32_t)(len > 0xFFFFFFFFull ? 0xFFFFFFFFull : len));
+        }
     }
 }
 
@@ -573,7 +576,9 @@ int continuityAssembleDevice(hpsdf_ctx* ctx, const hpsdf_node* nodes, uint64_t n
         if (e != hipSuccess) return fail2(e, "scan");
     }
     uint64_t nnz = 0;
+    uint32_t longest = 0;
     e = hipMemcpyAsync(&nnz, d.rowLen + nCoeffs, 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&longest, d.counters + 4, 4, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return fail2(e, "row pointer");
     const uint64_t entryBytes = al(nnz * 4 + 4) + al(nnz * 8 + 8);
@@ -589,7 +594,7 @@ int continuityAssembleDevice(hpsdf_ctx* ctx, const hpsdf_node* nodes, uint64_t n
     hipLaunchKernelGGL(ca_rows_kernel<true>, dim3((unsigned)nLeaves), dim3(kAsmThreads), 0, s, d);
     e = hipGetLastError();
     if (e != hipSuccess) return fail2(e, "kernels");
-    out.n = nCoeffs, out.nnz = nnz;
+    out.n = nCoeffs, out.nnz = nnz, out.maxRow = longest;
     out.dRowPtr = d.rowLen, out.dCol = d.col, out.dVal = d.val;
     st.n_pairs = hc[2] / 2;
     st.n_pairs_numeric = hc[3] / 2;

@@ -92,6 +92,8 @@ inline double cgCombine(const double* part, uint64_t n) {
     return a[0];
 }
 constexpr uint64_t kCgMaxChunksOnDevice = 65536;  // two levels of cgCombine: 16.7 M unknowns
+constexpr uint32_t kCgEntriesPerWg = 4096;  // entries of M a workgroup of the SpMV multiplies (its rows may run kCgRowTail past them)
+constexpr uint32_t kCgRowTail = 1024;
 struct CgScalars {
     double absNew, alpha, beta, resNorm2, threshold, lambda;
     double tol, rhsNorm2, jumpBefore, jumpAfter;
@@ -105,6 +107,11 @@ struct CgDev {
     const uint64_t* rowPtr;  // n + 1
     const uint32_t* col;
     const double* val;
+    // the SpMV's work list: workgroup w takes the rows whose first entry lies in [w, w + 1) * kCgEntriesPerWg, i.e. rows
+    // wgRow[w] .. wgRow[w + 1] - 1 (filled by launchCgStart).  nWg = 0: a row is longer than kCgRowTail, the row-owned
+    // SpMV runs instead.
+    uint32_t* wgRow;  // nWg + 1
+    uint32_t nWg;
     const double* c;  // the block's coefficients (right-hand side / lambda, initial guess / lambda)
     double *dinv, *rhs;
     double *x, *r, *p, *z, *tmp, *partA, *partB, *partC;
