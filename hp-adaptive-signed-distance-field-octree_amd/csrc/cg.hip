@@ -8,11 +8,13 @@
 //     rows -- each as 64 lane sums of 4 and a shuffle tree, then the chunk sums the same way again (cgCombine).
 // The loop's scalars (|r|^2, r . z, the iteration count, the stop flag) live in HBM; the host launches batches of
 // iterations and looks at the flag in between; the kernels of iterations past the stop return at once.
-// An iteration is TWO kernels (five in the first version: 42 us per iteration of which 21 were launch gaps):
+// An iteration is THREE kernels (five in the first version: 42 us per iteration of which 21 were launch gaps):
 //   step 1 (k): every workgroup sums the chunk sums of |r|^2 and r . z that step 2 (k - 1) left -- the same fixed order,
 //               so all of them get the same beta and the same verdict on the stop rule -- and then runs
 //               tmp = (M + lambda I) p with the new direction p = z + beta p_old formed on the fly, entry by entry,
-//               from z and the previous direction (two buffers, alternating; the products are the same bits);
+//               from z and the previous direction (two buffers, alternating; the products are the same bits).  The work
+//               is cut by ENTRIES of M, not rows (spmvEntries), so the chunk sums of p . tmp are formed by
+//   dot:        cg_dot_kernel, a workgroup per chunk of 256 rows;
 //   step 2 (k): every workgroup sums the chunk sums of p . tmp, alpha = (r . z) / (p . tmp), then x, r, z and the new
 //               chunk sums.
 // Only workgroup 0 writes scalars, and only into slots no workgroup of the same kernel reads.
