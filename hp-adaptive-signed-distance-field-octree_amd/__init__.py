@@ -381,9 +381,10 @@ class Field:
     def mesh_stats(self, reset=True):
         """BVH traversal counters (mesh fields created under HPSDF_MESH_STATS=1, diagnostic builds): wave queries, nodes
         visited, pairs through the lower-bound test ("tri_tests"), pairs through the closest-point test ("tri_test_lanes")."""
-        out = (C.c_uint64 * 4)()
+        out = (C.c_uint64 * 8)()
         check(lib().hpsdf_field_mesh_stats(self.handle, out, 1 if reset else 0))
-        return dict(zip(("wave_queries", "node_visits", "tri_tests", "tri_test_lanes"), (int(v) for v in out)))
+        return dict(zip(("wave_queries", "node_visits", "tri_tests", "tri_test_lanes", "leaf_pairs", "bound_batches", "closest_batches",
+                         "seed_exact"), (int(v) for v in out)))
 
     def close(self):
         if self.handle:

@@ -74,6 +74,8 @@ int makeFieldDev(const hpsdf_field* f, const double* dSamples, FieldDev* out) {
             out->mesh.triPos = reinterpret_cast<const float4*>(f->dTriPos);
             out->mesh.triPre = reinterpret_cast<const float4*>(f->dTriPre);
             out->mesh.bvh = f->dBvh;
+            out->mesh.slabs = f->dSlabs;
+            out->mesh.leafLog2 = f->leafLog2;
             out->mesh.nTris = f->nTris;
             out->mesh.nNodes = f->nBvhNodes;
             out->mesh.stats = f->dStats;
@@ -393,8 +395,8 @@ int hpsdf_field_create_mesh(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts,
     }
 #ifdef HPSDF_MESH_STATS_BUILD
     if (e == hipSuccess && std::getenv("HPSDF_MESH_STATS")) {
-        e = hipMalloc((void**)&f->dStats, 4 * sizeof(unsigned long long));
-        if (e == hipSuccess) e = hipMemset(f->dStats, 0, 4 * sizeof(unsigned long long));
+        e = hipMalloc((void**)&f->dStats, 8 * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMemset(f->dStats, 0, 8 * sizeof(unsigned long long));
     }
 #endif
     if (e != hipSuccess) {
@@ -465,14 +467,14 @@ int hpsdf_field_destroy(hpsdf_field* f) {
     return HPSDF_OK;
 }
 
-int hpsdf_field_mesh_stats(const hpsdf_field* f, uint64_t out[4], int reset) {
+int hpsdf_field_mesh_stats(const hpsdf_field* f, uint64_t out[8], int reset) {
     HPSDF_TRY
     if (!f || !out || f->kind != kHostMesh) return fail(HPSDF_ERR_INVALID_ARGUMENT, "not a mesh field");
     if (!f->dStats) return fail(HPSDF_ERR_UNSUPPORTED, "traversal counters need a diagnostic build (-DHPSDF_MESH_STATS_BUILD) and HPSDF_MESH_STATS=1");
     HPSDF_HIP(hipSetDevice(f->device));
     HPSDF_HIP(hipDeviceSynchronize());
-    HPSDF_HIP(hipMemcpy(out, f->dStats, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    if (reset) HPSDF_HIP(hipMemset(f->dStats, 0, 4 * sizeof(uint64_t)));
+    HPSDF_HIP(hipMemcpy(out, f->dStats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (reset) HPSDF_HIP(hipMemset(f->dStats, 0, 8 * sizeof(uint64_t)));
     return HPSDF_OK;
     HPSDF_CATCH
 }

@@ -68,6 +68,17 @@ struct alignas(64) BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "one line per node");
 
+// What a BVH child's triangles are known to lie in besides its box: the slab |n . (x - g)| <= e cut by the ball |x - g| <= rho
+// (mesh_build.hip, mb_slab_kernel).  A box says nothing about WHERE in it the surface runs: for a sample at distance D from a
+// surface patch of size H that is tilted against the axes, the patch's box reaches ~H/2 towards the sample, so every patch
+// within ~sqrt(D H) of the foot point passes the box test; the slab of a smooth patch is thin (e ~ H^2 / 8R) and leaves the
+// ones within ~rho.  n = 0 turns the bound into the ball's; e < 0 marks "no slab" (the walk skips the test; g and rho still hold a ball).
+struct alignas(64) NodeSlab {
+    float4 g0, n0;  // child 0: g.xyz rho | n.xyz e
+    float4 g1, n1;  // child 1
+};
+static_assert(sizeof(NodeSlab) == 64, "one line per node");
+
 struct MeshDev {
     const float* verts;        // xyz per vertex
     const uint32_t* tris;      // 3 vertex ids per triangle
@@ -78,7 +89,11 @@ struct MeshDev {
                                // second): a lower bound of the distance in ~20 instructions, and the slot -> triangle map
     const uint32_t* halfEdges; // twin half-edge per half-edge (Mesh.h:74)
     const BvhNode* bvh;        // node 0 is the root
+    const NodeSlab* slabs;     // per BVH node, for each child: its triangles lie within e of the plane through g across the unit
+                               // vector n and within rho of g (NodeSlab above); nullptr: boxes only (host-built trees)
     uint32_t nTris, nNodes;
+    uint32_t leafLog2;         // every leaf holds at most 1 << leafLog2 triangles (how the sampler cuts its lower-bound batches)
+    uint32_t pad0;
     // traversal statistics (diagnostic builds, -DHPSDF_MESH_STATS_BUILD, and the field created under HPSDF_MESH_STATS=1):
     // [0] wave-wide queries, [1] nodes visited by them, [2] triangle tests issued (wave level), [3] lanes that ran one
     unsigned long long* stats;

@@ -114,10 +114,11 @@ __device__ V3 pseudoNormal(const MeshDev& m, uint32_t t, int code) {
     uint32_t he = 3 * t + sidx, cur = t;
     int guard = 0;
     do {
-        V3 tri[3] = {meshVert(m, m.tris[3 * cur]), meshVert(m, m.tris[3 * cur + 1]), meshVert(m, m.tris[3 * cur + 2])};
-        const int k = he % 3;
-        const V3 ab = tri[(k + 1) % 3] - tri[k];
-        const V3 ac = tri[(k + 2) % 3] - tri[k];
+        const V3 t0 = meshVert(m, m.tris[3 * cur]), t1 = meshVert(m, m.tris[3 * cur + 1]), t2 = meshVert(m, m.tris[3 * cur + 2]);
+        const int k = he % 3;  // (selected, not indexed: an indexed array of registers lives in scratch memory)
+        const V3 pk = k == 0 ? t0 : (k == 1 ? t1 : t2), pk1 = k == 0 ? t1 : (k == 1 ? t2 : t0), pk2 = k == 0 ? t2 : (k == 1 ? t0 : t1);
+        const V3 ab = pk1 - pk;
+        const V3 ac = pk2 - pk;
         const float ang = acosf(dot(normalized(ab), normalized(ac)));
         n = n + ang * faceNormal(m, cur);
         he = m.halfEdges[he];
@@ -138,17 +139,29 @@ __device__ __forceinline__ uint32_t slotTriangle(const MeshDev& m, uint32_t slot
 // A box only says "the triangle is somewhere in here": for a sample at distance D from a surface tessellated at size h every
 // triangle whose box dips into the ball passes the box test, a patch ~sqrt(2 D h) wide (~300 triangles per sample on a
 // 1.3 M-triangle sphere); the plane-and-circle bound leaves the ones within ~h.
-// A triangle is dropped only if the bound exceeds the best distance by `slack` = 2e-5 of the mesh's scale (its extent, or
-// its largest coordinate if that is larger: f32 positions round at that scale) -- two orders of magnitude above the f32
-// rounding of either computation (mesh_tripre_kernel builds normal and circle with margins of their own) and far below a
-// triangle's size -- so the winner is still exactly the exhaustive scan's (test_mesh_bvh_equals_linear_scan_bitwise, the
+// A triangle is dropped only if the bound exceeds the best distance by `slack` = 2e-6 of the mesh's scale (its extent, or
+// its largest coordinate if that is larger: f32 positions round at that scale; meshSlack has the error budget) and by
+// 5e-6 of itself -- so the winner is still exactly the exhaustive scan's (test_mesh_bvh_equals_linear_scan_bitwise, the
 // fuzzers).  rejectBound = what the bound is compared with; a NaN bound never drops anything.
+// (Bounds, unlike the closest-point arithmetic, need not follow the reference operation by operation: their dot products
+// are fused multiply-adds -- three instructions instead of five -- and the square root is the raw v_sqrt_f32, 1 ulp; the
+// slack they are compared with is four orders of magnitude wider than either.)
+__device__ __forceinline__ float dotF(V3 a, V3 b) { return __builtin_fmaf(a.x, b.x, __builtin_fmaf(a.y, b.y, a.z * b.z)); }
 __device__ __forceinline__ float triLowerBound2(V3 p, float4 g, float4 nh) {
     const V3 dx = p - V3{g.x, g.y, g.z};
-    const float sd = dot(V3{nh.x, nh.y, nh.z}, dx), s2 = sd * sd;
-    const float off = fmaxf(sqrtf(fmaxf(sqnorm(dx) - s2, 0.0f)) - g.w, 0.0f);
-    return s2 + off * off;
+    const float sd = dotF(V3{nh.x, nh.y, nh.z}, dx), s2 = sd * sd;
+    const float off = fmaxf(__builtin_amdgcn_sqrtf(fmaxf(dotF(dx, dx) - s2, 0.0f)) - g.w, 0.0f);
+    return __builtin_fmaf(off, off, s2);
 }
+// The slack (a distance) a lower bound must exceed the best distance by before anything is dropped.  What it has to cover
+// (u = 2^-24, D the distance, M the largest coordinate; every f32 subtraction p - g is relatively exact, so most errors
+// scale with D and are absorbed by rejectBound's factor 1.00001 on the square, i.e. 5e-6 D):
+//   the reference's closest point q = a + t ab (or (u a + v b) + w c) is rounded where it is formed: <= 3 u M off the
+//     triangle, so its distance may come out that much below the true one                                  1.8e-7 M
+//   the record's plane misses the triangle's vertices by e <= 4e-7 of the scale (mesh_tripre_kernel checks) 4.0e-7 M
+//   n . (p - g), |p - g|^2 - (n . (p - g))^2, |n| - 1: ~16 u D                                              (factor)
+// 2e-6 of the scale is three and a half times their sum.  (Round 2 ran with 2e-5; the margin it adds around every foot
+// point, sqrt(2 D slack), was most of what the samples far from the surface queued: a triangle's width and more.)
 __device__ __forceinline__ float meshSlack(const BvhNode& root) {
     float e2 = 0.0f, big = 0.0f;
     for (int a = 0; a < 3; ++a) {
@@ -156,7 +169,7 @@ __device__ __forceinline__ float meshSlack(const BvhNode& root) {
         e2 += (hi - lo) * (hi - lo);
         big = fmaxf(big, fmaxf(fabsf(hi), fabsf(lo)));
     }
-    return 2e-5f * fmaxf(sqrtf(e2), big);
+    return 2e-6f * fmaxf(sqrtf(e2), big);
 }
 __device__ __forceinline__ float rejectBound(float best, float slack) {
     const float r = sqrtf(best) + slack;
@@ -380,41 +393,77 @@ __device__ __forceinline__ BvhNode loadNodeUniform(const BvhNode* base, int32_t 
 
 // The same traversal with the triangle tests COMPACTED and FILTERED (what mesh_sample_kernel runs).  In
 // meshSignedDistanceWave a leaf is tested the moment it is met, by the lanes whose bound asks for it: ~13 of 64 on a smooth
-// 1.3 M-triangle mesh, i.e. the closest-point code runs at a fifth of the machine's width.  Here a leaf only appends
-// (lane, slot) pairs to ring A in LDS.  Whenever 64 pairs are there the wave runs 64 lower-bound tests at once
-// (triLowerBound2; lane l takes pair l, the point comes from its owner's registers by ds_bpermute).  Survivors -- about one
-// pair in twelve -- go to ring B as (lane, triangle); whenever 64 are there the wave runs 64 closest-point tests at once and
-// merges every result into its owner's best with ONE 64-bit LDS atomic min on (distance bits << 32 | triangle): smallest
-// distance, ties to the lower index -- the linear scan's rule (Mesh.cpp:134-159), whatever the order.
+// 1.3 M-triangle mesh, i.e. the closest-point code runs at a fifth of the machine's width.  Here a leaf only appends one
+// (lane, leaf) pair per lane that wants it to ring A in LDS.  Whenever 64 >> leafLog2 pairs are there the wave runs 64
+// lower-bound tests at once (triLowerBound2; lane l takes slot l & (W - 1) of pair l >> leafLog2, W = 1 << leafLog2 the most a
+// leaf holds; the point comes from its owner's registers by ds_bpermute).  Survivors go to ring B as (lane, triangle);
+// whenever 64 are there the wave runs 64 closest-point tests at once and merges every result into its owner's best with ONE
+// 64-bit LDS atomic min on (distance bits << 32 | triangle): smallest distance, ties to the lower index -- the linear scan's
+// rule (Mesh.cpp:134-159), whatever the order.
 // Pruning works on bounds that are refreshed after every closest-point batch: a stale (looser) bound only adds pairs,
 // never drops one, so every lane still ends with exactly the triangle its own exhaustive scan finds.  The winner's closest
 // point and simplex are recomputed once at the end (same function, same bits).
+// Round 3: a child is wanted by a lane only if BOTH its box and its slab (NodeSlab: mesh_build.hip) come within the lane's
+// best distance.  A tilted patch of size H fills its box, so by the box alone a sample at distance D wants every patch within
+// ~sqrt(D H) of its foot point, at every level of the tree; the slab of a smooth patch is thin and leaves the patches within
+// ~H.  The per-lane descent that seeds the bounds follows the smaller of the two children's combined bounds and so ends in
+// the leaf under the sample (by boxes alone: a few triangles off, and everything in between passes the lower-bound test).
 struct MeshWaveLds {
-    unsigned long long best[64];
-    uint32_t aSlot[128];  // ring A: waiting for the lower-bound test
-    uint32_t bTri[128];   // ring B: waiting for the closest-point test
+    unsigned long long best[64];  // per lane: (squared distance bits << 32 | triangle) of the nearest triangle so far
+    float px[64], py[64], pz[64]; // per lane: its sample
+    float rj[64];                 // per lane: what a lower bound is compared with, rejectBound(best): refreshed with best
+    uint32_t aRef[128];           // ring A: (lane, leaf reference) waiting for the lower-bound tests of the leaf's slots
+    uint32_t bTri[128];           // ring B: (lane, triangle) waiting for the closest-point test
+    int32_t stack[kMeshStack];    // the walk's deferred siblings
     uint8_t aLane[128];
     uint8_t bLane[128];
-    int32_t stack[kMeshStack];
 };
+// lower bound of the squared distance from p to anything inside the slab |n . (x - g)| <= e cut by the ball |x - g| <= rho
+// (g = (g.xyz), rho = g.w, n = nh.xyz, e = nh.w): along n at least |n . (p - g)| - e, across it at least the distance of p
+// from the axis through g minus rho.  Raw v_sqrt_f32 (1 ulp): the caller's slack is four orders of magnitude wider.
+__device__ __forceinline__ float slabLowerBound2(V3 p, float4 g, float4 nh) {
+    const V3 dx = p - V3{g.x, g.y, g.z};
+    const float sd = dotF(V3{nh.x, nh.y, nh.z}, dx);
+    const float al = fmaxf(fabsf(sd) - nh.w, 0.0f);
+    const float off = fmaxf(__builtin_amdgcn_sqrtf(fmaxf(__builtin_fmaf(-sd, sd, dotF(dx, dx)), 0.0f)) - g.w, 0.0f);
+    return __builtin_fmaf(off, off, al * al);
+}
+__device__ __forceinline__ NodeSlab loadSlabUniform(const NodeSlab* base, int32_t idx) {
+    typedef const __attribute__((address_space(4))) uint32_t* ConstWords;
+    const ConstWords w = (ConstWords)(uintptr_t)(base + idx);
+    NodeSlab s;
+    s.g0 = make_float4(__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3]));
+    s.n0 = make_float4(__uint_as_float(w[4]), __uint_as_float(w[5]), __uint_as_float(w[6]), __uint_as_float(w[7]));
+    s.g1 = make_float4(__uint_as_float(w[8]), __uint_as_float(w[9]), __uint_as_float(w[10]), __uint_as_float(w[11]));
+    s.n1 = make_float4(__uint_as_float(w[12]), __uint_as_float(w[13]), __uint_as_float(w[14]), __uint_as_float(w[15]));
+    return s;
+}
 __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool active, MeshWaveLds& L) {
     const int lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
-    float bound = __builtin_inff();  // what a box distance is compared with: best * 1.00001f + 1e-30f
-    float reject = __builtin_inff(); // what a lower bound is compared with: (sqrt(best) + slack)^2
     L.best[lane] = ((unsigned long long)__float_as_uint(FLT_MAX) << 32) | 0xFFFFFFFFull;
+    L.px[lane] = pt.x, L.py[lane] = pt.y, L.pz[lane] = pt.z;
     uint32_t aHead = 0, aCount = 0, bHead = 0, bCount = 0;  // wave-uniform
+    float bound = __builtin_inff();   // what a box distance is compared with: best * 1.00001f + 1e-30f
+    float reject = __builtin_inff();  // what a lower bound is compared with: rejectBound(best)
+    const uint32_t lg = m.leafLog2, perBatch = 64u >> lg;               // pairs of ring A one lower-bound batch takes
+    const bool slabs = m.slabs != nullptr;
+    const float inf = __builtin_inff();
 #ifdef HPSDF_MESH_STATS_BUILD
-    unsigned nVisits = 0, nBound = 0, nClosest = 0;  // [1] nodes, [2] pairs through the lower-bound test, [3] through the closest-point test
+    unsigned nVisits = 0, nBound = 0, nClosest = 0;  // [1] nodes visited, [2] pairs through the lower-bound test, [3] through the closest-point test
+    unsigned nPairs = 0, nBoundBatches = 0, nClosestBatches = 0, nSeedExact = 0;  // [4] (lane, leaf) pairs, [5] [6] batches, [7] lanes whose seed was the answer
+    float seedBest = 0.0f;
 #endif
-    BvhNode n = loadNodeUniform(m.bvh, 0);
-    const float slack = meshSlack(n);
+    const float slack = meshSlack(loadNodeUniform(m.bvh, 0));
+    // the owner's sample and bounds as the batches see them: always the latest best (the closest-point batches write it)
+    auto ownerPoint = [&](int o) { return V3{L.px[o], L.py[o], L.pz[o]}; };
+    auto ownerBest = [&](int o) { return __uint_as_float((uint32_t)(L.best[o] >> 32)); };
     auto closestBatch = [&](uint32_t cnt) {  // the first cnt (<= 64) pairs of ring B
         const bool on = (uint32_t)lane < cnt;
         const uint32_t at = (bHead + (uint32_t)lane) & 127u;
         const uint32_t t = on ? L.bTri[at] : 0u;
         const int src = on ? (int)L.bLane[at] : lane;
-        const V3 p = {__shfl(pt.x, src, 64), __shfl(pt.y, src, 64), __shfl(pt.z, src, 64)};
+        const V3 p = ownerPoint(src);
         if (on) {
             V3 q;
             const float4 tp[3] = {m.triPos[3 * (size_t)t], m.triPos[3 * (size_t)t + 1], m.triPos[3 * (size_t)t + 2]};
@@ -423,22 +472,26 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool active, M
             atomicMin(&L.best[src], ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)t);
         }
         __builtin_amdgcn_wave_barrier();
-        const float best = __uint_as_float((uint32_t)(L.best[lane] >> 32));
+        const float best = ownerBest(lane);
         bound = best * 1.00001f + 1e-30f;
         reject = rejectBound(best, slack);
+        L.rj[lane] = reject;
         bHead = (bHead + cnt) & 127u;
         bCount -= cnt;
 #ifdef HPSDF_MESH_STATS_BUILD
-        nClosest += cnt;
+        nClosest += cnt, ++nClosestBatches;
 #endif
     };
-    auto boundBatch = [&](uint32_t cnt) {  // the first cnt (<= 64) pairs of ring A; ring B holds < 64 on entry
-        const bool on = (uint32_t)lane < cnt;
-        const uint32_t at = (aHead + (uint32_t)lane) & 127u;
-        const uint32_t slot = on ? L.aSlot[at] : 0u;
-        const int src = on ? (int)L.aLane[at] : lane;
-        const V3 p = {__shfl(pt.x, src, 64), __shfl(pt.y, src, 64), __shfl(pt.z, src, 64)};
-        const float rj = __shfl(reject, src, 64);
+    auto boundBatch = [&](uint32_t pairs) {  // the first `pairs` (<= perBatch) pairs of ring A; ring B holds < 64 on entry
+        const uint32_t e = (uint32_t)lane >> lg, k = (uint32_t)lane & ((1u << lg) - 1u);
+        const uint32_t at = (aHead + e) & 127u;
+        const bool have = e < pairs;
+        const int32_t ref = have ? (int32_t)L.aRef[at] : -1;
+        const int src = have ? (int)L.aLane[at] : lane;
+        const bool on = have && k < leafCount(ref);
+        const uint32_t slot = leafFirst(ref) + k;
+        const V3 p = ownerPoint(src);
+        const float rj = L.rj[src];
         bool pass = false;
         uint32_t tri = 0u;
         if (on) {
@@ -453,99 +506,218 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool active, M
             L.bLane[pos] = (uint8_t)src;
         }
         bCount += (uint32_t)__popcll(pb);
-        aHead = (aHead + cnt) & 127u;
-        aCount -= cnt;
+        aHead = (aHead + pairs) & 127u;
+        aCount -= pairs;
 #ifdef HPSDF_MESH_STATS_BUILD
-        nBound += cnt;
+        nBound += (unsigned)__popcll(__ballot(on)), ++nBoundBatches;
 #endif
         __builtin_amdgcn_wave_barrier();
         while (bCount >= 64) closestBatch(64);
     };
-    auto boxDist = [&](const float* lo, const float* hi) {  // clamp = median of (p, lo, hi): lo <= hi in every box
-        const float cx = __builtin_amdgcn_fmed3f(pt.x, lo[0], hi[0]);
-        const float cy = __builtin_amdgcn_fmed3f(pt.y, lo[1], hi[1]);
-        const float cz = __builtin_amdgcn_fmed3f(pt.z, lo[2], hi[2]);
-        return sqnorm(pt - V3{cx, cy, cz});
+    auto boxDist6 = [&](V3 p, float lx, float ly, float lz, float hx, float hy, float hz) {  // clamp = median of (p, lo, hi): lo <= hi in every box
+        const float cx = __builtin_amdgcn_fmed3f(p.x, lx, hx);
+        const float cy = __builtin_amdgcn_fmed3f(p.y, ly, hy);
+        const float cz = __builtin_amdgcn_fmed3f(p.z, lz, hz);
+        const V3 dd = p - V3{cx, cy, cz};
+        return dotF(dd, dd);
     };
-    auto worthIt = [&](float d) { return active && !(d > bound); };
-    auto enqueueLeaf = [&](unsigned long long b, bool w, int32_t c) {  // ring A holds < 64 on entry and on exit
-        const uint32_t first = leafFirst(c), cnt = leafCount(c), nb = (uint32_t)__popcll(b);
-        const uint32_t mine = (uint32_t)__popcll(b & below);
-        for (uint32_t k = 0; k < cnt; ++k) {
-            if (w) {
-                const uint32_t pos = (aHead + aCount + mine) & 127u;
-                L.aSlot[pos] = first + k;
-                L.aLane[pos] = (uint8_t)lane;
-            }
-            aCount += nb;
-            __builtin_amdgcn_wave_barrier();
-            if (aCount >= 64) boundBatch(64);
-        }
-    };
-    // Every lane first walks down to ONE leaf of its own, nearer child first, and tests its triangles: a bound within a
-    // triangle's size of the final distance before the shared traversal starts.  (Seeded from the first leaf the wave
-    // meets instead, the 64 samples -- spread over several triangle sizes -- start with bounds as loose as their spread
-    // and nine tenths of everything they queue passes the lower-bound test.)
-    if (active) {
-        int32_t c = 0;
-        do {
-            const BvhNode nd = m.bvh[c];
-            c = boxDist(nd.lo1, nd.hi1) < boxDist(nd.lo0, nd.hi0) ? nd.c1 : nd.c0;
-        } while (c >= 0);
-        float best = FLT_MAX;
-        uint32_t bestTri = 0xFFFFFFFFu;
-        for (uint32_t k = 0, first = leafFirst(c), cnt = leafCount(c); k < cnt; ++k) {
-            const uint32_t t = slotTriangle(m, first + k);
+#define HPSDF_BOX0(p, nd) boxDist6(p, (nd).lo0[0], (nd).lo0[1], (nd).lo0[2], (nd).hi0[0], (nd).hi0[1], (nd).hi0[2])
+#define HPSDF_BOX1(p, nd) boxDist6(p, (nd).lo1[0], (nd).lo1[1], (nd).lo1[2], (nd).hi1[0], (nd).hi1[1], (nd).hi1[2])
+    // Seeds.  Everything the walk below queues for a lane is what lies within the lane's best distance so far, and a best
+    // that is off by a fraction f of the distance D admits everything within sqrt(2 f) D of the foot point: 1 % is already
+    // 0.14 D, a dozen triangles across on a fine mesh.  So before anything is queued every lane gets a best distance that is
+    // the final one for most samples, in three steps (HPSDF_MESH_STATS_BUILD counts how many):
+    //   1. it walks down to ONE leaf of its own, towards the child whose centre is nearer (lower bounds decide badly here:
+    //      a sample sits inside both children's balls and slabs half of the time, and then their tilt decides), and tests
+    //      the leaf's triangles, the one with the smallest lower bound first, the others only if their bound allows;
+    //   2. it tries the triangles its six neighbours in the wave's 4 x 4 x 4 block of samples ended with, if their lower
+    //      bound allows, nearest bound first (a descent that took a wrong turn high up ends several leaves away; the
+    //      neighbouring sample's, three triangles further on, most likely did not) -- twice;
+    //   3. it walks over the mesh: while the closest point lies on an edge (or corner) of its triangle, the triangle across
+    //      that edge is tried -- the distance falls with every step, and the walk ends on the foot point's triangle unless
+    //      the surface folds in between.
+    // None of this has to be right: the walk below finds whatever is nearer.
+#ifndef HPSDF_SEED_EXCHANGE
+#define HPSDF_SEED_EXCHANGE 2
+#endif
+#ifndef HPSDF_SEED_WALK
+#define HPSDF_SEED_WALK 6
+#endif
+    {
+        float best = FLT_MAX, rj = inf;
+        uint32_t bestTri = 0xFFFFFFFFu, bestSlot = 0xFFFFFFFFu;
+        int bestCode = 8;
+        auto tryTriangle = [&](uint32_t t, uint32_t slot) {
             V3 q;
             const float4 tp[3] = {m.triPos[3 * (size_t)t], m.triPos[3 * (size_t)t + 1], m.triPos[3 * (size_t)t + 2]};
-            closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, q);
+            const int code = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, q);
             const float d = sqnorm(pt - q);
-            if (d < best || (d == best && t < bestTri)) best = d, bestTri = t;
+            const bool better = d < best || (d == best && t < bestTri);
+            if (better) best = d, bestTri = t, bestSlot = slot, bestCode = code, rj = rejectBound(d, slack);
+            return better;
+        };
+        if (active) {
+            int32_t c = 0;
+            do {
+                const BvhNode nd = m.bvh[c];
+                bool second;
+                if (slabs) {
+                    const NodeSlab ns = m.slabs[c];
+                    second = sqnorm(pt - V3{ns.g1.x, ns.g1.y, ns.g1.z}) < sqnorm(pt - V3{ns.g0.x, ns.g0.y, ns.g0.z});
+                } else {
+                    second = HPSDF_BOX1(pt, nd) < HPSDF_BOX0(pt, nd);
+                }
+                c = second ? nd.c1 : nd.c0;
+            } while (c >= 0);
+            const uint32_t first = leafFirst(c), cnt = leafCount(c);
+            uint32_t kMin = 0;
+            float lbMin = inf;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                const float lb = triLowerBound2(pt, m.triPre[2 * (size_t)(first + k)], m.triPre[2 * (size_t)(first + k) + 1]);
+                if (lb < lbMin) lbMin = lb, kMin = k;
+            }
+            for (uint32_t kk = 0; kk < cnt; ++kk) {  // kMin first, then the others in slot order
+                const uint32_t k = kk == 0 ? kMin : (kk <= kMin ? kk - 1 : kk);
+                const float4 g = m.triPre[2 * (size_t)(first + k)], nh = m.triPre[2 * (size_t)(first + k) + 1];
+                if (kk != 0 && triLowerBound2(pt, g, nh) > rj) continue;
+                tryTriangle(__float_as_uint(nh.w), first + k);
+            }
         }
-        L.best[lane] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)bestTri;
-        bound = best * 1.00001f + 1e-30f;
-        reject = rejectBound(best, slack);
+        for (int pass = 0; pass < HPSDF_SEED_EXCHANGE; ++pass) {
+            uint32_t candSlot = 0xFFFFFFFFu, candTri = 0u;
+            float candLb = inf;
+#pragma unroll
+            for (int nb = 0; nb < 6; ++nb) {
+                const int off = nb < 2 ? 1 : (nb < 4 ? 4 : 16);
+                const int src = (lane + ((nb & 1) ? off : 64 - off)) & 63;
+                const uint32_t slot = (uint32_t)__shfl((int)bestSlot, src, 64);
+                if (active && slot != 0xFFFFFFFFu && slot != bestSlot) {
+                    const float4 g = m.triPre[2 * (size_t)slot], nh = m.triPre[2 * (size_t)slot + 1];
+                    const float lb = triLowerBound2(pt, g, nh);
+                    if (lb < candLb && !(lb > rj)) candLb = lb, candSlot = slot, candTri = __float_as_uint(nh.w);
+                }
+            }
+            if (candSlot != 0xFFFFFFFFu) tryTriangle(candTri, candSlot);
+        }
+        {
+            // (one triangle per lane and step: at a corner the edge that starts there first, and if that does not help the
+            // edge that ends there in the next step)
+            bool moving = active;
+            int second = -1;  // the other edge of a corner whose first edge did not help
+            for (int step = 0; step < HPSDF_SEED_WALK && __ballot(moving) != 0ull; ++step) {
+                if (moving) {
+                    int e = second;
+                    second = -1;
+                    if (e < 0 && bestCode != 8) {
+                        e = bestCode >= 4 ? bestCode - 4 : bestCode;
+                        if (bestCode < 4) second = (bestCode + 2) % 3;
+                    }
+                    moving = false;
+                    if (e >= 0) {
+                        const uint32_t t = m.halfEdges[3 * bestTri + (uint32_t)e] / 3u;
+                        if (tryTriangle(t, 0xFFFFFFFFu))
+                            moving = true, second = -1;
+                        else
+                            moving = second >= 0;
+                    }
+                }
+            }
+        }
+        if (active) {
+            L.best[lane] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)bestTri;
+            bound = best * 1.00001f + 1e-30f;
+            reject = rj;
+        }
+        L.rj[lane] = reject;
+#ifdef HPSDF_MESH_STATS_BUILD
+        seedBest = best;
+#endif
     }
     __builtin_amdgcn_wave_barrier();
-    int sp = 0;  // wave-uniform
-    for (;;) {
+    // The walk: the wave visits a node if any lane still wants it, every lane against its own bound.  (Every (lane, node)
+    // pair as a work item of its own, 64 pairs from a pool in LDS per batch with per-lane node fetches, was tried in round 3:
+    // a lane wants ~170 nodes, 30 lanes share a node on average, so the pool moved 1.4 MB of nodes per wave through the
+    // vector memory path where this walk moves 45 KB through the scalar cache -- 10.1 against 7.1 ms.)
+    {
+        BvhNode n = loadNodeUniform(m.bvh, 0);
+        NodeSlab sl{};
+        if (slabs) sl = loadSlabUniform(m.slabs, 0);
+        int sp = 0;  // wave-uniform
+        for (;;) {
 #ifdef HPSDF_MESH_STATS_BUILD
-        ++nVisits;
+            ++nVisits;
 #endif
-        const float d0 = boxDist(n.lo0, n.hi0), d1 = boxDist(n.lo1, n.hi1);
-        const bool w0 = worthIt(d0), w1 = worthIt(d1);
-        const unsigned long long b0 = __ballot(w0), b1 = __ballot(w1);
-        const int32_t c0 = n.c0, c1 = n.c1;
-        int32_t next = -1;
-        const bool push0 = c0 >= 0 && b0 != 0ull, push1 = c1 >= 0 && b1 != 0ull;
-        if (push0 && push1) {
-            // the one that is nearer for the first lane that wants child 0 goes first, its sibling waits on the stack
-            const int l0 = __ffsll((long long)b0) - 1;
-            const float a0 = __shfl(d0, l0, 64), a1 = __shfl(d1, l0, 64);
-            const bool firstIs1 = __builtin_amdgcn_readfirstlane((int)(a1 < a0)) != 0;
-            next = firstIs1 ? c1 : c0;
-            if (sp < kMeshStack) {
-                if (lane == 0) L.stack[sp] = firstIs1 ? c0 : c1;
-                ++sp;
+            const float d0 = HPSDF_BOX0(pt, n), d1 = HPSDF_BOX1(pt, n);
+            bool w0 = active && !(d0 > bound), w1 = active && !(d1 > bound);
+            if (slabs) {  // (wave-uniform conditions: the slab came through the scalar cache)
+                if (sl.n0.w >= 0.0f && __ballot(w0) != 0ull) w0 = w0 && !(slabLowerBound2(pt, sl.g0, sl.n0) > reject);
+                if (sl.n1.w >= 0.0f && __ballot(w1) != 0ull) w1 = w1 && !(slabLowerBound2(pt, sl.g1, sl.n1) > reject);
             }
-        } else if (push0 || push1) {
-            next = push0 ? c0 : c1;
-        } else if (sp > 0) {
-            --sp;
-            next = __builtin_amdgcn_readfirstlane(L.stack[sp]);
-        }
-        const BvhNode nn = loadNodeUniform(m.bvh, __builtin_amdgcn_readfirstlane(next >= 0 ? next : 0));  // (the root again when the walk is over: never used)
-        if (c0 < 0 && b0 != 0ull) enqueueLeaf(b0, w0, c0);
-        if (c1 < 0 && b1 != 0ull) enqueueLeaf(b1, w1, c1);
-        if (next < 0 || (nn.pad[0] & nn.pad[1]) == 0xFFFFFFFFu) break;
-        n = nn;
-    }
-    if (aCount) boundBatch(aCount);
-    if (bCount) closestBatch(bCount);
+            const unsigned long long b0 = __ballot(w0), b1 = __ballot(w1);
+            const int32_t c0 = n.c0, c1 = n.c1;
+            int32_t next = -1;
+            const bool push0 = c0 >= 0 && b0 != 0ull, push1 = c1 >= 0 && b1 != 0ull;
+            if (push0 && push1) {
+                // the one that is nearer for the first lane that wants child 0 goes first, its sibling waits on the stack
+                const int l0 = __ffsll((long long)b0) - 1;
+                const float a0 = __shfl(d0, l0, 64), a1 = __shfl(d1, l0, 64);
+                const bool firstIs1 = __builtin_amdgcn_readfirstlane((int)(a1 < a0)) != 0;
+                next = firstIs1 ? c1 : c0;
+                if (sp < kMeshStack) {
+                    if (lane == 0) L.stack[sp] = firstIs1 ? c0 : c1;
+                    ++sp;
+                }
+            } else if (push0 || push1) {
+                next = push0 ? c0 : c1;
+            } else if (sp > 0) {
+                --sp;
+                next = __builtin_amdgcn_readfirstlane(L.stack[sp]);
+            }
+            // the next node's 128 bytes are asked for before this node's leaves are queued and tested
+            const int32_t nextIdx = __builtin_amdgcn_readfirstlane(next >= 0 ? next : 0);  // (the root again when the walk is over: never used)
+            const BvhNode nn = loadNodeUniform(m.bvh, nextIdx);
+            NodeSlab sn{};
+            if (slabs) sn = loadSlabUniform(m.slabs, nextIdx);
+            for (int side = 0; side < 2; ++side) {  // leaves: one (lane, leaf) pair per lane that wants it
+                const int32_t c = side ? c1 : c0;
+                const unsigned long long b = side ? b1 : b0;
+                if (c >= 0 || b == 0ull) continue;
+                if (side ? w1 : w0) {
+                    const uint32_t pos = (aHead + aCount + (uint32_t)__popcll(b & below)) & 127u;
+                    L.aRef[pos] = (uint32_t)c;
+                    L.aLane[pos] = (uint8_t)lane;
+                }
+                aCount += (uint32_t)__popcll(b);
 #ifdef HPSDF_MESH_STATS_BUILD
+                nPairs += (unsigned)__popcll(b);
+#endif
+                __builtin_amdgcn_wave_barrier();
+                while (aCount >= perBatch) boundBatch(perBatch);
+            }
+            // (the test on the two padding words, always zero, keeps all sixteen dwords of the prefetch live across the
+            // leaf tests: with them dead the register allocator reuses their SGPRs at once and waits for the load right here)
+            if (next < 0 || (nn.pad[0] & nn.pad[1]) == 0xFFFFFFFFu) break;
+            n = nn;
+            sl = sn;
+        }
+        while (aCount) boundBatch(aCount < perBatch ? aCount : perBatch);
+        if (bCount) closestBatch(bCount);
+    }
+#ifdef HPSDF_MESH_STATS_BUILD
+    nSeedExact = (unsigned)__popcll(__ballot(active && seedBest == ownerBest(lane)));
+#ifdef HPSDF_MESH_SEED_STATS  // how far off the seeds are: [5] within 1e-4 of the final distance, [6] within 1e-2, [4] within 10 %
+    {
+        const float rs = sqrtf(seedBest), rf = sqrtf(ownerBest(lane));
+        nBoundBatches = (unsigned)__popcll(__ballot(active && rs <= rf * 1.0001f));
+        nClosestBatches = (unsigned)__popcll(__ballot(active && rs <= rf * 1.01f));
+        nPairs = (unsigned)__popcll(__ballot(active && rs <= rf * 1.1f));
+    }
+#endif
     if (m.stats && lane == 0) {
         atomicAdd(m.stats + 0, 1ull), atomicAdd(m.stats + 1, (unsigned long long)nVisits);
         atomicAdd(m.stats + 2, (unsigned long long)nBound), atomicAdd(m.stats + 3, (unsigned long long)nClosest);
+        atomicAdd(m.stats + 4, (unsigned long long)nPairs), atomicAdd(m.stats + 5, (unsigned long long)nBoundBatches);
+        atomicAdd(m.stats + 6, (unsigned long long)nClosestBatches), atomicAdd(m.stats + 7, (unsigned long long)nSeedExact);
     }
 #endif
     float r = 0.0f;
@@ -561,6 +733,8 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool active, M
     }
     return r;
 }
+#undef HPSDF_BOX0
+#undef HPSDF_BOX1
 
 // ---------------------------------------------------------------------------
 // tree evaluation: Octree::Query (Octree.cpp:662-702) and FApprox (:859-901)
@@ -2071,12 +2245,12 @@ __global__ __launch_bounds__(256) void mesh_tripos_kernel(const float* __restric
 }
 
 // MeshDev::triPre: per leaf slot the data of the lower-bound test (meshSignedDistanceWaveQ) and the triangle's index.
-// g = the centroid (any point near the triangle's plane would do), nh = the unit normal, rho = the largest distance of a
+// g = the centre of the triangle's smallest circle (any point near its plane would do), nh = the unit normal, rho = the largest distance of a
 // vertex from g, widened by its rounding.  The bound is valid for ANY unit nh as long as the vertices lie within e of the
-// plane through g across nh; e is measured here (the centroid is off the plane by the rounding of its coordinates), and when
+// plane through g across nh; e is measured here (g is off the plane by the rounding of its coordinates), and when
 // it is not negligible (slivers, whose cross product cancels) nh is set to zero, which turns the test into the plain sphere
-// bound |p - g| - rho.  What is left of e (<= 2e-6 of the mesh's scale) and of |nh| - 1 is covered by the caller's slack
-// (2e-5 of that scale).
+// bound |p - g| - rho.  What is left of e (<= 4e-7 of the mesh's scale) and of |nh| - 1 is covered by the caller's slack
+// (2e-6 of that scale: meshSlack).
 __global__ __launch_bounds__(256) void mesh_tripre_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ tris,
                                                           const uint32_t* __restrict__ slotTri, uint64_t nTris, float4* __restrict__ triPre) {
     const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -2086,19 +2260,37 @@ __global__ __launch_bounds__(256) void mesh_tripre_kernel(const float* __restric
     const V3 a = {verts[3 * (size_t)ia], verts[3 * (size_t)ia + 1], verts[3 * (size_t)ia + 2]};
     const V3 b = {verts[3 * (size_t)ib], verts[3 * (size_t)ib + 1], verts[3 * (size_t)ib + 2]};
     const V3 c = {verts[3 * (size_t)ic], verts[3 * (size_t)ic + 1], verts[3 * (size_t)ic + 2]};
+    // g: the centre of the smallest circle around the triangle -- the middle of the longest edge if the angle across it is
+    // not acute, else the circumcentre (for the right triangles of a quad grid 0.75 of the centroid's radius) -- or the
+    // centroid when that is not finite.  Any g will do: rho and the distance of the vertices from the plane are MEASURED below.
+    const V3 ab = b - a, ac = c - a, bc = c - b;
+    const float lab = sqnorm(ab), lac = sqnorm(ac), lbc = sqnorm(bc);
+    const V3 n = cross(ab, ac);
+    V3 g;
+    if (lab >= lac && lab >= lbc && dot(a - c, b - c) <= 0.0f)
+        g = 0.5f * (a + b);
+    else if (lac >= lab && lac >= lbc && dot(a - b, c - b) <= 0.0f)
+        g = 0.5f * (a + c);
+    else if (lbc >= lab && lbc >= lac && dot(ab, ac) <= 0.0f)
+        g = 0.5f * (b + c);
+    else {
+        const float nn = 2.0f * sqnorm(n);
+        g = a + (1.0f / nn) * (lac * cross(n, ab) + lab * cross(ac, n));
+    }
     const float third = 1.0f / 3.0f;
-    const V3 g = third * (a + (b + c));
+    const V3 cen = third * (a + (b + c));
+    const float rc = fmaxf(sqnorm(a - cen), fmaxf(sqnorm(b - cen), sqnorm(c - cen)));
+    if (!(fmaxf(sqnorm(a - g), fmaxf(sqnorm(b - g), sqnorm(c - g))) <= rc)) g = cen;  // (also when g is not finite)
     const float rho = sqrtf(fmaxf(sqnorm(a - g), fmaxf(sqnorm(b - g), sqnorm(c - g)))) * 1.00001f + 1e-30f;
     // the scale the caller's slack is proportional to is at least this (the mesh's extent or its largest coordinate)
     const float scale = fmaxf(rho, fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fabsf(g.z)));
-    const V3 n = cross(b - a, c - a);
     const float len = sqrtf(sqnorm(n));
     V3 nh = {0.0f, 0.0f, 0.0f};
     if (len > 0.0f && len < __builtin_inff()) {
         nh = (1.0f / len) * n;
         const float e = fmaxf(fabsf(dot(nh, a - g)), fmaxf(fabsf(dot(nh, b - g)), fabsf(dot(nh, c - g))));
         const float unit = fabsf(sqnorm(nh) - 1.0f);
-        if (!(e <= 2e-6f * scale) || !(unit <= 1e-5f)) nh = V3{0.0f, 0.0f, 0.0f};
+        if (!(e <= 4e-7f * scale) || !(unit <= 1e-6f)) nh = V3{0.0f, 0.0f, 0.0f};
     }
     if (!(rho < __builtin_inff())) nh = V3{0.0f, 0.0f, 0.0f};  // (non-finite input: the bound degenerates to "always passes" via NaN)
     triPre[2 * s] = make_float4(g.x, g.y, g.z, rho);

@@ -130,7 +130,8 @@ __device__ __forceinline__ int mbDelta(const uint64_t* __restrict__ keys, int n,
 
 // inner node i of n - 1: its range of sorted leaves and its split
 __global__ __launch_bounds__(256) void mb_hierarchy_kernel(const uint64_t* __restrict__ keys, int n, int leafTris,
-                                                           BvhNode* __restrict__ nodes, int32_t* __restrict__ parent /* [2n - 1]: inner 0..n-2, leaves n-1.. */) {
+                                                           BvhNode* __restrict__ nodes, int32_t* __restrict__ parent /* [2n - 1]: inner 0..n-2, leaves n-1.. */,
+                                                           int32_t* __restrict__ ranges /* [3 (n - 1)]: first slot, split, last slot */) {
     const int i = (int)(blockIdx.x * 256u + threadIdx.x);
     if (i >= n - 1) return;
     const int d = mbDelta(keys, n, i, i + 1) - mbDelta(keys, n, i, i - 1) >= 0 ? 1 : -1;
@@ -157,6 +158,7 @@ __global__ __launch_bounds__(256) void mb_hierarchy_kernel(const uint64_t* __res
     nd.c0 = n0 <= leafTris ? ~(int32_t)(((uint32_t)lo << kMeshLeafShift) | (uint32_t)(n0 - 1)) : gamma;
     nd.c1 = n1 <= leafTris ? ~(int32_t)(((uint32_t)(gamma + 1) << kMeshLeafShift) | (uint32_t)(n1 - 1)) : gamma + 1;
     nd.pad[0] = nd.pad[1] = 0;
+    ranges[3 * (size_t)i] = lo, ranges[3 * (size_t)i + 1] = gamma, ranges[3 * (size_t)i + 2] = hi;
     parent[leaf0 ? (n - 1) + gamma : gamma] = i * 2;          // (child slot in the low bit)
     parent[leaf1 ? (n - 1) + gamma + 1 : gamma + 1] = i * 2 + 1;
     if (i == 0) parent[0] = -1;
@@ -192,6 +194,96 @@ __global__ __launch_bounds__(256) void mb_fit_kernel(const uint32_t* __restrict_
             box.f[3 + a] = fmaxf(box.f[3 + a], sib.f[3 + a]);
         }
         p = parent[node];
+    }
+}
+
+// Slabs (NodeSlab, device_types.hpp): for every child of every node the traversal can visit, a unit vector n, a point g and
+// two radii such that every point x of the child's triangles has |n . (x - g)| <= e and |x - g| <= rho.  One wave per node;
+// a child's triangles are the sorted slots [a, b], read three times: the sum of the (area-weighted) normals gives n; the
+// range of n . (v - c) over the vertices, c the centre of the child's box, puts g in the middle of the slab; then e and rho
+// are measured against that very g with the arithmetic the traversal uses for its sample (n . (p - g), |p - g|), widened by
+// 1e-5 of themselves -- what rounding leaves open beyond that is a few ulps of the mesh's extent and belongs to the
+// traversal's slack (2e-5 of that extent, meshSlack).  The bound is valid for ANY n of unit length: how n was chosen only
+// decides how thin the slab is (a patch that bends back on itself gets a thick one and is pruned by its ball and box alone).
+// Children of more than kSlabMaxTris triangles get the ball around their box and e = -1, "no slab": up there the boxes
+// decide, a wave would loop for too long, and a surface is rarely flat at that scale.
+constexpr int kSlabMaxTris = 2048;
+__device__ __forceinline__ float mbWaveSum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float mbWaveMax(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__global__ __launch_bounds__(256) void mb_slab_kernel(const int32_t* __restrict__ ranges, const uint32_t* __restrict__ slotTri,
+                                                      const float* __restrict__ triPos, int n, int leafTris, const BvhNode* __restrict__ nodes,
+                                                      NodeSlab* __restrict__ slabs) {
+    const int node = (int)(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (node >= n - 1) return;
+    const int lane = threadIdx.x & 63;
+    const int lo = ranges[3 * (size_t)node], gamma = ranges[3 * (size_t)node + 1], hi = ranges[3 * (size_t)node + 2];
+    if (node != 0 && hi - lo + 1 <= leafTris) return;  // below a leaf: nothing refers to this node (the root is always visited)
+    const BvhNode& nd = nodes[node];
+    const float inf = __builtin_inff();
+    for (int child = 0; child < 2; ++child) {
+        const int a = child ? gamma + 1 : lo, b = child ? hi : gamma;
+        const float* blo = child ? nd.lo1 : nd.lo0;
+        const float* bhi = child ? nd.hi1 : nd.hi0;
+        const float cx = 0.5f * (blo[0] + bhi[0]), cy = 0.5f * (blo[1] + bhi[1]), cz = 0.5f * (blo[2] + bhi[2]);
+        // (no slab: the ball around the box, and e = -1 tells the walk to leave the test out)
+        const float hx = 0.5f * (bhi[0] - blo[0]), hy = 0.5f * (bhi[1] - blo[1]), hz = 0.5f * (bhi[2] - blo[2]);
+        float4 og = make_float4(cx, cy, cz, sqrtf(hx * hx + (hy * hy + hz * hz)) * 1.00001f + 1e-30f), on = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+        if (b - a + 1 <= kSlabMaxTris) {
+            float nx = 0.0f, ny = 0.0f, nz = 0.0f;
+            for (int s = a + lane; s <= b; s += 64) {
+                const float* p = triPos + (size_t)kTriRecordFloats * slotTri[s];
+                nx += p[9], ny += p[10], nz += p[11];
+            }
+            nx = mbWaveSum(nx), ny = mbWaveSum(ny), nz = mbWaveSum(nz);
+            const float len = sqrtf(nx * nx + (ny * ny + nz * nz));
+            if (len > 0.0f && len < inf) {
+                nx /= len, ny /= len, nz /= len;
+                if (!(fabsf(nx * nx + (ny * ny + nz * nz) - 1.0f) <= 1e-6f)) nx = ny = nz = 0.0f;
+            } else {
+                nx = ny = nz = 0.0f;
+            }
+            float tmin = inf, tmax = -inf;
+            for (int s = a + lane; s <= b; s += 64) {
+                const float* p = triPos + (size_t)kTriRecordFloats * slotTri[s];
+                for (int v = 0; v < 3; ++v) {
+                    const float t = nx * (p[3 * v] - cx) + (ny * (p[3 * v + 1] - cy) + nz * (p[3 * v + 2] - cz));
+                    tmin = fminf(tmin, t), tmax = fmaxf(tmax, t);
+                }
+            }
+            tmin = -mbWaveMax(-tmin), tmax = mbWaveMax(tmax);
+            const float mid = 0.5f * (tmin + tmax);
+            const float gx = cx + mid * nx, gy = cy + mid * ny, gz = cz + mid * nz;
+            float e = 0.0f, r2 = 0.0f;
+            for (int s = a + lane; s <= b; s += 64) {
+                const float* p = triPos + (size_t)kTriRecordFloats * slotTri[s];
+                for (int v = 0; v < 3; ++v) {
+                    const float dx = p[3 * v] - gx, dy = p[3 * v + 1] - gy, dz = p[3 * v + 2] - gz;
+                    e = fmaxf(e, fabsf(nx * dx + (ny * dy + nz * dz)));
+                    r2 = fmaxf(r2, dx * dx + (dy * dy + dz * dz));
+                }
+            }
+            e = mbWaveMax(e), r2 = mbWaveMax(r2);
+            const float rho = sqrtf(r2) * 1.00001f + 1e-30f;
+            e = e * 1.00001f + 1e-30f;
+            if (rho < inf && e < inf && gx - gx == 0.0f && gy - gy == 0.0f && gz - gz == 0.0f) {  // (non-finite input: no bound)
+                og = make_float4(gx, gy, gz, rho);
+                on = make_float4(nx, ny, nz, e);
+            }
+        }
+        if (lane == 0) {
+            if (child)
+                slabs[node].g1 = og, slabs[node].n1 = on;
+            else
+                slabs[node].g0 = og, slabs[node].n0 = on;
+        }
     }
 }
 
@@ -261,6 +353,8 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
     int leafTris = 8;  // triangles per leaf (1..kMeshLeafMax); HPSDF_MESH_LEAF_TRIS overrides (experiments)
     if (const char* lt = std::getenv("HPSDF_MESH_LEAF_TRIS")) leafTris = std::atoi(lt);
     leafTris = leafTris < 1 ? 1 : (leafTris > (int)kMeshLeafMax ? (int)kMeshLeafMax : leafTris);
+    const char* ns = std::getenv("HPSDF_MESH_NO_SLABS");  // experiments: boxes only
+    const bool noSlabs = ns && ns[0] == '1';
     const uint64_t nCorners = 3 * nTris;
     const int n = (int)nTris;
     uint64_t* dTris64 = nullptr;
@@ -268,7 +362,7 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
     uint64_t *dKeys = nullptr, *dKeysOut = nullptr;
     uint32_t *dIds = nullptr, *dIdsOut = nullptr, *dArrived = nullptr, *dTabVal = nullptr;
     unsigned long long* dTabKey = nullptr;
-    int32_t* dParent = nullptr;
+    int32_t *dParent = nullptr, *dRanges = nullptr;
     MeshBuildFlags* dFlags = nullptr;
     void* dSortTmp = nullptr;
     size_t sortTmpBytes = 0;
@@ -289,12 +383,12 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
         const size_t oVerts = carve(fb, 3 * nVerts * sizeof(float)), oTris = carve(fb, nCorners * sizeof(uint32_t)),
                      oTriPos = carve(fb, (size_t)nTris * kTriRecordFloats * sizeof(float)),
                      oTriPre = carve(fb, (size_t)nTris * kTriPreFloats * sizeof(float)), oHe = carve(fb, nCorners * sizeof(uint32_t)),
-                     oBvh = carve(fb, (size_t)(n - 1) * sizeof(BvhNode));
+                     oBvh = carve(fb, (size_t)(n - 1) * sizeof(BvhNode)), oSlab = carve(fb, (size_t)(n - 1) * sizeof(NodeSlab));
         size_t tb = 0;
         const size_t oT64 = carve(tb, nCorners * sizeof(uint64_t)), oBox = carve(tb, 6 * nTris * sizeof(float)),
                      oK = carve(tb, nTris * sizeof(uint64_t)), oK2 = carve(tb, nTris * sizeof(uint64_t)), oI = carve(tb, nTris * sizeof(uint32_t)),
                      oI2 = carve(tb, nTris * sizeof(uint32_t)), oArr = carve(tb, nTris * sizeof(uint32_t)),
-                     oPar = carve(tb, 2 * nTris * sizeof(int32_t)), oTK = carve(tb, tabSize * sizeof(unsigned long long)),
+                     oPar = carve(tb, 2 * nTris * sizeof(int32_t)), oRan = carve(tb, 3 * nTris * sizeof(int32_t)), oTK = carve(tb, tabSize * sizeof(unsigned long long)),
                      oTV = carve(tb, tabSize * sizeof(uint32_t)), oFl = carve(tb, sizeof(MeshBuildFlags)),
                      oSort = carve(tb, sortTmpBytes ? sortTmpBytes : 16);
         if (e == hipSuccess) e = hipMalloc((void**)&fieldBlock, fb);
@@ -304,6 +398,8 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
             f->dVerts = (float*)(fieldBlock + oVerts), f->dTris = (uint32_t*)(fieldBlock + oTris), f->dTriPos = (float*)(fieldBlock + oTriPos);
             f->dTriPre = (float*)(fieldBlock + oTriPre);
             f->dHalfEdges = (uint32_t*)(fieldBlock + oHe), f->dBvh = (BvhNode*)(fieldBlock + oBvh);
+            f->dSlabs = (NodeSlab*)(fieldBlock + oSlab);
+            dRanges = (int32_t*)(tempBlock + oRan);
             dTris64 = (uint64_t*)(tempBlock + oT64), dTriBox = (float*)(tempBlock + oBox), dKeys = (uint64_t*)(tempBlock + oK);
             dKeysOut = (uint64_t*)(tempBlock + oK2), dIds = (uint32_t*)(tempBlock + oI), dIdsOut = (uint32_t*)(tempBlock + oI2);
             dArrived = (uint32_t*)(tempBlock + oArr), dParent = (int32_t*)(tempBlock + oPar), dTabKey = (unsigned long long*)(tempBlock + oTK);
@@ -319,6 +415,7 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
         fieldBlock = nullptr;
         f->dBlock = nullptr;
         f->dVerts = nullptr, f->dTris = nullptr, f->dTriPos = nullptr, f->dTriPre = nullptr, f->dHalfEdges = nullptr, f->dBvh = nullptr;
+        f->dSlabs = nullptr;
     };
     const double t1 = now();
     if (e == hipSuccess) e = hipMemcpyAsync(f->dVerts, verts, 3 * nVerts * sizeof(float), hipMemcpyHostToDevice, s);
@@ -343,8 +440,11 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
     hipLaunchKernelGGL(mb_morton_kernel, dim3(gt), dim3(256), 0, s, dTriBox, (uint32_t)nTris, dFlags, dKeys, dIds);
     if (e == hipSuccess) e = rocprim::radix_sort_pairs(dSortTmp, sortTmpBytes, dKeys, dKeysOut, dIds, dIdsOut, (size_t)nTris, 0, 63, s);
     if (e == hipSuccess) e = launchMeshTriPos(s, f->dVerts, f->dTris, nTris, nullptr, dIdsOut, f->dTriPre);  // slot order = sorted order
-    hipLaunchKernelGGL(mb_hierarchy_kernel, dim3(gt), dim3(256), 0, s, dKeysOut, n, leafTris, f->dBvh, dParent);
+    hipLaunchKernelGGL(mb_hierarchy_kernel, dim3(gt), dim3(256), 0, s, dKeysOut, n, leafTris, f->dBvh, dParent, dRanges);
     hipLaunchKernelGGL(mb_fit_kernel, dim3(gt), dim3(256), 0, s, dIdsOut, dTriBox, n, f->dBvh, dParent, dArrived);
+    if (!noSlabs)
+        hipLaunchKernelGGL(mb_slab_kernel, dim3((unsigned)((n - 1 + 3) / 4)), dim3(256), 0, s, dRanges, dIdsOut, f->dTriPos, n, leafTris, f->dBvh,
+                           f->dSlabs);
     hipLaunchKernelGGL(mb_edges_insert_kernel, dim3(gc), dim3(256), 0, s, f->dTris, nCorners, dTabKey, dTabVal, tabSize - 1, dFlags);
     hipLaunchKernelGGL(mb_edges_lookup_kernel, dim3(gc), dim3(256), 0, s, f->dTris, nCorners, dTabKey, dTabVal, tabSize - 1, f->dHalfEdges, dFlags);
     if (e == hipSuccess) e = hipGetLastError();
@@ -376,6 +476,9 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
     f->nVerts = (uint32_t)nVerts;
     f->nTris = (uint32_t)nTris;
     f->nBvhNodes = (uint32_t)(nTris - 1);
+    if (noSlabs) f->dSlabs = nullptr;
+    f->leafLog2 = 0;
+    while ((1 << f->leafLog2) < leafTris) ++f->leafLog2;
     return HPSDF_OK;
 }
 

@@ -126,6 +126,8 @@ struct hpsdf_field {
     float* dTriPre = nullptr;
     uint32_t* dHalfEdges = nullptr;
     hpsdf::BvhNode* dBvh = nullptr;
+    hpsdf::NodeSlab* dSlabs = nullptr;  // device-built meshes only (part of dBlock)
+    uint32_t leafLog2 = 0;              // leaves hold at most 1 << leafLog2 triangles
     uint32_t nTris = 0, nVerts = 0, nBvhNodes = 0;
     unsigned long long* dStats = nullptr;  // 4 counters, only under HPSDF_MESH_STATS=1
     // csg wrapper

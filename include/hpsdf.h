@@ -168,8 +168,10 @@ HPSDF_API int hpsdf_field_eval_wave_host(hpsdf_ctx* ctx, const hpsdf_field* f, c
 /* Diagnostics (no reference counterpart; HPSDF_ERR_UNSUPPORTED unless the library was built with
  * -DHPSDF_MESH_STATS_BUILD): BVH traversal counters of a mesh field created while the environment
  * variable HPSDF_MESH_STATS was set -- out[0] wave-wide closest-triangle queries (64 points each), [1] BVH nodes they visited,
- * [2] (point, triangle) pairs that went through the lower-bound test, [3] pairs that went on to the closest-point test.  Synchronises the device; reset != 0 zeroes the counters. */
-HPSDF_API int hpsdf_field_mesh_stats(const hpsdf_field* f, uint64_t out[4], int reset);
+ * [2] (point, triangle) pairs that went through the lower-bound test, [3] pairs that went on to the closest-point test,
+ * [4] (point, leaf) pairs queued, [5] wave-wide batches of lower-bound tests, [6] of closest-point tests, [7] points whose
+ * seed (the leaf their own descent ended in) already held the answer.  Synchronises the device; reset != 0 zeroes the counters. */
+HPSDF_API int hpsdf_field_mesh_stats(const hpsdf_field* f, uint64_t out[8], int reset);
 
 /* ---- Query: Octree::FromMemoryBlock + Octree::Query (Octree.cpp:403-421, 662-702, 859-901) */
 /* block layout: [u64 nCoeffs][f64 x nCoeffs][u64 nNodes][hpsdf_node x nNodes][hpsdf_config] */

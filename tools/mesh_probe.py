@@ -33,6 +33,8 @@ for level in (a for a in sys.argv[1:] or ["5", "7", "8"]):
         print("   traversal: %d wave queries; per query of 64 samples: %.0f nodes visited, %.0f (lane, triangle) pairs through the "
               "lower-bound test, %.0f through the closest-point test"
               % (q, ms["node_visits"] / q, ms["tri_tests"] / q, ms["tri_test_lanes"] / q))
+        print("              %.0f (lane, leaf) pairs queued, %.0f lower-bound batches, %.0f closest-point batches, %.1f of 64 seeds already the answer"
+              % (ms["leaf_pairs"] / q, ms["bound_batches"] / q, ms["closest_batches"] / q, ms["seed_exact"] / q))
     for tgt in [float(x) for x in os.environ.get("MESH_PROBE_TARGETS", "").split(",") if x]:  # e.g. MESH_PROBE_TARGETS=1e-6,1e-7
         c2 = H.make_config(tgt, tuple(lo), tuple(hi))
         H.create_block(ctx, c2, f, 1024)
