@@ -76,6 +76,10 @@ int makeFieldDev(const hpsdf_field* f, const double* dSamples, FieldDev* out) {
             out->mesh.bvh = f->dBvh;
             out->mesh.slabs = f->dSlabs;
             out->mesh.leafLog2 = f->leafLog2;
+            {
+                const char* pc = std::getenv("HPSDF_MESH_POOL_CAP");  // tests: a small pool sends lanes through the overflow path
+                out->mesh.poolCap = pc ? (uint32_t)std::strtoul(pc, nullptr, 10) : 0xFFFFFFFFu;
+            }
             out->mesh.nTris = f->nTris;
             out->mesh.nNodes = f->nBvhNodes;
             out->mesh.stats = f->dStats;

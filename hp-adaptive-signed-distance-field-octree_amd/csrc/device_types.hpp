@@ -93,7 +93,7 @@ struct MeshDev {
                                // vector n and within rho of g (NodeSlab above); nullptr: boxes only (host-built trees)
     uint32_t nTris, nNodes;
     uint32_t leafLog2;         // every leaf holds at most 1 << leafLog2 triangles (how the sampler cuts its lower-bound batches)
-    uint32_t pad0;
+    uint32_t poolCap;          // (lane, node) pairs the sampler's pool may hold, <= kMeshPoolCap (tests lower it to reach the overflow path)
     // traversal statistics (diagnostic builds, -DHPSDF_MESH_STATS_BUILD, and the field created under HPSDF_MESH_STATS=1):
     // [0] wave-wide queries, [1] nodes visited by them, [2] triangle tests issued (wave level), [3] lanes that ran one
     unsigned long long* stats;

@@ -408,15 +408,22 @@ __device__ __forceinline__ BvhNode loadNodeUniform(const BvhNode* base, int32_t 
 // ~sqrt(D H) of its foot point, at every level of the tree; the slab of a smooth patch is thin and leaves the patches within
 // ~H.  The per-lane descent that seeds the bounds follows the smaller of the two children's combined bounds and so ends in
 // the leaf under the sample (by boxes alone: a few triangles off, and everything in between passes the lower-bound test).
+constexpr uint32_t kMeshPoolCap = 256;  // (lane, node) pairs a wave's pool holds
+#ifndef HPSDF_MESH_SPARSE
+#define HPSDF_MESH_SPARSE 16            // a child that at most this many lanes want goes to the pool instead of being walked by the wave
+#endif
 struct MeshWaveLds {
     unsigned long long best[64];  // per lane: (squared distance bits << 32 | triangle) of the nearest triangle so far
     float px[64], py[64], pz[64]; // per lane: its sample
     float rj[64];                 // per lane: what a lower bound is compared with, rejectBound(best): refreshed with best
-    uint32_t aRef[128];           // ring A: (lane, leaf reference) waiting for the lower-bound tests of the leaf's slots
+    uint32_t nNode[kMeshPoolCap]; // pool N (a stack): (lane, inner node) pairs waiting for their two box / slab tests
+    uint32_t aRef[256];           // ring A: (lane, leaf reference) waiting for the lower-bound tests of the leaf's slots
     uint32_t bTri[128];           // ring B: (lane, triangle) waiting for the closest-point test
     int32_t stack[kMeshStack];    // the walk's deferred siblings
-    uint8_t aLane[128];
+    uint8_t nLane[kMeshPoolCap];
+    uint8_t aLane[256];
     uint8_t bLane[128];
+    uint8_t redo[64];             // lanes whose pairs found the pool full
 };
 // lower bound of the squared distance from p to anything inside the slab |n . (x - g)| <= e cut by the ball |x - g| <= rho
 // (g = (g.xyz), rho = g.w, n = nh.xyz, e = nh.w): along n at least |n . (p - g)| - e, across it at least the distance of p
@@ -443,16 +450,19 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool active, M
     const unsigned long long below = (1ull << lane) - 1ull;
     L.best[lane] = ((unsigned long long)__float_as_uint(FLT_MAX) << 32) | 0xFFFFFFFFull;
     L.px[lane] = pt.x, L.py[lane] = pt.y, L.pz[lane] = pt.z;
-    uint32_t aHead = 0, aCount = 0, bHead = 0, bCount = 0;  // wave-uniform
+    L.redo[lane] = 0;
+    uint32_t nCount = 0, aHead = 0, aCount = 0, bHead = 0, bCount = 0;  // wave-uniform
     float bound = __builtin_inff();   // what a box distance is compared with: best * 1.00001f + 1e-30f
     float reject = __builtin_inff();  // what a lower bound is compared with: rejectBound(best)
     const uint32_t lg = m.leafLog2, perBatch = 64u >> lg;               // pairs of ring A one lower-bound batch takes
     const bool slabs = m.slabs != nullptr;
+    const uint32_t poolCap = m.poolCap < 128u ? 128u : (m.poolCap > kMeshPoolCap ? kMeshPoolCap : m.poolCap);
     const float inf = __builtin_inff();
 #ifdef HPSDF_MESH_STATS_BUILD
     unsigned nVisits = 0, nBound = 0, nClosest = 0;  // [1] nodes visited, [2] pairs through the lower-bound test, [3] through the closest-point test
     unsigned nPairs = 0, nBoundBatches = 0, nClosestBatches = 0, nSeedExact = 0;  // [4] (lane, leaf) pairs, [5] [6] batches, [7] lanes whose seed was the answer
     float seedBest = 0.0f;
+    unsigned nPoolPairs = 0;
 #endif
     const float slack = meshSlack(loadNodeUniform(m.bvh, 0));
     // the owner's sample and bounds as the batches see them: always the latest best (the closest-point batches write it)
@@ -479,12 +489,15 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool active, M
         bHead = (bHead + cnt) & 127u;
         bCount -= cnt;
 #ifdef HPSDF_MESH_STATS_BUILD
-        nClosest += cnt, ++nClosestBatches;
+        nClosest += cnt;
+#ifndef HPSDF_MESH_VISIT_HIST
+        ++nClosestBatches;
+#endif
 #endif
     };
     auto boundBatch = [&](uint32_t pairs) {  // the first `pairs` (<= perBatch) pairs of ring A; ring B holds < 64 on entry
         const uint32_t e = (uint32_t)lane >> lg, k = (uint32_t)lane & ((1u << lg) - 1u);
-        const uint32_t at = (aHead + e) & 127u;
+        const uint32_t at = (aHead + e) & 255u;
         const bool have = e < pairs;
         const int32_t ref = have ? (int32_t)L.aRef[at] : -1;
         const int src = have ? (int)L.aLane[at] : lane;
@@ -506,10 +519,13 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool active, M
             L.bLane[pos] = (uint8_t)src;
         }
         bCount += (uint32_t)__popcll(pb);
-        aHead = (aHead + pairs) & 127u;
+        aHead = (aHead + pairs) & 255u;
         aCount -= pairs;
 #ifdef HPSDF_MESH_STATS_BUILD
-        nBound += (unsigned)__popcll(__ballot(on)), ++nBoundBatches;
+        nBound += (unsigned)__popcll(__ballot(on));
+#ifndef HPSDF_MESH_VISIT_HIST
+        ++nBoundBatches;
+#endif
 #endif
         __builtin_amdgcn_wave_barrier();
         while (bCount >= 64) closestBatch(64);
@@ -634,11 +650,90 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool active, M
 #endif
     }
     __builtin_amdgcn_wave_barrier();
-    // The walk: the wave visits a node if any lane still wants it, every lane against its own bound.  (Every (lane, node)
-    // pair as a work item of its own, 64 pairs from a pool in LDS per batch with per-lane node fetches, was tried in round 3:
-    // a lane wants ~170 nodes, 30 lanes share a node on average, so the pool moved 1.4 MB of nodes per wave through the
-    // vector memory path where this walk moves 45 KB through the scalar cache -- 10.1 against 7.1 ms.)
-    {
+    // The walk: the wave visits a node if any lane still wants it, every lane against its own bound -- as long as MANY lanes
+    // want it.  High up every lane wants the same few nodes and a visit (one 128-byte fetch through the scalar cache, two
+    // box and two slab tests across the wave) serves them all; near the leaves the samples' foot points lie a dozen triangles
+    // apart, half of the visits serve four lanes or fewer, and the wave-wide tests run for them alone.  So a child that at
+    // most HPSDF_MESH_SPARSE lanes want is not walked: each of those lanes drops a (lane, node) pair into a pool in LDS, and
+    // whenever 64 pairs are there one batch tests 64 pairs at once -- lane l fetches ITS pair's node and slab, tests both
+    // children for the pair's owner (whose sample and bounds come from LDS), inner children that pass go back into the pool
+    // (the nearer one on top), leaf children to ring A.  (The pool for EVERYTHING, from the root, was tried first: a lane
+    // wants ~170 nodes, 30 lanes share a node on average, and the pool moved 1.4 MB of nodes per wave through the vector
+    // memory path where the walk moves 45 KB through the scalar cache -- 10.1 against 7.1 ms.)  Every pair is tested against
+    // its owner's own bound, so each lane still ends with exactly what its own exhaustive scan finds.  If the pool is ever
+    // full, the owners concerned are marked and walk the tree once more at the end, without a pool.
+    auto poolBatch = [&]() {
+        const uint32_t cnt = nCount < 64u ? nCount : 64u;
+        const bool on = (uint32_t)lane < cnt;
+        const uint32_t at = on ? nCount - 1u - (uint32_t)lane : 0u;  // lane 0 takes the top of the stack
+        const uint32_t node = on ? L.nNode[at] : 0u;
+        const int o = on ? (int)L.nLane[at] : lane;
+        nCount -= cnt;
+        const V3 p = ownerPoint(o);
+        const float bd = ownerBest(o) * 1.00001f + 1e-30f, rj = L.rj[o];
+        bool w0 = false, w1 = false;
+        int32_t c0 = 0, c1 = 0;
+        float k0 = 0.0f, k1 = 0.0f;
+        if (on) {
+            const BvhNode nd = m.bvh[node];
+            k0 = HPSDF_BOX0(p, nd), k1 = HPSDF_BOX1(p, nd);
+            w0 = !(k0 > bd), w1 = !(k1 > bd);
+            c0 = nd.c0, c1 = nd.c1;
+            if (slabs) {
+                const NodeSlab ns = m.slabs[node];
+                if (ns.n0.w >= 0.0f) {
+                    const float sb = slabLowerBound2(p, ns.g0, ns.n0);
+                    w0 = w0 && !(sb > rj), k0 = fmaxf(k0, sb);
+                }
+                if (ns.n1.w >= 0.0f) {
+                    const float sb = slabLowerBound2(p, ns.g1, ns.n1);
+                    w1 = w1 && !(sb > rj), k1 = fmaxf(k1, sb);
+                }
+            }
+        }
+#ifdef HPSDF_MESH_STATS_BUILD
+        nPoolPairs += cnt;
+#endif
+        const bool i0 = w0 && c0 >= 0, i1 = w1 && c1 >= 0, l0 = w0 && c0 < 0, l1 = w1 && c1 < 0;
+        {   // inner children back to the pool: the farther one first, so that the nearer one is popped first
+            const unsigned long long bAny = __ballot(i0 || i1), bTwo = __ballot(i0 && i1);
+            const uint32_t total = (uint32_t)(__popcll(bAny) + __popcll(bTwo));
+            if (nCount + total <= poolCap) {
+                if (i0 || i1) {
+                    const uint32_t pos = nCount + (uint32_t)(__popcll(bAny & below) + __popcll(bTwo & below));
+                    const bool both = i0 && i1, nearIs1 = k1 < k0;
+                    L.nNode[pos] = (uint32_t)(both ? (nearIs1 ? c0 : c1) : (i0 ? c0 : c1));
+                    L.nLane[pos] = (uint8_t)o;
+                    if (both) {
+                        L.nNode[pos + 1u] = (uint32_t)(nearIs1 ? c1 : c0);
+                        L.nLane[pos + 1u] = (uint8_t)o;
+                    }
+                }
+                nCount += total;
+            } else if (i0 || i1) {
+                L.redo[o] = 1;  // no room: this owner walks the tree again at the end
+            }
+        }
+        {   // leaf children to ring A (which holds < perBatch on entry: at most 63 + 128 of its 256)
+            const unsigned long long bAny = __ballot(l0 || l1), bTwo = __ballot(l0 && l1);
+            if (l0 || l1) {
+                const uint32_t pos = aHead + aCount + (uint32_t)(__popcll(bAny & below) + __popcll(bTwo & below));
+                L.aRef[pos & 255u] = (uint32_t)(l0 ? c0 : c1);
+                L.aLane[pos & 255u] = (uint8_t)o;
+                if (l0 && l1) {
+                    L.aRef[(pos + 1u) & 255u] = (uint32_t)c1;
+                    L.aLane[(pos + 1u) & 255u] = (uint8_t)o;
+                }
+            }
+            aCount += (uint32_t)(__popcll(bAny) + __popcll(bTwo));
+#if defined(HPSDF_MESH_STATS_BUILD) && !defined(HPSDF_MESH_VISIT_HIST)
+            nPairs += (unsigned)(__popcll(bAny) + __popcll(bTwo));
+#endif
+        }
+        __builtin_amdgcn_wave_barrier();
+        while (aCount >= perBatch) boundBatch(perBatch);
+    };
+    auto walk = [&](bool act, uint32_t sparse) {  // sparse = 0: no pool, the wave walks everything some lane wants
         BvhNode n = loadNodeUniform(m.bvh, 0);
         NodeSlab sl{};
         if (slabs) sl = loadSlabUniform(m.slabs, 0);
@@ -648,15 +743,41 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool active, M
             ++nVisits;
 #endif
             const float d0 = HPSDF_BOX0(pt, n), d1 = HPSDF_BOX1(pt, n);
-            bool w0 = active && !(d0 > bound), w1 = active && !(d1 > bound);
+            bool w0 = act && !(d0 > bound), w1 = act && !(d1 > bound);
             if (slabs) {  // (wave-uniform conditions: the slab came through the scalar cache)
                 if (sl.n0.w >= 0.0f && __ballot(w0) != 0ull) w0 = w0 && !(slabLowerBound2(pt, sl.g0, sl.n0) > reject);
                 if (sl.n1.w >= 0.0f && __ballot(w1) != 0ull) w1 = w1 && !(slabLowerBound2(pt, sl.g1, sl.n1) > reject);
             }
             const unsigned long long b0 = __ballot(w0), b1 = __ballot(w1);
             const int32_t c0 = n.c0, c1 = n.c1;
+#ifdef HPSDF_MESH_VISIT_HIST  // how many lanes a visit serves: [4] <= 4 lanes wanted one of the children, [5] <= 8, [6] <= 16, [7] <= 32
+            {
+                const int pc = __popcll(b0 | b1);
+                nPairs += pc <= 4 ? 1u : 0u, nBoundBatches += pc > 4 && pc <= 8 ? 1u : 0u, nClosestBatches += pc > 8 && pc <= 16 ? 1u : 0u;
+                nSeedExact += pc > 16 && pc <= 32 ? 1u : 0u;
+            }
+#endif
+            bool push0 = c0 >= 0 && b0 != 0ull, push1 = c1 >= 0 && b1 != 0ull;
+            // inner children few lanes want: into the pool (if it has room for them and for what a batch can add)
+            if (push0 && (uint32_t)__popcll(b0) <= sparse && nCount + (uint32_t)__popcll(b0) + 64u <= poolCap) {
+                if (w0) {
+                    const uint32_t pos = nCount + (uint32_t)__popcll(b0 & below);
+                    L.nNode[pos] = (uint32_t)c0;
+                    L.nLane[pos] = (uint8_t)lane;
+                }
+                nCount += (uint32_t)__popcll(b0);
+                push0 = false;
+            }
+            if (push1 && (uint32_t)__popcll(b1) <= sparse && nCount + (uint32_t)__popcll(b1) + 64u <= poolCap) {
+                if (w1) {
+                    const uint32_t pos = nCount + (uint32_t)__popcll(b1 & below);
+                    L.nNode[pos] = (uint32_t)c1;
+                    L.nLane[pos] = (uint8_t)lane;
+                }
+                nCount += (uint32_t)__popcll(b1);
+                push1 = false;
+            }
             int32_t next = -1;
-            const bool push0 = c0 >= 0 && b0 != 0ull, push1 = c1 >= 0 && b1 != 0ull;
             if (push0 && push1) {
                 // the one that is nearer for the first lane that wants child 0 goes first, its sibling waits on the stack
                 const int l0 = __ffsll((long long)b0) - 1;
@@ -683,28 +804,41 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool active, M
                 const unsigned long long b = side ? b1 : b0;
                 if (c >= 0 || b == 0ull) continue;
                 if (side ? w1 : w0) {
-                    const uint32_t pos = (aHead + aCount + (uint32_t)__popcll(b & below)) & 127u;
+                    const uint32_t pos = (aHead + aCount + (uint32_t)__popcll(b & below)) & 255u;
                     L.aRef[pos] = (uint32_t)c;
                     L.aLane[pos] = (uint8_t)lane;
                 }
                 aCount += (uint32_t)__popcll(b);
-#ifdef HPSDF_MESH_STATS_BUILD
+#if defined(HPSDF_MESH_STATS_BUILD) && !defined(HPSDF_MESH_VISIT_HIST)
                 nPairs += (unsigned)__popcll(b);
 #endif
                 __builtin_amdgcn_wave_barrier();
                 while (aCount >= perBatch) boundBatch(perBatch);
             }
+            __builtin_amdgcn_wave_barrier();
+            while (nCount >= 64u) poolBatch();
             // (the test on the two padding words, always zero, keeps all sixteen dwords of the prefetch live across the
             // leaf tests: with them dead the register allocator reuses their SGPRs at once and waits for the load right here)
             if (next < 0 || (nn.pad[0] & nn.pad[1]) == 0xFFFFFFFFu) break;
             n = nn;
             sl = sn;
         }
+        while (nCount > 0u) poolBatch();
         while (aCount) boundBatch(aCount < perBatch ? aCount : perBatch);
         if (bCount) closestBatch(bCount);
+    };
+    walk(active, (uint32_t)HPSDF_MESH_SPARSE);
+    {
+        const bool again = L.redo[lane] != 0;
+        if (__ballot(again) != 0ull) walk(again, 0u);
     }
 #ifdef HPSDF_MESH_STATS_BUILD
+#ifndef HPSDF_MESH_VISIT_HIST
     nSeedExact = (unsigned)__popcll(__ballot(active && seedBest == ownerBest(lane)));
+#endif
+#ifdef HPSDF_MESH_POOL_STATS  // [7]: (lane, node) pairs that went through the pool
+    nSeedExact = nPoolPairs;
+#endif
 #ifdef HPSDF_MESH_SEED_STATS  // how far off the seeds are: [5] within 1e-4 of the final distance, [6] within 1e-2, [4] within 10 %
     {
         const float rs = sqrtf(seedBest), rf = sqrtf(ownerBest(lane));
