@@ -386,24 +386,26 @@ def main():
             t0 = time.perf_counter()
             O.Tree.create(O.default_config(TARGET), O.union3_field(), JOBS_PER_ROUND)
             tcs.append(time.perf_counter() - t0)
-        # the same Query on every host core (Octree::Query is const: the reference's own parallel use), ~5 s
-        from concurrent.futures import ThreadPoolExecutor
+        # the same Query on every host core (Octree::Query is const: the reference's own parallel use), ~4 s: one pthread per
+        # core inside the oracle's C loop (ora_query_batch_mt) -- no interpreter, no GIL between the cores and the points
         ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        chunks = np.array_split(np.arange(m), ncores * 4)
-
-        def qchunk(ix):
-            return otree.query(pts[ix[0]:ix[-1] + 1]) if len(ix) else None
-        with ThreadPoolExecutor(ncores) as pool:
-            list(pool.map(qchunk, chunks))  # warm the pool
-            tall, apasses = 0.0, 0
-            while tall < 4.0:
-                t0 = time.perf_counter()
-                list(pool.map(qchunk, chunks))
-                tall += time.perf_counter() - t0
-                apasses += 1
+        otree.query(pts[:m], threads=ncores)  # warm
+        tall, apasses = 0.0, 0
+        while tall < 4.0:
+            t0 = time.perf_counter()
+            otree.query(pts[:m], threads=ncores)
+            tall += time.perf_counter() - t0
+            apasses += 1
+        tca = []
+        for _ in range(3):  # ... and Create with a round's jobs on every core (same tree: the jobs of a round are pure)
+            t0 = time.perf_counter()
+            O.Tree.create(O.default_config(TARGET), O.union3_field(), JOBS_PER_ROUND, threads=ncores)
+            tca.append(time.perf_counter() - t0)
         out["cpu_baseline_all_cores"] = {"value": apasses * m / tall / 1e6, "unit": "Mpts/s", "cores": ncores, "kind": "port",
-                                         "sample": "oracle Query() over the same %d points split over %d threads, %d whole passes (%.1f s)"
-                                                   % (m, ncores, apasses, tall)}
+                                         "sample": "oracle Query() over the same %d points cut into %d contiguous parts, one pthread each, "
+                                                   "%d whole passes (%.1f s); oracle Create() with a round's jobs on %d pthreads, median of 3"
+                                                   % (m, ncores, apasses, tall, ncores),
+                                         "create_ms": float(np.median(tca)) * 1e3}
         out["cpu_baseline"] = {"value": passes * m / tq / 1e6, "unit": "Mpts/s", "cores": 1, "kind": "port",
                                "sample": "oracle Query() over the same %d points, %d whole passes (%.1f s); "
                                          "oracle Create() of the same config, median of 3" % (m, passes, tq),

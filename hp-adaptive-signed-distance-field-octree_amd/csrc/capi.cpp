@@ -1254,8 +1254,10 @@ int hpsdf_create_distributed(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsd
     if (world == 1) return hpsdf_create(ctx, cfg, field, K, block, size, stats);
     if (world < 1 || rank < 0 || rank >= world) return fail(HPSDF_ERR_INVALID_ARGUMENT, "rank outside [0, world)");
     if (!gather) return fail(HPSDF_ERR_INVALID_ARGUMENT, "an all-gather callback is required for world > 1");
-    int rc = frontierEligible(cfg, field, K) ? frontierCreate(ctx, cfg, field, K, block, size, stats, rank, world, gather, user)
-                                             : createShardedOnHostScheduler(ctx, cfg, field, K, rank, world, gather, user, block, size, stats);
+    // (the device-side frontier packs a segment's owner rank into three bits: more than 8 ranks take the host scheduler's rounds)
+    int rc = (frontierEligible(cfg, field, K) && world <= 8)
+                 ? frontierCreate(ctx, cfg, field, K, block, size, stats, rank, world, gather, user)
+                 : createShardedOnHostScheduler(ctx, cfg, field, K, rank, world, gather, user, block, size, stats);
     std::memset(&g_lastContinuity, 0, sizeof g_lastContinuity);
     if (!rc && cfg->continuity_enforce) {  // Octree.cpp:341-344: every rank on its identical copy (deterministic: no exchange)
         std::string err;

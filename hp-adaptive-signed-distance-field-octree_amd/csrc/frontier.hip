@@ -85,6 +85,13 @@ struct FrHdr {
     uint32_t hist2[2048];  // level-1 digits of the candidates of the current selection
 };
 constexpr size_t kFrHdrCopyBytes = offsetof(FrHdr, hist1);
+static inline void frCpuRelax() {  // the host's spin on the header mirror
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield");
+#endif
+}
 
 struct FrRound {  // shape classes of the current round (written by fr_batch_kernel, read by fr_tasks_kernel)
     uint32_t cCount[kFrClasses], cFirst[kFrClasses], cCursor[kFrClasses], cBlockFirst[kFrClasses], cBlocks[kFrClasses];
@@ -1362,7 +1369,7 @@ struct FrontierWorkspace {
         device = dev;
         hipError_t e = hipMalloc((void**)&d.hdr, sizeof(FrHdr));
         if (e == hipSuccess) e = hipMalloc((void**)&d.rnd, sizeof(FrRound));
-        if (e == hipSuccess) e = hipHostMalloc((void**)&hostHdr, sizeof(FrHdr), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&hostHdr, sizeof(FrHdr), hipHostMallocCoherent | hipHostMallocMapped);  // (the host watches it while kernels write it)
         if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&d.hostHdr, hostHdr, 0);
         if (e == hipSuccess) e = hipMalloc((void**)&d.taken, (kFrJobs + 64) * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc((void**)&d.wBatchIdx, kFrJobs * sizeof(uint32_t));
@@ -1757,9 +1764,19 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         {
             const volatile uint32_t* roundWord = &hh->round;
             const uint32_t want = (uint32_t)rounds + 1u;
-            const double limit = ts + 2.0e6;  // two seconds of watching, then the ordinary wait
-            while (*roundWord != want && now() < limit) __builtin_ia32_pause();
-            if (*roundWord != want) HPSDF_HIP(hipStreamSynchronize(s));
+            const double limit = ts + 2.0e3;  // two milliseconds of watching, then the ordinary wait
+            while (*roundWord != want && now() < limit) frCpuRelax();
+            if (*roundWord != want) {
+                HPSDF_HIP(hipStreamSynchronize(s));
+                if (*roundWord != want) {
+                    // The stream is idle and the mirror still shows the old round: the round ended on a path that does not
+                    // write it (fr_decide_kernel's capacity overflow makes fr_update_kernel return early), or the pinned
+                    // mirror is not coherent on this system.  Fetch the header itself and let it decide.
+                    HPSDF_HIP(hipMemcpy(ws->hostHdr, d.hdr, kFrHdrCopyBytes, hipMemcpyDeviceToHost));
+                    if (hh->overflow == 1) return fail(HPSDF_ERR_STATE, "frontier: node capacity exceeded");
+                    if (hh->round != want && !hh->done) return fail(HPSDF_ERR_STATE, "frontier: a round ended without advancing");
+                }
+            }
             std::atomic_thread_fence(std::memory_order_acquire);
         }
         tSync += now() - ts;

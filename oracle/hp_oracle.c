@@ -10,6 +10,7 @@
 #include <float.h>
 #include <math.h>
 #include <stdlib.h>
+#include <pthread.h>
 #include <string.h>
 
 /* ======================================================================== */
@@ -679,7 +680,46 @@ static void set_root_vectors(ora_tree* t) {
     }
 }
 
+/* A round's jobs are pure functions of (cell, degree, error, coefficients, field) (Octree.cpp:594-601, 804-856): with
+ * threads > 1 they are evaluated by a pool of pthreads, each job into buffers of its own, and applied afterwards in node
+ * order exactly as the single-threaded loop applies them -- same tree, same bytes, for any thread count.  (The all-cores CPU
+ * baseline of bench.py; fields given as Python callbacks must stay with threads = 1.) */
+typedef struct {
+    const ora_field* f;
+    const ora_config* cfg;
+    const ora_tree* t;
+    double** cptr;
+    const heap_ent* batch;
+    uint64_t want;
+    ora_job_result* res;
+    double** pb;
+    double** hb;
+    int literal;
+    uint64_t next; /* atomic */
+} round_work;
+static void* round_worker(void* arg) {
+    round_work* w = (round_work*)arg;
+    for (;;) {
+        const uint64_t bi = __atomic_fetch_add(&w->next, 1, __ATOMIC_RELAXED);
+        if (bi >= w->want) break;
+        const uint64_t idx = w->batch[bi].idx;
+        const ora_node* nd = &w->t->nodes[idx];
+        const int p = nd->degree, d = nd->depth;
+        const int coarse = fabs(w->batch[bi].err - ORA_INITIAL_NODE_ERR) < DBL_EPSILON;
+        const int np = coarse ? 2 : (p + 1 < ORA_BASIS_MAX_DEGREE ? p + 1 : p);
+        w->pb[bi] = (double*)malloc(sizeof(double) * g_count[np > p ? np : p]);
+        w->hb[bi] = (double*)malloc(sizeof(double) * 8 * g_count[p > 2 ? p : 2]);
+        ora_job(w->f, w->cfg, nd->aabb_min, nd->aabb_max, d, p, w->batch[bi].err, w->cptr[idx], w->pb[bi], w->hb[bi], &w->res[bi],
+                w->literal);
+    }
+    return NULL;
+}
+
 ora_tree* ora_create(const ora_config* cfg, const ora_field* f, uint64_t K, int literal, ora_build_stats* stats) {
+    return ora_create_mt(cfg, f, K, literal, stats, 1);
+}
+
+ora_tree* ora_create_mt(const ora_config* cfg, const ora_field* f, uint64_t K, int literal, ora_build_stats* stats, int threads) {
     ora_tables_init();
     ora_build_stats st;
     memset(&st, 0, sizeof(st));
@@ -708,24 +748,36 @@ ora_tree* ora_create(const ora_config* cfg, const ora_field* f, uint64_t K, int 
     double total = pow(8, 4) * ORA_INITIAL_NODE_ERR; /* :212 */
     heap_ent* batch = NULL;
     uint64_t batch_cap = 0;
-    double* pbuf = (double*)malloc(sizeof(double) * ORA_NCOEF_MAX);
-    double* hbuf = (double*)malloc(sizeof(double) * 8 * ORA_NCOEF_MAX);
+    ora_job_result* res = NULL;
+    double **pbs = NULL, **hbs = NULL;
+    if (threads < 1) threads = 1;
+    pthread_t* tids = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
     for (;;) {
         if (total < cfg->target_error_threshold || h.n == 0) break; /* :216 */
         uint64_t want = (st.rounds == 0) ? h.n : (K < h.n ? K : h.n);
         if (want > batch_cap) {
             batch_cap = want;
             batch = (heap_ent*)realloc(batch, batch_cap * sizeof(heap_ent));
+            res = (ora_job_result*)realloc(res, batch_cap * sizeof(ora_job_result));
+            pbs = (double**)realloc(pbs, batch_cap * sizeof(double*));
+            hbs = (double**)realloc(hbs, batch_cap * sizeof(double*));
         }
         for (uint64_t i = 0; i < want; ++i) batch[i] = heap_pop(&h);
         qsort(batch, want, sizeof(heap_ent), cmp_idx); /* apply in nodeIdx order */
+        {   /* evaluate (in parallel), then apply (in order) */
+            round_work w = {f, cfg, t, b.cptr, batch, want, res, pbs, hbs, literal, 0};
+            const int nt = (uint64_t)threads < want ? threads : (int)want;
+            for (int k = 1; k < nt; ++k) pthread_create(&tids[k], NULL, round_worker, &w);
+            round_worker(&w);
+            for (int k = 1; k < nt; ++k) pthread_join(tids[k], NULL);
+        }
         for (uint64_t bi = 0; bi < want; ++bi) {
             const uint64_t idx = batch[bi].idx;
             const double err = batch[bi].err;
             ora_node nd = t->nodes[idx]; /* copy: subdivide() may realloc */
             const int p = nd.degree, d = nd.depth;
-            ora_job_result r;
-            ora_job(f, cfg, nd.aabb_min, nd.aabb_max, d, p, err, b.cptr[idx], pbuf, hbuf, &r, literal);
+            const ora_job_result r = res[bi];
+            double *pbuf = pbs[bi], *hbuf = hbs[bi];
             st.jobs++;
             st.fits += r.coarse ? 1 : ((d < ORA_TREE_MAX_DEPTH ? 8 : 0) + (p < ORA_BASIS_MAX_DEGREE - 1 ? 1 : 0));
             if (r.refine_p) { /* :253-260, :286-290 */
@@ -757,12 +809,16 @@ ora_tree* ora_create(const ora_config* cfg, const ora_field* f, uint64_t K, int 
             } else {
                 st.dropped++; /* :643-655 */
             }
+            free(pbuf);
+            free(hbuf);
         }
         st.rounds++;
     }
     free(batch);
-    free(pbuf);
-    free(hbuf);
+    free(res);
+    free(pbs);
+    free(hbs);
+    free(tids);
     free(h.e);
     st.total_error = total;
 
@@ -923,4 +979,32 @@ void ora_query_gradient_batch(const ora_tree* t, const double* xyz, size_t n, do
 }
 void ora_query_batch(const ora_tree* t, const double* xyz, size_t n, double* out) {
     for (size_t i = 0; i < n; ++i) out[i] = ora_query(t, xyz + 3 * i);
+}
+/* Octree::Query is const (Octree.h:71): the reference's own parallel use.  The points are cut into `threads` contiguous
+ * parts, one pthread each -- the loop of HPBenchmarks.cpp:105-109 on every core, with no interpreter in between. */
+typedef struct {
+    const ora_tree* t;
+    const double* xyz;
+    size_t n;
+    double* out;
+} query_part;
+static void* query_worker(void* arg) {
+    const query_part* q = (const query_part*)arg;
+    ora_query_batch(q->t, q->xyz, q->n, q->out);
+    return NULL;
+}
+void ora_query_batch_mt(const ora_tree* t, const double* xyz, size_t n, double* out, int threads) {
+    if (threads < 1) threads = 1;
+    if ((size_t)threads > n) threads = n ? (int)n : 1;
+    pthread_t* tids = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
+    query_part* parts = (query_part*)malloc(sizeof(query_part) * (size_t)threads);
+    for (int k = 0; k < threads; ++k) {
+        const size_t a = n * (size_t)k / (size_t)threads, b = n * (size_t)(k + 1) / (size_t)threads;
+        parts[k].t = t, parts[k].xyz = xyz + 3 * a, parts[k].n = b - a, parts[k].out = out + a;
+        if (k) pthread_create(&tids[k], NULL, query_worker, &parts[k]);
+    }
+    query_worker(&parts[0]);
+    for (int k = 1; k < threads; ++k) pthread_join(tids[k], NULL);
+    free(tids);
+    free(parts);
 }

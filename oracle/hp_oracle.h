@@ -172,6 +172,9 @@ typedef struct {
  * nodeIdx asc)).  max_jobs_per_round = K. */
 ora_tree* ora_create(const ora_config* cfg, const ora_field* f, uint64_t max_jobs_per_round, int literal,
                      ora_build_stats* stats);
+/* the same with a round's jobs evaluated by `threads` pthreads (same tree for any thread count; C fields only) */
+ora_tree* ora_create_mt(const ora_config* cfg, const ora_field* f, uint64_t max_jobs_per_round, int literal,
+                        ora_build_stats* stats, int threads);
 void ora_tree_free(ora_tree* t);
 
 /* Octree::ToMemoryBlock / FromMemoryBlock, Octree.cpp:424-456, 403-421.
@@ -183,6 +186,7 @@ ora_tree* ora_tree_from_block(const void* block, size_t size);
 /* Octree::Query, Octree.cpp:662-702 */
 double ora_query(const ora_tree* t, const double pt[3]);
 void ora_query_batch(const ora_tree* t, const double* xyz, size_t n, double* out);
+void ora_query_batch_mt(const ora_tree* t, const double* xyz, size_t n, double* out, int threads);
 /* Octree::QueryWithGradient / FApproxWithGradient, Octree.cpp:749-789, 904-985 */
 double ora_fapprox_with_gradient(const double* coeffs, int degree, const float bmin[3], const float bmax[3],
                                  const double pt[3], int depth, double grad[3]);

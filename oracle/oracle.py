@@ -109,6 +109,9 @@ def lib():
     L.ora_fapprox.argtypes = [dp, C.c_int, fp, fp, dp, C.c_int]
     L.ora_create.restype = C.c_void_p
     L.ora_create.argtypes = [C.POINTER(Config), C.POINTER(Field), C.c_uint64, C.c_int, C.POINTER(BuildStats)]
+    L.ora_create_mt.restype = C.c_void_p
+    L.ora_create_mt.argtypes = [C.POINTER(Config), C.POINTER(Field), C.c_uint64, C.c_int, C.POINTER(BuildStats), C.c_int]
+    L.ora_query_batch_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
     L.ora_tree_free.argtypes = [C.c_void_p]
     L.ora_tree_block_size.restype = C.c_size_t
     L.ora_tree_block_size.argtypes = [C.c_void_p]
@@ -312,9 +315,13 @@ class Tree:
         self.handle = handle
 
     @staticmethod
-    def create(cfg, field, K=1024, literal=False):
+    def create(cfg, field, K=1024, literal=False, threads=1):
+        """threads > 1: a round's jobs on that many pthreads (same tree; fields implemented in C only)."""
         st = BuildStats()
-        h = lib().ora_create(C.byref(cfg), C.byref(field.f), K, 1 if literal else 0, C.byref(st))
+        if threads > 1:
+            h = lib().ora_create_mt(C.byref(cfg), C.byref(field.f), K, 1 if literal else 0, C.byref(st), threads)
+        else:
+            h = lib().ora_create(C.byref(cfg), C.byref(field.f), K, 1 if literal else 0, C.byref(st))
         t = Tree(h)
         t.stats = {k: getattr(st, k) for k, _ in BuildStats._fields_}
         return t
@@ -334,10 +341,13 @@ class Tree:
         L.ora_tree_to_block(self.handle, buf)
         return buf.raw
 
-    def query(self, pts):
+    def query(self, pts, threads=1):
         pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)
         out = np.empty(len(pts))
-        lib().ora_query_batch(self.handle, pts.ctypes.data_as(C.c_void_p), len(pts), out.ctypes.data_as(C.c_void_p))
+        if threads > 1:
+            lib().ora_query_batch_mt(self.handle, pts.ctypes.data_as(C.c_void_p), len(pts), out.ctypes.data_as(C.c_void_p), threads)
+        else:
+            lib().ora_query_batch(self.handle, pts.ctypes.data_as(C.c_void_p), len(pts), out.ctypes.data_as(C.c_void_p))
         return out
 
     def query_with_gradient(self, pts, grad_init=None):

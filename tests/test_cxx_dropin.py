@@ -44,10 +44,12 @@ int main(int argc, char** argv) {
         if (q0 != q1 || q0 != q2) { printf("MISMATCH query after copy/load\n"); return 4; }
         if (hpOctree.Query(outside) != std::numeric_limits<f64>::max()) { printf("outside != DBL_MAX\n"); return 5; }
         if (std::fabs(q0 - SphereFunc(p, 0)) > 0.01) { printf("accuracy\n"); return 6; }
-        std::vector<double> xyz(3000), out(1000);
-        for (int i = 0; i < 3000; ++i) xyz[i] = -0.5 + (i * 7919 % 1000) / 1000.0;
-        hpOctree.Query(xyz.data(), 1000, out.data());
-        for (int i = 0; i < 1000; ++i)
+        // scalar Query(pt), as the reference's own loops call it (HPUnitTests.cpp:64-75), against the batched overload: the
+        // same bits for 10 000 points (a scalar call is a launch and a wait, ~15 us: INTEGRATION.md section A)
+        std::vector<double> xyz(30000), out(10000);
+        for (int i = 0; i < 30000; ++i) xyz[i] = -0.5 + (i * 7919 % 1000) / 1000.0 + (i % 7) * 1e-4;
+        hpOctree.Query(xyz.data(), 10000, out.data());
+        for (int i = 0; i < 10000; ++i)
             if (out[i] != hpOctree.Query(Eigen::Vector3d(xyz[3*i], xyz[3*i+1], xyz[3*i+2]))) { printf("batched != scalar\n"); return 7; }
         Eigen::Vector3d nrm(0, 0, 0);
         const double qg = hpOctree.QueryWithGradient(p, nrm);   // Include/HP/Octree.h:78

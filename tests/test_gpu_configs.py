@@ -427,6 +427,15 @@ def test_create_distributed_argument_checks(H, ctx):
     assert e.value.status == H.ERR_INVALID_ARGUMENT
 
 
+def test_create_distributed_on_more_than_eight_ranks(H, ctx):
+    """The device-side frontier holds a segment's owner rank in three bits; nine ranks take the host scheduler's rounds
+    through the same entry point and end with the single-rank block."""
+    cfg = H.make_config(1e-7)
+    one, st = H.create_block(ctx, cfg, H.Field.union3(), 1024)
+    for blk, s in _create_on_simulated_ranks(H, 9, cfg, lambda c: H.Field.union3(), 1024):
+        assert blk == one and s["jobs"] == st["jobs"] and s["rounds"] == st["rounds"]
+
+
 # ------------------------------------------------------------------ the opt-in matrix-core fit (csrc/fit_mfma.hip)
 @pytest.mark.parametrize("name,target", [("union3", 1e-7), ("sphere", 1e-8), ("union3", 1e-8)])
 def test_fast_fit_within_tolerance_of_oracle(H, O, name, target):

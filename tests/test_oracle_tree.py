@@ -150,3 +150,18 @@ def test_query_with_gradient_oracle(O):
     assert np.allclose(np.linalg.norm(g, axis=1), 1.0, atol=1e-12) and cos.mean() > 0.999 and cos.min() > 0.9
     v2, g2 = t.query_with_gradient(np.array([[3.0, 0.0, 0.0]]), np.array([[5.0, 6.0, 7.0]]))
     assert v2[0] == DBL_MAX and g2.tolist() == [[5.0, 6.0, 7.0]]
+
+
+def test_oracle_threads_do_not_change_results(O):
+    """bench.py's all-cores CPU baseline: a round's jobs on several pthreads (ora_create_mt) and Query cut into contiguous
+    parts (ora_query_batch_mt) give the bytes of the single-threaded loops, for an analytic and for a weighted build."""
+    cfg = O.default_config(1e-6)
+    a = O.Tree.create(cfg, O.union3_field(), 256)
+    b = O.Tree.create(cfg, O.union3_field(), 256, threads=5)
+    assert a.to_block() == b.to_block() and a.stats == b.stats
+    w = O.default_config(1e-6)
+    w.weighting_type, w.weighting_strength = 2, 3.0
+    assert O.Tree.create(w, O.sphere_field(), 512).to_block() == O.Tree.create(w, O.sphere_field(), 512, threads=3).to_block()
+    p = O.splitmix64_points(30001, seed=9)
+    p[:7] *= 3.0
+    assert np.array_equal(a.query(p), a.query(p, threads=4)) and np.array_equal(a.query(p[:3]), a.query(p[:3], threads=8))
