@@ -102,17 +102,22 @@ def main():
                 torch.cuda.synchronize()
                 times.append((time.perf_counter() - t0) * 1e3)
             ms = float(np.median(times))
-            if world > 1:
-                t = torch.tensor([ms], device="cuda")
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                ms = float(t.item())
-            return blk, st, ms, times
+            per_rank = [ms]
+            if world > 1:  # every rank's own median; the job's figure is the slowest rank's
+                t = torch.zeros(world, device="cuda", dtype=torch.float64)
+                t[rank] = ms
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                per_rank = [float(x) for x in t.tolist()]
+                ms = max(per_rank)
+            return blk, st, ms, times, per_rank
 
-        block, stats, create_ms, create_times = timed_create("auto")
-        create_sharded_ms = None
+        block, stats, create_ms, create_times, _ = timed_create("auto")
+        create_sharded_ms, create_sharded = None, None
         if world > 1:
-            block_s, _, create_sharded_ms, _ = timed_create("shard")
+            block_s, st_s, create_sharded_ms, _, per_rank = timed_create("shard")
             assert block_s == block, "sharded and replicated Create disagree"
+            create_sharded = {"ms_per_rank": per_rank, "exchanges_per_create": st_s.get("exchanges"), "rounds": st_s["rounds"],
+                              "backend": dist.get_backend()}
 
         # ---------------- Query(): this rank's points, resident in HBM
         n = args.points
@@ -264,9 +269,12 @@ def main():
                     mt.append((time.perf_counter() - t0) * 1e3)
                 ms = float(np.median(mt))
                 if world > 1:
-                    t = torch.tensor([ms], device="cuda")
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                    ms = float(t.item())
+                    t = torch.zeros(world, device="cuda", dtype=torch.float64)
+                    t[rank] = ms
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                    mesh["create_ms_per_rank_" + key] = [float(x) for x in t.tolist()]
+                    mesh["exchanges_per_create_" + key] = mst.get("exchanges")
+                    ms = float(t.max().item())
                 mesh["create_ms_" + key] = ms
                 mesh["tree_" + key] = {"nodes": mst["n_nodes"], "rounds": mst["rounds"], "samples": mst["samples"],
                                        "msamples_per_s": mst["samples"] / ms / 1e3}
@@ -347,7 +355,7 @@ def main():
         "config": {"workload": "BASELINE configs[1]: union(sphere,box,torus) analytic SDF, targetError=1e-5, "
                                "continuity off, %d random Query() points per GPU" % n,
                    "jobs_per_round": JOBS_PER_ROUND, "points_per_gpu": n, "sharding": "replicated tree, points split"},
-        "create_ms": create_ms, "create_sharded_ms": create_sharded_ms,
+        "create_ms": create_ms, "create_sharded_ms": create_sharded_ms, "create_sharded": create_sharded,
         "create": {"nodes": stats["n_nodes"], "leaves": stats["n_leaves"], "coeffs": stats["n_coeffs"],
                    "rounds": stats["rounds"], "jobs": stats["jobs"], "fits": stats["fits"], "samples": stats["samples"],
                    "block_bytes": len(block), "ms_all": create_times},

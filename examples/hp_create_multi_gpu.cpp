@@ -51,9 +51,28 @@ int main(int argc, char** argv) {
     std::vector<ncclComm_t> comms(world);
     std::vector<int> devs(world);
     for (int r = 0; r < world; ++r) devs[r] = r;
-    if (world > 1 && ncclCommInitAll(comms.data(), world, devs.data()) != ncclSuccess) {
+    if (ncclCommInitAll(comms.data(), world, devs.data()) != ncclSuccess) {
         std::printf("ncclCommInitAll failed\n");
         return 3;
+    }
+    if (world == 1) {
+        // one GPU: the sharded build has nothing to exchange, but the adaptor itself still runs once -- an in-place
+        // ncclAllGather of one rank on a stream, the call every rank of a larger world makes twice per round
+        hipStream_t st;
+        unsigned char* buf = nullptr;
+        unsigned char host[256], back[256];
+        for (int i = 0; i < 256; ++i) host[i] = (unsigned char)(i * 7);
+        hpsdf_rccl::Comm comm{comms[0], 0};
+        bool fine = hipStreamCreate(&st) == hipSuccess && hipMalloc((void**)&buf, 256) == hipSuccess &&
+                    hipMemcpyAsync(buf, host, 256, hipMemcpyHostToDevice, st) == hipSuccess &&
+                    hpsdf_rccl::AllGather(&comm, buf, 256, st) == 0 && hipMemcpyAsync(back, buf, 256, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                    hipStreamSynchronize(st) == hipSuccess && std::memcmp(host, back, 256) == 0;
+        if (buf) (void)hipFree(buf);
+        if (!fine) {
+            std::printf("hpsdf_rccl::AllGather failed on one rank (RCCL status %d)\n", (int)comm.last);
+            return 4;
+        }
+        std::printf("hpsdf_rccl::AllGather: one-rank in-place all-gather on a stream ok\n");
     }
     std::vector<int> ok(world, 0);
     std::vector<double> ms(world, 0.0);
@@ -82,8 +101,7 @@ int main(int argc, char** argv) {
     for (int r = 0; r < world; ++r) good += ok[r], worst = ms[r] > worst ? ms[r] : worst;
     std::printf("union3 @ %g: 1 GPU %.3f ms; %d ranks %.3f ms (slowest rank); blocks identical to the single-GPU build on %d / %d ranks\n", target,
                 oneMs, world, worst, good, world);
-    if (world > 1)
-        for (auto& c : comms) ncclCommDestroy(c);
+    for (auto& c : comms) ncclCommDestroy(c);
     std::free(want.ptr);
     return good == world ? 0 : 1;
 }

@@ -1321,6 +1321,8 @@ struct FrontierWorkspace {
     FitTask* r0Tasks = nullptr;
     FitBlock* r0Blocks = nullptr;
     uint64_t* r0JobP = nullptr;
+    int r0Rank = -1, r0World = -1;  // what (rank, world, error stride) the three r0 arrays were built for
+    uint32_t r0ErrStride = 0;
     std::vector<FitTask> hostTmplTasks, hostR0Tasks;
     hipError_t ensureRanks(int world, hipStream_t s) {
         hipError_t e = hipSuccess;
@@ -1614,33 +1616,40 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         const uint32_t first = T0.sliceFirst[rank], count = T0.sliceFirst[rank + 1] - first;
         int g = 1, pl = 1;
         frShape(2, false, std::max(1u, count), &g, &pl);
-        std::vector<FitTask>& tk = ws->hostR0Tasks;
-        tk.assign(ws->hostTmplTasks.begin() + first, ws->hostTmplTasks.begin() + first + count);
-        std::vector<uint64_t> jobP(T.nLeaves, ~0ull & kOffMask);
-        for (uint32_t q = 0; q < count; ++q) {
-            tk[q].outOff = (uint64_t)q * frCoef(2);
-            tk[q].sampleOff = (uint64_t)q * 729;
-            tk[q].errSlot = (uint32_t)rank * ws->d.errStride + q * HPSDF_JOB_HEADER_DOUBLES;
-            jobP[first + q] = tk[q].outOff;
+        const uint32_t nBl = (count + (uint32_t)g - 1u) / (uint32_t)g;
+        // this rank's task list, workgroup list and job -> arena map of round 0 depend on (rank, world, error stride) alone:
+        // built and uploaded once, kept on the device for the Creates that follow (no upload, no wait per Create)
+        if (ws->r0Rank != rank || ws->r0World != world || ws->r0ErrStride != ws->d.errStride) {
+            std::vector<FitTask>& tk = ws->hostR0Tasks;
+            tk.assign(ws->hostTmplTasks.begin() + first, ws->hostTmplTasks.begin() + first + count);
+            std::vector<uint64_t> jobP(T.nLeaves, ~0ull & kOffMask);
+            for (uint32_t q = 0; q < count; ++q) {
+                tk[q].outOff = (uint64_t)q * frCoef(2);
+                tk[q].sampleOff = (uint64_t)q * 729;
+                tk[q].errSlot = (uint32_t)rank * ws->d.errStride + q * HPSDF_JOB_HEADER_DOUBLES;
+                jobP[first + q] = tk[q].outOff;
+            }
+            std::vector<FitBlock> bl(nBl);
+            for (uint32_t k = 0; k < bl.size(); ++k) {
+                FitBlock& fb = bl[k];
+                std::memset(&fb, 0, sizeof fb);
+                fb.firstTask = k * (uint32_t)g;
+                fb.nTasks = (uint16_t)std::min<uint32_t>((uint32_t)g, count - k * (uint32_t)g);
+                fb.degree = 2;
+                fb.planesPerChunk = (uint8_t)pl;
+                fb.rowStart = 0, fb.rowEnd = (uint16_t)frCoef(2);
+                fb.depth = ws->hostTmplTasks[0].depth;
+            }
+            ws->r0Rank = ws->r0World = -1;
+            HPSDF_HIP(hipMemcpyAsync(ws->r0Tasks, tk.data(), count * sizeof(FitTask), hipMemcpyHostToDevice, s));
+            HPSDF_HIP(hipMemcpyAsync(ws->r0Blocks, bl.data(), bl.size() * sizeof(FitBlock), hipMemcpyHostToDevice, s));
+            HPSDF_HIP(hipMemcpyAsync(ws->r0JobP, jobP.data(), jobP.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+            HPSDF_HIP(hipStreamSynchronize(s));  // (pageable sources)
+            ws->r0Rank = rank, ws->r0World = world, ws->r0ErrStride = ws->d.errStride;
         }
-        std::vector<FitBlock> bl((count + g - 1) / g);
-        for (uint32_t k = 0; k < bl.size(); ++k) {
-            FitBlock& fb = bl[k];
-            std::memset(&fb, 0, sizeof fb);
-            fb.firstTask = k * (uint32_t)g;
-            fb.nTasks = (uint16_t)std::min<uint32_t>((uint32_t)g, count - k * (uint32_t)g);
-            fb.degree = 2;
-            fb.planesPerChunk = (uint8_t)pl;
-            fb.rowStart = 0, fb.rowEnd = (uint16_t)frCoef(2);
-            fb.depth = ws->hostTmplTasks[0].depth;
-        }
-        HPSDF_HIP(hipMemcpyAsync(ws->r0Tasks, tk.data(), count * sizeof(FitTask), hipMemcpyHostToDevice, s));
-        HPSDF_HIP(hipMemcpyAsync(ws->r0Blocks, bl.data(), bl.size() * sizeof(FitBlock), hipMemcpyHostToDevice, s));
-        HPSDF_HIP(hipMemcpyAsync(ws->r0JobP, jobP.data(), jobP.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-        HPSDF_HIP(hipStreamSynchronize(s));  // (pageable sources)
         r0Tasks = ws->r0Tasks, r0Blocks = ws->r0Blocks, r0JobP = ws->r0JobP;
         r0Lds = frLds(2, g, pl);
-        T0.nTasks = count, T0.nBlocks = (uint32_t)bl.size();
+        T0.nTasks = count, T0.nBlocks = nBl;
         T0.arenaRows = (uint64_t)count * frCoef(2), T0.samples = (uint64_t)count * 729;
     }
     {

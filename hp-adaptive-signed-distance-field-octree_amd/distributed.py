@@ -65,24 +65,46 @@ class _DevBytes:
 
 
 def device_allgather(ctx, group=None):
-    """The in-place all-gather hpsdf_create_distributed asks for, over torch.distributed: RCCL (backend nccl) on the
-    device buffer itself; gloo (CPU tests, one-GPU rehearsals) through host memory."""
+    """The in-place all-gather hpsdf_create_distributed asks for, over torch.distributed.
+
+    backend nccl (RCCL over xGMI): ONE all_gather_into_tensor on the device buffer itself, issued with the context's
+    stream as torch's current stream -- the collective is ordered behind the kernels that wrote this rank's part and the
+    kernels that read the result are ordered behind the collective, by stream order alone: no host synchronisation, no
+    staging copy (rank r's part already sits at its place in the receive buffer; RCCL's all-gather is in-place when the
+    send buffer is recvbuf + rank * count).  backend gloo (CPU tests, one-GPU rehearsals): through host memory.
+
+    ``gather.calls`` counts the exchanges (bench.py reports it per Create)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     on_device = dist.get_backend(group) == "nccl"
+    device = torch.device("cuda", ctx.device)
+    streams = {}
+    state = {"in_place": True}
 
     def gather(d_buf, nbytes, stream):
-        ctx.synchronize()  # this rank's part was written on the context's stream; the collective runs on torch's
-        buf = torch.as_tensor(_DevBytes(d_buf, nbytes * world), device=torch.device("cuda", ctx.device))
+        gather.calls += 1
+        buf = torch.as_tensor(_DevBytes(d_buf, nbytes * world), device=device)
         mine = buf[rank * nbytes:(rank + 1) * nbytes]
         if on_device:
-            dist.all_gather_into_tensor(buf, mine.clone(), group=group)
-            torch.cuda.current_stream().synchronize()
+            key = int(stream or 0)
+            ext = streams.get(key)
+            if ext is None:
+                ext = streams[key] = torch.cuda.ExternalStream(key, device=device) if key else torch.cuda.default_stream(device)
+            with torch.cuda.stream(ext):
+                if state["in_place"]:
+                    try:
+                        dist.all_gather_into_tensor(buf, mine, group=group)
+                        return
+                    except RuntimeError:  # a torch build that rejects the aliasing: one small device copy instead
+                        state["in_place"] = False
+                dist.all_gather_into_tensor(buf, mine.clone(), group=group)
         else:
+            ctx.synchronize()  # this rank's part was written on the context's stream
             parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
             dist.all_gather(parts, mine.cpu(), group=group)
             buf.copy_(torch.cat(parts))
             torch.cuda.current_stream().synchronize()
+    gather.calls = 0
     return gather
 
 
@@ -111,7 +133,10 @@ def create_distributed(ctx, config, field, K=0, group=None, compute=None, policy
         # the whole sharded build behind the C ABI (hpsdf_create_distributed): the device-side frontier for fields the GPU
         # evaluates itself without nearness weighting, the host scheduler's rounds for the rest -- both over this all-gather
         from . import create_block_distributed
-        return create_block_distributed(ctx, config, field, K, rank, world, device_allgather(ctx, group))
+        gather = device_allgather(ctx, group)
+        block, stats = create_block_distributed(ctx, config, field, K, rank, world, gather)
+        stats["exchanges"] = gather.calls
+        return block, stats
     # Nearness-weighted builds: the weight (pow / exp) is applied on the host (one libm for GPU path and oracle), so the
     # per-round errors pass through host memory, and after every round the ranks hand each other the coefficient arrays
     # that round accepted -- an incremental fit copies the node's previous rows and may run on any rank.

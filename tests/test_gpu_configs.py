@@ -421,6 +421,46 @@ def test_bench_two_ranks_sharing_this_gpu():
         assert k in out
 
 
+    assert len(out["create_sharded"]["ms_per_rank"]) == 2 and out["create_sharded"]["exchanges_per_create"] >= 2
+    assert len(out["mesh_create"]["create_ms_per_rank_1e-6"]) == 2 and out["mesh_create"]["exchanges_per_create_1e-6"] >= 3
+
+
+_NCCL_GATHER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+import hpsdf_loader, importlib
+H = hpsdf_loader.load(); D = importlib.import_module("hpsdf_amd.distributed")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29547", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+stream = torch.cuda.Stream()
+ctx = H.Context(0, stream.cuda_stream)
+gather = D.device_allgather(ctx)
+with torch.cuda.stream(stream):
+    buf = torch.arange(4096, dtype=torch.uint8, device="cuda").repeat(4)   # written on the context's stream ...
+    gather(buf.data_ptr(), buf.numel(), stream.cuda_stream)                 # ... gathered on it, no host wait in between
+    after = buf + 1                                                         # ... and read on it
+stream.synchronize()
+assert gather.calls == 1 and torch.equal(after.cpu(), (torch.arange(4096, dtype=torch.uint8).repeat(4) + 1))
+# the same through the whole sharded entry point is world > 1 only; here: the RCCL path accepts the in-place aliasing
+print("ok")
+dist.destroy_process_group()
+'''
+
+
+def test_nccl_allgather_runs_on_the_context_stream(tmp_path):
+    """distributed.device_allgather with backend nccl (= RCCL) on the one GPU present: the in-place all_gather_into_tensor
+    issued with the context's stream current -- what every rank of a sharded Create does twice per round on real multi-GPU
+    hardware (the 2- and 8-rank cases need as many GPUs; the driver's scaling run is their first execution)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = tmp_path / "nccl_gather.py"
+    script.write_text(_NCCL_GATHER)
+    r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_create_distributed_argument_checks(H, ctx):
     with pytest.raises(H.HpsdfError) as e:
         H.create_block_distributed(ctx, H.make_config(1e-6), H.Field.sphere(), 1024, 2, 2, lambda *a: None)
