@@ -139,6 +139,13 @@ struct FrDev {
     double* pack;          // [world][packStride] all-gathered pack buffers (this rank writes its own)
     uint64_t packStride;
     int32_t fastFit;       // degrees >= 4 fitted by fit_mfma.hip: 16 cells per workgroup
+    // nearness weighting (Octree.cpp:1071-1092, 1209-1247): a fit keeps ONE full coefficient array (an incremental fit
+    // carries the old rows over, :847), fit_weight_kernel leaves |mean FApprox| of every fit in `means`, the host turns
+    // the means into weights with its libm (pow / exp: what the oracle calls) and fr_weigh_kernel scales the errors
+    int32_t weighted;
+    double* means;          // [jobs][9], pinned host memory as the device addresses it (written by fit_weight_kernel)
+    const double* weights;  // [jobs][9], pinned host memory as the device addresses it (written by the host)
+    uint32_t* hostFlag;     // pinned: {jobs of the round, stamp}: "the means are there"
 };
 
 __host__ __device__ inline uint32_t frCoef(int p) { return p == 6 ? 83u : (uint32_t)((p + 1) * (p + 2) * (p + 3) / 6); }
@@ -148,7 +155,7 @@ __host__ __device__ inline size_t frLds(int degree, int g, int planes) {  // = f
     return ((size_t)(degree + 1) * nq + 2 * nq + 8 * (size_t)g + (size_t)g * planes * nq * nq) * sizeof(double);
 }
 // workgroup shape of `count` fits of one class: what fitShape (kernels.hip) gives an unweighted, sampled-or-analytic fit
-__host__ __device__ inline void frShape(int degree, bool incr, uint32_t count, int* cells, int* planes, bool fast = false) {
+__host__ __device__ inline void frShape(int degree, bool incr, uint32_t count, int* cells, int* planes, bool fast = false, bool weighted = false) {
     if (fast && degree >= 4 && degree <= 9) {  // the matrix-core fit: one workgroup = one tile of 16 cells
         *cells = kMfmaCells, *planes = 1;
         return;
@@ -167,6 +174,13 @@ __host__ __device__ inline void frShape(int degree, bool incr, uint32_t count, i
     const int nq = 4 * degree + 1;
     int pl = nq;
     while (pl > 1 && frLds(degree, g, pl) > kFitChunkLdsBytes) --pl;
+    if (weighted) {  // as fitShape: the sample region is reused for the full coefficient array + 100 FApprox values of every cell
+        const int need = (int)frCoef(degree) + 100;
+        const int minPlanes = (need + nq * nq - 1) / (nq * nq);
+        const int want = nq < minPlanes ? nq : minPlanes;
+        pl = pl > want ? pl : want;
+        while (g > 1 && frLds(degree, g, pl) > kFitMaxLdsBytes) --g;
+    }
     *cells = g;
     *planes = pl;
 }
@@ -551,10 +565,11 @@ __global__ __launch_bounds__(1024) void fr_batch_kernel(FrDev d) {
         if (myCount) {
             const int deg = (int)tid / kFrDepths / 2;
             const bool incr = ((int)tid / kFrDepths) & 1;
-            frShape(deg, incr, myCount, &g, &pl, d.fastFit != 0);
+            frShape(deg, incr, myCount, &g, &pl, d.fastFit != 0, d.weighted != 0);
             myBlocks = (myCount + (uint32_t)g - 1u) / (uint32_t)g;
             const uint64_t nq = 4 * (uint64_t)deg + 1;
-            myRows = (uint64_t)(incr ? frCoef(deg) - frCoef(deg - 1) : frCoef(deg)) * myCount;
+            // (a weighted fit owns a full array: the incremental one too)
+            myRows = (uint64_t)((incr && !d.weighted) ? frCoef(deg) - frCoef(deg - 1) : frCoef(deg)) * myCount;
             mySamples = nq * nq * nq * myCount;
         }
     }
@@ -636,7 +651,7 @@ __global__ __launch_bounds__(256) void fr_tasks_kernel(FrDev d) {
         slot = __shfl(slot, (lane & ~15) | (k < 8 ? 0 : 8), 64) + (k < 8 ? (uint32_t)k : 0u);
         uint64_t outOff = ~0ull;
         if (mine) {
-            const uint64_t rows = incr ? frCoef(deg) - frCoef(deg - 1) : frCoef(deg);
+            const uint64_t rows = (incr && !d.weighted) ? frCoef(deg) - frCoef(deg - 1) : frCoef(deg);
             const uint64_t nq = 4 * (uint64_t)deg + 1;
             FitTask t;
             for (int a = 0; a < 3; ++a) {
@@ -650,7 +665,8 @@ __global__ __launch_bounds__(256) void fr_tasks_kernel(FrDev d) {
             }
             outOff = arenaBase + R->cArena[c] + (uint64_t)slot * rows;
             t.outOff = outOff;
-            t.copyOff = ~0ull;
+            // weighted incremental fit: the cell's current array (one segment: fr_update_kernel keeps it that way), :847
+            t.copyOff = (d.weighted && incr) ? (d.segOff[(size_t)d.batchIdx[j] * kFrSegs] & kOffMask) : ~0ull;
             t.sampleOff = R->cSample[c] + (uint64_t)slot * nq * nq * nq;
             t.errSlot = (uint32_t)frErrSlot(d, h, j) + (k < 8 ? 1u + (uint32_t)k : 0u);
             t.depth = (uint8_t)depth;
@@ -682,7 +698,7 @@ __global__ __launch_bounds__(256) void fr_tasks_kernel(FrDev d) {
         fb.rowStart = (uint16_t)(incr ? frCoef(deg - 1) : 0);
         fb.rowEnd = (uint16_t)frCoef(deg);
         fb.depth = (uint8_t)(c % kFrDepths);
-        fb.weighted = 0;
+        fb.weighted = d.weighted ? 1 : 0;
         fb.pad1[0] = fb.pad1[1] = 0;
         d.blocks[b] = fb;
     }
@@ -937,8 +953,9 @@ __global__ __launch_bounds__(256) void fr_update_kernel(FrDev d) {
             if (kind == 1) {  // :253-260, :286-290
                 if (sub == 0) {
                     const int np = coarse ? 2 : p + 1;
-                    const int first = coarse ? 2 : (int)d.segFirst[idx];
-                    if (coarse) d.segFirst[idx] = 2;
+                    // (weighted: the new array holds every row, so it is the node's one and only segment)
+                    const int first = (coarse || d.weighted) ? np : (int)d.segFirst[idx];
+                    if (coarse || d.weighted) d.segFirst[idx] = (uint8_t)np;
                     d.segOff[(size_t)idx * kFrSegs + (np - first)] = (d.jobP[j] & kOffMask) | ((uint64_t)(d.world == 1 ? 0 : d.jobOwner[j]) << 56);
                     d.nodes[idx].degree = (uint8_t)np;
                     const double pErr = d.errs[frErrSlot(d, h, j)];
@@ -1173,6 +1190,27 @@ __global__ __launch_bounds__(256) void fr_pack_kernel(FrDev d) {
     }
 }
 
+// Nearness weighting.  fr_means_done_kernel tells the host that the round's means have reached its memory (they were written
+// there by fit_weight_kernel, the launch before this one: a kernel boundary on one stream); the host answers with the
+// weights, and fr_weigh_kernel scales this rank's errors -- error * weight, Octree.cpp:1078-1086 -- before anything reads them.
+__global__ void fr_means_done_kernel(FrDev d, uint32_t stamp) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    volatile uint32_t* f = d.hostFlag;
+    f[0] = d.hdr->nJobs;
+    __threadfence_system();
+    f[1] = stamp;
+    __threadfence_system();
+}
+__global__ __launch_bounds__(256) void fr_weigh_kernel(FrDev d, uint32_t stride) {  // stride 9: every error of a job; round 0: the first only
+    const FrHdr* h = d.hdr;
+    if (h->done) return;
+    const uint32_t nJobs = h->nJobs;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nJobs * 9u) return;
+    if (stride == 1u && i % 9u != 0u) return;
+    d.errs[i] = d.errs[i] * d.weights[i];
+}
+
 // per-build initialisation: the uniformly refined tree (a copy of the context's template) and the header.  Round 0's
 // batch, tasks and workgroups are the template's, used in place.
 struct FrTemplate {
@@ -1253,6 +1291,28 @@ struct FrontierWorkspace {
     std::vector<hpsdf_node> hostNodesAfterRound0;  // the node array of a tree that stops after round 0, serialised
     char* pinned = nullptr;                        // staging of the finished block
     size_t pinnedCap = 0;
+    // weighted builds: the round's |mean FApprox| values as the device writes them, the weights as the host answers, the
+    // "means are there" word pair (pinned, coherent: both sides watch them while the other writes)
+    double* hostMeans = nullptr;
+    double* hostWeights = nullptr;
+    uint32_t* hostFlag = nullptr;
+    uint32_t flagStamp = 0;
+    hipError_t ensureWeighting() {
+        if (hostMeans) return hipSuccess;
+        const size_t n = (size_t)kFrJobs * HPSDF_JOB_HEADER_DOUBLES;
+        hipError_t e = hipHostMalloc((void**)&hostMeans, n * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&hostWeights, n * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&hostFlag, 64, hipHostMallocCoherent | hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&d.means, hostMeans, 0);
+        if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&d.weights, hostWeights, 0);
+        if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&d.hostFlag, hostFlag, 0);
+        if (e == hipSuccess) {
+            std::memset(hostMeans, 0, n * sizeof(double));
+            for (size_t i = 0; i < n; ++i) hostWeights[i] = 1.0;
+            hostFlag[0] = hostFlag[1] = 0;
+        }
+        return e;
+    }
     // A round's fits are one launch per degree, and none of them fills the chip (a few hundred workgroups of two per CU):
     // degrees beyond the first go to side streams and run beside it
     static constexpr int kSide = 3;
@@ -1476,6 +1536,9 @@ struct FrontierWorkspace {
             if (p) (void)hipFree(p);
         if (hostHdr) (void)hipHostFree(hostHdr);
         if (pinned) (void)hipHostFree(pinned);
+        if (hostMeans) (void)hipHostFree(hostMeans);
+        if (hostWeights) (void)hipHostFree(hostWeights);
+        if (hostFlag) (void)hipHostFree(hostFlag);
         for (int k = 0; k < kSide; ++k) {
             if (side[k]) (void)hipStreamDestroy(side[k]);
             if (joinEv[k]) (void)hipEventDestroy(joinEv[k]);
@@ -1487,7 +1550,7 @@ struct FrontierWorkspace {
 bool frontierEligible(const hpsdf_config* cfg, const hpsdf_field* field, uint64_t K) {
     if (const char* e = std::getenv("HPSDF_HOST_FRONTIER"))
         if (e[0] == '1') return false;
-    if (cfg->weighting_type != 0) return false;   // the weight is pow/exp of the host's libm
+    if (cfg->weighting_type > 2) return false;    // (unknown weighting: the host scheduler reports it)
     if (cfg->enable_logging) return false;        // the per-job log line is printed by the host scheduler
     const hpsdf_field* in = innermost(field);
     if (!in || (in->kind != kHostAnalytic && in->kind != kHostMesh)) return false;  // callbacks are sampled by host threads
@@ -1534,9 +1597,20 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         ~Release() { w->inUse = false; }
     } release{ws};
     const uint32_t Kj = (uint32_t)(K ? K : HPSDF_DEFAULT_JOBS_PER_ROUND);
+    const bool weighted = cfg.weighting_type != 0;
+    if (weighted) {
+        if (cfg.weighting_type > 2) return fail(HPSDF_ERR_INVALID_ARGUMENT, "unknown nearnessWeighting.type");
+        if (!(cfg.weighting_strength > 0.0)) return fail(HPSDF_ERR_INVALID_ARGUMENT, "nearnessWeighting.strength must be > 0");
+        // (on several ranks a weighted incremental fit needs the node's previous rows, which another rank may hold: the
+        // host scheduler's sharded rounds exchange them, capi.cpp)
+        if (world > 1) return fail(HPSDF_ERR_UNSUPPORTED, "weighted builds on several ranks run the host scheduler's rounds");
+        const hipError_t e = ws->ensureWeighting();
+        if (e != hipSuccess) return hipFail(e, "frontier weighting buffers");
+    }
     ws->d.K = Kj;
     ws->d.rank = rank, ws->d.world = world;
-    ws->d.fastFit = (ctx->fastFit && field->kind != kHostTreeCsg) ? 1 : 0;
+    ws->d.weighted = weighted ? 1 : 0;
+    ws->d.fastFit = (ctx->fastFit && field->kind != kHostTreeCsg && !weighted) ? 1 : 0;
     ws->d.errStride = kFrJobs * HPSDF_JOB_HEADER_DOUBLES;
     {
         const hipError_t e = ws->ensureRanks(world, s);
@@ -1559,20 +1633,28 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         rm.centre[a] = (double)((cfg.root_min[a] + cfg.root_max[a]) / 2.0f);  // Octree.cpp:322
     }
     // launch-time LDS of a fit launch of `deg`: the largest shape the device may pick
-    static const auto fitLdsTable = [] {
+    auto makeLdsTable = [](bool w) {
         std::vector<size_t> t(kMaxDegree + 1, 0);
         for (int deg = 1; deg <= kMaxDegree; ++deg)
             for (int incr = 0; incr < 2; ++incr) {
                 int g, pl;
-                frShape(deg, incr != 0, 1u << 20, &g, &pl);  // g = the class's largest
+                frShape(deg, incr != 0, 1u << 20, &g, &pl, false, w);  // g = the class's largest
                 for (int gg = 1; gg <= g; ++gg) {
-                    int pp = 4 * deg + 1;
+                    const int nq = 4 * deg + 1;
+                    int pp = nq;
                     while (pp > 1 && frLds(deg, gg, pp) > kFitChunkLdsBytes) --pp;
+                    if (w) {  // frShape's weighted adjustment
+                        const int minPlanes = ((int)frCoef(deg) + 100 + nq * nq - 1) / (nq * nq);
+                        pp = std::max(pp, std::min(nq, minPlanes));
+                        if (gg > 1 && frLds(deg, gg, pp) > kFitMaxLdsBytes) continue;  // (frShape stacks fewer cells)
+                    }
                     t[deg] = std::max(t[deg], frLds(deg, gg, pp));
                 }
             }
         return t;
-    }();
+    };
+    static const std::vector<size_t> fitLdsPlain = makeLdsTable(false), fitLdsWeighted = makeLdsTable(true);
+    const std::vector<size_t>& fitLdsTable = weighted ? fitLdsWeighted : fitLdsPlain;
     auto rowsPerJob = [](int pmax) {  // arena rows one job can need when no leaf exceeds degree pmax
         const int p = std::min(pmax, kMaxDegree - 1);
         return (uint64_t)8 * frCoef(p) + frCoef(std::min(p + 1, kMaxDegree));
@@ -1585,7 +1667,44 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
     FrDev& d = ws->d;
     const FrTemplate& T = ws->tmpl;
     const FrHdr* hh = ws->hostHdr;
-    double tSync = 0;
+    double tSync = 0, tWeights = 0;
+    // Weighted builds, once per round behind the fits: |mean FApprox| of every fit (fit_weight_kernel, straight into pinned
+    // host memory) -> the weight, with the HOST's pow / exp (Octree.cpp:1224-1226, :1246: the libm the oracle and the host
+    // scheduler call; a device pow would have to match it bit for bit) -> error * weight on the device (:1078-1086).
+    // Everything else of the round -- selection, tasks, decision, bookkeeping, packing -- stays where it is.
+    auto applyWeights = [&](const FitBlock* blocks, uint32_t maxBlocks, size_t lds, const FitTask* tasks, const uint32_t* dCount, bool round0) -> int {
+        HPSDF_HIP(launchFitWeight(s, blocks, maxBlocks, lds, tasks, ws->arena, d.means, ctx->dTables, dCount));
+        const uint32_t stamp = ++ws->flagStamp;
+        hipLaunchKernelGGL(fr_means_done_kernel, dim3(1), dim3(64), 0, s, d, stamp);
+        const double ts = now();
+        {
+            const volatile uint32_t* flag = ws->hostFlag;
+            const double limit = ts + 2.0e3;
+            while (flag[1] != stamp && now() < limit) frCpuRelax();
+            if (flag[1] != stamp) HPSDF_HIP(hipStreamSynchronize(s));
+            std::atomic_thread_fence(std::memory_order_acquire);
+            if (flag[1] != stamp) return fail(HPSDF_ERR_STATE, "frontier: the round's means did not arrive");
+        }
+        const double tw = now();
+        tSync += tw - ts;
+        const uint32_t nJobs = std::min<uint32_t>(ws->hostFlag[0], kFrJobs);
+        const double dd = std::sqrt(3.0), strength = cfg.weighting_strength;
+        const double* mean = ws->hostMeans;
+        double* w = ws->hostWeights;
+        const uint32_t step = round0 ? 9u : 1u;  // round 0: every job is a coarse cell with one fit (slot 0 of its nine)
+        for (uint32_t i = 0; i < nJobs * 9u; i += step) {
+            if (cfg.weighting_type == 1) {
+                const double k = std::pow(1.0 - mean[i] / dd, strength);
+                w[i] = std::min<double>(1.0, std::max<double>(k, 0.0));
+            } else {
+                w[i] = std::exp(-1.0 * strength * mean[i] / dd);
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_release);
+        tWeights += now() - tw;
+        hipLaunchKernelGGL(fr_weigh_kernel, dim3((std::max(1u, nJobs) * 9u + 255u) / 256u), dim3(256), 0, s, d, round0 ? 1u : 9u);
+        return HPSDF_OK;
+    };
     uint8_t* early = nullptr;  // the block of a build that stops after round 0, begun before the device has finished
     struct FreeEarly {
         uint8_t** p;
@@ -1664,6 +1783,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
             fdr.samples = ws->samples;
         }
         HPSDF_HIP(launchFit(s, 2, 1, r0Blocks, T0.nBlocks, r0Lds, r0Tasks, ws->arena, d.errs, nullptr, ctx->dTables, fdr, rm));
+        if (weighted && (rc = applyWeights(r0Blocks, T0.nBlocks, r0Lds, r0Tasks, nullptr, true))) return rc;
         if ((rc = exchange(d.errs, (size_t)d.errStride * sizeof(double), "round 0"))) return rc;
         FrDev d0 = d;
         d0.batchIdx = ws->tmplLeaves, d0.batchErr = ws->tmplErr, d0.jobP = r0JobP, d0.jobH = r0JobP;
@@ -1761,6 +1881,11 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
                 HPSDF_HIP(hipEventRecord(ws->joinEv[k], ws->side[k]));
                 HPSDF_HIP(hipStreamWaitEvent(s, ws->joinEv[k], 0));
             }
+        if (weighted) {
+            size_t lds = 0;
+            for (int deg = 2; deg <= degHi; ++deg) lds = std::max(lds, fitLdsTable[deg]);
+            if ((rc = applyWeights(d.blocks, taskBound, lds, d.tasks, &d.hdr->nBlocks, false))) return rc;
+        }
         if ((rc = exchange(d.errs, (size_t)d.errStride * sizeof(double), "a round's errors"))) return rc;
         hipLaunchKernelGGL(fr_decide_kernel, dim3(1), dim3(1024), 0, s, d);
         hipLaunchKernelGGL(fr_update_kernel, dim3(1 + (Kj + 31) / 32), dim3(256), 0, s, d);
@@ -1863,8 +1988,8 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         stats->n_nodes = nn, stats->n_leaves = hh->nLeaves, stats->n_coeffs = nc, stats->total_error = hh->total;
     }
     if (trace)
-        std::fprintf(stderr, "[frontierCreate] us: total %.0f (waiting for the device %.0f over %d rounds, block download %.0f)\n", now() - t0, tSync,
-                     rounds, tcopy);
+        std::fprintf(stderr, "[frontierCreate] us: total %.0f (waiting for the device %.0f over %d rounds, weights on the host %.0f, block download %.0f)\n",
+                     now() - t0, tSync, rounds, tWeights, tcopy);
     return HPSDF_OK;
 }
 

@@ -2097,10 +2097,11 @@ __global__ __launch_bounds__(kFitThreads, HPSDF_FIT_MIN_WAVES) void fit_multi_ke
 // (pow / exp) is applied by the host so that it matches the CPU path bit for bit.
 __global__ __launch_bounds__(kFitThreads) void fit_weight_kernel(const FitBlock* __restrict__ blocks, const FitTask* __restrict__ tasks,
                                                                  const double* __restrict__ arena, double* __restrict__ means,
-                                                                 const DeviceTables* __restrict__ T) {
+                                                                 const DeviceTables* __restrict__ T, const uint32_t* __restrict__ count) {
     extern __shared__ double lds[];
     __shared__ double sNl[13 * 11];
     __shared__ double sRec[26];
+    if (count != nullptr && blockIdx.x >= *count) return;  // (the device-side frontier writes the round's block count; the grid is an upper bound)
     const FitBlock blk = blocks[blockIdx.x];
     const int tid = threadIdx.x, deg = blk.degree, depth = blk.depth, G = blk.nTasks, nc = blk.rowEnd;
     stageQueryTables(T, sNl, sRec);
@@ -2474,9 +2475,9 @@ hipError_t launchMeshSampleRange(hipStream_t stream, const FitTask* dTasks, cons
 
 // weighted builds: |mean FApprox| of every fit of the blocks (full coefficient arrays at FitTask::outOff)
 hipError_t launchFitWeight(hipStream_t stream, const FitBlock* dBlocks, uint32_t nBlocks, size_t ldsBytes, const FitTask* dTasks,
-                           const double* dArena, double* dMeans, const DeviceTables* dTables) {
+                           const double* dArena, double* dMeans, const DeviceTables* dTables, const uint32_t* dCount) {
     if (nBlocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(fit_weight_kernel, dim3(nBlocks), dim3(kFitThreads), ldsBytes, stream, dBlocks, dTasks, dArena, dMeans, dTables);
+    hipLaunchKernelGGL(fit_weight_kernel, dim3(nBlocks), dim3(kFitThreads), ldsBytes, stream, dBlocks, dTasks, dArena, dMeans, dTables, dCount);
     return hipGetLastError();
 }
 

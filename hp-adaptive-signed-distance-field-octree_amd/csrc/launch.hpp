@@ -35,7 +35,7 @@ hipError_t launchFitMulti(hipStream_t stream, const FitBlock* dBlocks, uint32_t 
                           double* dArena, double* dErrs, const DeviceTables* dTables, const FieldDev& field, const RootMap& rm,
                           const uint32_t* dCount);
 hipError_t launchFitWeight(hipStream_t stream, const FitBlock* dBlocks, uint32_t nBlocks, size_t ldsBytes, const FitTask* dTasks,
-                           const double* dArena, double* dMeans, const DeviceTables* dTables);
+                           const double* dArena, double* dMeans, const DeviceTables* dTables, const uint32_t* dCount = nullptr);
 // opt-in fast fit of degrees 4..11 on the matrix cores (fit_mfma.hip): blocks of at most 16 fits, NOT bit-identical to launchFit
 constexpr int kMfmaCells = 16;
 bool fitMfmaSupports(int degree, const FieldDev& field);
