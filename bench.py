@@ -397,20 +397,20 @@ def main():
         # the same Query on every host core (Octree::Query is const: the reference's own parallel use), ~4 s: one pthread per
         # core inside the oracle's C loop (ora_query_batch_mt) -- no interpreter, no GIL between the cores and the points
         ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        otree.query(pts[:m], threads=ncores)  # warm
-        tall, apasses = 0.0, 0
-        while tall < 4.0:
-            t0 = time.perf_counter()
-            otree.query(pts[:m], threads=ncores)
-            tall += time.perf_counter() - t0
-            apasses += 1
+        t0 = time.perf_counter()
+        otree.query(pts[:m], threads=ncores, passes=4)  # warm, and a first estimate of a pass
+        est = (time.perf_counter() - t0) / 4
+        apasses = int(max(4, min(4000, 4.0 / max(est, 1e-4))))  # ~4 s in ONE call: the threads start once, each repeats its part
+        t0 = time.perf_counter()
+        otree.query(pts[:m], threads=ncores, passes=apasses)
+        tall = time.perf_counter() - t0
         tca = []
         for _ in range(3):  # ... and Create with a round's jobs on every core (same tree: the jobs of a round are pure)
             t0 = time.perf_counter()
             O.Tree.create(O.default_config(TARGET), O.union3_field(), JOBS_PER_ROUND, threads=ncores)
             tca.append(time.perf_counter() - t0)
         out["cpu_baseline_all_cores"] = {"value": apasses * m / tall / 1e6, "unit": "Mpts/s", "cores": ncores, "kind": "port",
-                                         "sample": "oracle Query() over the same %d points cut into %d contiguous parts, one pthread each, "
+                                         "sample": "oracle Query() over the same %d points cut into %d contiguous parts, one pthread each (started once), "
                                                    "%d whole passes (%.1f s); oracle Create() with a round's jobs on %d pthreads, median of 3"
                                                    % (m, ncores, apasses, tall, ncores),
                                          "create_ms": float(np.median(tca)) * 1e3}

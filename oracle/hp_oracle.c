@@ -987,20 +987,26 @@ typedef struct {
     const double* xyz;
     size_t n;
     double* out;
+    int passes;
 } query_part;
 static void* query_worker(void* arg) {
     const query_part* q = (const query_part*)arg;
-    ora_query_batch(q->t, q->xyz, q->n, q->out);
+    for (int p = 0; p < q->passes; ++p) ora_query_batch(q->t, q->xyz, q->n, q->out);
     return NULL;
 }
 void ora_query_batch_mt(const ora_tree* t, const double* xyz, size_t n, double* out, int threads) {
+    ora_query_batch_mt_passes(t, xyz, n, out, threads, 1);
+}
+/* the same, every thread going over its part `passes` times (a timing loop that starts its threads once: starting and
+ * joining 256 threads costs more than one pass over 10 M points) */
+void ora_query_batch_mt_passes(const ora_tree* t, const double* xyz, size_t n, double* out, int threads, int passes) {
     if (threads < 1) threads = 1;
     if ((size_t)threads > n) threads = n ? (int)n : 1;
     pthread_t* tids = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
     query_part* parts = (query_part*)malloc(sizeof(query_part) * (size_t)threads);
     for (int k = 0; k < threads; ++k) {
         const size_t a = n * (size_t)k / (size_t)threads, b = n * (size_t)(k + 1) / (size_t)threads;
-        parts[k].t = t, parts[k].xyz = xyz + 3 * a, parts[k].n = b - a, parts[k].out = out + a;
+        parts[k].t = t, parts[k].xyz = xyz + 3 * a, parts[k].n = b - a, parts[k].out = out + a, parts[k].passes = passes;
         if (k) pthread_create(&tids[k], NULL, query_worker, &parts[k]);
     }
     query_worker(&parts[0]);

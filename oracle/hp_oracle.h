@@ -187,6 +187,7 @@ ora_tree* ora_tree_from_block(const void* block, size_t size);
 double ora_query(const ora_tree* t, const double pt[3]);
 void ora_query_batch(const ora_tree* t, const double* xyz, size_t n, double* out);
 void ora_query_batch_mt(const ora_tree* t, const double* xyz, size_t n, double* out, int threads);
+void ora_query_batch_mt_passes(const ora_tree* t, const double* xyz, size_t n, double* out, int threads, int passes);
 /* Octree::QueryWithGradient / FApproxWithGradient, Octree.cpp:749-789, 904-985 */
 double ora_fapprox_with_gradient(const double* coeffs, int degree, const float bmin[3], const float bmax[3],
                                  const double pt[3], int depth, double grad[3]);

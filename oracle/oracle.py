@@ -112,6 +112,7 @@ def lib():
     L.ora_create_mt.restype = C.c_void_p
     L.ora_create_mt.argtypes = [C.POINTER(Config), C.POINTER(Field), C.c_uint64, C.c_int, C.POINTER(BuildStats), C.c_int]
     L.ora_query_batch_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+    L.ora_query_batch_mt_passes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int]
     L.ora_tree_free.argtypes = [C.c_void_p]
     L.ora_tree_block_size.restype = C.c_size_t
     L.ora_tree_block_size.argtypes = [C.c_void_p]
@@ -341,11 +342,14 @@ class Tree:
         L.ora_tree_to_block(self.handle, buf)
         return buf.raw
 
-    def query(self, pts, threads=1):
+    def query(self, pts, threads=1, passes=1):
+        """threads > 1: the points cut into that many contiguous parts, one pthread each, every thread going over its part
+        `passes` times (timing loops: the threads are started once)."""
         pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)
         out = np.empty(len(pts))
         if threads > 1:
-            lib().ora_query_batch_mt(self.handle, pts.ctypes.data_as(C.c_void_p), len(pts), out.ctypes.data_as(C.c_void_p), threads)
+            lib().ora_query_batch_mt_passes(self.handle, pts.ctypes.data_as(C.c_void_p), len(pts), out.ctypes.data_as(C.c_void_p), threads,
+                                            passes)
         else:
             lib().ora_query_batch(self.handle, pts.ctypes.data_as(C.c_void_p), len(pts), out.ctypes.data_as(C.c_void_p))
         return out
