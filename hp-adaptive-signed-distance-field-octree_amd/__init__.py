@@ -118,6 +118,7 @@ _SIGNATURES = {
     "hpsdf_field_eval_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hpsdf_field_eval_naive_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hpsdf_field_eval_wave_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hpsdf_field_eval_lane_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hpsdf_tree_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "hpsdf_tree_destroy": (C.c_int, [C.c_void_p]),
     "hpsdf_tree_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
@@ -375,6 +376,15 @@ class Field:
         pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)
         out = np.empty(len(pts))
         check(lib().hpsdf_field_eval_wave_host(ctx.handle, self.handle, pts.ctypes.data_as(C.c_void_p), len(pts),
+                                               out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def eval_lane(self, ctx, pts):
+        """Mesh fields: the per-point stack traversal (what the fused mesh fit and a mesh under a tree-CSG wrapper run;
+        eval() itself takes the shared traversal for plain mesh fields): same bits."""
+        pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)
+        out = np.empty(len(pts))
+        check(lib().hpsdf_field_eval_lane_host(ctx.handle, self.handle, pts.ctypes.data_as(C.c_void_p), len(pts),
                                                out.ctypes.data_as(C.c_void_p)))
         return out
 

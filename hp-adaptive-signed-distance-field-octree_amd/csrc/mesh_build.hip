@@ -199,15 +199,17 @@ __global__ __launch_bounds__(256) void mb_fit_kernel(const uint32_t* __restrict_
 
 // Slabs (NodeSlab, device_types.hpp): for every child of every node the traversal can visit, a unit vector n, a point g and
 // two radii such that every point x of the child's triangles has |n . (x - g)| <= e and |x - g| <= rho.  One wave per node;
-// a child's triangles are the sorted slots [a, b], read three times: the sum of the (area-weighted) normals gives n; the
-// range of n . (v - c) over the vertices, c the centre of the child's box, puts g in the middle of the slab; then e and rho
-// are measured against that very g with the arithmetic the traversal uses for its sample (n . (p - g), |p - g|), widened by
-// 1e-5 of themselves -- what rounding leaves open beyond that is a few ulps of the mesh's extent and belongs to the
-// traversal's slack (2e-5 of that extent, meshSlack).  The bound is valid for ANY n of unit length: how n was chosen only
+// a child's triangles are the sorted slots [a, b], read twice: the sum of the (area-weighted) normals gives n; the range of
+// n . (v - c) over the vertices, c the centre of the child's box, puts g in the middle of the slab and gives e, the largest
+// |v - c| gives rho (both with explicit allowances for their own rounding, below) -- what rounding leaves open beyond that
+// is a few ulps of the mesh's extent and belongs to the traversal's slack (2e-6 of that extent, meshSlack).  The bound is valid for ANY n of unit length: how n was chosen only
 // decides how thin the slab is (a patch that bends back on itself gets a thick one and is pruned by its ball and box alone).
 // Children of more than kSlabMaxTris triangles get the ball around their box and e = -1, "no slab": up there the boxes
 // decide, a wave would loop for too long, and a surface is rarely flat at that scale.
-constexpr int kSlabMaxTris = 2048;
+#ifndef HPSDF_SLAB_MAX_TRIS
+#define HPSDF_SLAB_MAX_TRIS 1024
+#endif
+constexpr int kSlabMaxTris = HPSDF_SLAB_MAX_TRIS;
 __device__ __forceinline__ float mbWaveSum(float v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -250,29 +252,27 @@ __global__ __launch_bounds__(256) void mb_slab_kernel(const int32_t* __restrict_
             } else {
                 nx = ny = nz = 0.0f;
             }
-            float tmin = inf, tmax = -inf;
+            // one pass over the vertices: the range of n . (v - c) and the largest |v - c|, c the centre of the child's box
+            float tmin = inf, tmax = -inf, r2 = 0.0f;
             for (int s = a + lane; s <= b; s += 64) {
                 const float* p = triPos + (size_t)kTriRecordFloats * slotTri[s];
                 for (int v = 0; v < 3; ++v) {
-                    const float t = nx * (p[3 * v] - cx) + (ny * (p[3 * v + 1] - cy) + nz * (p[3 * v + 2] - cz));
+                    const float dx = p[3 * v] - cx, dy = p[3 * v + 1] - cy, dz = p[3 * v + 2] - cz;
+                    const float t = nx * dx + (ny * dy + nz * dz);
                     tmin = fminf(tmin, t), tmax = fmaxf(tmax, t);
-                }
-            }
-            tmin = -mbWaveMax(-tmin), tmax = mbWaveMax(tmax);
-            const float mid = 0.5f * (tmin + tmax);
-            const float gx = cx + mid * nx, gy = cy + mid * ny, gz = cz + mid * nz;
-            float e = 0.0f, r2 = 0.0f;
-            for (int s = a + lane; s <= b; s += 64) {
-                const float* p = triPos + (size_t)kTriRecordFloats * slotTri[s];
-                for (int v = 0; v < 3; ++v) {
-                    const float dx = p[3 * v] - gx, dy = p[3 * v + 1] - gy, dz = p[3 * v + 2] - gz;
-                    e = fmaxf(e, fabsf(nx * dx + (ny * dy + nz * dz)));
                     r2 = fmaxf(r2, dx * dx + (dy * dy + dz * dz));
                 }
             }
-            e = mbWaveMax(e), r2 = mbWaveMax(r2);
-            const float rho = sqrtf(r2) * 1.00001f + 1e-30f;
-            e = e * 1.00001f + 1e-30f;
+            tmin = -mbWaveMax(-tmin), tmax = mbWaveMax(tmax), r2 = mbWaveMax(r2);
+            // g in the middle of the slab.  With g = c + mid n (rounded: each coordinate off by <= u |g_i|, u = 2^-24):
+            //   n . (v - g) = n . (v - c) - mid |n|^2 - n . (rounding of g)   =>  |n . (v - g)| <= (tmax - tmin) / 2 + 4 u |v - c| + 6 u |mid| + 2 u M
+            //   |v - g| <= |v - c| + |mid| (1 + 3 u) + 2 u M                      (M: the largest coordinate around here)
+            // -- both widened by 1e-5 of themselves and 4e-7 of the local scale, i.e. twice what the terms above come to
+            const float mid = 0.5f * (tmin + tmax), rc = sqrtf(r2);
+            const float gx = cx + mid * nx, gy = cy + mid * ny, gz = cz + mid * nz;
+            const float local = fmaxf(fmaxf(fabsf(cx), fabsf(cy)), fabsf(cz)) + rc;
+            float e = (0.5f * (tmax - tmin)) * 1.00001f + 4e-7f * local;
+            const float rho = (rc + fabsf(mid)) * 1.00001f + 4e-7f * local;
             if (rho < inf && e < inf && gx - gx == 0.0f && gy - gy == 0.0f && gz - gz == 0.0f) {  // (non-finite input: no bound)
                 og = make_float4(gx, gy, gz, rho);
                 on = make_float4(nx, ny, nz, e);

@@ -165,6 +165,9 @@ HPSDF_API int hpsdf_field_eval_naive_host(hpsdf_ctx* ctx, const hpsdf_field* f, 
  * uses: 64 consecutive points share one walk of the BVH.  Same values as hpsdf_field_eval_host bit for bit, whatever the
  * order of the points; faster when neighbours in the array are neighbours in space.  Mesh fields only. */
 HPSDF_API int hpsdf_field_eval_wave_host(hpsdf_ctx* ctx, const hpsdf_field* f, const double* xyz, size_t n, double* out);
+/* The same through the per-point stack traversal (what a mesh field under a tree-CSG wrapper and the fused mesh fit run;
+ * hpsdf_field_eval_* itself takes the faster shared traversal for plain mesh fields): same bits.  Diagnostics. */
+HPSDF_API int hpsdf_field_eval_lane_host(hpsdf_ctx* ctx, const hpsdf_field* f, const double* xyz, size_t n, double* out);
 /* Diagnostics (no reference counterpart; HPSDF_ERR_UNSUPPORTED unless the library was built with
  * -DHPSDF_MESH_STATS_BUILD): BVH traversal counters of a mesh field created while the environment
  * variable HPSDF_MESH_STATS was set -- out[0] wave-wide closest-triangle queries (64 points each), [1] BVH nodes they visited,

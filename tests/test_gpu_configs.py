@@ -131,7 +131,7 @@ def test_mesh_bvh_equals_linear_scan_bitwise(H, O, ctx):
         f = H.Field.mesh(ctx, verts, tris)
         pts = O.splitmix64_points(4000, seed=3)
         a, b = f.eval(ctx, pts), f.eval_naive(ctx, pts)
-        assert np.array_equal(bits(a), bits(b))
+        assert np.array_equal(bits(a), bits(b)) and np.array_equal(bits(f.eval_lane(ctx, pts)), bits(b))
         want, _, _ = O.MeshField(verts, tris).signed_distance(pts[:500])
         assert np.abs(b[:500] - want.astype(np.float64)).max() <= TOL
 
@@ -162,7 +162,8 @@ def test_tiny_meshes_through_the_device_build(H, ctx):
     for verts, tris in ((tetra_v, tetra_t), (octa_v, octa_t)):
         f = H.Field.mesh(ctx, verts, tris)
         want = f.eval_naive(ctx, pts)
-        assert np.array_equal(bits(f.eval(ctx, pts)), bits(want)) and np.array_equal(bits(f.eval_wave(ctx, pts)), bits(want))
+        assert np.array_equal(bits(f.eval_lane(ctx, pts)), bits(want)) and np.array_equal(bits(f.eval_wave(ctx, pts)), bits(want))
+        assert np.array_equal(bits(f.eval(ctx, pts)), bits(want))
         assert (want < 0).any() and (want > 0).any()
         blk, st = H.create_block(ctx, H.make_config(1e-3), f, 1024)
         assert st["n_nodes"] >= 4681
@@ -199,7 +200,7 @@ def test_mesh_lower_bound_filter_keeps_the_scan_winner(H, O, ctx, monkeypatch, h
         f = H.Field.mesh(ctx, verts, tris)
         pts = _hard_points(O, verts, tris, seed)
         want = f.eval_naive(ctx, pts)
-        assert np.array_equal(bits(f.eval(ctx, pts)), bits(want)), name
+        assert np.array_equal(bits(f.eval_lane(ctx, pts)), bits(want)), name
         assert np.array_equal(bits(f.eval_wave(ctx, pts)), bits(want)), name
         perm = np.random.default_rng(seed).permutation(len(pts))
         assert np.array_equal(bits(f.eval_wave(ctx, pts[perm])), bits(want[perm])), name

@@ -55,8 +55,8 @@ def test_full_size_hierarchy_equals_linear_scan_bitwise(H, ctx, torus, torus_bui
     f = torus_build[0]
     pts = _probe_points(verts, tris, lo, hi, 2048, 11)
     want = f.eval_naive(ctx, pts)
-    assert np.array_equal(bits(f.eval(ctx, pts)), bits(want))
-    assert np.array_equal(bits(f.eval_wave(ctx, pts)), bits(want))
+    assert np.array_equal(bits(f.eval_lane(ctx, pts)), bits(want))
+    assert np.array_equal(bits(f.eval_wave(ctx, pts)), bits(want)) and np.array_equal(bits(f.eval(ctx, pts)), bits(want))
     # neighbours in the array are neighbours in space for the sampler; shuffled they are not: same values either way
     perm = np.random.default_rng(1).permutation(len(pts))
     assert np.array_equal(bits(f.eval_wave(ctx, pts[perm])), bits(want[perm]))

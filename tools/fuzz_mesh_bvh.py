@@ -64,7 +64,7 @@ for seed in range(first, first + cases):
     f = H.Field.mesh(ctx, verts, tris)
     pts = _hard_points(None, verts, tris, seed)
     want = f.eval_naive(ctx, pts)
-    a, w = f.eval(ctx, pts), f.eval_wave(ctx, pts)
+    a, w = f.eval_lane(ctx, pts), f.eval_wave(ctx, pts)
     ok = np.array_equal(bits(a), bits(want)) and np.array_equal(bits(w), bits(want))
     note = ""
     if not ok and np.array_equal(bits(a), bits(w)):
