@@ -397,6 +397,20 @@ def main():
         # the same Query on every host core (Octree::Query is const: the reference's own parallel use), ~4 s: one pthread per
         # core inside the oracle's C loop (ora_query_batch_mt) -- no interpreter, no GIL between the cores and the points
         ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        visible = ncores
+        try:  # a container's CPU share (cgroup v2 cpu.max / v1 cfs quota) can be far below the cores it can see
+            quota = None
+            if os.path.exists("/sys/fs/cgroup/cpu.max"):
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+                quota = None if q == "max" else float(q) / float(per)
+            elif os.path.exists("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+                q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+                per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                quota = None if q <= 0 else q / per
+            if quota:
+                ncores = max(1, min(ncores, int(quota + 0.999)))
+        except Exception:
+            pass
         t0 = time.perf_counter()
         otree.query(pts[:m], threads=ncores, passes=4)  # warm, and a first estimate of a pass
         est = (time.perf_counter() - t0) / 4
@@ -413,7 +427,7 @@ def main():
                                          "sample": "oracle Query() over the same %d points cut into %d contiguous parts, one pthread each (started once), "
                                                    "%d whole passes (%.1f s); oracle Create() with a round's jobs on %d pthreads, median of 3"
                                                    % (m, ncores, apasses, tall, ncores),
-                                         "create_ms": float(np.median(tca)) * 1e3}
+                                         "create_ms": float(np.median(tca)) * 1e3, "visible_cpus": visible}
         out["cpu_baseline"] = {"value": passes * m / tq / 1e6, "unit": "Mpts/s", "cores": 1, "kind": "port",
                                "sample": "oracle Query() over the same %d points, %d whole passes (%.1f s); "
                                          "oracle Create() of the same config, median of 3" % (m, passes, tq),

@@ -28,7 +28,7 @@ hipError_t launchFit(hipStream_t, int, int, const FitBlock*, uint32_t, size_t, c
 hipError_t launchFitMulti(hipStream_t, const FitBlock*, uint32_t, size_t, const FitTask*, double*, double*, const DeviceTables*, const FieldDev&,
                           const RootMap&, const uint32_t*) { return hipErrorNoDevice; }
 hipError_t launchPack(hipStream_t, const PackItem*, uint32_t, const double*, double*) { return hipErrorNoDevice; }
-hipError_t launchFitWeight(hipStream_t, const FitBlock*, uint32_t, size_t, const FitTask*, const double*, double*, const DeviceTables*) { return hipErrorNoDevice; }
+hipError_t launchFitWeight(hipStream_t, const FitBlock*, uint32_t, size_t, const FitTask*, const double*, double*, const DeviceTables*, const uint32_t*) { return hipErrorNoDevice; }
 hipError_t launchFitMfma(hipStream_t, int, const FitBlock*, uint32_t, const FitTask*, double*, double*, const DeviceTables*, const FieldDev&,
                          const RootMap&, const uint32_t*) { return hipErrorNoDevice; }
 hipError_t launchCgIterations(hipStream_t, const CgDev&, int, int) { return hipErrorNoDevice; }
