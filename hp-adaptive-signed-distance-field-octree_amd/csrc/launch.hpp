@@ -53,7 +53,7 @@ hipError_t launchFieldEval(hipStream_t stream, const FieldDev& f, const DeviceTa
 hipError_t launchMeshEvalWave(hipStream_t stream, const FieldDev& f, const double* dXyz, size_t n, double* dOut);
 hipError_t launchMeshNaive(hipStream_t stream, const FieldDev& f, const double* dXyz, size_t n, double* dOut);
 constexpr int kTriRecordFloats = 12;  // MeshDev::triPos: a, b, c, cross(b - a, c - a)
-constexpr int kTriPreFloats = 8;      // MeshDev::triPre: g, rho, unit normal, triangle index
+constexpr int kTriPreFloats = 12;     // MeshDev::triPre: g hu | unit normal hv | unit edge vector, triangle index
 // dSlotTri: which triangle sits in leaf slot s (nullptr: slot s = triangle s); either output may be nullptr (skipped)
 hipError_t launchMeshTriPos(hipStream_t stream, const float* dVerts, const uint32_t* dTris, uint64_t nTris, float* dTriPos,
                             const uint32_t* dSlotTri, float* dTriPre);
