@@ -349,7 +349,13 @@ HPSDF_API int hpsdf_create(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_
  * decided and the tree updated on every rank's GPU).  Host callbacks, nearness-weighted configs, logging and K > 4096 run
  * the host scheduler's rounds, sharded the same way: the exchanges are staged through a device buffer for the same
  * `gather`, and a weighted build also hands the arrays each round accepted to every rank (hpsdf_build_rows_*).
- * The stepwise hpsdf_build_* calls expose the same loop to callers with a transport of their own. */
+ * The stepwise hpsdf_build_* calls expose the same loop to callers with a transport of their own.
+ * Fields the device evaluates itself run the device-side frontier on up to 8 ranks when the config has no nearness weighting;
+ * weighted configs on several ranks and worlds beyond 8 run the host scheduler's sharded rounds (same bytes).
+ * FAILURES: a rank whose part of the build fails (out of memory, a launch error) returns its error at once and does NOT
+ * enter the exchanges that would have followed; the other ranks then wait in their next all-gather.  A caller that gets a
+ * non-zero status from any rank must abort the communicator (ncclCommAbort / torch.distributed's abort) -- as for any
+ * collective program whose ranks can fail independently. */
 typedef int (*hpsdf_allgather_fn)(void* user, void* d_buf, size_t bytes_per_rank, void* stream);
 HPSDF_API int hpsdf_create_distributed(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* field,
                                        uint64_t max_jobs_per_round, int rank, int world, hpsdf_allgather_fn gather,
