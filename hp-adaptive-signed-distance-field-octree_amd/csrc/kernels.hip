@@ -586,6 +586,7 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool active, M
             if (better) best = d, bestTri = t, bestSlot = slot, bestCode = code, rj = rejectBound(d, slack);
             return better;
         };
+        uint32_t restMask = 0u, seedFirst = 0u;
         if (active) {
             int32_t c = 0;
             do {
@@ -600,17 +601,27 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool active, M
                 c = second ? nd.c1 : nd.c0;
             } while (c >= 0);
             const uint32_t first = leafFirst(c), cnt = leafCount(c);
+            seedFirst = first;
             uint32_t kMin = 0;
             float lbMin = inf;
             for (uint32_t k = 0; k < cnt; ++k) {
                 const float lb = triLowerBound2(pt, loadTriPre(m, first + k));
                 if (lb < lbMin) lbMin = lb, kMin = k;
             }
-            for (uint32_t kk = 0; kk < cnt; ++kk) {  // kMin first, then the others in slot order
-                const uint32_t k = kk == 0 ? kMin : (kk <= kMin ? kk - 1 : kk);
-                const TriPre rec = loadTriPre(m, first + k);
-                if (kk != 0 && triLowerBound2(pt, rec) > rj) continue;
-                tryTriangle(triPreTriangle(rec), first + k);
+            tryTriangle(slotTriangle(m, first + kMin), first + kMin);
+            uint32_t rest = 0;  // the other slots whose bound the first test's distance allows
+            for (uint32_t k = 0; k < cnt; ++k)
+                if (k != kMin && !(triLowerBound2(pt, loadTriPre(m, first + k)) > rj)) rest |= 1u << k;
+            restMask = rest;
+        }
+        // (the remaining candidates of all lanes side by side: as many rounds as the lane with the most of them has -- two or
+        // three -- instead of one round per slot of the leaf)
+        while (__ballot(restMask != 0u) != 0ull) {
+            if (restMask != 0u) {
+                const uint32_t k = (uint32_t)__ffs((int)restMask) - 1u;
+                restMask &= restMask - 1u;
+                const TriPre rec = loadTriPre(m, seedFirst + k);
+                if (!(triLowerBound2(pt, rec) > rj)) tryTriangle(triPreTriangle(rec), seedFirst + k);
             }
         }
         for (int pass = 0; pass < HPSDF_SEED_EXCHANGE; ++pass) {
@@ -2249,7 +2260,11 @@ FitShape fitShape(int degree, int nrows, uint32_t count, bool weighted, bool lat
 // and without the fit's accumulators twice as many waves fit on a CU.  grid = (ceil(nq^3 / 256), tasks of one degree).
 // range == nullptr: grid = (chunks of 256 samples, tasks).  Otherwise grid.y is an upper bound and row y samples task
 // range[0] + y if y < range[1] -- the device-side frontier's rounds (frontier.hip), whose task counts the host does not know.
-constexpr uint32_t kMeshXcdRun = 32;  // 16-64 measure alike; 1 (plain order) and >= 256 lose 3-7 %
+#ifndef HPSDF_MESH_WG
+#define HPSDF_MESH_WG 64  // threads of a sampling workgroup (a multiple of 64): the hardware deals out workgroups, so this is the grain of its load balancing
+#endif
+constexpr int kMeshWg = HPSDF_MESH_WG;
+constexpr uint32_t kMeshXcdRun = 128;  // workgroups of 64 samples: runs of 64-256 measure alike; 1 (plain order) and >= 1024 lose 3-7 %
 static uint32_t meshXcdRun() {  // HPSDF_MESH_XCD_RUN overrides (experiments); 1 = plain dispatch order
     static const uint32_t v = [] {
         const char* e = std::getenv("HPSDF_MESH_XCD_RUN");
@@ -2258,11 +2273,11 @@ static uint32_t meshXcdRun() {  // HPSDF_MESH_XCD_RUN overrides (experiments); 1
     }();
     return v;
 }
-__global__ __launch_bounds__(256) void mesh_sample_kernel(const FitTask* __restrict__ tasks, int degree,
+__global__ __launch_bounds__(kMeshWg) void mesh_sample_kernel(const FitTask* __restrict__ tasks, int degree,
                                                           const DeviceTables* __restrict__ T, MeshDev mesh, RootMap rm,
                                                           double* __restrict__ samples, const uint32_t* __restrict__ range,
                                                           uint32_t nTasksArg, uint32_t xcdRun) {
-    __shared__ MeshWaveLds sWave[4];
+    __shared__ MeshWaveLds sWave[kMeshWg / 64];
     __shared__ double sR[64];
     __shared__ unsigned char sPos[64];
     // Which (task, chunk) this workgroup samples.  Workgroups are dealt round-robin over the 8 XCDs in dispatch order
@@ -2291,7 +2306,7 @@ __global__ __launch_bounds__(256) void mesh_sample_kernel(const FitTask* __restr
     }
     __syncthreads();
     const FitTask& tk = tasks[task];
-    const int r = (int)chunk * 256 + tid;
+    const int r = (int)chunk * kMeshWg + tid;
     const bool active = r < total;
     const int rem = meshSampleOrder(active ? r : total - 1, nq, nq, sPos, sPos);
     const int i = rem / (nq * nq), jk = rem - i * nq * nq, j = jk / nq, k = jk - j * nq;
@@ -2481,12 +2496,12 @@ hipError_t launchMeshSample(hipStream_t stream, const FitTask* dTasks, uint32_t 
     if (nTasks == 0) return hipSuccess;
     if (degree < 1 || degree > 12 || field.kind != kFieldMesh) return hipErrorInvalidValue;
     const int nq = 4 * degree + 1;
-    const unsigned gx = (unsigned)((nq * nq * nq + 255) / 256);
+    const unsigned gx = (unsigned)((nq * nq * nq + kMeshWg - 1) / kMeshWg);
     for (uint32_t first = 0; first < nTasks; first += 65535u) {
         const uint32_t n = nTasks - first < 65535u ? nTasks - first : 65535u;
         // (grid rounded up to whole groups of 8 runs of the XCD interleave)
         const uint32_t run = meshXcdRun(), wgs = (n * gx + 8u * run - 1u) / (8u * run) * (8u * run);
-        hipLaunchKernelGGL(mesh_sample_kernel, dim3(gx, (wgs + gx - 1u) / gx), dim3(256), 0, stream, dTasks + first, degree, dTables, field.mesh, rm,
+        hipLaunchKernelGGL(mesh_sample_kernel, dim3(gx, (wgs + gx - 1u) / gx), dim3(kMeshWg), 0, stream, dTasks + first, degree, dTables, field.mesh, rm,
                            dSamples, (const uint32_t*)nullptr, n, run);
     }
     return hipGetLastError();
@@ -2497,11 +2512,11 @@ hipError_t launchMeshSampleRange(hipStream_t stream, const FitTask* dTasks, cons
                                  const DeviceTables* dTables, const FieldDev& field, const RootMap& rm, double* dSamples) {
     if (degree < 1 || degree > 12 || field.kind != kFieldMesh || maxTasks == 0 || maxTasks > 65535u) return hipErrorInvalidValue;
     const int nq = 4 * degree + 1;
-    const unsigned gx = (unsigned)((nq * nq * nq + 255) / 256);
+    const unsigned gx = (unsigned)((nq * nq * nq + kMeshWg - 1) / kMeshWg);
     const uint32_t run = meshXcdRun();
     const unsigned gy = maxTasks + (8u * run + gx - 1u) / gx;  // whole groups of 8 runs of the XCD interleave past the last task
     if (gy > 65535u) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(mesh_sample_kernel, dim3(gx, gy), dim3(256), 0, stream, dTasks, degree, dTables, field.mesh, rm, dSamples, dRange, 0u, run);
+    hipLaunchKernelGGL(mesh_sample_kernel, dim3(gx, gy), dim3(kMeshWg), 0, stream, dTasks, degree, dTables, field.mesh, rm, dSamples, dRange, 0u, run);
     return hipGetLastError();
 }
 
