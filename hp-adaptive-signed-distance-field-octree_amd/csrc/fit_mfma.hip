@@ -248,6 +248,8 @@ void launchMfmaT(hipStream_t stream, int degree, const FitBlock* dBlocks, uint32
                            rm, dRange);                                                                                           \
         break;
     switch (degree) {
+        HPSDF_MFMA_CASE(2)
+        HPSDF_MFMA_CASE(3)
         HPSDF_MFMA_CASE(4)
         HPSDF_MFMA_CASE(5)
         HPSDF_MFMA_CASE(6)
@@ -263,7 +265,9 @@ void launchMfmaT(hipStream_t stream, int degree, const FitBlock* dBlocks, uint32
 
 bool fitMfmaSupports(int degree, const FieldDev& field) {
     // (degrees 10 and 11 -- 18 and 23 tiles of accumulators -- do not fit the register file beside the pipeline's operands)
-    return degree >= 4 && degree <= 9 && field.csgOp < 0 && (field.kind == kFieldAnalytic || field.kind == kFieldSamples);
+    // (degrees 2 and 3 are instantiated for the micro-benchmark -- one and two tiles of 16 rows, 62.5 % full; builds send only
+    // degrees >= 4 here: builder.cpp fastDeg, frontier.hip frShape)
+    return degree >= 2 && degree <= 9 && field.csgOp < 0 && (field.kind == kFieldAnalytic || field.kind == kFieldSamples);
 }
 
 // Blocks of at most 16 fits of one class (degree `degree`, any mix of from-scratch and incremental blocks).
