@@ -1925,7 +1925,10 @@ __device__ __forceinline__ void fitBlockBody(const FitBlock blk, const FitTask* 
 
     // phase-2 ownership: thread -> (cell slot, row); a slot is R consecutive cells; cells with > 256 rows
     // (any-degree kernel only) use two rows per thread
-    const bool wide = nrows > kFitThreads;
+    // (two rows per thread only exist where a cell has more than 256 rows, i.e. beyond degree 9: the any-degree kernel.  Saying so
+    // at compile time removes the second row's code from the degree-specialised kernels -- it was where the degree-2 kernel spilled
+    // 448 bytes per lane: a fully unrolled plane of LDS reads for a branch that never runs)
+    const bool wide = DEG == 0 && nrows > kFitThreads;
     const int slot = wide ? 0 : tid / nrows;
     const int g2 = slot * R;  // first cell of this thread
     const int r0 = rowStart + (wide ? tid : tid % nrows);
@@ -2015,6 +2018,9 @@ __device__ __forceinline__ void fitBlockBody(const FitBlock blk, const FitTask* 
             for (int il = 0; il < np; ++il) {
                 const double* F = sF + g2 * cellStride + il * nq2;
                 const double a0 = sT[i0a * nq + iBase + il] * n0a;
+#ifdef HPSDF_FIT_ROW_UNROLL
+#pragma unroll HPSDF_FIT_ROW_UNROLL
+#endif
                 for (int j = 0; j < nq; ++j) {
                     const double a1 = a0 * tj[j] * n1a;
                     if constexpr (DEG > 0) {
