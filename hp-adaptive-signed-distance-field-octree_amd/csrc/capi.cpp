@@ -368,7 +368,14 @@ int hpsdf_field_create_mesh(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts,
             }
         }
     }
-    if (fallback) {
+    if (fallback == 2) {  // non-manifold: the twins from the host's sequential pairing, everything else is on the device already
+        std::vector<uint32_t> he;
+        if (!hostHalfEdges(tris, nTris, nVerts, &he)) {
+            hpsdf_field_destroy(f);
+            return fail(HPSDF_ERR_OPEN_MESH, "mesh is not closed: an edge has no twin (Mesh::CreateHalfEdges)");
+        }
+        e = hipMemcpy(f->dHalfEdges, he.data(), he.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    } else if (fallback) {
         for (uint64_t i = 0; i < 3 * nTris; ++i)
             if (tris[i] >= nVerts) {
                 delete f;

@@ -150,6 +150,17 @@ struct Builder {
 
 }  // namespace
 
+// Only the twins (Mesh::CreateHalfEdges, Mesh.cpp:87-131, with its sequential semantics for edges that occur twice): what a
+// non-manifold mesh still needs from the host when everything else was built on the device.
+bool hostHalfEdges(const uint64_t* tris, uint64_t nTris, uint64_t nVerts, std::vector<uint32_t>* he) {
+    std::vector<uint32_t> t(3 * nTris);
+    for (uint64_t i = 0; i < 3 * nTris; ++i) {
+        if (tris[i] >= nVerts) return false;
+        t[i] = (uint32_t)tris[i];
+    }
+    return twinHalfEdges(t, *he);
+}
+
 bool prepareMesh(const float* verts, uint64_t nVerts, const uint64_t* tris, uint64_t nTris, HostMesh* out) {
     const bool trace = std::getenv("HPSDF_TRACE") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };

@@ -338,8 +338,9 @@ __global__ __launch_bounds__(256) void mb_edges_lookup_kernel(const uint32_t* __
 }  // namespace
 
 // Everything a mesh field needs, from host arrays.  Returns HPSDF_OK and fills the device pointers, or an error / a
-// request to fall back: *fallback = 1 asks the caller to run the host preparation instead (non-manifold input, or a mesh
-// too small to be worth it); device buffers are released on any non-OK return.
+// request to fall back: *fallback = 1 asks the caller to run the host preparation instead (a mesh too small to be worth it: the
+// device buffers are released), *fallback = 2 to supply the twins of a non-manifold mesh from the host (everything else is built and
+// stays); device buffers are released on any non-OK return.
 int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const uint64_t* tris, uint64_t nTris, hpsdf_field* f, int* fallback) {
     *fallback = 0;
     const bool trace = std::getenv("HPSDF_TRACE") != nullptr;
@@ -464,9 +465,16 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
         return fail(HPSDF_ERR_INVALID_ARGUMENT, "triangle " + std::to_string(hf.badIndex / 3) + " refers to a vertex beyond the " +
                                                     std::to_string(nVerts) + " given");
     }
-    if (hf.nonManifold) {  // the reference's sequential pairing decides such meshes: the host path reproduces it
-        freeField();
-        *fallback = 1;
+    if (hf.nonManifold) {
+        // a directed edge occurs twice: the reference's sequential std::map pass decides which copy is paired (the first), and only
+        // the host reproduces that (hostHalfEdges).  The BVH, the slabs and the triangle records do not depend on the twins: they stay.
+        f->nVerts = (uint32_t)nVerts;
+        f->nTris = (uint32_t)nTris;
+        f->nBvhNodes = (uint32_t)(nTris - 1);
+        if (noSlabs) f->dSlabs = nullptr;
+        f->leafLog2 = 0;
+        while ((1 << f->leafLog2) < leafTris) ++f->leafLog2;
+        *fallback = 2;
         return HPSDF_OK;
     }
     if (hf.open) {

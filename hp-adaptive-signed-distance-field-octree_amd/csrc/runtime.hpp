@@ -180,7 +180,10 @@ struct HostMesh {
 };
 // returns false when the mesh is not closed (Mesh::CreateHalfEdges, Mesh.cpp:87-131)
 bool prepareMesh(const float* verts, uint64_t nVerts, const uint64_t* tris, uint64_t nTris, HostMesh* out);
-// the same on the device (mesh_build.hip): fills f's device pointers; *fallback = 1 asks for prepareMesh instead
+// the twins alone (non-manifold meshes whose BVH, slabs and records the device has built)
+bool hostHalfEdges(const uint64_t* tris, uint64_t nTris, uint64_t nVerts, std::vector<uint32_t>* he);
+// the same on the device (mesh_build.hip): fills f's device pointers; *fallback = 1 asks for prepareMesh instead, 2 for hostHalfEdges
+// (everything but the twins is in place: f->dHalfEdges waits for them)
 int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const uint64_t* tris, uint64_t nTris, hpsdf_field* f, int* fallback);
 
 }  // namespace hpsdf

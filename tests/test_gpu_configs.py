@@ -170,6 +170,60 @@ def test_tiny_meshes_through_the_device_build(H, ctx):
         f.close()
 
 
+def _membrane_bipyramid(n=48, levels=2):
+    """A bipyramid over an n-gon with a membrane across its equator: every equator edge has THREE faces (bottom, top, membrane),
+    so one directed edge occurs twice -- not a manifold.  The reference's one-pass pairing (Mesh.cpp:87-131) accepts it because
+    the direction that occurs once (the bottom's) comes first in index order: bottom, top, membrane."""
+    ang = np.arange(n) * (2.0 * np.pi / n)
+    eq = np.stack([0.33 * np.cos(ang), 0.33 * np.sin(ang), 0.02 * np.sin(3 * ang)], -1)
+    v = [tuple(p) for p in eq] + [(0.0, 0.0, 0.3), (0.0, 0.0, -0.27), (0.0, 0.0, 0.01)]
+    T, B, C = n, n + 1, n + 2
+    f = [(B, (i + 1) % n, i) for i in range(n)] + [(T, i, (i + 1) % n) for i in range(n)] + [(C, i, (i + 1) % n) for i in range(n)]
+    for _ in range(levels):
+        cache, nf = {}, []
+
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in cache:
+                v.append(tuple(0.5 * (np.array(v[a]) + np.array(v[b]))))
+                cache[key] = len(v) - 1
+            return cache[key]
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    return np.array(v, np.float32), np.array(f, np.uint64)
+
+
+def test_non_manifold_mesh_keeps_the_device_hierarchy(H, O, ctx, monkeypatch):
+    """A closed complex in which a directed edge occurs twice: the device's hash pairing cannot reproduce the reference's
+    sequential std::map pass for it, so the twins come from the host -- while BVH, slabs and triangle records stay the device's
+    (round 2 rebuilt everything on the host).  Same bits as the all-host preparation and as the O(n) scan, same Create block."""
+    verts, tris = _membrane_bipyramid()
+    pts = _hard_points(O, verts, tris, 5)
+    f = H.Field.mesh(ctx, verts, tris)
+    want = f.eval_naive(ctx, pts)
+    assert (want > 0).any() and (want < 0).any()
+    assert np.array_equal(bits(f.eval(ctx, pts)), bits(want)) and np.array_equal(bits(f.eval_lane(ctx, pts)), bits(want))
+    cfg = H.make_config(1e-5, (-0.5, -0.5, -0.5), (0.5, 0.5, 0.5))
+    blk, _ = H.create_block(ctx, cfg, f, 1024)
+    monkeypatch.setenv("HPSDF_MESH_HOST_BUILD", "1")
+    g = H.Field.mesh(ctx, verts, tris)
+    assert np.array_equal(bits(g.eval(ctx, pts)), bits(want))
+    assert H.create_block(ctx, cfg, g, 1024)[0] == blk
+    monkeypatch.delenv("HPSDF_MESH_HOST_BUILD")
+    # with the membrane FIRST the doubled direction meets an empty map and one half-edge stays without a twin: the reference
+    # returns false (Mesh.cpp:121-128), and so do both preparations here
+    n = len(tris) // 3
+    bad = np.vstack([tris[2 * n:], tris[:2 * n]])
+    for host in (False, True):
+        if host:
+            monkeypatch.setenv("HPSDF_MESH_HOST_BUILD", "1")
+        with pytest.raises(H.HpsdfError) as e:
+            H.Field.mesh(ctx, verts, bad)
+        assert e.value.status == H.ERR_OPEN_MESH
+
+
 def _hard_points(O, verts, tris, seed):
     rng = np.random.default_rng(seed)
     lo, hi = verts.min(0).astype(np.float64), verts.max(0).astype(np.float64)
