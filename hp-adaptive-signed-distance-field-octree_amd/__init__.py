@@ -119,6 +119,7 @@ _SIGNATURES = {
     "hpsdf_field_eval_naive_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hpsdf_field_eval_wave_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hpsdf_field_eval_lane_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hpsdf_selftest_acosf": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_size_t, C.c_void_p]),
     "hpsdf_tree_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "hpsdf_tree_destroy": (C.c_int, [C.c_void_p]),
     "hpsdf_tree_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
@@ -689,6 +690,13 @@ def continuity_last_stats():
     st = ContinuityStats()
     check(lib().hpsdf_continuity_last_stats(C.byref(st)))
     return st.as_dict()
+
+
+def selftest_acosf(ctx, first_bits, stride, n):
+    """The device's acosf (the angle weights of vertex pseudo-normals) of the floats with bit patterns first_bits + i * stride."""
+    out = np.empty(n, np.float32)
+    check(lib().hpsdf_selftest_acosf(ctx.handle, first_bits, stride, n, out.ctypes.data_as(C.c_void_p)))
+    return out
 
 
 def bench_fit(ctx, config, field, degree, depth, n_cells, repeats=5):

@@ -590,6 +590,19 @@ int hpsdf_field_eval_naive_host(hpsdf_ctx* ctx, const hpsdf_field* f, const doub
     HPSDF_CATCH
 }
 
+int hpsdf_selftest_acosf(hpsdf_ctx* ctx, uint32_t first_bits, uint32_t stride, size_t n, float* out) {
+    HPSDF_TRY
+    if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "a device context is required");
+    if (!out && n) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return HPSDF_OK;
+    HostArray arr[1] = {{nullptr, out, n * sizeof(float)}};
+    return hostCall(ctx, arr, 1, [&] {
+        HPSDF_HIP(launchAcosfSelftest(ctx->stream, first_bits, stride, n, (float*)arr[0].dev));
+        return (int)HPSDF_OK;
+    });
+    HPSDF_CATCH
+}
+
 // ---------------------------------------------------------------------------- tree + query
 int hpsdf_tree_upload(hpsdf_ctx* ctx, const void* block, size_t size, hpsdf_tree** out) {
     HPSDF_TRY

@@ -21,6 +21,7 @@
 #include <cstdint>
 #include <cstdlib>
 
+#include "acosf_host_libm.hpp"
 #include "device_types.hpp"
 #include "field_eval.hpp"
 #include "launch.hpp"
@@ -119,7 +120,7 @@ __device__ V3 pseudoNormal(const MeshDev& m, uint32_t t, int code) {
         const V3 pk = k == 0 ? t0 : (k == 1 ? t1 : t2), pk1 = k == 0 ? t1 : (k == 1 ? t2 : t0), pk2 = k == 0 ? t2 : (k == 1 ? t0 : t1);
         const V3 ab = pk1 - pk;
         const V3 ac = pk2 - pk;
-        const float ang = acosf(dot(normalized(ab), normalized(ac)));
+        const float ang = hpsdfAcosf(dot(normalized(ab), normalized(ac)));  // std::acos of the HOST's libm, bit for bit
         n = n + ang * faceNormal(m, cur);
         he = m.halfEdges[he];
         he = ((he % 3) == 2) ? (he - 2) : (he + 1);
@@ -2385,6 +2386,17 @@ hipError_t launchMeshEvalWave(hipStream_t stream, const FieldDev& f, const doubl
         const size_t m = std::min<size_t>((size_t)1 << 38, n - first);
         hipLaunchKernelGGL(mesh_eval_wave_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, f.mesh, dXyz + 3 * first, m, dOut + first);
     }
+    return hipGetLastError();
+}
+
+// hpsdfAcosf of the floats whose bit patterns are first, first + stride, ...: the device half of the acosf parity test
+__global__ __launch_bounds__(256) void acosf_selftest_kernel(uint32_t first, uint32_t stride, size_t n, float* out) {
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i < n) out[i] = hpsdfAcosf(__uint_as_float(first + (uint32_t)i * stride));
+}
+hipError_t launchAcosfSelftest(hipStream_t stream, uint32_t first, uint32_t stride, size_t n, float* dOut) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(acosf_selftest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, first, stride, n, dOut);
     return hipGetLastError();
 }
 

@@ -168,6 +168,10 @@ HPSDF_API int hpsdf_field_eval_wave_host(hpsdf_ctx* ctx, const hpsdf_field* f, c
 /* The same through the per-point stack traversal (what a mesh field under a tree-CSG wrapper and the fused mesh fit run;
  * hpsdf_field_eval_* itself takes the faster shared traversal for plain mesh fields): same bits.  Diagnostics. */
 HPSDF_API int hpsdf_field_eval_lane_host(hpsdf_ctx* ctx, const hpsdf_field* f, const double* xyz, size_t n, double* out);
+/* Diagnostics: the device's acosf -- the angle weights of a vertex pseudo-normal, std::acos in Source/Meshing/Mesh.cpp:226-231
+ * -- for the n floats whose bit patterns are first_bits, first_bits + stride, ...  It is the host libm's (glibc's) algorithm
+ * restated (csrc/acosf_host_libm.hpp), so out[] equals acosf() of the host bit for bit. */
+HPSDF_API int hpsdf_selftest_acosf(hpsdf_ctx* ctx, uint32_t first_bits, uint32_t stride, size_t n, float* out);
 /* Diagnostics (no reference counterpart; HPSDF_ERR_UNSUPPORTED unless the library was built with
  * -DHPSDF_MESH_STATS_BUILD): BVH traversal counters of a mesh field created while the environment
  * variable HPSDF_MESH_STATS was set -- out[0] wave-wide closest-triangle queries (64 points each), [1] BVH nodes they visited,

@@ -228,6 +228,8 @@ void ora_mesh_free(ora_mesh* m);
 /* naive O(n) signed distance, the reference test's own cross-check
  * (Source/Tests/MeshingUnitTests.cpp:110-138) */
 float ora_mesh_signed_distance(const ora_mesh* m, const float pt[3], uint64_t* tri_out, int* simplex_out);
+/* acosf of this machine's libm (what Mesh.cpp:226-231's std::acos is) for the floats with bit patterns first + i * stride */
+void ora_acosf_batch(uint32_t first, uint32_t stride, size_t n, float* out);
 
 #ifdef __cplusplus
 }

@@ -246,3 +246,12 @@ float ora_mesh_signed_distance(const ora_mesh* m, const float p[3], uint64_t* tr
     if (simplex_out) *simplex_out = best.simplex * 4 + best.simplexIdx;
     return sign * sqrtf(v3_sqnorm(d));
 }
+
+void ora_acosf_batch(uint32_t first, uint32_t stride, size_t n, float* out) {
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t b = first + (uint32_t)i * stride;
+        float x;
+        memcpy(&x, &b, 4);
+        out[i] = acosf(x);
+    }
+}

@@ -133,6 +133,7 @@ def lib():
     L.ora_mesh_create.restype = C.c_void_p
     L.ora_mesh_create.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
     L.ora_mesh_free.argtypes = [C.c_void_p]
+    L.ora_acosf_batch.argtypes = [C.c_uint32, C.c_uint32, C.c_size_t, C.c_void_p]
     L.ora_mesh_signed_distance.restype = C.c_float
     L.ora_mesh_signed_distance.argtypes = [C.c_void_p, fp, u64p, C.POINTER(C.c_int)]
     _LIB = L
@@ -256,6 +257,13 @@ class MeshField:
         if getattr(self, "handle", None):
             lib().ora_mesh_free(self.handle)
             self.handle = None
+
+
+def acosf_batch(first_bits, stride, n):
+    """acosf of the host libm for the floats with bit patterns first_bits + i * stride (numpy's arccos is not libm's)."""
+    out = np.empty(n, np.float32)
+    lib().ora_acosf_batch(first_bits, stride, n, out.ctypes.data_as(C.c_void_p))
+    return out
 
 
 class TreeCsgField:

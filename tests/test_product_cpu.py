@@ -162,6 +162,18 @@ def test_no_gpu_fails_loudly(H):
     assert e.value.status == H.ERR_NO_DEVICE
 
 
+def test_device_acosf_source_equals_host_libm_on_every_float(tmp_path):
+    """csrc/acosf_host_libm.hpp -- the acosf the mesh kernels call for the angle weights of Mesh.cpp:226-231 -- compiled for
+    the host and compared with this machine's libm on all 2 139 095 042 floats of [-1.5, 1.5] (tests/native/acosf_exhaustive.c):
+    no input differs in any bit.  (The device's own results are compared in tests/test_gpu_parity.py.)"""
+    exe = str(tmp_path / "acosf_exhaustive")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-I", os.path.join(ROOT, "hp-adaptive-signed-distance-field-octree_amd", "csrc"),
+                    "-o", exe, os.path.join(ROOT, "tests", "native", "acosf_exhaustive.c"), "-lm", "-pthread"], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout
+    assert re.search(r"inputs 2139095042 mismatches 0\b", r.stdout), r.stdout
+
+
 def test_product_sources_do_not_touch_the_oracle():
     pkg = os.path.join(ROOT, "hp-adaptive-signed-distance-field-octree_amd")
     for dirpath, _, files in os.walk(pkg):

@@ -35,10 +35,12 @@ def closest_pt_tri(p, a, b, c):  # Ericson, in float64
 def scan_artefact(verts, tris, p, naive, bvh):
     """True if the exhaustive f32 scan, not the hierarchy, is the one that is off: on sliver triangles the reference's f32
     closest-point routine (Utility.cpp:5-97) can return a point outside the triangle, i.e. a distance below the triangle's
-    own bounding-box distance, which no hierarchy reproduces.  Decided by an exhaustive scan in float64."""
+    own bounding-box distance, which no hierarchy reproduces.  Decided by an exhaustive scan in float64; the hierarchy's own
+    value is held to 1e-5 of it (on needles the f32 routine's in-triangle answers carry that much conditioning error too:
+    seed 100758, a sphere squashed to 1/1000 along x, is 1.7e-6 off)."""
     A, B, Cc = (verts[tris[:, k]].astype(np.float64) for k in range(3))
     d = min(np.linalg.norm(p - closest_pt_tri(p, A[i], B[i], Cc[i])) for i in range(len(tris)))
-    return abs(abs(bvh) - d) <= 1e-6 * max(1.0, d) and abs(naive) < d - 1e-6
+    return abs(abs(bvh) - d) <= 1e-5 * max(1.0, d) and abs(naive) < d - 1e-5
 
 
 bad = artefacts = 0

@@ -26,7 +26,7 @@ for seed in range(8):
     topo = np.array_equal(a["degree"], b["degree"]) and np.array_equal(a["childIdx"], b["childIdx"])
     dmax = float(np.abs(a["coeffs"] - b["coeffs"]).max()) if topo else float("nan")
     same = blk == ot.to_block()
-    ok = topo and dmax <= 1e-6
+    ok = same  # byte for byte (the device runs the host libm's acosf: csrc/acosf_host_libm.hpp)
     bad += 0 if ok else 1
     print("seed %d: %5d tris target %g -> %d nodes %d rounds | topology %s, max |dcoeff| %.2e, bytes identical %s (%.0f s)"
           % (seed, len(tris), target, st["n_nodes"], st["rounds"], topo, dmax, same, time.time() - t0), flush=True)

@@ -6,7 +6,8 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 obj = os.path.join(ROOT, "hp-adaptive-signed-distance-field-octree_amd", "build", sys.argv[1] + ".hip.o")
 with tempfile.TemporaryDirectory() as td:
     fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "k.co")
-    subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, obj], check=True, capture_output=True)
+    # (an output file is named: with the input alone llvm-objcopy rewrites it in place, and the fresh time stamp hides later header edits from build.py)
+    subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, obj, os.path.join(td, "copy.o")], check=True, capture_output=True)
     subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
                     "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True, capture_output=True)
     dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], capture_output=True, text=True).stdout

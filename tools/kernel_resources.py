@@ -9,7 +9,7 @@ notes = ""
 with tempfile.TemporaryDirectory() as td:
     for obj in sorted(f for f in os.listdir(objdir) if f.endswith(".hip.o")):
         fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "k.co")
-        subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, os.path.join(objdir, obj)],
+        subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, os.path.join(objdir, obj), os.path.join(td, "copy.o")],  # (no output named = rewritten in place)
                        check=True, capture_output=True)
         subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
                         "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True, capture_output=True)
