@@ -15,7 +15,7 @@ LIB = os.path.join(LIBDIR, "libhpsdf.so")
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
 
 SOURCES = ["kernels.hip", "frontier.hip", "fit_mfma.hip", "mesh_build.hip", "cg.hip", "continuity_asm.hip", "tables.cpp", "builder.cpp", "mesh.cpp", "obj.cpp", "continuity.cpp", "capi.cpp"]
-HEADERS = ["tables.hpp", "device_types.hpp", "launch.hpp", "runtime.hpp", "builder.hpp", "continuity.hpp", "block_check.hpp", "frontier.hpp", "field_eval.hpp", "acosf_host_libm.hpp"]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp"))  # every header: an edit to any of them rebuilds every object
 PUBLIC_HEADERS = ["hpsdf.h", "hpsdf_octree.hpp"]
 
 # -ffp-contract=off: no multiply-add is fused anywhere (bit parity with the x86-64 reference path)
