@@ -230,6 +230,9 @@ void ora_mesh_free(ora_mesh* m);
 float ora_mesh_signed_distance(const ora_mesh* m, const float pt[3], uint64_t* tri_out, int* simplex_out);
 /* acosf of this machine's libm (what Mesh.cpp:226-231's std::acos is) for the floats with bit patterns first + i * stride */
 void ora_acosf_batch(uint32_t first, uint32_t stride, size_t n, float* out);
+/* the restatement's scalars in the order of ref_tables.cpp's ref_scalars: max degree, max depth, sizeof i16 / i32 / u32 / usize /
+ * MemoryBlock as the reference's typedefs make them on LP64 (Literals.h:3-11), the bits of EPSILON_F32 */
+void ora_scalars(unsigned long long out[8]);
 
 #ifdef __cplusplus
 }

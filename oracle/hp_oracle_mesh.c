@@ -255,3 +255,13 @@ void ora_acosf_batch(uint32_t first, uint32_t stride, size_t n, float* out) {
         out[i] = acosf(x);
     }
 }
+
+void ora_scalars(unsigned long long out[8]) {
+    const float eps = EPSILON_F32;
+    uint32_t bits;
+    memcpy(&bits, &eps, 4);
+    out[0] = ORA_BASIS_MAX_DEGREE, out[1] = ORA_TREE_MAX_DEPTH;
+    out[2] = 4, out[3] = 8, out[4] = 8, out[5] = 8; /* int, long, unsigned long, size_t: "u32" is 8 bytes (a quirk the block layout keeps) */
+    out[6] = 16;                                  /* { usize size; void* ptr; } */
+    out[7] = bits;
+}

@@ -13,16 +13,27 @@
 //   Include/HP/Utility.h:112-127 LegendreCoefficent
 //   Include/HP/Utility.h:133-160 BasisIndexValues
 //   Include/HP/Legendre.h:7,2091 LegendreRoots / LegendreWeights
+//   Include/HP/Consts.h:7-8, Include/Utility/Literals.h:3-13, Include/Utility/MemoryBlock.h:5-9   scalars
 #include <cstddef>
 #include <cstring>
 #include "HP/Utility.h"
 #include "HP/Legendre.h"
+#include "Utility/MemoryBlock.h"
 
 extern "C" {
 
 int ref_basis_max_degree(void) { return (int)SDF::BASIS_MAX_DEGREE; }
 int ref_tree_max_depth(void) { return (int)SDF::TREE_MAX_DEPTH; }
 int ref_sizeof_u32(void) { return (int)sizeof(u32); }
+// out[8]: BASIS_MAX_DEGREE, TREE_MAX_DEPTH, sizeof i16 / i32 / u32 / usize / MemoryBlock, the bits of EPSILON_F32
+void ref_scalars(unsigned long long* out) {
+    const float eps = EPSILON_F32;
+    unsigned int bits;
+    std::memcpy(&bits, &eps, 4);
+    out[0] = SDF::BASIS_MAX_DEGREE, out[1] = SDF::TREE_MAX_DEPTH;
+    out[2] = sizeof(i16), out[3] = sizeof(i32), out[4] = sizeof(u32), out[5] = sizeof(usize), out[6] = sizeof(MemoryBlock);
+    out[7] = bits;
+}
 
 // out[50]
 void ref_sum_to_n(unsigned long long* out) {

@@ -18,6 +18,22 @@ def test_oracle_tables_match_reference_headers_bitwise(O):
         assert np.array_equal(bits(t[k]), bits(ref[k])), k
 
 
+def test_oracle_scalars_match_reference_headers(O):
+    """Consts.h:7-8, Literals.h:3-13 and MemoryBlock.h:5-9 compiled where they lie: the limits, the widths of the
+    reference's integer typedefs on this ABI ("u32" is 8 bytes) and EPSILON_F32 of the closest-point guards."""
+    import ctypes as C
+    want = [12, 10, 4, 8, 8, 8, 16, int(np.float32(0.000001).view(np.uint32))]
+    got = (C.c_ulonglong * 8)()
+    O.lib().ora_scalars(got)
+    assert list(got) == want
+    R = O.ref_tables_lib()
+    if R is None or not hasattr(R, "ref_scalars"):
+        pytest.skip("oracle/_ref not built (reference checkout absent)")
+    ref = (C.c_ulonglong * 8)()
+    R.ref_scalars(ref)
+    assert list(ref) == want
+
+
 def test_oracle_tables_match_committed_reference_hashes(O, golden):
     t = O.tables()
     for k in NAMES:
