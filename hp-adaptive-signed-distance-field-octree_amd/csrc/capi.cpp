@@ -536,7 +536,14 @@ static int meshNaiveDevice(hpsdf_ctx* ctx, const hpsdf_field* f, const double* d
     FieldDev fd;
     int rc = makeFieldDev(f, nullptr, &fd);
     if (rc) return rc;
-    HPSDF_HIP(launchMeshNaive(ctx->stream, fd, dXyz, n, dOut));
+    // tiny calls run on the pinned host buffer as the device sees it (hostCall): the scan's atomics then go to the device-side
+    // staging buffer, which such a call leaves unused and which holds the call's arrays (32 bytes a point) at least
+    unsigned long long* keys = nullptr;
+    if (ctx->hostPinDev && (char*)dOut >= ctx->hostPinDev && (char*)dOut < ctx->hostPinDev + ctx->hostPinCap) {
+        if (ctx->hostDevCap < n * sizeof(double)) return fail(HPSDF_ERR_STATE, "the staging buffer is smaller than the call");
+        keys = reinterpret_cast<unsigned long long*>(ctx->hostDev);
+    }
+    HPSDF_HIP(launchMeshNaive(ctx->stream, fd, dXyz, n, dOut, keys));
     return HPSDF_OK;
 }
 

@@ -2330,26 +2330,35 @@ __global__ __launch_bounds__(kMeshWg) void mesh_sample_kernel(const FitTask* __r
     if (active) samples[tk.sampleOff + (uint64_t)rem] = (double)mv;
 }
 
-// Mesh::SignedDistanceAtPt(pt) WITHOUT a BVH (Mesh.cpp:42-51 over the linear scan Mesh::ClosestTriangleToPt, :134-159):
-// one wave per point, lane l tests triangles l, l + 64, ... keeping the first strictly smaller squared distance (so the
-// lowest index among its own equals), then the lanes fold to the smallest distance, ties to the lower triangle index --
-// i.e. what the reference's `<` scan from triangle 0 upwards keeps.  The winner's lane forms the pseudo-normal sign.
+// Mesh::SignedDistanceAtPt(pt) WITHOUT a BVH (Mesh.cpp:42-51 over the linear scan Mesh::ClosestTriangleToPt, :134-159).
+// A wave takes one point and one SLICE of the triangles: lane l tests triangles first + l, first + l + 64, ... of the slice,
+// keeping the first strictly smaller squared distance (so the lowest index among its own equals); the lanes fold to the
+// smallest distance, ties to the lower triangle index, and the wave's winner goes into the point's 64-bit key
+// (distance bits << 32 | triangle) by atomicMin -- over all slices that leaves the smallest distance and, among equals, the
+// lowest triangle: what the reference's `<` scan from triangle 0 upwards keeps.  The key lives in the point's slot of the
+// OUTPUT array (8 bytes, preset to all ones) -- or in scratch of the caller's when the output is host memory mapped into the
+// device, where an atomic is a PCIe transaction --; mesh_naive_finish_kernel repeats the winner's closest-point test and
+// writes the signed distance.  The slices let a handful of points use the whole chip (one point: 8 ms -> 0.1 ms on 1 M
+// triangles); with thousands of points there is one slice and the atomic is one per wave.
 // It is the checker of the BVH path on the device (TestBVHQuerying, MeshingUnitTests.cpp:110-138) and O(n) per point.
-__global__ __launch_bounds__(256) void mesh_naive_kernel(MeshDev m, const double* __restrict__ xyz, size_t n, double* __restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+__global__ __launch_bounds__(256) void mesh_naive_kernel(MeshDev m, const double* __restrict__ xyz, size_t n, unsigned long long* __restrict__ keys,
+                                                         uint32_t slices) {
+    const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // wave = (point, slice), the slices of a point adjacent
+    const size_t i = w / slices;
     if (i >= n) return;  // wave-uniform
+    const uint32_t slice = (uint32_t)(w % slices);
+    const uint32_t per = ((m.nTris + slices - 1u) / slices + 63u) & ~63u;
+    const uint32_t first = slice * per, last = first + per < m.nTris ? first + per : m.nTris;
     const int lane = threadIdx.x & 63;
     const V3 pt = {(float)xyz[3 * i], (float)xyz[3 * i + 1], (float)xyz[3 * i + 2]};
     float best = FLT_MAX;
     uint32_t bestTri = 0xFFFFFFFFu;
-    int bestCode = 8;
-    V3 bestQ = {0.0f, 0.0f, 0.0f};
-    for (uint32_t t = (uint32_t)lane; t < m.nTris; t += 64u) {
+    for (uint32_t t = first + (uint32_t)lane; t < last; t += 64u) {
         V3 q;
         const float4 tp[3] = {m.triPos[3 * (size_t)t], m.triPos[3 * (size_t)t + 1], m.triPos[3 * (size_t)t + 2]};
-        const int code = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, q);
+        closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, q);
         const float d = sqnorm(pt - q);
-        if (d < best) best = d, bestTri = t, bestCode = code, bestQ = q;
+        if (d < best) best = d, bestTri = t;
     }
     float wd = best;
     uint32_t wt = bestTri;
@@ -2359,12 +2368,27 @@ __global__ __launch_bounds__(256) void mesh_naive_kernel(MeshDev m, const double
         const uint32_t ot = __shfl_xor(wt, off, 64);
         if (od < wd || (od == wd && ot < wt)) wd = od, wt = ot;
     }
-    if (wt == bestTri && bestTri != 0xFFFFFFFFu) {  // exactly one lane owns the winning triangle
-        const V3 nrm = pseudoNormal(m, bestTri, bestCode);
-        const V3 d = pt - bestQ;
-        const float sign = dot(nrm, d) > 0.0f ? 1.0f : -1.0f;
-        out[i] = (double)(sign * sqrtf(sqnorm(d)));
+    // (a squared distance that won a `<` against FLT_MAX is a non-negative finite float: its bits order like its value)
+    if (lane == 0 && wt != 0xFFFFFFFFu) atomicMin(&keys[i], ((unsigned long long)__float_as_uint(wd) << 32) | wt);
+}
+__global__ __launch_bounds__(256) void mesh_naive_finish_kernel(MeshDev m, const double* __restrict__ xyz, size_t n, const unsigned long long* keys,
+                                                                double* out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long key = keys[i];
+    if (key == ~0ull) {  // no triangle came closer than FLT_MAX: all ones (a NaN)
+        reinterpret_cast<unsigned long long*>(out)[i] = ~0ull;
+        return;
     }
+    const uint32_t t = (uint32_t)key;
+    const V3 pt = {(float)xyz[3 * i], (float)xyz[3 * i + 1], (float)xyz[3 * i + 2]};
+    V3 q;
+    const float4 tp[3] = {m.triPos[3 * (size_t)t], m.triPos[3 * (size_t)t + 1], m.triPos[3 * (size_t)t + 2]};
+    const int code = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, q);
+    const V3 nrm = pseudoNormal(m, t, code);
+    const V3 d = pt - q;
+    const float sign = dot(nrm, d) > 0.0f ? 1.0f : -1.0f;
+    out[i] = (double)(sign * sqrtf(sqnorm(d)));
 }
 
 // Mesh::SignedDistanceAtPt(pt, bvh) through the traversal the sampler uses: 64 consecutive points share one walk
@@ -2400,12 +2424,20 @@ hipError_t launchAcosfSelftest(hipStream_t stream, uint32_t first, uint32_t stri
     return hipGetLastError();
 }
 
-hipError_t launchMeshNaive(hipStream_t stream, const FieldDev& f, const double* dXyz, size_t n, double* dOut) {
+hipError_t launchMeshNaive(hipStream_t stream, const FieldDev& f, const double* dXyz, size_t n, double* dOut, unsigned long long* dKeys) {
     if (n == 0) return hipSuccess;
     if (f.kind != kFieldMesh || f.csgOp >= 0) return hipErrorInvalidValue;
-    for (size_t first = 0; first < n; first += (size_t)1 << 30) {  // grid.x stays below 2^31
-        const size_t m = std::min<size_t>((size_t)1 << 30, n - first);
-        hipLaunchKernelGGL(mesh_naive_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, stream, f.mesh, dXyz + 3 * first, m, dOut + first);
+    for (size_t first = 0; first < n; first += (size_t)1 << 28) {  // grid.x stays below 2^31
+        const size_t m = std::min<size_t>((size_t)1 << 28, n - first);
+        // enough waves to fill the chip: 256 CUs x 32 wave slots; a slice keeps at least 1024 triangles
+        const uint64_t byWaves = (8192 + m - 1) / m, byTris = std::max<uint64_t>(1, f.mesh.nTris / 1024);
+        const uint32_t slices = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min(byWaves, byTris), 4096));
+        unsigned long long* keys = dKeys ? dKeys + first : reinterpret_cast<unsigned long long*>(dOut + first);
+        hipError_t e = hipMemsetAsync(keys, 0xFF, m * sizeof(double), stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(mesh_naive_kernel, dim3((unsigned)((m * slices + 3) / 4)), dim3(256), 0, stream, f.mesh, dXyz + 3 * first, m, keys, slices);
+        hipLaunchKernelGGL(mesh_naive_finish_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, f.mesh, dXyz + 3 * first, m, keys,
+                           dOut + first);
     }
     return hipGetLastError();
 }

@@ -51,7 +51,8 @@ hipError_t launchFieldEval(hipStream_t stream, const FieldDev& f, const DeviceTa
                            size_t n, double* dOut);
 // mesh field, linear scan over all triangles (no BVH): Mesh::SignedDistanceAtPt(pt), Mesh.cpp:42-51,134-159
 hipError_t launchMeshEvalWave(hipStream_t stream, const FieldDev& f, const double* dXyz, size_t n, double* dOut);
-hipError_t launchMeshNaive(hipStream_t stream, const FieldDev& f, const double* dXyz, size_t n, double* dOut);
+// dKeys: n x 8 bytes of DEVICE memory for the per-point (distance, triangle) keys, or nullptr when dOut itself is device memory
+hipError_t launchMeshNaive(hipStream_t stream, const FieldDev& f, const double* dXyz, size_t n, double* dOut, unsigned long long* dKeys = nullptr);
 hipError_t launchAcosfSelftest(hipStream_t stream, uint32_t first, uint32_t stride, size_t n, float* dOut);
 constexpr int kTriRecordFloats = 12;  // MeshDev::triPos: a, b, c, cross(b - a, c - a)
 constexpr int kTriPreFloats = 12;     // MeshDev::triPre: g hu | unit normal hv | unit edge vector, triangle index

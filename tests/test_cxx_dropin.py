@@ -219,6 +219,27 @@ def test_example_benchmark_program_compiles(H, tmp_path):
     _build_example(H, tmp_path)
 
 
+def test_example_meshing_benchmark_program_compiles(H, tmp_path):
+    """examples/meshing_benchmarks.cpp (the reference's MeshingBenchmarks.cpp workloads through Meshing::ObjParser / Mesh / BVH)
+    builds with plain g++; its host-only legs (writing and parsing the .obj) run without a GPU."""
+    exe = _build_example(H, tmp_path, "meshing_benchmarks")
+    r = subprocess.run([exe, "48", "24"], capture_output=True, text=True, timeout=300, env=dict(os.environ, TMPDIR=str(tmp_path)))
+    assert "ObjParser::Load" in r.stdout and "(1152 vertices, 2304 triangles)" in r.stdout, r.stdout + r.stderr
+    assert "Mesh::CreateFromObj" in r.stdout
+
+
+@pytest.mark.gpu
+def test_example_meshing_benchmark_program_runs(H, tmp_path):
+    """MeshingBenchmarks.cpp:24-137 on a 131 072-triangle stand-in for Ramesses.obj: 10 000 one-point calls return what the batched
+    call returns, and the O(n) scan agrees with the BVH bit for bit (exit code 0 says so)."""
+    exe = _build_example(H, tmp_path, "meshing_benchmarks")
+    r = subprocess.run([exe, "256", "256"], capture_output=True, text=True, timeout=600, env=dict(os.environ, TMPDIR=str(tmp_path)))
+    assert r.returncode == 0, r.stdout + r.stderr
+    for line in ("BVH::Create", "SignedDistanceAtPt(pt, bvh), 10 000 calls", "the same distances", "equal to the BVH's answers: yes, bit for bit",
+                 "Octree::Create(config 1e-06, bvh.Field())"):
+        assert line in r.stdout, r.stdout
+
+
 @pytest.mark.gpu
 def test_example_benchmark_program_runs(H, tmp_path):
     r = subprocess.run([_build_example(H, tmp_path)], capture_output=True, text=True, timeout=600)
