@@ -133,6 +133,28 @@ def test_mesh_bvh_equals_linear_scan_bitwise(H, O, ctx):
         assert np.array_equal(bits(b[:500]), bits(want.astype(np.float64)))
 
 
+def test_linear_scan_is_the_same_however_it_is_cut(H, O, ctx):
+    """The O(n) scan cuts the triangles into as many slices as fill the chip (one point: hundreds; thousands of points: one)
+    and merges the slices' winners by (distance, triangle index): the answer does not depend on the cut, and the tie rule
+    is the reference's -- the first triangle of the scan among equals (Mesh.cpp:134-159) -- so points ON vertices and edges,
+    where up to six triangles tie exactly, return the oracle's triangle and bits."""
+    verts, tris = icosphere(4, 0.35, (0.02, 0.0, -0.01))  # 5120 triangles
+    f = H.Field.mesh(ctx, verts, tris)
+    rng = np.random.default_rng(5)
+    t = rng.integers(0, len(tris), 300)
+    a, b = verts[tris[t, 0].astype(np.int64)].astype(np.float64), verts[tris[t, 1].astype(np.int64)].astype(np.float64)
+    pts = np.concatenate([rng.uniform(-0.5, 0.5, (400, 3)), a, 0.5 * (a + b), a + 1e-3 * rng.normal(size=a.shape)])
+    whole = f.eval_naive(ctx, pts)
+    for n in (1, 2, 7, 100):
+        assert np.array_equal(bits(f.eval_naive(ctx, pts[:n])), bits(whole[:n]))
+        assert np.array_equal(bits(f.eval_naive(ctx, pts[-n:])), bits(whole[-n:]))
+    one_by_one = np.array([f.eval_naive(ctx, pts[i:i + 1])[0] for i in range(380, 440)])  # random points, then points on vertices
+    assert np.array_equal(bits(one_by_one), bits(whole[380:440]))
+    want, _, _ = O.MeshField(verts, tris).signed_distance(pts)
+    assert np.array_equal(bits(whole), bits(want.astype(np.float64)))
+    assert np.array_equal(bits(f.eval(ctx, pts)), bits(whole))
+
+
 def _hard_meshes():
     yield "icosphere L5", icosphere(5, 0.4)
     yield "displaced torus", displaced_torus(160, 96)
