@@ -31,6 +31,8 @@
 #include <cstring>
 #include <functional>
 #include <limits>
+#include <atomic>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -385,13 +387,15 @@ class Octree {
     }
     /// Batched Query over host arrays (xyz interleaved)
     void Query(const double* xyz, usize n, double* out) const {
-        if (!tree_) throw Error(HPSDF_ERR_STATE, "Query on an empty octree");
-        check(hpsdf_query_host(ctx_, tree_, xyz, n, out));
+        hpsdf_tree* t = deviceTree();
+        if (!t) throw Error(HPSDF_ERR_STATE, "Query on an empty octree");
+        check(hpsdf_query_host(ctx_, t, xyz, n, out));
     }
     /// Batched Query over device (HBM) arrays, asynchronous on the context stream
     void QueryDevice(const double* d_xyz, usize n, double* d_out) const {
-        if (!tree_) throw Error(HPSDF_ERR_STATE, "Query on an empty octree");
-        check(hpsdf_query_device(ctx_, tree_, d_xyz, n, d_out));
+        hpsdf_tree* t = deviceTree();
+        if (!t) throw Error(HPSDF_ERR_STATE, "Query on an empty octree");
+        check(hpsdf_query_device(ctx_, t, d_xyz, n, d_out));
     }
 
     /// As with Query, but with the unit "gradient" calculated via CD   (Octree.h:78, Octree.cpp:749-789)
@@ -404,8 +408,9 @@ class Octree {
     }
     /// Batched form; rows of grad for points outside the root are left untouched
     void QueryWithGradient(const double* xyz, usize n, double* out, double* grad) const {
-        if (!tree_) throw Error(HPSDF_ERR_STATE, "Query on an empty octree");
-        check(hpsdf_query_gradient_host(ctx_, tree_, xyz, n, out, grad));
+        hpsdf_tree* t = deviceTree();
+        if (!t) throw Error(HPSDF_ERR_STATE, "Query on an empty octree");
+        check(hpsdf_query_gradient_host(ctx_, t, xyz, n, out, grad));
     }
 
     /// Sphere tracing along ray_ (<= 200 Query steps).  As in the reference (Octree.cpp:705-746), t_ receives
@@ -421,19 +426,21 @@ class Octree {
     }
     /// Batched form over host arrays; t rows of misses are left untouched
     void QueryRay(const double* origins, const double* dirs, const double* tMax, usize n, uint8_t* hit, double* t) const {
-        if (!tree_) throw Error(HPSDF_ERR_STATE, "Query on an empty octree");
-        check(hpsdf_query_ray_host(ctx_, tree_, origins, dirs, tMax, n, hit, t));
+        hpsdf_tree* tr = deviceTree();
+        if (!tr) throw Error(HPSDF_ERR_STATE, "Query on an empty octree");
+        check(hpsdf_query_ray_host(ctx_, tr, origins, dirs, tMax, n, hit, t));
     }
 
     /// Outputs an image of the z = c_ slice over viewArea_ to <fName_>.bmp   (Octree.h:83-86, Octree.cpp:1131-1206;
     /// the reference needs stb_image_write for this, here the 24-bit BMP is written directly)
     void OutputFunctionSlice(const char* fName_, const f64 c_, const Eigen::AlignedBox3f& viewArea_) const {
-        if (!tree_) throw Error(HPSDF_ERR_STATE, "Query on an empty octree");
+        hpsdf_tree* t = deviceTree();
+        if (!t) throw Error(HPSDF_ERR_STATE, "Query on an empty octree");
         const uint64_t n = 2048;
         std::vector<uint8_t> rgb(n * n * 3);
         const float vmin[3] = {viewArea_.min()(0), viewArea_.min()(1), viewArea_.min()(2)};
         const float vmax[3] = {viewArea_.max()(0), viewArea_.max()(1), viewArea_.max()(2)};
-        check(hpsdf_function_slice(ctx_, tree_, c_, vmin, vmax, n, rgb.data(), nullptr));
+        check(hpsdf_function_slice(ctx_, t, c_, vmin, vmax, n, rgb.data(), nullptr));
         const std::string path = std::string(fName_) + ".bmp";
         std::FILE* fh = std::fopen(path.c_str(), "wb");
         if (!fh) throw Error(HPSDF_ERR_STATE, "cannot open " + path);
@@ -479,6 +486,21 @@ class Octree {
     void dropTree() {
         hpsdf_tree_destroy(tree_);
         tree_ = nullptr;
+        mirrorPending_.store(false, std::memory_order_release);
+    }
+    // The device mirror Query* and the CSG operations work on.  A tree this object has just built gets it on first use, not
+    // inside Create (the reference's Create ends when the tree is built; the mirror -- tables and a line-aligned copy of the
+    // coefficients, ~0.4 ms of host work -- is a cost of the first query here).  Query* are const and may be called from
+    // several threads (Octree.h:71-78): the first caller builds it under a lock.
+    hpsdf_tree* deviceTree() const {
+        if (mirrorPending_.load(std::memory_order_acquire)) {
+            std::lock_guard<std::mutex> guard(mirrorLock_);
+            if (mirrorPending_.load(std::memory_order_relaxed)) {
+                check(hpsdf_tree_upload(ctx_, block_, size_, &tree_));
+                mirrorPending_.store(false, std::memory_order_release);
+            }
+        }
+        return tree_;
     }
     void release() {
         Clear();
@@ -509,15 +531,16 @@ class Octree {
         block_ = blk;
         size_ = sz;
         config_ = config;
-        uploadTree();
+        mirrorPending_.store(true, std::memory_order_release);  // (deviceTree())
         // continuity.enforce: hpsdf_create has already run the host-side post-process (Octree.cpp:341-344)
         // on the block; LastContinuityStats() reports it.
         hpsdf_continuity_last_stats(&continuity_);
     }
     void csg(int op, const hpsdf_field* inner) {
-        if (!tree_) throw Error(HPSDF_ERR_STATE, "CSG on an empty octree");
+        hpsdf_tree* t = deviceTree();
+        if (!t) throw Error(HPSDF_ERR_STATE, "CSG on an empty octree");
         hpsdf_field* f = nullptr;
-        check(hpsdf_field_create_tree_csg(tree_, op, inner, &f));
+        check(hpsdf_field_create_tree_csg(t, op, inner, &f));
         FieldGuard g{f};
         createFrom(config_, f);  // Create(oldTree.config, ...), Octree.cpp:373
     }
@@ -550,6 +573,8 @@ class Octree {
         stats_ = o.stats_;
         ctx_ = o.ctx_;
         tree_ = o.tree_;
+        mirrorPending_.store(o.mirrorPending_.load(), std::memory_order_release);
+        o.mirrorPending_.store(false);
         block_ = o.block_;
         size_ = o.size_;
         o.ctx_ = nullptr;
@@ -565,7 +590,9 @@ class Octree {
     hpsdf_allgather_fn gather_ = nullptr;
     void* gatherUser_ = nullptr;
     mutable hpsdf_ctx* ctx_ = nullptr;
-    hpsdf_tree* tree_ = nullptr;
+    mutable hpsdf_tree* tree_ = nullptr;
+    mutable std::atomic<bool> mirrorPending_{false};  // block_ is a fresh build whose device mirror has not been made yet
+    mutable std::mutex mirrorLock_;
     void* block_ = nullptr;  // serialised tree: [nCoeffs][coeffs][nNodes][nodes][config]
     size_t size_ = 0;
     Config config_;
