@@ -8,7 +8,8 @@ import numpy as np, hpsdf_loader, oracle as O
 from helpers import icosphere, displaced_torus
 H = hpsdf_loader.load(); ctx = H.Context(0)
 bad = 0
-for seed in range(8):
+first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 0), (int(sys.argv[2]) if len(sys.argv) > 2 else 8)  # usage: fuzz_mesh_parity.py [first seed] [cases]
+for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
     if seed % 2 == 0:
         verts, tris = icosphere(1 + seed % 4 // 2, 0.3, tuple(rng.uniform(-0.05, 0.05, 3)))
