@@ -2403,12 +2403,74 @@ __global__ __launch_bounds__(256) void mesh_eval_wave_kernel(MeshDev m, const do
     if (active) out[i] = (double)v;
 }
 
+// The same for points in ANY order: the caller's points are visited along a Morton curve over the mesh's surroundings (30-bit
+// keys, an index sort), so that the 64 points of a wave are neighbours in space and share most of their walk -- 1 M random points
+// of a root box: 6.9 -> 3 ms on a 2.1 M-triangle mesh; every point's value is its own, whatever the order
+// (test_full_size_hierarchy_equals_linear_scan_bitwise).  Sets below kMeshEvalSortMin are not worth the sort's launches.
+constexpr size_t kMeshEvalSortMin = 4096;
+__device__ __forceinline__ uint32_t mortonSpread10(uint32_t v) {  // 10 bits -> every third bit
+    v &= 1023u;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__global__ __launch_bounds__(256) void mesh_eval_keys_kernel(MeshDev m, const double* __restrict__ xyz, uint32_t n, uint32_t* __restrict__ keys,
+                                                             uint32_t* __restrict__ ids) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const BvhNode& root = m.bvh[0];  // (its two child boxes: the mesh's box; a leaf root keeps the second empty)
+    uint32_t key = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const bool two = root.lo1[a] <= root.hi1[a];
+        const float lo = two ? fminf(root.lo0[a], root.lo1[a]) : root.lo0[a], hi = two ? fmaxf(root.hi0[a], root.hi1[a]) : root.hi0[a];
+        const float ext = fmaxf(hi - lo, 1e-30f);
+        // the grid spans the box and as much again on either side: points of a root box around the mesh keep their order too
+        const float t = ((float)xyz[3 * (size_t)i + a] - (lo - ext)) / (3.0f * ext);
+        const float q = fminf(fmaxf(t, 0.0f), 1.0f) * 1023.0f;  // (NaN -> 0 through fmaxf)
+        key |= mortonSpread10((uint32_t)q) << a;
+    }
+    keys[i] = key;
+    ids[i] = i;
+}
+__global__ __launch_bounds__(256) void mesh_eval_wave_sorted_kernel(MeshDev m, const double* __restrict__ xyz, const uint32_t* __restrict__ ids, size_t n,
+                                                                    double* __restrict__ out) {
+    __shared__ MeshWaveLds sWave[4];
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool active = i < n;
+    const size_t j = ids[active ? i : n - 1];
+    const float v = meshSignedDistanceWaveQ(m, V3{(float)xyz[3 * j], (float)xyz[3 * j + 1], (float)xyz[3 * j + 2]}, active, sWave[threadIdx.x >> 6]);
+    if (active) out[j] = (double)v;
+}
+
 hipError_t launchMeshEvalWave(hipStream_t stream, const FieldDev& f, const double* dXyz, size_t n, double* dOut) {
     if (n == 0) return hipSuccess;
     if (f.kind != kFieldMesh || f.csgOp >= 0) return hipErrorInvalidValue;
-    for (size_t first = 0; first < n; first += (size_t)1 << 38) {  // grid.x stays below 2^31
-        const size_t m = std::min<size_t>((size_t)1 << 38, n - first);
-        hipLaunchKernelGGL(mesh_eval_wave_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, f.mesh, dXyz + 3 * first, m, dOut + first);
+    static const bool noSort = std::getenv("HPSDF_MESH_EVAL_NO_SORT") != nullptr;  // measurement knob
+    for (size_t first = 0; first < n; first += (size_t)1 << 30) {  // a part's indices fit 32 bits
+        const size_t m = std::min<size_t>((size_t)1 << 30, n - first);
+        char* block = nullptr;
+        size_t tmpBytes = 0;
+        bool sorted = false;
+        if (!noSort && m >= kMeshEvalSortMin && sortPairsU32(stream, nullptr, tmpBytes, nullptr, nullptr, nullptr, nullptr, m, 30) == hipSuccess) {
+            const size_t arr = (m * sizeof(uint32_t) + 255) & ~(size_t)255;
+            // stream-ordered scratch: four index arrays and the sort's own; if the pool declines, the points go as they are
+            if (hipMallocAsync((void**)&block, 4 * arr + tmpBytes, stream) == hipSuccess) {
+                uint32_t *keys = (uint32_t*)block, *keysOut = (uint32_t*)(block + arr), *ids = (uint32_t*)(block + 2 * arr), *idsOut = (uint32_t*)(block + 3 * arr);
+                hipLaunchKernelGGL(mesh_eval_keys_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, f.mesh, dXyz + 3 * first, (uint32_t)m, keys, ids);
+                if (sortPairsU32(stream, block + 4 * arr, tmpBytes, keys, keysOut, ids, idsOut, m, 30) == hipSuccess) {
+                    hipLaunchKernelGGL(mesh_eval_wave_sorted_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, f.mesh, dXyz + 3 * first, idsOut, m,
+                                       dOut + first);
+                    sorted = true;
+                }
+                (void)hipFreeAsync(block, stream);
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        if (!sorted) hipLaunchKernelGGL(mesh_eval_wave_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, f.mesh, dXyz + 3 * first, m, dOut + first);
     }
     return hipGetLastError();
 }

@@ -490,4 +490,9 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
     return HPSDF_OK;
 }
 
+hipError_t sortPairsU32(hipStream_t stream, void* tmp, size_t& tmpBytes, const uint32_t* keys, uint32_t* keysOut, const uint32_t* vals, uint32_t* valsOut,
+                        size_t n, unsigned bits) {
+    return rocprim::radix_sort_pairs(tmp, tmpBytes, keys, keysOut, vals, valsOut, n, 0u, bits, stream);
+}
+
 }  // namespace hpsdf

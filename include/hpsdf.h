@@ -162,8 +162,9 @@ HPSDF_API int hpsdf_field_eval_host(hpsdf_ctx* ctx, const hpsdf_field* f, const 
  * (Source/Tests/MeshingUnitTests.cpp:110-138) compares the BVH answer with; same tie rule, so the two agree bit for bit. */
 HPSDF_API int hpsdf_field_eval_naive_host(hpsdf_ctx* ctx, const hpsdf_field* f, const double* xyz, size_t n, double* out);
 /* Mesh::SignedDistanceAtPt(pt, bvh, threadIdx) (Source/Meshing/Mesh.cpp:54-84) through the traversal Create's sampler
- * uses: 64 consecutive points share one walk of the BVH.  Same values as hpsdf_field_eval_host bit for bit, whatever the
- * order of the points; faster when neighbours in the array are neighbours in space.  Mesh fields only. */
+ * uses: 64 points share one walk of the BVH.  Same values as hpsdf_field_eval_host bit for bit, whatever the order of the
+ * points: sets of 4096 points or more are visited along a Morton curve (an index sort on the device), so that a wave's
+ * points are neighbours in space even when the array's are not.  Mesh fields only. */
 HPSDF_API int hpsdf_field_eval_wave_host(hpsdf_ctx* ctx, const hpsdf_field* f, const double* xyz, size_t n, double* out);
 /* The same through the per-point stack traversal (what a mesh field under a tree-CSG wrapper and the fused mesh fit run;
  * hpsdf_field_eval_* itself takes the faster shared traversal for plain mesh fields): same bits.  Diagnostics. */
