@@ -161,6 +161,23 @@ static bool TestOctreeCustomDomains() {  // :285-316
     return checkLoop(hpOctree, box, [&](const Eigen::Vector3d& p) { return Sphere075(p, 0); }, 0.01, "custom domain + continuity");
 }
 
+static bool TestObjParsing(const char* objPath) {  // MeshingUnitTests.cpp:45-49
+    Meshing::ObjParser objParser;
+    return objParser.Load(objPath);
+}
+
+static bool TestMeshCreation(const char* objPath) {  // :52-56
+    Meshing::Mesh objMesh;
+    return objMesh.CreateFromObj(objPath);
+}
+
+static bool TestBVHBuilding(const char* objPath) {  // :92-107 (TestNNOctreeQuerying, :59-89, exercises the point octree of the reference's
+    Meshing::Mesh objMesh;                            // CPU BVH builder, which has no counterpart here)
+    if (!objMesh.CreateFromObj(objPath)) return false;
+    Meshing::BVH objBVH;
+    return objBVH.Create(objMesh);
+}
+
 static bool TestBVHQuerying(const char* objPath) {  // MeshingUnitTests.cpp:110-138
     Meshing::Mesh objMesh;
     if (!objMesh.CreateFromObj(objPath)) return false;
@@ -191,7 +208,12 @@ int main(int argc, char** argv) {
         std::vector<T> tests = {{"TestOctreeCreation", TestOctreeCreation},           {"TestOctreeContinuity", TestOctreeContinuity},
                                 {"TestOctreeSerialisation", TestOctreeSerialisation}, {"TestOctreeCopying", TestOctreeCopying},
                                 {"TestOctreeSDFOperations", TestOctreeSDFOperations}, {"TestOctreeCustomDomains", TestOctreeCustomDomains}};
-        if (argc > 1) tests.push_back({"TestBVHQuerying", [&] { return TestBVHQuerying(argv[1]); }});
+        if (argc > 1) {
+            tests.push_back({"TestObjParsing", [&] { return TestObjParsing(argv[1]); }});
+            tests.push_back({"TestMeshCreation", [&] { return TestMeshCreation(argv[1]); }});
+            tests.push_back({"TestBVHBuilding", [&] { return TestBVHBuilding(argv[1]); }});
+            tests.push_back({"TestBVHQuerying", [&] { return TestBVHQuerying(argv[1]); }});
+        }
         int passed = 0;
         for (const T& t : tests) {
             const auto t0 = std::chrono::steady_clock::now();

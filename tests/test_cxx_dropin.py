@@ -262,7 +262,7 @@ def test_reference_unit_tests_program_compiles_and_fails_loudly_without_gpu(H, t
 
 @pytest.mark.gpu
 def test_reference_unit_tests_at_their_exact_settings(H, tmp_path):
-    """HPUnitTests.cpp:46-316 and MeshingUnitTests.cpp:110-138 through the C++ drop-in: targetError 1e-8, Polynomial(3)
+    """HPUnitTests.cpp:46-316 and MeshingUnitTests.cpp:45-56,92-138 through the C++ drop-in: targetError 1e-8, Polynomial(3)
     weighting, continuity strength 8, root [-0.25,5]^3 with continuity, 1 000 000 samples per loop, copy constructor then
     move assignment, Union/Intersect/Subtract at 1e-8, 50 naive-vs-BVH samples on the reference's own mesh."""
     import numpy as np
@@ -276,9 +276,10 @@ def test_reference_unit_tests_at_their_exact_settings(H, tmp_path):
             fh.write("f %d %d %d\n" % (a + 1, b + 1, c + 1))
     r = subprocess.run([exe, str(obj)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "7 / 7 tests passed" in r.stdout, r.stdout
+    assert "10 / 10 tests passed" in r.stdout, r.stdout
     for name in ("TestOctreeCreation", "TestOctreeContinuity", "TestOctreeSerialisation", "TestOctreeCopying",
-                 "TestOctreeSDFOperations", "TestOctreeCustomDomains", "TestBVHQuerying"):
+                 "TestOctreeSDFOperations", "TestOctreeCustomDomains", "TestObjParsing", "TestMeshCreation", "TestBVHBuilding",
+                 "TestBVHQuerying"):
         assert name + ": passed" in r.stdout, r.stdout
 
 
