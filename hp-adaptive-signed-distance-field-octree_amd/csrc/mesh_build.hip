@@ -32,6 +32,8 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 
+#include <mutex>
+
 #include "device_types.hpp"
 #include "launch.hpp"
 #include "runtime.hpp"
@@ -374,6 +376,7 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
     // two allocations in all (hipMalloc / hipFree cost ~0.1-0.3 ms apiece): the field's five arrays, and the temporaries
     char* fieldBlock = nullptr;
     char* tempBlock = nullptr;
+    bool tempPooled = false;
     {
         auto carve = [](size_t& at, size_t bytes) {
             const size_t o = at;
@@ -392,8 +395,30 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
                      oPar = carve(tb, 2 * nTris * sizeof(int32_t)), oRan = carve(tb, 3 * nTris * sizeof(int32_t)), oTK = carve(tb, tabSize * sizeof(unsigned long long)),
                      oTV = carve(tb, tabSize * sizeof(uint32_t)), oFl = carve(tb, sizeof(MeshBuildFlags)),
                      oSort = carve(tb, sortTmpBytes ? sortTmpBytes : 16);
-        if (e == hipSuccess) e = hipMalloc((void**)&fieldBlock, fb);
-        if (e == hipSuccess) e = hipMalloc((void**)&tempBlock, tb);
+        // Both blocks come from the device's stream-ordered pool, which is told to keep what is freed (releaseThreshold): a plain
+        // hipMalloc of a few hundred megabytes costs anything between 0.05 and 15 ms here, more than the whole build.  The field's
+        // block is still released by hipFree (hpsdf_field_destroy: it waits for the device, as before); if the pool declines
+        // (HPSDF_MESH_NO_POOL=1, or a runtime without it), hipMalloc it is.
+        static const bool noPool = std::getenv("HPSDF_MESH_NO_POOL") != nullptr;
+        if (e == hipSuccess && !noPool) {
+            static std::once_flag poolOnce[64];
+            int dev = 0;
+            if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64)
+                std::call_once(poolOnce[dev], [dev] {
+                    hipMemPool_t pool = nullptr;
+                    uint64_t keep = ~0ull;
+                    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+                    (void)hipGetLastError();
+                });
+            if (hipMallocAsync((void**)&fieldBlock, fb, s) != hipSuccess) fieldBlock = nullptr, (void)hipGetLastError();
+            if (fieldBlock && hipMallocAsync((void**)&tempBlock, tb, s) == hipSuccess) {
+                tempPooled = true;
+            } else {
+                tempBlock = nullptr, (void)hipGetLastError();
+            }
+        }
+        if (e == hipSuccess && !fieldBlock) e = hipMalloc((void**)&fieldBlock, fb);
+        if (e == hipSuccess && !tempBlock) e = hipMalloc((void**)&tempBlock, tb);
         if (e == hipSuccess) {
             f->dBlock = fieldBlock;
             f->dVerts = (float*)(fieldBlock + oVerts), f->dTris = (uint32_t*)(fieldBlock + oTris), f->dTriPos = (float*)(fieldBlock + oTriPos);
@@ -408,7 +433,7 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
         }
     }
     auto freeTemps = [&] {
-        if (tempBlock) (void)hipFree(tempBlock);
+        if (tempBlock) (void)(tempPooled ? hipFreeAsync(tempBlock, s) : hipFree(tempBlock));  // (stream-ordered: after the kernels that use it)
         tempBlock = nullptr;
     };
     auto freeField = [&] {

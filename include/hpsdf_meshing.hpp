@@ -163,11 +163,12 @@ class BVH {  // Include/Meshing/BVH.h:17-30
     bool Create(const Mesh& mesh_) {
         Clear();
         if (!ctx_ && hpsdf_ctx_create(device_, stream_, &ctx_) != HPSDF_OK) return false;
-        std::vector<float> v(3 * mesh_.vertices.size());
-        for (size_t i = 0; i < mesh_.vertices.size(); ++i)
-            for (int a = 0; a < 3; ++a) v[3 * i + a] = mesh_.vertices[i](a);
-        std::vector<uint64_t> t(mesh_.triIndices.begin(), mesh_.triIndices.end());
-        return hpsdf_field_create_mesh(ctx_, v.data(), mesh_.vertices.size(), t.data(), t.size() / 3, &field_) == HPSDF_OK;
+        // the mesh's own arrays go to the library as they are: a Vector3f is three packed floats (Eigen's as well as the
+        // stand-in's) and the reference's "u32" is an 8-byte unsigned integer (Literals.h:9)
+        static_assert(sizeof(Eigen::Vector3f) == 3 * sizeof(float), "Vector3f is three packed floats");
+        static_assert(sizeof(u32) == sizeof(uint64_t), "the reference's u32 is 8 bytes wide");
+        return hpsdf_field_create_mesh(ctx_, reinterpret_cast<const float*>(mesh_.vertices.data()), mesh_.vertices.size(),
+                                       reinterpret_cast<const uint64_t*>(mesh_.triIndices.data()), mesh_.triIndices.size() / 3, &field_) == HPSDF_OK;
     }
     /// The mesh as a field Octree::Create samples on the GPU: octree.Create(config, bvh.Field())
     const hpsdf_field* Field() const { return field_; }
