@@ -55,6 +55,12 @@ __device__ __forceinline__ V3 meshVert(const MeshDev& m, uint32_t i) {
 
 constexpr float kEpsF32 = 0.000001f;  // Include/Utility/Literals.h:13
 
+// A query point with a coordinate that is not a finite number has no closest triangle: every comparison of the reference's
+// search fails, its bestTri stays -1 and Mesh::SignedDistanceAtPt reads out of bounds (Mesh.cpp:139,157; BVH.cpp:281,343).
+// Here such a point takes no part in a traversal and its value is this NaN, on every path.
+__device__ __forceinline__ bool meshPointFinite(V3 p) { return fabsf(p.x) <= FLT_MAX && fabsf(p.y) <= FLT_MAX && fabsf(p.z) <= FLT_MAX; }
+__device__ __forceinline__ float meshNoTriangle() { return __uint_as_float(0xFFFFFFFFu); }
+
 // returns simplex*4 + simplexIdx; closest point in q
 // (n: the triangle's unnormalised normal cross(b - a, c - a), precomputed per triangle by mesh_tripos_kernel with these very
 // operations -- the value the reference recomputes in every call, Utility.cpp:41)
@@ -197,6 +203,7 @@ __device__ __forceinline__ float rejectBound(float best, float slack) {
 // Mesh::ClosestTriangleToPt (Mesh.cpp:134-159) whatever the visiting order.  `hint` (the winner of the
 // caller's previous, nearby query) is tested first so that the bound is tight from the start.
 __device__ float meshSignedDistance(const MeshDev& m, V3 pt, uint32_t& hint) {
+    if (!meshPointFinite(pt)) return meshNoTriangle();
     float best = FLT_MAX, reject = __builtin_inff();
     const float slack = meshSlack(m.bvh[0]);
     uint32_t bestTri = 0xFFFFFFFFu;
@@ -265,6 +272,7 @@ __device__ float meshSignedDistance(const MeshDev& m, V3 pt, uint32_t& hint) {
             stackD[sp++] = da;
         }
     }
+    if (bestTri == 0xFFFFFFFFu) return meshNoTriangle();  // (every triangle's distance overflowed)
     hint = bestTri;
     const V3 nrm = pseudoNormal(m, bestTri, bestCode);
     const V3 d = pt - bestQ;
@@ -280,7 +288,8 @@ __device__ float meshSignedDistance(const MeshDev& m, V3 pt, uint32_t& hint) {
 // scattered 64-byte nodes) become a few dozen uniform loads.  `stack` : kMeshStack ints of LDS owned by this wave (two entries per level of a BVH at most 31 levels deep).
 // Every lane of the wave must call this (inactive lanes with active = false).
 constexpr int kMeshStack = 128;
-__device__ float meshSignedDistanceWave(const MeshDev& m, V3 pt, bool active, uint32_t& hint, int32_t* stack) {
+__device__ float meshSignedDistanceWave(const MeshDev& m, V3 pt, bool activeIn, uint32_t& hint, int32_t* stack) {
+    const bool active = activeIn && meshPointFinite(pt);
     float best = FLT_MAX;
     float bound = __builtin_inff();  // best * 1.00001f + 1e-30f, kept beside best: what a box distance is compared with
     float reject = __builtin_inff();  // what a triangle's lower bound is compared with (rejectBound)
@@ -379,8 +388,8 @@ __device__ float meshSignedDistanceWave(const MeshDev& m, V3 pt, bool active, ui
         atomicAdd(m.stats + 2, (unsigned long long)nTriInstr), atomicAdd(m.stats + 3, (unsigned long long)nTriLanes);
     }
 #endif
-    float r = 0.0f;
-    if (active) {
+    float r = activeIn ? meshNoTriangle() : 0.0f;
+    if (active && bestTri != 0xFFFFFFFFu) {
         hint = bestTri;
         const V3 nrm = pseudoNormal(m, bestTri, bestCode);
         const V3 d = pt - bestQ;
@@ -460,7 +469,8 @@ __device__ __forceinline__ NodeSlab loadSlabUniform(const NodeSlab* base, int32_
     s.n1 = make_float4(__uint_as_float(w[12]), __uint_as_float(w[13]), __uint_as_float(w[14]), __uint_as_float(w[15]));
     return s;
 }
-__device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool active, MeshWaveLds& L) {
+__device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool activeIn, MeshWaveLds& L) {
+    const bool active = activeIn && meshPointFinite(pt);
     const int lane = threadIdx.x & 63;
     const unsigned long long below = (1ull << lane) - 1ull;
     L.best[lane] = ((unsigned long long)__float_as_uint(FLT_MAX) << 32) | 0xFFFFFFFFull;
@@ -880,8 +890,8 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool active, M
         atomicAdd(m.stats + 6, (unsigned long long)nClosestBatches), atomicAdd(m.stats + 7, (unsigned long long)nSeedExact);
     }
 #endif
-    float r = 0.0f;
-    if (active) {
+    float r = activeIn ? meshNoTriangle() : 0.0f;
+    if (active && (uint32_t)(L.best[lane] & 0xFFFFFFFFull) != 0xFFFFFFFFu) {
         const uint32_t bestTri = (uint32_t)(L.best[lane] & 0xFFFFFFFFull);
         V3 bestQ;
         const float4 tp[3] = {m.triPos[3 * (size_t)bestTri], m.triPos[3 * (size_t)bestTri + 1], m.triPos[3 * (size_t)bestTri + 2]};
@@ -2376,8 +2386,8 @@ __global__ __launch_bounds__(256) void mesh_naive_finish_kernel(MeshDev m, const
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const unsigned long long key = keys[i];
-    if (key == ~0ull) {  // no triangle came closer than FLT_MAX: all ones (a NaN)
-        reinterpret_cast<unsigned long long*>(out)[i] = ~0ull;
+    if (key == ~0ull) {  // no triangle came closer than FLT_MAX (a point that is not finite): the NaN of the other paths
+        out[i] = (double)meshNoTriangle();
         return;
     }
     const uint32_t t = (uint32_t)key;

@@ -157,6 +157,8 @@ HPSDF_API int hpsdf_field_destroy(hpsdf_field* f);
 HPSDF_API int hpsdf_field_eval_device(hpsdf_ctx* ctx, const hpsdf_field* f, const double* d_xyz, size_t n,
                                       double* d_out);
 HPSDF_API int hpsdf_field_eval_host(hpsdf_ctx* ctx, const hpsdf_field* f, const double* xyz, size_t n, double* out);
+/* (Mesh fields: a point with a coordinate that is not a finite number has no closest triangle -- the reference's search ends
+ * with bestTri = -1 there and reads out of bounds, Mesh.cpp:139,157 -- and evaluates to a NaN on every entry point below.) */
 /* Mesh::SignedDistanceAtPt(pt) without a BVH (Source/Meshing/Mesh.cpp:42-51 over the O(n) scan :134-159), mesh fields
  * only: every triangle is tested for every point (one wave per point).  What the reference's TestBVHQuerying
  * (Source/Tests/MeshingUnitTests.cpp:110-138) compares the BVH answer with; same tie rule, so the two agree bit for bit. */

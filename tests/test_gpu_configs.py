@@ -155,6 +155,29 @@ def test_linear_scan_is_the_same_however_it_is_cut(H, O, ctx):
     assert np.array_equal(bits(f.eval(ctx, pts)), bits(whole))
 
 
+def test_mesh_evaluation_order_does_not_matter(H, ctx):
+    """hpsdf_field_eval_* visits sets of 4096 points or more along a Morton curve (keys from the mesh's surroundings, an index
+    sort on the device); smaller sets go as they are.  Same bits either way -- also for points far outside the key grid and
+    repeated points.  A point with a coordinate that is not a finite number has no closest triangle (the reference's search
+    ends with bestTri = -1 and reads out of bounds, Mesh.cpp:139,157): here its value is a NaN, the same on every path, and
+    it costs its wave nothing."""
+    verts, tris = displaced_torus(96, 64)
+    f = H.Field.mesh(ctx, verts, tris)
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-0.6, 0.6, (9000, 3))
+    pts[100:200] = pts[0]                      # repeated
+    pts[200:260] *= 1e4                        # far outside the grid: all in the corner cells
+    pts[260:264, 1] = np.nan
+    pts[264, 0], pts[265, 2] = np.inf, -np.inf
+    whole = f.eval(ctx, pts)                   # sorted
+    parts = np.concatenate([f.eval(ctx, pts[i:i + 3000]) for i in range(0, 9000, 3000)])  # three calls below the threshold
+    assert np.array_equal(bits(whole), bits(parts))
+    assert np.array_equal(bits(f.eval(ctx, pts[:4096])), bits(parts[:4096])) and np.array_equal(bits(f.eval(ctx, pts[:4097])), bits(parts[:4097]))
+    assert np.isnan(whole[260:266]).all() and not np.isnan(np.delete(whole, np.arange(260, 266))).any()
+    assert np.array_equal(bits(whole), bits(f.eval_lane(ctx, pts))) and np.array_equal(bits(whole), bits(f.eval_wave(ctx, pts)))
+    assert np.array_equal(bits(whole[:600]), bits(f.eval_naive(ctx, pts[:600])))
+
+
 def _hard_meshes():
     yield "icosphere L5", icosphere(5, 0.4)
     yield "displaced torus", displaced_torus(160, 96)
