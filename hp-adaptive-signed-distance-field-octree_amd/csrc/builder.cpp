@@ -173,6 +173,10 @@ int builderSelect(hpsdf_build* b, uint64_t* nJobs) {
     *nJobs = 0;
     if (b->roundOpen) return fail(HPSDF_ERR_STATE, "previous round not applied");
     if (b->finished) return HPSDF_OK;
+    // A field that is NaN or infinite at a sample poisons that cell's error and the running total for good: the reference's loop
+    // (`finished = total < threshold || queue.empty()`, :216) then refines until memory ends.  Fail instead, after the first round.
+    if (!(std::fabs(b->total) <= DBL_MAX))
+        return fail(HPSDF_ERR_INVALID_ARGUMENT, "the field is not a finite number at some sample point (the build's total error is NaN or infinite)");
     if (b->total < b->cfg.target_error_threshold || b->heap.empty()) {  // Octree.cpp:216
         b->finished = true;
         return HPSDF_OK;

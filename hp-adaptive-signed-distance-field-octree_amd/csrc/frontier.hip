@@ -33,6 +33,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cfloat>
+#include <cmath>
 #include <cstddef>
 #include <chrono>
 #include <cstdio>
@@ -1827,6 +1828,9 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
     uint32_t knownNodes = hh->nNodes, knownMaxDeg = hh->maxDegree;
     uint64_t knownArena = hh->arenaUsed;
     while (!hh->done) {
+        // (as builderSelect: a total that is NaN or infinite never falls below the threshold -- the field is not finite somewhere)
+        if (!(std::fabs(hh->total) <= DBL_MAX))
+            return fail(HPSDF_ERR_INVALID_ARGUMENT, "the field is not a finite number at some sample point (the build's total error is NaN or infinite)");
         // capacities for this round (the device flags what the host failed to foresee; it cannot happen by these bounds)
         hipError_t e = ws->ensureNodes(knownNodes + 8u * Kj, s);
         if (e == hipSuccess) e = ws->ensureArena(knownArena + (uint64_t)Kj * rowsPerJob((int)knownMaxDeg), knownArena, s);

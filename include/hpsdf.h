@@ -334,7 +334,9 @@ HPSDF_API int hpsdf_continuity_matrix_device(hpsdf_ctx* ctx, const void* block, 
 HPSDF_API int hpsdf_continuity_last_stats(hpsdf_continuity_stats* out);
 
 /* whole Create on one GPU: begin .. assemble, then the continuity post-process when
- * cfg->continuity_enforce is set (Octree.cpp:341-344).  *block is malloc'd (caller frees). */
+ * cfg->continuity_enforce is set (Octree.cpp:341-344).  *block is malloc'd (caller frees).
+ * HPSDF_ERR_INVALID_ARGUMENT after the first round if the field is NaN or infinite at a sample point: the total error is then
+ * NaN / infinite for good and the reference's loop (Octree.cpp:216) would refine until memory ends. */
 HPSDF_API int hpsdf_create(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* field,
                            uint64_t max_jobs_per_round, void** block, size_t* size, hpsdf_build_stats* stats);
 

@@ -178,6 +178,20 @@ def test_mesh_evaluation_order_does_not_matter(H, ctx):
     assert np.array_equal(bits(whole[:600]), bits(f.eval_naive(ctx, pts[:600])))
 
 
+def test_field_that_is_not_finite_fails_the_build(H, ctx):
+    """A field that is NaN or infinite at a sample makes the running total NaN / infinite for good; the reference's loop
+    (`finished = total < threshold || queue.empty()`, Octree.cpp:216) would then refine until memory ends.  Here the build
+    fails after the first round, on the device frontier and on the host scheduler alike."""
+    for field in (H.Field.sphere((0.1, 0.0, 0.0), float("nan")), H.Field.sphere((float("inf"), 0.0, 0.0), 0.3),
+                  H.Field.callback(lambda p, t: float("nan") if p[0] > 0.25 else float(np.linalg.norm(p) - 0.3))):
+        with pytest.raises(H.HpsdfError) as e:
+            H.create_block(ctx, H.make_config(1e-6), field, 1024)
+        assert e.value.status == H.ERR_INVALID_ARGUMENT and "not a finite number" in str(e.value)
+    # and the context is usable afterwards
+    blk, st = H.create_block(ctx, H.make_config(1e-4), H.Field.sphere((0.25, 0, 0), 0.5), 1024)
+    assert st["n_nodes"] == 4681
+
+
 def _hard_meshes():
     yield "icosphere L5", icosphere(5, 0.4)
     yield "displaced torus", displaced_torus(160, 96)
