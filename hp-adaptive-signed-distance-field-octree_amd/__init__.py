@@ -170,6 +170,7 @@ _SIGNATURES = {
                                C.POINTER(C.c_size_t), C.POINTER(BuildStats)]),
     "hpsdf_create_distributed": (C.c_int, [C.c_void_p, C.POINTER(PodConfig), C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p,
                                            C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(BuildStats)]),
+    "hpsdf_fit_cells": (C.c_int, [C.c_void_p, C.POINTER(PodConfig), C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]),
     "hpsdf_bench_fit": (C.c_int, [C.c_void_p, C.POINTER(PodConfig), C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int,
                                   C.POINTER(C.c_double)]),
 }
@@ -704,6 +705,16 @@ def bench_fit(ctx, config, field, degree, depth, n_cells, repeats=5):
     ms = C.c_double()
     check(lib().hpsdf_bench_fit(ctx.handle, C.byref(pod), field.handle, degree, depth, n_cells, repeats, C.byref(ms)))
     return ms.value
+
+
+def fit_cells(ctx, config, field, degree, depth, n_cells):
+    """From-scratch fits of `degree` for the first n_cells cells of the depth-`depth` lattice (x fastest) -> (coeffs[n, ncoef], errs[n])."""
+    pod = config.to_pod()
+    nc = int(NCOEF[degree])
+    coeffs, errs = np.empty((n_cells, nc)), np.empty(n_cells)
+    check(lib().hpsdf_fit_cells(ctx.handle, C.byref(pod), field.handle, degree, depth, n_cells, coeffs.ctypes.data_as(C.c_void_p),
+                                errs.ctypes.data_as(C.c_void_p)))
+    return coeffs, errs
 
 
 class Octree:

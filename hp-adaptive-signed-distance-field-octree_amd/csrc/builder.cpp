@@ -312,7 +312,7 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
     const bool meshFused = innermost(field)->kind == kHostMesh && !meshSampled;
     // opt-in fast fit (hpsdf_ctx_set_fast_fit): degrees >= 4 of unweighted, non-CSG fields go to the matrix cores
     const bool fastOn = ctx->fastFit && !b->weighted && !meshFused && field->kind != kHostTreeCsg;
-    auto fastDeg = [&](int deg) { return fastOn && deg >= 4 && deg <= 9; };
+    auto fastDeg = [&](int deg) { return fastOn && deg >= 4 && deg <= 11; };
 
     // ---- workgroup table
     uint32_t nBlocks = 0;

@@ -1380,9 +1380,26 @@ int hpsdf_continuity_last_stats(hpsdf_continuity_stats* out) {
 }
 
 // ---------------------------------------------------------------------------- micro-benchmark
+static int benchFit(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* field, int degree, int depth, uint64_t nCells, int repeats,
+                    double* msPerLaunch, double* coeffsOut, double* errsOut);
 int hpsdf_bench_fit(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* field, int degree, int depth,
                     uint64_t nCells, int repeats, double* msPerLaunch) {
     HPSDF_TRY
+    if (!msPerLaunch) return fail(HPSDF_ERR_INVALID_ARGUMENT, "bad bench arguments");
+    return benchFit(ctx, cfg, field, degree, depth, nCells, repeats, msPerLaunch, nullptr, nullptr);
+    HPSDF_CATCH
+}
+int hpsdf_fit_cells(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* field, int degree, int depth, uint64_t nCells, double* coeffs,
+                    double* errs) {
+    HPSDF_TRY
+    if (!coeffs || !errs) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    double ms = 0.0;
+    return benchFit(ctx, cfg, field, degree, depth, nCells, 1, &ms, coeffs, errs);
+    HPSDF_CATCH
+}
+static int benchFit(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* field, int degree, int depth, uint64_t nCells, int repeats,
+                    double* msPerLaunch, double* coeffsOut, double* errsOut) {
+    {
     if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "a device context is required");
     if (!cfg || !field || !msPerLaunch || degree < 0 || degree > kMaxDegree || depth < 0 || depth > kMaxDepth || nCells == 0 ||
         repeats < 1)
@@ -1462,6 +1479,8 @@ int hpsdf_bench_fit(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* 
         float ms = 0.f;
         if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
         *msPerLaunch = (double)ms / repeats;
+        if (e == hipSuccess && coeffsOut) e = hipMemcpy(coeffsOut, dA, nCells * nc * sizeof(double), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && errsOut) e = hipMemcpy(errsOut, dE, nCells * sizeof(double), hipMemcpyDeviceToHost);
     }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
@@ -1472,7 +1491,7 @@ int hpsdf_bench_fit(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* 
     if (rc) return rc;
     if (e != hipSuccess) return hipFail(e, "bench_fit");
     return HPSDF_OK;
-    HPSDF_CATCH
+    }
 }
 
 }  // extern "C"

@@ -1,4 +1,4 @@
-// Opt-in fast fit for degrees 4..9 on the matrix cores (hpsdf_ctx_set_fast_fit).
+// Opt-in fast fit for degrees 4..11 on the matrix cores (hpsdf_ctx_set_fast_fit).
 //
 // Octree::FitPolynomial (Source/HP/Octree.cpp:1007-1093) is a contraction: with the basis row r = (a, b, c) and the sample
 // s = (i, j, k) of the (4p+1)^3 Gauss-Legendre grid,
@@ -256,6 +256,8 @@ void launchMfmaT(hipStream_t stream, int degree, const FitBlock* dBlocks, uint32
         HPSDF_MFMA_CASE(7)
         HPSDF_MFMA_CASE(8)
         HPSDF_MFMA_CASE(9)
+        HPSDF_MFMA_CASE(10)
+        HPSDF_MFMA_CASE(11)
         default: break;
     }
 #undef HPSDF_MFMA_CASE
@@ -264,10 +266,11 @@ void launchMfmaT(hipStream_t stream, int degree, const FitBlock* dBlocks, uint32
 }  // namespace
 
 bool fitMfmaSupports(int degree, const FieldDev& field) {
-    // (degrees 10 and 11 -- 18 and 23 tiles of accumulators -- do not fit the register file beside the pipeline's operands)
+    // (degrees 10 and 11 -- 18 and 23 tiles of accumulators -- take 351 and 438 of a lane's 512 registers at one wave per SIMD, no
+    // scratch: instantiated since round 3; tests/test_gpu_parity.py compares every degree 2..11 with the bit-exact kernel cell by cell)
     // (degrees 2 and 3 are instantiated for the micro-benchmark -- one and two tiles of 16 rows, 62.5 % full; builds send only
     // degrees >= 4 here: builder.cpp fastDeg, frontier.hip frShape)
-    return degree >= 2 && degree <= 9 && field.csgOp < 0 && (field.kind == kFieldAnalytic || field.kind == kFieldSamples);
+    return degree >= 2 && degree <= 11 && field.csgOp < 0 && (field.kind == kFieldAnalytic || field.kind == kFieldSamples);
 }
 
 // Blocks of at most 16 fits of one class (degree `degree`, any mix of from-scratch and incremental blocks).

@@ -157,7 +157,7 @@ __host__ __device__ inline size_t frLds(int degree, int g, int planes) {  // = f
 }
 // workgroup shape of `count` fits of one class: what fitShape (kernels.hip) gives an unweighted, sampled-or-analytic fit
 __host__ __device__ inline void frShape(int degree, bool incr, uint32_t count, int* cells, int* planes, bool fast = false, bool weighted = false) {
-    if (fast && degree >= 4 && degree <= 9) {  // the matrix-core fit: one workgroup = one tile of 16 cells
+    if (fast && degree >= 4 && degree <= 11) {  // the matrix-core fit: one workgroup = one tile of 16 cells
         *cells = kMfmaCells, *planes = 1;
         return;
     }
@@ -1874,7 +1874,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
                 if (!used[k]) HPSDF_HIP(hipStreamWaitEvent(fs, ws->forkEv, 0));
                 used[k] = true;
             }
-            if (d.fastFit && deg >= 4 && deg <= 9)
+            if (d.fastFit && deg >= 4 && deg <= 11)
                 HPSDF_HIP(launchFitMfma(fs, deg, d.blocks, taskBound, d.tasks, ws->arena, d.errs, ctx->dTables, fdr, rm, &d.hdr->degBlocks[deg][0]));
             else
                 HPSDF_HIP(launchFit(fs, deg <= 5 ? deg : 0, 1, d.blocks, taskBound, fitLdsTable[deg], d.tasks, ws->arena, d.errs, nullptr,

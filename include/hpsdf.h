@@ -374,6 +374,12 @@ HPSDF_API int hpsdf_create_distributed(hpsdf_ctx* ctx, const hpsdf_config* cfg, 
  * n_cells from-scratch fits of `degree` at `depth` over a lattice of cells, results discarded. */
 HPSDF_API int hpsdf_bench_fit(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* field, int degree,
                               int depth, uint64_t n_cells, int repeats, double* ms_per_launch);
+/* The same fits with their results: Octree::FitPolynomial (Octree.cpp:1007-1093) from scratch at `degree` for the first
+ * n_cells cells of the depth-`depth` lattice over [-1/2, 1/2]^3 (x fastest): coeffs[n_cells][ncoef(degree)], errs[n_cells].
+ * The kernel is the one a build would take: the bit-exact one, or the matrix-core one after hpsdf_ctx_set_fast_fit(1).
+ * What the fit known-answer tests compare with the oracle's FitPolynomial, degree by degree. */
+HPSDF_API int hpsdf_fit_cells(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* field, int degree, int depth,
+                              uint64_t n_cells, double* coeffs, double* errs);
 
 #ifdef __cplusplus
 }

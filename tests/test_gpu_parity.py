@@ -265,6 +265,33 @@ def test_csg_rebuild_bitwise(H, O, ctx, op_name):
     assert np.abs(t.Query(p) - true).max() <= 0.05
 
 
+# ------------------------------------------------------------------ fit known answers, degree by degree
+@pytest.mark.parametrize("degree", list(range(2, 12)))
+def test_fit_kernels_match_the_oracle_at_every_degree(H, O, ctx, degree):
+    """Octree::FitPolynomial (Octree.cpp:1007-1093) cell by cell through hpsdf_fit_cells: the default kernel -- degree-specialised
+    bodies for 2..5, the any-degree body for 6..11, which no BASELINE-sized build reaches -- returns the oracle's coefficients
+    and error bit for bit; the matrix-core kernel (hpsdf_ctx_set_fast_fit, every degree 2..11) the same to rounding."""
+    depth, n = 3, 40 if degree <= 8 else 12
+    cfg, ocfg = H.make_config(1e-5), O.default_config(1e-5)
+    got_c, got_e = H.fit_cells(ctx, cfg, product_field(H, "union3"), degree, depth, n)
+    of = oracle_field(O, "union3")
+    side, h = 1 << depth, np.float32(1.0) / np.float32(1 << depth)
+    for i in range(n):
+        ix, iy, iz = i % side, (i // side) % side, i // (side * side)
+        bmin = np.array([np.float32(-0.5) + np.float32(k) * h for k in (ix, iy, iz)], np.float32)
+        want_c, want_e = O.fit_polynomial(of, ocfg, bmin, bmin + h, degree, depth)
+        assert np.array_equal(bits(got_c[i]), bits(want_c)), (degree, i)
+        assert bits(np.array([got_e[i]]))[0] == bits(np.array([want_e]))[0], (degree, i)
+    fast = H.Context(0)
+    fast.set_fast_fit(True)
+    fc, fe = H.fit_cells(fast, cfg, product_field(H, "union3"), degree, depth, n)
+    fast.close()
+    scale = np.abs(got_c).max()
+    assert np.abs(fc - got_c).max() <= 1e-13 * scale
+    assert np.abs(fe - got_e).max() <= 1e-9 * got_e.max() + 1e-30
+    assert not np.array_equal(fc, got_c)  # (another arithmetic: the matrix-core kernel did run)
+
+
 # ------------------------------------------------------------------ mesh field (SURVEY 8 a-M)
 def test_device_acosf_is_the_host_libms(H, O, ctx):
     """The one libm call of the mesh path (Mesh.cpp:226-231, the angle weights of a vertex pseudo-normal): the device runs
