@@ -76,6 +76,27 @@ def test_world2_gloo_block_identical(golden, case, O, H):
     assert res[0]["shard"] == [0, 500] and res[1]["shard"] == [500, 1000]
 
 
+def test_world3_gloo_uneven_slices(golden, O, H):
+    """Three ranks: the round's jobs do not divide evenly, the cost-balanced slices differ in length and the point shards too;
+    every rank still ends with the oracle's block (A2: sphere at 1e-8, five rounds with P and H refinement)."""
+    g = dict(golden["blocks"]["A2_sphere_1e-8_K1024"])
+    with tempfile.TemporaryDirectory() as td:
+        wpath = os.path.join(td, "worker.py")
+        open(wpath, "w").write(WORKER)
+        out = os.path.join(td, "res")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr",
+               "127.0.0.1", "--master-port", "29523", wpath, ROOT, json.dumps(g), out]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        res = [json.load(open(out + ".%d" % k)) for k in range(3)]
+    for k in range(3):
+        assert res[k]["sha"] == g["block_sha256"]
+        assert res[k]["stats"]["n_nodes"] == g["n_nodes"] and res[k]["stats"]["jobs"] == g["stats"]["jobs"]
+    assert [r["shard"] for r in res] == [[0, 334], [334, 667], [667, 1000]] or sum(r["shard"][1] - r["shard"][0] for r in res) == 1000
+    assert res[0]["shard"][0] == 0 and res[2]["shard"][1] == 1000 and res[0]["shard"][1] == res[1]["shard"][0] and res[1]["shard"][1] == res[2]["shard"][0]
+
+
 def test_world2_gloo_weighted_build(O, H):
     """A nearness-weighted build over two gloo ranks: the per-round hand-over of the accepted coefficient arrays
     (distributed.py, hpsdf_build_rows_*) keeps every rank able to run any node's next incremental fit -- the hook below
