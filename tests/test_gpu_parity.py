@@ -88,6 +88,38 @@ def test_create_is_deterministic_and_stepwise_equals_oneshot(H, ctx):
     assert b.assemble([b.pack_host(ctx, counts[0])]) == one
 
 
+def test_job_results_match_the_oracle_job_by_job(H, O, ctx):
+    """A job's nine errors -- the incremental fit's (EstimatePImprovement, Octree.cpp:829-856) and the eight child fits'
+    (EstimateHImprovement, :804-826) -- as the GPU leaves them for the decision, against ora_job on the same cell, degree and
+    error: every round of union3 at 1e-7 (K = 256), 48 jobs spread over the round, bit for bit.  Unlike a block comparison this
+    also sees the errors of the alternative a job did NOT take."""
+    cfg, ocfg, f, of = H.make_config(1e-7), O.default_config(1e-7), H.Field.union3(), oracle_field(O, "union3")
+    b = H.Build(cfg, 256, 0, 1)
+    rounds = checked = 0
+    degrees = set()
+    while True:
+        n = b.select()
+        if n == 0:
+            break
+        jobs = b.jobs(n)
+        b.compute(ctx, f)
+        hdr = b.results_host(ctx).reshape(n, 9)
+        for j in np.unique(np.linspace(0, n - 1, 48 if rounds else 24).astype(int)):
+            jb = jobs[j]
+            prev = None if jb.coarse else np.zeros(O.NCOEF[jb.degree])  # (an unweighted incremental fit forms the new rows only)
+            res, _, _ = O.job(of, ocfg, tuple(jb.aabb_min), tuple(jb.aabb_max), jb.depth, jb.degree, jb.err, prev)
+            want = np.array([res.p_err] + list(res.h_err))
+            live = np.ones(9, bool)
+            if jb.coarse:
+                live[1:] = False  # a coarse job has no child fits (:836-843)
+            assert np.array_equal(bits(hdr[j][live]), bits(want[live])), (rounds, j, jb.degree, jb.depth)
+            checked += 1
+            degrees.add(int(jb.degree))
+        b.apply(hdr)
+        rounds += 1
+    assert rounds >= 10 and checked > 400 and max(degrees) >= 3
+
+
 def test_distributed_driver_world1(H, ctx, golden):
     import importlib
     D = importlib.import_module("hpsdf_amd.distributed")
