@@ -1236,21 +1236,39 @@ static int createShardedOnHostScheduler(hpsdf_ctx* ctx, const hpsdf_config* cfg,
         }
     } stage;
     std::vector<double> all;
-    // every rank's `mine` (count doubles, padded to `pad`) -> all[world][pad]
-    auto exchange = [&](const double* mine, uint64_t count, uint64_t pad, const char* what) -> int {
-        const uint64_t total = (uint64_t)world * pad;
+    uint64_t stride = 0;  // doubles per rank in `all` after an exchange
+    // every rank's `mine` (count doubles, padded to `pad`) -> all[world][stride], stride = pad + 1: the last double of a rank's
+    // part is its STATUS (0: fine).  A rank whose share of the round failed (localRc: device memory, a launch) still enters the
+    // exchange, with its status set, and returns its own error afterwards; the others find the status, and return
+    // HPSDF_ERR_STATE instead of waiting in the next collective for a rank that has left.
+    const char* injected = std::getenv("HPSDF_TEST_FAIL_RANK");  // tests: "<rank>:<exchange number>"
+    int exchanges = 0;
+    auto exchange = [&](const double* mine, uint64_t count, uint64_t pad, const char* what, int localRc) -> int {
+        if (injected && !localRc && std::atoi(injected) == rank && std::strchr(injected, ':') && std::atoi(std::strchr(injected, ':') + 1) == exchanges)
+            localRc = fail(HPSDF_ERR_OUT_OF_MEMORY, "injected failure (HPSDF_TEST_FAIL_RANK)");
+        ++exchanges;
+        const std::string ownError = localRc ? std::string(hpsdf_last_error()) : std::string();
+        stride = pad + 1;
+        const uint64_t total = (uint64_t)world * stride;
         if (stage.cap < total) {
             if (stage.d) (void)hipFree(stage.d);
             stage.d = nullptr, stage.cap = 0;
             HPSDF_HIP(hipMalloc((void**)&stage.d, (total + total / 2) * sizeof(double)));
             stage.cap = total + total / 2;
         }
-        if (count) HPSDF_HIP(hipMemcpyAsync(stage.d + (uint64_t)rank * pad, mine, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        const int grc = gather(user, stage.d, pad * sizeof(double), (void*)ctx->stream);
+        const double status = (double)localRc;
+        if (count && !localRc) HPSDF_HIP(hipMemcpyAsync(stage.d + (uint64_t)rank * stride, mine, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HPSDF_HIP(hipMemcpyAsync(stage.d + (uint64_t)rank * stride + pad, &status, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        const int grc = gather(user, stage.d, stride * sizeof(double), (void*)ctx->stream);
+        if (localRc) return fail(localRc, ownError);
         if (grc) return fail(HPSDF_ERR_STATE, std::string("the all-gather callback failed (") + what + "): " + std::to_string(grc));
         all.resize(total);
         HPSDF_HIP(hipMemcpyAsync(all.data(), stage.d, total * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HPSDF_HIP(hipStreamSynchronize(ctx->stream));
+        for (int r = 0; r < world; ++r)
+            if (all[(uint64_t)r * stride + pad] != 0.0)
+                return fail(HPSDF_ERR_STATE, "rank " + std::to_string(r) + " failed in this round (status " + std::to_string((int)all[(uint64_t)r * stride + pad]) +
+                                                 ", " + what + "): its own error was returned there");
         return HPSDF_OK;
     };
     std::vector<double> mine, headers;
@@ -1260,18 +1278,19 @@ static int createShardedOnHostScheduler(hpsdf_ctx* ctx, const hpsdf_config* cfg,
         uint64_t n = 0;
         if ((rc = builderSelect(b, &n))) return rc;
         if (n == 0) break;
-        if ((rc = builderCompute(b, ctx, field))) return rc;
+        // (this rank's share of the round: what can fail here fails on this rank alone -- the exchange carries the news)
+        rc = builderCompute(b, ctx, field);
         const uint64_t myCount = b->slices[rank].count * HPSDF_JOB_HEADER_DOUBLES;
         uint64_t maxSlice = 0;
         for (const auto& sl : b->slices) maxSlice = std::max(maxSlice, sl.count);
         mine.resize(std::max<uint64_t>(1, myCount));
-        if ((rc = hpsdf_build_round_results_host(b, ctx, mine.data()))) return rc;
+        if (!rc) rc = hpsdf_build_round_results_host(b, ctx, mine.data());
         const uint64_t pad = maxSlice * HPSDF_JOB_HEADER_DOUBLES;
-        if ((rc = exchange(mine.data(), myCount, pad, "a round's errors"))) return rc;
+        if ((rc = exchange(mine.data(), myCount, pad, "a round's errors", rc))) return rc;
         headers.resize(n * HPSDF_JOB_HEADER_DOUBLES);
         for (int r = 0; r < world; ++r)
             if (b->slices[r].count)
-                std::memcpy(headers.data() + b->slices[r].first * HPSDF_JOB_HEADER_DOUBLES, all.data() + (uint64_t)r * pad,
+                std::memcpy(headers.data() + b->slices[r].first * HPSDF_JOB_HEADER_DOUBLES, all.data() + (uint64_t)r * stride,
                             b->slices[r].count * HPSDF_JOB_HEADER_DOUBLES * sizeof(double));
         if ((rc = builderApply(b, headers.data()))) return rc;
         if (b->weighted) {  // the arrays this round accepted go to every rank (Octree.cpp:847 copies a node's previous rows)
@@ -1280,9 +1299,9 @@ static int createShardedOnHostScheduler(hpsdf_ctx* ctx, const hpsdf_config* cfg,
             for (uint64_t c : counts) rpad = std::max(rpad, c);
             if (rpad) {
                 mine.resize(std::max<uint64_t>(1, counts[rank]));
-                if ((rc = builderRowsPackHost(b, ctx, mine.data()))) return rc;
-                if ((rc = exchange(mine.data(), counts[rank], rpad, "a round's accepted rows"))) return rc;
-                for (int r = 0; r < world; ++r) parts[r] = all.data() + (uint64_t)r * rpad;
+                rc = builderRowsPackHost(b, ctx, mine.data());
+                if ((rc = exchange(mine.data(), counts[rank], rpad, "a round's accepted rows", rc))) return rc;
+                for (int r = 0; r < world; ++r) parts[r] = all.data() + (uint64_t)r * stride;
                 if ((rc = builderRowsUnpackHost(b, ctx, parts.data()))) return rc;
             }
         }
@@ -1291,9 +1310,9 @@ static int createShardedOnHostScheduler(hpsdf_ctx* ctx, const hpsdf_config* cfg,
     uint64_t ppad = 1;
     for (uint64_t c : b->packCounts) ppad = std::max(ppad, c);
     mine.resize(std::max<uint64_t>(1, b->packCounts[rank]));
-    if ((rc = builderPackHost(b, ctx, mine.data()))) return rc;
-    if ((rc = exchange(mine.data(), b->packCounts[rank], ppad, "the packed coefficients"))) return rc;
-    for (int r = 0; r < world; ++r) parts[r] = all.data() + (uint64_t)r * ppad;
+    rc = builderPackHost(b, ctx, mine.data());
+    if ((rc = exchange(mine.data(), b->packCounts[rank], ppad, "the packed coefficients", rc))) return rc;
+    for (int r = 0; r < world; ++r) parts[r] = all.data() + (uint64_t)r * stride;
     if ((rc = builderAssemble(b, parts.data(), block, size))) return rc;
     if (stats) hpsdf_build_get_stats(b, stats);
     return HPSDF_OK;

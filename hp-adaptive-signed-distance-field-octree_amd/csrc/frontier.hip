@@ -60,6 +60,11 @@ constexpr uint64_t kNotQueued = ~0ull;
 constexpr uint64_t kOffMask = (1ull << 56) - 1;  // a segment's arena offset; the bits above hold the rank that owns it
 constexpr uint32_t kFrSort = 4096;  // bitonic sort capacity (LDS): the fallback ordering of a batch
 constexpr uint32_t kFrExact = 64;   // candidates left when the digit-by-digit refinement hands over to exact ranking
+// Multi-rank builds: the last double of a rank's part of errs is its STATUS for the round's exchange.  A healthy rank zeroes it
+// (fr_init_kernel / fr_tasks_kernel); a rank whose share of the round failed on the host (device memory) sets it to all ones and
+// enters the exchange all the same; fr_round0_kernel / fr_decide_kernel find it and every rank leaves with an error instead of
+// waiting in a later collective for a rank that has gone.
+constexpr uint32_t kFrStatusPad = 8;
 
 struct FrHdr {
     uint32_t nNodes, nQueued, nJobs, done;
@@ -191,6 +196,13 @@ __device__ __forceinline__ size_t frErrSlot(const FrDev& d, const FrHdr* h, uint
     if (d.world == 1) return (size_t)j * 9;
     const uint32_t o = d.jobOwner[j];
     return (size_t)o * d.errStride + (size_t)(j - h->sliceFirst[o]) * 9;
+}
+__device__ __forceinline__ double* frStatusSlot(const FrDev& d, int r) { return d.errs + (size_t)r * d.errStride + (d.errStride - 1u); }
+// the lowest rank whose status slot says "failed" (+ 1), 0 if none; threads 0 .. world - 1 look, the result is valid after the caller's barrier
+__device__ __forceinline__ void frPeerCheck(const FrDev& d, uint32_t* sPeer) {
+    if (d.world > 1 && threadIdx.x < (uint32_t)d.world &&
+        (unsigned long long)__double_as_longlong(*(volatile double*)frStatusSlot(d, (int)threadIdx.x)) == ~0ull)
+        atomicMax(sPeer, threadIdx.x + 1u);
 }
 // flop-proportional cost of one job (builder.cpp jobCost): balances the ranks' slices
 __device__ __forceinline__ uint64_t frJobCost(int degree, int depth, bool coarse) {
@@ -630,6 +642,7 @@ __global__ __launch_bounds__(256) void fr_tasks_kernel(FrDev d) {
     FrRound* R = d.rnd;
     const uint32_t nJobs = h->nJobs, nBlocks = h->nBlocks;
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
+    if (gid == 0 && d.world > 1) *frStatusSlot(d, d.rank) = 0.0;
     const uint64_t arenaBase = R->arenaBase;
     const int lane = threadIdx.x & 63;
     for (uint32_t base = (gid >> 4) - ((uint32_t)lane >> 4); base < nJobs; base += stride >> 4) {  // 4 jobs per wave, wave-uniform trip count
@@ -714,12 +727,14 @@ __global__ __launch_bounds__(1024) void fr_decide_kernel(FrDev d) {
     __shared__ uint32_t sScan[16];
     __shared__ uint32_t sCnt[4];  // P, -, dropped, max degree
     __shared__ int sDelta;
+    __shared__ uint32_t sPeer;
     const uint32_t tid = threadIdx.x, nJobs = h->nJobs, nNodes0 = h->nNodes;
     const bool round0 = h->round == 0;
     FR_STAMP(8);
     if (tid < 4) sCnt[tid] = 0;
-    if (tid == 0) sDelta = 0;
+    if (tid == 0) sDelta = 0, sPeer = 0;
     __syncthreads();
+    frPeerCheck(d, &sPeer);
     // thread t owns jobs 4 t .. 4 t + 3 from the decision to the operand list: their errors stay in registers
     uint32_t nP = 0, nD = 0, maxDeg = 0;
     int delta = 0;
@@ -829,6 +844,7 @@ __global__ __launch_bounds__(1024) void fr_decide_kernel(FrDev d) {
         const uint32_t nH = all >> 16;
         h->rP = sCnt[0], h->rH = nH, h->rD = sCnt[2], h->rMaxDeg = sCnt[3];
         h->rOps = (all & 0xFFFFu) + 9u * nH;
+        h->rPad = sPeer;  // (barriers lie between the check and here) a rank that failed this round, + 1
         h->dbg[11] = __builtin_readcyclecounter();
         h->rCoeffDelta = (int64_t)sDelta;
         h->arrive = 0;
@@ -1020,8 +1036,12 @@ __global__ __launch_bounds__(256) void fr_round0_kernel(FrDev d) {
     const uint32_t tid = threadIdx.x, nJobs = h->nJobs;
     if (blockIdx.x == 0) {
         double total = h->total;
+        if (tid == 0) sTmp[0] = 0;
+        __syncthreads();
+        frPeerCheck(d, &sTmp[0]);
         for (uint32_t k = tid; k < 2048 && k < nJobs; k += 256) sOps[0][k] = d.errs[frErrSlot(d, h, k)] - d.batchErr[k];
         __syncthreads();
+        const uint32_t peer = sTmp[0];
         for (uint32_t c0 = 0, half = 0; c0 < nJobs; c0 += 2048, half ^= 1u) {
             const uint32_t n = nJobs - c0 < 2048u ? nJobs - c0 : 2048u;
             if (tid >= 64) {
@@ -1044,6 +1064,7 @@ __global__ __launch_bounds__(256) void fr_round0_kernel(FrDev d) {
         }
         if (tid == 0) {
             h->rTotal = total;
+            h->rPad = peer;
             h->rP = nJobs, h->rH = 0, h->rD = 0, h->rMaxDeg = 2, h->rCoeffDelta = 0;
         }
     } else {
@@ -1232,6 +1253,7 @@ __global__ __launch_bounds__(256) void fr_init_kernel(FrDev d, FrTemplate t, dou
         d.segFirst[i] = 2;
     }
     if (blockIdx.x != 0) return;
+    if (threadIdx.x == 0 && d.world > 1) *frStatusSlot(d, d.rank) = 0.0;
     uint32_t* hw = reinterpret_cast<uint32_t*>(d.hdr);
     for (uint32_t w = threadIdx.x; w < sizeof(FrHdr) / 4; w += 256u) hw[w] = 0;
     __syncthreads();
@@ -1388,7 +1410,7 @@ struct FrontierWorkspace {
     hipError_t ensureRanks(int world, hipStream_t s) {
         hipError_t e = hipSuccess;
         if (world > ranksCap) {
-            e = grow(&d.errs, 0, (size_t)world * kFrJobs * HPSDF_JOB_HEADER_DOUBLES, s, false);
+            e = grow(&d.errs, 0, (size_t)world * (kFrJobs * HPSDF_JOB_HEADER_DOUBLES + kFrStatusPad), s, false);
             if (e == hipSuccess) ranksCap = world;
         }
         if (e == hipSuccess && world > 1 && !d.jobOwner) {
@@ -1612,7 +1634,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
     ws->d.rank = rank, ws->d.world = world;
     ws->d.weighted = weighted ? 1 : 0;
     ws->d.fastFit = (ctx->fastFit && field->kind != kHostTreeCsg && !weighted) ? 1 : 0;
-    ws->d.errStride = kFrJobs * HPSDF_JOB_HEADER_DOUBLES;
+    ws->d.errStride = kFrJobs * HPSDF_JOB_HEADER_DOUBLES + kFrStatusPad;
     {
         const hipError_t e = ws->ensureRanks(world, s);
         if (e != hipSuccess) return hipFail(e, "frontier buffers");
@@ -1625,9 +1647,20 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         return HPSDF_OK;
     };
 
+    // Several ranks: which exchange the other ranks enter next (0: none pending, 1: round 0's errors, 2: a later round's).  If this
+    // rank's share fails while one is pending, it still enters that exchange -- with its status slot set (kFrStatusPad) -- before
+    // it returns its error: the others then leave with HPSDF_ERR_STATE instead of waiting for a rank that has gone.
+    int phase = 0;
+    const char* injected = std::getenv("HPSDF_TEST_FAIL_RANK");  // tests: "<rank>:<round>"
+    auto injectedFailure = [&](int round) {
+        return injected && world > 1 && std::atoi(injected) == rank && std::strchr(injected, ':') && std::atoi(std::strchr(injected, ':') + 1) == round;
+    };
+    auto body = [&]() -> int {
     FieldDev fd;
     int rc;
+    if (world > 1) phase = 1;
     if ((rc = makeFieldDev(field, nullptr, &fd))) return rc;
+    if (injectedFailure(0)) return fail(HPSDF_ERR_OUT_OF_MEMORY, "injected failure (HPSDF_TEST_FAIL_RANK)");
     RootMap rm;
     for (int a = 0; a < 3; ++a) {
         rm.bounds[a] = (double)(cfg.root_max[a] - cfg.root_min[a]);          // Octree.cpp:324
@@ -1786,6 +1819,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         HPSDF_HIP(launchFit(s, 2, 1, r0Blocks, T0.nBlocks, r0Lds, r0Tasks, ws->arena, d.errs, nullptr, ctx->dTables, fdr, rm));
         if (weighted && (rc = applyWeights(r0Blocks, T0.nBlocks, r0Lds, r0Tasks, nullptr, true))) return rc;
         if ((rc = exchange(d.errs, (size_t)d.errStride * sizeof(double), "round 0"))) return rc;
+        phase = 0;
         FrDev d0 = d;
         d0.batchIdx = ws->tmplLeaves, d0.batchErr = ws->tmplErr, d0.jobP = r0JobP, d0.jobH = r0JobP;
         hipLaunchKernelGGL(fr_round0_kernel, dim3(1 + (T.nLeaves + 255) / 256), dim3(256), 0, s, d0);
@@ -1807,7 +1841,8 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         tSync += now() - ts;
     }
     int rounds = 1;
-    d.errStride = Kj * HPSDF_JOB_HEADER_DOUBLES;  // later rounds have at most K jobs: smaller parts to all-gather
+    if (world > 1 && hh->rPad) return fail(HPSDF_ERR_STATE, "rank " + std::to_string(hh->rPad - 1) + " failed in round 0: its own error was returned there");
+    d.errStride = Kj * HPSDF_JOB_HEADER_DOUBLES + kFrStatusPad;  // later rounds have at most K jobs: smaller parts to all-gather
     const bool stoppedAfterRound0 = world == 1 && hh->done && hh->overflow != 1;
     if (stoppedAfterRound0 && early && hh->nCoeffs == T.arenaRows && hh->nNodes == T.nNodes) {
         std::memcpy(early + 8, ws->pinned, 8 * (size_t)T.arenaRows);
@@ -1831,6 +1866,8 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         // (as builderSelect: a total that is NaN or infinite never falls below the threshold -- the field is not finite somewhere)
         if (!(std::fabs(hh->total) <= DBL_MAX))
             return fail(HPSDF_ERR_INVALID_ARGUMENT, "the field is not a finite number at some sample point (the build's total error is NaN or infinite)");
+        if (world > 1) phase = 2;
+        if (injectedFailure(rounds)) return fail(HPSDF_ERR_OUT_OF_MEMORY, "injected failure (HPSDF_TEST_FAIL_RANK)");
         // capacities for this round (the device flags what the host failed to foresee; it cannot happen by these bounds)
         hipError_t e = ws->ensureNodes(knownNodes + 8u * Kj, s);
         if (e == hipSuccess) e = ws->ensureArena(knownArena + (uint64_t)Kj * rowsPerJob((int)knownMaxDeg), knownArena, s);
@@ -1891,6 +1928,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
             if ((rc = applyWeights(d.blocks, taskBound, lds, d.tasks, &d.hdr->nBlocks, false))) return rc;
         }
         if ((rc = exchange(d.errs, (size_t)d.errStride * sizeof(double), "a round's errors"))) return rc;
+        phase = 0;
         hipLaunchKernelGGL(fr_decide_kernel, dim3(1), dim3(1024), 0, s, d);
         hipLaunchKernelGGL(fr_update_kernel, dim3(1 + (Kj + 31) / 32), dim3(256), 0, s, d);
         if (world == 1) hipLaunchKernelGGL(fr_store_kernel, dim3(std::min<uint32_t>(2048u, (knownNodes + 8u * Kj + 3u) / 4u)), dim3(256), 0, s, d);
@@ -1919,6 +1957,8 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         }
         tSync += now() - ts;
         ++rounds;
+        if (world > 1 && hh->rPad)
+            return fail(HPSDF_ERR_STATE, "rank " + std::to_string(hh->rPad - 1) + " failed in round " + std::to_string(rounds - 1) + ": its own error was returned there");
         knownNodes = hh->nNodes, knownMaxDeg = hh->maxDegree, knownArena = hh->arenaUsed;
         if (trace) {
             std::fprintf(stderr, "[frontier round %d] batch phases (cycles):", rounds - 1);
@@ -1995,6 +2035,18 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         std::fprintf(stderr, "[frontierCreate] us: total %.0f (waiting for the device %.0f over %d rounds, weights on the host %.0f, block download %.0f)\n",
                      now() - t0, tSync, rounds, tWeights, tcopy);
     return HPSDF_OK;
+    };
+    const int rcBody = body();
+    if (rcBody && world > 1 && phase != 0) {
+        const std::string own = hpsdf_last_error();
+        const size_t stride = ws->d.errStride;
+        const unsigned long long ones = ~0ull;
+        if (hipMemcpyAsync(ws->d.errs + (size_t)rank * stride + (stride - 1), &ones, sizeof ones, hipMemcpyHostToDevice, s) == hipSuccess)
+            (void)gather(gatherUser, ws->d.errs, stride * sizeof(double), (void*)s);
+        (void)hipStreamSynchronize(s);
+        return fail(rcBody, own);
+    }
+    return rcBody;
 }
 
 }  // namespace hpsdf

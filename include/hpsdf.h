@@ -361,10 +361,13 @@ HPSDF_API int hpsdf_create(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_
  * The stepwise hpsdf_build_* calls expose the same loop to callers with a transport of their own.
  * Fields the device evaluates itself run the device-side frontier on up to 8 ranks when the config has no nearness weighting;
  * weighted configs on several ranks and worlds beyond 8 run the host scheduler's sharded rounds (same bytes).
- * FAILURES: a rank whose part of the build fails (out of memory, a launch error) returns its error at once and does NOT
- * enter the exchanges that would have followed; the other ranks then wait in their next all-gather.  A caller that gets a
- * non-zero status from any rank must abort the communicator (ncclCommAbort / torch.distributed's abort) -- as for any
- * collective program whose ranks can fail independently. */
+ * FAILURES: a rank whose share of a round fails on its own (device memory one GPU cannot serve) still enters the exchange the
+ * other ranks are heading for, with a status word set in its part of the exchanged buffer, and then returns its error; every
+ * other rank finds the status after the exchange and returns HPSDF_ERR_STATE naming the rank -- nobody is left waiting in a
+ * collective (tests: test_a_failing_rank_takes_the_others_out_with_it).  What this cannot cover: a failure of the exchange
+ * callback itself, a sticky device error (after which no further call succeeds), and the last exchange of the device-side
+ * frontier (the packed coefficients, whose only local failure is the allocation of the packed store): there the caller must
+ * abort the communicator when a rank reports an error, as for any collective program. */
 typedef int (*hpsdf_allgather_fn)(void* user, void* d_buf, size_t bytes_per_rank, void* stream);
 HPSDF_API int hpsdf_create_distributed(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* field,
                                        uint64_t max_jobs_per_round, int rank, int world, hpsdf_allgather_fn gather,

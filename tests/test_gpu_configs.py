@@ -192,6 +192,68 @@ def test_field_that_is_not_finite_fails_the_build(H, ctx):
     assert st["n_nodes"] == 4681
 
 
+def _ranks_collect(H, world, cfg, make_field, K):
+    """As _create_on_simulated_ranks, but every rank's outcome (block or exception) is returned and a rank left waiting in an
+    exchange shows as a broken barrier after a minute instead of hanging the test."""
+    import threading
+    import torch
+    ctxs = [H.Context(0) for _ in range(world)]
+    fields = [make_field(c) for c in ctxs]
+    barrier = threading.Barrier(world, timeout=60)
+    bufs, out = [None] * world, [None] * world
+
+    def gather_for(rank):
+        def gather(d_buf, nbytes, stream):
+            ctxs[rank].synchronize()
+            bufs[rank] = d_buf
+            barrier.wait()
+            mine = torch.as_tensor(_DevBytes(d_buf, nbytes * world), device="cuda")
+            for r in range(world):
+                if r != rank:
+                    other = torch.as_tensor(_DevBytes(bufs[r], nbytes * world), device="cuda")
+                    mine[r * nbytes:(r + 1) * nbytes].copy_(other[r * nbytes:(r + 1) * nbytes])
+            torch.cuda.synchronize()
+            barrier.wait()
+        return gather
+
+    def worker(rank):
+        try:
+            out[rank] = H.create_block_distributed(ctxs[rank], cfg, fields[rank], K, rank, world, gather_for(rank))
+        except BaseException as e:  # noqa: BLE001
+            out[rank] = e
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    return out
+
+
+@pytest.mark.parametrize("weighted,fail_at", [(False, 0), (False, 3), (True, 0), (True, 2)])
+def test_a_failing_rank_takes_the_others_out_with_it(H, ctx, monkeypatch, weighted, fail_at):
+    """One rank's share of a round fails on its own (HPSDF_TEST_FAIL_RANK stands in for a device allocation that one GPU cannot
+    serve): it still enters the exchange the others are heading for, with its status set; it returns its own error, every other
+    rank HPSDF_ERR_STATE naming it -- nobody is left waiting in a collective.  Device-side frontier (unweighted) and the host
+    scheduler's sharded rounds (weighted) alike; the contexts build normally afterwards."""
+    world, bad = 4, 2
+    cfg = H.make_config(1e-7)
+    if weighted:
+        cfg.nearnessWeighting_type, cfg.nearnessWeighting_strength = 2, 3.0
+    monkeypatch.setenv("HPSDF_TEST_FAIL_RANK", "%d:%d" % (bad, fail_at))
+    out = _ranks_collect(H, world, cfg, lambda c: H.Field.union3(), 256)
+    monkeypatch.delenv("HPSDF_TEST_FAIL_RANK")
+    for r in range(world):
+        assert isinstance(out[r], H.HpsdfError), (r, out[r])
+        if r == bad:
+            assert out[r].status == H.ERR_OUT_OF_MEMORY and "injected failure" in str(out[r])
+        else:
+            assert out[r].status == H.ERR_STATE and ("rank %d failed" % bad) in str(out[r])
+    good = _create_on_simulated_ranks(H, world, cfg, lambda c: H.Field.union3(), 256)
+    one, _ = H.create_block(ctx, cfg, H.Field.union3(), 256)
+    assert all(blk == one for blk, _ in good)
+
+
 def _hard_meshes():
     yield "icosphere L5", icosphere(5, 0.4)
     yield "displaced torus", displaced_torus(160, 96)
