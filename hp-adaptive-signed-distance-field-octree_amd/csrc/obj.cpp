@@ -33,6 +33,8 @@ int loadObj(const char* path, std::vector<float>& verts, std::vector<uint64_t>& 
         const size_t got = data.empty() ? 0 : std::fread(data.data(), 1, data.size(), fh);
         std::fclose(fh);
         data.resize(got);
+        for (char& c : data)
+            if (c == '\0') c = ' ';  // (a NUL inside the file would end the text for strchr below, in front of the line's newline)
         data.push_back('\n');
         data.push_back('\0');
     }

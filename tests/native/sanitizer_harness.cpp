@@ -198,6 +198,36 @@ int main(int argc, char** argv) {
         FILE* g = fopen(argv[3], "wb"); fputs(bad, g); fclose(g);
         if (hpsdf::loadObj(argv[3], v, t, err) == 0) { printf("malformed OBJ accepted\n"); return 8; }
     }
+    {
+        // a file with a NUL in the middle of a line, and 3000 random corruptions of a small valid file (a byte changed, a run
+        // deleted, a token from a list of awkward ones inserted): any status will do, the reader must only stay inside its buffers
+        const char nul[] = "v 0 0 0\nv 1 0\0 0\nv 0 1 0\nf 1 2 3\n";
+        FILE* g = fopen(argv[3], "wb"); fwrite(nul, 1, sizeof nul - 1, g); fclose(g);
+        (void)hpsdf::loadObj(argv[3], v, t, err);
+        const std::string good = "# tetrahedron\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\nvn 0 0 1\nvt 0.5 0.5\nf 1 3 2\nf 1//1 2//1 4//1\nf 2/1/1 3/1/1 4/1/1\nf -4 -1 -2\n";
+        const char* tokens[] = {"-1", "0", "99999999999999999999", "-99999999999999999999", "1e999", "nan", "inf", "//", "/", "f", "v", "\r", "\t", "1/2/3/4",
+                                "+", "-", ".", "e", "0x10", "f 1 2", "v 1", "\n\n", " "};
+        unsigned long long x = 88172645463325252ull;
+        auto rnd = [&]() { x ^= x << 13, x ^= x >> 7, x ^= x << 17; return x; };
+        int accepted = 0;
+        for (int it = 0; it < 3000; ++it) {
+            std::string m = good;
+            for (int k = 0, nk = 1 + (int)(rnd() % 3); k < nk && !m.empty(); ++k) {
+                const size_t at = rnd() % m.size();
+                switch (rnd() % 3) {
+                    case 0: m[at] = (char)(rnd() % 256); break;
+                    case 1: m.erase(at, 1 + rnd() % 8); break;
+                    default: m.insert(at, tokens[rnd() % (sizeof tokens / sizeof *tokens)]); break;
+                }
+            }
+            g = fopen(argv[3], "wb"); fwrite(m.data(), 1, m.size(), g); fclose(g);
+            if (hpsdf::loadObj(argv[3], v, t, err) == 0) {
+                ++accepted;
+                for (uint64_t i : t) if (i >= v.size() / 3) { printf("accepted OBJ with an index beyond its vertices\n"); return 9; }
+            }
+        }
+        printf("obj fuzz: 3000 corrupted files, %d still parse\n", accepted);
+    }
     if (int rc = schedulerRun()) { printf("scheduler rc %d\n", rc); return rc; }
     printf("OK\n");
     return 0;
