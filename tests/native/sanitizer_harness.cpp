@@ -6,6 +6,7 @@
 #include <string>
 #include <functional>
 #include <vector>
+#include "block_check.hpp"
 #include "builder.hpp"
 #include "continuity.hpp"
 #include "launch.hpp"
@@ -173,6 +174,36 @@ int main(int argc, char** argv) {
         bad += mutate("leaf depth lies", [](std::vector<char>&, uint64_t, uint64_t nn, hpsdf_node* n) {
             for (uint64_t i = 0; i < nn; ++i) if (n[i].child_idx == ~0ull) { n[i].depth = 1; break; } });
         if (bad) return 40;
+        {
+            // random corruption of the node array (1 to 4 bytes anywhere in it, or a field set to an awkward value): the validator
+            // both deserialisers share must say yes or no without leaving the array -- 6 000 blocks, both strictness levels, under the sanitizers
+            uint64_t nc, nn;
+            memcpy(&nc, blk.data(), 8);
+            memcpy(&nn, blk.data() + 8 + 8 * nc, 8);
+            std::vector<hpsdf_node> nodes(nn), work;
+            memcpy(nodes.data(), blk.data() + 16 + 8 * nc, nn * sizeof(hpsdf_node));
+            unsigned long long x = 0x9E3779B97F4A7C15ull;
+            auto rnd = [&]() { x ^= x << 13, x ^= x >> 7, x ^= x << 17; return x; };
+            const uint64_t awkward[] = {0ull, 1ull, 8ull, nn - 1, nn, nn + 1, ~0ull, ~0ull - 7, 1ull << 32, 1ull << 63, nc, nc - 1, nc + 1};
+            int stillValid = 0;
+            for (int it = 0; it < 6000; ++it) {
+                work = nodes;
+                for (int k = 0, nk = 1 + (int)(rnd() % 4); k < nk; ++k) {
+                    hpsdf_node& n = work[rnd() % nn];
+                    switch (rnd() % 5) {
+                        case 0: n.child_idx = awkward[rnd() % (sizeof awkward / sizeof *awkward)]; break;
+                        case 1: n.coeffs_start = awkward[rnd() % (sizeof awkward / sizeof *awkward)]; break;
+                        case 2: n.degree = (uint8_t)(rnd() % 256); break;
+                        case 3: n.depth = (uint8_t)(rnd() % 256); break;
+                        default: ((unsigned char*)&n)[rnd() % sizeof n] = (unsigned char)(rnd() % 256); break;
+                    }
+                }
+                hpsdf::BlockTreeInfo info;
+                for (int strict = 0; strict < 2; ++strict)
+                    if (hpsdf::checkBlockTree(work.data(), nn, nc, hpsdf::tables().coeffCount, strict != 0, true, &info, err) == 0) ++stillValid;
+            }
+            printf("block fuzz: 6000 corrupted node arrays, %d verdicts 'valid'\n", stillValid);
+        }
         // one interior root and nothing else: nNodes < 9
         std::vector<char> tiny(16 + sizeof(hpsdf_node) + sizeof(hpsdf_config), 0);
         const uint64_t one = 1;
