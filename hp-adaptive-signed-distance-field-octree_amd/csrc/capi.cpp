@@ -193,7 +193,7 @@ int hostCall(hpsdf_ctx* ctx, HostArray* arrays, int nArrays, Run&& run) {
 extern "C" {
 
 const char* hpsdf_last_error(void) { return g_lastError.c_str(); }
-const char* hpsdf_version(void) { return "hpsdf-gfx950 0.1"; }
+const char* hpsdf_version(void) { return "hpsdf-gfx950 0.3"; }  // (minor = the round the ABI last grew in)
 
 int hpsdf_config_default(hpsdf_config* c) {
     if (!c) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null config");
