@@ -8,12 +8,12 @@
  * load this library; the product (libhpsdf.so) never links or calls it.
  *
  * Pinning status (see oracle/README.md and DESIGN.md "Oracle"):
- *   - constant tables: PINNED bit-for-bit against the reference's own headers
- *     (Include/HP/Utility.h, Include/HP/Legendre.h compiled from where they lie
- *     into oracle/_ref/libref_tables.so; tests/test_oracle_tables.py).
- *   - fit / query numerics: pinned to the known-answer values of SURVEY.md
- *     Appendix C (10-13 significant digits) and to the reference's own
- *     end-to-end tests (Source/Tests/HPUnitTests.cpp:46-77,115-154,285-316:
+ *   - constant tables and scalars (limits, typedef widths, EPSILON_F32): PINNED bit-for-bit against the reference's own
+ *     headers (Include/HP/Utility.h, Legendre.h, Consts.h, Include/Utility/Literals.h, MemoryBlock.h compiled from where they
+ *     lie into oracle/_ref/libref_tables.so; tests/test_oracle_tables.py).
+ *   - fit / query numerics: checked against the known-answer values of SURVEY.md
+ *     Appendix C (10-13 significant digits; the survey produced them with a stand-in for Eigen, so they are a consistency
+ *     check, not a pin) and against the reference's own end-to-end tests (Source/Tests/HPUnitTests.cpp:46-77,115-154,285-316:
  *     |Query - true| <= 1e-2).  The reference holds no golden coefficient,
  *     topology or serialisation vectors, and Source/HP/Octree.cpp itself is
  *     UNBUILDABLE here (needs Eigen, which is neither vendored nor installed),
