@@ -117,6 +117,68 @@ def test_dropin_reproduces_oracle_block(H, golden, tmp_path):
     assert hashlib.sha256(bytes(blk)).hexdigest() == g["block_sha256"]
 
 
+THREADS_SRC = r'''
+// Octree::Query is const and the reference calls it from many threads (Octree.h:71-78).  Here the first query after a Create
+// also builds the tree's device mirror (hpsdf_octree.hpp, deviceTree()): eight threads start querying the fresh tree at once.
+#include "HP/Octree.h"
+#include <atomic>
+#include <cstdio>
+#include <thread>
+#include <vector>
+int main() {
+    try {
+        SDF::Config cfg;
+        cfg.targetErrorThreshold = 1e-6;
+        for (int rep = 0; rep < 5; ++rep) {
+            SDF::Octree tree;
+            tree.Create(cfg, SDF::DeviceField::Sphere(0.25, 0, 0, 0.5));
+            const int nThreads = 8, per = 300;
+            std::vector<double> got(nThreads * per), xyz(3 * nThreads * per);
+            for (size_t i = 0; i < xyz.size(); ++i) xyz[i] = -0.5 + (double)((i * 2654435761u) % 1000003u) / 1000003.0;
+            std::atomic<int> go{0}, failed{0};
+            std::vector<std::thread> ts;
+            for (int t = 0; t < nThreads; ++t)
+                ts.emplace_back([&, t] {
+                    while (!go.load()) {}
+                    try {
+                        for (int k = 0; k < per; ++k) {
+                            const size_t i = (size_t)t * per + k;
+                            got[i] = k % 3 ? tree.Query(Eigen::Vector3d(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]))
+                                           : [&] { double o; tree.Query(&xyz[3 * i], 1, &o); return o; }();
+                        }
+                    } catch (...) { failed.fetch_add(1); }
+                });
+            go.store(1);
+            for (auto& th : ts) th.join();
+            std::vector<double> want(got.size());
+            tree.Query(xyz.data(), got.size(), want.data());
+            for (size_t i = 0; i < got.size(); ++i)
+                if (got[i] != want[i]) { std::printf("rep %d point %zu: %.17g vs %.17g\n", rep, i, got[i], want[i]); return 1; }
+            if (failed.load()) { std::printf("rep %d: %d threads threw\n", rep, failed.load()); return 1; }
+        }
+        std::printf("threads ok\n");
+        return 0;
+    } catch (const SDF::Error& e) {
+        std::printf("SDF::Error %d: %s\n", e.status, e.what());
+        return e.status == HPSDF_ERR_NO_DEVICE ? 42 : 2;
+    }
+}
+'''
+
+
+@pytest.mark.gpu
+def test_dropin_query_from_many_threads_on_a_fresh_tree(H, tmp_path):
+    src, exe = str(tmp_path / "threads.cpp"), str(tmp_path / "threads")
+    open(src, "w").write(THREADS_SRC)
+    libdir = os.path.dirname(H.LIB_PATH)
+    cmd = ["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), src, "-o", exe, "-L", libdir, "-lhpsdf", "-Wl,-rpath," + libdir,
+           "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-pthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "threads ok" in r.stdout, r.stdout + r.stderr
+
+
 MESH_SRC = r'''
 #include "Meshing/Mesh.h"     // the reference's include paths (Include/Meshing/*.h, Include/HP/Octree.h)
 #include "Meshing/BVH.h"
