@@ -18,6 +18,7 @@
 #pragma once
 
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "hpsdf_octree.hpp"
@@ -189,14 +190,21 @@ inline void Mesh::SignedDistanceAtPt(const float* xyz, usize n, float* out, cons
     for (usize i = 0; i < n; ++i) out[i] = (float)res[i];  // the field value is the f32 distance widened
 }
 inline void Mesh::SignedDistanceAtPt(const float* xyz, usize n, float* out) {
-    if (!scan_) {
-        auto b = std::make_shared<BVH>();
-        if (!b->Create(*this)) throw SDF::Error(HPSDF_ERR_STATE, hpsdf_last_error());
-        scan_ = b;
+    std::shared_ptr<BVH> scan;
+    {
+        // (the device copy is made by whoever comes first; the reference's method has no state and is called from several threads)
+        static std::mutex firstUse;
+        std::lock_guard<std::mutex> guard(firstUse);
+        if (!scan_) {
+            auto b = std::make_shared<BVH>();
+            if (!b->Create(*this)) throw SDF::Error(HPSDF_ERR_STATE, hpsdf_last_error());
+            scan_ = b;
+        }
+        scan = scan_;
     }
     std::vector<double> in(3 * n), res(n);
     for (usize i = 0; i < 3 * n; ++i) in[i] = (double)xyz[i];
-    SDF::check(hpsdf_field_eval_naive_host(scan_->Context(), scan_->Field(), in.data(), n, res.data()));
+    SDF::check(hpsdf_field_eval_naive_host(scan->Context(), scan->Field(), in.data(), n, res.data()));
     for (usize i = 0; i < n; ++i) out[i] = (float)res[i];
 }
 inline f32 Mesh::SignedDistanceAtPt(const Eigen::Vector3f& pt_) {
