@@ -69,9 +69,11 @@ for seed in range(first, first + cases):
     a, w = f.eval_lane(ctx, pts), f.eval_wave(ctx, pts)
     ok = np.array_equal(bits(a), bits(want)) and np.array_equal(bits(w), bits(want))
     note = ""
-    if not ok and np.array_equal(bits(a), bits(w)):
-        diff = np.nonzero(a != want)[0]
-        if len(diff) <= 8 and all(scan_artefact(verts, tris, pts[i], want[i], a[i]) for i in diff):
+    if not ok:
+        # a point where the scan's value lies below the float64 truth: each traversal may either have come across the needle whose
+        # closest point the f32 routine misplaced (and then agrees with the scan) or have pruned it by its box (and then holds the truth)
+        diff = np.nonzero((bits(a) != bits(want)) | (bits(w) != bits(want)))[0]
+        if len(diff) <= 8 and all(all(v[i] == want[i] or scan_artefact(verts, tris, pts[i], want[i], v[i]) for v in (a, w)) for i in diff):
             ok, note = True, " (%d point(s) where the f32 scan leaves a sliver triangle; hierarchy = float64 truth)" % len(diff)
             artefacts += len(diff)
     bad += 0 if ok else 1
