@@ -36,6 +36,44 @@ TARGET = 1e-5
 JOBS_PER_ROUND = 1024
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run --nproc-per-node N bench.py <same
+    arguments>` as a child process (one rank per GPU, rendezvous on 127.0.0.1), pass rank 0's JSON line through and return the
+    child's exit code.  The parent makes no GPU call before or after (device_count() does not initialise the runtime here)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("HPSDF_BENCH_SHARE_GPU") != "1":
+        print("bench.py: --gpus %d but %d GPU(s) visible (HPSDF_BENCH_SHARE_GPU=1 rehearses the N-rank path on one GPU over gloo)"
+              % (n, have), file=sys.stderr)
+        return 2
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's peer buffers need it on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in child.stdout:  # the ranks print nothing but rank 0's line; anything else is passed on to stderr
+        if out.startswith('{"metric"'):
+            line = out
+        else:
+            sys.stderr.write(out)
+    rc = child.wait()
+    if line is not None:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    elif rc == 0:
+        print("bench.py: the ranks exited without a result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,8 +95,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("--gpus %d needs the torch.distributed.run launcher (one process per GPU)" % args.gpus)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started bare (`python bench.py --gpus N`): this process becomes the launcher.  Nothing here has touched the GPU
+        # yet (torch is imported, no device call made), and the ranks are CHILD processes -- never an exec.
+        raise SystemExit(self_launch(args.gpus))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the launcher's rank count and --gpus must agree" % (args.gpus, world))
     # functional dry-run of the N > 1 path on a one-GPU box: every rank on device 0, exchange over gloo
     share_gpu = os.environ.get("HPSDF_BENCH_SHARE_GPU") == "1"
     if share_gpu:
@@ -70,6 +112,7 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    backend = dist.get_backend() if world > 1 else None
 
     import hpsdf_loader
     H = hpsdf_loader.load()
@@ -352,6 +395,9 @@ def main():
         "value": value, "unit": "Mpts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
+        # what the collective layer saw (N > 1): ranks, backend (nccl = RCCL over xGMI), all-gathers per sharded Create
+        "world": world, "backend": backend,
+        "exchanges_per_create": None if create_sharded is None else create_sharded["exchanges_per_create"],
         "config": {"workload": "BASELINE configs[1]: union(sphere,box,torus) analytic SDF, targetError=1e-5, "
                                "continuity off, %d random Query() points per GPU" % n,
                    "jobs_per_round": JOBS_PER_ROUND, "points_per_gpu": n, "sharding": "replicated tree, points split"},

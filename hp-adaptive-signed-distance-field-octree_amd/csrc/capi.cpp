@@ -464,6 +464,7 @@ int hpsdf_field_destroy(hpsdf_field* f) {
         (void)hipSetDevice(f->device);
         if (f->dBlock) {
             (void)hipFree(f->dBlock);
+            hpsdf::meshPoolTrim(f->device);
         } else {
             if (f->dVerts) (void)hipFree(f->dVerts);
             if (f->dTris) (void)hipFree(f->dTris);

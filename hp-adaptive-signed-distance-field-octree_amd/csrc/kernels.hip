@@ -2467,7 +2467,9 @@ hipError_t launchMeshEvalWave(hipStream_t stream, const FieldDev& f, const doubl
         if (!noSort && m >= kMeshEvalSortMin && sortPairsU32(stream, nullptr, tmpBytes, nullptr, nullptr, nullptr, nullptr, m, 30) == hipSuccess) {
             const size_t arr = (m * sizeof(uint32_t) + 255) & ~(size_t)255;
             // stream-ordered scratch: four index arrays and the sort's own; if the pool declines, the points go as they are
-            if (hipMallocAsync((void**)&block, 4 * arr + tmpBytes, stream) == hipSuccess) {
+            int dev = 0;
+            hipMemPool_t pool = hipGetDevice(&dev) == hipSuccess ? meshPool(dev) : nullptr;  // the library's own pool, not the default one
+            if (pool && hipMallocFromPoolAsync((void**)&block, 4 * arr + tmpBytes, pool, stream) == hipSuccess) {
                 uint32_t *keys = (uint32_t*)block, *keysOut = (uint32_t*)(block + arr), *ids = (uint32_t*)(block + 2 * arr), *idsOut = (uint32_t*)(block + 3 * arr);
                 hipLaunchKernelGGL(mesh_eval_keys_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, f.mesh, dXyz + 3 * first, (uint32_t)m, keys, ids);
                 if (sortPairsU32(stream, block + 4 * arr, tmpBytes, keys, keysOut, ids, idsOut, m, 30) == hipSuccess) {

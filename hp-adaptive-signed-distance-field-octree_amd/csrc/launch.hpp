@@ -54,6 +54,9 @@ hipError_t launchMeshEvalWave(hipStream_t stream, const FieldDev& f, const doubl
 // rocPRIM's radix sort of (key, value) pairs on the low `bits` bits (mesh_build.hip); tmp == nullptr: tmpBytes receives the scratch size
 hipError_t sortPairsU32(hipStream_t stream, void* tmp, size_t& tmpBytes, const uint32_t* keys, uint32_t* keysOut, const uint32_t* vals, uint32_t* valsOut,
                         size_t n, unsigned bits);
+// the library's private stream-ordered pool of a device (mesh_build.hip; never the application's default pool), and its trim
+hipMemPool_t meshPool(int dev);
+void meshPoolTrim(int dev);
 // dKeys: n x 8 bytes of DEVICE memory for the per-point (distance, triangle) keys, or nullptr when dOut itself is device memory
 hipError_t launchMeshNaive(hipStream_t stream, const FieldDev& f, const double* dXyz, size_t n, double* dOut, unsigned long long* dKeys = nullptr);
 hipError_t launchAcosfSelftest(hipStream_t stream, uint32_t first, uint32_t stride, size_t n, float* dOut);

@@ -339,6 +339,52 @@ __global__ __launch_bounds__(256) void mb_edges_lookup_kernel(const uint32_t* __
 
 }  // namespace
 
+// The library's private stream-ordered pool of device `dev` (created on first use, one per device, never the device's default
+// pool).  It holds on to at most kMeshPoolKeep bytes of freed blocks (HPSDF_MESH_POOL_KEEP_MB overrides): what a destroyed mesh
+// field occupied beyond that goes back to the driver, so other allocators in the process (PyTorch's, RCCL's) do not starve.
+static uint64_t meshPoolKeepBytes() {
+    static const uint64_t keep = [] {
+        uint64_t mb = 1024;
+        if (const char* v = std::getenv("HPSDF_MESH_POOL_KEEP_MB")) mb = std::strtoull(v, nullptr, 10);
+        return mb << 20;
+    }();
+    return keep;
+}
+static std::mutex gMeshPoolLock;
+static hipMemPool_t gMeshPools[64];
+hipMemPool_t meshPool(int dev) {
+    if (dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> g(gMeshPoolLock);
+    if (!gMeshPools[dev]) {
+        hipMemPoolProps props;
+        std::memset(&props, 0, sizeof props);
+        props.allocType = hipMemAllocationTypePinned;
+        props.handleTypes = hipMemHandleTypeNone;
+        props.location.type = hipMemLocationTypeDevice;
+        props.location.id = dev;
+        hipMemPool_t pool = nullptr;
+        if (hipMemPoolCreate(&pool, &props) != hipSuccess || !pool) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        uint64_t keep = meshPoolKeepBytes();
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        (void)hipGetLastError();
+        gMeshPools[dev] = pool;
+    }
+    return gMeshPools[dev];
+}
+// after a mesh field's block has been freed: give back what the pool holds beyond its bound
+void meshPoolTrim(int dev) {
+    if (dev < 0 || dev >= 64) return;
+    hipMemPool_t pool;
+    {
+        std::lock_guard<std::mutex> g(gMeshPoolLock);
+        pool = gMeshPools[dev];
+    }
+    if (pool) (void)hipMemPoolTrimTo(pool, meshPoolKeepBytes()), (void)hipGetLastError();
+}
+
 // Everything a mesh field needs, from host arrays.  Returns HPSDF_OK and fills the device pointers, or an error / a
 // request to fall back: *fallback = 1 asks the caller to run the host preparation instead (a mesh too small to be worth it: the
 // device buffers are released), *fallback = 2 to supply the twins of a non-manifold mesh from the host (everything else is built and
@@ -395,26 +441,22 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
                      oPar = carve(tb, 2 * nTris * sizeof(int32_t)), oRan = carve(tb, 3 * nTris * sizeof(int32_t)), oTK = carve(tb, tabSize * sizeof(unsigned long long)),
                      oTV = carve(tb, tabSize * sizeof(uint32_t)), oFl = carve(tb, sizeof(MeshBuildFlags)),
                      oSort = carve(tb, sortTmpBytes ? sortTmpBytes : 16);
-        // Both blocks come from the device's stream-ordered pool, which is told to keep what is freed (releaseThreshold): a plain
-        // hipMalloc of a few hundred megabytes costs anything between 0.05 and 15 ms here, more than the whole build.  The field's
-        // block is still released by hipFree (hpsdf_field_destroy: it waits for the device, as before); if the pool declines
-        // (HPSDF_MESH_NO_POOL=1, or a runtime without it), hipMalloc it is.
+        // Both blocks come from a stream-ordered pool of the library's OWN (meshPool: the application's default pool and its
+        // attributes are left alone), which keeps up to a bounded amount of what is freed: a plain hipMalloc of a few hundred
+        // megabytes costs anything between 0.05 and 15 ms here, more than the whole build.  The field's block is still released by
+        // hipFree (hpsdf_field_destroy: it waits for the device, as before, then trims the pool to its bound); if the pool
+        // declines (HPSDF_MESH_NO_POOL=1, or a runtime without it), hipMalloc it is.
         static const bool noPool = std::getenv("HPSDF_MESH_NO_POOL") != nullptr;
         if (e == hipSuccess && !noPool) {
-            static std::once_flag poolOnce[64];
             int dev = 0;
-            if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64)
-                std::call_once(poolOnce[dev], [dev] {
-                    hipMemPool_t pool = nullptr;
-                    uint64_t keep = ~0ull;
-                    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-                    (void)hipGetLastError();
-                });
-            if (hipMallocAsync((void**)&fieldBlock, fb, s) != hipSuccess) fieldBlock = nullptr, (void)hipGetLastError();
-            if (fieldBlock && hipMallocAsync((void**)&tempBlock, tb, s) == hipSuccess) {
-                tempPooled = true;
-            } else {
-                tempBlock = nullptr, (void)hipGetLastError();
+            hipMemPool_t pool = hipGetDevice(&dev) == hipSuccess ? meshPool(dev) : nullptr;
+            if (pool) {
+                if (hipMallocFromPoolAsync((void**)&fieldBlock, fb, pool, s) != hipSuccess) fieldBlock = nullptr, (void)hipGetLastError();
+                if (fieldBlock && hipMallocFromPoolAsync((void**)&tempBlock, tb, pool, s) == hipSuccess) {
+                    tempPooled = true;
+                } else {
+                    tempBlock = nullptr, (void)hipGetLastError();
+                }
             }
         }
         if (e == hipSuccess && !fieldBlock) e = hipMalloc((void**)&fieldBlock, fb);

@@ -598,6 +598,26 @@ def test_bench_two_ranks_sharing_this_gpu():
     assert len(out["mesh_create"]["create_ms_per_rank_1e-6"]) == 2 and out["mesh_create"]["exchanges_per_create_1e-6"] >= 3
 
 
+def test_bench_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2` with NO launcher (how the driver starts the N = 1 run): the parent spawns the two ranks as
+    child processes before it has made any GPU call, relays rank 0's line and the exit code.  Octree::Create sharded over the
+    ranks is Octree.cpp:312-352 run by N processes."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, HPSDF_BENCH_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--points", "400000",
+           "--mesh", "5", "--no-fit-bench", "--no-cpu-baseline", "--no-refined", "--no-sorted-ceiling"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["world"] == 2 and out["backend"] == "gloo" and out["value"] > 0
+    assert out["exchanges_per_create"] >= 2 and out["create_sharded_ms"] > 0
+
+
 _NCCL_GATHER = r'''
 import os, sys
 sys.path.insert(0, sys.argv[1])
