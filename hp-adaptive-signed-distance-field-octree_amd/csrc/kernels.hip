@@ -61,10 +61,57 @@ constexpr float kEpsF32 = 0.000001f;  // Include/Utility/Literals.h:13
 __device__ __forceinline__ bool meshPointFinite(V3 p) { return fabsf(p.x) <= FLT_MAX && fabsf(p.y) <= FLT_MAX && fabsf(p.z) <= FLT_MAX; }
 __device__ __forceinline__ float meshNoTriangle() { return __uint_as_float(0xFFFFFFFFu); }
 
+// The closest point of a triangle in float64 (Ericson's region walk on exact inputs): what closestSimplex falls back on when the
+// reference's face case has left the triangle.  Cold path: a handful of calls per million tests on meshes of needles, none elsewhere.
+__device__ __noinline__ int closestSimplexRobust(V3 ptf, V3 af, V3 bf, V3 cf, V3& q) {
+    const double px = ptf.x, py = ptf.y, pz = ptf.z;
+    const double ax = af.x, ay = af.y, az = af.z, bx = bf.x, by = bf.y, bz = bf.z, cx = cf.x, cy = cf.y, cz = cf.z;
+    const double abx = bx - ax, aby = by - ay, abz = bz - az, acx = cx - ax, acy = cy - ay, acz = cz - az;
+    const double apx = px - ax, apy = py - ay, apz = pz - az;
+    const double d1 = abx * apx + aby * apy + abz * apz, d2 = acx * apx + acy * apy + acz * apz;
+    int code;
+    double t0 = 0.0, t1 = 0.0;  // q = a + t0 ab + t1 ac
+    const double bpx = px - bx, bpy = py - by, bpz = pz - bz;
+    const double d3 = abx * bpx + aby * bpy + abz * bpz, d4 = acx * bpx + acy * bpy + acz * bpz;
+    const double cpx = px - cx, cpy = py - cy, cpz = pz - cz;
+    const double d5 = abx * cpx + aby * cpy + abz * cpz, d6 = acx * cpx + acy * cpy + acz * cpz;
+    const double vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+    if (d1 <= 0.0 && d2 <= 0.0) {
+        code = 0;
+    } else if (d3 >= 0.0 && d4 <= d3) {
+        code = 1, t0 = 1.0;
+    } else if (vc <= 0.0 && d1 >= 0.0 && d3 <= 0.0) {
+        code = 4, t0 = d1 / (d1 - d3);
+    } else if (d6 >= 0.0 && d5 <= d6) {
+        code = 2, t1 = 1.0;
+    } else if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0) {
+        code = 6, t1 = d2 / (d2 - d6);
+    } else if (va <= 0.0 && (d4 - d3) >= 0.0 && (d5 - d6) >= 0.0) {
+        const double w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+        code = 5, t0 = 1.0 - w, t1 = w;
+    } else {
+        const double den = 1.0 / (va + vb + vc);
+        code = 8, t0 = vb * den, t1 = vc * den;
+    }
+    q = V3{(float)(ax + (t0 * abx + t1 * acx)), (float)(ay + (t0 * aby + t1 * acy)), (float)(az + (t0 * abz + t1 * acz))};
+    return code;
+}
+
 // returns simplex*4 + simplexIdx; closest point in q
 // (n: the triangle's unnormalised normal cross(b - a, c - a), precomputed per triangle by mesh_tripos_kernel with these very
 // operations -- the value the reference recomputes in every call, Utility.cpp:41)
-__device__ int closestSimplex(V3 pt, V3 a, V3 b, V3 c, V3 n, V3& q) {
+// The reference's routine, operation by operation, with ONE stated exception (`tol`, a distance: a quarter of the traversal's
+// slack).  Vertex and edge cases return points OF the triangle (a vertex; a + t ab with 0 < t < 1).  The face case forms
+// q = u a + v b + w c from barycentric quotients and returns it whatever the weights are: the absolute 1e-6 guards of the edge tests
+// (snom > eps ...) are lengths SQUARED, so beside a short edge of a needle they let points through that lie well outside the
+// triangle -- q is then a point of the triangle's PLANE, up to eps / (shortest altitude) away from it, and its distance lies
+// BELOW the triangle's.  No bound can be a bound on that: a search that comes across the needle returns the artefact, one that has
+// pruned it (by its box, rightly) does not, and two traversals disagree (tools/fuzz_mesh_bvh.py seeds 100758, 501177: a sphere
+// squashed 1000 : 1).  The weights say exactly where q is -- a negative weight m puts it |m| altitudes beyond the opposite edge,
+// i.e. |m| |n| / |edge| outside -- so: a face-case point farther than `tol` outside its triangle is not taken; the closest point
+// is then computed in float64 (closestSimplexRobust).  Every traversal and the O(n) scan kernel share this function, so they
+// agree bit for bit on every mesh; against the reference the value differs exactly where the reference's is such an artefact.
+__device__ int closestSimplex(V3 pt, V3 a, V3 b, V3 c, V3 n, float tol, V3& q) {
     const V3 ab = b - a, ac = c - a, bc = c - b;
     const float snom = dot(pt - a, ab), sdenom = dot(pt - b, a - b);
     const float tnom = dot(pt - a, ac), tdenom = dot(pt - c, a - c);
@@ -100,6 +147,11 @@ __device__ int closestSimplex(V3 pt, V3 a, V3 b, V3 c, V3 n, V3& q) {
     const float v = vb / (va + vb + vc);
     const float w = 1.0f - u - v;
     q = (u * a + v * b) + w * c;
+    const float m = fminf(u, fminf(v, w));  // (NaN weights -- a triangle without area -- stay the reference's NaN point)
+    if (m < 0.0f) {
+        const float e2 = m == u ? sqnorm(bc) : (m == v ? sqnorm(ac) : sqnorm(ab));  // the edge opposite the negative weight
+        if ((m * m) * sqnorm(n) > (tol * tol) * e2) return closestSimplexRobust(pt, a, b, c, q);
+    }
     return 8;
 }
 
@@ -192,6 +244,9 @@ __device__ __forceinline__ float meshSlack(const BvhNode& root) {
     }
     return 2e-6f * fmaxf(sqrtf(e2), big);
 }
+// closestSimplex's face-case tolerance as a fraction of that slack: a point it accepts lies at most this far outside its triangle, so a
+// distance it returns is at most a quarter of the slack (plus the 3 u M of forming q) below the triangle's true distance
+constexpr float kMeshTolOfSlack = 0.25f;
 __device__ __forceinline__ float rejectBound(float best, float slack) {
     const float r = sqrtf(best) + slack;
     return r * r * 1.00001f;
@@ -212,7 +267,7 @@ __device__ float meshSignedDistance(const MeshDev& m, V3 pt, uint32_t& hint) {
     auto visitTri = [&](uint32_t t) {
         V3 q;
         const float4 tp[3] = {m.triPos[3 * (size_t)t], m.triPos[3 * (size_t)t + 1], m.triPos[3 * (size_t)t + 2]};
-        const int code = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, q);
+        const int code = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, kMeshTolOfSlack * slack, q);
         const float d = sqnorm(pt - q);
         if (d < best || (d == best && t < bestTri)) {
             best = d;
@@ -300,7 +355,7 @@ __device__ float meshSignedDistanceWave(const MeshDev& m, V3 pt, bool activeIn, 
     auto visitTri = [&](uint32_t t) {
         V3 q;
         const float4 tp[3] = {m.triPos[3 * (size_t)t], m.triPos[3 * (size_t)t + 1], m.triPos[3 * (size_t)t + 2]};
-        const int code = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, q);
+        const int code = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, kMeshTolOfSlack * slack, q);
         const float d = sqnorm(pt - q);
         if (d < best || (d == best && t < bestTri)) {
             best = d;
@@ -502,7 +557,7 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool activeIn,
         if (on) {
             V3 q;
             const float4 tp[3] = {m.triPos[3 * (size_t)t], m.triPos[3 * (size_t)t + 1], m.triPos[3 * (size_t)t + 2]};
-            closestSimplex(p, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, q);
+            closestSimplex(p, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, kMeshTolOfSlack * slack, q);
             const float d = sqnorm(p - q);
             atomicMin(&L.best[src], ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)t);
         }
@@ -591,7 +646,7 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool activeIn,
         auto tryTriangle = [&](uint32_t t, uint32_t slot) {
             V3 q;
             const float4 tp[3] = {m.triPos[3 * (size_t)t], m.triPos[3 * (size_t)t + 1], m.triPos[3 * (size_t)t + 2]};
-            const int code = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, q);
+            const int code = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, kMeshTolOfSlack * slack, q);
             const float d = sqnorm(pt - q);
             const bool better = d < best || (d == best && t < bestTri);
             if (better) best = d, bestTri = t, bestSlot = slot, bestCode = code, rj = rejectBound(d, slack);
@@ -895,7 +950,7 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool activeIn,
         const uint32_t bestTri = (uint32_t)(L.best[lane] & 0xFFFFFFFFull);
         V3 bestQ;
         const float4 tp[3] = {m.triPos[3 * (size_t)bestTri], m.triPos[3 * (size_t)bestTri + 1], m.triPos[3 * (size_t)bestTri + 2]};
-        const int bestCode = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, bestQ);
+        const int bestCode = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, kMeshTolOfSlack * slack, bestQ);
         const V3 nrm = pseudoNormal(m, bestTri, bestCode);
         const V3 d = pt - bestQ;
         const float sign = dot(nrm, d) > 0.0f ? 1.0f : -1.0f;
@@ -2363,10 +2418,11 @@ __global__ __launch_bounds__(256) void mesh_naive_kernel(MeshDev m, const double
     const V3 pt = {(float)xyz[3 * i], (float)xyz[3 * i + 1], (float)xyz[3 * i + 2]};
     float best = FLT_MAX;
     uint32_t bestTri = 0xFFFFFFFFu;
+    const float slack = meshSlack(loadNodeUniform(m.bvh, 0));  // (the face-case tolerance of closestSimplex: the same on every path)
     for (uint32_t t = first + (uint32_t)lane; t < last; t += 64u) {
         V3 q;
         const float4 tp[3] = {m.triPos[3 * (size_t)t], m.triPos[3 * (size_t)t + 1], m.triPos[3 * (size_t)t + 2]};
-        closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, q);
+        closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, kMeshTolOfSlack * slack, q);
         const float d = sqnorm(pt - q);
         if (d < best) best = d, bestTri = t;
     }
@@ -2392,9 +2448,10 @@ __global__ __launch_bounds__(256) void mesh_naive_finish_kernel(MeshDev m, const
     }
     const uint32_t t = (uint32_t)key;
     const V3 pt = {(float)xyz[3 * i], (float)xyz[3 * i + 1], (float)xyz[3 * i + 2]};
+    const float slack = meshSlack(m.bvh[0]);
     V3 q;
     const float4 tp[3] = {m.triPos[3 * (size_t)t], m.triPos[3 * (size_t)t + 1], m.triPos[3 * (size_t)t + 2]};
-    const int code = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, q);
+    const int code = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, kMeshTolOfSlack * slack, q);
     const V3 nrm = pseudoNormal(m, t, code);
     const V3 d = pt - q;
     const float sign = dot(nrm, d) > 0.0f ? 1.0f : -1.0f;
@@ -2582,17 +2639,16 @@ __global__ __launch_bounds__(256) void mesh_tripre_kernel(const float* __restric
         const float e = fmaxf(fabsf(sa), fmaxf(fabsf(sb), fabsf(sc)));
         const float wa = sqrtf(fmaxf(ra - sa * sa - ua * ua, 0.0f)), wb = sqrtf(fmaxf(rb - sb * sb - ub * ub, 0.0f)),
                     wc = sqrtf(fmaxf(rcq - sc * sc - uc * uc, 0.0f));
-        // What the rectangle has to hold is not the triangle but what the reference's closest-point routine (Utility.cpp:5-97)
-        // can return for it: its face case forms q = u a + v b + w c from barycentrics whose relative error grows as the
-        // triangle gets thin -- ~8 ulps over the sine of its smallest angle -- so q may leave the triangle IN ITS PLANE by that
-        // fraction of the longest edge (on a needle, by any amount: the ball takes over).  A circle around the whole triangle
-        // happened to cover that; the rectangle is made to.
-        const float l2 = sqrtf(fmaxf(fminf(fmaxf(lab, lac), fmaxf(fminf(lab, lac), lbc)), 0.0f));  // the second-longest edge
-        const float sine = len / (ll * l2);                                                            // of the smallest angle (about)
-        const float play = (1e-6f / fmaxf(sine, 1e-30f)) * ll;
-        hu = fmaxf(fabsf(ua), fmaxf(fabsf(ub), fabsf(uc))) * 1.00001f + 4e-7f * scale + play;
-        hv = fmaxf(wa, fmaxf(wb, wc)) * 1.00001f + 4e-7f * scale + play;
-        framed = e <= 4e-7f * scale && hu < inf && hv < inf && play < rho;
+        // The rectangle holds the TRIANGLE (measured above, with allowances for its own rounding).  What the closest-point routine
+        // returns for the triangle lies within a quarter of the traversal's slack of it: closestSimplex does not take a face-case
+        // point farther outside than that (until round 4 the rectangle was widened by a "play" of 1e-6 longest edge / sin(smallest
+        // angle) instead, an estimate of how far the reference's barycentric quotients can throw q: it did not hold on needles).
+        hu = fmaxf(fabsf(ua), fmaxf(fabsf(ub), fabsf(uc))) * 1.00001f + 4e-7f * scale;
+        // (hv also takes 1e-3 hu: the test forms the in-plane distance across u as sqrt(|d|^2 - s^2 - a^2), whose cancellation leaves up to
+        // sqrt(2 ulp) |d| = 3.5e-4 |d| where the true value is nearly zero -- beside a needle that is more than its width; past ~3 hu from
+        // g the excess is below 1e-6 of the bound itself, which rejectBound's factor covers)
+        hv = fmaxf(wa, fmaxf(wb, wc)) * 1.00001f + 4e-7f * scale + 1e-3f * hu;
+        framed = e <= 4e-7f * scale && hu < inf && hv < inf;
     }
     if (!framed || !(rho < inf)) {  // (non-finite input: the bound degenerates to "always passes" via NaN)
         nh = V3{0.0f, 0.0f, 0.0f}, uh = V3{0.0f, 0.0f, 0.0f};

@@ -157,6 +157,15 @@ HPSDF_API int hpsdf_field_destroy(hpsdf_field* f);
 HPSDF_API int hpsdf_field_eval_device(hpsdf_ctx* ctx, const hpsdf_field* f, const double* d_xyz, size_t n,
                                       double* d_out);
 HPSDF_API int hpsdf_field_eval_host(hpsdf_ctx* ctx, const hpsdf_field* f, const double* xyz, size_t n, double* out);
+/* Mesh fields, the one stated deviation from the reference's closest-point arithmetic (Source/Meshing/Utility.cpp:5-97): its face
+ * case returns q = u a + v b + w c whatever the barycentric weights are, and beside the short edges of needle-shaped triangles
+ * (its 1e-6 guards are absolute) a weight can be negative enough to put q well outside the triangle -- a distance below the
+ * triangle's own, which a search reports or not depending on what it has pruned (the reference's BVH and its linear scan
+ * disagree there too).  Here a face-case point farther outside its triangle than 5e-7 of the mesh's scale (a quarter of the
+ * traversal's slack) is replaced by the triangle's closest point computed in float64.  Consequences: the four evaluation paths
+ * below (naive scan, per-lane traversal, shared traversal, hpsdf_field_eval_*) agree BIT FOR BIT on every mesh; against the
+ * reference's arithmetic they differ exactly at the points where its own value is such an artefact (6 points in 8 000 random
+ * meshes x 5 301 points, all on meshes squashed 100 : 1 or more; tests/test_gpu_configs.py::test_needle_meshes_one_answer_on_every_path). */
 /* (Mesh fields: a point with a coordinate that is not a finite number has no closest triangle -- the reference's search ends
  * with bestTri = -1 there and reads out of bounds, Mesh.cpp:139,157 -- and evaluates to a NaN on every entry point below.) */
 /* Mesh::SignedDistanceAtPt(pt) without a BVH (Source/Meshing/Mesh.cpp:42-51 over the O(n) scan :134-159), mesh fields
@@ -172,8 +181,10 @@ HPSDF_API int hpsdf_field_eval_wave_host(hpsdf_ctx* ctx, const hpsdf_field* f, c
  * hpsdf_field_eval_* itself takes the faster shared traversal for plain mesh fields): same bits.  Diagnostics. */
 HPSDF_API int hpsdf_field_eval_lane_host(hpsdf_ctx* ctx, const hpsdf_field* f, const double* xyz, size_t n, double* out);
 /* Diagnostics: the device's acosf -- the angle weights of a vertex pseudo-normal, std::acos in Source/Meshing/Mesh.cpp:226-231
- * -- for the n floats whose bit patterns are first_bits, first_bits + stride, ...  It is the host libm's (glibc's) algorithm
- * restated (csrc/acosf_host_libm.hpp), so out[] equals acosf() of the host bit for bit. */
+ * -- for the n floats whose bit patterns are first_bits, first_bits + stride, ...  It is glibc's float acos as shipped up to glibc
+ * 2.40 (the fdlibm e_acosf algorithm, restated in csrc/acosf_host_libm.hpp): out[] equals acosf() of such a host bit for bit.
+ * glibc >= 2.41 (correctly rounded CORE-MATH acosf), musl and other libms may differ from it in the last place; the tests
+ * detect that (tests/test_product_cpu.py compares with the machine's libm and says which one it found). */
 HPSDF_API int hpsdf_selftest_acosf(hpsdf_ctx* ctx, uint32_t first_bits, uint32_t stride, size_t n, float* out);
 /* Diagnostics (no reference counterpart; HPSDF_ERR_UNSUPPORTED unless the library was built with
  * -DHPSDF_MESH_STATS_BUILD): BVH traversal counters of a mesh field created while the environment

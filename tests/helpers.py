@@ -217,3 +217,74 @@ def displaced_torus(nu=1024, nv=1024, R=0.3, r=0.1, amp=0.02):
     d = (i * nv + (j + 1) % nv).ravel()
     tris = np.concatenate([np.stack([a, b, c], -1), np.stack([a, c, d], -1)]).astype(np.uint64)
     return verts, tris
+
+
+def hard_points(verts, tris, seed):
+    """Points where a BVH's bounds and leaf grouping could bite: around the mesh, on vertices / edges / faces, just off the surface,
+    the medial region (near-ties everywhere), far away."""
+    rng = np.random.default_rng(seed)
+    lo, hi = verts.min(0).astype(np.float64), verts.max(0).astype(np.float64)
+    ext = (hi - lo).max()
+    c = 0.5 * (lo + hi)
+    tri = verts[tris[rng.integers(0, len(tris), 600)]].astype(np.float64)
+    w = rng.dirichlet((1.0, 1.0, 1.0), 600)
+    return np.concatenate([
+        lo - 0.1 * ext + rng.random((3000, 3)) * (hi - lo + 0.2 * ext),        # around the mesh
+        verts[rng.integers(0, len(verts), 300)].astype(np.float64),             # on vertices
+        0.5 * (tri[:300, 0] + tri[:300, 1]),                                    # on edges
+        (tri * w[:, :, None]).sum(1),                                           # on faces
+        (tri * w[:, :, None]).sum(1) + 1e-4 * ext * rng.standard_normal((600, 3)),  # just off the surface
+        c + 1e-3 * ext * rng.standard_normal((300, 3)), c[None, :],             # the medial region: near-ties everywhere
+        c + 10.0 * ext * rng.standard_normal((200, 3)),                         # far away
+    ])
+
+
+def fuzz_mesh_case(seed):
+    """The random closed mesh of tools/fuzz_mesh_bvh.py for a seed: a bumpy icosphere or a displaced torus under a random affine map
+    (anisotropic scales down to 1e-3 -- needles --, translations up to 100 extents).  Returns verts, tris, leaf size, host build, scale."""
+    rng = np.random.default_rng(seed)
+    if seed % 2 == 0:
+        verts, tris = icosphere(int(rng.integers(2, 6)), 0.3)
+        d = verts / np.linalg.norm(verts, axis=1, keepdims=True)
+        verts = verts * (1 + rng.uniform(0, 0.3) * np.sin(rng.integers(2, 9) * d[:, 0] + seed) * np.cos(rng.integers(2, 9) * d[:, 1]))[:, None]
+    else:
+        verts, tris = displaced_torus(int(rng.integers(10, 120)), int(rng.integers(8, 90)), 0.28, 0.09, float(rng.uniform(0, 0.03)))
+    scale = 10.0 ** rng.uniform(-3, 0, 3) if seed % 3 == 0 else np.ones(3)
+    shift = rng.uniform(-1, 1, 3) * (100.0 if seed % 5 == 0 else 0.1)
+    verts = (verts * scale + shift).astype(np.float32)
+    leaf = int(rng.choice([1, 2, 4, 8, 16]))
+    return verts, tris, leaf, seed % 7 == 3, scale, shift
+
+
+def closest_point_on_triangle_f64(p, a, b, c):
+    """Ericson's closest point of a triangle, vectorised over triangles, in float64 (the brute-force truth of the mesh tests)."""
+    ab, ac, ap = b - a, c - a, p - a
+    d1, d2 = (ab * ap).sum(1), (ac * ap).sum(1)
+    bp = p - b
+    d3, d4 = (ab * bp).sum(1), (ac * bp).sum(1)
+    cp = p - c
+    d5, d6 = (ab * cp).sum(1), (ac * cp).sum(1)
+    vc, vb, va = d1 * d4 - d3 * d2, d5 * d2 - d1 * d6, d3 * d6 - d5 * d4
+    with np.errstate(all="ignore"):
+        den = 1.0 / (va + vb + vc)
+        q = a + ab * (vb * den)[:, None] + ac * (vc * den)[:, None]
+        m = (va <= 0) & (d4 - d3 >= 0) & (d5 - d6 >= 0)
+        q[m] = (b + (c - b) * ((d4 - d3) / ((d4 - d3) + (d5 - d6)))[:, None])[m]
+        m = (vb <= 0) & (d2 >= 0) & (d6 <= 0)
+        q[m] = (a + ac * (d2 / (d2 - d6))[:, None])[m]
+        m = (d6 >= 0) & (d5 <= d6)
+        q[m] = c[m]
+        m = (vc <= 0) & (d1 >= 0) & (d3 <= 0)
+        q[m] = (a + ab * (d1 / (d1 - d3))[:, None])[m]
+        m = (d3 >= 0) & (d4 <= d3)
+        q[m] = b[m]
+        m = (d1 <= 0) & (d2 <= 0)
+        q[m] = a[m]
+    return q
+
+
+def true_distance_f64(verts, tris, p):
+    """Unsigned distance of one point from the mesh by an exhaustive float64 scan."""
+    A, B, Cc = (verts[tris[:, k]].astype(np.float64) for k in range(3))
+    q = closest_point_on_triangle_f64(np.asarray(p, np.float64)[None, :], A, B, Cc)
+    return float(np.sqrt(((q - p) ** 2).sum(1)).min())

@@ -343,21 +343,8 @@ def test_non_manifold_mesh_keeps_the_device_hierarchy(H, O, ctx, monkeypatch):
 
 
 def _hard_points(O, verts, tris, seed):
-    rng = np.random.default_rng(seed)
-    lo, hi = verts.min(0).astype(np.float64), verts.max(0).astype(np.float64)
-    ext = (hi - lo).max()
-    c = 0.5 * (lo + hi)
-    tri = verts[tris[rng.integers(0, len(tris), 600)]].astype(np.float64)
-    w = rng.dirichlet((1.0, 1.0, 1.0), 600)
-    return np.concatenate([
-        lo - 0.1 * ext + rng.random((3000, 3)) * (hi - lo + 0.2 * ext),        # around the mesh
-        verts[rng.integers(0, len(verts), 300)].astype(np.float64),             # on vertices
-        0.5 * (tri[:300, 0] + tri[:300, 1]),                                    # on edges
-        (tri * w[:, :, None]).sum(1),                                           # on faces
-        (tri * w[:, :, None]).sum(1) + 1e-4 * ext * rng.standard_normal((600, 3)),  # just off the surface
-        c + 1e-3 * ext * rng.standard_normal((300, 3)), c[None, :],             # the medial region: near-ties everywhere
-        c + 10.0 * ext * rng.standard_normal((200, 3)),                         # far away
-    ])
+    from helpers import hard_points
+    return hard_points(verts, tris, seed)
 
 
 @pytest.mark.parametrize("host_build", [False, True])
@@ -377,6 +364,37 @@ def test_mesh_lower_bound_filter_keeps_the_scan_winner(H, O, ctx, monkeypatch, h
         perm = np.random.default_rng(seed).permutation(len(pts))
         assert np.array_equal(bits(f.eval_wave(ctx, pts[perm])), bits(want[perm])), name
         f.close()
+
+
+@pytest.mark.parametrize("seed", [228, 489, 3624, 4851, 100758, 501177])
+def test_needle_meshes_one_answer_on_every_path(H, O, ctx, monkeypatch, seed):
+    """The six random meshes on which three rounds of tools/fuzz_mesh_bvh.py soaks saw the exhaustive scan and the hierarchy
+    disagree (spheres and tori squashed up to 1000 : 1: every triangle a needle).  The reference's closest-point routine
+    (Utility.cpp:5-97) forms its face-case point from barycentric quotients and returns it even when the weights put it outside
+    the triangle -- its absolute 1e-6 guards let that happen beside short edges -- i.e. a distance BELOW the triangle's, which a
+    search sees or not depending on what it prunes (BVH.cpp:263-342 would too).  The product's rule (kernels.hip, closestSimplex):
+    a face-case point farther outside its triangle than a quarter of the traversal's slack is replaced by the float64 closest
+    point.  So: (1) the O(n) scan kernel, the per-lane traversal and the shared traversal agree BIT FOR BIT, always; (2) wherever
+    they differ from the oracle's scan (= the reference's arithmetic), the oracle's value is such an artefact -- below the
+    float64 brute-force distance -- and the product's is that distance."""
+    from helpers import fuzz_mesh_case, hard_points, true_distance_f64
+    verts, tris, leaf, host, scale, shift = fuzz_mesh_case(seed)
+    monkeypatch.setenv("HPSDF_MESH_LEAF_TRIS", str(leaf))
+    if host:
+        monkeypatch.setenv("HPSDF_MESH_HOST_BUILD", "1")
+    f = H.Field.mesh(ctx, verts, tris)
+    pts = hard_points(verts, tris, seed)
+    scan, lane, wave = f.eval_naive(ctx, pts), f.eval_lane(ctx, pts), f.eval_wave(ctx, pts)
+    assert np.array_equal(bits(lane), bits(scan)) and np.array_equal(bits(wave), bits(scan))
+    ref = O.MeshField(verts, tris).signed_distance(pts)[0].astype(np.float64)
+    diff = np.nonzero(bits(ref) != bits(scan))[0]
+    assert 1 <= len(diff) <= 8, len(diff)  # (the soaks found one point each)
+    ext = float(np.linalg.norm(verts.max(0) - verts.min(0)))
+    for i in diff:
+        d = true_distance_f64(verts, tris, pts[i])
+        assert abs(ref[i]) < d - 1e-6 * ext, (i, ref[i], d)                   # the reference's value: below the true distance
+        assert abs(abs(scan[i]) - d) <= 1e-4 * max(ext, d), (i, scan[i], d)   # the product's: the true distance
+    f.close()
 
 
 # ------------------------------------------------------------------ blocks shaped like the reference's (SURVEY H5)
@@ -546,6 +564,28 @@ def test_create_distributed_device_frontier_byte_identical(H, ctx, world):
              (H.make_config(1e-5), lambda c: H.Field.union3(), 1024)]
     for cfg, make_field, K in cases:
         one, st = H.create_block(ctx, cfg, make_field(ctx), K)
+        for blk, s in _create_on_simulated_ranks(H, world, cfg, make_field, K):
+            assert blk == one
+            assert s["rounds"] == st["rounds"] and s["n_nodes"] == st["n_nodes"] and s["jobs"] == st["jobs"]
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_create_distributed_with_continuity_byte_identical(H, ctx, world):
+    """BASELINE configs[4]'s actual combination -- mesh field x continuity.enforce x sharded ranks -- through
+    hpsdf_create_distributed: every rank runs the post-process (Octree.cpp:341-344) on its identical copy of the gathered tree,
+    so every rank's block equals the single-rank block, which equals the host post-process of the plain sharded build.  And the
+    same for the refined analytic tree."""
+    verts, tris = _mesh()
+    cases = [(1e-6, MESH_ROOT, lambda c: H.Field.mesh(c, verts, tris), MESH_K),
+             (1e-7, ((-0.5,) * 3, (0.5,) * 3), lambda c: H.Field.union3(), 256)]
+    for target, root, make_field, K in cases:
+        cfg = H.make_config(target, *root, continuity=True)
+        one, st = H.create_block(ctx, cfg, make_field(ctx), K)
+        plain, _ = H.create_block(ctx, H.make_config(target, *root), make_field(ctx), K)
+        b0 = bytearray(plain)
+        b0[-80 + 16] = 1  # Config::continuity.enforce of the serialised block (Config.h:12-43)
+        assert H.continuity_post_process(bytes(b0))[0] == one
+        assert one != bytes(b0)  # (the post-process did move coefficients)
         for blk, s in _create_on_simulated_ranks(H, world, cfg, make_field, K):
             assert blk == one
             assert s["rounds"] == st["rounds"] and s["n_nodes"] == st["n_nodes"] and s["jobs"] == st["jobs"]

@@ -119,3 +119,20 @@ def test_full_size_create_with_continuity(H, ctx, torus, torus_build):
     b0 = bytearray(plain)
     b0[-80 + 16] = 1
     assert H.continuity_post_process(bytes(b0))[0] == blk
+
+
+def test_full_size_sharded_create_with_continuity(H, ctx, torus, torus_build):
+    """BASELINE configs[4] as written -- 2 M-triangle mesh, targetError 1e-5, continuity.enforce, frontier sharded over 8 ranks --
+    through hpsdf_create_distributed (eight threads, one context and one copy of the mesh each): every rank's block equals the
+    single-rank Create with continuity, which equals the host post-process of the plain build."""
+    verts, tris, lo, hi = torus
+    f = torus_build[0]
+    cfg = H.make_config(1e-5, lo, hi, continuity=True)
+    one, st = H.create_block(ctx, cfg, f, K)
+    plain, _ = H.create_block(ctx, H.make_config(1e-5, lo, hi), f, K)
+    b0 = bytearray(plain)
+    b0[-80 + 16] = 1
+    assert H.continuity_post_process(bytes(b0))[0] == one
+    for blk, s in _create_on_simulated_ranks(H, 8, cfg, lambda c: H.Field.mesh(c, verts, tris), K):
+        assert blk == one
+        assert s["n_nodes"] == st["n_nodes"] and s["jobs"] == st["jobs"]
