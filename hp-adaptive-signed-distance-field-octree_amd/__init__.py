@@ -104,6 +104,9 @@ _SIGNATURES = {
     "hpsdf_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hpsdf_ctx_synchronize": (C.c_int, [C.c_void_p]),
     "hpsdf_ctx_set_fast_fit": (C.c_int, [C.c_void_p, C.c_int]),
+    "hpsdf_ctx_set_fit_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "hpsdf_ctx_get_fit_mode": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "hpsdf_ctx_set_split_min_degree": (C.c_int, [C.c_void_p, C.c_int]),
     "hpsdf_ctx_stream": (C.c_void_p, [C.c_void_p]),
     "hpsdf_field_create_analytic": (C.c_int, [C.POINTER(Prim), C.c_int, C.POINTER(C.c_void_p)]),
     "hpsdf_field_create_callback": (C.c_int, [CALLBACK, C.c_void_p, C.POINTER(C.c_void_p)]),
@@ -263,6 +266,9 @@ class Config:
         return c
 
 
+FIT_EXACT, FIT_SPLIT, FIT_FAST = 0, 1, 2
+
+
 def make_config(target=1e-10, root_min=(-0.5, -0.5, -0.5), root_max=(0.5, 0.5, 0.5), threads=1, continuity=False):
     c = Config()
     c.targetErrorThreshold = target
@@ -284,8 +290,22 @@ class Context:
         check(lib().hpsdf_ctx_set_stream(self.handle, C.c_void_p(stream) if stream else None))
 
     def set_fast_fit(self, on=True):
-        """Opt-in: cell fits of degree >= 4 on the matrix cores (not bit-identical to the default path)."""
+        """Every row of every fit of degree >= 4 on the matrix cores (FIT_FAST; errors then only agree to ~1e-15)."""
         check(lib().hpsdf_ctx_set_fast_fit(self.handle, 1 if on else 0))
+
+    def set_fit_mode(self, mode):
+        """FIT_EXACT (0): every row bit-exact, the canonical bytes; FIT_SPLIT (1, default): top-degree rows of from-scratch fits of
+        degree >= 4 exact, the rows below them on the matrix cores -- errors and topology canonical; FIT_FAST (2): all rows there."""
+        check(lib().hpsdf_ctx_set_fit_mode(self.handle, int(mode)))
+
+    def set_split_min_degree(self, degree):
+        """FIT_SPLIT splits from-scratch fits from this degree on (4..12; default 6)."""
+        check(lib().hpsdf_ctx_set_split_min_degree(self.handle, int(degree)))
+
+    def fit_mode(self):
+        m = C.c_int(0)
+        check(lib().hpsdf_ctx_get_fit_mode(self.handle, C.byref(m)))
+        return m.value
 
     def synchronize(self):
         check(lib().hpsdf_ctx_synchronize(self.handle))

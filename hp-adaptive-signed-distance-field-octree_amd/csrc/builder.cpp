@@ -311,8 +311,25 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
     }
     const bool meshFused = innermost(field)->kind == kHostMesh && !meshSampled;
     // opt-in fast fit (hpsdf_ctx_set_fast_fit): degrees >= 4 of unweighted, non-CSG fields go to the matrix cores
-    const bool fastOn = ctx->fastFit && !b->weighted && !meshFused && field->kind != kHostTreeCsg;
+    const bool fastOn = ctx->fitMode == HPSDF_FIT_FAST && !b->weighted && !meshFused && field->kind != kHostTreeCsg;
     auto fastDeg = [&](int deg) { return fastOn && deg >= 4 && deg <= 11; };
+    // the default (HPSDF_FIT_SPLIT): a from-scratch fit of degree >= 4 is cut in two -- its rows of top degree by the bit-exact kernel
+    // (they alone enter the error, Octree.cpp:1062-1069), the rows below them by fit_mfma_low_kernel from the same samples.  Not for
+    // weighted builds (the weight reads every row) nor for mesh fits that sample inside the fit kernel; a round whose samples would
+    // not fit the sample buffer's 16 GB is fitted exactly throughout.
+    bool splitOn = ctx->fitMode == HPSDF_FIT_SPLIT && !b->weighted && !meshFused;
+    if (splitOn) {
+        uint64_t need = 0;
+        bool any = false;
+        for (int c = 0; c < kClasses; ++c) {
+            const int deg = c / kDepths / 2;
+            const uint64_t nq = 4 * (uint64_t)deg + 1;
+            need += classCount[c] * nq * nq * nq;
+            any |= classCount[c] && !((c / kDepths) & 1) && fitSplitSupports(deg, ctx->splitMinDegree);
+        }
+        splitOn = any && need <= (1ull << 31);
+    }
+    auto splitClass = [&](int deg, bool incr) { return splitOn && !incr && fitSplitSupports(deg, ctx->splitMinDegree); };
 
     // ---- workgroup table
     uint32_t nBlocks = 0;
@@ -323,7 +340,7 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
         if (!classCount[c]) continue;
         const int deg = c / kDepths / 2;
         const bool incr = (c / kDepths) & 1;
-        const int nrows = incr ? (int)(T.coeffCount[deg] - T.coeffCount[deg - 1]) : (int)T.coeffCount[deg];
+        const int nrows = (incr || splitClass(deg, incr)) ? (int)(T.coeffCount[deg] - T.coeffCount[deg - 1]) : (int)T.coeffCount[deg];
         classShape[c] = fitShape(deg, nrows, classCount[c], b->weighted, meshFused);
         if (fastDeg(deg)) classShape[c] = FitShape{kMfmaCells, 1, 1, 0};  // one workgroup = one 16-cell tile of the matrix-core fit
         nBlocks += (classCount[c] + classShape[c].cells - 1) / classShape[c].cells;
@@ -348,10 +365,11 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
                 fb.nTasks = (uint16_t)std::min<uint32_t>(g, classCount[c] - i);
                 fb.degree = (uint8_t)deg;
                 fb.planesPerChunk = (uint8_t)classShape[c].planes;
-                fb.rowStart = (uint16_t)(incr ? T.coeffCount[deg - 1] : 0);
+                fb.rowStart = (uint16_t)((incr || splitClass(deg, incr)) ? T.coeffCount[deg - 1] : 0);
                 fb.rowEnd = (uint16_t)T.coeffCount[deg];
                 fb.depth = (uint8_t)(c % kDepths);
                 fb.weighted = b->weighted ? 1 : 0;
+                fb.split = splitClass(deg, incr) ? 1 : 0;
             }
         }
     }
@@ -491,7 +509,7 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
         HPSDF_HIP(hipMemcpyAsync(ws.tasks.dev, ws.tasks.host, nTasks * sizeof(FitTask), hipMemcpyHostToDevice, ctx->stream));
         HPSDF_HIP(hipMemcpyAsync(ws.blocks.dev, ws.blocks.host, nBlocks * sizeof(FitBlock), hipMemcpyHostToDevice, ctx->stream));
     }
-    if (meshSampled && nTasks) {
+    if ((meshSampled || (splitOn && !sampled)) && nTasks) {  // (split fits of an analytic field leave their values here for the matrix-core kernel)
         if (sampleNeed > ws.meshSamplesCap) {
             uint64_t nc = std::max<uint64_t>(ws.meshSamplesCap * 2, 1ull << 22);
             while (nc < sampleNeed) nc *= 2;
@@ -502,13 +520,13 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
             ws.meshSamplesCap = nc;
         }
         // the tasks of one degree are contiguous (classes are ordered degree-major)
-        for (int deg = 0; deg <= kMaxDegree; ++deg) {
+        for (int deg = 0; deg <= kMaxDegree && meshSampled; ++deg) {
             const uint32_t first = classFirst[classOf(deg, false, 0)];
             const uint32_t last = deg == kMaxDegree ? nTasks : classFirst[classOf(deg + 1, false, 0)];
             if (last > first)
                 HPSDF_HIP(launchMeshSample(ctx->stream, ws.tasks.dev + first, last - first, deg, ctx->dTables, fd, rm, ws.meshSamples));
         }
-        fd.kind = kFieldSamples;  // the fit reads what the sampler wrote (a csg wrapper still applies on top)
+        if (meshSampled) fd.kind = kFieldSamples;  // the fit reads what the sampler wrote (a csg wrapper still applies on top)
         fd.samples = ws.meshSamples;
     }
     HPSDF_HIP(hipMemsetAsync(ws.errs.dev, 0, (b->weighted ? 2 : 1) * nSlots * sizeof(double), ctx->stream));
@@ -548,6 +566,12 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
                                       ws.tasks.dev, ws.arena, ws.errs.dev + nSlots, ctx->dTables));
         c = e;
     }
+    if (splitOn)  // the rows below the top degree of the split fits: the from-scratch tasks of a degree are one contiguous run
+        for (int deg = std::max(4, ctx->splitMinDegree); deg <= 11; ++deg) {
+            const uint32_t first = classFirst[classOf(deg, false, 0)], count = classFirst[classOf(deg, true, 0)] - first;
+            if (count)
+                HPSDF_HIP(launchFitMfmaLow(ctx->stream, deg, ws.tasks.dev, nullptr, first, count, 0u, ws.arena, ctx->dTables, fd.samples, rm));
+        }
     b->computed = true;
     return HPSDF_OK;
 }

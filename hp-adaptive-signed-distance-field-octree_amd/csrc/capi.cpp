@@ -239,6 +239,12 @@ int hpsdf_ctx_create(int device, void* stream, hpsdf_ctx** out) {
     HPSDF_HIP(hipSetDevice(device));
     hpsdf_ctx* c = new hpsdf_ctx();
     c->device = device;
+    c->splitMinDegree = fitSplitDefaultMinDegree();
+    if (const char* fm = std::getenv("HPSDF_FIT_MODE")) {  // the mode a context starts with (hpsdf_ctx_set_fit_mode changes it)
+        if (!std::strcmp(fm, "exact")) c->fitMode = HPSDF_FIT_EXACT;
+        else if (!std::strcmp(fm, "fast")) c->fitMode = HPSDF_FIT_FAST;
+        else if (!std::strcmp(fm, "split")) c->fitMode = HPSDF_FIT_SPLIT;
+    }
     if (stream) {
         c->stream = (hipStream_t)stream;
     } else {
@@ -301,11 +307,24 @@ int hpsdf_ctx_set_stream(hpsdf_ctx* c, void* stream) {
     return HPSDF_OK;
 }
 
-int hpsdf_ctx_set_fast_fit(hpsdf_ctx* c, int on) {
+int hpsdf_ctx_set_fit_mode(hpsdf_ctx* c, int mode) {
     if (!c) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null context");
-    c->fastFit = on != 0;
+    if (mode != HPSDF_FIT_EXACT && mode != HPSDF_FIT_SPLIT && mode != HPSDF_FIT_FAST) return fail(HPSDF_ERR_INVALID_ARGUMENT, "unknown fit mode");
+    c->fitMode = mode;
     return HPSDF_OK;
 }
+int hpsdf_ctx_get_fit_mode(hpsdf_ctx* c, int* mode) {
+    if (!c || !mode) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    *mode = c->fitMode;
+    return HPSDF_OK;
+}
+int hpsdf_ctx_set_split_min_degree(hpsdf_ctx* c, int degree) {
+    if (!c) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null context");
+    if (degree < 4 || degree > 12) return fail(HPSDF_ERR_INVALID_ARGUMENT, "split_min_degree: 4..12 (12 = never split)");
+    c->splitMinDegree = degree;
+    return HPSDF_OK;
+}
+int hpsdf_ctx_set_fast_fit(hpsdf_ctx* c, int on) { return hpsdf_ctx_set_fit_mode(c, on ? HPSDF_FIT_FAST : HPSDF_FIT_SPLIT); }
 
 int hpsdf_ctx_synchronize(hpsdf_ctx* c) {
     if (!c) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null ctx");
@@ -725,6 +744,8 @@ int hpsdf_tree_upload(hpsdf_ctx* ctx, const void* block, size_t size, hpsdf_tree
         t->dev.rootCentre[a] = (double)((cfg.root_min[a] + cfg.root_max[a]) / 2.0f);  // Octree.cpp:419
         t->dev.rootInvSizes[a] = (double)(1.0f / (cfg.root_max[a] - cfg.root_min[a]));  // Octree.cpp:420
     }
+    t->hNodes = std::move(nodes);  // (validated above: every child index and coefficient range lies inside the block)
+    t->hCoeffs.assign(coeffs, coeffs + nCoeffs);
     *out = t;
     return HPSDF_OK;
     HPSDF_CATCH
@@ -789,10 +810,23 @@ int hpsdf_query_device(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* dXyz, 
     HPSDF_CATCH
 }
 
+// HPSDF_SMALL_QUERIES_ON_DEVICE=1 (read once) sends calls of a few points through query_few_kernel as before round 4: a measurement knob
+static bool smallQueriesOnHost() {
+    static const bool on = [] {
+        const char* e = std::getenv("HPSDF_SMALL_QUERIES_ON_DEVICE");
+        return !(e && e[0] == '1');
+    }();
+    return on;
+}
+
 int hpsdf_query_host(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* xyz, size_t n, double* out) {
     HPSDF_TRY
     if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "a device context is required");
     if (!t || (!xyz && n) || (!out && n)) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    if (n <= kHostQueryPoints && smallQueriesOnHost()) {  // a scalar Query(pt): ~0.1 us here, ~15 us as a launch (host_query.cpp)
+        for (size_t i = 0; i < n; ++i) out[i] = hostQueryPoint(*t, xyz + 3 * i);
+        return HPSDF_OK;
+    }
     return hostRoundTrip(
         ctx, xyz, n, out,
         [](hpsdf_ctx* c, const void* o, const double* d, size_t m, double* r) {
@@ -817,6 +851,10 @@ int hpsdf_query_gradient_host(hpsdf_ctx* ctx, const hpsdf_tree* t, const double*
     if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "a device context is required");
     if (!t || (n && (!xyz || !out || !grad))) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
     if (n == 0) return HPSDF_OK;
+    if (n <= kHostQueryPoints && smallQueriesOnHost()) {
+        for (size_t i = 0; i < n; ++i) hostQueryPointWithGradient(*t, xyz + 3 * i, out + i, grad + 3 * i);
+        return HPSDF_OK;
+    }
     // rows of points outside the root keep what the caller passed in (the reference leaves its output untouched)
     HostArray arr[3] = {{xyz, nullptr, n * 3 * sizeof(double)}, {nullptr, out, n * sizeof(double)}, {grad, grad, n * 3 * sizeof(double)}};
     return hostCall(ctx, arr, 3, [&] {
@@ -1430,12 +1468,17 @@ static int benchFit(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* 
     const uint64_t nc = T.coeffCount[degree];
     const int nrows = (int)nc;
     FitShape shape = fitShape(degree, nrows, (uint32_t)std::min<uint64_t>(nCells, 0xFFFFFFFFull), false);
-    bool fast = false;
+    bool fast = false, split = false;
     {
         FieldDev probe;
-        if (ctx->fastFit && makeFieldDev(field, nullptr, &probe) == HPSDF_OK && fitMfmaSupports(degree, probe)) fast = true;
+        if (ctx->fitMode == HPSDF_FIT_FAST && makeFieldDev(field, nullptr, &probe) == HPSDF_OK && fitMfmaSupports(degree, probe)) fast = true;
+        // the default: top-degree rows exact, the rows below them on the matrix cores from the samples the exact kernel leaves
+        if (ctx->fitMode == HPSDF_FIT_SPLIT && fitSplitSupports(degree, ctx->splitMinDegree) && innermost(field)->kind != kHostMesh) split = true;
     }
+    const uint64_t rowsTop = nc - (degree > 0 ? T.coeffCount[degree - 1] : 0);
     if (fast) shape = FitShape{kMfmaCells, 1, 1, 0};  // the matrix-core fit: one workgroup per 16-cell tile
+    if (split) shape = fitShape(degree, (int)rowsTop, (uint32_t)std::min<uint64_t>(nCells, 0xFFFFFFFFull), false);
+    const uint64_t nq3 = (4 * (uint64_t)degree + 1) * (4 * (uint64_t)degree + 1) * (4 * (uint64_t)degree + 1);
     const int g = shape.cells, planes = shape.planes;
     std::vector<FitTask> tasks(nCells);
     const uint64_t side = 1ull << depth;
@@ -1449,6 +1492,7 @@ static int benchFit(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* 
         for (int a = 0; a < 3; ++a) t.bmax[a] = t.bmin[a] + h;
         t.outOff = i * nc;
         t.copyOff = ~0ull;
+        t.sampleOff = i * nq3;
         t.errSlot = (uint32_t)i;
         t.depth = (uint8_t)depth;
     }
@@ -1461,19 +1505,21 @@ static int benchFit(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* 
         fb.degree = (uint8_t)degree;
         fb.planesPerChunk = (uint8_t)planes;
         fb.depth = (uint8_t)depth;
-        fb.rowStart = 0;
+        fb.rowStart = (uint16_t)(split ? nc - rowsTop : 0);
         fb.rowEnd = (uint16_t)nc;
+        fb.split = split ? 1 : 0;
         blocks.push_back(fb);
     }
     FitTask* dT = nullptr;
     FitBlock* dB = nullptr;
-    double *dA = nullptr, *dE = nullptr;
+    double *dA = nullptr, *dE = nullptr, *dS = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = HPSDF_OK;
     hipError_t e = hipMalloc((void**)&dT, tasks.size() * sizeof(FitTask));
     if (e == hipSuccess) e = hipMalloc((void**)&dB, blocks.size() * sizeof(FitBlock));
     if (e == hipSuccess) e = hipMalloc((void**)&dA, nCells * nc * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&dE, nCells * sizeof(double));
+    if (e == hipSuccess && split) e = hipMalloc((void**)&dS, nCells * nq3 * sizeof(double));
     if (e == hipSuccess) e = hipMemcpy(dT, tasks.data(), tasks.size() * sizeof(FitTask), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(dB, blocks.data(), blocks.size() * sizeof(FitBlock), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipEventCreate(&e0);
@@ -1486,10 +1532,14 @@ static int benchFit(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* 
         rm.centre[a] = (double)((cfg->root_min[a] + cfg->root_max[a]) / 2.0f);
     }
     const size_t lds = shape.ldsBytes;
+    if (split) fd.samples = dS;
     if (e == hipSuccess && rc == HPSDF_OK) {
         auto launch = [&]() {
-            return fast ? launchFitMfma(ctx->stream, degree, dB, (uint32_t)blocks.size(), dT, dA, dE, ctx->dTables, fd, rm)
-                        : launchFit(ctx->stream, degree, shape.cellsPerThread, dB, (uint32_t)blocks.size(), lds, dT, dA, dE, nullptr, ctx->dTables, fd, rm);
+            if (fast) return launchFitMfma(ctx->stream, degree, dB, (uint32_t)blocks.size(), dT, dA, dE, ctx->dTables, fd, rm);
+            hipError_t le = launchFit(ctx->stream, degree, shape.cellsPerThread, dB, (uint32_t)blocks.size(), lds, dT, dA, dE, nullptr, ctx->dTables, fd, rm);
+            if (le == hipSuccess && split)
+                le = launchFitMfmaLow(ctx->stream, degree, dT, nullptr, 0u, (uint32_t)nCells, 0u, dA, ctx->dTables, dS, rm);
+            return le;
         };
         e = launch();  // warm-up
         if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
@@ -1508,6 +1558,7 @@ static int benchFit(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* 
     (void)hipFree(dB);
     (void)hipFree(dA);
     (void)hipFree(dE);
+    if (dS) (void)hipFree(dS);
     if (rc) return rc;
     if (e != hipSuccess) return hipFail(e, "bench_fit");
     return HPSDF_OK;

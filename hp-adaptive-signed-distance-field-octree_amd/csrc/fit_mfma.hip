@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
 
 #include "device_types.hpp"
 #include "field_eval.hpp"
@@ -37,7 +39,9 @@ __host__ __device__ constexpr int mfmaCoef(int p) { return p == 6 ? 83 : (p + 1)
 // instructions -- B elements of the NEXT step (three LDS reads, two multiplications per tile) and the next A element are
 // formed while the matrix pipe works through this step's TN instructions (64 cycles each): the scheduler is told to deal
 // them out one MFMA, one tile's worth of LDS reads and VALU work at a time.
-template <int KIND, int TN, int KW>
+// LOW: the rows below the top degree of a split fit (FitBlock::split, device_types.hpp) -- the cells of a tile may differ in depth
+// (the normalisation is looked up per cell), and no error is formed: the top-degree rows, which alone enter it, are fit_kernel's.
+template <int KIND, int TN, int KW, bool LOW = false>
 __device__ __forceinline__ void mfmaContract(const FitBlock& blk, const FitTask* __restrict__ tasks, double* __restrict__ arena,
                                              double* __restrict__ errs, const DeviceTables* __restrict__ T, const FieldDev& field,
                                              const RootMap& rm, const double* sT, const double* sR, const double* sW, const double* sNl,
@@ -167,13 +171,20 @@ __device__ __forceinline__ void mfmaContract(const FitBlock& blk, const FitTask*
             for (int q = 0; q < 4; ++q) {
                 const int c2 = (lane >> 4) + 4 * q;
                 if (c2 < G) {
-                    const double v = sRed[(t * 4 + q) * 64 + lane] * nrm;
-                    arena[tasks[blk.firstTask + c2].outOff + (uint64_t)(r - rowStart)] = v;
+                    const FitTask& tc = tasks[blk.firstTask + c2];
+                    double nc = nrm;
+                    if constexpr (LOW) {
+                        const int dc = tc.depth;
+                        nc = sNl[ia * 11 + dc] * sNl[ib * 11 + dc] * sNl[ic * 11 + dc];
+                    }
+                    const double v = sRed[(t * 4 + q) * 64 + lane] * nc;
+                    arena[tc.outOff + (uint64_t)(r - rowStart)] = v;
                     if (top) e4[q] += v * v;
                 }
             }
         }
     }
+    if constexpr (LOW) return;
     // error: over the 16 lanes of a row group, then over the waves (through LDS, wave order)
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -239,6 +250,48 @@ __global__ __launch_bounds__(64 * MfmaWaves<DEG>::value) void fit_mfma_kernel(co
         mfmaContract<KIND, NTI, KW>(blk, tasks, arena, errs, T, field, rm, sT, sR, sW, sNl, sRed);
 }
 
+// The rows below the top degree of the split fits of degree DEG (the default for from-scratch fits of degree >= 4): tasks
+// [range[0], range[0] + range[1]) are from-scratch fits of degree DEG in any mix of depths, 16 to a workgroup; their field values
+// are in the sample buffer (fit_kernel wrote them back while it fitted the top-degree rows, or the mesh sampler put them there);
+// rows [0, ncoef(DEG - 1)) go to the start of every task's array.  No FitBlock list: a tile is 16 consecutive tasks.
+template <int DEG>
+__global__ __launch_bounds__(64 * MfmaWaves<DEG>::value) void fit_mfma_low_kernel(const FitTask* __restrict__ tasks, double* __restrict__ arena,
+                                                                                    const DeviceTables* __restrict__ T, FieldDev field, RootMap rm,
+                                                                                    const uint32_t* __restrict__ range, uint32_t first, uint32_t count) {
+    constexpr int NTL = (mfmaCoef(DEG - 1) + 15) / 16;
+    constexpr int NQ = 4 * DEG + 1, KW = MfmaWaves<DEG>::value;
+    __shared__ double sT[(DEG + 2) * NQ];
+    __shared__ double sR[NQ], sW[NQ];
+    __shared__ double sNl[13 * 11];
+    __shared__ double sRed[NTL * 4 * 64];
+    if (range != nullptr) first = range[0], count = range[1];
+    if (blockIdx.x * (uint32_t)kMfmaCells >= count) return;
+    FitBlock blk;
+    blk.firstTask = first + blockIdx.x * (uint32_t)kMfmaCells;
+    blk.nTasks = (uint16_t)(count - blockIdx.x * (uint32_t)kMfmaCells < (uint32_t)kMfmaCells ? count - blockIdx.x * (uint32_t)kMfmaCells : (uint32_t)kMfmaCells);
+    blk.degree = DEG, blk.planesPerChunk = 1;
+    blk.rowStart = 0, blk.rowEnd = (uint16_t)mfmaCoef(DEG - 1);
+    blk.depth = 0, blk.weighted = 0, blk.split = 0, blk.pad1[0] = 0;
+    const int tid = threadIdx.x;
+    constexpr int gl = NQ * (NQ - 1) / 2;
+    for (int i = tid; i < 13 * 11; i += 64 * KW) sNl[i] = (&T->nl[0][0])[i];
+    for (int q = tid; q < NQ; q += 64 * KW) {
+        const double x = T->roots[gl + q];
+        sR[q] = x;
+        sW[q] = T->weights[gl + q];
+        double m2 = 0.0, m1 = 1.0;
+        sT[q] = 1.0;
+        for (int i = 1; i <= DEG; ++i) {
+            const double l = T->rec[i][0] * x * m1 - T->rec[i][1] * m2;
+            m2 = m1, m1 = l;
+            sT[i * NQ + q] = l;
+        }
+        sT[(DEG + 1) * NQ + q] = 0.0;
+    }
+    __syncthreads();
+    mfmaContract<kFieldSamples, NTL, KW, true>(blk, tasks, arena, nullptr, T, field, rm, sT, sR, sW, sNl, sRed);
+}
+
 template <int KIND>
 void launchMfmaT(hipStream_t stream, int degree, const FitBlock* dBlocks, uint32_t nBlocks, const FitTask* dTasks, double* dArena, double* dErrs,
                  const DeviceTables* dTables, const FieldDev& field, const RootMap& rm, const uint32_t* dRange) {
@@ -282,6 +335,51 @@ hipError_t launchFitMfma(hipStream_t stream, int degree, const FitBlock* dBlocks
         launchMfmaT<kFieldAnalytic>(stream, degree, dBlocks, nBlocks, dTasks, dArena, dErrs, dTables, field, rm, dRange);
     else
         launchMfmaT<kFieldSamples>(stream, degree, dBlocks, nBlocks, dTasks, dArena, dErrs, dTables, field, rm, dRange);
+    return hipGetLastError();
+}
+
+// Rows [0, ncoef(degree - 1)) of the split fits of `degree` (4..11) from the sample buffer; the tasks are [dRange[0], +dRange[1]) when
+// dRange is given (device-written; the grid then covers maxTasks), else [first, first + count).
+// From which degree a from-scratch fit is split by default (a context's splitMinDegree starts with this).  Measured (16 384 cells,
+// union3 field, profiles/r04_split_fit.txt): the two kernels sample the field once (the exact one writes the values back) but the exact
+// kernel's per-sample work outside the contraction -- index arithmetic, the field, the weights -- is paid for 37 % of the rows at
+// degree 5 instead of all of them: degree 4 1.05 -> 1.23 ms, 5: 2.22 -> 2.37 (slower), 6: 5.93 -> 5.00, 7: 12.05 -> 8.79,
+// 8: 26.85 -> 15.41 ms.  HPSDF_SPLIT_MIN_DEGREE overrides the default (4..12; 12 = never); hpsdf_ctx_set_split_min_degree a context's.
+int fitSplitDefaultMinDegree() {
+    static const int v = [] {
+        int d = 6;
+        if (const char* e = std::getenv("HPSDF_SPLIT_MIN_DEGREE")) d = std::atoi(e);
+        return d < 4 ? 4 : (d > 12 ? 12 : d);
+    }();
+    return v;
+}
+bool fitSplitSupports(int degree, int minDegree) { return degree >= (minDegree < 4 ? 4 : minDegree) && degree <= 11; }
+hipError_t launchFitMfmaLow(hipStream_t stream, int degree, const FitTask* dTasks, const uint32_t* dRange, uint32_t first, uint32_t count,
+                            uint32_t maxTasks, double* dArena, const DeviceTables* dTables, const double* dSamples, const RootMap& rm) {
+    const uint32_t n = dRange ? maxTasks : count;
+    if (n == 0) return hipSuccess;
+    if (!fitSplitSupports(degree, 4) || dSamples == nullptr) return hipErrorInvalidValue;
+    FieldDev fd;
+    std::memset(&fd, 0, sizeof fd);
+    fd.kind = kFieldSamples, fd.csgOp = -1, fd.samples = dSamples;
+    const unsigned grid = (n + (uint32_t)kMfmaCells - 1u) / (uint32_t)kMfmaCells;
+#define HPSDF_LOW_CASE(D)                                                                                                                  \
+    case D:                                                                                                                                \
+        hipLaunchKernelGGL((fit_mfma_low_kernel<D>), dim3(grid), dim3(64 * MfmaWaves<D>::value), 0, stream, dTasks, dArena, dTables, fd, rm, \
+                           dRange, first, count);                                                                                          \
+        break;
+    switch (degree) {
+        HPSDF_LOW_CASE(4)
+        HPSDF_LOW_CASE(5)
+        HPSDF_LOW_CASE(6)
+        HPSDF_LOW_CASE(7)
+        HPSDF_LOW_CASE(8)
+        HPSDF_LOW_CASE(9)
+        HPSDF_LOW_CASE(10)
+        HPSDF_LOW_CASE(11)
+        default: break;
+    }
+#undef HPSDF_LOW_CASE
     return hipGetLastError();
 }
 

@@ -75,6 +75,8 @@ struct FrHdr {
     uint32_t nLeaves, arrive;
     uint32_t degBlocks[13][2];  // {first block, count} per degree: the range a fit launch walks
     uint32_t degTasks[13][2];   // {first task, count} per degree: the range a mesh-sampler launch walks
+    uint32_t lowTasks[13][2];   // {first task, count} per degree: the from-scratch fits that are split (FitBlock::split), i.e. the
+                                // range fit_mfma_low_kernel walks for the rows below the top degree
     uint64_t arenaUsed, sampleUsed, nCoeffs, pad1;
     uint64_t jobs, pRefines, hRefines, dropped, fits, samples;
     double total, target;
@@ -145,6 +147,7 @@ struct FrDev {
     double* pack;          // [world][packStride] all-gathered pack buffers (this rank writes its own)
     uint64_t packStride;
     int32_t fastFit;       // degrees >= 4 fitted by fit_mfma.hip: 16 cells per workgroup
+    int32_t splitFit;      // 0, or the lowest degree (.. 11) whose from-scratch fits are split: top-degree rows exact, the rest by fit_mfma_low_kernel
     // nearness weighting (Octree.cpp:1071-1092, 1209-1247): a fit keeps ONE full coefficient array (an incremental fit
     // carries the old rows over, :847), fit_weight_kernel leaves |mean FApprox| of every fit in `means`, the host turns
     // the means into weights with its libm (pow / exp: what the oracle calls) and fr_weigh_kernel scales the errors
@@ -161,11 +164,15 @@ __host__ __device__ inline size_t frLds(int degree, int g, int planes) {  // = f
     return ((size_t)(degree + 1) * nq + 2 * nq + 8 * (size_t)g + (size_t)g * planes * nq * nq) * sizeof(double);
 }
 // workgroup shape of `count` fits of one class: what fitShape (kernels.hip) gives an unweighted, sampled-or-analytic fit
-__host__ __device__ inline void frShape(int degree, bool incr, uint32_t count, int* cells, int* planes, bool fast = false, bool weighted = false) {
+// splitFit: 0 = off, else the lowest degree whose from-scratch fits are split (the context's splitMinDegree)
+__host__ __device__ inline bool frSplit(int splitFit, int degree, bool incr) { return splitFit > 0 && !incr && degree >= splitFit && degree <= 11; }
+__host__ __device__ inline void frShape(int degree, bool incr, uint32_t count, int* cells, int* planes, bool fast = false, bool weighted = false,
+                                        int split = 0) {
     if (fast && degree >= 4 && degree <= 11) {  // the matrix-core fit: one workgroup = one tile of 16 cells
         *cells = kMfmaCells, *planes = 1;
         return;
     }
+    if (frSplit(split, degree, incr)) incr = true;  // the exact kernel fits the top-degree rows only: the shape of an incremental fit
     const int nrows = incr ? (int)(frCoef(degree) - frCoef(degree - 1)) : (int)frCoef(degree);
     int gmax = nrows > kFitBlockThreads ? 1 : kFitBlockThreads / nrows;
     while (gmax > 1 && frLds(degree, gmax, 1) > kFitMaxLdsBytes) --gmax;
@@ -578,7 +585,7 @@ __global__ __launch_bounds__(1024) void fr_batch_kernel(FrDev d) {
         if (myCount) {
             const int deg = (int)tid / kFrDepths / 2;
             const bool incr = ((int)tid / kFrDepths) & 1;
-            frShape(deg, incr, myCount, &g, &pl, d.fastFit != 0, d.weighted != 0);
+            frShape(deg, incr, myCount, &g, &pl, d.fastFit != 0, d.weighted != 0, d.splitFit);
             myBlocks = (myCount + (uint32_t)g - 1u) / (uint32_t)g;
             const uint64_t nq = 4 * (uint64_t)deg + 1;
             // (a weighted fit owns a full array: the incremental one too)
@@ -620,6 +627,9 @@ __global__ __launch_bounds__(1024) void fr_batch_kernel(FrDev d) {
         const uint32_t t0 = lo ? sCnt[lo - 1] : 0u, b0 = lo ? sBlk[lo - 1] : 0u;
         h->degTasks[tid][0] = t0, h->degTasks[tid][1] = sCnt[hi] - t0;
         h->degBlocks[tid][0] = b0, h->degBlocks[tid][1] = sBlk[hi] - b0;
+        // the from-scratch classes of a degree come first (frClass): their tasks are one contiguous run
+        h->lowTasks[tid][0] = t0;
+        h->lowTasks[tid][1] = frSplit(d.splitFit, (int)tid, false) ? sCnt[lo + kFrDepths - 1] - t0 : 0u;
     }
     if (tid == 0) {
         const uint32_t t = sCnt[kFrClasses - 1], b = sBlk[kFrClasses - 1];
@@ -709,11 +719,13 @@ __global__ __launch_bounds__(256) void fr_tasks_kernel(FrDev d) {
         fb.nTasks = (uint16_t)(left < g ? left : g);
         fb.degree = (uint8_t)deg;
         fb.planesPerChunk = R->cPlanes[c];
-        fb.rowStart = (uint16_t)(incr ? frCoef(deg - 1) : 0);
+        const bool split = frSplit(d.splitFit, deg, incr);
+        fb.rowStart = (uint16_t)((incr || split) ? frCoef(deg - 1) : 0);
         fb.rowEnd = (uint16_t)frCoef(deg);
         fb.depth = (uint8_t)(c % kFrDepths);
         fb.weighted = d.weighted ? 1 : 0;
-        fb.pad1[0] = fb.pad1[1] = 0;
+        fb.split = split ? 1 : 0;
+        fb.pad1[0] = 0;
         d.blocks[b] = fb;
     }
 }
@@ -1633,7 +1645,9 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
     ws->d.K = Kj;
     ws->d.rank = rank, ws->d.world = world;
     ws->d.weighted = weighted ? 1 : 0;
-    ws->d.fastFit = (ctx->fastFit && field->kind != kHostTreeCsg && !weighted) ? 1 : 0;
+    ws->d.fastFit = (ctx->fitMode == HPSDF_FIT_FAST && field->kind != kHostTreeCsg && !weighted) ? 1 : 0;
+    const bool splitMode = ctx->fitMode == HPSDF_FIT_SPLIT && !weighted;
+    ws->d.splitFit = 0;
     ws->d.errStride = kFrJobs * HPSDF_JOB_HEADER_DOUBLES + kFrStatusPad;
     {
         const hipError_t e = ws->ensureRanks(world, s);
@@ -1871,11 +1885,19 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         // capacities for this round (the device flags what the host failed to foresee; it cannot happen by these bounds)
         hipError_t e = ws->ensureNodes(knownNodes + 8u * Kj, s);
         if (e == hipSuccess) e = ws->ensureArena(knownArena + (uint64_t)Kj * rowsPerJob((int)knownMaxDeg), knownArena, s);
-        if (e == hipSuccess && mesh) {
+        // split fits (the default for from-scratch fits of degree >= 4) hand their field values to the matrix-core kernel through the
+        // sample buffer, which mesh fields use anyway; a round whose samples would not fit 16 GB is fitted exactly throughout
+        bool splitRound = splitMode && (int)knownMaxDeg >= ctx->splitMinDegree;
+        if (e == hipSuccess && (mesh || splitRound)) {
             const uint64_t need = (uint64_t)Kj * samplesPerJob((int)knownMaxDeg);
-            if (need > (1ull << 31)) return fail(HPSDF_ERR_UNSUPPORTED, "round too large for the sampled mesh path");
-            e = ws->ensureSamples(need, s);
+            if (need > (1ull << 31)) {
+                if (mesh) return fail(HPSDF_ERR_UNSUPPORTED, "round too large for the sampled mesh path");
+                splitRound = false;
+            } else {
+                e = ws->ensureSamples(need, s);
+            }
         }
+        d.splitFit = splitRound ? std::max(4, ctx->splitMinDegree) : 0;
         if (e != hipSuccess) return hipFail(e, "frontier buffers");
         hipLaunchKernelGGL(fr_select_kernel, dim3(std::min<uint32_t>(512u, (knownNodes + 255u) / 256u)), dim3(256), 0, s, d);
         hipLaunchKernelGGL(fr_batch_kernel, dim3(1), dim3(1024), 0, s, d);
@@ -1890,6 +1912,8 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
                                                 rm, ws->samples));
             fdr.kind = kFieldSamples;
             fdr.samples = ws->samples;
+        } else if (splitRound) {
+            fdr.samples = ws->samples;  // (the exact kernel writes the field values of split fits there)
         }
         // One launch for every degree of the round (kernels.hip fit_multi_kernel); the matrix-core fit and
         // HPSDF_FRONTIER_SPLIT_FITS=1 keep one launch per degree, side by side on three streams.
@@ -1922,6 +1946,9 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
                 HPSDF_HIP(hipEventRecord(ws->joinEv[k], ws->side[k]));
                 HPSDF_HIP(hipStreamWaitEvent(s, ws->joinEv[k], 0));
             }
+        if (splitRound)  // the rows below the top degree of the split fits, from the samples the exact kernel left (H children: degree <= knownMaxDeg)
+            for (int deg = std::max(4, ctx->splitMinDegree); deg <= (int)std::min<uint32_t>(knownMaxDeg, 11u); ++deg)
+                HPSDF_HIP(launchFitMfmaLow(s, deg, d.tasks, &d.hdr->lowTasks[deg][0], 0u, 0u, 8u * Kj, ws->arena, ctx->dTables, ws->samples, rm));
         if (weighted) {
             size_t lds = 0;
             for (int deg = 2; deg <= degHi; ++deg) lds = std::max(lds, fitLdsTable[deg]);

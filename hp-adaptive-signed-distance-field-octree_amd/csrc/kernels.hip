@@ -1955,6 +1955,7 @@ __device__ __forceinline__ void fitBlockBody(const FitBlock blk, const FitTask* 
     const int gl = nq * (nq - 1) / 2;  // Legendre.h: rule n starts at n(n-1)/2 (:1016-1017)
     const int planes = blk.planesPerChunk;  // i-planes per chunk
     const int depth = blk.depth;            // every cell of the workgroup has this depth
+    const bool split = blk.split != 0;       // the top-degree rows of a from-scratch fit (device_types.hpp): outOff addresses row 0
 
     double* sT = lds;               // [deg+1][nq]  LpX(p, root_q)
     double* sR = sT + (deg + 1) * nq;  // [nq] roots
@@ -2074,7 +2075,13 @@ __device__ __forceinline__ void fitBlockBody(const FitBlock blk, const FitTask* 
             } else {
                 fv = activeS ? fieldEvalWorld<KIND, CSG>(field, wx, wy, wz, sidx, sNl, sRec, meshHint) : 0.0;
             }
-            if (activeS) sF[g * cellStride + rem] = c[6] * (sW[i] * (sW[j] * sW[k])) * fv;  // :1040
+            if (activeS) {
+                sF[g * cellStride + rem] = c[6] * (sW[i] * (sW[j] * sW[k])) * fv;  // :1040
+                // a split fit (FitBlock::split): the field's value goes (back) into the sample buffer, from where
+                // fit_mfma_low_kernel contracts the rows below the top degree
+                if constexpr (KIND != kFieldMesh)
+                    if (split) const_cast<double*>(field.samples)[sidx] = fv;
+            }
         }
         __syncthreads();
         // ---- phase 2: accumulate the chunk, planes ascending (:1043-1053)
@@ -2128,16 +2135,17 @@ __device__ __forceinline__ void fitBlockBody(const FitBlock blk, const FitTask* 
     // earlier fit of the cell put them).  Weighted fits keep one full array per cell: outOff addresses row 0.
     const bool weighted = blk.weighted != 0;
     const int stashStride = weighted ? rowEnd : nrows, stashBase = weighted ? 0 : rowStart;
+    const int outBase = split ? 0 : stashBase;  // (a split fit's array starts at row 0: the rows below rowStart come from the matrix cores)
     if (act0) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
             if (g2 + r < G) {
-                arena[tasks[blk.firstTask + g2 + r].outOff + (r0 - stashBase)] = acc[r];
+                arena[tasks[blk.firstTask + g2 + r].outOff + (r0 - outBase)] = acc[r];
                 sF[(g2 + r) * stashStride + (r0 - stashBase)] = acc[r];
             }
     }
     if (act1) {
-        arena[tasks[blk.firstTask].outOff + (r1 - stashBase)] = acc1;
+        arena[tasks[blk.firstTask].outOff + (r1 - outBase)] = acc1;
         sF[r1 - stashBase] = acc1;
     }
     if (weighted && rowStart > 0) {  // carry the old rows over (:847)

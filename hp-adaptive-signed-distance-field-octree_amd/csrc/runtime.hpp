@@ -76,7 +76,11 @@ struct hpsdf_ctx {
     hipStream_t stream = nullptr;
     bool ownsStream = false;
     hpsdf::DeviceTables* dTables = nullptr;
-    bool fastFit = false;  // hpsdf_ctx_set_fast_fit: degrees >= 4 on the matrix cores (fit_mfma.hip), not bit-identical
+    // hpsdf_ctx_set_fit_mode: how from-scratch fits of degree >= 4 run.  HPSDF_FIT_SPLIT (default): rows of top degree bit-exact, the
+    // rows below them on the matrix cores (errors and so every decision canonical); HPSDF_FIT_EXACT: every row bit-exact (the
+    // canonical bytes); HPSDF_FIT_FAST: every row of every fit of degree >= 4 on the matrix cores (errors within ~1e-15, ties may flip)
+    int fitMode = HPSDF_FIT_SPLIT;
+    int splitMinDegree = 6;  // HPSDF_FIT_SPLIT: from-scratch fits of this degree and above are split (hpsdf_ctx_set_split_min_degree)
     hpsdf::Workspace ws;
     // Scratch of the *_host entry points (host arrays in, host arrays out): one device buffer and one pinned buffer,
     // kept across calls -- a scalar Query(pt) through the C++ drop-in must not pay two hipMalloc/hipFree pairs.
@@ -108,6 +112,10 @@ struct hpsdf_tree {
     int maxDegree = 0, maxDepth = 0;
     bool allInline = false;  // every leaf sits in the top table with degree <= 2: query_kernel serves it
     hpsdf_config config{};
+    // the block's node array and packed coefficients as uploaded: calls of a few points are answered from them on the calling
+    // thread (host_query.cpp), with the kernels' statements in the kernels' order
+    std::vector<hpsdf_node> hNodes;
+    std::vector<double> hCoeffs;
 };
 
 enum HostFieldKind { kHostAnalytic = 0, kHostCallback = 1, kHostMesh = 2, kHostTreeCsg = 3 };
@@ -147,6 +155,11 @@ int hipFail(hipError_t e, const char* what);
         hipError_t e_ = (call);                                   \
         if (e_ != hipSuccess) return ::hpsdf::hipFail(e_, #call); \
     } while (0)
+
+// Query / QueryWithGradient of one point on the calling thread (host_query.cpp): the kernels' values bit for bit
+constexpr size_t kHostQueryPoints = 32;  // calls of up to this many points never reach the device
+double hostQueryPoint(const hpsdf_tree& t, const double* xyz);
+void hostQueryPointWithGradient(const hpsdf_tree& t, const double* xyz, double* out, double* grad);
 
 // innermost non-CSG field and the FieldDev the kernels take
 const hpsdf_field* innermost(const hpsdf_field* f);

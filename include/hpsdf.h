@@ -108,12 +108,27 @@ HPSDF_API int hpsdf_ctx_create(int device, void* stream, hpsdf_ctx** out);
 HPSDF_API int hpsdf_ctx_destroy(hpsdf_ctx* ctx);
 HPSDF_API int hpsdf_ctx_set_stream(hpsdf_ctx* ctx, void* stream);
 HPSDF_API int hpsdf_ctx_synchronize(hpsdf_ctx* ctx);
-/* Opt-in fast fit (default off).  on != 0: cell fits of degree >= 4 (Octree::FitPolynomial, Octree.cpp:1007-1093) run as
- * a GEMM on the matrix cores (v_mfma_f64_16x16x4_f64; csrc/fit_mfma.hip) instead of the term-by-term kernel that
- * reproduces the reference's summation order.  Coefficients then agree with the default path to ~1e-15 relative -- far
- * inside 1e-6 -- but are NOT bit-identical to it, and refinement decisions that are exact ties in the default arithmetic
- * may fall the other way.  Applies to unweighted builds of analytic, mesh and callback fields; everything
- * else keeps the default kernel. */
+/* How cell fits of degree >= 4 (Octree::FitPolynomial, Octree.cpp:1007-1093) use the matrix cores (v_mfma_f64_16x16x4_f64;
+ * csrc/fit_mfma.hip).  A fit's returned error is the sum of squares of its rows of TOP total degree alone (:1062-1069), and the
+ * errors are all that selection, the P/H decision (:600-601) and the stop rule (:216) ever read.
+ *   HPSDF_FIT_SPLIT (default): a from-scratch fit of degree p >= 6 (hpsdf_ctx_set_split_min_degree) is cut in two -- the rows of total degree p by the term-by-term
+ *     kernel that reproduces the reference's summation order bit for bit, the rows below p as a GEMM on the matrix cores from the
+ *     same samples.  Incremental fits (all their rows are top-degree rows) stay exact.  Errors, topology, node array: identical
+ *     to HPSDF_FIT_EXACT by construction, no guard band; coefficients of rows below the top degree of leaves that were created by
+ *     a split at degree >= 6 agree with it to ~1e-17 absolute (not bit for bit).  Trees whose leaves never exceed degree 5 --
+ *     the BASELINE configs stop at 3 -- are byte-identical in both modes.  Weighted builds (the weight reads every row, :1209-1247) and
+ *     mesh fits that sample inside the fit kernel keep the exact kernel.
+ *   HPSDF_FIT_EXACT: every row by the bit-exact kernel: the canonical bytes (what the CPU oracle produces).
+ *   HPSDF_FIT_FAST: every row of every fit of degree >= 4 on the matrix cores.  Errors then agree to ~1e-15 relative only, and
+ *     refinement decisions that are exact ties in the reference's arithmetic may fall the other way.
+ * hpsdf_ctx_set_fast_fit(ctx, on) = set_fit_mode(on ? HPSDF_FIT_FAST : HPSDF_FIT_SPLIT).  The environment variable
+ * HPSDF_FIT_MODE=exact|split|fast sets the mode a new context starts with. */
+enum { HPSDF_FIT_EXACT = 0, HPSDF_FIT_SPLIT = 1, HPSDF_FIT_FAST = 2 };
+HPSDF_API int hpsdf_ctx_set_fit_mode(hpsdf_ctx* ctx, int mode);
+HPSDF_API int hpsdf_ctx_get_fit_mode(hpsdf_ctx* ctx, int* mode);
+/* HPSDF_FIT_SPLIT splits from-scratch fits from this degree on (4..12, 12 = never; default 6, or HPSDF_SPLIT_MIN_DEGREE when the
+ * context is created): below it the two-kernel form costs more than it saves (csrc/fit_mfma.hip, fitSplitDefaultMinDegree). */
+HPSDF_API int hpsdf_ctx_set_split_min_degree(hpsdf_ctx* ctx, int degree);
 HPSDF_API int hpsdf_ctx_set_fast_fit(hpsdf_ctx* ctx, int on);
 HPSDF_API void* hpsdf_ctx_stream(hpsdf_ctx* ctx);
 
@@ -390,7 +405,7 @@ HPSDF_API int hpsdf_bench_fit(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hps
                               int depth, uint64_t n_cells, int repeats, double* ms_per_launch);
 /* The same fits with their results: Octree::FitPolynomial (Octree.cpp:1007-1093) from scratch at `degree` for the first
  * n_cells cells of the depth-`depth` lattice over [-1/2, 1/2]^3 (x fastest): coeffs[n_cells][ncoef(degree)], errs[n_cells].
- * The kernel is the one a build would take: the bit-exact one, or the matrix-core one after hpsdf_ctx_set_fast_fit(1).
+ * The kernels are the ones a build would take in the context's fit mode (hpsdf_ctx_set_fit_mode).
  * What the fit known-answer tests compare with the oracle's FitPolynomial, degree by degree. */
 HPSDF_API int hpsdf_fit_cells(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* field, int degree, int depth,
                               uint64_t n_cells, double* coeffs, double* errs);

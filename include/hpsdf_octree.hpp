@@ -304,12 +304,14 @@ class Octree {
     }
     /// Jobs per round of the canonical schedule (K); part of the result's definition.
     void SetJobsPerRound(uint64_t k) { jobsPerRound_ = k; }
-    /// Additive, default off: fits of degree >= 4 on the matrix cores (hpsdf_ctx_set_fast_fit) -- within ~1e-15 of the
-    /// default path but not bit-identical to it.
-    void SetFastFit(bool on) {
+    /// Additive: how fits of degree >= 4 use the matrix cores (hpsdf_ctx_set_fit_mode).  Default HPSDF_FIT_SPLIT: errors, decisions and
+    /// topology are those of the bit-exact path by construction, the rows below a from-scratch fit's top degree agree with it to
+    /// ~1e-17; HPSDF_FIT_EXACT: every row bit-exact; HPSDF_FIT_FAST (= SetFastFit(true)): every row on the matrix cores.
+    void SetFitMode(int mode) {
         ensureCtx();
-        check(hpsdf_ctx_set_fast_fit(ctx_, on ? 1 : 0));
+        check(hpsdf_ctx_set_fit_mode(ctx_, mode));
     }
+    void SetFastFit(bool on) { SetFitMode(on ? HPSDF_FIT_FAST : HPSDF_FIT_SPLIT); }
     /// Additive: Create() over `world` GPUs of one node -- one Octree per GPU (SetDevice), every rank calls Create with
     /// the same config and field; `gather` is the in-place all-gather of hpsdf_create_distributed (for RCCL:
     /// hpsdf_rccl::AllGather with an hpsdf_rccl::Comm as `user`, include/hpsdf_rccl.hpp).  Every rank ends with the

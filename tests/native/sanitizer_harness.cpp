@@ -32,6 +32,9 @@ hipError_t launchPack(hipStream_t, const PackItem*, uint32_t, const double*, dou
 hipError_t launchFitWeight(hipStream_t, const FitBlock*, uint32_t, size_t, const FitTask*, const double*, double*, const DeviceTables*, const uint32_t*) { return hipErrorNoDevice; }
 hipError_t launchFitMfma(hipStream_t, int, const FitBlock*, uint32_t, const FitTask*, double*, double*, const DeviceTables*, const FieldDev&,
                          const RootMap&, const uint32_t*) { return hipErrorNoDevice; }
+bool fitSplitSupports(int, int) { return false; }
+hipError_t launchFitMfmaLow(hipStream_t, int, const FitTask*, const uint32_t*, uint32_t, uint32_t, uint32_t, double*, const DeviceTables*, const double*,
+                            const RootMap&) { return hipErrorNoDevice; }
 hipError_t launchCgIterations(hipStream_t, const CgDev&, int, int) { return hipErrorNoDevice; }
 hipError_t launchCgStart(hipStream_t, const CgDev&) { return hipErrorNoDevice; }
 hipError_t launchCgFinish(hipStream_t, const CgDev&) { return hipErrorNoDevice; }

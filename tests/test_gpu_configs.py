@@ -731,6 +731,67 @@ def test_fast_fit_within_tolerance_of_oracle(H, O, name, target):
     fast.close()
 
 
+@pytest.mark.parametrize("name,target,K", [("union3", 1e-8, 1024), ("sphere", 1e-9, 1024), ("union3", 1e-7, 256)])
+def test_split_fit_keeps_errors_and_topology_canonical(H, O, ctx, name, target, K, monkeypatch):
+    """The default fit mode (HPSDF_FIT_SPLIT), made to split from degree 4 so that these trees have split fits at all (the default
+    threshold is 6): a from-scratch fit's rows of top degree come from the bit-exact kernel, the rows below them from the matrix
+    cores.  Only the top rows enter a fit's error (Octree.cpp:1062-1069) and only errors are read by selection, the P/H decision
+    (:600-601) and the stop rule (:216) -- so the node array, the statistics (total error included) and every coefficient of top
+    degree equal the ORACLE's bit for bit with no guard band, and the other coefficients agree to 1e-12.  The host scheduler, the
+    device-side frontier and two sharded ranks give the same bytes as each other."""
+    from helpers import oracle_field, product_field
+    split = H.Context(0)
+    split.set_split_min_degree(4)
+    blk, st = H.create_block(split, H.make_config(target), product_field(H, name), K)
+    want = O.Tree.create(O.default_config(target), oracle_field(O, name), K).to_block()
+    a, b = O.parse_block(blk), O.parse_block(want)
+    nc = len(a["coeffs"])
+    assert len(blk) == len(want) and blk[8 + 8 * nc:] == want[8 + 8 * nc:]       # node array and Config: byte for byte
+    assert np.abs(a["coeffs"] - b["coeffs"]).max() <= 1e-12
+    exact = H.Context(0)
+    exact.set_fit_mode(H.FIT_EXACT)
+    eb, est = H.create_block(exact, H.make_config(target), product_field(H, name), K)
+    assert eb == want and est == st                                              # (statistics: jobs, rounds, fits, total error)
+    if name == "union3" and target == 1e-8:
+        assert blk != want and a["degree"][a["degree"] != 13].max() >= 4         # the matrix cores did produce rows
+    monkeypatch.setenv("HPSDF_HOST_FRONTIER", "1")
+    assert H.create_block(split, H.make_config(target), product_field(H, name), K)[0] == blk
+    monkeypatch.setenv("HPSDF_HOST_FRONTIER", "0")
+    pts = O.splitmix64_points(50000, seed=13)
+    assert np.abs(H.DeviceTree(split, blk).query(pts) - H.DeviceTree(split, want).query(pts)).max() <= 1e-12
+    split.close(), exact.close()
+
+
+def test_split_fit_sharded_and_sampled_fields(H, O, ctx):
+    """Split fits where the samples come from somewhere else: a mesh field (the BVH sampler's buffer), and two simulated ranks
+    (every rank splits its own slice): same bytes as one rank in the same mode; node arrays equal the exact mode's."""
+    verts, tris = _mesh()
+    cfg = H.make_config(1e-7, *MESH_ROOT)
+
+    def mk(mode_ctx):
+        mode_ctx.set_split_min_degree(4)
+        return H.Field.mesh(mode_ctx, verts, tris)
+    split, exact = H.Context(0), H.Context(0)
+    exact.set_fit_mode(H.FIT_EXACT)
+    sb, sst = H.create_block(split, cfg, mk(split), 256)
+    eb, est = H.create_block(exact, cfg, H.Field.mesh(exact, verts, tris), 256)
+    a, b = O.parse_block(sb), O.parse_block(eb)
+    nc = len(a["coeffs"])
+    assert sb[8 + 8 * nc:] == eb[8 + 8 * nc:] and sst == est and a["degree"][a["degree"] != 13].max() >= 4
+    assert np.abs(a["coeffs"] - b["coeffs"]).max() <= 1e-12 and sb != eb
+
+    import threading  # two ranks, each a context in split mode from degree 4
+    ucfg = H.make_config(1e-8)
+    one, _ = H.create_block(split, ucfg, H.Field.union3(), 1024)
+
+    def make_field(c):
+        c.set_split_min_degree(4)
+        return H.Field.union3()
+    for blk, s in _create_on_simulated_ranks(H, 2, ucfg, make_field, 1024):
+        assert blk == one
+    split.close(), exact.close()
+
+
 def test_fast_fit_on_a_sampled_field(H, O, ctx):
     """The fast fit on a sampled field (mesh: samples from the BVH kernel; host callbacks take the same kernel)."""
     fast = H.Context(0)

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from conftest import bits
-from helpers import (oracle_field, product_field, query_points, edge_points, synthetic_block, icosphere, displaced_torus, sha)
+from helpers import (oracle_field, product_field, query_points, edge_points, synthetic_block, deep_chain_block, icosphere, displaced_torus, sha)
 
 pytestmark = pytest.mark.gpu
 DBL_MAX = np.finfo(np.float64).max
@@ -211,6 +211,41 @@ def test_query_few_points_bitwise(H, O, ctx, golden, case):
         assert np.all(gg[~inside] == 7.0)
 
 
+def test_scalar_calls_answered_on_the_host_equal_the_kernels(H, O, ctx, golden):
+    """Calls of up to 32 points (a scalar Octree::Query(pt), Octree.cpp:662-702; the loops of HPUnitTests.cpp:64-75) are evaluated
+    on the calling thread from the tree handle's copy of the block (csrc/host_query.cpp): the kernels' statements in the kernels'
+    order, so the same bits as the batched kernel, as query_few_kernel (calls of 33..256 points) and as the oracle --
+    point by point over the edge-point set (cell faces, mid-planes, the root's boundary, outside points, NaN), on refined trees
+    and on synthetic trees with leaves of every degree 0..12 down to depth 10, values and gradients."""
+    rng = np.random.default_rng(3)
+    g = golden["blocks"]["A1_union3_1e-7_K1024"]
+    blocks = [H.create_block(ctx, H.make_config(g["target"], g["root_min"], g["root_max"]), product_field(H, g["field"]), g["K"])[0],
+              synthetic_block(rng, list(range(13)) * 2, depth=2), deep_chain_block(rng)]
+    for blk in blocks:
+        tree, otree = H.DeviceTree(ctx, blk), O.Tree.from_block(blk)
+        pts = np.concatenate([O.splitmix64_points(500, seed=9), edge_points(np.random.default_rng(5), 1500),
+                              np.array([[np.nan, 0.0, 0.0], [0.1, np.inf, 0.0], [0.5, 0.5, 0.5], [-0.5, -0.5, -0.5]])])
+        want = otree.query(pts)
+        big = tree.query(pts)                                           # batched kernels
+        assert np.array_equal(bits(big), bits(want))
+        one = np.concatenate([tree.query(pts[i:i + 1]) for i in range(len(pts))])   # host, one point a call
+        assert np.array_equal(bits(one), bits(big))
+        some = np.concatenate([tree.query(pts[i:i + 32]) for i in range(0, len(pts), 32)])  # host, 32 a call
+        assert np.array_equal(bits(some), bits(big))
+        wv, wg = otree.query_with_gradient(pts)
+        init = np.full((len(pts), 3), 7.0)
+        gv = np.empty(len(pts))
+        gg = np.empty((len(pts), 3))
+        for i in range(0, len(pts), 5):
+            gv[i:i + 5], gg[i:i + 5] = tree.query_with_gradient(pts[i:i + 5], init[i:i + 5])
+        bv, bg = tree.query_with_gradient(pts, init)
+        assert np.array_equal(bits(gv), bits(bv)) and np.array_equal(bits(gg), bits(bg))
+        inside = wv < 1e300
+        assert np.array_equal(bits(gv), bits(wv)) and np.array_equal(bits(gg[inside]), bits(wg[inside])) and np.all(gg[~inside] == 7.0)
+        few = np.concatenate([tree.query(pts[i:i + 40]) for i in range(0, len(pts), 40)])   # 33..256 points: ONE launch of query_few_kernel
+        assert np.array_equal(bits(few), bits(big))
+
+
 def test_query_rejects_bad_blocks(H, ctx):
     for bad in (b"", b"\x00" * 50, np.array([1 << 40], np.uint64).tobytes() + b"\x00" * 300):
         with pytest.raises(H.HpsdfError):
@@ -300,12 +335,17 @@ def test_csg_rebuild_bitwise(H, O, ctx, op_name):
 # ------------------------------------------------------------------ fit known answers, degree by degree
 @pytest.mark.parametrize("degree", list(range(2, 12)))
 def test_fit_kernels_match_the_oracle_at_every_degree(H, O, ctx, degree):
-    """Octree::FitPolynomial (Octree.cpp:1007-1093) cell by cell through hpsdf_fit_cells: the default kernel -- degree-specialised
-    bodies for 2..5, the any-degree body for 6..11, which no BASELINE-sized build reaches -- returns the oracle's coefficients
-    and error bit for bit; the matrix-core kernel (hpsdf_ctx_set_fast_fit, every degree 2..11) the same to rounding."""
+    """Octree::FitPolynomial (Octree.cpp:1007-1093) cell by cell through hpsdf_fit_cells, in the three fit modes
+    (hpsdf_ctx_set_fit_mode).  EXACT: the term-by-term kernel -- degree-specialised bodies for 2..5, the any-degree body for 6..11,
+    which no BASELINE-sized build reaches -- returns the oracle's coefficients and error bit for bit.  SPLIT (the default; made to
+    split from degree 4 here, 6 is the default): the ERROR and the rows of top degree, which alone enter it (:1062-1069), bit for
+    bit; the rows below them, from the matrix cores, to 1e-13 of the coefficients' scale.  FAST: everything to rounding."""
     depth, n = 3, 40 if degree <= 8 else 12
     cfg, ocfg = H.make_config(1e-5), O.default_config(1e-5)
-    got_c, got_e = H.fit_cells(ctx, cfg, product_field(H, "union3"), degree, depth, n)
+    exact = H.Context(0)
+    exact.set_fit_mode(H.FIT_EXACT)
+    got_c, got_e = H.fit_cells(exact, cfg, product_field(H, "union3"), degree, depth, n)
+    exact.close()
     of = oracle_field(O, "union3")
     side, h = 1 << depth, np.float32(1.0) / np.float32(1 << depth)
     for i in range(n):
@@ -314,11 +354,27 @@ def test_fit_kernels_match_the_oracle_at_every_degree(H, O, ctx, degree):
         want_c, want_e = O.fit_polynomial(of, ocfg, bmin, bmin + h, degree, depth)
         assert np.array_equal(bits(got_c[i]), bits(want_c)), (degree, i)
         assert bits(np.array([got_e[i]]))[0] == bits(np.array([want_e]))[0], (degree, i)
+    scale = np.abs(got_c).max()
+    # the default context: splits from degree 6; below that it IS the exact kernel
+    dc, de = H.fit_cells(ctx, cfg, product_field(H, "union3"), degree, depth, n)
+    assert ctx.fit_mode() == H.FIT_SPLIT
+    assert np.array_equal(bits(de), bits(got_e))
+    if degree < 6:
+        assert np.array_equal(bits(dc), bits(got_c))
+    split = H.Context(0)
+    split.set_split_min_degree(4)
+    for c, (sc, se) in ((ctx, (dc, de)), (split, H.fit_cells(split, cfg, product_field(H, "union3"), degree, depth, n))):
+        nlow = int(H.NCOEF[degree - 1])
+        assert np.array_equal(bits(se), bits(got_e)), degree                                  # errors: bit for bit
+        assert np.array_equal(bits(sc[:, nlow:]), bits(got_c[:, nlow:])), degree               # rows of top degree: bit for bit
+        assert np.abs(sc[:, :nlow] - got_c[:, :nlow]).max() <= 1e-13 * scale, degree           # the rows below: the matrix cores
+    if degree >= 4:
+        assert not np.array_equal(sc, got_c)  # (the matrix-core kernel did run)
+    split.close()
     fast = H.Context(0)
     fast.set_fast_fit(True)
     fc, fe = H.fit_cells(fast, cfg, product_field(H, "union3"), degree, depth, n)
     fast.close()
-    scale = np.abs(got_c).max()
     assert np.abs(fc - got_c).max() <= 1e-13 * scale
     assert np.abs(fe - got_e).max() <= 1e-9 * got_e.max() + 1e-30
     assert not np.array_equal(fc, got_c)  # (another arithmetic: the matrix-core kernel did run)
