@@ -70,11 +70,21 @@ int main() {
         std::uniform_real_distribution<double> U(-0.5, 0.5);
         for (auto& v : xyz) v = U(rng);
         t0 = std::chrono::steady_clock::now();
-        const usize nScalar = 20000;
+        // HPBenchmarks.cpp:105-109: 8 M scalar calls.  A call of a few points is answered on the calling thread (csrc/host_query.cpp)
+        const usize nScalar = n;
         double acc = 0.0;
         for (usize i = 0; i < nScalar; ++i) acc += treeDev.Query(Eigen::Vector3d(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]));
-        std::printf("Query(pt), one call per point: %.1f us per call (%llu calls, checksum %.6f)\n", seconds(t0) / nScalar * 1e6,
-                    (unsigned long long)nScalar, acc);
+        std::printf("Query(pt), one call per point: %.3f us per call (%llu calls, %.2f s, checksum %.6f)\n", seconds(t0) / nScalar * 1e6,
+                    (unsigned long long)nScalar, seconds(t0), acc);
+        {
+            t0 = std::chrono::steady_clock::now();
+            const usize nG = 1000000;
+            double accG = 0.0;
+            Eigen::Vector3d g(0, 0, 0);
+            for (usize i = 0; i < nG; ++i) accG += treeDev.QueryWithGradient(Eigen::Vector3d(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]), g) + g.x();
+            std::printf("QueryWithGradient(pt), one call per point: %.3f us per call (%llu calls, checksum %.6f)\n", seconds(t0) / nG * 1e6,
+                        (unsigned long long)nG, accG);
+        }
         treeDev.Query(xyz.data(), n, out.data());
         t0 = std::chrono::steady_clock::now();
         treeDev.Query(xyz.data(), n, out.data());

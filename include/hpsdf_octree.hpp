@@ -9,12 +9,11 @@
 // program uses.
 //
 // Differences from the reference, all additive or documented in DESIGN.md:
-//   * Query(const double* xyz, n, out) -- the batched form every throughput-minded
-//     caller should use; Query(pt) is the same path with n = 1.
-//     !! A scalar Query(pt) is a kernel launch and a wait: ~14.6 us per call against ~75 ns
-//     in the reference's CPU path.  Loops over Query(pt) (the reference's own tests and
-//     benchmarks: HPUnitTests.cpp:64-75, HPBenchmarks.cpp:105-109) return the same values
-//     but must be batched to run at GPU speed.
+//   * Query(const double* xyz, n, out) -- the batched form: one pass of the GPU kernels over the
+//     points.  A scalar Query(pt) / QueryWithGradient(pt, n) -- any call of up to 32 points -- is
+//     answered on the calling thread from the tree handle's copy of the block (~0.1 us, the
+//     kernels' values bit for bit: csrc/host_query.cpp), so loops over Query(pt) (the reference's
+//     own tests and benchmarks: HPUnitTests.cpp:64-75, HPBenchmarks.cpp:105-109) run as they are.
 //   * Create(config, DeviceField) -- fields the GPU evaluates itself (analytic
 //     primitives, triangle meshes); Create(config, std::function) still works and
 //     samples the callback with config.threadCount host threads per round.
