@@ -1286,18 +1286,34 @@ static int createShardedOnHostScheduler(hpsdf_ctx* ctx, const hpsdf_config* cfg,
         if (injected && !localRc && std::atoi(injected) == rank && std::strchr(injected, ':') && std::atoi(std::strchr(injected, ':') + 1) == exchanges)
             localRc = fail(HPSDF_ERR_OUT_OF_MEMORY, "injected failure (HPSDF_TEST_FAIL_RANK)");
         ++exchanges;
-        const std::string ownError = localRc ? std::string(hpsdf_last_error()) : std::string();
+        std::string ownError = localRc ? std::string(hpsdf_last_error()) : std::string();
         stride = pad + 1;
         const uint64_t total = (uint64_t)world * stride;
         if (stage.cap < total) {
             if (stage.d) (void)hipFree(stage.d);
             stage.d = nullptr, stage.cap = 0;
-            HPSDF_HIP(hipMalloc((void**)&stage.d, (total + total / 2) * sizeof(double)));
-            stage.cap = total + total / 2;
+            uint64_t want = total + total / 2;
+            hipError_t me = hipMalloc((void**)&stage.d, want * sizeof(double));
+            if (me != hipSuccess) {  // without the headroom, then: what the exchange itself needs
+                (void)hipGetLastError();
+                want = total;
+                me = hipMalloc((void**)&stage.d, want * sizeof(double));
+            }
+            // (no buffer at all: this rank has nothing to enter the in-place exchange with -- the one failure the status word cannot carry)
+            if (me != hipSuccess) return localRc ? fail(localRc, ownError) : hipFail(me, "staging buffer of the exchange");
+            stage.cap = want;
+        }
+        // a failing copy is this rank's failure like any other: it enters the exchange with its status set (the peers leave with
+        // HPSDF_ERR_STATE instead of waiting for it in the next collective) and returns its own error afterwards
+        if (count && !localRc) {
+            const hipError_t ce = hipMemcpyAsync(stage.d + (uint64_t)rank * stride, mine, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+            if (ce != hipSuccess) localRc = hipFail(ce, "upload of this rank's part of the exchange"), ownError = hpsdf_last_error();
         }
         const double status = (double)localRc;
-        if (count && !localRc) HPSDF_HIP(hipMemcpyAsync(stage.d + (uint64_t)rank * stride, mine, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        HPSDF_HIP(hipMemcpyAsync(stage.d + (uint64_t)rank * stride + pad, &status, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        {
+            const hipError_t ce = hipMemcpyAsync(stage.d + (uint64_t)rank * stride + pad, &status, sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+            if (ce != hipSuccess && !localRc) localRc = hipFail(ce, "upload of this rank's status word"), ownError = hpsdf_last_error();
+        }
         const int grc = gather(user, stage.d, stride * sizeof(double), (void*)ctx->stream);
         if (localRc) return fail(localRc, ownError);
         if (grc) return fail(HPSDF_ERR_STATE, std::string("the all-gather callback failed (") + what + "): " + std::to_string(grc));

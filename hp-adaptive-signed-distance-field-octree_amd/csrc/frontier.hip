@@ -1597,6 +1597,15 @@ bool frontierEligible(const hpsdf_config* cfg, const hpsdf_field* field, uint64_
     return k <= kFrJobs;
 }
 
+// A launch that failed (LDS over-subscription, a grid beyond the limits) used to surface a round later as "a round ended without
+// advancing": every launch of the build loop reports its own failure at once.
+#define FR_LAUNCH(kernel, grid, block, stream, ...)                                         \
+    do {                                                                                    \
+        hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                    \
+        const hipError_t le_ = hipGetLastError();                                           \
+        if (le_ != hipSuccess) return ::hpsdf::hipFail(le_, "launch of " #kernel);          \
+    } while (0)
+
 int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field* field, uint64_t K, void** block, size_t* size,
                    hpsdf_build_stats* stats, int rank, int world, hpsdf_allgather_fn gather, void* gatherUser) {
     if (world < 1 || world > 8 || rank < 0 || rank >= world) return fail(HPSDF_ERR_INVALID_ARGUMENT, "bad rank/world (1..8 ranks)");
@@ -1723,7 +1732,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
     auto applyWeights = [&](const FitBlock* blocks, uint32_t maxBlocks, size_t lds, const FitTask* tasks, const uint32_t* dCount, bool round0) -> int {
         HPSDF_HIP(launchFitWeight(s, blocks, maxBlocks, lds, tasks, ws->arena, d.means, ctx->dTables, dCount));
         const uint32_t stamp = ++ws->flagStamp;
-        hipLaunchKernelGGL(fr_means_done_kernel, dim3(1), dim3(64), 0, s, d, stamp);
+        FR_LAUNCH(fr_means_done_kernel, dim3(1), dim3(64), s, d, stamp);
         const double ts = now();
         {
             const volatile uint32_t* flag = ws->hostFlag;
@@ -1750,7 +1759,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         }
         std::atomic_thread_fence(std::memory_order_release);
         tWeights += now() - tw;
-        hipLaunchKernelGGL(fr_weigh_kernel, dim3((std::max(1u, nJobs) * 9u + 255u) / 256u), dim3(256), 0, s, d, round0 ? 1u : 9u);
+        FR_LAUNCH(fr_weigh_kernel, dim3((std::max(1u, nJobs) * 9u + 255u) / 256u), dim3(256), s, d, round0 ? 1u : 9u);
         return HPSDF_OK;
     };
     uint8_t* early = nullptr;  // the block of a build that stops after round 0, begun before the device has finished
@@ -1823,7 +1832,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         hipError_t e = ws->ensureArena(std::max<uint64_t>(1, T0.arenaRows), 0, s);
         if (e == hipSuccess && mesh) e = ws->ensureSamples(std::max<uint64_t>(1, T0.samples), s);
         if (e != hipSuccess) return hipFail(e, "frontier buffers");
-        hipLaunchKernelGGL(fr_init_kernel, dim3((T.nNodes + 255) / 256), dim3(256), 0, s, d, T0, cfg.target_error_threshold);
+        FR_LAUNCH(fr_init_kernel, dim3((T.nNodes + 255) / 256), dim3(256), s, d, T0, cfg.target_error_threshold);
         FieldDev fdr = fd;
         if (mesh) {
             HPSDF_HIP(launchMeshSample(s, r0Tasks, T0.nTasks, 2, ctx->dTables, fd, rm, ws->samples));
@@ -1836,7 +1845,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         phase = 0;
         FrDev d0 = d;
         d0.batchIdx = ws->tmplLeaves, d0.batchErr = ws->tmplErr, d0.jobP = r0JobP, d0.jobH = r0JobP;
-        hipLaunchKernelGGL(fr_round0_kernel, dim3(1 + (T.nLeaves + 255) / 256), dim3(256), 0, s, d0);
+        FR_LAUNCH(fr_round0_kernel, dim3(1 + (T.nLeaves + 255) / 256), dim3(256), s, d0);
         if (world == 1) {
             // a build that stops here has its packed store at the start of the arena: fetch it right behind the round
             HPSDF_HIP(hipMemcpyAsync(ws->pinned, ws->arena, T.arenaRows * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -1899,9 +1908,9 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         }
         d.splitFit = splitRound ? std::max(4, ctx->splitMinDegree) : 0;
         if (e != hipSuccess) return hipFail(e, "frontier buffers");
-        hipLaunchKernelGGL(fr_select_kernel, dim3(std::min<uint32_t>(512u, (knownNodes + 255u) / 256u)), dim3(256), 0, s, d);
-        hipLaunchKernelGGL(fr_batch_kernel, dim3(1), dim3(1024), 0, s, d);
-        hipLaunchKernelGGL(fr_tasks_kernel, dim3((16u * Kj + 255u) / 256u), dim3(256), 0, s, d);
+        FR_LAUNCH(fr_select_kernel, dim3(std::min<uint32_t>(512u, (knownNodes + 255u) / 256u)), dim3(256), s, d);
+        FR_LAUNCH(fr_batch_kernel, dim3(1), dim3(1024), s, d);
+        FR_LAUNCH(fr_tasks_kernel, dim3((16u * Kj + 255u) / 256u), dim3(256), s, d);
         const int degHi = (int)std::min<uint32_t>(kMaxDegree - 1, knownMaxDeg + 1);
         const uint32_t taskBound = 9u * Kj;
         bool degHiDone = false;
@@ -1956,9 +1965,9 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         }
         if ((rc = exchange(d.errs, (size_t)d.errStride * sizeof(double), "a round's errors"))) return rc;
         phase = 0;
-        hipLaunchKernelGGL(fr_decide_kernel, dim3(1), dim3(1024), 0, s, d);
-        hipLaunchKernelGGL(fr_update_kernel, dim3(1 + (Kj + 31) / 32), dim3(256), 0, s, d);
-        if (world == 1) hipLaunchKernelGGL(fr_store_kernel, dim3(std::min<uint32_t>(2048u, (knownNodes + 8u * Kj + 3u) / 4u)), dim3(256), 0, s, d);
+        FR_LAUNCH(fr_decide_kernel, dim3(1), dim3(1024), s, d);
+        FR_LAUNCH(fr_update_kernel, dim3(1 + (Kj + 31) / 32), dim3(256), s, d);
+        if (world == 1) FR_LAUNCH(fr_store_kernel, dim3(std::min<uint32_t>(2048u, (knownNodes + 8u * Kj + 3u) / 4u)), dim3(256), s, d);
         // The round is over for the host when the header's mirror shows the next round number: the update kernel's last
         // workgroup writes it into pinned memory behind a system-scope fence.  Watching that word costs ~3 us; waking up
         // from hipStreamSynchronize ~20 (everything launched next is ordered behind this round on the stream anyway;
@@ -2001,7 +2010,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         hipError_t e = ws->ensureStore(hh->nCoeffs, s);
         if (e != hipSuccess) return hipFail(e, "coefficient store");
         HPSDF_HIP(hipMemsetAsync(&d.hdr->overflow, 0, sizeof(uint32_t), s));
-        hipLaunchKernelGGL(fr_packpos_kernel, dim3(1), dim3(1024), 0, s, d);
+        FR_LAUNCH(fr_packpos_kernel, dim3(1), dim3(1024), s, d);
         HPSDF_HIP(hipStreamSynchronize(s));
         uint64_t stride = 1;
         for (int r = 0; r < world; ++r) stride = std::max<uint64_t>(stride, hh->packCount[r]);
@@ -2009,15 +2018,15 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         e = ws->ensurePack((uint64_t)world * stride, s);
         if (e != hipSuccess) return hipFail(e, "pack buffers");
         d.packStride = stride;
-        hipLaunchKernelGGL(fr_pack_kernel, dim3(std::min<uint32_t>(2048u, (knownNodes + 3u) / 4u)), dim3(256), 0, s, d);
+        FR_LAUNCH(fr_pack_kernel, dim3(std::min<uint32_t>(2048u, (knownNodes + 3u) / 4u)), dim3(256), s, d);
         if ((rc = exchange(d.pack, (size_t)stride * sizeof(double), "the packed coefficients"))) return rc;
-        hipLaunchKernelGGL(fr_store_kernel, dim3(std::min<uint32_t>(2048u, (knownNodes + 3u) / 4u)), dim3(256), 0, s, d);
+        FR_LAUNCH(fr_store_kernel, dim3(std::min<uint32_t>(2048u, (knownNodes + 3u) / 4u)), dim3(256), s, d);
         HPSDF_HIP(hipStreamSynchronize(s));
     } else if (hh->overflow == 2) {  // the packed store was too small: grow, run ReallocCoeffs again
         hipError_t e = ws->ensureStore(hh->nCoeffs, s);
         if (e != hipSuccess) return hipFail(e, "coefficient store");
         HPSDF_HIP(hipMemsetAsync(&d.hdr->overflow, 0, sizeof(uint32_t), s));
-        hipLaunchKernelGGL(fr_store_kernel, dim3(std::min<uint32_t>(2048u, (knownNodes + 3u) / 4u)), dim3(256), 0, s, d);
+        FR_LAUNCH(fr_store_kernel, dim3(std::min<uint32_t>(2048u, (knownNodes + 3u) / 4u)), dim3(256), s, d);
         HPSDF_HIP(hipStreamSynchronize(s));
     }
     // Octree::ToMemoryBlock, Octree.cpp:424-456: [u64 nCoeffs][f64 x nCoeffs][u64 nNodes][Node x nNodes][Config]

@@ -1408,11 +1408,27 @@ __device__ __forceinline__ void queryGeneralBody(const TreeDev& t, const DeviceT
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane & ~7, sub = lane & 7;
     const size_t segStart = (size_t)blockIdx.x * tilesPerWg * TILE;  // this workgroup's run of deferIdx
+    // The points of a tile are asked for while the previous tile still waits for its last coefficient fetch (below): a wave's tile is a
+    // chain of dependent round trips -- points from HBM (~1.8 us under load), record, walk, two coefficient fetches from L2 (~0.8 us
+    // each), ~0.5 us of arithmetic -- and with 16 waves on a CU the kernel runs at what that chain's length allows, not at a bandwidth
+    // limit (profiles/r02w_query_general_counters.txt: the texture addresser is busy half of the time).  The first link now overlaps
+    // the previous tile's last fetch and its evaluation.
+    typedef double qg_double2 __attribute__((ext_vector_type(2)));
+    qg_double2 nxy = {0.0, 0.0};
+    double nz = 0.0;
+    {
+        const size_t i0 = (size_t)blockIdx.x * TILE + threadIdx.x;
+        if ((size_t)blockIdx.x * TILE < n) {
+            const size_t il0 = i0 < n ? i0 : n - 1;
+            nxy.x = xyz[3 * il0], nxy.y = xyz[3 * il0 + 1], nz = xyz[3 * il0 + 2];
+        }
+    }
     for (size_t base = (size_t)blockIdx.x * TILE; base < n; base += (size_t)gridDim.x * TILE) {
         const size_t i = base + threadIdx.x;
         const bool valid = i < n;
-        const size_t il = valid ? i : n - 1;
-        const double x = xyz[3 * il], y = xyz[3 * il + 1], z = xyz[3 * il + 2];
+        const double x = nxy.x, y = nxy.y, z = nz;
+        const size_t nextBase = base + (size_t)gridDim.x * TILE;
+        const bool more = nextBase < n;  // workgroup-uniform
         const double p3[3] = {(x - t.rootCentre[0]) * t.rootInvSizes[0], (y - t.rootCentre[1]) * t.rootInvSizes[1],
                               (z - t.rootCentre[2]) * t.rootInvSizes[2]};  // Octree.cpp:665
         const float fx = (float)p3[0], fy = (float)p3[1], fz = (float)p3[2];
@@ -1465,7 +1481,21 @@ __device__ __forceinline__ void queryGeneralBody(const TreeDev& t, const DeviceT
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                      (__attribute__((address_space(3))) void*)&sRows[wave][4][0], 16, 0, 0);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (pass == 1 && more) {
+                // the next tile's points, issued BEHIND this tile's last coefficient fetch: memory operations of a wave complete in
+                // order, so "all but the two youngest" (vmcnt(2)) is exactly "the coefficients are in LDS", and the two point loads
+                // stay in flight across the read-back and the evaluation (written out as instructions: the count in the wait must be
+                // the number of loads, which the compiler is free to merge or split; the values are claimed further down, before the
+                // stores, by a wait of their own)
+                const size_t in = nextBase + threadIdx.x;
+                const double* np = xyz + 3 * (in < n ? in : n - 1);
+                asm volatile("global_load_dwordx4 %0, %2, off nt\n\tglobal_load_dwordx2 %1, %2, off offset:16 nt\n\ts_waitcnt vmcnt(2)"
+                             : "=&v"(nxy), "=&v"(nz)
+                             : "v"(np)
+                             : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_wave_barrier();
             if ((sub >> 2) == pass) {
                 const double2* row = &sRows[wave][sub & 3][grp];
@@ -1508,6 +1538,9 @@ __device__ __forceinline__ void queryGeneralBody(const TreeDev& t, const DeviceT
                 }
             }
         }
+        // the next tile's points have had the evaluation's time to arrive: claim them before this tile's stores are issued (a wait
+        // behind the stores would wait for those too)
+        if (more) asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxy), "+v"(nz)::"memory");
         if constexpr (DEFER) {
             const unsigned long long dmask = __ballot(defer);
             if (dmask) {  // one LDS atomic per wave reserves the slots

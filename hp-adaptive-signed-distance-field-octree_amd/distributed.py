@@ -95,7 +95,14 @@ def device_allgather(ctx, group=None):
                     try:
                         dist.all_gather_into_tensor(buf, mine, group=group)
                         return
-                    except RuntimeError:  # a torch build that rejects the aliasing: one small device copy instead
+                    except (RuntimeError, ValueError) as e:
+                        # ONLY the argument check of a torch build that rejects an input aliasing the output: it is raised before
+                        # anything is enqueued and on every rank alike (same torch, same call), so every rank takes the copy below
+                        # from now on.  Anything else -- an RCCL error, out of memory -- is this rank's alone: issuing a second
+                        # collective here would leave the ranks' sequences out of step, so it is passed on.
+                        msg = str(e).lower()
+                        if not any(k in msg for k in ("overlap", "alias", "in-place", "inplace", "same tensor", "same memory")):
+                            raise
                         state["in_place"] = False
                 dist.all_gather_into_tensor(buf, mine.clone(), group=group)
         else:

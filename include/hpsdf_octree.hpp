@@ -309,6 +309,7 @@ class Octree {
     void SetFitMode(int mode) {
         ensureCtx();
         check(hpsdf_ctx_set_fit_mode(ctx_, mode));
+        fitMode_ = mode;
     }
     void SetFastFit(bool on) { SetFitMode(on ? HPSDF_FIT_FAST : HPSDF_FIT_SPLIT); }
     /// Additive: Create() over `world` GPUs of one node -- one Octree per GPU (SetDevice), every rank calls Create with
@@ -482,7 +483,10 @@ class Octree {
         return (*fn)(Eigen::Vector3d(pt[0], pt[1], pt[2]), (u32)threadIdx);
     }
     void ensureCtx() const {
-        if (!ctx_) check(hpsdf_ctx_create(device_, stream_, &ctx_));
+        if (!ctx_) {
+            check(hpsdf_ctx_create(device_, stream_, &ctx_));
+            if (fitMode_ >= 0) check(hpsdf_ctx_set_fit_mode(ctx_, fitMode_));  // (a copy keeps the mode its source was given)
+        }
     }
     void dropTree() {
         hpsdf_tree_destroy(tree_);
@@ -552,12 +556,20 @@ class Octree {
         FieldGuard g{inner};
         csg(op, inner);
     }
-    void copyFrom(const Octree& o) {
+    // everything that is a setting of the object rather than its tree: a copy or a moved-into Octree builds the way its source did
+    void copySettings(const Octree& o) {
         device_ = o.device_;
         stream_ = o.stream_;
         jobsPerRound_ = o.jobsPerRound_;
+        rank_ = o.rank_, world_ = o.world_;
+        gather_ = o.gather_, gatherUser_ = o.gatherUser_;
+        fitMode_ = o.fitMode_;
         config_ = o.config_;
         stats_ = o.stats_;
+        continuity_ = o.continuity_;
+    }
+    void copyFrom(const Octree& o) {
+        copySettings(o);
         if (o.block_) {
             block_ = std::malloc(o.size_);
             if (!block_) throw Error(HPSDF_ERR_OUT_OF_MEMORY, "malloc failed");
@@ -567,11 +579,7 @@ class Octree {
         }
     }
     void steal(Octree& o) {
-        device_ = o.device_;
-        stream_ = o.stream_;
-        jobsPerRound_ = o.jobsPerRound_;
-        config_ = o.config_;
-        stats_ = o.stats_;
+        copySettings(o);
         ctx_ = o.ctx_;
         tree_ = o.tree_;
         mirrorPending_.store(o.mirrorPending_.load(), std::memory_order_release);
@@ -588,6 +596,7 @@ class Octree {
     void* stream_ = nullptr;
     uint64_t jobsPerRound_ = 0;
     int rank_ = 0, world_ = 1;
+    int fitMode_ = -1;  // -1: the context's default
     hpsdf_allgather_fn gather_ = nullptr;
     void* gatherUser_ = nullptr;
     mutable hpsdf_ctx* ctx_ = nullptr;

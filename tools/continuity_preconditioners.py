@@ -59,3 +59,38 @@ for r in range(n):
     cols = cols[cols < r]
     if len(cols): lev[r] = lev[cols].max() + 1
 print("levels of the triangular solve:", int(lev.max()) + 1, "rows per level (median): %d" % np.median(np.bincount(lev)))
+
+# ---- round 4: SpMV-only preconditioners (no triangular solves): Chebyshev polynomials of the Jacobi-scaled operator D^-1/2 S D^-1/2
+# on [lmin, lmax] (lmax by 30 power iterations + 5 %, lmin = lmax / kappa for a few guesses), and the truncated Neumann series.
+# What counts is SpMVs in all: a polynomial of degree m costs m SpMVs per application on top of the iteration's own.
+dis = 1.0 / np.sqrt(d)
+Ah = sp.diags(dis) @ S @ sp.diags(dis)
+v = np.random.default_rng(0).standard_normal(n)
+for _ in range(30):
+    v = Ah @ v
+    v /= np.linalg.norm(v)
+lmax = float(v @ (Ah @ v)) * 1.05
+print("largest eigenvalue of the Jacobi-scaled matrix ~ %.3f" % lmax)
+def cheb(m, lmin):
+    theta, delta = 0.5 * (lmax + lmin), 0.5 * (lmax - lmin)
+    def apply(r):  # m steps of the Chebyshev iteration for S z = r from z = 0, in the scaled variables
+        rh = dis * r
+        z = np.zeros(n); p = np.zeros(n); res = rh.copy()
+        alpha = 0.0
+        for k in range(m + 1):
+            if k == 0:
+                p = res / theta; alpha = 1.0 / theta
+            else:
+                beta = (0.5 * delta * alpha) ** 2 if k > 1 else 0.5 * (delta * alpha) ** 2
+                alpha = 1.0 / (theta - beta / alpha)
+                p = alpha * res + beta * p  # (standard three-term form)
+            z = z + p
+            if k < m: res = res - Ah @ p
+        return dis * z
+    return apply
+for m in (1, 2, 3, 4):
+    for kappa in (10.0, 30.0, 100.0):
+        it = [0]
+        def cb(x): it[0] += 1
+        x, info = spl.cg(S, b, x0=b.copy(), rtol=1e-6, maxiter=2000, M=spl.LinearOperator((n, n), cheb(m, lmax / kappa)), callback=cb)
+        print("Chebyshev degree %d on [lmax/%g, lmax]: iterations %3d, SpMVs in all %4d (Jacobi: 107)" % (m, kappa, it[0], it[0] * (m + 1)))
