@@ -11,6 +11,7 @@ import numpy as np, hpsdf_loader
 H = hpsdf_loader.load()
 exact, split, fast = H.Context(0), H.Context(0), H.Context(0)
 exact.set_fit_mode(H.FIT_EXACT); split.set_fit_mode(H.FIT_SPLIT); fast.set_fit_mode(H.FIT_FAST)
+split.set_split_min_degree(int(os.environ.get('SPLIT_FROM', '4')))
 cfg = H.make_config(1e-5)
 union3 = H.Field.union3()
 ok = True
