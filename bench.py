@@ -111,7 +111,8 @@ def main():
         if share_gpu:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            import datetime
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=datetime.timedelta(minutes=5))
     backend = dist.get_backend() if world > 1 else None
 
     import hpsdf_loader
@@ -156,11 +157,6 @@ def main():
 
         block, stats, create_ms, create_times, _ = timed_create("auto")
         create_sharded_ms, create_sharded = None, None
-        if world > 1:
-            block_s, st_s, create_sharded_ms, _, per_rank = timed_create("shard")
-            assert block_s == block, "sharded and replicated Create disagree"
-            create_sharded = {"ms_per_rank": per_rank, "exchanges_per_create": st_s.get("exchanges"), "rounds": st_s["rounds"],
-                              "backend": dist.get_backend()}
 
         # ---------------- Query(): this rank's points, resident in HBM
         n = args.points
@@ -197,6 +193,20 @@ def main():
 
         # sanity: the timed output is the real answer (spot parity against the oracle on rank 0)
         got = d_out[:: max(1, n // 2000)].cpu().numpy()
+
+        # ---------------- Create() with the frontier sharded over the ranks (one all-gather per round).  Behind the headline leg and
+        # inside a try: this is the part of the run that needs RCCL to take an in-place all-gather on the library's stream, which no
+        # box this was developed on could exercise with more than one GPU -- if it fails, the line still carries the weak-scaling Query
+        # numbers and says what went wrong instead of taking the whole record down.
+        if world > 1:
+            try:
+                block_s, st_s, create_sharded_ms, _, per_rank = timed_create("shard")
+                assert block_s == block, "sharded and replicated Create disagree"
+                create_sharded = {"ms_per_rank": per_rank, "exchanges_per_create": st_s.get("exchanges"), "rounds": st_s["rounds"],
+                                  "backend": dist.get_backend()}
+            except Exception as e:  # noqa: BLE001
+                create_sharded_ms, create_sharded = None, {"error": "%s: %s" % (type(e).__name__, str(e)[:500])}
+                args.mesh = "none"  # (the mesh leg shards the same way)
 
         # locality ceiling: the same points sorted by depth-4 cell, so neighbouring lanes share tree lines
         sorted_ms = None
@@ -300,7 +310,11 @@ def main():
                     if world > 1:
                         return D.create_distributed(ctx, mcfg, mfield, JOBS_PER_ROUND, policy="shard")
                     return H.create_block(ctx, mcfg, mfield, JOBS_PER_ROUND)
-                mcreate()
+                try:
+                    mcreate()
+                except Exception as e:  # noqa: BLE001  (N > 1 only in practice: see the sharded Create above)
+                    mesh["error_" + key] = "%s: %s" % (type(e).__name__, str(e)[:500])
+                    break
                 mt = []
                 for _ in range(3):
                     if world > 1:
@@ -321,7 +335,15 @@ def main():
                 mesh["create_ms_" + key] = ms
                 mesh["tree_" + key] = {"nodes": mst["n_nodes"], "rounds": mst["rounds"], "samples": mst["samples"],
                                        "msamples_per_s": mst["samples"] / ms / 1e3}
-            mesh["create_ms"] = mesh["create_ms_1e-5"]  # the north_star's "2 M-tri mesh at targetError 1e-5"
+            mesh["create_ms"] = mesh.get("create_ms_1e-5")  # the north_star's "2 M-tri mesh at targetError 1e-5"
+            # What bounds the sampling leg: mesh_sample_kernel is VALU-issue bound, not HBM bound (8 B written per sample against ~1.4 KB
+            # gathered, mostly from L2 / Infinity Cache).  The issue fraction is a counter figure (SQ_INSTS_VALU x 4 cycles / (GRBM_GUI_ACTIVE
+            # / 8 XCDs x 1024 SIMDs), tools/mesh_pmc.sh) and cannot be read from inside this process: it is the one committed with the
+            # profile named here; the live part is samples/s.
+            mesh["roofline"] = {"kernel": "mesh_sample_kernel", "bound": "valu-issue", "unit": "G samples/s",
+                                "achieved": mesh["tree_1e-6"]["msamples_per_s"] / 1e3 if "tree_1e-6" in mesh else None, "frac_valu_issue": 0.77, "lane_utilisation": 0.65,
+                                "valu_insts_per_64_samples": 27500, "fetched_bytes_per_sample": 1400, "written_bytes_per_sample": 20,
+                                "algorithmic_bytes_per_sample": 8, "measured_from": "profiles/r03z_mesh_sample_counters.txt"}
             del mfield
 
         fit = None
@@ -331,9 +353,13 @@ def main():
             # the headline field and with a field that costs nothing (contraction only).  Algorithmic flops:
             # 2 ncoef(p) (4p+1)^3 per fit, against the FP64 peak (78.6 TFLOP/s, vector = matrix on this chip: measured
             # 77.6 with back-to-back v_mfma_f64_16x16x4_f64, tools/mfma_f64_rate.hip).
-            fit = {}
+            fit = {"default_mode": "HPSDF_FIT_SPLIT: from-scratch fits of degree >= 6 keep their rows of top degree on the bit-exact kernel (errors, "
+                                   "decisions, topology canonical) and send the rows below them to the matrix cores; degrees 2-5 are the "
+                                   "bit-exact kernel throughout"}
             fast_ctx = H.Context(local, stream.cuda_stream)
             fast_ctx.set_fast_fit(True)
+            exact_ctx = H.Context(local, stream.cuda_stream)
+            exact_ctx.set_fit_mode(H.FIT_EXACT)
             plane = H.Field.analytic([(H.PRIM_PLANE, H.OP_UNION, [0.3, -0.2, 0.5, 0.1])])  # F costs ~nothing: contraction only
             for p in (2, 3, 4, 5, 6, 7, 8):  # p in {2..8}; degrees > 5 run the any-degree kernel by default
                 cells = 65536 if p <= 3 else 16384
@@ -344,6 +370,12 @@ def main():
                                   "frac_fp64_peak": flops / ms / 1e9 / FP64_PEAK_TFLOPS,
                                   "contraction_only_ms": ms_c, "contraction_only_tflops": flops / ms_c / 1e9,
                                   "contraction_only_frac_fp64_peak": flops / ms_c / 1e9 / FP64_PEAK_TFLOPS}
+                fit["p%d" % p]["kernel"] = ("fit_kernel (top-degree rows, bit-exact) + fit_mfma_low_kernel (v_mfma_f64_16x16x4_f64)" if p >= 6
+                                            else "fit_kernel (bit-exact)")
+                if p >= 6:  # what the default replaced: every row on the bit-exact kernel
+                    ems = H.bench_fit(exact_ctx, cfg, field, p, 5, cells, 3)
+                    fit["p%d" % p]["exact_fit"] = {"kernel": "fit_kernel (bit-exact, every row)", "ms": ems, "tflops_algorithmic": flops / ems / 1e9,
+                                                   "frac_fp64_peak": flops / ems / 1e9 / FP64_PEAK_TFLOPS}
                 if p >= 2:  # (degrees 2-3 reach the matrix cores in this micro-benchmark only: builds send degrees >= 4 there)
                     fms = H.bench_fit(fast_ctx, cfg, field, p, 5, cells, 3)
                     fms_c = H.bench_fit(fast_ctx, cfg, plane, p, 5, cells, 3)
@@ -353,6 +385,7 @@ def main():
                                                   "contraction_only_ms": fms_c, "contraction_only_tflops": flops / fms_c / 1e9,
                                                   "contraction_only_frac_fp64_peak": flops / fms_c / 1e9 / FP64_PEAK_TFLOPS}
             fast_ctx.close()
+            exact_ctx.close()
 
     ms_per_step = wall * 1e3 / args.steps
     value = world * n * args.steps / wall / 1e6  # Mpts/s, whole job
@@ -397,7 +430,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         # what the collective layer saw (N > 1): ranks, backend (nccl = RCCL over xGMI), all-gathers per sharded Create
         "world": world, "backend": backend,
-        "exchanges_per_create": None if create_sharded is None else create_sharded["exchanges_per_create"],
+        "exchanges_per_create": None if create_sharded is None else create_sharded.get("exchanges_per_create"),
         "config": {"workload": "BASELINE configs[1]: union(sphere,box,torus) analytic SDF, targetError=1e-5, "
                                "continuity off, %d random Query() points per GPU" % n,
                    "jobs_per_round": JOBS_PER_ROUND, "points_per_gpu": n, "sharding": "replicated tree, points split"},

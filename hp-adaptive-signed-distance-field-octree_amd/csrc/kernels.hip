@@ -61,39 +61,29 @@ constexpr float kEpsF32 = 0.000001f;  // Include/Utility/Literals.h:13
 __device__ __forceinline__ bool meshPointFinite(V3 p) { return fabsf(p.x) <= FLT_MAX && fabsf(p.y) <= FLT_MAX && fabsf(p.z) <= FLT_MAX; }
 __device__ __forceinline__ float meshNoTriangle() { return __uint_as_float(0xFFFFFFFFu); }
 
-// The closest point of a triangle in float64 (Ericson's region walk on exact inputs): what closestSimplex falls back on when the
-// reference's face case has left the triangle.  Cold path: a handful of calls per million tests on meshes of needles, none elsewhere.
-__device__ __noinline__ int closestSimplexRobust(V3 ptf, V3 af, V3 bf, V3 cf, V3& q) {
-    const double px = ptf.x, py = ptf.y, pz = ptf.z;
-    const double ax = af.x, ay = af.y, az = af.z, bx = bf.x, by = bf.y, bz = bf.z, cx = cf.x, cy = cf.y, cz = cf.z;
-    const double abx = bx - ax, aby = by - ay, abz = bz - az, acx = cx - ax, acy = cy - ay, acz = cz - az;
-    const double apx = px - ax, apy = py - ay, apz = pz - az;
-    const double d1 = abx * apx + aby * apy + abz * apz, d2 = acx * apx + acy * apy + acz * apz;
-    int code;
-    double t0 = 0.0, t1 = 0.0;  // q = a + t0 ab + t1 ac
-    const double bpx = px - bx, bpy = py - by, bpz = pz - bz;
-    const double d3 = abx * bpx + aby * bpy + abz * bpz, d4 = acx * bpx + acy * bpy + acz * bpz;
-    const double cpx = px - cx, cpy = py - cy, cpz = pz - cz;
-    const double d5 = abx * cpx + aby * cpy + abz * cpz, d6 = acx * cpx + acy * cpy + acz * cpz;
-    const double vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
-    if (d1 <= 0.0 && d2 <= 0.0) {
-        code = 0;
-    } else if (d3 >= 0.0 && d4 <= d3) {
-        code = 1, t0 = 1.0;
-    } else if (vc <= 0.0 && d1 >= 0.0 && d3 <= 0.0) {
-        code = 4, t0 = d1 / (d1 - d3);
-    } else if (d6 >= 0.0 && d5 <= d6) {
-        code = 2, t1 = 1.0;
-    } else if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0) {
-        code = 6, t1 = d2 / (d2 - d6);
-    } else if (va <= 0.0 && (d4 - d3) >= 0.0 && (d5 - d6) >= 0.0) {
-        const double w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
-        code = 5, t0 = 1.0 - w, t1 = w;
-    } else {
-        const double den = 1.0 / (va + vb + vc);
-        code = 8, t0 = vb * den, t1 = vc * den;
-    }
-    q = V3{(float)(ax + (t0 * abx + t1 * acx)), (float)(ay + (t0 * aby + t1 * acy)), (float)(az + (t0 * abz + t1 * acz))};
+// What closestSimplex falls back on when the reference's face case has left the triangle: the point the weights describe lies outside,
+// so the triangle's closest point is on its boundary -- the nearest of the closest points of its three edges (a + t ab, t the clamped
+// projection: well conditioned in f32 whatever the triangle's shape; ties go to ab, then bc, then ca).  A function of its own, called:
+// inlined into closestSimplex's five copies inside mesh_sample_kernel it made the kernel 14 % slower WITHOUT ever running (3 000 more
+// instructions in the hot loops: the instruction cache), behind a call 3 % (2.1 M-triangle torus at 1e-6: 30.5 ms without any of
+// this, 34.5 inlined, 31.6 called).  (If the weights were wrong -- cancellation on a needle, the point really inside -- the answer is off by
+// at most the needle's width, upwards: a distance that is too large never breaks a bound.)
+__device__ __noinline__ int closestOnBoundary(V3 pt, V3 a, V3 b, V3 c, V3& q) {
+    int code = 0;
+    float best = __builtin_inff();
+    auto edge = [&](V3 p0, V3 p1, int edgeCode, int v0, int v1) {
+        const V3 e = p1 - p0;
+        const float den = dot(e, e);
+        float t = den > 0.0f ? dot(pt - p0, e) / den : 0.0f;
+        t = fminf(fmaxf(t, 0.0f), 1.0f);
+        const V3 x = p0 + t * e;
+        const float d = sqnorm(pt - x);
+        if (d < best) best = d, q = x, code = t <= 0.0f ? v0 : (t >= 1.0f ? v1 : edgeCode);
+    };
+    edge(a, b, 4, 0, 1);
+    edge(b, c, 5, 1, 2);
+    edge(a, c, 6, 0, 2);
+    if (!(best < __builtin_inff())) q = a, code = 0;  // (nothing finite: the vertex, like the reference's first case)
     return code;
 }
 
@@ -108,10 +98,10 @@ __device__ __noinline__ int closestSimplexRobust(V3 ptf, V3 af, V3 bf, V3 cf, V3
 // BELOW the triangle's.  No bound can be a bound on that: a search that comes across the needle returns the artefact, one that has
 // pruned it (by its box, rightly) does not, and two traversals disagree (tools/fuzz_mesh_bvh.py seeds 100758, 501177: a sphere
 // squashed 1000 : 1).  The weights say exactly where q is -- a negative weight m puts it |m| altitudes beyond the opposite edge,
-// i.e. |m| |n| / |edge| outside -- so: a face-case point farther than `tol` outside its triangle is not taken; the closest point
-// is then computed in float64 (closestSimplexRobust).  Every traversal and the O(n) scan kernel share this function, so they
+// i.e. |m| |n| / |edge| outside -- so: a face-case point farther than `tol` outside its triangle is not taken by a search that could
+// make it its best (`best`: the caller's squared distance so far); it takes the boundary's closest point instead (closestOnBoundary).  Every traversal and the O(n) scan kernel share this function, so they
 // agree bit for bit on every mesh; against the reference the value differs exactly where the reference's is such an artefact.
-__device__ int closestSimplex(V3 pt, V3 a, V3 b, V3 c, V3 n, float tol, V3& q) {
+__device__ int closestSimplex(V3 pt, V3 a, V3 b, V3 c, V3 n, float tol, float best, V3& q) {
     const V3 ab = b - a, ac = c - a, bc = c - b;
     const float snom = dot(pt - a, ab), sdenom = dot(pt - b, a - b);
     const float tnom = dot(pt - a, ac), tdenom = dot(pt - c, a - c);
@@ -148,9 +138,18 @@ __device__ int closestSimplex(V3 pt, V3 a, V3 b, V3 c, V3 n, float tol, V3& q) {
     const float w = 1.0f - u - v;
     q = (u * a + v * b) + w * c;
     const float m = fminf(u, fminf(v, w));  // (NaN weights -- a triangle without area -- stay the reference's NaN point)
-    if (m < 0.0f) {
+    // Two cheap tests in front, for every face-case result.  The weight alone: an altitude is at most the mesh's extent E and
+    // tol = 5e-7 max(E, largest coordinate), so a weight above -5e-7 cannot put q more than tol outside.  And whether the value could
+    // win at all (d <= best; ties count, they go to the lower triangle index): one that cannot is left as it is -- the triangle's
+    // proper distance is larger still, so it loses either way.  On a fine mesh negative weights are the rule, not the exception (the
+    // reference's absolute guards send most outside points of a small triangle here), but a test beats its caller's best once or twice
+    // per search: what passes both is measured exactly, and the three divisions of closestOnBoundary are spent on potential winners
+    // only.  (Substituting at the call sites instead of here cost 18 VGPRs and a wave per SIMD.)  best = +inf passes
+    // everything: the winner's recomputation, which must equal what the search stored for it (a winner whose face-case point had left
+    // the triangle was, by this rule, substituted when it won).
+    if (m < -5e-7f && sqnorm(pt - q) <= best) {
         const float e2 = m == u ? sqnorm(bc) : (m == v ? sqnorm(ac) : sqnorm(ab));  // the edge opposite the negative weight
-        if ((m * m) * sqnorm(n) > (tol * tol) * e2) return closestSimplexRobust(pt, a, b, c, q);
+        if ((m * m) * sqnorm(n) > (tol * tol) * e2) return closestOnBoundary(pt, a, b, c, q);
     }
     return 8;
 }
@@ -267,7 +266,7 @@ __device__ float meshSignedDistance(const MeshDev& m, V3 pt, uint32_t& hint) {
     auto visitTri = [&](uint32_t t) {
         V3 q;
         const float4 tp[3] = {m.triPos[3 * (size_t)t], m.triPos[3 * (size_t)t + 1], m.triPos[3 * (size_t)t + 2]};
-        const int code = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, kMeshTolOfSlack * slack, q);
+        const int code = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, kMeshTolOfSlack * slack, best, q);
         const float d = sqnorm(pt - q);
         if (d < best || (d == best && t < bestTri)) {
             best = d;
@@ -355,7 +354,7 @@ __device__ float meshSignedDistanceWave(const MeshDev& m, V3 pt, bool activeIn, 
     auto visitTri = [&](uint32_t t) {
         V3 q;
         const float4 tp[3] = {m.triPos[3 * (size_t)t], m.triPos[3 * (size_t)t + 1], m.triPos[3 * (size_t)t + 2]};
-        const int code = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, kMeshTolOfSlack * slack, q);
+        const int code = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, kMeshTolOfSlack * slack, best, q);
         const float d = sqnorm(pt - q);
         if (d < best || (d == best && t < bestTri)) {
             best = d;
@@ -557,7 +556,7 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool activeIn,
         if (on) {
             V3 q;
             const float4 tp[3] = {m.triPos[3 * (size_t)t], m.triPos[3 * (size_t)t + 1], m.triPos[3 * (size_t)t + 2]};
-            closestSimplex(p, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, kMeshTolOfSlack * slack, q);
+            closestSimplex(p, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, kMeshTolOfSlack * slack, ownerBest(src), q);  // (a stale best only substitutes more often than needed)
             const float d = sqnorm(p - q);
             atomicMin(&L.best[src], ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)t);
         }
@@ -646,7 +645,7 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool activeIn,
         auto tryTriangle = [&](uint32_t t, uint32_t slot) {
             V3 q;
             const float4 tp[3] = {m.triPos[3 * (size_t)t], m.triPos[3 * (size_t)t + 1], m.triPos[3 * (size_t)t + 2]};
-            const int code = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, kMeshTolOfSlack * slack, q);
+            const int code = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, kMeshTolOfSlack * slack, best, q);
             const float d = sqnorm(pt - q);
             const bool better = d < best || (d == best && t < bestTri);
             if (better) best = d, bestTri = t, bestSlot = slot, bestCode = code, rj = rejectBound(d, slack);
@@ -950,7 +949,7 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool activeIn,
         const uint32_t bestTri = (uint32_t)(L.best[lane] & 0xFFFFFFFFull);
         V3 bestQ;
         const float4 tp[3] = {m.triPos[3 * (size_t)bestTri], m.triPos[3 * (size_t)bestTri + 1], m.triPos[3 * (size_t)bestTri + 2]};
-        const int bestCode = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, kMeshTolOfSlack * slack, bestQ);
+        const int bestCode = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, kMeshTolOfSlack * slack, __builtin_inff(), bestQ);
         const V3 nrm = pseudoNormal(m, bestTri, bestCode);
         const V3 d = pt - bestQ;
         const float sign = dot(nrm, d) > 0.0f ? 1.0f : -1.0f;
@@ -2463,7 +2462,7 @@ __global__ __launch_bounds__(256) void mesh_naive_kernel(MeshDev m, const double
     for (uint32_t t = first + (uint32_t)lane; t < last; t += 64u) {
         V3 q;
         const float4 tp[3] = {m.triPos[3 * (size_t)t], m.triPos[3 * (size_t)t + 1], m.triPos[3 * (size_t)t + 2]};
-        closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, kMeshTolOfSlack * slack, q);
+        closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, kMeshTolOfSlack * slack, best, q);
         const float d = sqnorm(pt - q);
         if (d < best) best = d, bestTri = t;
     }
@@ -2492,7 +2491,7 @@ __global__ __launch_bounds__(256) void mesh_naive_finish_kernel(MeshDev m, const
     const float slack = meshSlack(m.bvh[0]);
     V3 q;
     const float4 tp[3] = {m.triPos[3 * (size_t)t], m.triPos[3 * (size_t)t + 1], m.triPos[3 * (size_t)t + 2]};
-    const int code = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, kMeshTolOfSlack * slack, q);
+    const int code = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, kMeshTolOfSlack * slack, __builtin_inff(), q);
     const V3 nrm = pseudoNormal(m, t, code);
     const V3 d = pt - q;
     const float sign = dot(nrm, d) > 0.0f ? 1.0f : -1.0f;

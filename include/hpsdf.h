@@ -177,7 +177,8 @@ HPSDF_API int hpsdf_field_eval_host(hpsdf_ctx* ctx, const hpsdf_field* f, const 
  * (its 1e-6 guards are absolute) a weight can be negative enough to put q well outside the triangle -- a distance below the
  * triangle's own, which a search reports or not depending on what it has pruned (the reference's BVH and its linear scan
  * disagree there too).  Here a face-case point farther outside its triangle than 5e-7 of the mesh's scale (a quarter of the
- * traversal's slack) is replaced by the triangle's closest point computed in float64.  Consequences: the four evaluation paths
+ * traversal's slack) is not taken by a search it could win: the closest point of the triangle's boundary (the nearest of its three
+ * edges' closest points, f32) takes its place.  Consequences: the four evaluation paths
  * below (naive scan, per-lane traversal, shared traversal, hpsdf_field_eval_*) agree BIT FOR BIT on every mesh; against the
  * reference's arithmetic they differ exactly at the points where its own value is such an artefact (6 points in 8 000 random
  * meshes x 5 301 points, all on meshes squashed 100 : 1 or more; tests/test_gpu_configs.py::test_needle_meshes_one_answer_on_every_path). */

@@ -373,8 +373,8 @@ def test_needle_meshes_one_answer_on_every_path(H, O, ctx, monkeypatch, seed):
     (Utility.cpp:5-97) forms its face-case point from barycentric quotients and returns it even when the weights put it outside
     the triangle -- its absolute 1e-6 guards let that happen beside short edges -- i.e. a distance BELOW the triangle's, which a
     search sees or not depending on what it prunes (BVH.cpp:263-342 would too).  The product's rule (kernels.hip, closestSimplex):
-    a face-case point farther outside its triangle than a quarter of the traversal's slack is replaced by the float64 closest
-    point.  So: (1) the O(n) scan kernel, the per-lane traversal and the shared traversal agree BIT FOR BIT, always; (2) wherever
+    a face-case point farther outside its triangle than a quarter of the traversal's slack is not taken by a search it could win;
+    the closest point of the triangle's boundary takes its place.  So: (1) the O(n) scan kernel, the per-lane traversal and the shared traversal agree BIT FOR BIT, always; (2) wherever
     they differ from the oracle's scan (= the reference's arithmetic), the oracle's value is such an artefact -- below the
     float64 brute-force distance -- and the product's is that distance."""
     from helpers import fuzz_mesh_case, hard_points, true_distance_f64

@@ -170,8 +170,14 @@ def test_device_acosf_source_equals_host_libm_on_every_float(tmp_path):
     subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-I", os.path.join(ROOT, "hp-adaptive-signed-distance-field-octree_amd", "csrc"),
                     "-o", exe, os.path.join(ROOT, "tests", "native", "acosf_exhaustive.c"), "-lm", "-pthread"], check=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout
-    assert re.search(r"inputs 2139095042 mismatches 0\b", r.stdout), r.stdout
+    import platform
+    libc = " ".join(platform.libc_ver())
+    why = ("csrc/acosf_host_libm.hpp restates glibc's float acos as shipped up to glibc 2.40 (fdlibm e_acosf); this machine's libm (%s) "
+           "returns other bits for some inputs -- glibc >= 2.41 ships the correctly rounded CORE-MATH acosf, musl and others differ too.  "
+           "The GPU path still equals a glibc <= 2.40 build of the reference; the oracle on THIS machine calls this libm, so the mesh "
+           "parity tests that compare with it may differ in the last place of an angle weight.\n" % libc)
+    assert r.returncode == 0, why + r.stdout
+    assert re.search(r"inputs 2139095042 mismatches 0\b", r.stdout), why + r.stdout
 
 
 def test_product_sources_do_not_touch_the_oracle():
