@@ -98,6 +98,11 @@ int main(int argc, char** argv) {
         objBVH.Create(objMesh);
         std::vector<float> pts;
         double acc = 0.0;
+        // (the first one-point call fetches host copies of the arrays BVH::Create built on the device: one-point calls are answered
+        // on the calling thread from them)
+        t0 = std::chrono::steady_clock::now();
+        objMesh.SignedDistanceAtPt(meshRoot.sample(), objBVH);
+        std::printf("SignedDistanceAtPt(pt, bvh), first call (host copies of the device-built arrays): %.1f ms\n", seconds(t0) * 1e3);
         t0 = std::chrono::steady_clock::now();
         for (u32 i = 0; i < 10000; ++i) {
             const Eigen::Vector3f sample = meshRoot.sample();

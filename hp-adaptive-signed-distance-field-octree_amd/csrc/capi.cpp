@@ -537,10 +537,59 @@ static int hostRoundTrip(hpsdf_ctx* ctx, const double* xyz, size_t n, double* ou
     return hostCall(ctx, arr, 2, [&] { return run(ctx, obj, (const double*)arr[0].dev, n, (double*)arr[1].dev); });
 }
 
+// HPSDF_SMALL_QUERIES_ON_DEVICE=1 (read once) sends calls of a few points through query_few_kernel as before round 4: a measurement knob
+static bool smallQueriesOnHost() {
+    static const bool on = [] {
+        const char* e = std::getenv("HPSDF_SMALL_QUERIES_ON_DEVICE");
+        return !(e && e[0] == '1');
+    }();
+    return on;
+}
+
+// The host copies of a mesh field's arrays (made once, by the first call of a few points)
+static int meshHostMirror(const hpsdf_field* f, std::shared_ptr<hpsdf_field::HostMirror>* out) {
+    std::lock_guard<std::mutex> guard(f->hostMirrorLock);
+    if (!f->hostMirror) {
+        HPSDF_HIP(hipSetDevice(f->device));
+        auto m = std::make_shared<hpsdf_field::HostMirror>();
+        m->verts.resize(3 * (size_t)f->nVerts);
+        m->tris.resize(3 * (size_t)f->nTris);
+        m->halfEdges.resize(3 * (size_t)f->nTris);
+        m->triPos.resize((size_t)kTriRecordFloats * f->nTris);
+        m->triPre.resize((size_t)kTriPreFloats * f->nTris);
+        m->bvh.resize(std::max<size_t>(1, f->nBvhNodes));
+        HPSDF_HIP(hipDeviceSynchronize());  // (the field's arrays may still be being written on some stream)
+        HPSDF_HIP(hipMemcpy(m->verts.data(), f->dVerts, m->verts.size() * sizeof(float), hipMemcpyDeviceToHost));
+        HPSDF_HIP(hipMemcpy(m->tris.data(), f->dTris, m->tris.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HPSDF_HIP(hipMemcpy(m->halfEdges.data(), f->dHalfEdges, m->halfEdges.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HPSDF_HIP(hipMemcpy(m->triPos.data(), f->dTriPos, m->triPos.size() * sizeof(float), hipMemcpyDeviceToHost));
+        HPSDF_HIP(hipMemcpy(m->triPre.data(), f->dTriPre, m->triPre.size() * sizeof(float), hipMemcpyDeviceToHost));
+        if (f->nBvhNodes) HPSDF_HIP(hipMemcpy(m->bvh.data(), f->dBvh, (size_t)f->nBvhNodes * sizeof(BvhNode), hipMemcpyDeviceToHost));
+        MeshDev& d = m->dev;
+        d.verts = m->verts.data(), d.tris = m->tris.data(), d.halfEdges = m->halfEdges.data();
+        d.triPos = reinterpret_cast<const float4*>(m->triPos.data());
+        d.triPre = reinterpret_cast<const float4*>(m->triPre.data());
+        d.bvh = m->bvh.data(), d.slabs = nullptr;  // (the per-point traversal uses boxes and triangle records only)
+        d.nTris = f->nTris, d.nNodes = f->nBvhNodes, d.leafLog2 = f->leafLog2, d.poolCap = 0, d.stats = nullptr;
+        f->hostMirror = m;
+    }
+    *out = f->hostMirror;
+    return HPSDF_OK;
+}
+
 int hpsdf_field_eval_host(hpsdf_ctx* ctx, const hpsdf_field* f, const double* xyz, size_t n, double* out) {
     HPSDF_TRY
     if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "a device context is required");
     if (!f || (!xyz && n) || (!out && n)) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    // Mesh::SignedDistanceAtPt(pt, bvh): a call of a few points on a plain mesh field never reaches the device (~57 us as a launch;
+    // a user's SDF lambda that calls it per sample -- the reference's own usage, Mesh.cpp:54-63 -- would cost minutes per Create)
+    if (n && n <= kHostQueryPoints && f->kind == kHostMesh && f->nTris >= 1 && f->nBvhNodes >= 1 && smallQueriesOnHost()) {
+        std::shared_ptr<hpsdf_field::HostMirror> m;
+        const int rc = meshHostMirror(f, &m);
+        if (rc) return rc;
+        meshEvalHostPoints(m->dev, xyz, n, out);
+        return HPSDF_OK;
+    }
     return hostRoundTrip(
         ctx, xyz, n, out,
         [](hpsdf_ctx* c, const void* o, const double* d, size_t m, double* r) {
@@ -808,15 +857,6 @@ int hpsdf_query_device(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* dXyz, 
     if (!t || (!dXyz && n) || (!dOut && n)) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
     return queryDevice(ctx, t, dXyz, n, dOut, nullptr);
     HPSDF_CATCH
-}
-
-// HPSDF_SMALL_QUERIES_ON_DEVICE=1 (read once) sends calls of a few points through query_few_kernel as before round 4: a measurement knob
-static bool smallQueriesOnHost() {
-    static const bool on = [] {
-        const char* e = std::getenv("HPSDF_SMALL_QUERIES_ON_DEVICE");
-        return !(e && e[0] == '1');
-    }();
-    return on;
 }
 
 int hpsdf_query_host(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* xyz, size_t n, double* out) {

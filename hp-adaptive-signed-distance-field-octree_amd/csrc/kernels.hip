@@ -30,18 +30,31 @@ namespace hpsdf {
 
 // ---- mesh signed distance (all f32) ----------------------------------------
 // Source/Meshing/Utility.cpp:5-97, Source/Meshing/Mesh.cpp:54-63,162-242.
+// The per-point path below (closest-point routine, pseudo-normals, bounds, the stack traversal) also compiles for the HOST: calls of a
+// few points on a plain mesh field are answered on the calling thread from a host copy of the field's arrays (meshEvalHostPoints, at the
+// end of this file) -- same statements, -ffp-contract=off on both sides, IEEE divide and square root: the device's bits.
+#define HPSDF_HD __host__ __device__
+// a bound's square root: the raw 1-ulp instruction on the device, sqrtf on the host (bounds only have to be conservative; their slack is
+// four orders of magnitude wider than either)
+HPSDF_HD __forceinline__ float boundSqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return sqrtf(x);
+#endif
+}
 struct V3 {
     float x, y, z;
 };
-__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-__device__ __forceinline__ V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
-__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
-__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+HPSDF_HD __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+HPSDF_HD __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+HPSDF_HD __forceinline__ V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+HPSDF_HD __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+HPSDF_HD __forceinline__ V3 cross(V3 a, V3 b) {
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
-__device__ __forceinline__ float sqnorm(V3 a) { return a.x * a.x + (a.y * a.y + a.z * a.z); }
-__device__ __forceinline__ V3 normalized(V3 a) {
+HPSDF_HD __forceinline__ float sqnorm(V3 a) { return a.x * a.x + (a.y * a.y + a.z * a.z); }
+HPSDF_HD __forceinline__ V3 normalized(V3 a) {
     const float z = sqnorm(a);
     if (z > 0.0f) {
         const float n = sqrtf(z);
@@ -49,7 +62,7 @@ __device__ __forceinline__ V3 normalized(V3 a) {
     }
     return a;
 }
-__device__ __forceinline__ V3 meshVert(const MeshDev& m, uint32_t i) {
+HPSDF_HD __forceinline__ V3 meshVert(const MeshDev& m, uint32_t i) {
     return {m.verts[3 * i], m.verts[3 * i + 1], m.verts[3 * i + 2]};
 }
 
@@ -58,8 +71,8 @@ constexpr float kEpsF32 = 0.000001f;  // Include/Utility/Literals.h:13
 // A query point with a coordinate that is not a finite number has no closest triangle: every comparison of the reference's
 // search fails, its bestTri stays -1 and Mesh::SignedDistanceAtPt reads out of bounds (Mesh.cpp:139,157; BVH.cpp:281,343).
 // Here such a point takes no part in a traversal and its value is this NaN, on every path.
-__device__ __forceinline__ bool meshPointFinite(V3 p) { return fabsf(p.x) <= FLT_MAX && fabsf(p.y) <= FLT_MAX && fabsf(p.z) <= FLT_MAX; }
-__device__ __forceinline__ float meshNoTriangle() { return __uint_as_float(0xFFFFFFFFu); }
+HPSDF_HD __forceinline__ bool meshPointFinite(V3 p) { return fabsf(p.x) <= FLT_MAX && fabsf(p.y) <= FLT_MAX && fabsf(p.z) <= FLT_MAX; }
+HPSDF_HD __forceinline__ float meshNoTriangle() { return hpsdfAcosfBits(0xFFFFFFFFu); }
 
 // What closestSimplex falls back on when the reference's face case has left the triangle: the point the weights describe lies outside,
 // so the triangle's closest point is on its boundary -- the nearest of the closest points of its three edges (a + t ab, t the clamped
@@ -68,7 +81,7 @@ __device__ __forceinline__ float meshNoTriangle() { return __uint_as_float(0xFFF
 // instructions in the hot loops: the instruction cache), behind a call 3 % (2.1 M-triangle torus at 1e-6: 30.5 ms without any of
 // this, 34.5 inlined, 31.6 called).  (If the weights were wrong -- cancellation on a needle, the point really inside -- the answer is off by
 // at most the needle's width, upwards: a distance that is too large never breaks a bound.)
-__device__ __noinline__ int closestOnBoundary(V3 pt, V3 a, V3 b, V3 c, V3& q) {
+HPSDF_HD __noinline__ int closestOnBoundary(V3 pt, V3 a, V3 b, V3 c, V3& q) {
     int code = 0;
     float best = __builtin_inff();
     auto edge = [&](V3 p0, V3 p1, int edgeCode, int v0, int v1) {
@@ -101,7 +114,7 @@ __device__ __noinline__ int closestOnBoundary(V3 pt, V3 a, V3 b, V3 c, V3& q) {
 // i.e. |m| |n| / |edge| outside -- so: a face-case point farther than `tol` outside its triangle is not taken by a search that could
 // make it its best (`best`: the caller's squared distance so far); it takes the boundary's closest point instead (closestOnBoundary).  Every traversal and the O(n) scan kernel share this function, so they
 // agree bit for bit on every mesh; against the reference the value differs exactly where the reference's is such an artefact.
-__device__ int closestSimplex(V3 pt, V3 a, V3 b, V3 c, V3 n, float tol, float best, V3& q) {
+HPSDF_HD int closestSimplex(V3 pt, V3 a, V3 b, V3 c, V3 n, float tol, float best, V3& q) {
     const V3 ab = b - a, ac = c - a, bc = c - b;
     const float snom = dot(pt - a, ab), sdenom = dot(pt - b, a - b);
     const float tnom = dot(pt - a, ac), tdenom = dot(pt - c, a - c);
@@ -154,12 +167,12 @@ __device__ int closestSimplex(V3 pt, V3 a, V3 b, V3 c, V3 n, float tol, float be
     return 8;
 }
 
-__device__ V3 faceNormal(const MeshDev& m, uint32_t t) {
+HPSDF_HD V3 faceNormal(const MeshDev& m, uint32_t t) {
     const V3 a = meshVert(m, m.tris[3 * t]), b = meshVert(m, m.tris[3 * t + 1]), c = meshVert(m, m.tris[3 * t + 2]);
     return normalized(cross(b - a, c - a));
 }
 
-__device__ V3 pseudoNormal(const MeshDev& m, uint32_t t, int code) {
+HPSDF_HD V3 pseudoNormal(const MeshDev& m, uint32_t t, int code) {
     const int simplex = code >> 2, sidx = code & 3;
     if (simplex == 2) return faceNormal(m, t);
     if (simplex == 1) {  // Mesh.cpp:201-215
@@ -187,19 +200,19 @@ __device__ V3 pseudoNormal(const MeshDev& m, uint32_t t, int code) {
 }
 
 // A leaf reference (BvhNode::c0 / c1 < 0): its first slot and how many, and the triangle a slot holds.
-__device__ __forceinline__ uint32_t leafFirst(int32_t c) { return (uint32_t)~c >> kMeshLeafShift; }
-__device__ __forceinline__ uint32_t leafCount(int32_t c) { return ((uint32_t)~c & (kMeshLeafMax - 1u)) + 1u; }
+HPSDF_HD __forceinline__ uint32_t leafFirst(int32_t c) { return (uint32_t)~c >> kMeshLeafShift; }
+HPSDF_HD __forceinline__ uint32_t leafCount(int32_t c) { return ((uint32_t)~c & (kMeshLeafMax - 1u)) + 1u; }
 // A triPre record (three float4 per leaf slot): g.xyz hu | n.xyz hv | u.xyz triangle -- the triangle lies in the plane through g
 // across the unit normal n, inside the rectangle |u . (x - g)| <= hu, |v . (x - g)| <= hv of that plane (u a unit vector along its
 // longest edge, v = n x u).  n = u = 0, hu = 0, hv = rho degrades it to the ball of radius rho around g (slivers whose normal cancels).
 struct TriPre {
     float4 g, n, u;
 };
-__device__ __forceinline__ TriPre loadTriPre(const MeshDev& m, uint32_t slot) {
+HPSDF_HD __forceinline__ TriPre loadTriPre(const MeshDev& m, uint32_t slot) {
     return TriPre{m.triPre[3 * (size_t)slot], m.triPre[3 * (size_t)slot + 1], m.triPre[3 * (size_t)slot + 2]};
 }
-__device__ __forceinline__ uint32_t triPreTriangle(const TriPre& r) { return __float_as_uint(r.u.w); }
-__device__ __forceinline__ uint32_t slotTriangle(const MeshDev& m, uint32_t slot) { return __float_as_uint(m.triPre[3 * (size_t)slot + 2].w); }
+HPSDF_HD __forceinline__ uint32_t triPreTriangle(const TriPre& r) { return hpsdfAcosfWord(r.u.w); }
+HPSDF_HD __forceinline__ uint32_t slotTriangle(const MeshDev& m, uint32_t slot) { return hpsdfAcosfWord(m.triPre[3 * (size_t)slot + 2].w); }
 
 // The lower-bound test on a triPre record: with s = n . (p - g) and a = u . (p - g) the squared distance of p from the triangle is
 // at least s^2 + max(|a| - hu, 0)^2 + max(sqrt(|p - g|^2 - s^2 - a^2) - hv, 0)^2 -- two dozen instructions against the two hundred
@@ -216,13 +229,13 @@ __device__ __forceinline__ uint32_t slotTriangle(const MeshDev& m, uint32_t slot
 // (Bounds, unlike the closest-point arithmetic, need not follow the reference operation by operation: their dot products
 // are fused multiply-adds -- three instructions instead of five -- and the square root is the raw v_sqrt_f32, 1 ulp; the
 // slack they are compared with is four orders of magnitude wider than either.)
-__device__ __forceinline__ float dotF(V3 a, V3 b) { return __builtin_fmaf(a.x, b.x, __builtin_fmaf(a.y, b.y, a.z * b.z)); }
-__device__ __forceinline__ float triLowerBound2(V3 p, const TriPre& r) {
+HPSDF_HD __forceinline__ float dotF(V3 a, V3 b) { return __builtin_fmaf(a.x, b.x, __builtin_fmaf(a.y, b.y, a.z * b.z)); }
+HPSDF_HD __forceinline__ float triLowerBound2(V3 p, const TriPre& r) {
     const V3 dx = p - V3{r.g.x, r.g.y, r.g.z};
     const float sd = dotF(V3{r.n.x, r.n.y, r.n.z}, dx), ad = dotF(V3{r.u.x, r.u.y, r.u.z}, dx);
     const float lat2 = __builtin_fmaf(-ad, ad, __builtin_fmaf(-sd, sd, dotF(dx, dx)));
     const float ou = fmaxf(fabsf(ad) - r.g.w, 0.0f);
-    const float ov = fmaxf(__builtin_amdgcn_sqrtf(fmaxf(lat2, 0.0f)) - r.n.w, 0.0f);
+    const float ov = fmaxf(boundSqrt(fmaxf(lat2, 0.0f)) - r.n.w, 0.0f);
     return __builtin_fmaf(ov, ov, __builtin_fmaf(ou, ou, sd * sd));
 }
 // The slack (a distance) a lower bound must exceed the best distance by before anything is dropped.  What it has to cover
@@ -234,7 +247,7 @@ __device__ __forceinline__ float triLowerBound2(V3 p, const TriPre& r) {
 //   n . (p - g), |p - g|^2 - (n . (p - g))^2, |n| - 1: ~16 u D                                              (factor)
 // 2e-6 of the scale is three and a half times their sum.  (Round 2 ran with 2e-5; the margin it adds around every foot
 // point, sqrt(2 D slack), was most of what the samples far from the surface queued: a triangle's width and more.)
-__device__ __forceinline__ float meshSlack(const BvhNode& root) {
+HPSDF_HD __forceinline__ float meshSlack(const BvhNode& root) {
     float e2 = 0.0f, big = 0.0f;
     for (int a = 0; a < 3; ++a) {
         const float hi = fmaxf(root.hi0[a], root.hi1[a]), lo = fminf(root.lo0[a], root.lo1[a]);
@@ -246,7 +259,7 @@ __device__ __forceinline__ float meshSlack(const BvhNode& root) {
 // closestSimplex's face-case tolerance as a fraction of that slack: a point it accepts lies at most this far outside its triangle, so a
 // distance it returns is at most a quarter of the slack (plus the 3 u M of forming q) below the triangle's true distance
 constexpr float kMeshTolOfSlack = 0.25f;
-__device__ __forceinline__ float rejectBound(float best, float slack) {
+HPSDF_HD __forceinline__ float rejectBound(float best, float slack) {
     const float r = sqrtf(best) + slack;
     return r * r * 1.00001f;
 }
@@ -256,7 +269,7 @@ __device__ __forceinline__ float rejectBound(float best, float slack) {
 // guard band for f32 rounding of the box distance), so the winner equals the linear scan of
 // Mesh::ClosestTriangleToPt (Mesh.cpp:134-159) whatever the visiting order.  `hint` (the winner of the
 // caller's previous, nearby query) is tested first so that the bound is tight from the start.
-__device__ float meshSignedDistance(const MeshDev& m, V3 pt, uint32_t& hint) {
+HPSDF_HD float meshSignedDistance(const MeshDev& m, V3 pt, uint32_t& hint) {
     if (!meshPointFinite(pt)) return meshNoTriangle();
     float best = FLT_MAX, reject = __builtin_inff();
     const float slack = meshSlack(m.bvh[0]);
@@ -2962,6 +2975,18 @@ hipError_t launchPack(hipStream_t stream, const PackItem* dItems, uint32_t nItem
     const unsigned blocks = (nItems + 3) / 4;  // 4 waves per block
     hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, stream, dItems, nItems, dArena, dOut);
     return hipGetLastError();
+}
+
+// Mesh::SignedDistanceAtPt(pt, bvh) for a few points, on the calling thread: `hm` holds HOST copies of the field's arrays (capi.cpp
+// keeps them with the field after the first such call).  The per-point stack traversal of meshSignedDistance, compiled for the host
+// from the very statements the device runs: the same bits as every device path (tests/test_gpu_parity.py).
+void meshEvalHostPoints(const MeshDev& hm, const double* xyz, size_t n, double* out) {
+    // The previous answer of this thread is tried first (the `hint` of meshSignedDistance: a search that starts with a tight bound visits
+    // a fraction of the nodes; the answer does not depend on it).  Successive one-point calls of a thread are what a per-sample SDF lambda
+    // makes: neighbouring samples of one cell.
+    static thread_local uint32_t hint = 0xFFFFFFFFu;
+    for (size_t i = 0; i < n; ++i)
+        out[i] = (double)meshSignedDistance(hm, V3{(float)xyz[3 * i], (float)xyz[3 * i + 1], (float)xyz[3 * i + 2]}, hint);
 }
 
 }  // namespace hpsdf

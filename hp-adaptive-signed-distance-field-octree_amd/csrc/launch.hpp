@@ -64,6 +64,8 @@ hipError_t sortPairsU32(hipStream_t stream, void* tmp, size_t& tmpBytes, const u
 // the library's private stream-ordered pool of a device (mesh_build.hip; never the application's default pool), and its trim
 hipMemPool_t meshPool(int dev);
 void meshPoolTrim(int dev);
+// a few points of a plain mesh field on the calling thread; hm: HOST copies of the field's arrays
+void meshEvalHostPoints(const MeshDev& hm, const double* xyz, size_t n, double* out);
 // dKeys: n x 8 bytes of DEVICE memory for the per-point (distance, triangle) keys, or nullptr when dOut itself is device memory
 hipError_t launchMeshNaive(hipStream_t stream, const FieldDev& f, const double* dXyz, size_t n, double* dOut, unsigned long long* dKeys = nullptr);
 hipError_t launchAcosfSelftest(hipStream_t stream, uint32_t first, uint32_t stride, size_t n, float* dOut);

@@ -138,6 +138,17 @@ struct hpsdf_field {
     uint32_t leafLog2 = 0;              // leaves hold at most 1 << leafLog2 triangles
     uint32_t nTris = 0, nVerts = 0, nBvhNodes = 0;
     unsigned long long* dStats = nullptr;  // 4 counters, only under HPSDF_MESH_STATS=1
+    // host copies of the arrays above, made by the first call of a few points (hpsdf_field_eval_host, n <= kHostQueryPoints): such calls
+    // are answered on the calling thread (kernels.hip, meshEvalHostPoints) -- what Mesh::SignedDistanceAtPt(pt, bvh) inside a user's
+    // SDF lambda costs decides whether code written against the reference is usable as it is
+    struct HostMirror {
+        std::vector<float> verts, triPos, triPre;
+        std::vector<uint32_t> tris, halfEdges;
+        std::vector<hpsdf::BvhNode> bvh;
+        hpsdf::MeshDev dev{};
+    };
+    mutable std::shared_ptr<HostMirror> hostMirror;
+    mutable std::mutex hostMirrorLock;
     // csg wrapper
     const hpsdf_tree* oldTree = nullptr;
     int csgOp = -1;

@@ -7,9 +7,10 @@
 //   Mesh::CreateFromObj / SignedDistanceAtPt(pt, bvh, threadIdx) / CalculateMeshAABB / Clear
 //   BVH::Create(mesh) / Clear
 // The reference evaluates one point at a time on the calling host thread (per-thread priority queue, f32);
-// here BVH::Create uploads the mesh, its twin half-edges and a BVH to the GPU and every distance query runs
-// there.  The single-point signatures are kept (one kernel launch per call -- correct, not fast); the forms
-// meant for use are additive:
+// here BVH::Create uploads the mesh, its twin half-edges and a BVH to the GPU and batched distance queries run
+// there.  The single-point signature SignedDistanceAtPt(pt, bvh) is answered on the calling thread from host copies of
+// the device-built arrays (a few microseconds, the device's bits), so an SDF lambda that calls it per sample works as
+// it does against the reference; the BVH-less O(n) scan SignedDistanceAtPt(pt) is a launch per call.  Additive:
 //   Mesh::SignedDistanceAtPt(const float* xyz, n, float* out, bvh)   batched
 //   BVH::Field()   a SDF::DeviceField-compatible handle for Octree::Create(config, field): the fit kernel
 //                  samples the mesh on the GPU, no host callback in the loop.
@@ -113,7 +114,7 @@ class Mesh {  // Include/Meshing/Mesh.h:45-77
     inline f32 SignedDistanceAtPt(const Eigen::Vector3f& pt_);
     /// Batched form of the O(n) scan (additive)
     inline void SignedDistanceAtPt(const float* xyz, usize n, float* out);
-    /// > 0 implies outside mesh   (Mesh.h:54, Mesh.cpp:54-63) -- one GPU launch per call; prefer the batched form
+    /// > 0 implies outside mesh   (Mesh.h:54, Mesh.cpp:54-63) -- on the calling thread (host copies of the device-built arrays)
     inline f32 SignedDistanceAtPt(const Eigen::Vector3f& pt_, const BVH& bvh_, const u32 threadIdx_ = 0);
     /// Batched form: xyz interleaved f32 points in, f32 signed distances out (host arrays)
     inline void SignedDistanceAtPt(const float* xyz, usize n, float* out, const BVH& bvh_) const;
@@ -214,10 +215,12 @@ inline f32 Mesh::SignedDistanceAtPt(const Eigen::Vector3f& pt_) {
     return out;
 }
 inline f32 Mesh::SignedDistanceAtPt(const Eigen::Vector3f& pt_, const BVH& bvh_, const u32) {
-    const float xyz[3] = {pt_(0), pt_(1), pt_(2)};
-    float out = 0.0f;
-    SignedDistanceAtPt(xyz, 1, &out, bvh_);
-    return out;
+    // (a call of a few points is answered on the calling thread from host copies of the field's arrays: ~2 us, the device's bits)
+    if (!bvh_.Field()) throw SDF::Error(HPSDF_ERR_STATE, "BVH::Create has not succeeded");
+    const double in[3] = {(double)pt_(0), (double)pt_(1), (double)pt_(2)};  // f32 -> f64 -> f32 is exact
+    double res = 0.0;
+    SDF::check(hpsdf_field_eval_host(bvh_.Context(), bvh_.Field(), in, 1, &res));
+    return (float)res;
 }
 
 }  // namespace Meshing

@@ -366,9 +366,9 @@ def test_mesh_lower_bound_filter_keeps_the_scan_winner(H, O, ctx, monkeypatch, h
         f.close()
 
 
-@pytest.mark.parametrize("seed", [228, 489, 3624, 4851, 100758, 501177])
+@pytest.mark.parametrize("seed", [228, 489, 3624, 4851, 100758, 501177, 202581, 202707])
 def test_needle_meshes_one_answer_on_every_path(H, O, ctx, monkeypatch, seed):
-    """The six random meshes on which three rounds of tools/fuzz_mesh_bvh.py soaks saw the exhaustive scan and the hierarchy
+    """The random meshes on which four rounds of tools/fuzz_mesh_bvh.py soaks saw the exhaustive scan and the hierarchy
     disagree (spheres and tori squashed up to 1000 : 1: every triangle a needle).  The reference's closest-point routine
     (Utility.cpp:5-97) forms its face-case point from barycentric quotients and returns it even when the weights put it outside
     the triangle -- its absolute 1e-6 guards let that happen beside short edges -- i.e. a distance BELOW the triangle's, which a
@@ -389,11 +389,12 @@ def test_needle_meshes_one_answer_on_every_path(H, O, ctx, monkeypatch, seed):
     ref = O.MeshField(verts, tris).signed_distance(pts)[0].astype(np.float64)
     diff = np.nonzero(bits(ref) != bits(scan))[0]
     assert 1 <= len(diff) <= 8, len(diff)  # (the soaks found one point each)
-    ext = float(np.linalg.norm(verts.max(0) - verts.min(0)))
+    ext = max(float(np.linalg.norm(verts.max(0) - verts.min(0))), float(np.abs(verts).max()))  # the scale the slack is proportional to
     for i in diff:
         d = true_distance_f64(verts, tris, pts[i])
         assert abs(ref[i]) < d - 1e-6 * ext, (i, ref[i], d)                   # the reference's value: below the true distance
-        assert abs(abs(scan[i]) - d) <= 1e-4 * max(ext, d), (i, scan[i], d)   # the product's: the true distance
+        # the product's: not below it (beyond the slack), above it by no more than the f32 routine's conditioning on needles
+        assert -1e-5 * ext <= abs(scan[i]) - d <= 2e-4 * max(ext, d), (i, scan[i], d)
     f.close()
 
 
@@ -790,6 +791,37 @@ def test_split_fit_sharded_and_sampled_fields(H, O, ctx):
     for blk, s in _create_on_simulated_ranks(H, 2, ucfg, make_field, 1024):
         assert blk == one
     split.close(), exact.close()
+
+
+def test_split_fit_under_a_csg_wrapper(H, O, ctx):
+    """UnionSDF (Octree.cpp:355-400: the old tree queried inside the new build's field) with split fits forced from degree 4: the
+    exact kernel writes the COMBINED field value (old tree min new field) back to the sample buffer, so the matrix-core rows see
+    what the exact rows saw.  Same operand tree for both builds; node array and statistics identical to the all-exact rebuild,
+    coefficients to 1e-12, the device frontier and the host scheduler agree byte for byte."""
+    import os
+    exact, split = H.Context(0), H.Context(0)
+    exact.set_fit_mode(H.FIT_EXACT)
+    split.set_split_min_degree(4)
+    cfg = H.make_config(1e-8)
+    old_blk, _ = H.create_block(exact, cfg, H.Field.union3(), 1024)  # (leaves up to degree 5: the rebuild's jobs include from-scratch fits at 4 and 5)
+    out = {}
+    for name, c in (("exact", exact), ("split", split)):
+        old = H.DeviceTree(c, old_blk)
+        f = H.Field.tree_csg(old, H.OP_UNION, H.Field.sphere((0.3, 0.3, 0.3), 0.15))
+        out[name] = H.create_block(c, cfg, f, 1024)
+        if name == "split":
+            os.environ["HPSDF_HOST_FRONTIER"] = "1"
+            try:
+                assert H.create_block(c, cfg, f, 1024)[0] == out[name][0]
+            finally:
+                os.environ["HPSDF_HOST_FRONTIER"] = "0"
+    (eb, est), (sb, sst) = out["exact"], out["split"]
+    a, b = O.parse_block(eb), O.parse_block(sb)
+    nc = len(a["coeffs"])
+    assert sb[8 + 8 * nc:] == eb[8 + 8 * nc:] and sst == est
+    assert a["degree"][a["degree"] != 13].max() >= 4
+    assert np.abs(a["coeffs"] - b["coeffs"]).max() <= 1e-12
+    exact.close(), split.close()
 
 
 def test_fast_fit_on_a_sampled_field(H, O, ctx):

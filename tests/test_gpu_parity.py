@@ -4,6 +4,7 @@ topology; the kernels run the reference's operation order with no fused multiply
 demand BIT-IDENTICAL MemoryBlocks and Query values, which implies both."""
 import ctypes as C
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -244,6 +245,31 @@ def test_scalar_calls_answered_on_the_host_equal_the_kernels(H, O, ctx, golden):
         assert np.array_equal(bits(gv), bits(wv)) and np.array_equal(bits(gg[inside]), bits(wg[inside])) and np.all(gg[~inside] == 7.0)
         few = np.concatenate([tree.query(pts[i:i + 40]) for i in range(0, len(pts), 40)])   # 33..256 points: ONE launch of query_few_kernel
         assert np.array_equal(bits(few), bits(big))
+
+
+@pytest.mark.parametrize("host_build", [False, True])
+def test_mesh_scalar_calls_answered_on_the_host_equal_the_kernels(H, O, ctx, monkeypatch, host_build):
+    """Mesh::SignedDistanceAtPt(pt, bvh) (Mesh.cpp:54-63) one point at a time -- what a user's SDF lambda written against the
+    reference does per sample: calls of up to 32 points on a plain mesh field are answered on the calling thread from host copies
+    of the field's arrays (capi.cpp meshHostMirror, kernels.hip meshEvalHostPoints: the per-point traversal compiled for the
+    host from the statements the device runs).  Same bits as the batched device paths and the O(n) scan -- on a smooth mesh, on
+    the reference's own mesh, on a needle mesh, for points on vertices / edges / faces, in the medial region, far away, NaN."""
+    from helpers import fuzz_mesh_case, hard_points
+    if host_build:
+        monkeypatch.setenv("HPSDF_MESH_HOST_BUILD", "1")
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "halfedge_fail_mesh.npz"))
+    meshes = [icosphere(3, 0.35), (d["verts"], d["tris"].astype(np.uint64)), fuzz_mesh_case(100758)[:2]]
+    for k, (verts, tris) in enumerate(meshes):
+        f = H.Field.mesh(ctx, verts, tris)
+        pts = np.concatenate([hard_points(verts, tris, k)[::5], np.array([[np.nan, 0, 0], [np.inf, 0, 0]])])
+        want = f.eval_naive(ctx, pts)                       # the O(n) scan kernel
+        big = f.eval(ctx, pts)                              # one batched call: the shared traversal on the device
+        assert np.array_equal(bits(big), bits(want))
+        one = np.concatenate([f.eval(ctx, pts[i:i + 1]) for i in range(len(pts))])      # host, one point a call
+        assert np.array_equal(bits(one), bits(want)), k
+        some = np.concatenate([f.eval(ctx, pts[i:i + 32]) for i in range(0, len(pts), 32)])
+        assert np.array_equal(bits(some), bits(want)), k
+        f.close()
 
 
 def test_query_rejects_bad_blocks(H, ctx):
