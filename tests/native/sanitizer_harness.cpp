@@ -263,6 +263,37 @@ int main(int argc, char** argv) {
         printf("obj fuzz: 3000 corrupted files, %d still parse\n", accepted);
     }
     if (int rc = schedulerRun()) { printf("scheduler rc %d\n", rc); return rc; }
+    if (argc > 5) {
+        // host_query.cpp: scalar-sized Query / QueryWithGradient calls are answered on the calling thread from the tree handle's copy of
+        // the block.  Here, under the sanitizers and without a GPU: a handle filled the way hpsdf_tree_upload fills it, the points of
+        // argv[4] (f64 xyz) in, values and gradients out to argv[5] -- tests/test_sanitizers.py compares them with the oracle bit for bit.
+        uint64_t nc, nn;
+        memcpy(&nc, blk.data(), 8);
+        memcpy(&nn, blk.data() + 8 + 8 * nc, 8);
+        hpsdf_tree tree;
+        tree.hNodes.resize(nn);
+        memcpy(tree.hNodes.data(), blk.data() + 16 + 8 * nc, nn * sizeof(hpsdf_node));
+        tree.hCoeffs.assign((const double*)(blk.data() + 8), (const double*)(blk.data() + 8) + nc);
+        hpsdf_config cfg;
+        memcpy(&cfg, blk.data() + 16 + 8 * nc + nn * sizeof(hpsdf_node), sizeof cfg);
+        for (int a = 0; a < 3; ++a) {
+            tree.dev.rootCentre[a] = (double)((cfg.root_min[a] + cfg.root_max[a]) / 2.0f);
+            tree.dev.rootInvSizes[a] = (double)(1.0f / (cfg.root_max[a] - cfg.root_min[a]));
+        }
+        FILE* pf = fopen(argv[4], "rb");
+        fseek(pf, 0, SEEK_END); long psz = ftell(pf); fseek(pf, 0, SEEK_SET);
+        std::vector<double> xyz(psz / 8); if (fread(xyz.data(), 8, xyz.size(), pf) != xyz.size()) return 11; fclose(pf);
+        const size_t np = xyz.size() / 3;
+        std::vector<double> res(4 * np, 7.0);  // [values | gradients]; gradient rows of outside points keep the 7s
+        for (size_t i = 0; i < np; ++i) {
+            res[i] = hpsdf::hostQueryPoint(tree, xyz.data() + 3 * i);
+            double v = 0.0;
+            hpsdf::hostQueryPointWithGradient(tree, xyz.data() + 3 * i, &v, res.data() + np + 3 * i);
+            if (memcmp(&v, &res[i], 8) != 0) { printf("Query and QueryWithGradient disagree on the value of point %zu\n", i); return 12; }
+        }
+        FILE* of = fopen(argv[5], "wb"); fwrite(res.data(), 8, res.size(), of); fclose(of);
+        printf("host query: %zu points\n", np);
+    }
     printf("OK\n");
     return 0;
 }

@@ -1,7 +1,9 @@
 """The host-side native code of libhpsdf.so under AddressSanitizer + UndefinedBehaviorSanitizer (CPU build only: GPU
 sanitizers are not available on the pool).  tests/native/sanitizer_harness.cpp drives the continuity post-process
 (1/3/8 threads, truncated block), the OBJ reader (good and malformed files), the mesh preparation (closed and open
-mesh) and the round scheduler (two simulated ranks through the injection hook) in one binary built with g++."""
+mesh), the round scheduler (two simulated ranks through the injection hook) and the scalar-call path of Query /
+QueryWithGradient (csrc/host_query.cpp: 5 000 points incl. the edge cases, compared with the oracle bit for bit) in one
+binary built with g++."""
 import os
 import subprocess
 
@@ -16,7 +18,7 @@ CSRC = os.path.join(ROOT, "hp-adaptive-signed-distance-field-octree_amd", "csrc"
 def test_host_native_code_is_clean_under_asan_ubsan(O, tmp_path):
     exe = str(tmp_path / "harness")
     srcs = [os.path.join(ROOT, "tests", "native", "sanitizer_harness.cpp")] + \
-           [os.path.join(CSRC, f) for f in ("continuity.cpp", "tables.cpp", "obj.cpp", "mesh.cpp", "builder.cpp")]
+           [os.path.join(CSRC, f) for f in ("continuity.cpp", "tables.cpp", "obj.cpp", "mesh.cpp", "builder.cpp", "host_query.cpp")]
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=all",
            "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I", CSRC, "-I", os.path.join(ROOT, "include")] + srcs + \
           ["-o", exe, "-pthread", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"]
@@ -33,7 +35,19 @@ def test_host_native_code_is_clean_under_asan_ubsan(O, tmp_path):
         for a, b, c in t:
             fh.write("f %d/1/1 %d/1/1 %d/1/1\n" % (a + 1, b + 1, c + 1))
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
-    r = subprocess.run([exe, str(tmp_path / "blk.bin"), str(tmp_path / "ico.obj"), str(tmp_path / "bad.obj")],
-                       capture_output=True, text=True, timeout=600, env=env)
+    # the scalar-call path of Query / QueryWithGradient (csrc/host_query.cpp) on the same block: edge points, outside points, NaN
+    from helpers import edge_points
+    pts = np.concatenate([O.splitmix64_points(3000, seed=4), edge_points(np.random.default_rng(2), 2000)])
+    pts.astype(np.float64).tofile(tmp_path / "pts.bin")
+    r = subprocess.run([exe, str(tmp_path / "blk.bin"), str(tmp_path / "ico.obj"), str(tmp_path / "bad.obj"), str(tmp_path / "pts.bin"),
+                        str(tmp_path / "res.bin")], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-2000:] + r.stderr[-4000:]
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
+    res = np.fromfile(tmp_path / "res.bin", np.float64)
+    n = len(pts)
+    otree = O.Tree.from_block(blk)
+    wv, wg = otree.query_with_gradient(pts)
+    assert np.array_equal(res[:n].view(np.uint64), otree.query(pts).view(np.uint64))      # Octree::Query, bit for bit
+    inside = wv < 1e300
+    got_g = res[n:].reshape(n, 3)
+    assert np.array_equal(got_g[inside].view(np.uint64), wg[inside].view(np.uint64)) and np.all(got_g[~inside] == 7.0)
