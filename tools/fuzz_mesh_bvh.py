@@ -32,6 +32,10 @@ for seed in range(first, first + cases):
     a, w = f.eval_lane(ctx, pts), f.eval_wave(ctx, pts)
     # strict: scan kernel, per-lane traversal and shared traversal share closestSimplex and its face-case rule -- one answer, always
     ok = np.array_equal(bits(a), bits(want)) and np.array_equal(bits(w), bits(want))
+    # ... and the calling-thread path of scalar-sized calls (host copies of the arrays, the per-point traversal compiled for the host)
+    idx = np.arange(seed % 7, len(pts), 23)
+    one = np.concatenate([f.eval(ctx, pts[i:i + 1]) for i in idx])
+    ok = ok and np.array_equal(bits(one), bits(want[idx]))
     note = ""
     if ok and check_ref and len(tris) <= 25000:
         # against the reference's arithmetic (the oracle's scan): a difference must be a reference artefact -- a face-case point that
