@@ -107,6 +107,8 @@ _SIGNATURES = {
     "hpsdf_ctx_set_fit_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "hpsdf_ctx_get_fit_mode": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "hpsdf_ctx_set_split_min_degree": (C.c_int, [C.c_void_p, C.c_int]),
+    "hpsdf_set_reduction_order": (None, [C.c_int]),
+    "hpsdf_get_reduction_order": (C.c_int, []),
     "hpsdf_ctx_stream": (C.c_void_p, [C.c_void_p]),
     "hpsdf_field_create_analytic": (C.c_int, [C.POINTER(Prim), C.c_int, C.POINTER(C.c_void_p)]),
     "hpsdf_field_create_callback": (C.c_int, [CALLBACK, C.c_void_p, C.POINTER(C.c_void_p)]),
@@ -267,6 +269,16 @@ class Config:
 
 
 FIT_EXACT, FIT_SPLIT, FIT_FAST = 0, 1, 2
+
+
+def set_reduction_order(left_assoc):
+    """Eigen's 3-vector reductions (prod / norm / normalize) as (a . b) . c (True) instead of a . (b . c) (False, the default): which one
+    the reference computes depends on how its Eigen was built (include/hpsdf.h).  Process-wide; set it between calls, not during."""
+    lib().hpsdf_set_reduction_order(1 if left_assoc else 0)
+
+
+def reduction_order():
+    return int(lib().hpsdf_get_reduction_order())
 
 
 def make_config(target=1e-10, root_min=(-0.5, -0.5, -0.5), root_max=(0.5, 0.5, 0.5), threads=1, continuity=False):

@@ -1,6 +1,7 @@
 // C ABI of include/hpsdf.h: contexts, fields, tree upload + batched Query, the stepwise build.
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
 #include <cfloat>
 #include <chrono>
 #include <cmath>
@@ -46,6 +47,14 @@ const hpsdf_field* innermost(const hpsdf_field* f) {
     return f;
 }
 
+static int envLeftAssoc() {
+    const char* e = std::getenv("HPSDF_REDUCTION_ORDER");  // "left" / "1": (a . b) . c from the start
+    return e && (e[0] == 'l' || e[0] == 'L' || e[0] == '1');
+}
+static std::atomic<int> gLeftAssoc{envLeftAssoc()};
+int reductionLeftAssoc() { return gLeftAssoc.load(std::memory_order_relaxed); }
+void setReductionLeftAssoc(int left) { gLeftAssoc.store(left != 0, std::memory_order_relaxed); }
+
 int makeFieldDev(const hpsdf_field* f, const double* dSamples, FieldDev* out) {
     std::memset(out, 0, sizeof(*out));
     out->csgOp = -1;
@@ -87,6 +96,7 @@ int makeFieldDev(const hpsdf_field* f, const double* dSamples, FieldDev* out) {
         default:
             return fail(HPSDF_ERR_INVALID_ARGUMENT, "unknown field kind");
     }
+    out->leftAssoc = reductionLeftAssoc();
     return HPSDF_OK;
 }
 
@@ -324,6 +334,8 @@ int hpsdf_ctx_set_split_min_degree(hpsdf_ctx* c, int degree) {
     c->splitMinDegree = degree;
     return HPSDF_OK;
 }
+void hpsdf_set_reduction_order(int left_assoc) { setReductionLeftAssoc(left_assoc); }
+int hpsdf_get_reduction_order(void) { return reductionLeftAssoc(); }
 int hpsdf_ctx_set_fast_fit(hpsdf_ctx* c, int on) { return hpsdf_ctx_set_fit_mode(c, on ? HPSDF_FIT_FAST : HPSDF_FIT_SPLIT); }
 
 int hpsdf_ctx_synchronize(hpsdf_ctx* c) {
@@ -845,7 +857,9 @@ static int queryDevice(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* dXyz, 
                 ctx->deferCap = need;
             }
         }
-        HPSDF_HIP(launchQuery(ctx->stream, t->dev, ctx->dTables, dXyz + 3 * off, m, dOut + off, dGrad ? dGrad + 3 * off : nullptr,
+        TreeDev td = t->dev;
+        td.leftAssoc = reductionLeftAssoc();
+        HPSDF_HIP(launchQuery(ctx->stream, td, ctx->dTables, dXyz + 3 * off, m, dOut + off, dGrad ? dGrad + 3 * off : nullptr,
                               t->allInline, ctx->dDeferCount, ctx->dDefer));
     }
     return HPSDF_OK;

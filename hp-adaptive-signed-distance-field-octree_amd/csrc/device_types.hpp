@@ -46,6 +46,8 @@ struct TreeDev {
     const double* coeffs;    // per-leaf blocks, each padded to whole 128-byte lines
     int32_t topDepth;        // every node above this depth is interior (1..5)
     int32_t maxDegree;
+    int32_t leftAssoc;       // hpsdf_set_reduction_order() at the time of the launch (the gradient's normalize())
+    int32_t pad;
     double nlTop[3];         // NormalisedLengths[j][topDepth], j <= 2 (degrees of the inline leaves)
     double rootCentre[3];    // Octree.cpp:322 (f32 centre widened)
     double rootInvSizes[3];  // Octree.cpp:323 (f32 reciprocal widened)
@@ -104,7 +106,7 @@ struct FieldDev {
     int32_t kind;      // FieldKind of the innermost field
     int32_t nPrims;
     int32_t csgOp;     // -1: none; else HPSDF_OP_* combining oldTree.Query with the inner field
-    int32_t pad;
+    int32_t leftAssoc;  // hpsdf_set_reduction_order(): Eigen's 3-vector reductions as (a . b) . c instead of a . (b . c)
     hpsdf_prim prims[HPSDF_MAX_PRIMS];
     const double* samples;  // kFieldSamples: F values, indexed by FitTask::sampleOff + sample number
     MeshDev mesh;

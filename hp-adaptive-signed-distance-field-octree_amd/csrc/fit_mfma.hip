@@ -41,7 +41,7 @@ __host__ __device__ constexpr int mfmaCoef(int p) { return p == 6 ? 83 : (p + 1)
 // them out one MFMA, one tile's worth of LDS reads and VALU work at a time.
 // LOW: the rows below the top degree of a split fit (FitBlock::split, device_types.hpp) -- the cells of a tile may differ in depth
 // (the normalisation is looked up per cell), and no error is formed: the top-degree rows, which alone enter it, are fit_kernel's.
-template <int KIND, int TN, int KW, bool LOW = false>
+template <int KIND, int TN, int KW, bool LEFT, bool LOW = false>
 __device__ __forceinline__ void mfmaContract(const FitBlock& blk, const FitTask* __restrict__ tasks, double* __restrict__ arena,
                                              double* __restrict__ errs, const DeviceTables* __restrict__ T, const FieldDev& field,
                                              const RootMap& rm, const double* sT, const double* sR, const double* sW, const double* sNl,
@@ -59,7 +59,7 @@ __device__ __forceinline__ void mfmaContract(const FitBlock& blk, const FitTask*
         sc[a] = (double)(tk.bmax[a] - tk.bmin[a]) * 0.5;     // :1020 sizes() in f32
         ce[a] = (double)((tk.bmin[a] + tk.bmax[a]) / 2.0f);  // :1021 center() in f32
     }
-    const double S = cellLive ? sc[0] * (sc[1] * sc[2]) : 0.0;  // :1022 (0: a cell slot beyond the block contributes nothing)
+    const double S = cellLive ? prod3<LEFT>(sc[0], sc[1], sc[2]) : 0.0;  // :1022 (0: a cell slot beyond the block contributes nothing)
     const uint64_t sampleOff = tk.sampleOff;
     // this lane's row per tile: offsets of its three P rows into sT; rows beyond rowEnd read the zero row appended to sT
     const int zeroRow = (deg + 1) * nq;
@@ -99,10 +99,10 @@ __device__ __forceinline__ void mfmaContract(const FitBlock& blk, const FitTask*
         const double wz = uz * rm.bounds[2] + rm.centre[2];
         double fv;
         if constexpr (KIND == kFieldAnalytic)
-            fv = analyticEval(field, xi, yj, wz);
+            fv = analyticEval<LEFT>(field, xi, yj, wz);
         else
             fv = field.samples[sampleOff + (uint64_t)(live && cellLive ? (i * nq + j) * nq + k : 0)];
-        a = (live ? S : 0.0) * (wi * (wj * sW[kk])) * fv;  // :1040
+        a = (live ? S : 0.0) * prod3<LEFT>(wi, wj, sW[kk]) * fv;  // :1040
 #pragma unroll
         for (int t = 0; t < TN; ++t) b[t] = u[t] * sT[(off[t] >> 20) + kk];
     };
@@ -210,7 +210,7 @@ template <int DEG>
 struct MfmaWaves {
     static constexpr int value = DEG <= 8 ? 8 : 4;
 };
-template <int KIND, int DEG>
+template <int KIND, int DEG, bool LEFT>
 __global__ __launch_bounds__(64 * MfmaWaves<DEG>::value) void fit_mfma_kernel(const FitBlock* __restrict__ blocks, const FitTask* __restrict__ tasks,
                                                        double* __restrict__ arena, double* __restrict__ errs,
                                                        const DeviceTables* __restrict__ T, FieldDev field, RootMap rm,
@@ -245,16 +245,16 @@ __global__ __launch_bounds__(64 * MfmaWaves<DEG>::value) void fit_mfma_kernel(co
     }
     __syncthreads();
     if (blk.rowStart == 0)
-        mfmaContract<KIND, NT, KW>(blk, tasks, arena, errs, T, field, rm, sT, sR, sW, sNl, sRed);
+        mfmaContract<KIND, NT, KW, LEFT>(blk, tasks, arena, errs, T, field, rm, sT, sR, sW, sNl, sRed);
     else
-        mfmaContract<KIND, NTI, KW>(blk, tasks, arena, errs, T, field, rm, sT, sR, sW, sNl, sRed);
+        mfmaContract<KIND, NTI, KW, LEFT>(blk, tasks, arena, errs, T, field, rm, sT, sR, sW, sNl, sRed);
 }
 
 // The rows below the top degree of the split fits of degree DEG (the default for from-scratch fits of degree >= 4): tasks
 // [range[0], range[0] + range[1]) are from-scratch fits of degree DEG in any mix of depths, 16 to a workgroup; their field values
 // are in the sample buffer (fit_kernel wrote them back while it fitted the top-degree rows, or the mesh sampler put them there);
 // rows [0, ncoef(DEG - 1)) go to the start of every task's array.  No FitBlock list: a tile is 16 consecutive tasks.
-template <int DEG>
+template <int DEG, bool LEFT>
 __global__ __launch_bounds__(64 * MfmaWaves<DEG>::value) void fit_mfma_low_kernel(const FitTask* __restrict__ tasks, double* __restrict__ arena,
                                                                                     const DeviceTables* __restrict__ T, FieldDev field, RootMap rm,
                                                                                     const uint32_t* __restrict__ range, uint32_t first, uint32_t count) {
@@ -289,15 +289,15 @@ __global__ __launch_bounds__(64 * MfmaWaves<DEG>::value) void fit_mfma_low_kerne
         sT[(DEG + 1) * NQ + q] = 0.0;
     }
     __syncthreads();
-    mfmaContract<kFieldSamples, NTL, KW, true>(blk, tasks, arena, nullptr, T, field, rm, sT, sR, sW, sNl, sRed);
+    mfmaContract<kFieldSamples, NTL, KW, LEFT, true>(blk, tasks, arena, nullptr, T, field, rm, sT, sR, sW, sNl, sRed);
 }
 
-template <int KIND>
+template <int KIND, bool LEFT>
 void launchMfmaT(hipStream_t stream, int degree, const FitBlock* dBlocks, uint32_t nBlocks, const FitTask* dTasks, double* dArena, double* dErrs,
                  const DeviceTables* dTables, const FieldDev& field, const RootMap& rm, const uint32_t* dRange) {
 #define HPSDF_MFMA_CASE(D)                                                                                                        \
     case D:                                                                                                                       \
-        hipLaunchKernelGGL((fit_mfma_kernel<KIND, D>), dim3(nBlocks), dim3(64 * MfmaWaves<D>::value), 0, stream, dBlocks, dTasks, dArena, dErrs, dTables, field, \
+        hipLaunchKernelGGL((fit_mfma_kernel<KIND, D, LEFT>), dim3(nBlocks), dim3(64 * MfmaWaves<D>::value), 0, stream, dBlocks, dTasks, dArena, dErrs, dTables, field, \
                            rm, dRange);                                                                                           \
         break;
     switch (degree) {
@@ -331,10 +331,13 @@ hipError_t launchFitMfma(hipStream_t stream, int degree, const FitBlock* dBlocks
                          double* dErrs, const DeviceTables* dTables, const FieldDev& field, const RootMap& rm, const uint32_t* dRange) {
     if (nBlocks == 0) return hipSuccess;
     if (!fitMfmaSupports(degree, field)) return hipErrorInvalidValue;
-    if (field.kind == kFieldAnalytic)
-        launchMfmaT<kFieldAnalytic>(stream, degree, dBlocks, nBlocks, dTasks, dArena, dErrs, dTables, field, rm, dRange);
-    else
-        launchMfmaT<kFieldSamples>(stream, degree, dBlocks, nBlocks, dTasks, dArena, dErrs, dTables, field, rm, dRange);
+    if (field.kind == kFieldAnalytic) {
+        if (field.leftAssoc) launchMfmaT<kFieldAnalytic, true>(stream, degree, dBlocks, nBlocks, dTasks, dArena, dErrs, dTables, field, rm, dRange);
+        else launchMfmaT<kFieldAnalytic, false>(stream, degree, dBlocks, nBlocks, dTasks, dArena, dErrs, dTables, field, rm, dRange);
+    } else {
+        if (field.leftAssoc) launchMfmaT<kFieldSamples, true>(stream, degree, dBlocks, nBlocks, dTasks, dArena, dErrs, dTables, field, rm, dRange);
+        else launchMfmaT<kFieldSamples, false>(stream, degree, dBlocks, nBlocks, dTasks, dArena, dErrs, dTables, field, rm, dRange);
+    }
     return hipGetLastError();
 }
 
@@ -361,12 +364,16 @@ hipError_t launchFitMfmaLow(hipStream_t stream, int degree, const FitTask* dTask
     if (!fitSplitSupports(degree, 4) || dSamples == nullptr) return hipErrorInvalidValue;
     FieldDev fd;
     std::memset(&fd, 0, sizeof fd);
-    fd.kind = kFieldSamples, fd.csgOp = -1, fd.samples = dSamples;
+    fd.kind = kFieldSamples, fd.csgOp = -1, fd.samples = dSamples, fd.leftAssoc = reductionLeftAssoc();
     const unsigned grid = (n + (uint32_t)kMfmaCells - 1u) / (uint32_t)kMfmaCells;
 #define HPSDF_LOW_CASE(D)                                                                                                                  \
     case D:                                                                                                                                \
-        hipLaunchKernelGGL((fit_mfma_low_kernel<D>), dim3(grid), dim3(64 * MfmaWaves<D>::value), 0, stream, dTasks, dArena, dTables, fd, rm, \
-                           dRange, first, count);                                                                                          \
+        if (fd.leftAssoc)                                                                                                                  \
+            hipLaunchKernelGGL((fit_mfma_low_kernel<D, true>), dim3(grid), dim3(64 * MfmaWaves<D>::value), 0, stream, dTasks, dArena, dTables, fd, rm, \
+                               dRange, first, count);                                                                                      \
+        else                                                                                                                               \
+            hipLaunchKernelGGL((fit_mfma_low_kernel<D, false>), dim3(grid), dim3(64 * MfmaWaves<D>::value), 0, stream, dTasks, dArena, dTables, fd, rm, \
+                               dRange, first, count);                                                                                      \
         break;
     switch (degree) {
         HPSDF_LOW_CASE(4)

@@ -1034,7 +1034,7 @@ __device__ __forceinline__ double evalLeafVals(const double (&cv)[NV], double ux
 // query_grad_kernel's any-degree loop (and as the oracle), with the tables in registers.
 template <int P, int NV>
 __device__ __forceinline__ double evalLeafGradVals(const double (&cv)[NV], const double (&u)[3], int depth, const double* sNl,
-                                                   const double* sRec, double (&g)[3]) {
+                                                   const double* sRec, double (&g)[3], int left) {
     constexpr int N = coeffCount(P);
     static_assert(NV >= N, "coefficient registers");
     const double eps = 0.0001;
@@ -1061,7 +1061,7 @@ __device__ __forceinline__ double evalLeafGradVals(const double (&cv)[NV], const
         }
         g[k] = (p1 - m1) / (2.0 * eps);
     }
-    const double z = g[0] * g[0] + (g[1] * g[1] + g[2] * g[2]);  // Eigen normalize()
+    const double z = left ? sum3<true>(g[0] * g[0], g[1] * g[1], g[2] * g[2]) : sum3<false>(g[0] * g[0], g[1] * g[1], g[2] * g[2]);  // Eigen normalize()
     if (z > 0.0) {
         const double nrm = sqrt(z);
         g[0] = g[0] / nrm, g[1] = g[1] / nrm, g[2] = g[2] / nrm;
@@ -1534,10 +1534,10 @@ __device__ __forceinline__ void queryGeneralBody(const TreeDev& t, const DeviceT
         if (inside) {
             if constexpr (GRAD) {
                 switch (degree) {
-                    case 0: r = evalLeafGradVals<0>(cv, u, depth, sNl, sRec, g); break;
-                    case 1: r = evalLeafGradVals<1>(cv, u, depth, sNl, sRec, g); break;
-                    case 2: r = evalLeafGradVals<2>(cv, u, depth, sNl, sRec, g); break;
-                    case 3: r = evalLeafGradVals<3>(cv, u, depth, sNl, sRec, g); break;
+                    case 0: r = evalLeafGradVals<0>(cv, u, depth, sNl, sRec, g, t.leftAssoc); break;
+                    case 1: r = evalLeafGradVals<1>(cv, u, depth, sNl, sRec, g, t.leftAssoc); break;
+                    case 2: r = evalLeafGradVals<2>(cv, u, depth, sNl, sRec, g, t.leftAssoc); break;
+                    case 3: r = evalLeafGradVals<3>(cv, u, depth, sNl, sRec, g, t.leftAssoc); break;
                     default: defer = valid; break;
                 }
             } else {
@@ -1739,7 +1739,7 @@ __device__ void queryPointWithGradient(const TreeDev& t, size_t i, const double*
         }
         g[k] = (p1 - m1) / (2.0 * eps);
     }
-    const double z = g[0] * g[0] + (g[1] * g[1] + g[2] * g[2]);  // Eigen normalize()
+    const double z = t.leftAssoc ? sum3<true>(g[0] * g[0], g[1] * g[1], g[2] * g[2]) : sum3<false>(g[0] * g[0], g[1] * g[1], g[2] * g[2]);  // Eigen normalize()
     if (z > 0.0) {
         const double nrm = sqrt(z);
         g[0] = g[0] / nrm, g[1] = g[1] / nrm, g[2] = g[2] / nrm;
@@ -1881,12 +1881,12 @@ __device__ __forceinline__ double applyCsg(const FieldDev& f, double v, double x
 }
 
 // F at a world-space point, with the optional CSG wrapper of Octree.cpp:355-400
-template <int KIND, bool CSG>
+template <int KIND, bool CSG, bool LEFT>
 __device__ __forceinline__ double fieldEvalWorld(const FieldDev& f, double x, double y, double z, uint64_t sampleIdx,
                                                  const double* sNl, const double* sRec, uint32_t& meshHint) {
     double v;
     if constexpr (KIND == kFieldAnalytic)
-        v = analyticEval(f, x, y, z);
+        v = analyticEval<LEFT>(f, x, y, z);
     else if constexpr (KIND == kFieldSamples)
         v = f.samples[sampleIdx];
     else  // SURVEY 3.4 user glue: (f64) mesh.SignedDistanceAtPt(p.cast<f32>())
@@ -1894,7 +1894,7 @@ __device__ __forceinline__ double fieldEvalWorld(const FieldDev& f, double x, do
     return applyCsg<CSG>(f, v, x, y, z, sNl, sRec);
 }
 
-template <int KIND, bool CSG>
+template <int KIND, bool CSG, bool LEFT>
 __global__ __launch_bounds__(256) void field_kernel(FieldDev f, const DeviceTables* __restrict__ T,
                                                     const double* __restrict__ xyz, size_t n, double* __restrict__ out) {
     __shared__ double sNl[13 * 11];
@@ -1904,7 +1904,7 @@ __global__ __launch_bounds__(256) void field_kernel(FieldDev f, const DeviceTabl
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     uint32_t hint = 0xFFFFFFFFu;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        out[i] = fieldEvalWorld<KIND, CSG>(f, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], i, sNl, sRec, hint);
+        out[i] = fieldEvalWorld<KIND, CSG, LEFT>(f, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], i, sNl, sRec, hint);
 }
 
 // ---------------------------------------------------------------------------
@@ -1984,7 +1984,7 @@ __device__ __forceinline__ double fitRowAny(double acc, double a1, const double*
 // R > 1 (DEG > 0 only): a thread owns one row of R cells.  The product Lp of a sample does not depend on
 // the cell (all cells of a workgroup share degree and depth), so it is formed once per sample and used
 // for R accumulators: 2 + 3/R multiply/add instructions per (cell, sample, row) instead of 5.
-template <int KIND, bool CSG, int DEG, int R>
+template <int KIND, bool CSG, int DEG, int R, bool LEFT>
 __device__ __forceinline__ void fitBlockBody(const FitBlock blk, const FitTask* __restrict__ tasks, double* __restrict__ arena,
                                              double* __restrict__ errs, double* __restrict__ means,
                                              const DeviceTables* __restrict__ T, const FieldDev& field, const RootMap& rm, double* lds) {
@@ -2030,7 +2030,7 @@ __device__ __forceinline__ void fitBlockBody(const FitBlock blk, const FitTask* 
             sC[8 * g + 3 + a] = (double)((tk.bmin[a] + tk.bmax[a]) / 2.0f);  // :1021 center() in f32
             sC[8 * g + a] = sc[a];
         }
-        sC[8 * g + 6] = sc[0] * (sc[1] * sc[2]);  // :1022 Eigen prod(): a*(b*c)
+        sC[8 * g + 6] = prod3<LEFT>(sc[0], sc[1], sc[2]);  // :1022 Eigen prod()
         sC[8 * g + 7] = __longlong_as_double((long long)tk.sampleOff);
     }
     __syncthreads();
@@ -2118,10 +2118,10 @@ __device__ __forceinline__ void fitBlockBody(const FitBlock blk, const FitTask* 
                                                                  sMeshStack[tid >> 6]);
                 fv = activeS ? applyCsg<CSG>(field, mv, wx, wy, wz, sNl, sRec) : 0.0;
             } else {
-                fv = activeS ? fieldEvalWorld<KIND, CSG>(field, wx, wy, wz, sidx, sNl, sRec, meshHint) : 0.0;
+                fv = activeS ? fieldEvalWorld<KIND, CSG, LEFT>(field, wx, wy, wz, sidx, sNl, sRec, meshHint) : 0.0;
             }
             if (activeS) {
-                sF[g * cellStride + rem] = c[6] * (sW[i] * (sW[j] * sW[k])) * fv;  // :1040
+                sF[g * cellStride + rem] = c[6] * prod3<LEFT>(sW[i], sW[j], sW[k]) * fv;  // :1040
                 // a split fit (FitBlock::split): the field's value goes (back) into the sample buffer, from where
                 // fit_mfma_low_kernel contracts the rows below the top degree
                 if constexpr (KIND != kFieldMesh)
@@ -2221,7 +2221,7 @@ __device__ __forceinline__ void fitBlockBody(const FitBlock blk, const FitTask* 
 // handed out from the END of the array -- highest degree, longest fits first -- and workgroups of every degree share the chip
 // at once, which is what the per-degree launches on side streams were for (their fork / join events cost 20-50 us a round).
 // count: the round's number of blocks, written by the device; the grid is an upper bound.
-template <int KIND, bool CSG>
+template <int KIND, bool CSG, bool LEFT>
 __global__ __launch_bounds__(kFitThreads, HPSDF_FIT_MIN_WAVES) void fit_multi_kernel(const FitBlock* __restrict__ blocks,
                                                                 const FitTask* __restrict__ tasks, double* __restrict__ arena,
                                                                 double* __restrict__ errs, const DeviceTables* __restrict__ T,
@@ -2232,11 +2232,11 @@ __global__ __launch_bounds__(kFitThreads, HPSDF_FIT_MIN_WAVES) void fit_multi_ke
     if (blockIdx.x >= n) return;
     const FitBlock blk = blocks[n - 1u - blockIdx.x];
     switch (blk.degree) {
-        case 2: fitBlockBody<KIND, CSG, 2, 1>(blk, tasks, arena, errs, nullptr, T, field, rm, lds); break;
-        case 3: fitBlockBody<KIND, CSG, 3, 1>(blk, tasks, arena, errs, nullptr, T, field, rm, lds); break;
-        case 4: fitBlockBody<KIND, CSG, 4, 1>(blk, tasks, arena, errs, nullptr, T, field, rm, lds); break;
-        case 5: fitBlockBody<KIND, CSG, 5, 1>(blk, tasks, arena, errs, nullptr, T, field, rm, lds); break;
-        default: fitBlockBody<KIND, CSG, 0, 1>(blk, tasks, arena, errs, nullptr, T, field, rm, lds); break;
+        case 2: fitBlockBody<KIND, CSG, 2, 1, LEFT>(blk, tasks, arena, errs, nullptr, T, field, rm, lds); break;
+        case 3: fitBlockBody<KIND, CSG, 3, 1, LEFT>(blk, tasks, arena, errs, nullptr, T, field, rm, lds); break;
+        case 4: fitBlockBody<KIND, CSG, 4, 1, LEFT>(blk, tasks, arena, errs, nullptr, T, field, rm, lds); break;
+        case 5: fitBlockBody<KIND, CSG, 5, 1, LEFT>(blk, tasks, arena, errs, nullptr, T, field, rm, lds); break;
+        default: fitBlockBody<KIND, CSG, 0, 1, LEFT>(blk, tasks, arena, errs, nullptr, T, field, rm, lds); break;
     }
 }
 
@@ -2292,7 +2292,7 @@ __global__ __launch_bounds__(kFitThreads) void fit_weight_kernel(const FitBlock*
 // workgroup b fits blocks[range[0] + b] if b < range[1]: the device-side frontier (frontier.hip) writes the round's block
 // list and its per-degree ranges itself, so the host never learns how many blocks a round has before it launches the fits
 // (a grid-stride loop over the range instead cost 37 more VGPRs at degree 3-4: one wave per SIMD less).
-template <int KIND, bool CSG, int DEG, int R>
+template <int KIND, bool CSG, int DEG, int R, bool LEFT>
 __global__ __launch_bounds__(kFitThreads, HPSDF_FIT_MIN_WAVES) void fit_kernel(const FitBlock* __restrict__ blocks,
                                                           const FitTask* __restrict__ tasks, double* __restrict__ arena,
                                                           double* __restrict__ errs, double* __restrict__ means,
@@ -2304,7 +2304,7 @@ __global__ __launch_bounds__(kFitThreads, HPSDF_FIT_MIN_WAVES) void fit_kernel(c
         if (b >= range[1]) return;
         b += range[0];
     }
-    fitBlockBody<KIND, CSG, DEG, R>(blocks[b], tasks, arena, errs, means, T, field, rm, lds);
+    fitBlockBody<KIND, CSG, DEG, R, LEFT>(blocks[b], tasks, arena, errs, means, T, field, rm, lds);
 }
 
 // ---------------------------------------------------------------------------
@@ -2761,12 +2761,12 @@ hipError_t launchFitWeight(hipStream_t stream, const FitBlock* dBlocks, uint32_t
     return hipGetLastError();
 }
 
-template <int KIND, bool CSG>
+template <int KIND, bool CSG, bool LEFT>
 static void launchFitT(hipStream_t stream, int degree, int cellsPerThread, const FitBlock* dBlocks, uint32_t nBlocks,
                        size_t ldsBytes, const FitTask* dTasks, double* dArena, double* dErrs, double* dMeans,
                        const DeviceTables* dTables, const FieldDev& field, const RootMap& rm, const uint32_t* dRange) {
 #define HPSDF_FIT_LAUNCH(D, RR)                                                                                       \
-    hipLaunchKernelGGL((fit_kernel<KIND, CSG, D, RR>), dim3(nBlocks), dim3(kFitThreads), ldsBytes, stream, dBlocks, \
+    hipLaunchKernelGGL((fit_kernel<KIND, CSG, D, RR, LEFT>), dim3(nBlocks), dim3(kFitThreads), ldsBytes, stream, dBlocks, \
                        dTasks, dArena, dErrs, dMeans, dTables, field, rm, dRange)
 #define HPSDF_FIT_CASE(D)       \
     case D:                     \
@@ -2785,32 +2785,38 @@ static void launchFitT(hipStream_t stream, int degree, int cellsPerThread, const
 #undef HPSDF_FIT_LAUNCH
 }
 
-#define HPSDF_DISPATCH_FIELD(FN, field, ...)                                     \
-    do {                                                                         \
-        const bool csg_ = (field).csgOp >= 0;                                    \
-        switch ((field).kind) {                                                  \
-            case kFieldAnalytic:                                                 \
-                if (csg_) FN<kFieldAnalytic, true>(__VA_ARGS__);                 \
-                else FN<kFieldAnalytic, false>(__VA_ARGS__);                     \
-                break;                                                           \
-            case kFieldSamples:                                                  \
-                if (csg_) FN<kFieldSamples, true>(__VA_ARGS__);                  \
-                else FN<kFieldSamples, false>(__VA_ARGS__);                      \
-                break;                                                           \
-            default:                                                             \
-                if (csg_) FN<kFieldMesh, true>(__VA_ARGS__);                     \
-                else FN<kFieldMesh, false>(__VA_ARGS__);                         \
-                break;                                                           \
-        }                                                                        \
+// FN<kind, csg wrapper, reduction order>(...): the instantiation for a FieldDev
+#define HPSDF_DISPATCH_FIELD_ORDER(FN, K, C, field, ...)  \
+    do {                                                  \
+        if ((field).leftAssoc) FN<K, C, true>(__VA_ARGS__); \
+        else FN<K, C, false>(__VA_ARGS__);                \
+    } while (0)
+#define HPSDF_DISPATCH_FIELD(FN, field, ...)                                                        \
+    do {                                                                                            \
+        const bool csg_ = (field).csgOp >= 0;                                                       \
+        switch ((field).kind) {                                                                     \
+            case kFieldAnalytic:                                                                    \
+                if (csg_) HPSDF_DISPATCH_FIELD_ORDER(FN, kFieldAnalytic, true, field, __VA_ARGS__); \
+                else HPSDF_DISPATCH_FIELD_ORDER(FN, kFieldAnalytic, false, field, __VA_ARGS__);     \
+                break;                                                                              \
+            case kFieldSamples:                                                                     \
+                if (csg_) HPSDF_DISPATCH_FIELD_ORDER(FN, kFieldSamples, true, field, __VA_ARGS__);  \
+                else HPSDF_DISPATCH_FIELD_ORDER(FN, kFieldSamples, false, field, __VA_ARGS__);      \
+                break;                                                                              \
+            default:                                                                                \
+                if (csg_) HPSDF_DISPATCH_FIELD_ORDER(FN, kFieldMesh, true, field, __VA_ARGS__);     \
+                else HPSDF_DISPATCH_FIELD_ORDER(FN, kFieldMesh, false, field, __VA_ARGS__);         \
+                break;                                                                              \
+        }                                                                                           \
     } while (0)
 
 // One launch per degree: `degree` selects the compile-time-specialised kernel (0 = any; the blocks then carry
 // their own degree).
-template <int KIND, bool CSG>
+template <int KIND, bool CSG, bool LEFT>
 static void launchFitMultiT(hipStream_t stream, const FitBlock* dBlocks, uint32_t maxBlocks, size_t ldsBytes, const FitTask* dTasks,
                             double* dArena, double* dErrs, const DeviceTables* dTables, const FieldDev& field, const RootMap& rm,
                             const uint32_t* dCount) {
-    hipLaunchKernelGGL((fit_multi_kernel<KIND, CSG>), dim3(maxBlocks), dim3(kFitThreads), ldsBytes, stream, dBlocks, dTasks, dArena, dErrs,
+    hipLaunchKernelGGL((fit_multi_kernel<KIND, CSG, LEFT>), dim3(maxBlocks), dim3(kFitThreads), ldsBytes, stream, dBlocks, dTasks, dArena, dErrs,
                        dTables, field, rm, dCount, maxBlocks);
 }
 // every block of dBlocks[0 .. *dCount) -- or [0 .. maxBlocks) when dCount is null --, whatever its degree, in one launch;
@@ -2957,10 +2963,10 @@ hipError_t launchSlicePoints(hipStream_t stream, double c, float minX, float min
     return hipGetLastError();
 }
 
-template <int KIND, bool CSG>
+template <int KIND, bool CSG, bool LEFT>
 static void launchFieldT(hipStream_t stream, const FieldDev& f, const DeviceTables* dTables, const double* dXyz,
                          size_t n, double* dOut) {
-    hipLaunchKernelGGL((field_kernel<KIND, CSG>), dim3(gridFor(n)), dim3(256), 0, stream, f, dTables, dXyz, n, dOut);
+    hipLaunchKernelGGL((field_kernel<KIND, CSG, LEFT>), dim3(gridFor(n)), dim3(256), 0, stream, f, dTables, dXyz, n, dOut);
 }
 
 hipError_t launchFieldEval(hipStream_t stream, const FieldDev& f, const DeviceTables* dTables, const double* dXyz,

@@ -64,6 +64,10 @@ hipError_t sortPairsU32(hipStream_t stream, void* tmp, size_t& tmpBytes, const u
 // the library's private stream-ordered pool of a device (mesh_build.hip; never the application's default pool), and its trim
 hipMemPool_t meshPool(int dev);
 void meshPoolTrim(int dev);
+
+// hpsdf_set_reduction_order(): 0 = Eigen's 3-vector reductions as a . (b . c) (default), 1 = (a . b) . c.  Process-wide; read when
+// a launch is prepared (capi.cpp).
+int reductionLeftAssoc();
 // a few points of a plain mesh field on the calling thread; hm: HOST copies of the field's arrays
 void meshEvalHostPoints(const MeshDev& hm, const double* xyz, size_t n, double* out);
 // dKeys: n x 8 bytes of DEVICE memory for the per-point (distance, triangle) keys, or nullptr when dOut itself is device memory

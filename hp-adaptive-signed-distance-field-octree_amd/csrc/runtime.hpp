@@ -175,6 +175,8 @@ void hostQueryPointWithGradient(const hpsdf_tree& t, const double* xyz, double* 
 // innermost non-CSG field and the FieldDev the kernels take
 const hpsdf_field* innermost(const hpsdf_field* f);
 int makeFieldDev(const hpsdf_field* f, const double* dSamples, FieldDev* out);
+int reductionLeftAssoc();  // hpsdf_set_reduction_order()
+void setReductionLeftAssoc(int left);
 
 // host mesh preparation (mesh.cpp)
 // std::allocator that leaves trivially constructible elements uninitialised on resize(): the big mesh arrays are

@@ -130,6 +130,16 @@ HPSDF_API int hpsdf_ctx_get_fit_mode(hpsdf_ctx* ctx, int* mode);
  * context is created): below it the two-kernel form costs more than it saves (csrc/fit_mfma.hip, fitSplitDefaultMinDegree). */
 HPSDF_API int hpsdf_ctx_set_split_min_degree(hpsdf_ctx* ctx, int degree);
 HPSDF_API int hpsdf_ctx_set_fast_fit(hpsdf_ctx* ctx, int on);
+/* Which way Eigen's 3-vector reductions associate is a property of the reference's BUILD, not of its source: a . (b . c) when Eigen
+ * does not vectorise the reduction (EIGEN_DONT_VECTORIZE, non-SSE targets; the default here and in the oracle), (a . b) . c when it
+ * reduces a Vector3d through a Packet2d first (what an SSE2 build of Eigen 3.4 appears to do).  Four statements of the path depend on
+ * it: aabbScale.prod() (Source/HP/Octree.cpp:1022), unitWeights.prod() (:1040), grad.normalize() (:970) and Vector3d::norm() in the
+ * analytic test fields (Source/Tests/HPUnitTests.cpp:48-51; the HPSDF_PRIM_* primitives here).  left_assoc != 0 switches all of them,
+ * in every kernel and in the host-answered scalar calls, process-wide and for launches prepared afterwards (call it before Create /
+ * Query, not during).  Under either setting the blocks are byte-identical to the oracle's under ora_set_reduction_order() of the same
+ * value (tests/test_gpu_parity.py::test_reduction_order_switch_matches_the_oracle).  HPSDF_REDUCTION_ORDER=left sets it at load. */
+HPSDF_API void hpsdf_set_reduction_order(int left_assoc);
+HPSDF_API int hpsdf_get_reduction_order(void);
 HPSDF_API void* hpsdf_ctx_stream(hpsdf_ctx* ctx);
 
 /* ---- fields: the callback F of Octree::Create (Include/HP/Octree.h:50) ------ */

@@ -312,6 +312,9 @@ class Octree {
         fitMode_ = mode;
     }
     void SetFastFit(bool on) { SetFitMode(on ? HPSDF_FIT_FAST : HPSDF_FIT_SPLIT); }
+    /// Additive, process-wide (hpsdf_set_reduction_order): Eigen's Vector3d prod() / norm() / normalize() as (a . b) . c -- what an SSE2
+    /// build of Eigen computes, by our reading -- instead of a . (b . c); set it once, before any Create / Query, to match your build.
+    static void SetReductionOrder(bool leftAssoc) { hpsdf_set_reduction_order(leftAssoc ? 1 : 0); }
     /// Additive: Create() over `world` GPUs of one node -- one Octree per GPU (SetDevice), every rank calls Create with
     /// the same config and field; `gather` is the in-place all-gather of hpsdf_create_distributed (for RCCL:
     /// hpsdf_rccl::AllGather with an hpsdf_rccl::Comm as `user`, include/hpsdf_rccl.hpp).  Every rank ends with the

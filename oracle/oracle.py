@@ -136,8 +136,19 @@ def lib():
     L.ora_acosf_batch.argtypes = [C.c_uint32, C.c_uint32, C.c_size_t, C.c_void_p]
     L.ora_mesh_signed_distance.restype = C.c_float
     L.ora_mesh_signed_distance.argtypes = [C.c_void_p, fp, u64p, C.POINTER(C.c_int)]
+    L.ora_set_reduction_order.argtypes = [C.c_int]
+    L.ora_get_reduction_order.restype = C.c_int
     _LIB = L
     return L
+
+
+def set_reduction_order(left_assoc):
+    """hp_oracle.c: Eigen's 3-vector reductions as (a . b) . c (1) instead of a . (b . c) (0, the default).  Process-wide."""
+    lib().ora_set_reduction_order(1 if left_assoc else 0)
+
+
+def reduction_order():
+    return int(lib().ora_get_reduction_order())
 
 
 def ref_tables_lib():

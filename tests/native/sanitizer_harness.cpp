@@ -33,6 +33,9 @@ hipError_t launchFitWeight(hipStream_t, const FitBlock*, uint32_t, size_t, const
 hipError_t launchFitMfma(hipStream_t, int, const FitBlock*, uint32_t, const FitTask*, double*, double*, const DeviceTables*, const FieldDev&,
                          const RootMap&, const uint32_t*) { return hipErrorNoDevice; }
 bool fitSplitSupports(int, int) { return false; }
+static int gLeft = 0;  // capi.cpp's hpsdf_set_reduction_order(); here from HPSDF_REDUCTION_ORDER (main)
+int reductionLeftAssoc() { return gLeft; }
+void setReductionLeftAssoc(int left) { gLeft = left != 0; }
 hipError_t launchFitMfmaLow(hipStream_t, int, const FitTask*, const uint32_t*, uint32_t, uint32_t, uint32_t, double*, const DeviceTables*, const double*,
                             const RootMap&) { return hipErrorNoDevice; }
 hipError_t launchCgIterations(hipStream_t, const CgDev&, int, int) { return hipErrorNoDevice; }
@@ -267,6 +270,7 @@ int main(int argc, char** argv) {
         // host_query.cpp: scalar-sized Query / QueryWithGradient calls are answered on the calling thread from the tree handle's copy of
         // the block.  Here, under the sanitizers and without a GPU: a handle filled the way hpsdf_tree_upload fills it, the points of
         // argv[4] (f64 xyz) in, values and gradients out to argv[5] -- tests/test_sanitizers.py compares them with the oracle bit for bit.
+        if (const char* e = getenv("HPSDF_REDUCTION_ORDER")) hpsdf::setReductionLeftAssoc(e[0] == 'l');
         uint64_t nc, nn;
         memcpy(&nc, blk.data(), 8);
         memcpy(&nn, blk.data() + 8 + 8 * nc, 8);

@@ -406,6 +406,81 @@ def test_fit_kernels_match_the_oracle_at_every_degree(H, O, ctx, degree):
     assert not np.array_equal(fc, got_c)  # (another arithmetic: the matrix-core kernel did run)
 
 
+@pytest.fixture
+def left_assoc(H, O):
+    """Both sides under the OTHER reading of Eigen's 3-vector reductions, (a . b) . c; restored afterwards (the switch is process-wide)."""
+    H.set_reduction_order(1)
+    O.set_reduction_order(1)
+    yield
+    H.set_reduction_order(0)
+    O.set_reduction_order(0)
+
+
+def test_reduction_order_switch_matches_the_oracle(H, O, ctx, golden, left_assoc, monkeypatch):
+    """hpsdf_set_reduction_order(1): which way Eigen associates prod() / norm() / normalize() of a Vector3d depends on how the
+    reference's Eigen was built (include/hpsdf.h); with the switch thrown on both sides the product is still the oracle bit for bit --
+    field values, single fits, whole blocks from both schedulers, gradients from the kernels and from the host-answered scalar calls --
+    and it is not a no-op: the blocks differ from the default order's."""
+    assert H.reduction_order() == 1 and O.reduction_order() == 1
+    pts = O.splitmix64_points(200000, seed=3)
+    for name in ("sphere", "union3"):
+        assert np.array_equal(bits(product_field(H, name).eval(ctx, pts)), bits(oracle_field(O, name).eval(pts)))
+    spec = [(O.PRIM_BOX, O.OP_UNION, [0.1, 0.0, -0.1, 0.2, 0.15, 0.1]), (O.PRIM_SPHERE, O.OP_SUBTRACT, [0.2, 0.1, 0.0, 0.12])]
+    assert np.array_equal(bits(H.Field.analytic(spec).eval(ctx, pts * 1.5)), bits(O.AnalyticField(spec).eval(pts * 1.5)))
+    # single fits: the degree-specialised bodies, the any-degree body and (default context, degree >= 6) the split kernels' exact half
+    exact = H.Context(0)
+    exact.set_fit_mode(H.FIT_EXACT)
+    cfg, ocfg, of = H.make_config(1e-5), O.default_config(1e-5), oracle_field(O, "union3")
+    depth, n = 3, 12
+    side, h = 1 << depth, np.float32(1.0) / np.float32(1 << depth)
+    for degree in (2, 3, 4, 5, 7, 9):
+        got_c, got_e = H.fit_cells(exact, cfg, product_field(H, "union3"), degree, depth, n)
+        dc, de = H.fit_cells(ctx, cfg, product_field(H, "union3"), degree, depth, n)
+        nlow = int(H.NCOEF[degree - 1])
+        for i in range(n):
+            ix, iy, iz = i % side, (i // side) % side, i // (side * side)
+            bmin = np.array([np.float32(-0.5) + np.float32(k) * h for k in (ix, iy, iz)], np.float32)
+            want_c, want_e = O.fit_polynomial(of, ocfg, bmin, bmin + h, degree, depth)
+            assert np.array_equal(bits(got_c[i]), bits(want_c)), (degree, i)
+            assert bits(np.array([got_e[i]]))[0] == bits(np.array([want_e]))[0] == bits(np.array([de[i]]))[0], (degree, i)
+            assert np.array_equal(bits(dc[i, nlow:]), bits(want_c[nlow:])), (degree, i)
+        assert np.abs(dc - got_c).max() <= 1e-13 * np.abs(got_c).max()
+    # whole blocks: device frontier and host scheduler, exact mode: the oracle's bytes; the default (split) mode: its nodes and statistics
+    for case in ("C2_union3_1e-5", "A1_union3_1e-7_K1024", "D1_sphere075_customroot_1e-6"):
+        g = golden["blocks"][case]
+        hcfg = H.make_config(g["target"], g["root_min"], g["root_max"])
+        ot = O.Tree.create(O.default_config(g["target"], g["root_min"], g["root_max"]), oracle_field(O, g["field"]), g["K"])
+        ob = ot.to_block()
+        blk, st = H.create_block(exact, hcfg, product_field(H, g["field"]), g["K"])
+        assert blk == ob, case
+        assert hashlib.sha256(blk).hexdigest() != g["block_sha256"], case   # not the default order's block
+        monkeypatch.setenv("HPSDF_HOST_FRONTIER", "1")
+        assert H.create_block(exact, hcfg, product_field(H, g["field"]), g["K"])[0] == ob, case
+        monkeypatch.setenv("HPSDF_HOST_FRONTIER", "0")
+        sblk, sst = H.create_block(ctx, hcfg, product_field(H, g["field"]), g["K"])
+        a, b = O.parse_block(sblk), O.parse_block(ob)
+        assert np.array_equal(a["degree"], b["degree"]) and np.array_equal(a["childIdx"], b["childIdx"]) and sst == st, case
+        assert np.abs(a["coeffs"] - b["coeffs"]).max() <= 1e-12, case
+        # gradients: kernels (many points), the host-answered scalar calls (<= 32 points) -- and the values, which do not depend on it
+        tree = H.DeviceTree(ctx, ob)
+        qp = np.concatenate([O.splitmix64_points(30000, seed=31), edge_points(np.random.default_rng(2), 1000)])
+        init = np.full((len(qp), 3), 7.0)
+        gv, gg = tree.query_with_gradient(qp, init)
+        wv, wg = ot.query_with_gradient(qp, init)
+        assert np.array_equal(bits(gv), bits(wv)) and np.array_equal(bits(gg), bits(wg)), case
+        for lo in range(0, 320, 32):
+            sv, sg = tree.query_with_gradient(qp[lo:lo + 32], init[lo:lo + 32])
+            assert np.array_equal(bits(sv), bits(wv[lo:lo + 32])) and np.array_equal(bits(sg), bits(wg[lo:lo + 32])), (case, lo)
+    exact.close()
+    rng = np.random.default_rng(4)
+    blk = synthetic_block(rng, [8, 9, 10, 11, 12, 6, 7, 2], depth=2)
+    p2 = rng.uniform(-0.5, 0.5, (3000, 3))
+    a, b = H.DeviceTree(ctx, blk).query_with_gradient(p2), O.Tree.from_block(blk).query_with_gradient(p2)
+    assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(bits(a[1]), bits(b[1]))
+    O.set_reduction_order(0)
+    assert not np.array_equal(bits(O.Tree.from_block(blk).query_with_gradient(p2)[1]), bits(b[1]))  # normalize() did change
+
+
 # ------------------------------------------------------------------ mesh field (SURVEY 8 a-M)
 def test_device_acosf_is_the_host_libms(H, O, ctx):
     """The one libm call of the mesh path (Mesh.cpp:226-231, the angle weights of a vertex pseudo-normal): the device runs

@@ -51,3 +51,15 @@ def test_host_native_code_is_clean_under_asan_ubsan(O, tmp_path):
     inside = wv < 1e300
     got_g = res[n:].reshape(n, 3)
     assert np.array_equal(got_g[inside].view(np.uint64), wg[inside].view(np.uint64)) and np.all(got_g[~inside] == 7.0)
+    # the other reading of Eigen's normalize() (hpsdf_set_reduction_order(1) / ora_set_reduction_order(1)): same bits again
+    r = subprocess.run([exe, str(tmp_path / "blk.bin"), str(tmp_path / "ico.obj"), str(tmp_path / "bad.obj"), str(tmp_path / "pts.bin"),
+                        str(tmp_path / "res_left.bin")], capture_output=True, text=True, timeout=600, env=dict(env, HPSDF_REDUCTION_ORDER="left"))
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-2000:] + r.stderr[-4000:]
+    O.set_reduction_order(1)
+    try:
+        _, wgl = otree.query_with_gradient(pts)
+    finally:
+        O.set_reduction_order(0)
+    got_l = np.fromfile(tmp_path / "res_left.bin", np.float64)[n:].reshape(n, 3)
+    assert np.array_equal(got_l[inside].view(np.uint64), wgl[inside].view(np.uint64))
+    assert not np.array_equal(wgl[inside].view(np.uint64), wg[inside].view(np.uint64))  # the switch is not a no-op on these points
