@@ -477,8 +477,31 @@ def test_reduction_order_switch_matches_the_oracle(H, O, ctx, golden, left_assoc
     p2 = rng.uniform(-0.5, 0.5, (3000, 3))
     a, b = H.DeviceTree(ctx, blk).query_with_gradient(p2), O.Tree.from_block(blk).query_with_gradient(p2)
     assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(bits(a[1]), bits(b[1]))
+    # the other kernel families: sampled fields (a host callback; anisotropic root, so that the cell-scale product has three different
+    # factors), mesh fields (the sampler feeds the fit from samples) and the tree-CSG wrapper around an analytic field
+    import math
+
+    def sphere(pt, thread_idx):  # the user's own Eigen: here the switched order, as oracle's sphere under ora_set_reduction_order(1)
+        dx, dy, dz = pt[0] - 0.05, pt[1], pt[2] + 0.02
+        return math.sqrt((dx * dx + dy * dy) + dz * dz) - 0.3
+
+    root = ((-0.4, -0.45, -0.5), (0.5, 0.4, 0.45))
+    cb, _ = H.create_block(ctx, H.make_config(1e-6, *root), H.Field.callback(sphere), 1024)
+    want = O.Tree.create(O.default_config(1e-6, *root), O.sphere_field((0.05, 0.0, -0.02), 0.3), 1024).to_block()
+    assert cb == want
+    verts, tris = icosphere(1, 0.3)
+    mroot = ((-0.4, -0.4, -0.4), (0.4, 0.45, 0.4))
+    mb, _ = H.create_block(ctx, H.make_config(1e-4, *mroot), H.Field.mesh(ctx, verts, tris), 1024)
+    assert mb == O.Tree.create(O.default_config(1e-4, *mroot), O.MeshField(verts, tris), 1024).to_block()
+    t = H.Octree(jobs_per_round=1024)
+    t.Create(H.make_config(1e-6), H.Field.sphere((0.25, 0, 0), 0.5))
+    t.SubtractSDF(H.Field.sphere((-0.25, 0, 0), 0.5))
+    ocfg = O.default_config(1e-6)
+    oldt = O.Tree.create(ocfg, O.sphere_field((0.25, 0, 0), 0.5), 1024)
+    assert t.ToMemoryBlock() == O.Tree.create(ocfg, O.TreeCsgField(oldt, O.sphere_field((-0.25, 0, 0), 0.5), H.OP_SUBTRACT), 1024).to_block()
     O.set_reduction_order(0)
     assert not np.array_equal(bits(O.Tree.from_block(blk).query_with_gradient(p2)[1]), bits(b[1]))  # normalize() did change
+    assert cb != O.Tree.create(O.default_config(1e-6, *root), O.sphere_field((0.05, 0.0, -0.02), 0.3), 1024).to_block()
 
 
 # ------------------------------------------------------------------ mesh field (SURVEY 8 a-M)
