@@ -138,6 +138,7 @@ static int schedulerRun() {
     return exercised ? 0 : 28;
 }
 int main(int argc, char** argv) {
+    const bool quick = getenv("HPSDF_HARNESS_QUICK") != nullptr;  // the ThreadSanitizer run: the threaded parts in full, the single-threaded fuzz loops cut short
     FILE* f = fopen(argv[1], "rb");
     fseek(f, 0, SEEK_END); long sz = ftell(f); fseek(f, 0, SEEK_SET);
     std::vector<char> blk(sz); if (fread(blk.data(), 1, sz, f) != (size_t)sz) return 2; fclose(f);
@@ -192,7 +193,7 @@ int main(int argc, char** argv) {
             auto rnd = [&]() { x ^= x << 13, x ^= x >> 7, x ^= x << 17; return x; };
             const uint64_t awkward[] = {0ull, 1ull, 8ull, nn - 1, nn, nn + 1, ~0ull, ~0ull - 7, 1ull << 32, 1ull << 63, nc, nc - 1, nc + 1};
             int stillValid = 0;
-            for (int it = 0; it < 6000; ++it) {
+            for (int it = 0; it < (quick ? 200 : 6000); ++it) {
                 work = nodes;
                 for (int k = 0, nk = 1 + (int)(rnd() % 4); k < nk; ++k) {
                     hpsdf_node& n = work[rnd() % nn];
@@ -247,7 +248,7 @@ int main(int argc, char** argv) {
         unsigned long long x = 88172645463325252ull;
         auto rnd = [&]() { x ^= x << 13, x ^= x >> 7, x ^= x << 17; return x; };
         int accepted = 0;
-        for (int it = 0; it < 3000; ++it) {
+        for (int it = 0; it < (quick ? 100 : 3000); ++it) {
             std::string m = good;
             for (int k = 0, nk = 1 + (int)(rnd() % 3); k < nk && !m.empty(); ++k) {
                 const size_t at = rnd() % m.size();

@@ -63,3 +63,29 @@ def test_host_native_code_is_clean_under_asan_ubsan(O, tmp_path):
     got_l = np.fromfile(tmp_path / "res_left.bin", np.float64)[n:].reshape(n, 3)
     assert np.array_equal(got_l[inside].view(np.uint64), wgl[inside].view(np.uint64))
     assert not np.array_equal(wgl[inside].view(np.uint64), wg[inside].view(np.uint64))  # the switch is not a no-op on these points
+
+
+def test_host_threads_are_clean_under_tsan(O, tmp_path):
+    """The same harness under ThreadSanitizer: the continuity post-process on 1, 3 and 8 threads (pair enumeration, assembly, the CG's
+    chunked dot products), the host round scheduler for two ranks, mesh preparation -- no data race reported."""
+    exe = str(tmp_path / "harness_tsan")
+    srcs = [os.path.join(ROOT, "tests", "native", "sanitizer_harness.cpp")] + \
+           [os.path.join(CSRC, f) for f in ("continuity.cpp", "tables.cpp", "obj.cpp", "mesh.cpp", "builder.cpp", "host_query.cpp")]
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-fno-omit-frame-pointer",
+           "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I", CSRC, "-I", os.path.join(ROOT, "include")] + srcs + \
+          ["-o", exe, "-pthread", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    cfg = O.default_config(1e-6, continuity=True)
+    (tmp_path / "blk.bin").write_bytes(O.Tree.create(cfg, oracle_field(O, "union3"), 1024).to_block())
+    v, t = icosphere(2, 0.35)
+    with open(tmp_path / "ico.obj", "w") as fh:
+        for p in v:
+            fh.write("v %.9g %.9g %.9g\n" % tuple(p))
+        for a, b, c in t:
+            fh.write("f %d %d %d\n" % (a + 1, b + 1, c + 1))
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0:report_signal_unsafe=0", HPSDF_HARNESS_QUICK="1")
+    r = subprocess.run([exe, str(tmp_path / "blk.bin"), str(tmp_path / "ico.obj"), str(tmp_path / "bad.obj")],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-2000:] + r.stderr[-4000:]
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-6000:]
