@@ -36,6 +36,16 @@ def test_field_primitives_and_ops_bitwise(H, O, ctx):
     got = H.Field.analytic(spec).eval(ctx, pts)
     want = O.AnalyticField(spec).eval(pts)
     assert np.array_equal(bits(got), bits(want))
+    # the square root's special inputs (field_eval.hpp sqrtExact: 0, subnormal and tiny squared distances, overflow to infinity), alone in
+    # a wave and mixed with ordinary points
+    c = np.array([0.2, 0.1, 0.0])
+    offs = [0.0, 5e-324, 1e-310, 1e-200, 3e-162, 1.5e-154, 1e-120, 1e-115, 1e-100, 1e-30, 1e150, 1e154, 1.4e154, 1e200, 1e308]
+    special = np.array([c + np.array([o, 0.0, 0.0]) for o in offs] + [c + np.array([o, -o, o]) for o in offs] + [c - np.array([0.0, o, 0.0]) for o in offs])
+    sphere = [(O.PRIM_SPHERE, O.OP_UNION, [0.2, 0.1, 0.0, 0.12])]
+    torus = [(O.PRIM_TORUS_Y, O.OP_UNION, [0.2, 0.1, 0.0, 0.0, 0.05])]
+    for sp in (sphere, torus, spec):
+        for batch in (special, np.concatenate([special, pts[:83]]), np.repeat(special, 64, axis=0)):
+            assert np.array_equal(bits(H.Field.analytic(sp).eval(ctx, batch)), bits(O.AnalyticField(sp).eval(batch))), sp[0][0]
 
 
 # ------------------------------------------------------------------ Create
