@@ -952,6 +952,10 @@ int hpsdf_query_ray_host(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* orig
     if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "a device context is required");
     if (!t || (n && (!origins || !dirs || !tMax || !hit || !tOut))) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
     if (n == 0) return HPSDF_OK;
+    if (n <= kHostQueryPoints && smallQueriesOnHost()) {  // a scalar QueryRay(ray, tMax, t): <= 200 host Query steps instead of a launch
+        for (size_t i = 0; i < n; ++i) hit[i] = hostQueryRay(*t, origins + 3 * i, dirs + 3 * i, tMax[i], tOut + i) ? 1 : 0;
+        return HPSDF_OK;
+    }
     // t of a miss keeps the caller's value (the reference leaves t_ untouched)
     HostArray arr[5] = {{origins, nullptr, n * 3 * sizeof(double)}, {dirs, nullptr, n * 3 * sizeof(double)},
                         {tMax, nullptr, n * sizeof(double)},        {tOut, tOut, n * sizeof(double)},

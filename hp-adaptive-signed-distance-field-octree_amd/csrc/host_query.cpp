@@ -132,4 +132,46 @@ void hostQueryPointWithGradient(const hpsdf_tree& t, const double* xyz, double* 
     grad[0] = g[0], grad[1] = g[1], grad[2] = g[2];
 }
 
+// Octree::QueryRay (Octree.cpp:705-746; Ray::IntersectAABB, Source/Utility/Ray.cpp:18-68): the statements of query_ray_kernel
+// (kernels.hip) -- the origin moved to the unit cube, the direction left as it is, the first intersection with [-0.5, 0.5]^3 unless the
+// origin lies inside, then at most 200 steps of Query at the stepped point (Query maps to the unit cube AGAIN, as the reference's
+// call does).  *tOut is written on a hit only.
+bool hostQueryRay(const hpsdf_tree& t, const double* origin, const double* dir, double tMax, double* tOut) {
+    double o[3], d[3], inv[3];
+    int sgn[3];
+    for (int a = 0; a < 3; ++a) {
+        o[a] = (origin[a] - t.dev.rootCentre[a]) * t.dev.rootInvSizes[a];  // :711
+        d[a] = dir[a];
+        inv[a] = 1.0 / d[a];  // Ray.cpp:10 cwiseInverse
+        sgn[a] = inv[a] < 0.0 ? 1 : 0;
+    }
+    double im[3] = {o[0], o[1], o[2]};  // intMin
+    const float fx = (float)o[0], fy = (float)o[1], fz = (float)o[2];
+    const bool inside = fx >= -0.5f && fx <= 0.5f && fy >= -0.5f && fy <= 0.5f && fz >= -0.5f && fz <= 0.5f;
+    if (!inside) {
+        double a0 = ((sgn[0] ? 0.5 : -0.5) - o[0]) * inv[0], b0 = ((sgn[0] ? -0.5 : 0.5) - o[0]) * inv[0];
+        const double a1 = ((sgn[1] ? 0.5 : -0.5) - o[1]) * inv[1], b1 = ((sgn[1] ? -0.5 : 0.5) - o[1]) * inv[1];
+        if ((a0 > b1) || (a1 > b0)) return false;
+        if (a1 > a0) a0 = a1;
+        if (b1 < b0) b0 = b1;
+        const double a2 = ((sgn[2] ? 0.5 : -0.5) - o[2]) * inv[2], b2 = ((sgn[2] ? -0.5 : 0.5) - o[2]) * inv[2];
+        if ((a0 > b2) || (a2 > b0)) return false;
+        if (a2 > a0) a0 = a2;
+        im[0] = a0, im[1] = a1, im[2] = a2;
+    }
+    const double eps = 0.0001, minStep = 0.0001;
+    double dist = 0.0;
+    for (int s = 0; s < 200; ++s) {
+        const double p[3] = {im[0] + dist * d[0], im[1] + dist * d[1], im[2] + dist * d[2]};
+        const double v = hostQueryPoint(t, p);
+        if (v < eps) {
+            *tOut = v;  // :730
+            return true;
+        }
+        dist = dist + (v * 0.95 + minStep);  // :736
+        if (dist > tMax) break;
+    }
+    return false;
+}
+
 }  // namespace hpsdf

@@ -171,6 +171,7 @@ int hipFail(hipError_t e, const char* what);
 constexpr size_t kHostQueryPoints = 32;  // calls of up to this many points never reach the device
 double hostQueryPoint(const hpsdf_tree& t, const double* xyz);
 void hostQueryPointWithGradient(const hpsdf_tree& t, const double* xyz, double* out, double* grad);
+bool hostQueryRay(const hpsdf_tree& t, const double* origin, const double* dir, double tMax, double* tOut);
 
 // innermost non-CSG field and the FieldDev the kernels take
 const hpsdf_field* innermost(const hpsdf_field* f);

@@ -242,7 +242,8 @@ HPSDF_API int hpsdf_query_gradient_host(hpsdf_ctx* ctx, const hpsdf_tree* t, con
 /* Octree::QueryRay (Octree.cpp:705-746; Ray: Include/HP/Ray.h, Source/HP/Ray.cpp:5-68) for n rays: sphere
  * tracing, <= 200 Query steps each.  hit[i] = 1/0; t[i] is written only on a hit (the reference leaves t_
  * untouched otherwise) and receives what the reference stores there -- the field value at the stopping point
- * (Octree.cpp:730).  origins/dirs: xyz interleaved, world coordinates; dirs are used as given. */
+ * (Octree.cpp:730).  origins/dirs: xyz interleaved, world coordinates; dirs are used as given.  A _host call of up to 32 rays -- the
+ * scalar QueryRay(ray, tMax, t) -- is stepped on the calling thread like the scalar Query (csrc/host_query.cpp): same bits, no launch. */
 HPSDF_API int hpsdf_query_ray_device(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* d_origins,
                                      const double* d_dirs, const double* d_tmax, size_t n, uint8_t* d_hit,
                                      double* d_t);

@@ -298,6 +298,20 @@ int main(int argc, char** argv) {
         }
         FILE* of = fopen(argv[5], "wb"); fwrite(res.data(), 8, res.size(), of); fclose(of);
         printf("host query: %zu points\n", np);
+        if (argc > 7) {  // rays: argv[6] = rows of (origin, direction, tMax) f64 x 7 in, argv[7] = rows of (hit, t) f64 x 2 out (t of a miss: -123)
+            FILE* rf = fopen(argv[6], "rb");
+            fseek(rf, 0, SEEK_END); long rsz = ftell(rf); fseek(rf, 0, SEEK_SET);
+            std::vector<double> rays(rsz / 8); if (fread(rays.data(), 8, rays.size(), rf) != rays.size()) return 13; fclose(rf);
+            const size_t nr = rays.size() / 7;
+            std::vector<double> rr(2 * nr);
+            for (size_t i = 0; i < nr; ++i) {
+                double tv = -123.0;
+                rr[2 * i] = hpsdf::hostQueryRay(tree, &rays[7 * i], &rays[7 * i + 3], rays[7 * i + 6], &tv) ? 1.0 : 0.0;
+                rr[2 * i + 1] = tv;
+            }
+            FILE* wf = fopen(argv[7], "wb"); fwrite(rr.data(), 8, rr.size(), wf); fclose(wf);
+            printf("host rays: %zu\n", nr);
+        }
     }
     printf("OK\n");
     return 0;

@@ -741,6 +741,15 @@ def test_query_ray_bitwise(H, O, ctx, golden, case):
     assert np.array_equal(bits(t), bits(wt))
     assert 0 < hit.sum() < len(hit)
     assert np.all(t[hit == 0] == -123.0)  # t_ untouched on a miss (Octree.cpp:705-746)
+    # a scalar QueryRay(ray, tMax, t) -- calls of up to 32 rays -- is stepped on the calling thread (csrc/host_query.cpp): same answers
+    tree = H.DeviceTree(ctx, blk)
+    sel = np.concatenate([np.arange(0, 400), np.arange(2490, 2540), np.arange(5000, 6500)])  # outside origins, axis-parallel, inside
+    so, sd, sm, si = o[sel], d[sel], tmax[sel], init[sel]
+    one = [tree.query_ray(so[i:i + 1], sd[i:i + 1], sm[i:i + 1], t_init=si[i:i + 1]) for i in range(len(sel))]
+    assert np.array_equal(np.concatenate([h for h, _ in one]), whit[sel]) and np.array_equal(bits(np.concatenate([v for _, v in one])), bits(wt[sel]))
+    some = [tree.query_ray(so[i:i + 32], sd[i:i + 32], sm[i:i + 32], t_init=si[i:i + 32]) for i in range(0, len(sel), 32)]
+    assert np.array_equal(np.concatenate([h for h, _ in some]), whit[sel]) and np.array_equal(bits(np.concatenate([v for _, v in some])), bits(wt[sel]))
+    assert 0 < whit[sel].sum() < len(sel)
 
 
 def test_function_slice_bitwise(H, O, ctx, golden, tmp_path):

@@ -39,8 +39,19 @@ def test_host_native_code_is_clean_under_asan_ubsan(O, tmp_path):
     from helpers import edge_points
     pts = np.concatenate([O.splitmix64_points(3000, seed=4), edge_points(np.random.default_rng(2), 2000)])
     pts.astype(np.float64).tofile(tmp_path / "pts.bin")
+    rng = np.random.default_rng(11)
+    nr = 3000
+    ro = rng.uniform(-0.6, 0.6, (nr, 3))
+    ro[:400] = rng.uniform(-3.0, 3.0, (400, 3))          # far outside: Ray::IntersectAABB
+    rd = rng.standard_normal((nr, 3))
+    rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    rd[400:416, 1] = 0.0                                  # axis-parallel components: infinite slab parameters
+    rd[416:432] = [1.0, 0.0, 0.0]
+    rt = rng.uniform(0.05, 3.0, nr)
+    np.concatenate([ro, rd, rt[:, None]], axis=1).astype(np.float64).tofile(tmp_path / "rays.bin")
     r = subprocess.run([exe, str(tmp_path / "blk.bin"), str(tmp_path / "ico.obj"), str(tmp_path / "bad.obj"), str(tmp_path / "pts.bin"),
-                        str(tmp_path / "res.bin")], capture_output=True, text=True, timeout=600, env=env)
+                        str(tmp_path / "res.bin"), str(tmp_path / "rays.bin"), str(tmp_path / "rays_out.bin")],
+                       capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-2000:] + r.stderr[-4000:]
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
     res = np.fromfile(tmp_path / "res.bin", np.float64)
@@ -51,6 +62,10 @@ def test_host_native_code_is_clean_under_asan_ubsan(O, tmp_path):
     inside = wv < 1e300
     got_g = res[n:].reshape(n, 3)
     assert np.array_equal(got_g[inside].view(np.uint64), wg[inside].view(np.uint64)) and np.all(got_g[~inside] == 7.0)
+    # Octree::QueryRay on the calling thread (hostQueryRay), bit for bit the oracle's
+    rr = np.fromfile(tmp_path / "rays_out.bin", np.float64).reshape(nr, 2)
+    whit, wt = otree.query_ray(ro, rd, rt, t_init=np.full(nr, -123.0))
+    assert np.array_equal(rr[:, 0] != 0.0, whit != 0) and np.array_equal(rr[:, 1].view(np.uint64), wt.view(np.uint64)) and 0 < whit.sum() < nr
     # the other reading of Eigen's normalize() (hpsdf_set_reduction_order(1) / ora_set_reduction_order(1)): same bits again
     r = subprocess.run([exe, str(tmp_path / "blk.bin"), str(tmp_path / "ico.obj"), str(tmp_path / "bad.obj"), str(tmp_path / "pts.bin"),
                         str(tmp_path / "res_left.bin")], capture_output=True, text=True, timeout=600, env=dict(env, HPSDF_REDUCTION_ORDER="left"))
