@@ -83,8 +83,11 @@ struct HpsdfVec3 {
     HpsdfVec3 operator*(T s) const { return {T(v[0] * s), T(v[1] * s), T(v[2] * s)}; }
     HpsdfVec3 operator/(T s) const { return {T(v[0] / s), T(v[1] / s), T(v[2] / s)}; }
     HpsdfVec3 cwiseProduct(const HpsdfVec3& o) const { return {T(v[0] * o.v[0]), T(v[1] * o.v[1]), T(v[2] * o.v[2])}; }
-    T dot(const HpsdfVec3& o) const { return v[0] * o.v[0] + (v[1] * o.v[1] + v[2] * o.v[2]); }
-    T squaredNorm() const { return v[0] * v[0] + (v[1] * v[1] + v[2] * v[2]); }
+    // Eigen's reduction of three elements: a . (b . c) by default; a double vector follows hpsdf_set_reduction_order() (include/hpsdf.h:
+    // a vectorised Eigen reduces a Vector3d as (a . b) . c), a float vector is a . (b . c) in every build
+    static T sum3(T a, T b, T c) { return (sizeof(T) == 8 && hpsdf_get_reduction_order()) ? (a + b) + c : a + (b + c); }
+    T dot(const HpsdfVec3& o) const { return sum3(v[0] * o.v[0], v[1] * o.v[1], v[2] * o.v[2]); }
+    T squaredNorm() const { return sum3(v[0] * v[0], v[1] * v[1], v[2] * v[2]); }
     T norm() const { return std::sqrt(squaredNorm()); }
 };
 typedef HpsdfVec3<double> Vector3d;

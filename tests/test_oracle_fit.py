@@ -22,6 +22,26 @@ def test_fit_scratch_kat(O, golden, p):
     assert rel(co[-1], want["clast"]) < 5e-12
 
 
+def test_kats_tell_the_reduction_orders_apart(O, golden):
+    """The survey's known answers were printed to 13 digits, and the last coefficient of the degree-7 fit (4.4e-10, five orders below the
+    first) is small enough to feel which way unitWeights.prod() and the field's norm() associate: under a . (b . c) -- the oracle's and the
+    product's default -- it is reproduced to the printed digits (7e-14), under (a . b) . c it is off by 1.1e-10.  So the surveyor's Eigen
+    stand-in reduced as a . (b . c); what a real Eigen build does is a separate question (a vectorised Eigen >= 3.3
+    should give (a . b) . c for a Vector3d; the switch exists on both sides and is tested both ways)."""
+    k = golden["kats"]
+    cell, want = k["fit_cell"], k["fit_scratch"]["7"]
+    cfg = O.default_config(1e-4)
+    got = {}
+    try:
+        for order in (0, 1):
+            O.set_reduction_order(order)
+            co, _ = O.fit_polynomial(O.sphere_field(), cfg, cell["min"], cell["max"], 7, cell["depth"])
+            got[order] = rel(co[-1], want["clast"])
+    finally:
+        O.set_reduction_order(0)
+    assert got[0] < 2e-13 and got[1] > 2e-11, got
+
+
 @pytest.mark.parametrize("p", [2, 3, 4, 5, 6])
 def test_fit_incremental_kat(O, golden, p):
     cell = golden["kats"]["fit_cell"]
