@@ -282,6 +282,41 @@ def test_mesh_scalar_calls_answered_on_the_host_equal_the_kernels(H, O, ctx, mon
         f.close()
 
 
+def test_scalar_calls_from_many_threads_at_once(H, O, ctx, golden):
+    """What the reference's users do: an SDF lambda that calls Mesh::SignedDistanceAtPt(pt, bvh) per sample from threadCount threads
+    (Source/Tests/MeshingUnitTests.cpp), and Query(pt) loops on several threads.  The host-answered calls share one context, one tree
+    handle and one field handle (whose host mirror the first call builds -- here several first calls race for it); every thread must
+    get the single-threaded bits."""
+    import threading
+    verts, tris = icosphere(4, 0.35)
+    f = H.Field.mesh(ctx, verts, tris)
+    g = golden["blocks"]["A1_union3_1e-7_K1024"]
+    tree = H.DeviceTree(ctx, H.create_block(ctx, H.make_config(g["target"]), product_field(H, g["field"]), g["K"])[0])
+    pts = O.splitmix64_points(4000, seed=17) * 0.9
+    want_m = f.eval_naive(ctx, pts)
+    want_q = tree.query(pts)
+    nthreads, out_m, out_q, errs = 8, {}, {}, []
+
+    def work(t):
+        try:
+            idx = range(t, len(pts), nthreads)
+            out_m[t] = np.array([f.eval(ctx, pts[i:i + 1])[0] for i in idx])
+            out_q[t] = np.array([tree.query(pts[i:i + 1])[0] for i in idx])
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs
+    for t in range(nthreads):
+        assert np.array_equal(bits(out_m[t]), bits(want_m[t::nthreads])), t
+        assert np.array_equal(bits(out_q[t]), bits(want_q[t::nthreads])), t
+    f.close()
+
+
 def test_query_rejects_bad_blocks(H, ctx):
     for bad in (b"", b"\x00" * 50, np.array([1 << 40], np.uint64).tobytes() + b"\x00" * 300):
         with pytest.raises(H.HpsdfError):
