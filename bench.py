@@ -354,8 +354,8 @@ def main():
             # 2 ncoef(p) (4p+1)^3 per fit, against the FP64 peak (78.6 TFLOP/s, vector = matrix on this chip: measured
             # 77.6 with back-to-back v_mfma_f64_16x16x4_f64, tools/mfma_f64_rate.hip).
             fit = {"default_mode": "HPSDF_FIT_SPLIT: from-scratch fits of degree >= 6 keep their rows of top degree on the bit-exact kernel (errors, "
-                                   "decisions, topology canonical) and send the rows below them to the matrix cores; degrees 2-5 are the "
-                                   "bit-exact kernel throughout"}
+                                   "decisions, topology canonical) and compute the rows below them by sum factorisation from the same samples (fit_low_kernel; "
+                                   "HPSDF_LOW_KERNEL=mfma: the direct contraction on the matrix cores); degrees 2-5 are the bit-exact kernel throughout"}
             fast_ctx = H.Context(local, stream.cuda_stream)
             fast_ctx.set_fast_fit(True)
             exact_ctx = H.Context(local, stream.cuda_stream)
@@ -370,7 +370,7 @@ def main():
                                   "frac_fp64_peak": flops / ms / 1e9 / FP64_PEAK_TFLOPS,
                                   "contraction_only_ms": ms_c, "contraction_only_tflops": flops / ms_c / 1e9,
                                   "contraction_only_frac_fp64_peak": flops / ms_c / 1e9 / FP64_PEAK_TFLOPS}
-                fit["p%d" % p]["kernel"] = ("fit_kernel (top-degree rows, bit-exact) + fit_mfma_low_kernel (v_mfma_f64_16x16x4_f64)" if p >= 6
+                fit["p%d" % p]["kernel"] = ("fit_kernel (top-degree rows, bit-exact) + fit_low_kernel (the rows below them, sum-factorised, FMA)" if p >= 6
                                             else "fit_kernel (bit-exact)")
                 if p >= 6:  # what the default replaced: every row on the bit-exact kernel
                     ems = H.bench_fit(exact_ctx, cfg, field, p, 5, cells, 3)

@@ -14,7 +14,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libhpsdf.so")
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
 
-SOURCES = ["kernels.hip", "frontier.hip", "fit_mfma.hip", "mesh_build.hip", "cg.hip", "continuity_asm.hip", "tables.cpp", "builder.cpp", "mesh.cpp", "obj.cpp", "continuity.cpp", "host_query.cpp", "capi.cpp"]
+SOURCES = ["kernels.hip", "frontier.hip", "fit_mfma.hip", "fit_low.hip", "mesh_build.hip", "cg.hip", "continuity_asm.hip", "tables.cpp", "builder.cpp", "mesh.cpp", "obj.cpp", "continuity.cpp", "host_query.cpp", "capi.cpp"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp"))  # every header: an edit to any of them rebuilds every object
 PUBLIC_HEADERS = ["hpsdf.h", "hpsdf_octree.hpp"]
 

@@ -317,7 +317,9 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
     // (they alone enter the error, Octree.cpp:1062-1069), the rows below them by fit_mfma_low_kernel from the same samples.  Not for
     // weighted builds (the weight reads every row) nor for mesh fits that sample inside the fit kernel; a round whose samples would
     // not fit the sample buffer's 16 GB is fitted exactly throughout.
-    bool splitOn = ctx->fitMode == HPSDF_FIT_SPLIT && !b->weighted && !meshFused;
+    // (round 0 -- every coarse cell's degree-2 fit -- is never split: the device-side frontier fits it through its own path, and the two
+    // schedulers promise the same bytes in the same mode)
+    bool splitOn = ctx->fitMode == HPSDF_FIT_SPLIT && !b->weighted && !meshFused && b->stats.rounds > 0;
     if (splitOn) {
         uint64_t need = 0;
         bool any = false;
@@ -567,7 +569,7 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
         c = e;
     }
     if (splitOn)  // the rows below the top degree of the split fits: the from-scratch tasks of a degree are one contiguous run
-        for (int deg = std::max(4, ctx->splitMinDegree); deg <= 11; ++deg) {
+        for (int deg = std::max(2, ctx->splitMinDegree); deg <= 11; ++deg) {
             const uint32_t first = classFirst[classOf(deg, false, 0)], count = classFirst[classOf(deg, true, 0)] - first;
             if (count)
                 HPSDF_HIP(launchFitMfmaLow(ctx->stream, deg, ws.tasks.dev, nullptr, first, count, 0u, ws.arena, ctx->dTables, fd.samples, rm));

@@ -330,7 +330,7 @@ int hpsdf_ctx_get_fit_mode(hpsdf_ctx* c, int* mode) {
 }
 int hpsdf_ctx_set_split_min_degree(hpsdf_ctx* c, int degree) {
     if (!c) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null context");
-    if (degree < 4 || degree > 12) return fail(HPSDF_ERR_INVALID_ARGUMENT, "split_min_degree: 4..12 (12 = never split)");
+    if (degree < 2 || degree > 12) return fail(HPSDF_ERR_INVALID_ARGUMENT, "split_min_degree: 2..12 (12 = never split)");
     c->splitMinDegree = degree;
     return HPSDF_OK;
 }

@@ -341,26 +341,35 @@ hipError_t launchFitMfma(hipStream_t stream, int degree, const FitBlock* dBlocks
     return hipGetLastError();
 }
 
-// Rows [0, ncoef(degree - 1)) of the split fits of `degree` (4..11) from the sample buffer; the tasks are [dRange[0], +dRange[1]) when
-// dRange is given (device-written; the grid then covers maxTasks), else [first, first + count).
-// From which degree a from-scratch fit is split by default (a context's splitMinDegree starts with this).  Measured (16 384 cells,
-// union3 field, profiles/r04_split_fit.txt): the two kernels sample the field once (the exact one writes the values back) but the exact
-// kernel's per-sample work outside the contraction -- index arithmetic, the field, the weights -- is paid for 37 % of the rows at
-// degree 5 instead of all of them: degree 4 1.05 -> 1.23 ms, 5: 2.22 -> 2.37 (slower), 6: 5.93 -> 5.00, 7: 12.05 -> 8.79,
-// 8: 26.85 -> 15.41 ms.  HPSDF_SPLIT_MIN_DEGREE overrides the default (4..12; 12 = never); hpsdf_ctx_set_split_min_degree a context's.
+// From which degree a from-scratch fit is split by default (a context's splitMinDegree starts with this).  The two kernels sample the
+// field once (the exact one writes the values back), the exact kernel's per-sample work outside the contraction -- index arithmetic, the
+// field, the weights -- is paid for the rows of top degree only (37 % of the rows at degree 5), and the rows below them cost next to
+// nothing by sum factorisation (fit_low.hip); what the split adds is the samples' trip through memory, 16 bytes a sample.  Measured
+// (16 384 cells, union3 field, ms exact -> split; profiles/r04_low_rows_sum_factorised.txt): degree 2 0.11 -> 0.16, 3: 0.41 -> 0.48,
+// 4: 0.99 -> 1.14 (slower); 5: 2.27 -> 2.05, 6: 6.03 -> 4.42, 7: 11.99 -> 7.70, 8: 26.71 -> 14.04.  (With the direct contraction on the
+// matrix cores, fit_mfma_low_kernel below, which round 4 started with: 4: 1.23, 5: 2.35, 6: 4.99, 7: 8.82, 8: 15.51.)  The default stays
+// at 6 -- trees whose leaves stop at degree 5 keep the canonical bytes in the default mode --; HPSDF_SPLIT_MIN_DEGREE overrides it
+// (2..12; 12 = never), hpsdf_ctx_set_split_min_degree a context's.
 int fitSplitDefaultMinDegree() {
     static const int v = [] {
         int d = 6;
         if (const char* e = std::getenv("HPSDF_SPLIT_MIN_DEGREE")) d = std::atoi(e);
-        return d < 4 ? 4 : (d > 12 ? 12 : d);
+        return d < 2 ? 2 : (d > 12 ? 12 : d);
     }();
     return v;
 }
-bool fitSplitSupports(int degree, int minDegree) { return degree >= (minDegree < 4 ? 4 : minDegree) && degree <= 11; }
+bool fitSplitSupports(int degree, int minDegree) { return degree >= (minDegree < 2 ? 2 : minDegree) && degree <= 11; }
+// Rows [0, ncoef(degree - 1)) of the split fits of `degree` (2..11) from the sample buffer; the tasks are [dRange[0], +dRange[1]) when
+// dRange is given (device-written; the grid then covers maxTasks), else [first, first + count).
 hipError_t launchFitMfmaLow(hipStream_t stream, int degree, const FitTask* dTasks, const uint32_t* dRange, uint32_t first, uint32_t count,
                             uint32_t maxTasks, double* dArena, const DeviceTables* dTables, const double* dSamples, const RootMap& rm) {
     const uint32_t n = dRange ? maxTasks : count;
     if (n == 0) return hipSuccess;
+    // The default: the sum-factorised kernel of fit_low.hip (three one-axis contractions on the vector units).  HPSDF_LOW_KERNEL=mfma keeps
+    // the direct contraction on the matrix cores below (degrees 4..11), which it replaced in round 4 (profiles/r04_low_rows_sum_factorised.txt).
+    const char* lowEnv = std::getenv("HPSDF_LOW_KERNEL");  // (read per launch: a few launches a round; tests switch it)
+    const bool direct = lowEnv && lowEnv[0] == 'm';
+    if (!direct || degree < 4) return launchFitLow(stream, degree, dTasks, dRange, first, count, maxTasks, dArena, dTables, dSamples);
     if (!fitSplitSupports(degree, 4) || dSamples == nullptr) return hipErrorInvalidValue;
     FieldDev fd;
     std::memset(&fd, 0, sizeof fd);

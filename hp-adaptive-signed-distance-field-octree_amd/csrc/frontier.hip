@@ -1906,7 +1906,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
                 e = ws->ensureSamples(need, s);
             }
         }
-        d.splitFit = splitRound ? std::max(4, ctx->splitMinDegree) : 0;
+        d.splitFit = splitRound ? std::max(2, ctx->splitMinDegree) : 0;
         if (e != hipSuccess) return hipFail(e, "frontier buffers");
         FR_LAUNCH(fr_select_kernel, dim3(std::min<uint32_t>(512u, (knownNodes + 255u) / 256u)), dim3(256), s, d);
         FR_LAUNCH(fr_batch_kernel, dim3(1), dim3(1024), s, d);
@@ -1956,7 +1956,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
                 HPSDF_HIP(hipStreamWaitEvent(s, ws->joinEv[k], 0));
             }
         if (splitRound)  // the rows below the top degree of the split fits, from the samples the exact kernel left (H children: degree <= knownMaxDeg)
-            for (int deg = std::max(4, ctx->splitMinDegree); deg <= (int)std::min<uint32_t>(knownMaxDeg, 11u); ++deg)
+            for (int deg = std::max(2, ctx->splitMinDegree); deg <= (int)std::min<uint32_t>(knownMaxDeg, 11u); ++deg)
                 HPSDF_HIP(launchFitMfmaLow(s, deg, d.tasks, &d.hdr->lowTasks[deg][0], 0u, 0u, 8u * Kj, ws->arena, ctx->dTables, ws->samples, rm));
         if (weighted) {
             size_t lds = 0;

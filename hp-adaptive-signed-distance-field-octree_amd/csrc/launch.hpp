@@ -46,6 +46,8 @@ hipError_t launchFitMfma(hipStream_t stream, int degree, const FitBlock* dBlocks
 // decision of the build, stay those of the all-exact fit; the lower rows agree with it to ~1e-17.
 int fitSplitDefaultMinDegree();  // 6 unless HPSDF_SPLIT_MIN_DEGREE says otherwise
 bool fitSplitSupports(int degree, int minDegree);
+hipError_t launchFitLow(hipStream_t stream, int degree, const FitTask* dTasks, const uint32_t* dRange, uint32_t first, uint32_t count,
+                        uint32_t maxTasks, double* dArena, const DeviceTables* dTables, const double* dSamples);  // fit_low.hip
 hipError_t launchFitMfmaLow(hipStream_t stream, int degree, const FitTask* dTasks, const uint32_t* dRange, uint32_t first, uint32_t count,
                             uint32_t maxTasks, double* dArena, const DeviceTables* dTables, const double* dSamples, const RootMap& rm);
 hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dXyz, size_t n,

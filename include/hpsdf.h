@@ -108,12 +108,13 @@ HPSDF_API int hpsdf_ctx_create(int device, void* stream, hpsdf_ctx** out);
 HPSDF_API int hpsdf_ctx_destroy(hpsdf_ctx* ctx);
 HPSDF_API int hpsdf_ctx_set_stream(hpsdf_ctx* ctx, void* stream);
 HPSDF_API int hpsdf_ctx_synchronize(hpsdf_ctx* ctx);
-/* How cell fits of degree >= 4 (Octree::FitPolynomial, Octree.cpp:1007-1093) use the matrix cores (v_mfma_f64_16x16x4_f64;
- * csrc/fit_mfma.hip).  A fit's returned error is the sum of squares of its rows of TOP total degree alone (:1062-1069), and the
+/* How cell fits (Octree::FitPolynomial, Octree.cpp:1007-1093) may leave the reference's term-by-term summation where that changes no
+ * decision (csrc/fit_low.hip, csrc/fit_mfma.hip).  A fit's returned error is the sum of squares of its rows of TOP total degree alone (:1062-1069), and the
  * errors are all that selection, the P/H decision (:600-601) and the stop rule (:216) ever read.
  *   HPSDF_FIT_SPLIT (default): a from-scratch fit of degree p >= 6 (hpsdf_ctx_set_split_min_degree) is cut in two -- the rows of total degree p by the term-by-term
- *     kernel that reproduces the reference's summation order bit for bit, the rows below p as a GEMM on the matrix cores from the
- *     same samples.  Incremental fits (all their rows are top-degree rows) stay exact.  Errors, topology, node array: identical
+ *     kernel that reproduces the reference's summation order bit for bit, the rows below p from the same samples by sum factorisation
+ *     (three one-axis contractions with fused multiply-adds: 5-13 x fewer operations than the direct contraction; csrc/fit_low.hip.
+ *     HPSDF_LOW_KERNEL=mfma: the direct contraction as a GEMM on the matrix cores instead, v_mfma_f64_16x16x4_f64, degrees >= 4).  Incremental fits (all their rows are top-degree rows) stay exact.  Errors, topology, node array: identical
  *     to HPSDF_FIT_EXACT by construction, no guard band; coefficients of rows below the top degree of leaves that were created by
  *     a split at degree >= 6 agree with it to ~1e-17 absolute (not bit for bit).  Trees whose leaves never exceed degree 5 --
  *     the BASELINE configs stop at 3 -- are byte-identical in both modes.  Weighted builds (the weight reads every row, :1209-1247) and
@@ -126,8 +127,9 @@ HPSDF_API int hpsdf_ctx_synchronize(hpsdf_ctx* ctx);
 enum { HPSDF_FIT_EXACT = 0, HPSDF_FIT_SPLIT = 1, HPSDF_FIT_FAST = 2 };
 HPSDF_API int hpsdf_ctx_set_fit_mode(hpsdf_ctx* ctx, int mode);
 HPSDF_API int hpsdf_ctx_get_fit_mode(hpsdf_ctx* ctx, int* mode);
-/* HPSDF_FIT_SPLIT splits from-scratch fits from this degree on (4..12, 12 = never; default 6, or HPSDF_SPLIT_MIN_DEGREE when the
- * context is created): below it the two-kernel form costs more than it saves (csrc/fit_mfma.hip, fitSplitDefaultMinDegree). */
+/* HPSDF_FIT_SPLIT splits from-scratch fits from this degree on (2..12, 12 = never; default 6, or HPSDF_SPLIT_MIN_DEGREE when the
+ * context is created): the two-kernel form pays from degree 5 (-9 %; -27 % / -36 % / -47 % at 6 / 7 / 8), below that the samples' trip
+ * through memory costs more than the rows saved (csrc/fit_mfma.hip, fitSplitDefaultMinDegree).  Round 0's coarse fits are never split. */
 HPSDF_API int hpsdf_ctx_set_split_min_degree(hpsdf_ctx* ctx, int degree);
 HPSDF_API int hpsdf_ctx_set_fast_fit(hpsdf_ctx* ctx, int on);
 /* Which way Eigen's 3-vector reductions associate is a property of the reference's BUILD, not of its source: a . (b . c) when Eigen

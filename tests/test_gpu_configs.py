@@ -734,15 +734,16 @@ def test_fast_fit_within_tolerance_of_oracle(H, O, name, target):
 
 @pytest.mark.parametrize("name,target,K", [("union3", 1e-8, 1024), ("sphere", 1e-9, 1024), ("union3", 1e-7, 256)])
 def test_split_fit_keeps_errors_and_topology_canonical(H, O, ctx, name, target, K, monkeypatch):
-    """The default fit mode (HPSDF_FIT_SPLIT), made to split from degree 4 so that these trees have split fits at all (the default
-    threshold is 6): a from-scratch fit's rows of top degree come from the bit-exact kernel, the rows below them from the matrix
-    cores.  Only the top rows enter a fit's error (Octree.cpp:1062-1069) and only errors are read by selection, the P/H decision
+    """The default fit mode (HPSDF_FIT_SPLIT), made to split from degree 2 so that EVERY from-scratch fit of these trees is split (the
+    default threshold is 6): a from-scratch fit's rows of top degree come from the bit-exact kernel, the rows below them from the
+    sum-factorised kernel (csrc/fit_low.hip) -- and, second pass, from the direct contraction on the matrix cores (HPSDF_LOW_KERNEL=mfma,
+    degrees >= 4).  Only the top rows enter a fit's error (Octree.cpp:1062-1069) and only errors are read by selection, the P/H decision
     (:600-601) and the stop rule (:216) -- so the node array, the statistics (total error included) and every coefficient of top
     degree equal the ORACLE's bit for bit with no guard band, and the other coefficients agree to 1e-12.  The host scheduler, the
     device-side frontier and two sharded ranks give the same bytes as each other."""
     from helpers import oracle_field, product_field
     split = H.Context(0)
-    split.set_split_min_degree(4)
+    split.set_split_min_degree(2)
     blk, st = H.create_block(split, H.make_config(target), product_field(H, name), K)
     want = O.Tree.create(O.default_config(target), oracle_field(O, name), K).to_block()
     a, b = O.parse_block(blk), O.parse_block(want)
@@ -760,6 +761,13 @@ def test_split_fit_keeps_errors_and_topology_canonical(H, O, ctx, name, target, 
     monkeypatch.setenv("HPSDF_HOST_FRONTIER", "0")
     pts = O.splitmix64_points(50000, seed=13)
     assert np.abs(H.DeviceTree(split, blk).query(pts) - H.DeviceTree(split, want).query(pts)).max() <= 1e-12
+    # the direct contraction on the matrix cores (fit_mfma_low_kernel, degrees >= 4), which the sum-factorised kernel replaced as the default
+    monkeypatch.setenv("HPSDF_LOW_KERNEL", "mfma")
+    split.set_split_min_degree(4)
+    mb, mst = H.create_block(split, H.make_config(target), product_field(H, name), K)
+    monkeypatch.delenv("HPSDF_LOW_KERNEL")
+    m = O.parse_block(mb)
+    assert mb[8 + 8 * nc:] == want[8 + 8 * nc:] and mst == st and np.abs(m["coeffs"] - b["coeffs"]).max() <= 1e-12
     split.close(), exact.close()
 
 
@@ -770,7 +778,7 @@ def test_split_fit_sharded_and_sampled_fields(H, O, ctx):
     cfg = H.make_config(1e-7, *MESH_ROOT)
 
     def mk(mode_ctx):
-        mode_ctx.set_split_min_degree(4)
+        mode_ctx.set_split_min_degree(2)
         return H.Field.mesh(mode_ctx, verts, tris)
     split, exact = H.Context(0), H.Context(0)
     exact.set_fit_mode(H.FIT_EXACT)
@@ -786,7 +794,7 @@ def test_split_fit_sharded_and_sampled_fields(H, O, ctx):
     one, _ = H.create_block(split, ucfg, H.Field.union3(), 1024)
 
     def make_field(c):
-        c.set_split_min_degree(4)
+        c.set_split_min_degree(2)
         return H.Field.union3()
     for blk, s in _create_on_simulated_ranks(H, 2, ucfg, make_field, 1024):
         assert blk == one
@@ -801,7 +809,7 @@ def test_split_fit_under_a_csg_wrapper(H, O, ctx):
     import os
     exact, split = H.Context(0), H.Context(0)
     exact.set_fit_mode(H.FIT_EXACT)
-    split.set_split_min_degree(4)
+    split.set_split_min_degree(2)
     cfg = H.make_config(1e-8)
     old_blk, _ = H.create_block(exact, cfg, H.Field.union3(), 1024)  # (leaves up to degree 5: the rebuild's jobs include from-scratch fits at 4 and 5)
     out = {}

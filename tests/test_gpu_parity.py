@@ -409,8 +409,8 @@ def test_fit_kernels_match_the_oracle_at_every_degree(H, O, ctx, degree):
     """Octree::FitPolynomial (Octree.cpp:1007-1093) cell by cell through hpsdf_fit_cells, in the three fit modes
     (hpsdf_ctx_set_fit_mode).  EXACT: the term-by-term kernel -- degree-specialised bodies for 2..5, the any-degree body for 6..11,
     which no BASELINE-sized build reaches -- returns the oracle's coefficients and error bit for bit.  SPLIT (the default; made to
-    split from degree 4 here, 6 is the default): the ERROR and the rows of top degree, which alone enter it (:1062-1069), bit for
-    bit; the rows below them, from the matrix cores, to 1e-13 of the coefficients' scale.  FAST: everything to rounding."""
+    split from degree 2 here, 6 is the default): the ERROR and the rows of top degree, which alone enter it (:1062-1069), bit for
+    bit; the rows below them, from the sum-factorised kernel, to 1e-13 of the coefficients' scale.  FAST: everything to rounding."""
     depth, n = 3, 40 if degree <= 8 else 12
     cfg, ocfg = H.make_config(1e-5), O.default_config(1e-5)
     exact = H.Context(0)
@@ -433,7 +433,7 @@ def test_fit_kernels_match_the_oracle_at_every_degree(H, O, ctx, degree):
     if degree < 6:
         assert np.array_equal(bits(dc), bits(got_c))
     split = H.Context(0)
-    split.set_split_min_degree(4)
+    split.set_split_min_degree(2)   # every from-scratch fit split: the rows below the top degree by csrc/fit_low.hip (sum factorisation)
     for c, (sc, se) in ((ctx, (dc, de)), (split, H.fit_cells(split, cfg, product_field(H, "union3"), degree, depth, n))):
         nlow = int(H.NCOEF[degree - 1])
         assert np.array_equal(bits(se), bits(got_e)), degree                                  # errors: bit for bit

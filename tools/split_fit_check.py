@@ -1,6 +1,7 @@
-"""The default fit mode (HPSDF_FIT_SPLIT: top-degree rows of from-scratch fits of degree >= 4 bit-exact, the rows below them on the
-matrix cores) against the all-exact mode, on the GPU (by hand):  python tools/split_fit_check.py
-1. single fits, degrees 4..11: errors and top-degree rows bit for bit, lower rows within 1e-15 of the cell's scale;
+"""The split fit mode (HPSDF_FIT_SPLIT: top-degree rows of from-scratch fits of degree >= SPLIT_FROM (env, default 2) bit-exact, the rows
+below them by the sum-factorised kernel of csrc/fit_low.hip -- or, HPSDF_LOW_KERNEL=mfma, by the direct contraction on the matrix cores)
+against the all-exact mode, on the GPU (by hand):  python tools/split_fit_check.py
+1. single fits, degrees SPLIT_FROM..11: errors and top-degree rows bit for bit, lower rows within 1e-15 of the cell's scale;
 2. whole builds (union3 @ 1e-8, sphere @ 1e-9, union3 @ 1e-7 K = 256, CSG rebuild): node arrays and statistics identical, coefficients
    within 1e-12; the host scheduler and two simulated ranks give the split mode's own bytes;
 3. the fit micro-benchmark per mode."""
@@ -11,13 +12,14 @@ import numpy as np, hpsdf_loader
 H = hpsdf_loader.load()
 exact, split, fast = H.Context(0), H.Context(0), H.Context(0)
 exact.set_fit_mode(H.FIT_EXACT); split.set_fit_mode(H.FIT_SPLIT); fast.set_fit_mode(H.FIT_FAST)
-split.set_split_min_degree(int(os.environ.get('SPLIT_FROM', '4')))
+SPLIT_FROM = int(os.environ.get('SPLIT_FROM', '2'))
+split.set_split_min_degree(SPLIT_FROM)
 cfg = H.make_config(1e-5)
 union3 = H.Field.union3()
 ok = True
 
 print("== single fits (64 cells of the depth-5 lattice, union3)")
-for p in range(4, 12):
+for p in range(SPLIT_FROM, 12):
     ce, ee = H.fit_cells(exact, cfg, union3, p, 5, 64)
     cs, es = H.fit_cells(split, cfg, union3, p, 5, 64)
     nlow = int(H.NCOEF[p - 1])
@@ -64,7 +66,7 @@ for name, c, mk, K in cases:
 o = H.Octree(0, jobs_per_round=1024)
 print("== fit micro-benchmark (union3 field; TFLOP/s algorithmic, fraction of 78.6)")
 plane = H.Field.analytic([(H.PRIM_PLANE, H.OP_UNION, [0.3, -0.2, 0.5, 0.1])])
-for p in (4, 5, 6, 7, 8):
+for p in (2, 3, 4, 5, 6, 7, 8):
     cells = 16384
     flops = 2.0 * H.NCOEF[p] * (4 * p + 1) ** 3 * cells
     row = []
