@@ -1031,7 +1031,7 @@ __device__ __forceinline__ double evalLeafVals(const double (&cv)[NV], double ux
 // Octree::FApproxWithGradient (Octree.cpp:904-985) for a compile-time degree: the value as FApprox, the "gradient"
 // as the reference forms it -- per axis k the central difference of sum_r c_r * Lhat_{idx[r][k]}(u_k +- eps), i.e. with
 // the other two axes' factors left out (:956-968) -- then normalised.  Same statements, same order as
-// query_grad_kernel's any-degree loop (and as the oracle), with the tables in registers.
+// queryPointWithGradient's any-degree loop (and as the oracle), with the tables in registers.
 template <int P, int NV>
 __device__ __forceinline__ double evalLeafGradVals(const double (&cv)[NV], const double (&u)[3], int depth, const double* sNl,
                                                    const double* sRec, double (&g)[3], int left) {
@@ -1282,9 +1282,11 @@ __device__ __forceinline__ void topCell(const double (&p3)[3], int topDepth, int
 // (global_load_lds_dwordx4: lane-linear destination, per-lane source), i.e. 8 whole lines per
 // wave-instruction instead of 64 fragments; afterwards every lane reads back its own point's row.
 // Every other tree goes through query_general_kernel below.
-template <int TOPD, bool DEDUPE>
-__global__ __launch_bounds__(256, 7) void query_kernel(TreeDev t, const double* __restrict__ xyz, size_t n,
-                                                    double* __restrict__ out) {
+// GRAD: QueryWithGradient (Octree.cpp:749-789, 904-985) on the same trees -- the same fetch, value and "gradient" from the row
+// (evalLeafGradVals); rows of grad for points outside the root are left untouched, as the reference leaves its output argument.
+template <int TOPD, bool DEDUPE, bool GRAD>
+__device__ __forceinline__ void queryTopBody(const TreeDev& t, const double* __restrict__ xyz, size_t n, double* __restrict__ out,
+                                             double* __restrict__ grad, const double* sNl, const double* sRec) {
     // per wave: 4 steps x 64 lanes x 16 B (two passes; less LDS = more waves).  Each step's kilobyte is followed by
     // 32 bytes of padding: a lane reads row (sub & 3), so without it the four lanes of a group hit the same banks
     // one kilobyte apart (measured: 70 % of the LDS cycles were bank conflicts).
@@ -1359,19 +1361,55 @@ __global__ __launch_bounds__(256, 7) void query_kernel(TreeDev t, const double* 
             __builtin_amdgcn_wave_barrier();  // the window is rewritten by the next pass / tile
         }
         double r = DBL_MAX;  // :668-671 outside the root
-        if (inside) {
-            // :862  unitPt = (pt - centre) * (2 << depth)
-            const double s = (double)(2 << topDepth);
-            const double ux = (p3[0] - c3[0]) * s, uy = (p3[1] - c3[1]) * s, uz = (p3[2] - c3[2]) * s;
-            if (hdr.y == 2u)
-                r = evalLeafTop<2>(cv, ux, uy, uz, t.nlTop);
-            else if (hdr.y == 1u)
-                r = evalLeafTop<1>(cv, ux, uy, uz, t.nlTop);
-            else
-                r = evalLeafTop<0>(cv, ux, uy, uz, t.nlTop);
+        if constexpr (GRAD) {
+            double g[3] = {0.0, 0.0, 0.0};
+            if (inside) {
+                const double s = (double)(2 << topDepth);  // :862
+                const double u[3] = {(p3[0] - c3[0]) * s, (p3[1] - c3[1]) * s, (p3[2] - c3[2]) * s};
+                if (hdr.y == 2u)
+                    r = evalLeafGradVals<2>(cv, u, topDepth, sNl, sRec, g, t.leftAssoc);
+                else if (hdr.y == 1u)
+                    r = evalLeafGradVals<1>(cv, u, topDepth, sNl, sRec, g, t.leftAssoc);
+                else
+                    r = evalLeafGradVals<0>(cv, u, topDepth, sNl, sRec, g, t.leftAssoc);
+            }
+            if (valid) {
+                out[i] = r;
+                if (inside) grad[3 * i] = g[0], grad[3 * i + 1] = g[1], grad[3 * i + 2] = g[2];
+            }
+        } else {
+            if (inside) {
+                // :862  unitPt = (pt - centre) * (2 << depth)
+                const double s = (double)(2 << topDepth);
+                const double ux = (p3[0] - c3[0]) * s, uy = (p3[1] - c3[1]) * s, uz = (p3[2] - c3[2]) * s;
+                if (hdr.y == 2u)
+                    r = evalLeafTop<2>(cv, ux, uy, uz, t.nlTop);
+                else if (hdr.y == 1u)
+                    r = evalLeafTop<1>(cv, ux, uy, uz, t.nlTop);
+                else
+                    r = evalLeafTop<0>(cv, ux, uy, uz, t.nlTop);
+            }
+            if (valid) out[i] = r;
         }
-        if (valid) out[i] = r;
     }
+}
+
+template <int TOPD, bool DEDUPE>
+__global__ __launch_bounds__(256, 7) void query_kernel(TreeDev t, const double* __restrict__ xyz, size_t n,
+                                                    double* __restrict__ out) {
+    queryTopBody<TOPD, DEDUPE, false>(t, xyz, n, out, nullptr, nullptr, nullptr);
+}
+
+// QueryWithGradient on the trees query_kernel serves (every leaf in the top table, degree <= 2): one line a point like Query, where
+// the any-tree kernel (query_general_grad_kernel) pays a record lookup, a walk and a second round trip.
+template <int TOPD>
+__global__ __launch_bounds__(256, 4) void query_grad_kernel(TreeDev t, const DeviceTables* __restrict__ T, const double* __restrict__ xyz,
+                                                            size_t n, double* __restrict__ out, double* __restrict__ grad) {
+    __shared__ double sNl[13 * 11];
+    __shared__ double sRec[26];
+    stageQueryTables(T, sNl, sRec);
+    __syncthreads();
+    queryTopBody<TOPD, true, true>(t, xyz, n, out, grad, sNl, sRec);
 }
 
 // 16-byte chunks a leaf of degree d occupies in the device mirror (blocks are 128-byte aligned there)
@@ -2868,6 +2906,13 @@ hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables*
         return hipGetLastError();
     }
     const dim3 grid(gridFor(n)), block(256);
+    if (allInline && dGrad && std::getenv("HPSDF_QUERY_GRAD_GENERAL") == nullptr) {
+        if (t.topDepth == 4)
+            hipLaunchKernelGGL((query_grad_kernel<4>), grid, block, 0, stream, t, dTables, dXyz, n, dOut, dGrad);
+        else
+            hipLaunchKernelGGL((query_grad_kernel<0>), grid, block, 0, stream, t, dTables, dXyz, n, dOut, dGrad);
+        return hipGetLastError();
+    }
     if (allInline && !dGrad) {
         const char* e = std::getenv("HPSDF_QUERY_DEDUPE");  // tuning knob; default on
         const bool dedupe = !(e && e[0] == '0');

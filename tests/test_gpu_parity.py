@@ -699,6 +699,18 @@ def test_query_with_gradient_bitwise(H, O, ctx, golden):
     p2 = rng.uniform(-0.5, 0.5, (3000, 3))
     a, b = H.DeviceTree(ctx, blk).query_with_gradient(p2), O.Tree.from_block(blk).query_with_gradient(p2)
     assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(bits(a[1]), bits(b[1]))
+    # trees whose leaves all sit in the top table with degree <= 2 (the BASELINE thresholds' trees) take query_grad_kernel, one line a
+    # point like Query: the two headline trees (top level at depth 4), and synthetic ones with the top level elsewhere and degrees 0..2
+    cases = [O.Tree.create(O.default_config(golden["blocks"][c]["target"]), oracle_field(O, golden["blocks"][c]["field"]), 1024).to_block()
+             for c in ("C1_sphere_1e-4", "C2_union3_1e-5")]
+    cases += [synthetic_block(rng, [2, 1, 0, 2, 2, 1, 2, 0], depth=1), synthetic_block(rng, [2] * 8, depth=1)]
+    for blk in cases:
+        dt, ot = H.DeviceTree(ctx, blk), O.Tree.from_block(blk)
+        gv, gg = dt.query_with_gradient(pts, init)
+        wv, wg = ot.query_with_gradient(pts, init)
+        assert np.array_equal(bits(gv), bits(wv)) and np.array_equal(bits(gg), bits(wg))
+        assert np.array_equal(bits(gv), bits(dt.query(pts)))
+        assert np.all(gg[gv == DBL_MAX] == 7.0)
 
 
 def test_csg_with_host_callback_inner_field(H, O, ctx):
