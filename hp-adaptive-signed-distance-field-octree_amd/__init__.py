@@ -307,11 +307,12 @@ class Context:
 
     def set_fit_mode(self, mode):
         """FIT_EXACT (0): every row bit-exact, the canonical bytes; FIT_SPLIT (1, default): top-degree rows of from-scratch fits of
-        degree >= 4 exact, the rows below them on the matrix cores -- errors and topology canonical; FIT_FAST (2): all rows there."""
+        degree >= split_min_degree (default 6) exact, the rows below them by sum factorisation from the same samples -- errors and topology
+        canonical; FIT_FAST (2): every row of every fit of degree >= 4 on the matrix cores."""
         check(lib().hpsdf_ctx_set_fit_mode(self.handle, int(mode)))
 
     def set_split_min_degree(self, degree):
-        """FIT_SPLIT splits from-scratch fits from this degree on (4..12; default 6)."""
+        """FIT_SPLIT splits from-scratch fits from this degree on (2..12, 12 = never; default 6: it pays from degree 5)."""
         check(lib().hpsdf_ctx_set_split_min_degree(self.handle, int(degree)))
 
     def fit_mode(self):

@@ -306,9 +306,10 @@ class Octree {
     }
     /// Jobs per round of the canonical schedule (K); part of the result's definition.
     void SetJobsPerRound(uint64_t k) { jobsPerRound_ = k; }
-    /// Additive: how fits of degree >= 4 use the matrix cores (hpsdf_ctx_set_fit_mode).  Default HPSDF_FIT_SPLIT: errors, decisions and
-    /// topology are those of the bit-exact path by construction, the rows below a from-scratch fit's top degree agree with it to
-    /// ~1e-17; HPSDF_FIT_EXACT: every row bit-exact; HPSDF_FIT_FAST (= SetFastFit(true)): every row on the matrix cores.
+    /// Additive: where fits may leave the reference's term-by-term summation (hpsdf_ctx_set_fit_mode).  Default HPSDF_FIT_SPLIT: errors,
+    /// decisions and topology are those of the bit-exact path by construction; the rows below the top degree of a from-scratch fit of
+    /// degree >= 6 (sum-factorised from the same samples) agree with it to ~1e-17.  HPSDF_FIT_EXACT: every row bit-exact;
+    /// HPSDF_FIT_FAST (= SetFastFit(true)): every row of every fit of degree >= 4 on the matrix cores.
     void SetFitMode(int mode) {
         ensureCtx();
         check(hpsdf_ctx_set_fit_mode(ctx_, mode));
