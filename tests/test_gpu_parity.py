@@ -711,6 +711,12 @@ def test_query_with_gradient_bitwise(H, O, ctx, golden):
         assert np.array_equal(bits(gv), bits(wv)) and np.array_equal(bits(gg), bits(wg))
         assert np.array_equal(bits(gv), bits(dt.query(pts)))
         assert np.all(gg[gv == DBL_MAX] == 7.0)
+        os.environ["HPSDF_QUERY_GRAD_GENERAL"] = "1"   # the any-tree kernel on the same tree: same bits
+        try:
+            ov, og = dt.query_with_gradient(pts, init)
+        finally:
+            del os.environ["HPSDF_QUERY_GRAD_GENERAL"]
+        assert np.array_equal(bits(ov), bits(gv)) and np.array_equal(bits(og), bits(gg))
 
 
 def test_csg_with_host_callback_inner_field(H, O, ctx):
