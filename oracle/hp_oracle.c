@@ -210,11 +210,20 @@ void ora_config_default(ora_config* c) {
 /* Eigen's Vector3d::norm() reduces as x^2 + (y^2 + z^2); the reference test
  * fields are written with it (Source/Tests/HPUnitTests.cpp:48-51). */
 /* Which way a 3-vector reduction (prod / squaredNorm / dot) associates is Eigen's choice, not the reference's: a + (b + c)
- * (the default here and in the product) or (a + b) + c (ora_set_reduction_order(1): what an SSE2 build of Eigen 3.4 with
- * unaligned vectorisation appears to do for a Vector3d).  Eigen is absent, so neither is verified; the switch exists so
- * that the effect of the other choice on coefficients and topology is a measured number (tools/assoc_sensitivity.py,
- * DESIGN.md section 2).  Sites: Vector3d::norm() in the test fields, aabbScale.prod() (:1022), unitWeights.prod() (:1040),
- * grad.normalize() (:970). */
+ * (the default here and in the product) or (a + b) + c (ora_set_reduction_order(1) / hpsdf_set_reduction_order(1)).
+ * What Eigen does, from memory of Core/Redux.h (Eigen is absent from this image, so this is a reading, not a test): Eigen >= 3.3 --
+ * the reference clones Eigen's HEAD (Build.sh:3-11) and sets no vectorisation macro (CMakeLists.txt) -- reduces a fixed-size vector by
+ * redux_impl<LinearVectorizedTraversal, CompleteUnrolling>: the first (Size / PacketSize) * PacketSize elements in packets (predux),
+ * then func(res, <the rest>).  find_best_packet<double, 3> is Packet2d on every vectorised target (SSE2 is the x86-64 baseline; with
+ * AVX Packet4d is halved because 3 % 4 != 0; aarch64 NEON has a Packet2d), so a Vector3d would reduce as (a . b) . c; a Vector3f gets
+ * Packet4f, of which no whole packet fits three floats, so redux_novec_unroller's halving remains: a . (b . c), what the f32 mesh path
+ * (hp_oracle_mesh.c) restates.  An unvectorised build (EIGEN_DONT_VECTORIZE, Eigen 3.2) reduces doubles as a . (b . c) too.
+ * The DEFAULT stays a . (b . c) because that is the arithmetic every reference-derived number this repository holds was produced with:
+ * the survey's known answers (tests/golden/kats.json, 13 digits) are reproduced under it and missed under the other order
+ * (tests/test_oracle_fit.py::test_kats_tell_the_reduction_orders_apart) -- the surveyor's Eigen stand-in reduced that way.  What the
+ * choice moves is a measured number (tools/assoc_sensitivity.py), and both settings are tested against the
+ * product bit for bit (tests/test_gpu_parity.py::test_reduction_order_switch_matches_the_oracle).  Sites: Vector3d::norm() in the test
+ * fields, aabbScale.prod() (:1022), unitWeights.prod() (:1040), grad.normalize() (:970). */
 static int g_leftAssoc = 0;
 void ora_set_reduction_order(int left_assoc) { g_leftAssoc = left_assoc != 0; }
 int ora_get_reduction_order(void) { return g_leftAssoc; }
