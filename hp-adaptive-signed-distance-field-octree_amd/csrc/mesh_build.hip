@@ -503,6 +503,41 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
     const double t2 = now();
     const unsigned gc = (unsigned)((nCorners + 255) / 256), gt = (unsigned)((nTris + 255) / 256);
     hipLaunchKernelGGL(mb_tris_kernel, dim3(gc), dim3(256), 0, s, dTris64, nCorners, nVerts, f->dTris, dFlags);
+    // The twin search (two hash-table kernels, ~1 ms on 2 M triangles: random 8-byte atomics) needs the 32-bit indices only, the BVH chain
+    // (boxes -> codes -> sort -> hierarchy -> boxes bottom-up -> slabs, ~1.5 ms, a dozen dependent launches) everything but the twins: they
+    // run side by side on two streams (a side stream and two events per host thread and device, made once).  HPSDF_MESH_ONE_STREAM=1: in a row.
+    struct Side {
+        int dev = -1;
+        hipStream_t stream = nullptr;
+        hipEvent_t fork = nullptr, join = nullptr;
+    };
+    static thread_local Side side;
+    hipStream_t es = s;  // the stream of the twin search
+    {
+        static const bool oneStream = std::getenv("HPSDF_MESH_ONE_STREAM") != nullptr;
+        int dev = -1;
+        if (!oneStream && hipGetDevice(&dev) == hipSuccess) {
+            if (side.dev != dev) {
+                Side fresh;
+                if (hipStreamCreateWithFlags(&fresh.stream, hipStreamNonBlocking) == hipSuccess &&
+                    hipEventCreateWithFlags(&fresh.fork, hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&fresh.join, hipEventDisableTiming) == hipSuccess) {
+                    fresh.dev = dev;
+                    side = fresh;  // (one per host thread and device for the life of the thread; an earlier device's is left to the runtime)
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
+            if (side.dev == dev && hipEventRecord(side.fork, s) == hipSuccess && hipStreamWaitEvent(side.stream, side.fork, 0) == hipSuccess)
+                es = side.stream;
+            else
+                (void)hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL(mb_edges_insert_kernel, dim3(gc), dim3(256), 0, es, f->dTris, nCorners, dTabKey, dTabVal, tabSize - 1, dFlags);
+    hipLaunchKernelGGL(mb_edges_lookup_kernel, dim3(gc), dim3(256), 0, es, f->dTris, nCorners, dTabKey, dTabVal, tabSize - 1, f->dHalfEdges, dFlags);
+    bool joined = es == s;
+    if (!joined && hipEventRecord(side.join, es) == hipSuccess) joined = true;  // (waited for below, behind the BVH chain)
     e = launchMeshTriPos(s, f->dVerts, f->dTris, nTris, f->dTriPos, nullptr, nullptr);
     hipLaunchKernelGGL(mb_boxes_kernel, dim3(gt), dim3(256), 0, s, f->dTriPos, (uint32_t)nTris, dTriBox, dFlags);
     hipLaunchKernelGGL(mb_morton_kernel, dim3(gt), dim3(256), 0, s, dTriBox, (uint32_t)nTris, dFlags, dKeys, dIds);
@@ -513,8 +548,12 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
     if (!noSlabs)
         hipLaunchKernelGGL(mb_slab_kernel, dim3((unsigned)((n - 1 + 3) / 4)), dim3(256), 0, s, dRanges, dIdsOut, f->dTriPos, n, leafTris, f->dBvh,
                            f->dSlabs);
-    hipLaunchKernelGGL(mb_edges_insert_kernel, dim3(gc), dim3(256), 0, s, f->dTris, nCorners, dTabKey, dTabVal, tabSize - 1, dFlags);
-    hipLaunchKernelGGL(mb_edges_lookup_kernel, dim3(gc), dim3(256), 0, s, f->dTris, nCorners, dTabKey, dTabVal, tabSize - 1, f->dHalfEdges, dFlags);
+    if (es != s) {
+        // join: everything behind this point on s (the flags' download, the temporaries' stream-ordered release) is behind the twin search too
+        hipError_t je = joined ? hipStreamWaitEvent(s, side.join, 0) : hipErrorUnknown;
+        if (je != hipSuccess) je = hipStreamSynchronize(es);  // (no event: wait for the side stream on the host instead)
+        if (e == hipSuccess) e = je;
+    }
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(&hf, dFlags, sizeof hf, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);

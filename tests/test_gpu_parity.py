@@ -758,6 +758,15 @@ def test_capi_argument_checks(H, ctx):
     assert L.hpsdf_tree_upload(ctx.handle, None, 0, C.byref(C.c_void_p())) == 4  # HPSDF_ERR_BAD_BLOCK
     assert L.hpsdf_field_eval_host(ctx.handle, None, None, 0, None) == 1
     assert b"" != L.hpsdf_last_error()
+    tmp = H.Context(0)   # context settings: ranges checked, nothing silently clamped
+    for bad in (1, 13, -3):
+        assert L.hpsdf_ctx_set_split_min_degree(tmp.handle, bad) == 1
+    for ok in (2, 6, 12):
+        assert L.hpsdf_ctx_set_split_min_degree(tmp.handle, ok) == 0
+    assert L.hpsdf_ctx_set_fit_mode(tmp.handle, 3) == 1 and L.hpsdf_ctx_set_fit_mode(tmp.handle, H.FIT_EXACT) == 0 and tmp.fit_mode() == H.FIT_EXACT
+    assert L.hpsdf_ctx_set_split_min_degree(None, 6) == 1
+    tmp.close()
+    assert H.reduction_order() == 0   # (the process-wide default: a . (b . c))
     blk, _ = H.create_block(ctx, H.make_config(1e-4), H.Field.sphere(), 0)  # K = 0 -> default
     tree = H.DeviceTree(ctx, blk)
     assert tree.query(np.zeros((0, 3))).shape == (0,)
