@@ -10,6 +10,9 @@ import oracle as O
 from helpers import edge_points
 H = hpsdf_loader.load()
 ctx = H.Context(0)
+if os.environ.get("HPSDF_REDUCTION_ORDER", "")[:1] in ("l", "1"):  # the product reads the variable itself at load; the oracle follows
+    O.set_reduction_order(1)
+    print("reduction order: (a . b) . c on both sides (product %d, oracle %d)" % (H.reduction_order(), O.reduction_order()))
 bits = lambda a: np.ascontiguousarray(a, np.float64).view(np.uint64)
 cases, first = (int(sys.argv[1]) if len(sys.argv) > 1 else 24), (int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
