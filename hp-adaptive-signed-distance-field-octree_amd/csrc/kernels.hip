@@ -2125,45 +2125,77 @@ __device__ __forceinline__ void fitBlockBody(const FitBlock blk, const FitTask* 
             }
             __syncthreads();
         }
-        const int chunkSamples = np * nq2, total = G * chunkSamples;
-        const float invChunk = 1.0f / (float)chunkSamples;
-        for (int s0 = 0; s0 < total; s0 += kFitThreads) {  // every lane iterates (the mesh path works wave-wide)
-            const int s = s0 + tid;
-            const bool activeS = s < total;
-            const int sc = activeS ? s : total - 1;
-            // s -> (cell g, sample rem) without an integer division by the run-time chunk size
-            int g = (int)(((float)sc + 0.5f) * invChunk);
-            int rem = sc - g * chunkSamples;
-            if (rem < 0) {
-                --g;
-                rem += chunkSamples;
-            } else if (rem >= chunkSamples) {
-                ++g;
-                rem -= chunkSamples;
+        if constexpr (KIND != kFieldMesh) {
+            // A thread takes (cell, j, k) COLUMNS of the chunk and walks the chunk's planes i: the column's index arithmetic, its y and z
+            // coordinates and (a . (b . c) order) the product w_j w_k are formed once per column instead of once per sample -- ~30 of a
+            // sample's ~330 instructions at degree 2.  The sample's own statements are those of the sample-major loop below, so are the bits.
+            const int cols = G * nq2;
+            for (int c0 = 0; c0 < cols; c0 += kFitThreads) {
+                const int cc = c0 + tid;
+                const bool activeS = cc < cols;
+                const int ccl = activeS ? cc : cols - 1;
+                const int g = ccl / nq2, jk = ccl - g * nq2, j = jk / nq, k = jk - j * nq;
+                const double* c = sC + 8 * g;
+                const double uy = sR[j] * c[1] + c[4], uz = sR[k] * c[2] + c[5];
+                const double wy = uy * rm.bounds[1] + rm.centre[1];  // Octree.cpp:327
+                const double wz = uz * rm.bounds[2] + rm.centre[2];
+                const double wj = sW[j], wk = sW[k], c6 = c[6];
+                const uint64_t sbase = (uint64_t)__double_as_longlong(c[7]) + (uint64_t)(j * nq + k);
+                for (int il = 0; il < np; ++il) {
+                    const int i = iBase + il;
+                    const double ux = sR[i] * c[0] + c[3];
+                    const double wx = ux * rm.bounds[0] + rm.centre[0];
+                    const uint64_t sidx = sbase + (uint64_t)(i * nq2);
+                    const double fv = activeS ? fieldEvalWorld<KIND, CSG, LEFT>(field, wx, wy, wz, sidx, sNl, sRec, meshHint) : 0.0;
+                    if (activeS) {
+                        sF[g * cellStride + il * nq2 + jk] = c6 * prod3<LEFT>(sW[i], wj, wk) * fv;  // :1040
+                        // a split fit (FitBlock::split): the field's value goes (back) into the sample buffer, from where
+                        // fit_low_kernel computes the rows below the top degree
+                        if (split) const_cast<double*>(field.samples)[sidx] = fv;
+                    }
+                }
             }
-            if constexpr (KIND == kFieldMesh) rem = meshSampleOrder(rem, np, nq, sPosI, sPosJK);
-            const double* c = sC + 8 * g;
-            const int il = rem / nq2, jk = rem - il * nq2, j = jk / nq, k = jk - j * nq, i = iBase + il;
-            const double ux = sR[i] * c[0] + c[3], uy = sR[j] * c[1] + c[4], uz = sR[k] * c[2] + c[5];
-            const double wx = ux * rm.bounds[0] + rm.centre[0];  // Octree.cpp:327
-            const double wy = uy * rm.bounds[1] + rm.centre[1];
-            const double wz = uz * rm.bounds[2] + rm.centre[2];
-            const uint64_t sidx = (uint64_t)__double_as_longlong(c[7]) + (uint64_t)((i * nq + j) * nq + k);
-            double fv;
-            if constexpr (KIND == kFieldMesh) {
-                // SURVEY 3.4 user glue: (f64) mesh.SignedDistanceAtPt(p.cast<f32>()) -- one traversal per wave
-                const double mv = (double)meshSignedDistanceWave(field.mesh, V3{(float)wx, (float)wy, (float)wz}, activeS, meshHint,
-                                                                 sMeshStack[tid >> 6]);
-                fv = activeS ? applyCsg<CSG>(field, mv, wx, wy, wz, sNl, sRec) : 0.0;
-            } else {
-                fv = activeS ? fieldEvalWorld<KIND, CSG, LEFT>(field, wx, wy, wz, sidx, sNl, sRec, meshHint) : 0.0;
-            }
-            if (activeS) {
-                sF[g * cellStride + rem] = c[6] * prod3<LEFT>(sW[i], sW[j], sW[k]) * fv;  // :1040
-                // a split fit (FitBlock::split): the field's value goes (back) into the sample buffer, from where
-                // fit_mfma_low_kernel contracts the rows below the top degree
-                if constexpr (KIND != kFieldMesh)
-                    if (split) const_cast<double*>(field.samples)[sidx] = fv;
+        } else {
+            const int chunkSamples = np * nq2, total = G * chunkSamples;
+            const float invChunk = 1.0f / (float)chunkSamples;
+            for (int s0 = 0; s0 < total; s0 += kFitThreads) {  // every lane iterates (the mesh path works wave-wide)
+                const int s = s0 + tid;
+                const bool activeS = s < total;
+                const int sc = activeS ? s : total - 1;
+                // s -> (cell g, sample rem) without an integer division by the run-time chunk size
+                int g = (int)(((float)sc + 0.5f) * invChunk);
+                int rem = sc - g * chunkSamples;
+                if (rem < 0) {
+                    --g;
+                    rem += chunkSamples;
+                } else if (rem >= chunkSamples) {
+                    ++g;
+                    rem -= chunkSamples;
+                }
+                if constexpr (KIND == kFieldMesh) rem = meshSampleOrder(rem, np, nq, sPosI, sPosJK);
+                const double* c = sC + 8 * g;
+                const int il = rem / nq2, jk = rem - il * nq2, j = jk / nq, k = jk - j * nq, i = iBase + il;
+                const double ux = sR[i] * c[0] + c[3], uy = sR[j] * c[1] + c[4], uz = sR[k] * c[2] + c[5];
+                const double wx = ux * rm.bounds[0] + rm.centre[0];  // Octree.cpp:327
+                const double wy = uy * rm.bounds[1] + rm.centre[1];
+                const double wz = uz * rm.bounds[2] + rm.centre[2];
+                const uint64_t sidx = (uint64_t)__double_as_longlong(c[7]) + (uint64_t)((i * nq + j) * nq + k);
+                double fv;
+                if constexpr (KIND == kFieldMesh) {
+                    // SURVEY 3.4 user glue: (f64) mesh.SignedDistanceAtPt(p.cast<f32>()) -- one traversal per wave
+                    const double mv = (double)meshSignedDistanceWave(field.mesh, V3{(float)wx, (float)wy, (float)wz}, activeS, meshHint,
+                                                                     sMeshStack[tid >> 6]);
+                    fv = activeS ? applyCsg<CSG>(field, mv, wx, wy, wz, sNl, sRec) : 0.0;
+                } else {
+                    fv = activeS ? fieldEvalWorld<KIND, CSG, LEFT>(field, wx, wy, wz, sidx, sNl, sRec, meshHint) : 0.0;
+                }
+                if (activeS) {
+                    sF[g * cellStride + rem] = c[6] * prod3<LEFT>(sW[i], sW[j], sW[k]) * fv;  // :1040
+                    // a split fit (FitBlock::split): the field's value goes (back) into the sample buffer, from where
+                    // fit_mfma_low_kernel contracts the rows below the top degree
+                    if constexpr (KIND != kFieldMesh)
+                        if (split) const_cast<double*>(field.samples)[sidx] = fv;
+                }
             }
         }
         __syncthreads();
