@@ -553,6 +553,20 @@ static int hostRoundTrip(hpsdf_ctx* ctx, const double* xyz, size_t n, double* ou
     return hostCall(ctx, arr, 2, [&] { return run(ctx, obj, (const double*)arr[0].dev, n, (double*)arr[1].dev); });
 }
 
+// Up to how many points / rays a *_host call is answered on the calling thread.  The defaults are where the two paths cost the same on an
+// MI355X box (tools/host_api_latency.py, profiles/r04_host_call_thresholds.txt): a launch round trip is ~15 us (~55 us for the mesh
+// traversal), a point on the host 0.045 us (Query), 0.07 us (gradient), <= 9 us (a ray: up to 200 Query steps), ~23 us (mesh distance).
+// HPSDF_HOST_QUERY_POINTS / _GRADIENT_POINTS / _RAYS / _MESH_POINTS override them (read once).
+static size_t hostLimit(const char* env, size_t dflt) {
+    const char* e = std::getenv(env);
+    if (!e) return dflt;
+    const long v = std::atol(e);
+    return v < 0 ? 0 : (size_t)v;
+}
+static size_t hostQueryLimit() { static const size_t v = hostLimit("HPSDF_HOST_QUERY_POINTS", kHostQueryPoints); return v; }
+static size_t hostGradientLimit() { static const size_t v = hostLimit("HPSDF_HOST_GRADIENT_POINTS", kHostGradientPoints); return v; }
+static size_t hostRayLimit() { static const size_t v = hostLimit("HPSDF_HOST_RAYS", kHostRays); return v; }
+static size_t hostMeshLimit() { static const size_t v = hostLimit("HPSDF_HOST_MESH_POINTS", kHostMeshPoints); return v; }
 // HPSDF_SMALL_QUERIES_ON_DEVICE=1 (read once) sends calls of a few points through query_few_kernel as before round 4: a measurement knob
 static bool smallQueriesOnHost() {
     static const bool on = [] {
@@ -599,7 +613,7 @@ int hpsdf_field_eval_host(hpsdf_ctx* ctx, const hpsdf_field* f, const double* xy
     if (!f || (!xyz && n) || (!out && n)) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
     // Mesh::SignedDistanceAtPt(pt, bvh): a call of a few points on a plain mesh field never reaches the device (~57 us as a launch;
     // a user's SDF lambda that calls it per sample -- the reference's own usage, Mesh.cpp:54-63 -- would cost minutes per Create)
-    if (n && n <= kHostQueryPoints && f->kind == kHostMesh && f->nTris >= 1 && f->nBvhNodes >= 1 && smallQueriesOnHost()) {
+    if (n && n <= hostMeshLimit() && f->kind == kHostMesh && f->nTris >= 1 && f->nBvhNodes >= 1 && smallQueriesOnHost()) {
         std::shared_ptr<hpsdf_field::HostMirror> m;
         const int rc = meshHostMirror(f, &m);
         if (rc) return rc;
@@ -881,7 +895,7 @@ int hpsdf_query_host(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* xyz, siz
     HPSDF_TRY
     if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "a device context is required");
     if (!t || (!xyz && n) || (!out && n)) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
-    if (n <= kHostQueryPoints && smallQueriesOnHost()) {  // a scalar Query(pt): ~0.1 us here, ~15 us as a launch (host_query.cpp)
+    if (n <= hostQueryLimit() && smallQueriesOnHost()) {  // a scalar Query(pt): ~0.05 us here, ~15 us as a launch (host_query.cpp)
         for (size_t i = 0; i < n; ++i) out[i] = hostQueryPoint(*t, xyz + 3 * i);
         return HPSDF_OK;
     }
@@ -909,7 +923,7 @@ int hpsdf_query_gradient_host(hpsdf_ctx* ctx, const hpsdf_tree* t, const double*
     if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "a device context is required");
     if (!t || (n && (!xyz || !out || !grad))) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
     if (n == 0) return HPSDF_OK;
-    if (n <= kHostQueryPoints && smallQueriesOnHost()) {
+    if (n <= hostGradientLimit() && smallQueriesOnHost()) {
         for (size_t i = 0; i < n; ++i) hostQueryPointWithGradient(*t, xyz + 3 * i, out + i, grad + 3 * i);
         return HPSDF_OK;
     }
@@ -956,7 +970,7 @@ int hpsdf_query_ray_host(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* orig
     if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "a device context is required");
     if (!t || (n && (!origins || !dirs || !tMax || !hit || !tOut))) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
     if (n == 0) return HPSDF_OK;
-    if (n <= kHostQueryPoints && smallQueriesOnHost()) {  // a scalar QueryRay(ray, tMax, t): <= 200 host Query steps instead of a launch
+    if (n <= hostRayLimit() && smallQueriesOnHost()) {  // a scalar QueryRay(ray, tMax, t): <= 200 host Query steps instead of a launch
         for (size_t i = 0; i < n; ++i) hit[i] = hostQueryRay(*t, origins + 3 * i, dirs + 3 * i, tMax[i], tOut + i) ? 1 : 0;
         return HPSDF_OK;
     }

@@ -138,7 +138,7 @@ struct hpsdf_field {
     uint32_t leafLog2 = 0;              // leaves hold at most 1 << leafLog2 triangles
     uint32_t nTris = 0, nVerts = 0, nBvhNodes = 0;
     unsigned long long* dStats = nullptr;  // 4 counters, only under HPSDF_MESH_STATS=1
-    // host copies of the arrays above, made by the first call of a few points (hpsdf_field_eval_host, n <= kHostQueryPoints): such calls
+    // host copies of the arrays above, made by the first call of one or two points (hpsdf_field_eval_host, n <= kHostMeshPoints): such calls
     // are answered on the calling thread (kernels.hip, meshEvalHostPoints) -- what Mesh::SignedDistanceAtPt(pt, bvh) inside a user's
     // SDF lambda costs decides whether code written against the reference is usable as it is
     struct HostMirror {
@@ -168,7 +168,11 @@ int hipFail(hipError_t e, const char* what);
     } while (0)
 
 // Query / QueryWithGradient of one point on the calling thread (host_query.cpp): the kernels' values bit for bit
-constexpr size_t kHostQueryPoints = 32;  // calls of up to this many points never reach the device
+constexpr size_t kHostQueryPoints = 32;     // Query calls of up to this many points never reach the device (capi.cpp: hostQueryLimit)
+constexpr size_t kHostGradientPoints = 32;  // QueryWithGradient
+constexpr size_t kHostRays = 32;            // QueryRay
+constexpr size_t kHostMeshPoints = 2;       // mesh signed distance (hpsdf_field_eval_host on a plain mesh field): ~23-50 us a point on the host, a launch
+                                            // round trip ~55 us + ~3 us a point -- from three points on the device is the faster one
 double hostQueryPoint(const hpsdf_tree& t, const double* xyz);
 void hostQueryPointWithGradient(const hpsdf_tree& t, const double* xyz, double* out, double* grad);
 bool hostQueryRay(const hpsdf_tree& t, const double* origin, const double* dir, double tMax, double* tOut);

@@ -260,7 +260,7 @@ def test_scalar_calls_answered_on_the_host_equal_the_kernels(H, O, ctx, golden):
 @pytest.mark.parametrize("host_build", [False, True])
 def test_mesh_scalar_calls_answered_on_the_host_equal_the_kernels(H, O, ctx, monkeypatch, host_build):
     """Mesh::SignedDistanceAtPt(pt, bvh) (Mesh.cpp:54-63) one point at a time -- what a user's SDF lambda written against the
-    reference does per sample: calls of up to 32 points on a plain mesh field are answered on the calling thread from host copies
+    reference does per sample: calls of one or two points on a plain mesh field are answered on the calling thread from host copies
     of the field's arrays (capi.cpp meshHostMirror, kernels.hip meshEvalHostPoints: the per-point traversal compiled for the
     host from the statements the device runs).  Same bits as the batched device paths and the O(n) scan -- on a smooth mesh, on
     the reference's own mesh, on a needle mesh, for points on vertices / edges / faces, in the medial region, far away, NaN."""
@@ -277,7 +277,9 @@ def test_mesh_scalar_calls_answered_on_the_host_equal_the_kernels(H, O, ctx, mon
         assert np.array_equal(bits(big), bits(want))
         one = np.concatenate([f.eval(ctx, pts[i:i + 1]) for i in range(len(pts))])      # host, one point a call
         assert np.array_equal(bits(one), bits(want)), k
-        some = np.concatenate([f.eval(ctx, pts[i:i + 32]) for i in range(0, len(pts), 32)])
+        two = np.concatenate([f.eval(ctx, pts[i:i + 2]) for i in range(0, len(pts), 2)])   # host, two points a call
+        assert np.array_equal(bits(two), bits(want)), k
+        some = np.concatenate([f.eval(ctx, pts[i:i + 32]) for i in range(0, len(pts), 32)])  # from three points on: one launch a call
         assert np.array_equal(bits(some), bits(want)), k
         f.close()
 
