@@ -562,7 +562,7 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
                                     ws.arena, ws.errs.dev, ctx->dTables, fd, rm));
         else
             HPSDF_HIP(launchFit(ctx->stream, deg, cpt, ws.blocks.dev + classBlockFirst[c], classBlockFirst[e] - classBlockFirst[c],
-                                ldsBytes, ws.tasks.dev, ws.arena, ws.errs.dev, ws.errs.dev + nSlots, ctx->dTables, fd, rm));
+                                ldsBytes, ws.tasks.dev, ws.arena, ws.errs.dev, nullptr, ctx->dTables, fd, rm));
         if (b->weighted)  // Octree.cpp:1071-1092: the weight's |mean FApprox|, from the coefficients just written
             HPSDF_HIP(launchFitWeight(ctx->stream, ws.blocks.dev + classBlockFirst[c], classBlockFirst[e] - classBlockFirst[c], ldsBytes,
                                       ws.tasks.dev, ws.arena, ws.errs.dev + nSlots, ctx->dTables));

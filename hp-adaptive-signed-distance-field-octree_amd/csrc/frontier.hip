@@ -10,22 +10,22 @@
 // the frontier), the parent index and up to 10 coefficient segments (a leaf of degree p that started at degree f owns rows
 // [0, ncoef(f)) from its first fit and one more run of rows per P-refinement: nothing is copied when a degree rises).
 //
-// A round (r >= 1):
-//   fr_select_kernel   top-K of the frontier by (error desc, node index asc) as an MSB radix select over the error's bit
-//                      pattern: level 0 (exponent, 2048 bins) against a histogram kept incrementally -- its threshold bin
-//                      is known since the previous round closed; everything strictly above the bin is taken, the bin
-//                      itself becomes the candidate list
-//   fr_batch_kernel    (one workgroup) refines the candidates digit by digit until <= 4096 remain, sorts those exactly,
-//                      sorts the taken nodes by index -> the batch; counts the round's cell fits per shape class and
-//                      lays out task list, workgroup list, arena rows and sample slots by prefix sums
-//   fr_tasks_kernel    (grid) writes the FitTask / FitBlock lists
-//   mesh_sample_kernel / fit_kernel   (kernels.hip) over device-written ranges: grids are upper bounds
-//   fr_decide_kernel   (one workgroup) improvements (:814-825, :846-854), decision (:600-601), first child of every split
-//   fr_update_kernel   (grid) child creation, queue, coefficient counts of the ancestors; workgroup 0 carries the running
-//                      total in the reference's order (:253-290); the last workgroup to finish applies the stop rule
-//                      (:216) and computes the next selection's threshold bin
-//   fr_store_kernel    when the stop rule has fired: ReallocCoeffs -- every leaf's coeffsStart by walking up its
-//                      ancestors, coefficients gathered into the packed store
+// A round (r >= 1) is TWO launches around its fits (round 5; rounds 2-4 ran six small kernels, ~90 us of their own latencies):
+//   fr_round_kernel    closes round r - 1 and opens round r in one launch of 1 + K / 128 workgroups of 1024 threads:
+//        workgroups 1.. : eight lanes per job -- the decision (:594-601: improvements :814-825, :846-854), child creation
+//                         (Subdivide / CornerAABB), queue, coefficient counts of the ancestors.  A splitting job's first child is
+//                         nNodes + 8 x (splitting jobs before it): every workgroup publishes its own counts and adds up its
+//                         predecessors' (one hop, no chain), so no single workgroup has to see all jobs first
+//        workgroup 0    : the running total in the reference's order (:253-290), one dependent addition after the other, from the
+//                         dense operand list the others write; when all have arrived: counters, stop rule (:216); then -- trees up
+//                         to kFrInlineNodes -- the NEXT round's selection (top-K of the frontier by (error desc, node index asc) as
+//                         an MSB radix select over the error's bit pattern), the batch in node order, the round's shape classes and
+//                         its FitTask / FitBlock lists, all from LDS; the header's mirror in pinned host memory tells the host
+//   mesh_sample_kernel / fit_multi_kernel   (kernels.hip) over device-written ranges: grids are upper bounds
+// Larger trees select with a grid: fr_select_kernel (level 0 against the histogram the updates keep), fr_batch_kernel (one
+// workgroup: remaining digits, exact order, classes), fr_tasks_kernel (grid: the lists).
+//   fr_store_kernel    once the stop rule has fired: ReallocCoeffs -- every leaf's coeffsStart by walking up its
+//                      ancestors, coefficients gathered into the packed store, the node array behind it (one download)
 // Round 0 (the 4096 coarse cells) is the same for every build and comes from a template: no selection, no task emission,
 // and if the build stops there (the BASELINE thresholds do) the packed store is the arena itself.
 #include <hip/hip_runtime.h>
@@ -89,8 +89,13 @@ struct FrHdr {
     uint64_t dbg[24];  // phase time stamps (s_memtime) of the one-workgroup kernels, read under HPSDF_TRACE
     int64_t rCoeffDelta;
     double rTotal;
+    uint32_t opsArrive, stuck;  // fr_round_kernel: update workgroups whose operands are written; a wait that ran out (never, by construction)
+    uint32_t chainStamp;  // round + 1 once rTotal holds that round's running total
+    uint32_t landed;      // (mirror only) the build's stamp, written when round 0's closing launch starts: the fit before it has finished, so
+                          // the rows it wrote into pinned host memory are there
     uint32_t hist1[2048];  // queued nodes per exponent bin (kept by update / batch)
-    uint32_t hist2[2048];  // level-1 digits of the candidates of the current selection
+    uint32_t hist2[2048];  // level-1 digits of the candidates of the current selection (grid selection only)
+    uint64_t agg[kFrJobs / 128];  // fr_round_kernel: per update workgroup {round stamp, splitting jobs << 16 | P jobs}
 };
 constexpr size_t kFrHdrCopyBytes = offsetof(FrHdr, hist1);
 static inline void frCpuRelax() {  // the host's spin on the header mirror
@@ -129,8 +134,6 @@ struct FrDev {
     double* wBatchErr;
     uint64_t* wJobP;
     uint64_t* wJobH;
-    uint8_t* kind;             // per job: 0 dropped, 1 P, 2 H
-    uint32_t* base;            // per H job: index of its first child
     double* ops;               // the round's additions to the running total, densely, in job order
     FitTask* tasks;
     FitBlock* blocks;
@@ -142,6 +145,7 @@ struct FrDev {
     // multi-rank builds (world > 1): this rank fits a cost-balanced slice of every round's jobs
     int32_t rank, world;
     uint32_t errStride;    // doubles per rank in errs: rank r's slice sits at errs + r * errStride (all-gathered in place)
+    uint32_t errStrideNext;  // ... in the round being prepared (round 0 exchanges 4096 jobs' errors, later rounds K)
     uint8_t* jobOwner;     // per job: the rank that fits it
     uint32_t* packPos;     // [node][kFrSegs]: where the segment sits in its owner's pack buffer
     double* pack;          // [world][packStride] all-gathered pack buffers (this rank writes its own)
@@ -151,6 +155,8 @@ struct FrDev {
     // nearness weighting (Octree.cpp:1071-1092, 1209-1247): a fit keeps ONE full coefficient array (an incremental fit
     // carries the old rows over, :847), fit_weight_kernel leaves |mean FApprox| of every fit in `means`, the host turns
     // the means into weights with its libm (pow / exp: what the oracle calls) and fr_weigh_kernel scales the errors
+    uint32_t buildStamp, padB;  // a number of the build (FrHdr::landed)
+    double target;         // targetErrorThreshold of the build (the header is initialised before the build is known: FrontierWorkspace::clean)
     int32_t weighted;
     double* means;          // [jobs][9], pinned host memory as the device addresses it (written by fit_weight_kernel)
     const double* weights;  // [jobs][9], pinned host memory as the device addresses it (written by the host)
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(256) void fr_select_kernel(FrDev d) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// selection, remaining levels + exact sort -> the batch; then the round's shape classes
+// selection, remaining levels + exact order -> the batch; then the round's shape classes (and, inline, its lists)
 // ---------------------------------------------------------------------------------------------------------------------
 // In-place bitonic sort of n (a power of two, <= 4096) (key, val) pairs in LDS by "key descending, then val ascending".
 __device__ void frBitonic(uint64_t* key, uint32_t* val, uint32_t n) {
@@ -340,41 +346,87 @@ __device__ __forceinline__ uint32_t frPow2(uint32_t n) {
     return p;
 }
 
-__global__ __launch_bounds__(1024) void fr_batch_kernel(FrDev d) {
+// LDS of the 1024-thread workgroups (fr_batch_kernel, fr_round_kernel): 62 KB, reused phase by phase -- who lives where is said
+// where it happens.
+static_assert(sizeof(FitTask) == 56 && sizeof(hpsdf_node) == 56, "frStoreRecords moves records of seven 8-byte words");
+struct FrLds {
+    uint64_t key[kFrSort];  // 32 KB: sort keys / node bitmap / cost prefix / scans + per-job records / the running total's operands
+    uint32_t val[kFrSort];  // 16 KB: the batch in node order
+    uint32_t hist[2048];    // radix histograms; later the class tables of the inline emission
+    uint32_t tmp[1024];
+    uint32_t count[kFrClasses];
+    uint32_t wave[16];
+    uint32_t slice[9];
+    int t;
+    uint32_t above, c, next, flag, stuck;
+    // per wave: 64 records of 7 words (a FitTask, a serialised node: 56 bytes) on their way to memory.  A lane writes its record's
+    // words, the wave reads the 448 words back in order and stores THOSE: runs of whole records instead of 8 bytes every 56
+    // (which cost the lists of a 1024-job round 60 k cycles, most of them waiting for the stores to drain)
+    uint64_t stage[16][64 * 7];
+};
+// One wave: record `lane` (7 words, w[]) goes to dst64 + base (in 8-byte words) if valid; the records of the eight lanes of an
+// octet are contiguous in memory when `octets` (base = the octet's first record: taken from its first lane).
+__device__ __forceinline__ void frStoreRecords(uint64_t* st, uint64_t* dst64, const uint64_t (&w)[7], uint64_t base, bool valid, bool octets) {
+    const int lane = (int)(threadIdx.x & 63);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) st[lane * 7 + k] = w[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const long long b = valid ? (long long)base : -1ll;
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        const int q = r * 64 + lane;                 // word q of the wave's 448
+        const int rec = q / 7, off = q - rec * 7;    // record and word within it
+        const int src = octets ? (rec & ~7) : rec;   // the lane that knows where it goes
+        const long long sb = __shfl(b, src, 64);
+        const uint64_t v = st[q];
+        if (sb >= 0) dst64[(uint64_t)sb + (uint64_t)(octets ? (rec & 7) * 7 + off : off)] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+#define FR_STAMP(k) do { if (threadIdx.x == 0) d.hdr->dbg[k] = __builtin_readcyclecounter(); } while (0)
+
+// where job j's 9 errors go in the round being prepared (frErrSlot's rule with the coming round's stride), and that round's status slot
+__device__ __forceinline__ uint32_t frErrSlotNext(const FrDev& d, const uint32_t* slice, uint32_t owner, uint32_t j) {
+    if (d.world == 1) return j * 9u;
+    return owner * d.errStrideNext + (j - slice[owner]) * 9u;
+}
+__device__ __forceinline__ double* frStatusSlotNext(const FrDev& d, int r) { return d.errs + (size_t)r * d.errStrideNext + (d.errStrideNext - 1u); }
+
+// From the selection's level 0 to the round's shape classes.  nQ: queued nodes; above / cand / taken: level 0's counts
+// (nodes in exponent bins above the threshold bin -- already in d.taken --, candidates in d.candA, entries of d.taken).
+// INLINE (fr_round_kernel's workgroup 0, which has just run level 0 itself: L.hist holds the level-1 digits of the
+// candidates): the workgroup also writes the round's FitTask / FitBlock lists -- a job's slots are reserved while its fits
+// are counted, the per-job facts wait in LDS, one lane per (job, fit) writes a task.  Otherwise (fr_batch_kernel, behind
+// fr_select_kernel): the histogram sits in the header, the classes go to d.rnd and fr_tasks_kernel follows.
+template <bool INLINE>
+__device__ void frBatchBody(const FrDev& d, FrLds& L, uint32_t nQ, uint32_t above, uint32_t cand, uint32_t taken, uint32_t nNodes) {
     FrHdr* h = d.hdr;
     FrRound* R = d.rnd;
     const uint32_t tid = threadIdx.x;
-    if (h->done) {
-        if (tid < 13) h->degBlocks[tid][0] = h->degBlocks[tid][1] = h->degTasks[tid][0] = h->degTasks[tid][1] = 0;
-        if (tid == 0) h->nJobs = 0, h->nTasks = 0, h->nBlocks = 0;
-        return;
-    }
-    __shared__ uint64_t sKey[kFrSort];
-    __shared__ uint32_t sVal[kFrSort];
-    __shared__ uint32_t sHist[2048];
-    __shared__ uint32_t sTmp[1024];
-    __shared__ uint32_t sCount[kFrClasses];
-    __shared__ int sT;
-    __shared__ uint32_t sAbove, sC, sNext;
-#define FR_STAMP(k) do { if (tid == 0) h->dbg[k] = __builtin_readcyclecounter(); } while (0)
+    uint64_t* sKey = L.key;
+    uint32_t* sVal = L.val;
+    uint32_t* sHist = L.hist;
+    uint32_t* sTmp = L.tmp;
+    uint32_t* sCount = L.count;
     FR_STAMP(0);
-    const uint32_t nQ = h->nQueued;
     const uint32_t nJobs = nQ < d.K ? nQ : d.K;
-    uint32_t need = nJobs - h->above;  // still to come out of the candidates
-    uint32_t C = h->candCount;
+    uint32_t need = nJobs - above;  // still to come out of the candidates
+    uint32_t C = cand;
     uint32_t* cur = d.candA;
     uint32_t* nxt = d.candB;
     int level = 1;
-    if (C > kFrExact) {
+    if (!INLINE && C > kFrExact) {
         for (uint32_t i = tid; i < 2048; i += 1024) sHist[i] = h->hist2[i];
         __syncthreads();
     }
-    uint32_t tk = h->takenCount;
+    uint32_t tk = taken;
     while (C > kFrExact && level <= 8) {  // refine by the digit of `level` (its histogram is in sHist)
-        frThreshold(sHist, need, sTmp, &sT, &sAbove);
-        const int T = sT;
-        const uint32_t abv = sAbove;
-        if (tid == 0) sC = 0, sNext = tk;
+        frThreshold(sHist, need, sTmp, &L.t, &L.above);
+        const int T = L.t;
+        const uint32_t abv = L.above;
+        if (tid == 0) L.c = 0, L.next = tk;
         __syncthreads();
         for (uint32_t i = tid; i < 2048; i += 1024) sHist[i] = 0;
         __syncthreads();
@@ -385,9 +437,9 @@ __global__ __launch_bounds__(1024) void fr_batch_kernel(FrDev d) {
                 const uint64_t bits = d.qErr[idx];
                 const int dg = (int)frDigit(level, bits, idx);
                 if (dg > T) {
-                    d.taken[atomicAdd(&sNext, 1u)] = idx;
+                    d.taken[atomicAdd(&L.next, 1u)] = idx;
                 } else if (dg == T) {
-                    nxt[atomicAdd(&sC, 1u)] = idx;
+                    nxt[atomicAdd(&L.c, 1u)] = idx;
                     if (level < 8) atomicAdd(&sHist[frDigit(level + 1, bits, idx)], 1u);
                 }
             }
@@ -395,8 +447,8 @@ __global__ __launch_bounds__(1024) void fr_batch_kernel(FrDev d) {
         __threadfence_block();
         __syncthreads();
         need -= abv;
-        C = sC;
-        tk = sNext;
+        C = L.c;
+        tk = L.next;
         __syncthreads();
         uint32_t* t = cur;
         cur = nxt, nxt = t;
@@ -420,22 +472,22 @@ __global__ __launch_bounds__(1024) void fr_batch_kernel(FrDev d) {
     __threadfence_block();
     __syncthreads();
     // the batch in node-index order: a bitmap over the nodes (bit = taken), prefix population counts, every set bit's
-    // position is its rank (trees beyond 262144 nodes: bitonic sort of the indices)
+    // position is its rank (trees beyond 262144 nodes: bitonic sort of the indices).  A thread owns 8 words, or one word
+    // while the tree has at most 32768 nodes (eight times the threads then share the bit loop).
     FR_STAMP(2);
-    const uint32_t nNodes = h->nNodes;
     if (nNodes <= 8192u * 32u) {
         uint32_t* bm = reinterpret_cast<uint32_t*>(sKey);  // 8192 words
         const uint32_t words = (nNodes + 31u) >> 5;
-        for (uint32_t w = tid; w < 8192u; w += 1024) bm[w] = 0;
+        const uint32_t per = words <= 1024u ? 1u : 8u;
+        for (uint32_t w = tid; w < per * 1024u; w += 1024) bm[w] = 0;
         __syncthreads();
         for (uint32_t i = tid; i < nJobs; i += 1024) {
             const uint32_t idx = d.taken[i];
             atomicOr(&bm[idx >> 5], 1u << (idx & 31u));
         }
         __syncthreads();
-        uint32_t own = 0;  // thread t owns words 8 t .. 8 t + 7
-        if (tid * 8u < words)
-            for (int k = 0; k < 8; ++k) own += (uint32_t)__popc(bm[tid * 8 + k]);
+        uint32_t own = 0;
+        for (uint32_t k = 0; k < per; ++k) own += (uint32_t)__popc(bm[tid * per + k]);
         uint32_t inc = own;  // inclusive scan over the wave's lanes
         const int lane = (int)(tid & 63);
         for (int off = 1; off < 64; off <<= 1) {
@@ -448,12 +500,12 @@ __global__ __launch_bounds__(1024) void fr_batch_kernel(FrDev d) {
         for (uint32_t w = 0; w < (tid >> 6); ++w) before += sTmp[w];
         uint32_t pos = before + inc - own;
         if (own)
-            for (int k = 0; k < 8; ++k) {
-                uint32_t bits = bm[tid * 8 + k];
+            for (uint32_t k = 0; k < per; ++k) {
+                uint32_t bits = bm[tid * per + k];
                 while (bits) {
                     const int bpos = __ffs((int)bits) - 1;
                     bits &= bits - 1u;
-                    sVal[pos++] = (tid * 8u + (uint32_t)k) * 32u + (uint32_t)bpos;
+                    sVal[pos++] = (tid * per + k) * 32u + (uint32_t)bpos;
                 }
             }
         __syncthreads();
@@ -469,20 +521,24 @@ __global__ __launch_bounds__(1024) void fr_batch_kernel(FrDev d) {
     FR_STAMP(3);
     for (uint32_t i = tid; i < 2048; i += 1024) sHist[i] = 0;
     for (uint32_t c = tid; c < (uint32_t)kFrClasses; c += 1024) sCount[c] = 0;
+    if (tid < 9) L.slice[tid] = tid ? nJobs : 0u;
     __syncthreads();
     // ---- the jobs leave the frontier; every job becomes 1 (coarse) or up to 9 cell fits: count them per shape class.
     //      Thread t owns jobs 4 t .. 4 t + 3.  With several ranks every rank counts only the fits of its own slice: the
     //      slices are contiguous job ranges of (nearly) equal cost, cut where the host scheduler cuts them (builderSelect).
     uint64_t* sCost = sKey;  // (the bitmap is dead) inclusive prefix of the jobs' costs
+    // per-job records of the inline emission (written once the cost prefix is dead): A = H slot | P slot << 16 | degree << 28;
+    // B = coarse | ours << 1 | owner << 2 | depth << 5.  Words 2048.. of sKey: the scans below use the first 2048.
+    uint32_t* sJobA = reinterpret_cast<uint32_t*>(sKey) + 2048;
+    uint16_t* sJobB = reinterpret_cast<uint16_t*>(reinterpret_cast<uint32_t*>(sKey) + 6144);
     {
-        uint32_t jIdx[4];
         int jP[4], jDep[4];
         bool jCoarse[4];
         uint64_t own = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint32_t j = tid * 4u + (uint32_t)q;
-            jIdx[q] = 0xFFFFFFFFu, jP[q] = 0, jDep[q] = 0, jCoarse[q] = false;
+            jP[q] = 0, jDep[q] = 0, jCoarse[q] = false;
             if (j >= nJobs) continue;
             const uint32_t idx = sVal[j];
             const uint64_t bits = d.qErr[idx];
@@ -492,7 +548,7 @@ __global__ __launch_bounds__(1024) void fr_batch_kernel(FrDev d) {
             d.qErr[idx] = kNotQueued;
             atomicAdd(&sHist[frDigit(0, bits, idx)], 1u);
             const hpsdf_node& n = d.nodes[idx];
-            jIdx[q] = idx, jP[q] = n.degree, jDep[q] = n.depth;
+            jP[q] = n.degree, jDep[q] = n.depth;
             jCoarse[q] = fabs(e - HPSDF_INITIAL_NODE_ERR) < DBL_EPSILON;  // coarse, Octree.cpp:806,831
             own += frJobCost(jP[q], jDep[q], jCoarse[q]);
         }
@@ -537,6 +593,7 @@ __global__ __launch_bounds__(1024) void fr_batch_kernel(FrDev d) {
             if (tid == 0) {
                 uint32_t start = 0;
                 h->sliceFirst[0] = 0;
+                L.slice[0] = 0;
                 for (int r = 0; r < d.world; ++r) {
                     uint32_t end = nJobs;
                     if (r + 1 < d.world) {
@@ -545,29 +602,35 @@ __global__ __launch_bounds__(1024) void fr_batch_kernel(FrDev d) {
                         end = end > nJobs ? nJobs : end;
                     }
                     h->sliceFirst[r + 1] = end;
-                    sTmp[32 + r + 1] = end;
+                    L.slice[r + 1] = end;
                     start = end;
                 }
-                sTmp[32] = 0;
             }
-            __syncthreads();
         }
+        __syncthreads();
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint32_t j = tid * 4u + (uint32_t)q;
             if (j >= nJobs) continue;
+            uint32_t o = 0;
             if (d.world > 1) {
-                uint32_t o = 0;
-                for (int r = 1; r < d.world; ++r) o += sTmp[32 + r] <= j ? 1u : 0u;
+                for (int r = 1; r < d.world; ++r) o += L.slice[r] <= j ? 1u : 0u;
                 d.jobOwner[j] = (uint8_t)o;
-                if ((int)o != d.rank) continue;  // another rank's job: none of its fits here
             }
+            const bool ours = d.world == 1 || (int)o == d.rank;  // another rank's job: none of its fits here
             const int p = jP[q], dep = jDep[q];
-            if (jCoarse[q]) {
-                atomicAdd(&sCount[frClass(2, false, dep)], 1u);  // :836-843
-            } else {
-                if (dep < kMaxDepth) atomicAdd(&sCount[frClass(p, false, dep + 1)], 8u);     // :814-822
-                if (p < kMaxDegree - 1) atomicAdd(&sCount[frClass(p + 1, true, dep)], 1u);  // :846-851
+            uint32_t slotH = 0, slotP = 0;
+            if (ours) {
+                if (jCoarse[q]) {
+                    slotP = atomicAdd(&sCount[frClass(2, false, dep)], 1u);  // :836-843
+                } else {
+                    if (dep < kMaxDepth) slotH = atomicAdd(&sCount[frClass(p, false, dep + 1)], 8u);     // :814-822
+                    if (p < kMaxDegree - 1) slotP = atomicAdd(&sCount[frClass(p + 1, true, dep)], 1u);  // :846-851
+                }
+            }
+            if (INLINE) {
+                sJobA[j] = slotH | (slotP << 16) | ((uint32_t)p << 28);
+                sJobB[j] = (uint16_t)((jCoarse[q] ? 1u : 0u) | (ours ? 2u : 0u) | (o << 2) | ((uint32_t)dep << 5));
             }
         }
     }
@@ -576,7 +639,8 @@ __global__ __launch_bounds__(1024) void fr_batch_kernel(FrDev d) {
     for (uint32_t i = tid; i < 2048; i += 1024)
         if (sHist[i]) h->hist1[i] -= sHist[i];
     // ---- shapes, then prefix sums over the classes (degree-major): tasks, workgroups, arena rows, samples.
-    //      Thread c owns class c; the scan runs over 512 slots in LDS (sKey doubles as the 64-bit scan buffer).
+    //      Thread c owns class c; the scan runs over 512 slots in LDS (the first 2048 words of sKey hold the two 64-bit scans,
+    //      the halves of sTmp the task and workgroup counts).
     uint32_t myCount = 0, myBlocks = 0;
     uint64_t myRows = 0, mySamples = 0;
     int g = 1, pl = 1;
@@ -595,11 +659,10 @@ __global__ __launch_bounds__(1024) void fr_batch_kernel(FrDev d) {
     }
     __syncthreads();
     FR_STAMP(5);
-    // four inclusive scans over 512 slots: counts and blocks in sTmp / sVal (32 bit), rows and samples in sKey halves
     uint64_t* sRows = sKey;
     uint64_t* sSmp = sKey + 512;
     uint32_t* sCnt = sTmp;
-    uint32_t* sBlk = sVal;
+    uint32_t* sBlk = sTmp + 512;
     if (tid < 512) sCnt[tid] = myCount, sBlk[tid] = myBlocks, sRows[tid] = myRows, sSmp[tid] = mySamples;
     __syncthreads();
     for (uint32_t off = 1; off < 512; off <<= 1) {
@@ -611,14 +674,20 @@ __global__ __launch_bounds__(1024) void fr_batch_kernel(FrDev d) {
         __syncthreads();
     }
     FR_STAMP(6);
-    if (tid < (uint32_t)kFrClasses) {
+    const uint32_t nTasks = sCnt[kFrClasses - 1], nBlocks = sBlk[kFrClasses - 1];
+    const uint64_t rowsAll = sRows[kFrClasses - 1], smpAll = sSmp[kFrClasses - 1];
+    const uint64_t arenaBase = *(volatile uint64_t*)&h->arenaUsed;
+    uint32_t exCnt = 0, exBlk = 0;
+    uint64_t exRows = 0, exSmp = 0;
+    if (tid < (uint32_t)kFrClasses) exCnt = sCnt[tid] - myCount, exBlk = sBlk[tid] - myBlocks, exRows = sRows[tid] - myRows, exSmp = sSmp[tid] - mySamples;
+    if (!INLINE && tid < (uint32_t)kFrClasses) {
         R->cCount[tid] = myCount;
-        R->cFirst[tid] = sCnt[tid] - myCount;
+        R->cFirst[tid] = exCnt;
         R->cCursor[tid] = 0;
-        R->cBlockFirst[tid] = sBlk[tid] - myBlocks;
+        R->cBlockFirst[tid] = exBlk;
         R->cBlocks[tid] = myBlocks;
-        R->cArena[tid] = sRows[tid] - myRows;
-        R->cSample[tid] = sSmp[tid] - mySamples;
+        R->cArena[tid] = exRows;
+        R->cSample[tid] = exSmp;
         R->cG[tid] = (uint8_t)g;
         R->cPlanes[tid] = (uint8_t)pl;
     }
@@ -631,28 +700,152 @@ __global__ __launch_bounds__(1024) void fr_batch_kernel(FrDev d) {
         h->lowTasks[tid][0] = t0;
         h->lowTasks[tid][1] = frSplit(d.splitFit, (int)tid, false) ? sCnt[lo + kFrDepths - 1] - t0 : 0u;
     }
+    __syncthreads();  // (every thread has read the header's arenaUsed)
     if (tid == 0) {
-        const uint32_t t = sCnt[kFrClasses - 1], b = sBlk[kFrClasses - 1];
-        const uint64_t rows = sRows[kFrClasses - 1], smp = sSmp[kFrClasses - 1];
-        h->nJobs = nJobs, h->nTasks = t, h->nBlocks = b;
-        h->sampleUsed = smp;
-        h->fits += t, h->samples += smp;
-        R->arenaBase = h->arenaUsed;
-        h->arenaUsed += rows;
+        h->nJobs = nJobs, h->nTasks = nTasks, h->nBlocks = nBlocks;
+        h->sampleUsed = smpAll;
+        h->fits += nTasks, h->samples += smpAll;
+        R->arenaBase = arenaBase;
+        h->arenaUsed = arenaBase + rowsAll;
+        if (!INLINE && d.world > 1) *frStatusSlotNext(d, d.rank) = 0.0;  // (inline: the leader, once nobody reads the closing round's errors any more)
     }
     FR_STAMP(7);
+    if (!INLINE) return;
+    // ---- the lists.  Class tables into LDS (the histogram and the scans are dead -- the barrier above): per class the first
+    //      task, the first workgroup, the count, the shape; the arena rows and sample slots before it.
+    uint32_t* tabTask = sHist;
+    uint32_t* tabBlk = sHist + kFrClasses;
+    uint32_t* tabCount = sHist + 2 * kFrClasses;
+    uint32_t* tabShape = sHist + 3 * kFrClasses;
+    uint64_t* tabArena = sKey;
+    uint64_t* tabSample = sKey + kFrClasses;
+    if (tid < (uint32_t)kFrClasses) {
+        tabTask[tid] = exCnt, tabBlk[tid] = exBlk, tabCount[tid] = myCount, tabShape[tid] = (uint32_t)g | ((uint32_t)pl << 8);
+        tabArena[tid] = exRows, tabSample[tid] = exSmp;
+    }
+    __syncthreads();
+    // One lane per fit, the records through the wave's staging buffer (frStoreRecords).  First the from-scratch fits of the children
+    // (EstimateHImprovement, :814-822): lane 8 j + k is child k of job j, a job's eight tasks are contiguous.
+    const int wv = (int)(tid >> 6);
+    uint64_t* tasks64 = reinterpret_cast<uint64_t*>(d.tasks);
+    auto word2 = [](float lo, float hi) { return (uint64_t)__float_as_uint(lo) | ((uint64_t)__float_as_uint(hi) << 32); };
+    for (uint32_t i0 = 0; i0 < 8u * nJobs; i0 += 1024u) {
+        const uint32_t i = i0 + tid, j = i >> 3;
+        const int k = (int)(i & 7u);
+        const bool live = j < nJobs;
+        float bn[3] = {0, 0, 0}, bx[3] = {0, 0, 0};
+        uint32_t ja = 0, jb = 0;
+        if (live) {
+            const hpsdf_node& n = d.nodes[sVal[j]];
+            for (int a = 0; a < 3; ++a) bn[a] = n.aabb_min[a], bx[a] = n.aabb_max[a];
+            ja = sJobA[j], jb = sJobB[j];
+        }
+        const int p = (int)(ja >> 28), dep = (int)(jb >> 5);
+        const bool hasH = live && (jb & 2u) != 0 && (jb & 1u) == 0 && dep < kMaxDepth;
+        const int c = frClass(p, false, dep + 1 <= kMaxDepth ? dep + 1 : kMaxDepth);
+        const uint32_t slot0 = ja & 0xFFFFu;
+        const uint64_t rows = frCoef(p), nq = 4 * (uint64_t)p + 1;
+        float mn[3], mx[3];
+        for (int a = 0; a < 3; ++a) {  // Octree::CornerAABB, :1096-1112
+            const float mid = (bx[a] + bn[a]) * 0.5f;
+            mn[a] = (k >> a) & 1 ? mid : bn[a];
+            mx[a] = (k >> a) & 1 ? bx[a] : mid;
+        }
+        uint64_t w[7];
+        w[0] = word2(mn[0], mn[1]), w[1] = word2(mn[2], mx[0]), w[2] = word2(mx[1], mx[2]);
+        w[3] = arenaBase + tabArena[c] + (uint64_t)(slot0 + (uint32_t)k) * rows;  // outOff
+        w[4] = ~0ull;                                                              // copyOff
+        w[5] = tabSample[c] + (uint64_t)(slot0 + (uint32_t)k) * nq * nq * nq;      // sampleOff
+        w[6] = (uint64_t)(frErrSlotNext(d, L.slice, (jb >> 2) & 7u, live ? j : 0u) + 1u + (uint32_t)k) | ((uint64_t)(dep + 1) << 32) | ((uint64_t)p << 40);
+        frStoreRecords(L.stage[wv], tasks64, w, ((uint64_t)tabTask[c] + slot0) * 7u, hasH, true);
+    }
+    // ... then every job's own fit (the coarse degree-2 fit :836-843 or the incremental one :846-851), and where the job's results
+    // will lie in the arena
+    for (uint32_t j0 = 0; j0 < nJobs; j0 += 1024u) {
+        const uint32_t j = j0 + tid;
+        const bool live = j < nJobs;
+        float bn[3] = {0, 0, 0}, bx[3] = {0, 0, 0};
+        uint32_t ja = 0, jb = 0, idx = 0;
+        if (live) {
+            idx = sVal[j];
+            const hpsdf_node& n = d.nodes[idx];
+            for (int a = 0; a < 3; ++a) bn[a] = n.aabb_min[a], bx[a] = n.aabb_max[a];
+            ja = sJobA[j], jb = sJobB[j];
+        }
+        const int p = (int)(ja >> 28), dep = (int)(jb >> 5);
+        const bool coarse = (jb & 1u) != 0, ours = (jb & 2u) != 0;
+        const bool hasH = live && ours && !coarse && dep < kMaxDepth, hasP = live && ours && (coarse || p < kMaxDegree - 1);
+        const int deg = coarse ? 2 : (p + 1 <= kMaxDegree ? p + 1 : kMaxDegree);
+        const bool incr = !coarse;
+        const int c = frClass(deg, incr, dep), cH = frClass(p, false, dep + 1 <= kMaxDepth ? dep + 1 : kMaxDepth);
+        const uint32_t slot = (ja >> 16) & 4095u;
+        const uint64_t rows = (incr && !d.weighted) ? frCoef(deg) - frCoef(deg - 1) : frCoef(deg), nq = 4 * (uint64_t)deg + 1;
+        const uint64_t outP = arenaBase + tabArena[c] + (uint64_t)slot * rows;
+        uint64_t w[7];
+        w[0] = word2(bn[0], bn[1]), w[1] = word2(bn[2], bx[0]), w[2] = word2(bx[1], bx[2]);
+        w[3] = outP;
+        // weighted incremental fit: the cell's current array (one segment: the update keeps it that way), :847
+        w[4] = (hasP && d.weighted && incr) ? (d.segOff[(size_t)idx * kFrSegs] & kOffMask) : ~0ull;
+        w[5] = tabSample[c] + (uint64_t)slot * nq * nq * nq;
+        w[6] = (uint64_t)frErrSlotNext(d, L.slice, (jb >> 2) & 7u, live ? j : 0u) | ((uint64_t)dep << 32) | ((uint64_t)deg << 40);
+        frStoreRecords(L.stage[wv], tasks64, w, ((uint64_t)tabTask[c] + slot) * 7u, hasP, false);
+        if (live) {
+            d.wJobP[j] = hasP ? outP : ~0ull;
+            d.wJobH[j] = hasH ? arenaBase + tabArena[cH] + (uint64_t)(ja & 0xFFFFu) * frCoef(p) : ~0ull;
+        }
+    }
+    for (uint32_t b = tid; b < nBlocks; b += 1024) {
+        int lo = 0, hi = kFrClasses;  // the last class whose first workgroup is <= b is the one that owns b
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (tabBlk[mid] <= b)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const int c = lo;
+        const int deg = c / kFrDepths / 2;
+        const bool incr = (c / kFrDepths) & 1;
+        const uint32_t gg = tabShape[c] & 255u, local = b - tabBlk[c];
+        FitBlock fb;
+        fb.firstTask = tabTask[c] + local * gg;
+        const uint32_t left = tabCount[c] - local * gg;
+        fb.nTasks = (uint16_t)(left < gg ? left : gg);
+        fb.degree = (uint8_t)deg;
+        fb.planesPerChunk = (uint8_t)(tabShape[c] >> 8);
+        const bool split = frSplit(d.splitFit, deg, incr);
+        fb.rowStart = (uint16_t)((incr || split) ? frCoef(deg - 1) : 0);
+        fb.rowEnd = (uint16_t)frCoef(deg);
+        fb.depth = (uint8_t)(c % kFrDepths);
+        fb.weighted = d.weighted ? 1 : 0;
+        fb.split = split ? 1 : 0;
+        fb.pad1[0] = 0;
+        d.blocks[b] = fb;
+    }
+    FR_STAMP(8);
 }
 
-// the round's FitTask / FitBlock lists, grouped by shape class.  Grid-wide: sixteen lanes per job -- lane k < 8 writes the
-// from-scratch fit of child k (EstimateHImprovement, :814-822), lane 8 the job's own fit (the coarse degree-2 fit :836-843
-// or the incremental one :846-851); lanes 0 and 8 reserve the slots of their class -- then one lane per workgroup record.
+__global__ __launch_bounds__(1024) void fr_batch_kernel(FrDev d) {
+    FrHdr* h = d.hdr;
+    const uint32_t tid = threadIdx.x;
+    if (h->done) {
+        if (tid < 13) h->degBlocks[tid][0] = h->degBlocks[tid][1] = h->degTasks[tid][0] = h->degTasks[tid][1] = 0;
+        if (tid == 0) h->nJobs = 0, h->nTasks = 0, h->nBlocks = 0;
+        return;
+    }
+    __shared__ FrLds L;
+    frBatchBody<false>(d, L, h->nQueued, h->above, h->candCount, h->takenCount, h->nNodes);
+}
+
+// the round's FitTask / FitBlock lists, grouped by shape class (behind fr_batch_kernel).  Grid-wide: sixteen lanes per job -- lane
+// k < 8 writes the from-scratch fit of child k (EstimateHImprovement, :814-822), lane 8 the job's own fit (the coarse degree-2 fit
+// :836-843 or the incremental one :846-851); lanes 0 and 8 reserve the slots of their class -- then one lane per workgroup record.
 __global__ __launch_bounds__(256) void fr_tasks_kernel(FrDev d) {
     FrHdr* h = d.hdr;
     if (h->done) return;
     FrRound* R = d.rnd;
     const uint32_t nJobs = h->nJobs, nBlocks = h->nBlocks;
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
-    if (gid == 0 && d.world > 1) *frStatusSlot(d, d.rank) = 0.0;
     const uint64_t arenaBase = R->arenaBase;
     const int lane = threadIdx.x & 63;
     for (uint32_t base = (gid >> 4) - ((uint32_t)lane >> 4); base < nJobs; base += stride >> 4) {  // 4 jobs per wave, wave-uniform trip count
@@ -662,7 +855,8 @@ __global__ __launch_bounds__(256) void fr_tasks_kernel(FrDev d) {
         const hpsdf_node& n = d.nodes[d.batchIdx[live ? j : 0]];
         const int p = n.degree, dep = n.depth;
         const bool coarse = fabs(d.batchErr[live ? j : 0] - HPSDF_INITIAL_NODE_ERR) < DBL_EPSILON;
-        const bool ours = live && (d.world == 1 || (int)d.jobOwner[j] == d.rank);
+        const uint32_t owner = d.world == 1 ? 0u : d.jobOwner[live ? j : 0];
+        const bool ours = live && (d.world == 1 || (int)owner == d.rank);
         const bool hasH = ours && !coarse && dep < kMaxDepth, hasP = ours && (coarse || p < kMaxDegree - 1);
         // this lane's fit, if any
         const bool mine = (k < 8 && hasH) || (k == 8 && hasP);
@@ -689,10 +883,10 @@ __global__ __launch_bounds__(256) void fr_tasks_kernel(FrDev d) {
             }
             outOff = arenaBase + R->cArena[c] + (uint64_t)slot * rows;
             t.outOff = outOff;
-            // weighted incremental fit: the cell's current array (one segment: fr_update_kernel keeps it that way), :847
+            // weighted incremental fit: the cell's current array (one segment: the update keeps it that way), :847
             t.copyOff = (d.weighted && incr) ? (d.segOff[(size_t)d.batchIdx[j] * kFrSegs] & kOffMask) : ~0ull;
             t.sampleOff = R->cSample[c] + (uint64_t)slot * nq * nq * nq;
-            t.errSlot = (uint32_t)frErrSlot(d, h, j) + (k < 8 ? 1u + (uint32_t)k : 0u);
+            t.errSlot = frErrSlotNext(d, h->sliceFirst, owner, j) + (k < 8 ? 1u + (uint32_t)k : 0u);
             t.depth = (uint8_t)depth;
             t.pad[0] = (uint8_t)deg, t.pad[1] = t.pad[2] = 0;
             d.tasks[R->cFirst[c] + slot] = t;
@@ -731,372 +925,513 @@ __global__ __launch_bounds__(256) void fr_tasks_kernel(FrDev d) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// decide: Octree.cpp:594-601 per job, and the index of every splitting job's first child
+// fr_round_kernel: closes a round (Octree.cpp:243-299 in node-index order, :594-601 per job, :216) and opens the next
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void fr_decide_kernel(FrDev d) {
+constexpr uint32_t kFrInlineNodes = 65536;  // trees up to here are selected by the closing workgroup itself (64 passes of 1024 lanes)
+constexpr unsigned long long kFrWaitTicks = 200000000ull;  // two seconds of the 100 MHz clock: a wait this long means a workgroup is gone
+
+__device__ __forceinline__ uint32_t frLoad(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// one lane waits until *p >= want (the counter's writers fence before they add); false: the wait ran out
+__device__ bool frWaitAtLeast(const uint32_t* p, uint32_t want) {
+    if (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        for (int k = 0; k < 64; ++k) {
+            if (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (wall_clock64() - t0 > kFrWaitTicks) return false;
+    }
+}
+
+// Workgroups 1 .. gridDim.x - 2: 128 jobs each, eight lanes per job.
+__device__ void frUpdateJobs(const FrDev& d, FrLds& L) {
     FrHdr* h = d.hdr;
-    if (h->done) return;
-    __shared__ uint32_t sScan[16];
-    __shared__ uint32_t sCnt[4];  // P, -, dropped, max degree
-    __shared__ int sDelta;
-    __shared__ uint32_t sPeer;
-    const uint32_t tid = threadIdx.x, nJobs = h->nJobs, nNodes0 = h->nNodes;
-    const bool round0 = h->round == 0;
-    FR_STAMP(8);
-    if (tid < 4) sCnt[tid] = 0;
-    if (tid == 0) sDelta = 0, sPeer = 0;
-    __syncthreads();
-    frPeerCheck(d, &sPeer);
-    // thread t owns jobs 4 t .. 4 t + 3 from the decision to the operand list: their errors stay in registers
-    uint32_t nP = 0, nD = 0, maxDeg = 0;
-    int delta = 0;
-    int kd[4];
-    double ev[4][9], be[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const uint32_t j = tid * 4u + (uint32_t)q;
-        kd[q] = 0;
-        be[q] = 0.0;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) ev[q][i] = 0.0;
-        if (j >= nJobs) continue;
-        const uint32_t idx = d.batchIdx[j];
-        const double err = d.batchErr[j];
-        be[q] = err;
-        const int p = d.nodes[idx].degree, dep = d.nodes[idx].depth;
-        const double* e = d.errs + frErrSlot(d, h, j);
-        const bool coarse = fabs(err - HPSDF_INITIAL_NODE_ERR) < DBL_EPSILON;
+    const uint32_t tid = threadIdx.x, w = blockIdx.x - 1u;
+    const int lane = (int)(tid & 63), sub = (int)(tid & 7), wave = (int)(tid >> 6), b0 = lane & ~7;
+    const uint32_t j = w * 128u + (tid >> 3);
+    // (what depends on the job number alone is asked for together with the header: the batch arrays hold kFrJobs entries whatever the round's size)
+    const uint32_t nJobs = h->nJobs, nNodes0 = h->nNodes, stamp = h->round + 1u;
+    uint32_t idx = d.batchIdx[j];
+    const double err = d.batchErr[j];
+    const uint32_t owner = d.world == 1 ? 0u : d.jobOwner[j];
+    const bool round0 = stamp == 1u;
+    if (w * 128u >= nJobs) {  // no jobs here (the grid is sized for K): arrive all the same -- the leader rewrites the header only when
+        if (tid == 0) {       // every workgroup of the launch has read it
+            if (!round0) atomicAdd(&h->opsArrive, 1u);
+            atomicAdd(&h->arrive, 1u);
+        }
+        return;
+    }
+    const bool live = j < nJobs;
+    for (uint32_t i = tid; i < 2048; i += 1024) L.hist[i] = 0;
+    if (tid == 0) L.c = 0, L.next = 0, L.stuck = 0;  // largest new degree, coefficients gained (as an int)
+    double e = 0.0, e0 = 0.0;
+    int p = 0, dep = 0;
+    bool coarse = false;
+    float bmn[3] = {0, 0, 0}, bmx[3] = {0, 0, 0};
+    if (live) {
+        const hpsdf_node& n = d.nodes[idx];
+        const size_t slot = frErrSlot(d, h, j);
+        coarse = fabs(err - HPSDF_INITIAL_NODE_ERR) < DBL_EPSILON;
+        const double ek = d.errs[slot + 1 + sub], ep = d.errs[slot];  // (nine doubles a job, whether or not a fit wrote them)
+        p = n.degree, dep = n.depth;
+        for (int a = 0; a < 3; ++a) bmn[a] = n.aabb_min[a], bmx[a] = n.aabb_max[a];
         const bool hasH = !coarse && dep < kMaxDepth, hasP = coarse || p < kMaxDegree - 1;
-        if (hasP) ev[q][0] = e[0];
-        if (hasH) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) ev[q][1 + i] = e[1 + i];
-        }
-        const double pErr = ev[q][0];
-        double pImp, hImp;
-        if (coarse) {
-            hImp = 0.0;   // :806-810
-            pImp = pErr;  // :842
-        } else {
-            if (dep < kMaxDepth) {
-                double maxNewErr = 0.0;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) maxNewErr = maxNewErr < ev[q][1 + i] ? ev[q][1 + i] : maxNewErr;  // std::max
-                hImp = (1.0 / (7.0 * (double)frCoef(p))) * (err - 8.0 * maxNewErr);  // :825
-            } else {
-                hImp = 0.0;
-            }
-            if (p < kMaxDegree - 1)
-                pImp = (1.0 / (double)(frCoef(p + 1) - frCoef(p))) * (err - 8.0 * pErr);  // :854
-            else
-                pImp = 0.0;
-        }
-        bool refineP = p < (kMaxDegree - 1) && (dep == kMaxDepth || pImp > hImp);  // :600
-        if (coarse) refineP = true;
-        const bool refineH = dep < kMaxDepth && !refineP;  // :601
-        const int kind = refineP ? 1 : (refineH ? 2 : 0);
-        kd[q] = kind;
-        d.kind[j] = (uint8_t)kind;
-        if (kind == 1) {
-            const int np = coarse ? 2 : p + 1;
-            ++nP;
-            maxDeg = (uint32_t)np > maxDeg ? (uint32_t)np : maxDeg;
-            // coefficients gained (the template's subtree counts already stand for "every cell at degree 2")
-            delta += (int)frCoef(np) - (int)(round0 ? frCoef(2) : frCoef(p));
-        } else if (kind == 2) {
-            delta += 7 * (int)frCoef(p);
-        } else {
-            ++nD;
-        }
+        if (hasH) e = ek;
+        if (hasP && sub == 0) e0 = ep;
+    } else {
+        idx = 0;
     }
-    if (nP) atomicAdd(&sCnt[0], nP);
-    if (nD) atomicAdd(&sCnt[2], nD);
-    if (maxDeg) atomicMax(&sCnt[3], maxDeg);
-    if (delta) atomicAdd(&sDelta, delta);
-    FR_STAMP(9);
-    // first child of every H job: node count so far + 8 x (H jobs before it).  The same scan (H count in the high half,
-    // P count in the low half of one word) places every job's additions to the running total in a dense list: a P result
-    // adds (newErr - initialErr) (:255); an H result subtracts initialErr once (:268) and adds its 8 children's errors (:272).
-    uint32_t c = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) c += kd[q] == 2 ? 0x10000u : (kd[q] == 1 ? 1u : 0u);
-    uint32_t inc = c;
-    const int lane = (int)(tid & 63);
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t v = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += v;
+    __syncthreads();
+    // ---- the decision, Octree.cpp:594-601, on every lane of the job alike
+    const double pErr = __shfl(e0, b0, 64);
+    double maxNewErr = 0.0;
+    for (int i = 0; i < 8; ++i) {
+        const double v = __shfl(e, b0 + i, 64);
+        maxNewErr = maxNewErr < v ? v : maxNewErr;  // std::max
     }
-    if (lane == 63) sScan[tid >> 6] = inc;
+    double pImp, hImp;
+    if (coarse) {
+        hImp = 0.0;   // :806-810
+        pImp = pErr;  // :842
+    } else {
+        hImp = dep < kMaxDepth ? (1.0 / (7.0 * (double)frCoef(p))) * (err - 8.0 * maxNewErr) : 0.0;           // :825
+        pImp = p < kMaxDegree - 1 ? (1.0 / (double)(frCoef(p + 1) - frCoef(p))) * (err - 8.0 * pErr) : 0.0;  // :854
+    }
+    bool refineP = p < (kMaxDegree - 1) && (dep == kMaxDepth || pImp > hImp);  // :600
+    if (coarse) refineP = true;
+    const bool refineH = dep < kMaxDepth && !refineP;  // :601
+    const int kind = !live ? 0 : (refineP ? 1 : (refineH ? 2 : 0));
+    const int np = coarse ? 2 : p + 1;
+    int delta = 0;
+    if (kind == 1)
+        delta = (int)frCoef(np) - (int)(round0 ? frCoef(2) : frCoef(p));  // (the header's count already stands for "every cell at degree 2")
+    else if (kind == 2)
+        delta = 7 * (int)frCoef(p);
+    // ---- splitting / P jobs before this one: in the wave by ballots, in the workgroup over the 16 wave counts, in the round
+    //      over the counts the workgroups before this one have published
+    const bool lead = live && sub == 0;
+    const unsigned long long mH = __ballot(lead && kind == 2), mP = __ballot(lead && kind == 1);
+    const unsigned long long below = (1ull << b0) - 1ull;
+    if (lane == 0) L.wave[wave] = ((uint32_t)__popcll(mH) << 16) | (uint32_t)__popcll(mP);
+    if (lead && kind == 1) atomicMax(&L.c, (uint32_t)np);
+    if (lead && delta) atomicAdd(reinterpret_cast<int*>(&L.next), delta);
     __syncthreads();
     uint32_t before = 0, all = 0;
-    for (uint32_t w = 0; w < 16; ++w) {
-        if (w < (tid >> 6)) before += sScan[w];
-        all += sScan[w];
+    for (int ww = 0; ww < 16; ++ww) {
+        const uint32_t v = L.wave[ww];
+        if (ww < wave) before += v;
+        all += v;
     }
-    FR_STAMP(10);
-    uint32_t run = before + inc - c;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const uint32_t j = tid * 4u + (uint32_t)q;
-        if (j >= nJobs) continue;
-        const uint32_t hBefore = run >> 16, pBefore = run & 0xFFFFu;
-        d.base[j] = nNodes0 + 8u * hBefore;
+    if (tid == 0) {
+        __hip_atomic_store(&h->agg[w], ((uint64_t)stamp << 32) | all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the round's counts (the last workgroup sizes the operand list from them: ahead of the operands' "written" signal)
+        const uint32_t mine = nJobs - w * 128u < 128u ? nJobs - w * 128u : 128u, nP = all & 0xFFFFu, nH = all >> 16;
+        if (nP) atomicAdd(&h->rP, nP);
+        if (nH) atomicAdd(&h->rH, nH);
+        if (mine - nP - nH) atomicAdd(&h->rD, mine - nP - nH);
+        if (L.c) atomicMax(&h->rMaxDeg, L.c);
+        const int dl = *reinterpret_cast<int*>(&L.next);
+        if (dl) atomicAdd(reinterpret_cast<unsigned long long*>(&h->rCoeffDelta), (unsigned long long)(long long)dl);
+    }
+    if (tid < 64) {
+        uint32_t v = 0;
+        if (tid < w) {
+            uint64_t a = __hip_atomic_load(&h->agg[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint32_t)(a >> 32) != stamp) {
+                const unsigned long long t0 = wall_clock64();
+                do {
+                    __builtin_amdgcn_s_sleep(1);
+                    a = __hip_atomic_load(&h->agg[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } while ((uint32_t)(a >> 32) != stamp && wall_clock64() - t0 < kFrWaitTicks);
+                if ((uint32_t)(a >> 32) != stamp) L.stuck = 1, a = 0;
+            }
+            v = (uint32_t)a;
+        }
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (tid == 0) L.above = v;
+    }
+    __syncthreads();
+    const bool stuck = L.stuck != 0;
+    const uint32_t run = L.above + before;
+    const uint32_t hBefore = (run >> 16) + (uint32_t)__popcll(mH & below), pBefore = (run & 0xFFFFu) + (uint32_t)__popcll(mP & below);
+    const uint32_t c0 = nNodes0 + 8u * hBefore;          // first child of a splitting job
+    const bool full = kind == 2 && c0 + 8u > d.nodeCap;  // cannot happen: the host sizes for 8 K new nodes
+    if (full && sub == 0) atomicExch(&h->overflow, 1u);
+    if (stuck && tid == 0) atomicExch(&h->stuck, 1u);
+    const bool apply = live && !full && !stuck;
+    // ---- the job's additions to the running total, densely, in job order: a P result adds (newErr - initialErr) (:255); an H
+    //      result subtracts initialErr once (:268) and adds its 8 children's errors (:272).  (Round 0: the last workgroup reads
+    //      the errors themselves.)
+    if (!round0 && apply) {
         double* o = d.ops + (pBefore + 9u * hBefore);
-        if (kd[q] == 1) {
-            o[0] = ev[q][0] - be[q];
-            run += 1u;
-        } else if (kd[q] == 2) {
-            o[0] = be[q] * -1.0;  // total -= err  ==  total + (-err)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) o[1 + i] = ev[q][1 + i];
-            run += 0x10000u;
+        if (kind == 1) {
+            if (sub == 0) o[0] = pErr - err;
+        } else if (kind == 2) {
+            if (sub == 0) o[0] = err * -1.0;  // total -= err  ==  total + (-err)
+            o[1 + sub] = e;
         }
     }
+    // ---- tree and queue.  (The coefficient counts of the subtrees, which ReallocCoeffs needs, are added up once, when the build
+    //      has stopped -- fr_subtree_kernel; walking up every job's ancestors here was a chain of dependent atomics a round.)
+    if (apply && kind == 1) {  // :253-260, :286-290
+        if (sub == 0) {
+            // (weighted: the new array holds every row, so it is the node's one and only segment)
+            const int first = (coarse || d.weighted) ? np : (int)d.segFirst[idx];
+            if (coarse || d.weighted) d.segFirst[idx] = (uint8_t)np;
+            d.segOff[(size_t)idx * kFrSegs + (np - first)] = (d.jobP[j] & kOffMask) | ((uint64_t)owner << 56);
+            d.nodes[idx].degree = (uint8_t)np;
+            const uint64_t bits = (uint64_t)__double_as_longlong(pErr);
+            d.qErr[idx] = bits;
+            atomicAdd(&L.hist[frDigit(0, bits, idx)], 1u);
+        }
+    }
+    {   // :262-279, :286-290; Octree::Subdivide :1115-1128 -- the eight children of a splitting job are eight consecutive nodes:
+        // lane `sub` makes child `sub`, the wave stores its 64 records in order (frStoreRecords)
+        const bool split = apply && kind == 2;
+        const uint32_t ch = c0 + (uint32_t)sub;
+        float mn[3], mx[3];
+        for (int a = 0; a < 3; ++a) {  // CornerAABB
+            const float mid = (bmx[a] + bmn[a]) * 0.5f;
+            mn[a] = (sub >> a) & 1 ? mid : bmn[a];
+            mx[a] = (sub >> a) & 1 ? bmx[a] : mid;
+        }
+        auto word2 = [](float lo, float hi) { return (uint64_t)__float_as_uint(lo) | ((uint64_t)__float_as_uint(hi) << 32); };
+        uint64_t wd[7];
+        wd[0] = ~0ull;  // child_idx: a leaf
+        wd[1] = word2(mn[0], mn[1]), wd[2] = word2(mn[2], mx[0]), wd[3] = word2(mx[1], mx[2]);
+        wd[4] = 0;                        // coeffs_start
+        wd[5] = (uint64_t)(uint32_t)p;    // degree, pad0
+        wd[6] = (uint64_t)(uint32_t)(dep + 1);  // depth, pad1
+        frStoreRecords(L.stage[wave], reinterpret_cast<uint64_t*>(d.nodes), wd, (uint64_t)c0 * 7u, split, true);
+        if (split) {
+            d.parent[ch] = idx;
+            d.sub[ch] = 0;
+            d.segFirst[ch] = (uint8_t)p;
+            d.segOff[(size_t)ch * kFrSegs] = ((d.jobH[j] + (uint64_t)sub * frCoef(p)) & kOffMask) | ((uint64_t)owner << 56);
+            const uint64_t bits = (uint64_t)__double_as_longlong(e);
+            d.qErr[ch] = bits;
+            atomicAdd(&L.hist[frDigit(0, bits, ch)], 1u);
+            if (sub == 0) {
+                d.nodes[idx].child_idx = c0;
+                d.nodes[idx].degree = kInteriorDegree;
+                d.nodes[idx].coeffs_start = 0;
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < 2048; i += 1024)
+        if (L.hist[i]) atomicAdd(&h->hist1[i], L.hist[i]);
+    __threadfence();
+    __syncthreads();
     if (tid == 0) {
-        const uint32_t nH = all >> 16;
-        h->rP = sCnt[0], h->rH = nH, h->rD = sCnt[2], h->rMaxDeg = sCnt[3];
-        h->rOps = (all & 0xFFFFu) + 9u * nH;
-        h->rPad = sPeer;  // (barriers lie between the check and here) a rank that failed this round, + 1
-        h->dbg[11] = __builtin_readcyclecounter();
-        h->rCoeffDelta = (int64_t)sDelta;
-        h->arrive = 0;
-        if (nNodes0 + 8u * nH > d.nodeCap) h->overflow = 1, h->done = 1;  // cannot happen: the host sizes for 8 K new nodes
+        if (!round0) atomicAdd(&h->opsArrive, 1u);
+        atomicAdd(&h->arrive, 1u);
     }
 }
 
-__device__ __forceinline__ double frReadLane(double v, int l) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-    return __hiloint2double(hi, lo);
-}
-
-// Whoever arrives last closes the round: counters, stop rule (Octree.cpp:216), the threshold bin of the next selection,
-// and the header's mirror in pinned host memory (the host waits for the stream and reads it there: no copy to launch).
-__device__ void frCloseRound(const FrDev& d, uint32_t nJobs, bool round0, uint32_t* sHist, uint32_t* sTmp) {
-    FrHdr* h = d.hdr;
-    __shared__ int sLast, sT;
-    __shared__ uint32_t sAbove;
+// all threads: every header word but the round number, a system-scope fence, then the round number -- the host watches that word
+__device__ __forceinline__ void frMirror(const FrDev& d) {
     const uint32_t tid = threadIdx.x;
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) sLast = atomicAdd(&h->arrive, 1u) == gridDim.x - 1u ? 1 : 0;
-    __syncthreads();
-    if (!sLast) return;
-    __threadfence();
-    const uint32_t nP = *(volatile uint32_t*)&h->rP, nH = *(volatile uint32_t*)&h->rH, nD = *(volatile uint32_t*)&h->rD;
-    const uint32_t nQ = h->nQueued - (round0 ? 0u : nJobs) + nP + 8u * nH;  // (round 0's batch never sat in the queue)
-    const double total = *(volatile double*)&h->rTotal;
-    const bool done = total < h->target || nQ == 0;  // Octree.cpp:216
-    for (uint32_t i = tid; i < 2048; i += 256) {
-        sHist[i] = *(volatile uint32_t*)&h->hist1[i];
-        h->hist2[i] = 0;
-    }
-    __syncthreads();
-    if (!done && nQ > d.K) {
-        frThreshold(sHist, d.K, sTmp, &sT, &sAbove);
-    } else {
-        if (tid == 0) sT = -1, sAbove = nQ;
-        __syncthreads();
-    }
-    if (tid == 0) {
-        h->nQueued = nQ;
-        h->nNodes += 8u * nH;
-        h->total = total;
-        h->jobs += nJobs, h->pRefines += nP, h->hRefines += nH, h->dropped += nD;
-        h->nLeaves += 7u * nH;
-        h->nCoeffs = (uint64_t)((int64_t)h->nCoeffs + *(volatile int64_t*)&h->rCoeffDelta);
-        const uint32_t md = *(volatile uint32_t*)&h->rMaxDeg;
-        if (md > h->maxDegree) h->maxDegree = md;
-        h->round += 1;
-        h->takenCount = 0, h->candCount = 0, h->arrive = 0;
-        h->t1 = sT, h->above = sAbove;
-        if (done && h->nCoeffs > d.storeCap) h->overflow = 2;  // the host grows the store and runs fr_store_kernel again
-        h->done = done ? 1u : 0u;
-        __threadfence();
-    }
-    __syncthreads();
-    // the mirror: every word but the round number, a system-scope fence, then the round number -- the host watches that word
     constexpr uint32_t kRoundWord = offsetof(FrHdr, round) / 4;
-    if (tid < kFrHdrCopyBytes / 4 && tid != kRoundWord)
-        reinterpret_cast<volatile uint32_t*>(d.hostHdr)[tid] = reinterpret_cast<volatile uint32_t*>(h)[tid];
+    __threadfence();
+    __syncthreads();
+    constexpr uint32_t kLandedWord = offsetof(FrHdr, landed) / 4;
+    if (tid < kFrHdrCopyBytes / 4 && tid != kRoundWord && tid != kLandedWord)
+        reinterpret_cast<volatile uint32_t*>(d.hostHdr)[tid] = reinterpret_cast<volatile uint32_t*>(d.hdr)[tid];
     __threadfence_system();
     __syncthreads();
     if (tid == 0) {
-        reinterpret_cast<volatile uint32_t*>(d.hostHdr)[kRoundWord] = reinterpret_cast<volatile uint32_t*>(h)[kRoundWord];
+        reinterpret_cast<volatile uint32_t*>(d.hostHdr)[kRoundWord] = reinterpret_cast<volatile uint32_t*>(d.hdr)[kRoundWord];
         __threadfence_system();
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// update: Octree.cpp:243-299 in node-index order.  Workgroup 0 carries the running total (one dependent addition after
-// the other, the reference's order); the others update tree and queue, eight lanes per job.  The workgroup that finishes
-// last closes the round: counters, stop rule (:216), the next selection's threshold bin.
-// ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fr_update_kernel(FrDev d) {
-    FrHdr* h = d.hdr;
-    if (h->done) return;  // (set by an earlier round, or by decide on overflow: uniform over the grid)
-    __shared__ uint32_t sHist[2048];
-    __shared__ uint32_t sTmp[256];
-    __shared__ double sOps[2][2048];  // workgroup 0: the running total's operands, double-buffered
-    const uint32_t tid = threadIdx.x, nJobs = h->nJobs;
-    const bool round0 = h->round == 0;
-    if (blockIdx.x == 0) {
-        // The running total: one dependent addition after the other, in the dense order fr_decide_kernel laid out.  Wave 0
-        // adds; waves 1..3 bring the next 2048 operands into the other half of the LDS buffer meanwhile (a lone wave
-        // loading its own operands waits out an L2 round trip every 64 jobs: 129 us for round 0's 4096 additions).
-        const uint32_t nOps = h->rOps;
-        double total = h->total;
-        for (uint32_t k = tid; k < 2048 && k < nOps; k += 256) sOps[0][k] = d.ops[k];
-        __syncthreads();
-        for (uint32_t c0 = 0, half = 0; c0 < nOps; c0 += 2048, half ^= 1u) {
-            const uint32_t n = nOps - c0 < 2048u ? nOps - c0 : 2048u;
-            if (tid >= 64) {
-                const uint32_t nx = c0 + 2048;
-                for (uint32_t k = tid - 64; k < 2048 && nx + k < nOps; k += 192) sOps[half ^ 1u][k] = d.ops[nx + k];
-            } else {
-                const double* src = sOps[half];
-                uint32_t q = 0;
-                for (; q + 16 <= n; q += 16) {
-                    double o[16];
+// The running total, Octree.cpp:253-290 -- one dependent addition after the other in the reference's order, from the dense operand
+// list the update workgroups have written (round 0: straight from the fits' error slots).  One workgroup: wave 0 adds, alone on its
+// SIMD (waves 4, 8 and 12 do nothing); the twelve waves of the other three SIMDs bring the next 2048 operands into the other half of an
+// LDS buffer meanwhile, each lane's loads in flight together (a lone wave loading its own operands waits out an L2 round trip every
+// 64 jobs: 129 us for round 0's 4096 additions; three loader waves taking their elements one round trip after the other still left
+// the adder waiting).  The adder's pace is that of v_add_f64 with a fresh operand, 8.6 cycles: tools/chain_lab.hip tried what else
+// could feed it -- DPP broadcasts, SGPR operands through scalar loads, one active lane, a hand-scheduled loop -- and nothing did better.
+// All waves that are still there call (barriers inside).
+__device__ double frRunChain(const FrDev& d, FrLds& L, double total, uint32_t nOps, bool round0) {
+    const FrHdr* h = d.hdr;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6;
+    const bool adder = wave == 0, loader = (wave & 3u) != 0;
+    const uint32_t ltid = (wave - 1u - (wave >> 2)) * 64u + (tid & 63u);  // 0 .. 767 among the loaders
+    double* sOps = reinterpret_cast<double*>(L.key);                         // [2][2048]
+    auto operand = [&](uint32_t k) { return round0 ? d.errs[frErrSlot(d, h, k)] - d.batchErr[k] : d.ops[k]; };
+    auto loadChunk = [&](uint32_t first, double* dst) {  // operands [first, first + 2048) (those below nOps): three a lane
+        double v[3];
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) o[k] = src[q + k];
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) total = total + o[k];
-                }
-                for (; q < n; ++q) total = total + src[q];
-            }
-            __syncthreads();
+        for (int u = 0; u < 3; ++u) {
+            const uint32_t k = ltid + (uint32_t)u * 768u;
+            v[u] = (k < 2048u && first + k < nOps) ? operand(first + k) : 0.0;
         }
-        if (tid == 0) h->rTotal = total;
-    } else {
-        for (uint32_t i = tid; i < 2048; i += 256) sHist[i] = 0;
-        __syncthreads();
-        const int sub = (int)(tid & 7);
-        const uint32_t j = (blockIdx.x - 1u) * 32u + (tid >> 3);
-        if (j < nJobs) {
-            const uint32_t idx = d.batchIdx[j];
-            const int kind = d.kind[j];
-            const hpsdf_node par = d.nodes[idx];
-            const int p = par.degree, dep = par.depth;
-            const bool coarse = fabs(d.batchErr[j] - HPSDF_INITIAL_NODE_ERR) < DBL_EPSILON;
-            int delta = 0;
-            if (kind == 1) {  // :253-260, :286-290
-                if (sub == 0) {
-                    const int np = coarse ? 2 : p + 1;
-                    // (weighted: the new array holds every row, so it is the node's one and only segment)
-                    const int first = (coarse || d.weighted) ? np : (int)d.segFirst[idx];
-                    if (coarse || d.weighted) d.segFirst[idx] = (uint8_t)np;
-                    d.segOff[(size_t)idx * kFrSegs + (np - first)] = (d.jobP[j] & kOffMask) | ((uint64_t)(d.world == 1 ? 0 : d.jobOwner[j]) << 56);
-                    d.nodes[idx].degree = (uint8_t)np;
-                    const double pErr = d.errs[frErrSlot(d, h, j)];
-                    const uint64_t bits = (uint64_t)__double_as_longlong(pErr);
-                    d.qErr[idx] = bits;
-                    atomicAdd(&sHist[frDigit(0, bits, idx)], 1u);
-                    delta = (int)frCoef(np) - (int)(round0 ? frCoef(2) : frCoef(p));
-                }
-            } else if (kind == 2) {  // :262-279, :286-290; Octree::Subdivide :1115-1128
-                const uint32_t c0 = d.base[j], ch = c0 + (uint32_t)sub;
-                hpsdf_node c;
-                c.child_idx = ~0ull;
-                for (int a = 0; a < 3; ++a) {  // CornerAABB
-                    const float mid = (par.aabb_max[a] + par.aabb_min[a]) * 0.5f;
-                    c.aabb_min[a] = (sub >> a) & 1 ? mid : par.aabb_min[a];
-                    c.aabb_max[a] = (sub >> a) & 1 ? par.aabb_max[a] : mid;
-                }
-                c.coeffs_start = 0;
-                c.degree = (uint8_t)p;
-                for (int a = 0; a < 7; ++a) c.pad0[a] = 0, c.pad1[a] = 0;
-                c.depth = (uint8_t)(dep + 1);
-                d.nodes[ch] = c;
-                d.parent[ch] = idx;
-                d.segFirst[ch] = (uint8_t)p;
-                d.segOff[(size_t)ch * kFrSegs] = ((d.jobH[j] + (uint64_t)sub * frCoef(p)) & kOffMask) | ((uint64_t)(d.world == 1 ? 0 : d.jobOwner[j]) << 56);
-                const double hErr = d.errs[frErrSlot(d, h, j) + 1 + sub];
-                const uint64_t bits = (uint64_t)__double_as_longlong(hErr);
-                d.qErr[ch] = bits;
-                atomicAdd(&sHist[frDigit(0, bits, ch)], 1u);
-                if (sub == 0) {
-                    d.nodes[idx].child_idx = c0;
-                    d.nodes[idx].degree = kInteriorDegree;
-                    d.nodes[idx].coeffs_start = 0;
-                    d.sub[idx] = 8u * frCoef(p);
-                    delta = 7 * (int)frCoef(p);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const uint32_t k = ltid + (uint32_t)u * 768u;
+            if (k < 2048u && first + k < nOps) dst[k] = v[u];
+        }
+    };
+    if (loader) loadChunk(0, sOps);
+    __syncthreads();
+    for (uint32_t c0 = 0, half = 0; c0 < nOps; c0 += 2048, half ^= 1u) {
+        const uint32_t n = nOps - c0 < 2048u ? nOps - c0 : 2048u;
+        if (loader) {
+            if (c0 + 2048u < nOps) loadChunk(c0 + 2048u, sOps + (half ^ 1u) * 2048u);
+        } else if (adder) {
+            // two batches of sixteen operands in registers (the compiler turns them into "read 32, add 32")
+            const double* src = sOps + half * 2048u;
+            uint32_t q = 0;
+            if (n >= 32) {
+                double a[16], b[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) a[k] = src[k];
+                for (; q + 32 <= n; q += 32) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) b[k] = src[q + 16 + k];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) total = total + a[k];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) a[k] = src[q + 32 + k];  // (at most 32 entries past n: inside the buffer pair)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) total = total + b[k];
                 }
             }
-            if (delta != 0) {  // coefficient counts of the ancestors (the root's is the header's nCoeffs)
-                uint32_t a = d.parent[idx];
-                while (a != 0) {
-                    atomicAdd(&d.sub[a], (uint32_t)delta);
-                    a = d.parent[a];
-                }
-            }
+            for (; q < n; ++q) total = total + src[q];
         }
         __syncthreads();
-        for (uint32_t i = tid; i < 2048; i += 256)
-            if (sHist[i]) atomicAdd(&h->hist1[i], sHist[i]);
     }
-    frCloseRound(d, nJobs, round0, sHist, sTmp);
+    if (tid == 0) sOps[0] = total;  // (wave 0's lanes all carry it; the other waves get it through LDS)
+    __syncthreads();
+    return sOps[0];
 }
 
-// Round 0 for itself: every job is a coarse cell that takes its degree-2 fit (:806-810, :836-843), so there is nothing to
-// decide and no child to place -- workgroup 0 sums (newErr - 100) in job order straight from the fit's error slots, the
-// others (one lane per cell) set degree, first segment and queued error.
-__global__ __launch_bounds__(256) void fr_round0_kernel(FrDev d) {
+// The last workgroup: the running total of rounds >= 1, beside everything else -- nobody waits for it before the next round is
+// prepared: the leader only needs the total for the stop rule.  (Round 0's total the leader adds up itself: its operands are there when
+// the launch starts, and most builds at everyday thresholds end with it -- no hand-over on their critical path.)
+__device__ void frChainTotal(const FrDev& d, FrLds& L) {
     FrHdr* h = d.hdr;
-    __shared__ uint32_t sHist[2048];
-    __shared__ uint32_t sTmp[256];
-    __shared__ double sOps[2][2048];
-    const uint32_t tid = threadIdx.x, nJobs = h->nJobs;
-    if (blockIdx.x == 0) {
-        double total = h->total;
-        if (tid == 0) sTmp[0] = 0;
-        __syncthreads();
-        frPeerCheck(d, &sTmp[0]);
-        for (uint32_t k = tid; k < 2048 && k < nJobs; k += 256) sOps[0][k] = d.errs[frErrSlot(d, h, k)] - d.batchErr[k];
-        __syncthreads();
-        const uint32_t peer = sTmp[0];
-        for (uint32_t c0 = 0, half = 0; c0 < nJobs; c0 += 2048, half ^= 1u) {
-            const uint32_t n = nJobs - c0 < 2048u ? nJobs - c0 : 2048u;
-            if (tid >= 64) {
-                const uint32_t nx = c0 + 2048;
-                for (uint32_t k = tid - 64; k < 2048 && nx + k < nJobs; k += 192)
-                    sOps[half ^ 1u][k] = d.errs[frErrSlot(d, h, nx + k)] - d.batchErr[nx + k];
-            } else {
-                const double* src = sOps[half];
-                uint32_t q = 0;
-                for (; q + 16 <= n; q += 16) {
-                    double o[16];
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) o[k] = src[q + k];
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) total = total + o[k];
-                }
-                for (; q < n; ++q) total = total + src[q];
-            }
-            __syncthreads();
-        }
-        if (tid == 0) {
-            h->rTotal = total;
-            h->rPad = peer;
-            h->rP = nJobs, h->rH = 0, h->rD = 0, h->rMaxDeg = 2, h->rCoeffDelta = 0;
-        }
-    } else {
-        for (uint32_t i = tid; i < 2048; i += 256) sHist[i] = 0;
-        __syncthreads();
-        const uint32_t j = (blockIdx.x - 1u) * 256u + tid;
-        if (j < nJobs) {
-            const uint32_t idx = d.batchIdx[j];
-            d.segFirst[idx] = 2;
-            d.segOff[(size_t)idx * kFrSegs] = (d.jobP[j] & kOffMask) | ((uint64_t)(d.world == 1 ? 0 : d.jobOwner[j]) << 56);
-            d.nodes[idx].degree = 2;
-            const uint64_t bits = (uint64_t)__double_as_longlong(d.errs[frErrSlot(d, h, j)]);
-            d.qErr[idx] = bits;
-            atomicAdd(&sHist[frDigit(0, bits, idx)], 1u);
-        }
-        __syncthreads();
-        for (uint32_t i = tid; i < 2048; i += 256)
-            if (sHist[i]) atomicAdd(&h->hist1[i], sHist[i]);
+    const uint32_t tid = threadIdx.x, wave = tid >> 6;
+    if (wave != 0 && (wave & 3u) == 0) return;  // (whole waves: the barriers below count the waves that are still there)
+    const uint32_t stamp = h->round + 1u;
+    const bool round0 = stamp == 1u;
+    double total = h->total;
+    if (tid == 0) L.stuck = 0;
+    __syncthreads();
+    // (the header has been read: the leader may rewrite it.  The round's counters it leaves alone until this workgroup has finished.)
+    if (tid == 0) __hip_atomic_fetch_add(&h->arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (round0) return;
+    if (tid == 0 && !frWaitAtLeast(&h->opsArrive, gridDim.x - 2u)) L.stuck = 1;
+    __syncthreads();
+    __threadfence();
+    uint32_t nOps = frLoad(&h->rP) + 9u * frLoad(&h->rH);
+    if (L.stuck) nOps = 0;
+    if (tid == 0) h->dbg[13] = __builtin_readcyclecounter();
+    total = frRunChain(d, L, total, nOps, false);
+    if (tid == 0) {
+        h->dbg[14] = __builtin_readcyclecounter();
+        if (L.stuck) atomicExch(&h->stuck, 1u);
+        h->rTotal = total;
+        __threadfence();
+        __hip_atomic_store(&h->chainStamp, stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
-    frCloseRound(d, nJobs, true, sHist, sTmp);
+}
+
+// Workgroup 0.  When every update workgroup has arrived: counters, the threshold bin of the next selection; then the stop rule
+// (:216) -- if the running total is there already (round 0: always), else the next round is prepared first, on the assumption that
+// the build goes on (`pre`: selection, batch and lists, by this workgroup), and the rule is applied when the total has come: a
+// build that stops takes the prepared round's entries out of the header again (what else the preparation touched -- queue marks,
+// histogram, lists -- is not read after the stop).  Last the header's mirror in pinned host memory (the host watches the round
+// word: no copy).
+__device__ void frLeadRound(const FrDev& d, FrLds& L, int pre) {
+    FrHdr* h = d.hdr;
+    const uint32_t tid = threadIdx.x, nJobs = h->nJobs, round = h->round, stamp = round + 1u;
+    const bool round0 = round == 0;
+    const uint32_t nNodes0 = h->nNodes, nQ0 = h->nQueued;
+    const double target = d.target;
+    if (tid == 0) L.flag = 0, L.stuck = 0;
+    if (tid == 0 && round0) {
+        *(volatile uint32_t*)&d.hostHdr->landed = d.buildStamp;
+        __threadfence_system();
+    }
+    __syncthreads();
+    frPeerCheck(d, &L.flag);
+    FR_STAMP(9);
+    double total0 = 0.0;
+    if (round0) {  // the round's total, here and now: every cell's (newErr - initialErr) in cell order
+        if (tid == 0) h->dbg[13] = __builtin_readcyclecounter();
+        total0 = frRunChain(d, L, h->total, nJobs, true);
+        if (tid == 0) h->dbg[14] = __builtin_readcyclecounter();
+    }
+    if (tid == 0 && !frWaitAtLeast(&h->arrive, gridDim.x - 1u)) L.stuck = 1;  // (the update workgroups, and the last one's "header read")
+    __syncthreads();
+    __threadfence();
+    FR_STAMP(10);
+    // ---- the round closes
+    const uint32_t nP = frLoad(&h->rP), nH = frLoad(&h->rH), nD = frLoad(&h->rD), md = frLoad(&h->rMaxDeg);
+    const long long cd = (long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&h->rCoeffDelta), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t overflow = frLoad(&h->overflow) | ((L.stuck || frLoad(&h->stuck)) ? 4u : 0u);
+    const uint32_t nQ = nQ0 - (round0 ? 0u : nJobs) + nP + 8u * nH;  // (round 0's batch never sat in the queue)
+    const uint32_t nNodes = nNodes0 + 8u * nH;
+    for (uint32_t i = tid; i < 2048; i += 1024) L.hist[i] = frLoad(&h->hist1[i]);
+    if (tid == 0) L.c = (round0 || frLoad(&h->chainStamp) == stamp) ? 1u : 0u;
+    __syncthreads();
+    bool haveTotal = L.c != 0;
+    const bool canGoOn = nQ != 0 && overflow == 0;
+    if (canGoOn && nQ > d.K) {
+        frThreshold(L.hist, d.K, L.tmp, &L.t, &L.above);
+    } else {
+        if (tid == 0) L.t = -1, L.above = nQ;
+        __syncthreads();
+    }
+    const int T = L.t;
+    const uint32_t above = L.above;
+    // the total: wait for it now unless the next round can be prepared meanwhile
+    auto awaitTotal = [&]() {
+        if (tid == 0 && !frWaitAtLeast(&h->chainStamp, stamp)) L.stuck = 1;  // (stamps only grow within a build)
+        __syncthreads();
+        if (L.stuck) overflow |= 4u;
+    };
+    const bool speculate = !haveTotal && pre && canGoOn;
+    if (!haveTotal && !speculate) awaitTotal(), haveTotal = true;
+    double total = 0.0;
+    bool done = false;
+    if (haveTotal) {
+        if (round0) {
+            total = total0;
+        } else {
+            __threadfence();
+            total = *(volatile double*)&h->rTotal;
+        }
+        done = total < target || !canGoOn || overflow != 0;  // Octree.cpp:216
+    }
+    if (tid == 0) {
+        h->nQueued = nQ;
+        h->nNodes = nNodes;
+        h->jobs += nJobs, h->pRefines += nP, h->hRefines += nH, h->dropped += nD;
+        h->nLeaves += 7u * nH;
+        h->nCoeffs = (uint64_t)((int64_t)h->nCoeffs + cd);
+        if (md > h->maxDegree) h->maxDegree = md;
+        h->round = stamp;
+        h->takenCount = 0, h->candCount = 0;
+        h->rPad = L.flag;  // a rank that failed this round, + 1
+        h->t1 = T, h->above = above;
+    }
+    FR_STAMP(11);
+    const uint64_t fits0 = h->fits, samples0 = h->samples, arena0 = h->arenaUsed;  // (what a prepared round adds to)
+    __syncthreads();
+    if (pre && !done) {
+        // ---- the next round's selection, level 0: everything in the exponent bins above T is taken, bin T is the candidate list
+        //      (its level-1 digits counted as they are found)
+        for (uint32_t i = tid; i < 2048; i += 1024) L.hist[i] = 0;
+        if (tid == 0) L.c = 0, L.next = 0;
+        __syncthreads();
+        {
+            const int lane = (int)(tid & 63);
+            for (uint32_t base = 0; base < nNodes; base += 1024u) {
+                const uint32_t i = base + tid;
+                const uint64_t bits = i < nNodes ? d.qErr[i] : kNotQueued;
+                const bool queued = bits != kNotQueued;
+                const int d0 = (int)frDigit(0, bits, i);
+                const bool take = queued && d0 > T, cand = queued && d0 == T;
+                const unsigned long long mt = __ballot(take), mc = __ballot(cand);
+                if (mt) {
+                    uint32_t s = 0;
+                    const int leader = __ffsll((long long)mt) - 1;
+                    if (lane == leader) s = atomicAdd(&L.next, (uint32_t)__popcll(mt));
+                    s = __shfl(s, leader, 64);
+                    if (take) d.taken[s + (uint32_t)__popcll(mt & ((1ull << lane) - 1ull))] = i;
+                }
+                if (mc) {
+                    uint32_t s = 0;
+                    const int leader = __ffsll((long long)mc) - 1;
+                    if (lane == leader) s = atomicAdd(&L.c, (uint32_t)__popcll(mc));
+                    s = __shfl(s, leader, 64);
+                    if (cand) {
+                        d.candA[s + (uint32_t)__popcll(mc & ((1ull << lane) - 1ull))] = i;
+                        atomicAdd(&L.hist[frDigit(1, bits, i)], 1u);
+                    }
+                }
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        const uint32_t cand = L.c, taken = L.next;
+        __syncthreads();
+        frBatchBody<true>(d, L, nQ, above, cand, taken, nNodes);
+        __syncthreads();
+        if (!haveTotal) {
+            awaitTotal();
+            __threadfence();
+            total = *(volatile double*)&h->rTotal;
+            done = total < target || overflow != 0;
+            if (done && tid == 0) h->fits = fits0, h->samples = samples0, h->arenaUsed = arena0, h->sampleUsed = 0;
+        }
+    }
+    if (tid == 0) {
+        h->total = total;
+        // (the total is there, so the last workgroup has finished with the round's counters)
+        h->arrive = 0, h->opsArrive = 0;
+        h->rP = 0, h->rH = 0, h->rD = 0, h->rMaxDeg = 0, h->rCoeffDelta = 0;
+        if (overflow) h->overflow = overflow;
+        h->done = done ? 1u : 0u;
+        if (done) h->nJobs = 0, h->nTasks = 0, h->nBlocks = 0;
+        if (!done && pre && d.world > 1) *frStatusSlotNext(d, d.rank) = 0.0;  // this rank's status for the coming round's exchange
+    }
+    if (done && tid < 13)
+        h->degBlocks[tid][0] = h->degBlocks[tid][1] = h->degTasks[tid][0] = h->degTasks[tid][1] = h->lowTasks[tid][0] = h->lowTasks[tid][1] = 0;
+    if (!done && !pre)
+        for (uint32_t i = tid; i < 2048; i += 1024) h->hist2[i] = 0;  // (the grid selection's level-1 histogram)
+    FR_STAMP(12);
+    frMirror(d);
+}
+
+__global__ __launch_bounds__(1024) void fr_round_kernel(FrDev d, int pre) {
+    if (d.hdr->done) return;  // (set by an earlier launch: uniform over the grid -- this launch's leader sets it only after every workgroup has arrived)
+    __shared__ FrLds L;
+    if (blockIdx.x == 0)
+        frLeadRound(d, L, pre);
+    else if (blockIdx.x == gridDim.x - 1u)
+        frChainTotal(d, L);
+    else
+        frUpdateJobs(d, L);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The coefficient count of every subtree, once the stop rule has fired: every leaf adds its own to each of its ancestors but the
+// root (whose count is the header's nCoeffs).  d.sub is zero before: fr_init_kernel, and no round touches it.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fr_subtree_kernel(FrDev d) {
+    const FrHdr* h = d.hdr;
+    if (!h->done || h->overflow) return;
+    // The first three levels below the root -- nodes 1 .. 584 of the uniformly refined tree -- are ancestors of everything: a
+    // workgroup (256 consecutive nodes, i.e. relatives) adds its leaves up in LDS first and touches each of them once (every leaf
+    // for itself: ten thousand atomics on the same eight words, 131 us)
+    __shared__ uint32_t sTop[1024];
+    for (uint32_t k = threadIdx.x; k < 1024; k += 256) sTop[k] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < h->nNodes) {
+        const uint32_t deg = d.nodes[i].degree;
+        if (deg != kInteriorDegree) {
+            const uint32_t c = frCoef((int)deg);
+            uint32_t a = d.parent[i];
+            while (a != 0) {
+                if (a < 1024u)
+                    atomicAdd(&sTop[a], c);
+                else
+                    atomicAdd(&d.sub[a], c);
+                a = d.parent[a];
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < 1024; k += 256)
+        if (sTop[k]) atomicAdd(&d.sub[k], sTop[k]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1110,9 +1445,15 @@ __global__ __launch_bounds__(256) void fr_store_kernel(FrDev d) {
     if (!h->done || h->overflow) return;
     const uint32_t n = h->nNodes;
     const int lane = threadIdx.x & 63;
+    // the serialised node array goes behind the coefficients (ToMemoryBlock's order, :424-456): the block is ONE download
+    uint64_t* nodesOut = reinterpret_cast<uint64_t*>(d.store + h->nCoeffs);
     for (uint32_t i = (blockIdx.x * 256u + threadIdx.x) >> 6; i < n; i += gridDim.x * 4u) {
         const hpsdf_node nd = d.nodes[i];
-        if (nd.degree == kInteriorDegree) continue;
+        const uint64_t* words = reinterpret_cast<const uint64_t*>(&d.nodes[i]);
+        if (nd.degree == kInteriorDegree) {
+            if (lane < 7) nodesOut[(size_t)i * 7 + lane] = words[lane];
+            continue;
+        }
         uint32_t start = 0;
         uint32_t a = i;
         while (a != 0) {  // lanes 0..6 look at the siblings before `a`
@@ -1129,6 +1470,7 @@ __global__ __launch_bounds__(256) void fr_store_kernel(FrDev d) {
             a = par;
         }
         if (lane == 0) d.nodes[i].coeffs_start = start;
+        if (lane < 7) nodesOut[(size_t)i * 7 + lane] = lane == 4 ? (uint64_t)start : words[lane];  // (word 4: coeffs_start, @32)
         const int first = d.segFirst[i];
         for (int s = 0; s <= (int)nd.degree - first; ++s) {
             const uint32_t r0 = s == 0 ? 0u : frCoef(first + s - 1), r1 = frCoef(first + s);
@@ -1255,12 +1597,12 @@ struct FrTemplate {
     uint64_t arenaRows, samples;
     uint32_t sliceFirst[9];
 };
-__global__ __launch_bounds__(256) void fr_init_kernel(FrDev d, FrTemplate t, double target) {
+__global__ __launch_bounds__(256) void fr_init_kernel(FrDev d, FrTemplate t) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < t.nNodes) {
         d.nodes[i] = t.nodes[i];
         d.parent[i] = t.parent[i];
-        d.sub[i] = t.sub[i];
+        d.sub[i] = 0;  // (fr_subtree_kernel, when the build has stopped)
         d.qErr[i] = kNotQueued;
         d.segFirst[i] = 2;
     }
@@ -1276,7 +1618,6 @@ __global__ __launch_bounds__(256) void fr_init_kernel(FrDev d, FrTemplate t, dou
         h->nLeaves = t.nLeaves;
         h->t1 = -1;
         h->total = 4096.0 * HPSDF_INITIAL_NODE_ERR;  // pow(8, 4) * INITIAL_NODE_ERR, Octree.cpp:212
-        h->target = target;
         h->maxDegree = 2;
         h->nTasks = t.nTasks, h->nBlocks = t.nBlocks;
         h->degTasks[2][0] = 0, h->degTasks[2][1] = t.nTasks;
@@ -1323,8 +1664,14 @@ struct FrontierWorkspace {
     FitTask* tmplTasks = nullptr;
     FitBlock* tmplBlocks = nullptr;
     size_t tmplLds = 0;
+    // fr_init_kernel has run for (cleanRank, cleanWorld) and nothing since: a build that ends well leaves the workspace ready for the
+    // next one (the launch runs while the host hands the block over), so a Create starts with its first fit
+    bool clean = false;
+    int cleanRank = -1, cleanWorld = -1;
+    uint32_t buildStamp = 0;
     std::vector<hpsdf_node> hostNodesAfterRound0;  // the node array of a tree that stops after round 0, serialised
     char* pinned = nullptr;                        // staging of the finished block
+    double* pinnedDev = nullptr;                   // ... as the device addresses it
     size_t pinnedCap = 0;
     // weighted builds: the round's |mean FApprox| values as the device writes them, the weights as the host answers, the
     // "means are there" word pair (pinned, coherent: both sides watch them while the other writes)
@@ -1396,8 +1743,7 @@ struct FrontierWorkspace {
     }
     hipError_t ensureSamples(uint64_t need, hipStream_t s) {
         if (need <= sampleCap) return hipSuccess;
-        uint64_t nc = sampleCap ? sampleCap : (1ull << 22);
-        while (nc < need) nc *= 2;
+        const uint64_t nc = (need + (1ull << 20) - 1) & ~((1ull << 20) - 1);  // to the need (GBs at high degrees), not to a power of two
         hipError_t e = grow(&samples, 0, nc, s, false);
         if (e == hipSuccess) sampleCap = nc;
         return e;
@@ -1451,8 +1797,9 @@ struct FrontierWorkspace {
         size_t nc = pinnedCap ? pinnedCap : (1u << 20);
         while (nc < need) nc *= 2;
         if (pinned) (void)hipHostFree(pinned);
-        pinned = nullptr, pinnedCap = 0;
-        hipError_t e = hipHostMalloc((void**)&pinned, nc, hipHostMallocDefault);
+        pinned = nullptr, pinnedDev = nullptr, pinnedCap = 0;
+        hipError_t e = hipHostMalloc((void**)&pinned, nc, hipHostMallocCoherent | hipHostMallocMapped);  // (round 0's fit writes it while the host may look)
+        if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&pinnedDev, pinned, 0);
         if (e == hipSuccess) pinnedCap = nc;
         return e;
     }
@@ -1473,8 +1820,6 @@ struct FrontierWorkspace {
         if (e == hipSuccess) e = hipMalloc((void**)&d.wBatchErr, kFrJobs * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void**)&d.wJobP, kFrJobs * sizeof(uint64_t));
         if (e == hipSuccess) e = hipMalloc((void**)&d.wJobH, kFrJobs * sizeof(uint64_t));
-        if (e == hipSuccess) e = hipMalloc((void**)&d.kind, kFrJobs);
-        if (e == hipSuccess) e = hipMalloc((void**)&d.base, kFrJobs * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc((void**)&d.ops, (size_t)kFrJobs * 9 * sizeof(double));
         if (e == hipSuccess) e = hipMalloc((void**)&d.tasks, kFrTasks * sizeof(FitTask));
         if (e == hipSuccess) e = hipMalloc((void**)&d.blocks, kFrTasks * sizeof(FitBlock));
@@ -1564,7 +1909,7 @@ struct FrontierWorkspace {
         if (device >= 0) (void)hipSetDevice(device);
         for (void* p : {(void*)d.hdr, (void*)d.rnd, (void*)d.nodes, (void*)d.qErr, (void*)d.parent, (void*)d.segOff, (void*)d.segFirst,
                         (void*)d.sub, (void*)d.taken, (void*)d.candA, (void*)d.candB, (void*)d.wBatchIdx, (void*)d.wBatchErr, (void*)d.wJobP,
-                        (void*)d.wJobH, (void*)d.kind, (void*)d.base, (void*)d.ops, (void*)d.tasks, (void*)d.blocks, (void*)d.errs, (void*)d.store,
+                        (void*)d.wJobH, (void*)d.ops, (void*)d.tasks, (void*)d.blocks, (void*)d.errs, (void*)d.store,
                         (void*)arena, (void*)samples, (void*)tmplNodes, (void*)tmplParent, (void*)tmplSub, (void*)tmplLeaves, (void*)tmplErr,
                         (void*)tmplJobP, (void*)tmplTasks, (void*)tmplBlocks, (void*)d.jobOwner, (void*)d.packPos, (void*)d.pack, (void*)r0Tasks,
                         (void*)r0Blocks, (void*)r0JobP})
@@ -1604,7 +1949,16 @@ bool frontierEligible(const hpsdf_config* cfg, const hpsdf_field* field, uint64_
         hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                    \
         const hipError_t le_ = hipGetLastError();                                           \
         if (le_ != hipSuccess) return ::hpsdf::hipFail(le_, "launch of " #kernel);          \
+        if (frSyncEveryLaunch()) {                                                          \
+            std::fprintf(stderr, "[frontier] " #kernel " ...");                             \
+            const hipError_t se_ = hipStreamSynchronize(stream);                            \
+            std::fprintf(stderr, " %s\n", hipGetErrorString(se_));                          \
+        }                                                                                   \
     } while (0)
+static bool frSyncEveryLaunch() {  // HPSDF_FRONTIER_SYNC=1: a fault names its kernel (diagnostic; the host's waits then find every round closed)
+    static const bool on = std::getenv("HPSDF_FRONTIER_SYNC") != nullptr;
+    return on;
+}
 
 int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field* field, uint64_t K, void** block, size_t* size,
                    hpsdf_build_stats* stats, int rank, int world, hpsdf_allgather_fn gather, void* gatherUser) {
@@ -1763,6 +2117,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         return HPSDF_OK;
     };
     uint8_t* early = nullptr;  // the block of a build that stops after round 0, begun before the device has finished
+    bool earlyCopied = false;  // ... its coefficients are in it
     struct FreeEarly {
         uint8_t** p;
         ~FreeEarly() { std::free(*p); }
@@ -1828,89 +2183,40 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         T0.nTasks = count, T0.nBlocks = nBl;
         T0.arenaRows = (uint64_t)count * frCoef(2), T0.samples = (uint64_t)count * 729;
     }
-    {
-        hipError_t e = ws->ensureArena(std::max<uint64_t>(1, T0.arenaRows), 0, s);
-        if (e == hipSuccess && mesh) e = ws->ensureSamples(std::max<uint64_t>(1, T0.samples), s);
-        if (e != hipSuccess) return hipFail(e, "frontier buffers");
-        FR_LAUNCH(fr_init_kernel, dim3((T.nNodes + 255) / 256), dim3(256), s, d, T0, cfg.target_error_threshold);
-        FieldDev fdr = fd;
-        if (mesh) {
-            HPSDF_HIP(launchMeshSample(s, r0Tasks, T0.nTasks, 2, ctx->dTables, fd, rm, ws->samples));
-            fdr.kind = kFieldSamples;
-            fdr.samples = ws->samples;
-        }
-        HPSDF_HIP(launchFit(s, 2, 1, r0Blocks, T0.nBlocks, r0Lds, r0Tasks, ws->arena, d.errs, nullptr, ctx->dTables, fdr, rm));
-        if (weighted && (rc = applyWeights(r0Blocks, T0.nBlocks, r0Lds, r0Tasks, nullptr, true))) return rc;
-        if ((rc = exchange(d.errs, (size_t)d.errStride * sizeof(double), "round 0"))) return rc;
-        phase = 0;
-        FrDev d0 = d;
-        d0.batchIdx = ws->tmplLeaves, d0.batchErr = ws->tmplErr, d0.jobP = r0JobP, d0.jobH = r0JobP;
-        FR_LAUNCH(fr_round0_kernel, dim3(1 + (T.nLeaves + 255) / 256), dim3(256), s, d0);
-        if (world == 1) {
-            // a build that stops here has its packed store at the start of the arena: fetch it right behind the round
-            HPSDF_HIP(hipMemcpyAsync(ws->pinned, ws->arena, T.arenaRows * sizeof(double), hipMemcpyDeviceToHost, s));
-            // ... and everything else of its block is known in advance: write that part while the device works
-            const uint64_t nc0 = T.arenaRows, nn0 = T.nNodes;
-            early = (uint8_t*)std::malloc(8 + 8 * (size_t)nc0 + 8 + sizeof(hpsdf_node) * (size_t)nn0 + sizeof(hpsdf_config));
-            if (early) {
-                std::memcpy(early, &nc0, 8);
-                std::memcpy(early + 8 + 8 * (size_t)nc0, &nn0, 8);
-                std::memcpy(early + 16 + 8 * (size_t)nc0, ws->hostNodesAfterRound0.data(), sizeof(hpsdf_node) * (size_t)nn0);
-                std::memcpy(early + 16 + 8 * (size_t)nc0 + sizeof(hpsdf_node) * (size_t)nn0, &cfg, sizeof cfg);
-            }
-        }
-        const double ts = now();
-        HPSDF_HIP(hipStreamSynchronize(s));
-        tSync += now() - ts;
-    }
-    int rounds = 1;
-    if (world > 1 && hh->rPad) return fail(HPSDF_ERR_STATE, "rank " + std::to_string(hh->rPad - 1) + " failed in round 0: its own error was returned there");
-    d.errStride = Kj * HPSDF_JOB_HEADER_DOUBLES + kFrStatusPad;  // later rounds have at most K jobs: smaller parts to all-gather
-    const bool stoppedAfterRound0 = world == 1 && hh->done && hh->overflow != 1;
-    if (stoppedAfterRound0 && early && hh->nCoeffs == T.arenaRows && hh->nNodes == T.nNodes) {
-        std::memcpy(early + 8, ws->pinned, 8 * (size_t)T.arenaRows);
-        *block = early;
-        *size = 8 + 8 * (size_t)T.arenaRows + 8 + sizeof(hpsdf_node) * (size_t)T.nNodes + sizeof(hpsdf_config);
-        early = nullptr;
-        if (stats) {
-            std::memset(stats, 0, sizeof *stats);
-            stats->rounds = hh->round, stats->jobs = hh->jobs, stats->p_refines = hh->pRefines, stats->h_refines = hh->hRefines;
-            stats->dropped = hh->dropped, stats->fits = hh->fits, stats->samples = hh->samples;
-            stats->n_nodes = hh->nNodes, stats->n_leaves = hh->nLeaves, stats->n_coeffs = hh->nCoeffs, stats->total_error = hh->total;
-        }
-        if (trace) std::fprintf(stderr, "[frontierCreate] us: total %.0f (waiting for the device %.0f, stopped after round 0)\n", now() - t0, tSync);
-        return HPSDF_OK;
-    }
-    std::free(early);
-    early = nullptr;
-    uint32_t knownNodes = hh->nNodes, knownMaxDeg = hh->maxDegree;
-    uint64_t knownArena = hh->arenaUsed;
-    while (!hh->done) {
-        // (as builderSelect: a total that is NaN or infinite never falls below the threshold -- the field is not finite somewhere)
-        if (!(std::fabs(hh->total) <= DBL_MAX))
-            return fail(HPSDF_ERR_INVALID_ARGUMENT, "the field is not a finite number at some sample point (the build's total error is NaN or infinite)");
-        if (world > 1) phase = 2;
-        if (injectedFailure(rounds)) return fail(HPSDF_ERR_OUT_OF_MEMORY, "injected failure (HPSDF_TEST_FAIL_RANK)");
-        // capacities for this round (the device flags what the host failed to foresee; it cannot happen by these bounds)
+    // ---- what a round needs beyond its lists
+    // (later rounds have at most K jobs: smaller parts to all-gather than round 0's 4096)
+    const uint32_t stride0 = kFrJobs * HPSDF_JOB_HEADER_DOUBLES + kFrStatusPad, strideK = Kj * HPSDF_JOB_HEADER_DOUBLES + kFrStatusPad;
+    static const uint32_t inlineNodes = [] {
+        const char* e = std::getenv("HPSDF_FRONTIER_INLINE_NODES");  // tests: 0 sends every round through the grid selection
+        return e ? (uint32_t)std::strtoul(e, nullptr, 10) : kFrInlineNodes;
+    }();
+    // fr_round_kernel closes round r and opens round r + 1 in one launch, so what round r + 1 can need -- nodes for round r's
+    // splits, arena rows and sample slots for round r + 1's fits -- is bounded from what the host knows when it launches it: the tree
+    // after round r - 1 (whose largest degree can have risen by one since).  Also decides whether round r + 1's from-scratch fits
+    // are split (ctx->fitMode): they are unless the sample buffer they hand their field values over in cannot be had.
+    bool splitOpen = false, samplesTooLarge = false;
+    auto prepareNext = [&](uint32_t knownNodes, uint64_t knownArena, uint32_t knownMaxDeg) -> int {
+        const int degBound = (int)std::min<uint32_t>(knownMaxDeg + 1u, kMaxDegree);
         hipError_t e = ws->ensureNodes(knownNodes + 8u * Kj, s);
-        if (e == hipSuccess) e = ws->ensureArena(knownArena + (uint64_t)Kj * rowsPerJob((int)knownMaxDeg), knownArena, s);
-        // split fits (the default for from-scratch fits of degree >= 4) hand their field values to the matrix-core kernel through the
-        // sample buffer, which mesh fields use anyway; a round whose samples would not fit 16 GB is fitted exactly throughout
-        bool splitRound = splitMode && (int)knownMaxDeg >= ctx->splitMinDegree;
-        if (e == hipSuccess && (mesh || splitRound)) {
-            const uint64_t need = (uint64_t)Kj * samplesPerJob((int)knownMaxDeg);
+        if (e == hipSuccess) e = ws->ensureArena(knownArena + (uint64_t)Kj * rowsPerJob(degBound), knownArena, s);
+        if (e != hipSuccess) return hipFail(e, "frontier buffers");
+        splitOpen = splitMode && degBound >= ctx->splitMinDegree;
+        samplesTooLarge = false;
+        if (mesh || splitOpen) {
+            const uint64_t need = (uint64_t)Kj * samplesPerJob(degBound);
             if (need > (1ull << 31)) {
-                if (mesh) return fail(HPSDF_ERR_UNSUPPORTED, "round too large for the sampled mesh path");
-                splitRound = false;
-            } else {
-                e = ws->ensureSamples(need, s);
+                samplesTooLarge = true;  // (a mesh build fails when that round comes; a split round is fitted exactly instead)
+                splitOpen = false;
+            } else if ((e = ws->ensureSamples(need, s)) != hipSuccess) {
+                if (mesh) return hipFail(e, "frontier sample buffer");
+                (void)hipGetLastError();  // no room for the hand-over buffer: the exact fit needs none
+                splitOpen = false;
             }
         }
-        d.splitFit = splitRound ? std::max(2, ctx->splitMinDegree) : 0;
-        if (e != hipSuccess) return hipFail(e, "frontier buffers");
-        FR_LAUNCH(fr_select_kernel, dim3(std::min<uint32_t>(512u, (knownNodes + 255u) / 256u)), dim3(256), s, d);
-        FR_LAUNCH(fr_batch_kernel, dim3(1), dim3(1024), s, d);
-        FR_LAUNCH(fr_tasks_kernel, dim3((16u * Kj + 255u) / 256u), dim3(256), s, d);
+        return HPSDF_OK;
+    };
+    // a round's fits, from the lists the device wrote (kernels.hip; grids are upper bounds)
+    auto launchRoundFits = [&](uint32_t knownMaxDeg, bool splitRound) -> int {
         const int degHi = (int)std::min<uint32_t>(kMaxDegree - 1, knownMaxDeg + 1);
         const uint32_t taskBound = 9u * Kj;
         bool degHiDone = false;
@@ -1961,73 +2267,189 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         if (weighted) {
             size_t lds = 0;
             for (int deg = 2; deg <= degHi; ++deg) lds = std::max(lds, fitLdsTable[deg]);
-            if ((rc = applyWeights(d.blocks, taskBound, lds, d.tasks, &d.hdr->nBlocks, false))) return rc;
+            int rcw;
+            if ((rcw = applyWeights(d.blocks, taskBound, lds, d.tasks, &d.hdr->nBlocks, false))) return rcw;
         }
-        if ((rc = exchange(d.errs, (size_t)d.errStride * sizeof(double), "a round's errors"))) return rc;
-        phase = 0;
-        FR_LAUNCH(fr_decide_kernel, dim3(1), dim3(1024), s, d);
-        FR_LAUNCH(fr_update_kernel, dim3(1 + (Kj + 31) / 32), dim3(256), s, d);
-        if (world == 1) FR_LAUNCH(fr_store_kernel, dim3(std::min<uint32_t>(2048u, (knownNodes + 8u * Kj + 3u) / 4u)), dim3(256), s, d);
-        // The round is over for the host when the header's mirror shows the next round number: the update kernel's last
-        // workgroup writes it into pinned memory behind a system-scope fence.  Watching that word costs ~3 us; waking up
-        // from hipStreamSynchronize ~20 (everything launched next is ordered behind this round on the stream anyway;
-        // the download of a finished build synchronises the stream itself).
+        return HPSDF_OK;
+    };
+    // The round is over for the host when the header's mirror shows the next round number: the closing workgroup writes it into
+    // pinned memory behind a system-scope fence.  Watching that word costs ~3 us; waking up from hipStreamSynchronize ~20.
+    auto waitForRound = [&](uint32_t want) -> int {
         const double ts = now();
-        {
-            const volatile uint32_t* roundWord = &hh->round;
-            const uint32_t want = (uint32_t)rounds + 1u;
-            const double limit = ts + 2.0e3;  // two milliseconds of watching, then the ordinary wait
-            while (*roundWord != want && now() < limit) frCpuRelax();
+        const volatile uint32_t* roundWord = &hh->round;
+        const double limit = ts + 2.0e3;  // two milliseconds of watching, then the ordinary wait
+        while (*roundWord != want && now() < limit) frCpuRelax();
+        if (*roundWord != want) {
+            HPSDF_HIP(hipStreamSynchronize(s));
             if (*roundWord != want) {
-                HPSDF_HIP(hipStreamSynchronize(s));
-                if (*roundWord != want) {
-                    // The stream is idle and the mirror still shows the old round: the round ended on a path that does not
-                    // write it (fr_decide_kernel's capacity overflow makes fr_update_kernel return early), or the pinned
-                    // mirror is not coherent on this system.  Fetch the header itself and let it decide.
-                    HPSDF_HIP(hipMemcpy(ws->hostHdr, d.hdr, kFrHdrCopyBytes, hipMemcpyDeviceToHost));
-                    if (hh->overflow == 1) return fail(HPSDF_ERR_STATE, "frontier: node capacity exceeded");
-                    if (hh->round != want && !hh->done) return fail(HPSDF_ERR_STATE, "frontier: a round ended without advancing");
+                // The stream is idle and the mirror still shows the old round: the pinned mirror is not coherent on this system.
+                // Fetch the header itself and let it decide.
+                HPSDF_HIP(hipMemcpy(ws->hostHdr, d.hdr, kFrHdrCopyBytes, hipMemcpyDeviceToHost));
+                if (hh->round != want) return fail(HPSDF_ERR_STATE, "frontier: a round ended without advancing");
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        tSync += now() - ts;
+        return HPSDF_OK;
+    };
+
+    d.errStride = stride0, d.errStrideNext = strideK;
+    d.buildStamp = ++ws->buildStamp ? ws->buildStamp : ++ws->buildStamp;  // (never 0)
+    ws->hostHdr->round = 0, ws->hostHdr->done = 0;  // (the mirror still shows the previous build's last round: the waits below watch it)
+    auto initDev = [&] {  // what fr_init_kernel sees: the arrays as they are now, round 0's stride (where this rank's status for round 0's exchange lies)
+        FrDev di = d;
+        di.errStride = stride0;
+        return di;
+    };
+    {
+        hipError_t e = ws->ensureArena(std::max<uint64_t>(1, T0.arenaRows), 0, s);
+        if (e == hipSuccess && mesh) e = ws->ensureSamples(std::max<uint64_t>(1, T0.samples), s);
+        if (e != hipSuccess) return hipFail(e, "frontier buffers");
+        if ((rc = prepareNext(T.nNodes, T0.arenaRows, 2u))) return rc;
+        d.target = cfg.target_error_threshold;
+        if (!ws->clean || ws->cleanRank != rank || ws->cleanWorld != world) FR_LAUNCH(fr_init_kernel, dim3((T.nNodes + 255) / 256), dim3(256), s, initDev(), T0);
+        ws->clean = false;
+        FieldDev fdr = fd;
+        if (mesh) {
+            HPSDF_HIP(launchMeshSample(s, r0Tasks, T0.nTasks, 2, ctx->dTables, fd, rm, ws->samples));
+            fdr.kind = kFieldSamples;
+            fdr.samples = ws->samples;
+        }
+        // (one rank: the rows also go straight into pinned host memory -- if the build stops after this round they are its packed store)
+        HPSDF_HIP(launchFit(s, 2, 1, r0Blocks, T0.nBlocks, r0Lds, r0Tasks, ws->arena, d.errs, world == 1 ? ws->pinnedDev : nullptr, ctx->dTables, fdr, rm));
+        if (weighted && (rc = applyWeights(r0Blocks, T0.nBlocks, r0Lds, r0Tasks, nullptr, true))) return rc;
+        if ((rc = exchange(d.errs, (size_t)stride0 * sizeof(double), "round 0"))) return rc;
+        phase = 0;
+        d.errStride = strideK;  // (of the exchange that comes next: where a failing rank leaves its status)
+    }
+    int rounds = 0;  // rounds the host has seen closed
+    uint32_t knownNodes = T.nNodes, knownMaxDeg = 2;
+    uint64_t knownArena = T0.arenaRows;
+    for (;;) {
+        // close round `rounds`, open the next
+        const bool pre = (uint64_t)knownNodes + 8ull * Kj <= inlineNodes;
+        const bool splitCur = splitOpen, tooLargeCur = samplesTooLarge;
+        FrDev dk = d;
+        dk.splitFit = splitCur ? std::max(2, ctx->splitMinDegree) : 0;
+        if (rounds == 0) {
+            dk.batchIdx = ws->tmplLeaves, dk.batchErr = ws->tmplErr, dk.jobP = r0JobP, dk.jobH = r0JobP;
+            dk.errStride = stride0;
+        }
+        FR_LAUNCH(fr_round_kernel, dim3(2 + ((rounds == 0 ? T.nLeaves : Kj) + 127u) / 128u), dim3(1024), s, dk, pre ? 1 : 0);
+        // From the second round on the fits are launched without waiting for the header (one rank, no host step in between): what they
+        // need to know is on the device -- their lists and counts -- and a build that has stopped leaves them nothing to do.  The
+        // largest degree may have risen once more than the host knows.
+        const bool blind = rounds >= 1 && pre && world == 1 && !weighted && !frSyncEveryLaunch();
+        if (blind) {
+            if (mesh && tooLargeCur) return fail(HPSDF_ERR_UNSUPPORTED, "round too large for the sampled mesh path");
+            d.splitFit = dk.splitFit;
+            if ((rc = launchRoundFits(std::min<uint32_t>(knownMaxDeg + 1u, kMaxDegree), splitCur))) return rc;
+        }
+        if (rounds == 0 && world == 1) {
+            // a build that stops here has its packed store in pinned memory already (the fit wrote it there too), and everything else
+            // of its block is known in advance: write that part while the device works
+            const uint64_t nc0 = T.arenaRows, nn0 = T.nNodes;
+            early = (uint8_t*)std::malloc(8 + 8 * (size_t)nc0 + 8 + sizeof(hpsdf_node) * (size_t)nn0 + sizeof(hpsdf_config));
+            if (early) {
+                std::memcpy(early, &nc0, 8);
+                std::memcpy(early + 8 + 8 * (size_t)nc0, &nn0, 8);
+                std::memcpy(early + 16 + 8 * (size_t)nc0, ws->hostNodesAfterRound0.data(), sizeof(hpsdf_node) * (size_t)nn0);
+                std::memcpy(early + 16 + 8 * (size_t)nc0 + sizeof(hpsdf_node) * (size_t)nn0, &cfg, sizeof cfg);
+                // ... and the rows themselves as soon as the closing launch says that the fit before it has finished -- long before it
+                // can say whether the build stops here (the running total is 4096 dependent additions away): 320 KB out of memory the
+                // GPU has just written take a core ~20 us, which now pass while the device works.  In pieces, with an eye on the round
+                // word: a build that goes on must not wait for a copy it will not use.
+                const volatile uint32_t* landed = &hh->landed;
+                const volatile uint32_t* roundWord = &hh->round;
+                const double limit = now() + 2.0e3;
+                while (*landed != d.buildStamp && *roundWord == 0 && now() < limit) frCpuRelax();
+                if (*landed == d.buildStamp) {
+                    std::atomic_thread_fence(std::memory_order_acquire);
+                    const size_t total = 8 * (size_t)nc0, piece = 32768;
+                    size_t at = 0;
+                    for (; at < total && (*roundWord == 0 || *(const volatile uint32_t*)&hh->done); at += piece) std::memcpy(early + 8 + at, ws->pinned + at, std::min(piece, total - at));
+                    earlyCopied = at >= total;
                 }
             }
-            std::atomic_thread_fence(std::memory_order_acquire);
         }
-        tSync += now() - ts;
+        if ((rc = waitForRound((uint32_t)rounds + 1u))) return rc;
         ++rounds;
         if (world > 1 && hh->rPad)
             return fail(HPSDF_ERR_STATE, "rank " + std::to_string(hh->rPad - 1) + " failed in round " + std::to_string(rounds - 1) + ": its own error was returned there");
-        knownNodes = hh->nNodes, knownMaxDeg = hh->maxDegree, knownArena = hh->arenaUsed;
+        if (hh->overflow & 1u) return fail(HPSDF_ERR_STATE, "frontier: node capacity exceeded");
+        if (hh->overflow & 4u) return fail(HPSDF_ERR_STATE, "frontier: a workgroup of the round's kernel did not arrive");
         if (trace) {
-            std::fprintf(stderr, "[frontier round %d] batch phases (cycles):", rounds - 1);
-            for (int k = 1; k <= 7; ++k) std::fprintf(stderr, " %lld", (long long)(hh->dbg[k] - hh->dbg[k - 1]));
-            std::fprintf(stderr, " | decide:");
-            for (int k = 9; k <= 11; ++k) std::fprintf(stderr, " %lld", (long long)(hh->dbg[k] - hh->dbg[k - 1]));
+            std::fprintf(stderr, "[frontier round %d] lead (cycles): wait-all %lld close %lld", rounds - 1, (long long)(hh->dbg[10] - hh->dbg[9]),
+                         (long long)(hh->dbg[11] - hh->dbg[10]));
+            if (!hh->done && pre) {
+                std::fprintf(stderr, " | select %lld batch", (long long)(hh->dbg[0] - hh->dbg[11]));
+                for (int k = 1; k <= 8; ++k) std::fprintf(stderr, " %lld", (long long)(hh->dbg[k] - hh->dbg[k - 1]));
+                std::fprintf(stderr, " | total+commit %lld", (long long)(hh->dbg[12] - hh->dbg[8]));
+            }
+            std::fprintf(stderr, " | chain %lld", (long long)(hh->dbg[14] - hh->dbg[13]));
             std::fprintf(stderr, "\n");
         }
+        if (rounds == 1 && world == 1 && hh->done && early && hh->nCoeffs == T.arenaRows && hh->nNodes == T.nNodes) {
+            if (!earlyCopied) std::memcpy(early + 8, ws->pinned, 8 * (size_t)T.arenaRows);
+            hipLaunchKernelGGL(fr_init_kernel, dim3((T.nNodes + 255) / 256), dim3(256), 0, s, initDev(), T0);  // for the next build
+            ws->clean = hipGetLastError() == hipSuccess, ws->cleanRank = rank, ws->cleanWorld = world;
+            *block = early;
+            *size = 8 + 8 * (size_t)T.arenaRows + 8 + sizeof(hpsdf_node) * (size_t)T.nNodes + sizeof(hpsdf_config);
+            early = nullptr;
+            if (stats) {
+                std::memset(stats, 0, sizeof *stats);
+                stats->rounds = hh->round, stats->jobs = hh->jobs, stats->p_refines = hh->pRefines, stats->h_refines = hh->hRefines;
+                stats->dropped = hh->dropped, stats->fits = hh->fits, stats->samples = hh->samples;
+                stats->n_nodes = hh->nNodes, stats->n_leaves = hh->nLeaves, stats->n_coeffs = hh->nCoeffs, stats->total_error = hh->total;
+            }
+            if (trace) std::fprintf(stderr, "[frontierCreate] us: total %.0f (waiting for the device %.0f, stopped after round 0)\n", now() - t0, tSync);
+            return HPSDF_OK;
+        }
+        std::free(early);
+        early = nullptr;
+        if (hh->done) break;
+        // (as builderSelect: a total that is NaN or infinite never falls below the threshold -- the field is not finite somewhere)
+        if (!(std::fabs(hh->total) <= DBL_MAX))
+            return fail(HPSDF_ERR_INVALID_ARGUMENT, "the field is not a finite number at some sample point (the build's total error is NaN or infinite)");
+        knownNodes = hh->nNodes, knownMaxDeg = hh->maxDegree, knownArena = hh->arenaUsed;
+        if (world > 1) phase = 2;
+        if (injectedFailure(rounds)) return fail(HPSDF_ERR_OUT_OF_MEMORY, "injected failure (HPSDF_TEST_FAIL_RANK)");
+        if (mesh && tooLargeCur) return fail(HPSDF_ERR_UNSUPPORTED, "round too large for the sampled mesh path");
+        if (!pre) {  // a large tree: the selection as a grid, then batch and lists (the header's arenaUsed lags one round: bound it)
+            FrDev dl = d;
+            dl.splitFit = dk.splitFit;
+            FR_LAUNCH(fr_select_kernel, dim3(std::min<uint32_t>(512u, (knownNodes + 255u) / 256u)), dim3(256), s, dl);
+            FR_LAUNCH(fr_batch_kernel, dim3(1), dim3(1024), s, dl);
+            FR_LAUNCH(fr_tasks_kernel, dim3((16u * Kj + 255u) / 256u), dim3(256), s, dl);
+        }
+        // capacities of the launch that closes this round; the arena may move: nothing that writes it is in flight
+        if ((rc = prepareNext(knownNodes, knownArena + (pre ? 0ull : (uint64_t)Kj * rowsPerJob((int)knownMaxDeg)), knownMaxDeg))) return rc;
+        d.splitFit = dk.splitFit;
+        if (!blind && (rc = launchRoundFits(knownMaxDeg, splitCur))) return rc;
+        if (frSyncEveryLaunch()) std::fprintf(stderr, "[frontier] fits of round %d ... %s\n", rounds, hipGetErrorString(hipStreamSynchronize(s)));
+        if ((rc = exchange(d.errs, (size_t)strideK * sizeof(double), "a round's errors"))) return rc;
+        phase = 0;
     }
-    if (hh->overflow == 1) return fail(HPSDF_ERR_STATE, "frontier: node capacity exceeded");
-    if (world > 1) {
-        // the packed store from one all-gather of the ranks' pack buffers (each rank's own segments in node order)
-        hipError_t e = ws->ensureStore(hh->nCoeffs, s);
+    {
+        // ReallocCoeffs: the packed store, the node array behind it
+        const uint64_t nc = hh->nCoeffs, nn = hh->nNodes;
+        hipError_t e = ws->ensureStore(nc + 7ull * nn, s);
         if (e != hipSuccess) return hipFail(e, "coefficient store");
-        HPSDF_HIP(hipMemsetAsync(&d.hdr->overflow, 0, sizeof(uint32_t), s));
-        FR_LAUNCH(fr_packpos_kernel, dim3(1), dim3(1024), s, d);
-        HPSDF_HIP(hipStreamSynchronize(s));
-        uint64_t stride = 1;
-        for (int r = 0; r < world; ++r) stride = std::max<uint64_t>(stride, hh->packCount[r]);
-        stride = (stride + 15) & ~15ull;
-        e = ws->ensurePack((uint64_t)world * stride, s);
-        if (e != hipSuccess) return hipFail(e, "pack buffers");
-        d.packStride = stride;
-        FR_LAUNCH(fr_pack_kernel, dim3(std::min<uint32_t>(2048u, (knownNodes + 3u) / 4u)), dim3(256), s, d);
-        if ((rc = exchange(d.pack, (size_t)stride * sizeof(double), "the packed coefficients"))) return rc;
-        FR_LAUNCH(fr_store_kernel, dim3(std::min<uint32_t>(2048u, (knownNodes + 3u) / 4u)), dim3(256), s, d);
-        HPSDF_HIP(hipStreamSynchronize(s));
-    } else if (hh->overflow == 2) {  // the packed store was too small: grow, run ReallocCoeffs again
-        hipError_t e = ws->ensureStore(hh->nCoeffs, s);
-        if (e != hipSuccess) return hipFail(e, "coefficient store");
-        HPSDF_HIP(hipMemsetAsync(&d.hdr->overflow, 0, sizeof(uint32_t), s));
-        FR_LAUNCH(fr_store_kernel, dim3(std::min<uint32_t>(2048u, (knownNodes + 3u) / 4u)), dim3(256), s, d);
-        HPSDF_HIP(hipStreamSynchronize(s));
+        FR_LAUNCH(fr_subtree_kernel, dim3(((uint32_t)nn + 255u) / 256u), dim3(256), s, d);
+        if (world > 1) {
+            // the packed store from one all-gather of the ranks' pack buffers (each rank's own segments in node order)
+            FR_LAUNCH(fr_packpos_kernel, dim3(1), dim3(1024), s, d);
+            HPSDF_HIP(hipStreamSynchronize(s));
+            uint64_t stride = 1;
+            for (int r = 0; r < world; ++r) stride = std::max<uint64_t>(stride, hh->packCount[r]);
+            stride = (stride + 15) & ~15ull;
+            e = ws->ensurePack((uint64_t)world * stride, s);
+            if (e != hipSuccess) return hipFail(e, "pack buffers");
+            d.packStride = stride;
+            FR_LAUNCH(fr_pack_kernel, dim3(std::min<uint32_t>(2048u, (knownNodes + 3u) / 4u)), dim3(256), s, d);
+            if ((rc = exchange(d.pack, (size_t)stride * sizeof(double), "the packed coefficients"))) return rc;
+        }
+        FR_LAUNCH(fr_store_kernel, dim3(std::min<uint32_t>(2048u, ((uint32_t)nn + 3u) / 4u)), dim3(256), s, d);
     }
     // Octree::ToMemoryBlock, Octree.cpp:424-456: [u64 nCoeffs][f64 x nCoeffs][u64 nNodes][Node x nNodes][Config]
     const uint64_t nc = hh->nCoeffs, nn = hh->nNodes;
@@ -2035,29 +2457,20 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
     uint8_t* p = (uint8_t*)std::malloc(bytes);
     if (!p) return fail(HPSDF_ERR_OUT_OF_MEMORY, "malloc of the memory block failed");
     const double tc = now();
-    const hpsdf_node* nodesSrc;
-    if (stoppedAfterRound0) {
-        if (nc != T.arenaRows || nn != T.nNodes) {
-            std::free(p);
-            return fail(HPSDF_ERR_STATE, "frontier: round-0 tree does not match its template");
-        }
-        nodesSrc = ws->hostNodesAfterRound0.data();  // (its coefficients came with the header)
-    } else {
+    {
         hipError_t e = ws->ensurePinned(8 * (size_t)nc + sizeof(hpsdf_node) * (size_t)nn);
-        if (e == hipSuccess && nc) e = hipMemcpyAsync(ws->pinned, d.store, 8 * (size_t)nc, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(ws->pinned + 8 * (size_t)nc, d.nodes, sizeof(hpsdf_node) * (size_t)nn, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(ws->pinned, d.store, 8 * (size_t)nc + sizeof(hpsdf_node) * (size_t)nn, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) {
             std::free(p);
             return hipFail(e, "block download");
         }
-        nodesSrc = reinterpret_cast<const hpsdf_node*>(ws->pinned + 8 * (size_t)nc);
     }
     const double tcopy = now() - tc;
     std::memcpy(p, &nc, 8);
     std::memcpy(p + 8, ws->pinned, 8 * (size_t)nc);
     std::memcpy(p + 8 + 8 * (size_t)nc, &nn, 8);
-    std::memcpy(p + 16 + 8 * (size_t)nc, nodesSrc, sizeof(hpsdf_node) * (size_t)nn);
+    std::memcpy(p + 16 + 8 * (size_t)nc, ws->pinned + 8 * (size_t)nc, sizeof(hpsdf_node) * (size_t)nn);
     std::memcpy(p + 16 + 8 * (size_t)nc + sizeof(hpsdf_node) * (size_t)nn, &cfg, sizeof cfg);
     *block = p;
     *size = bytes;
@@ -2067,6 +2480,8 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         stats->dropped = hh->dropped, stats->fits = hh->fits, stats->samples = hh->samples;
         stats->n_nodes = nn, stats->n_leaves = hh->nLeaves, stats->n_coeffs = nc, stats->total_error = hh->total;
     }
+    hipLaunchKernelGGL(fr_init_kernel, dim3((T.nNodes + 255) / 256), dim3(256), 0, s, initDev(), T0);  // for the next build
+    ws->clean = hipGetLastError() == hipSuccess, ws->cleanRank = rank, ws->cleanWorld = world;
     if (trace)
         std::fprintf(stderr, "[frontierCreate] us: total %.0f (waiting for the device %.0f over %d rounds, weights on the host %.0f, block download %.0f)\n",
                      now() - t0, tSync, rounds, tWeights, tcopy);

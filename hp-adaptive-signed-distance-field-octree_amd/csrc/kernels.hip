@@ -2024,7 +2024,7 @@ __device__ __forceinline__ double fitRowAny(double acc, double a1, const double*
 // for R accumulators: 2 + 3/R multiply/add instructions per (cell, sample, row) instead of 5.
 template <int KIND, bool CSG, int DEG, int R, bool LEFT>
 __device__ __forceinline__ void fitBlockBody(const FitBlock blk, const FitTask* __restrict__ tasks, double* __restrict__ arena,
-                                             double* __restrict__ errs, double* __restrict__ means,
+                                             double* __restrict__ errs, double* __restrict__ mirror,
                                              const DeviceTables* __restrict__ T, const FieldDev& field, const RootMap& rm, double* lds) {
     static_assert(R == 1 || DEG > 0, "cell blocking needs a compile-time degree");
     __shared__ double sNl[13 * 11];
@@ -2255,7 +2255,11 @@ __device__ __forceinline__ void fitBlockBody(const FitBlock blk, const FitTask* 
 #pragma unroll
         for (int r = 0; r < R; ++r)
             if (g2 + r < G) {
-                arena[tasks[blk.firstTask + g2 + r].outOff + (r0 - outBase)] = acc[r];
+                const uint64_t at = tasks[blk.firstTask + g2 + r].outOff + (r0 - outBase);
+                arena[at] = acc[r];
+                // mirror (round 0 of the device-side frontier, one rank): host memory the device writes straight into -- a build that
+                // stops after that round has its packed store there when the round closes, without a copy to wait for
+                if (mirror != nullptr) mirror[at] = acc[r];
                 sF[(g2 + r) * stashStride + (r0 - stashBase)] = acc[r];
             }
     }
@@ -2365,7 +2369,7 @@ __global__ __launch_bounds__(kFitThreads) void fit_weight_kernel(const FitBlock*
 template <int KIND, bool CSG, int DEG, int R, bool LEFT>
 __global__ __launch_bounds__(kFitThreads, HPSDF_FIT_MIN_WAVES) void fit_kernel(const FitBlock* __restrict__ blocks,
                                                           const FitTask* __restrict__ tasks, double* __restrict__ arena,
-                                                          double* __restrict__ errs, double* __restrict__ means,
+                                                          double* __restrict__ errs, double* __restrict__ mirror,
                                                           const DeviceTables* __restrict__ T, FieldDev field, RootMap rm,
                                                           const uint32_t* __restrict__ range) {
     extern __shared__ double lds[];
@@ -2374,7 +2378,7 @@ __global__ __launch_bounds__(kFitThreads, HPSDF_FIT_MIN_WAVES) void fit_kernel(c
         if (b >= range[1]) return;
         b += range[0];
     }
-    fitBlockBody<KIND, CSG, DEG, R, LEFT>(blocks[b], tasks, arena, errs, means, T, field, rm, lds);
+    fitBlockBody<KIND, CSG, DEG, R, LEFT>(blocks[b], tasks, arena, errs, mirror, T, field, rm, lds);
 }
 
 // ---------------------------------------------------------------------------
@@ -2901,12 +2905,12 @@ hipError_t launchFitMulti(hipStream_t stream, const FitBlock* dBlocks, uint32_t 
 }
 
 hipError_t launchFit(hipStream_t stream, int degree, int cellsPerThread, const FitBlock* dBlocks, uint32_t nBlocks,
-                     size_t ldsBytes, const FitTask* dTasks, double* dArena, double* dErrs, double* dMeans,
+                     size_t ldsBytes, const FitTask* dTasks, double* dArena, double* dErrs, double* dMirror,
                      const DeviceTables* dTables, const FieldDev& field, const RootMap& rm, const uint32_t* dRange) {
     if (nBlocks == 0) return hipSuccess;
     if (ldsBytes > kFitMaxLdsBytes) return hipErrorInvalidValue;
     HPSDF_DISPATCH_FIELD(launchFitT, field, stream, degree, cellsPerThread, dBlocks, nBlocks, ldsBytes, dTasks, dArena,
-                         dErrs, dMeans, dTables, field, rm, dRange);
+                         dErrs, dMirror, dTables, field, rm, dRange);
     return hipGetLastError();
 }
 

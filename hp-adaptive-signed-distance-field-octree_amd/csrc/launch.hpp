@@ -29,7 +29,7 @@ FitShape fitShape(int degree, int nrows, uint32_t count, bool weighted, bool lat
 
 
 hipError_t launchFit(hipStream_t stream, int degree, int cellsPerThread, const FitBlock* dBlocks, uint32_t nBlocks, size_t ldsBytes,
-                     const FitTask* dTasks, double* dArena, double* dErrs, double* dMeans,
+                     const FitTask* dTasks, double* dArena, double* dErrs, double* dMirror,  // dMirror: a second destination of the rows (host memory the device can write), or nullptr
                      const DeviceTables* dTables, const FieldDev& field, const RootMap& rm, const uint32_t* dRange = nullptr);
 hipError_t launchFitMulti(hipStream_t stream, const FitBlock* dBlocks, uint32_t maxBlocks, size_t ldsBytes, const FitTask* dTasks,
                           double* dArena, double* dErrs, const DeviceTables* dTables, const FieldDev& field, const RootMap& rm,
