@@ -135,6 +135,8 @@ struct FrDev {
     uint64_t* wJobP;
     uint64_t* wJobH;
     double* ops;               // the round's additions to the running total, densely, in job order
+    uint32_t* jobRecA;         // per job of the round being opened, for fr_emit_kernel: H slot | P slot << 16 | degree << 28
+    uint16_t* jobRecB;         //   coarse | ours << 1 | owner << 2 | depth << 5
     FitTask* tasks;
     FitBlock* blocks;
     double* errs;       // [jobs][9]
@@ -171,6 +173,7 @@ __host__ __device__ inline size_t frLds(int degree, int g, int planes) {  // = f
 }
 // workgroup shape of `count` fits of one class: what fitShape (kernels.hip) gives an unweighted, sampled-or-analytic fit
 // splitFit: 0 = off, else the lowest degree whose from-scratch fits are split (the context's splitMinDegree)
+constexpr size_t kFrFitLdsCap = 45 * 1024;
 __host__ __device__ inline bool frSplit(int splitFit, int degree, bool incr) { return splitFit > 0 && !incr && degree >= splitFit && degree <= 11; }
 __host__ __device__ inline void frShape(int degree, bool incr, uint32_t count, int* cells, int* planes, bool fast = false, bool weighted = false,
                                         int split = 0) {
@@ -181,7 +184,10 @@ __host__ __device__ inline void frShape(int degree, bool incr, uint32_t count, i
     if (frSplit(split, degree, incr)) incr = true;  // the exact kernel fits the top-degree rows only: the shape of an incremental fit
     const int nrows = incr ? (int)(frCoef(degree) - frCoef(degree - 1)) : (int)frCoef(degree);
     int gmax = nrows > kFitBlockThreads ? 1 : kFitBlockThreads / nrows;
-    while (gmax > 1 && frLds(degree, gmax, 1) > kFitMaxLdsBytes) --gmax;
+    // (45 KB of dynamic LDS + the fit kernel's 7 KB of static keep three workgroups on a CU at every degree.  Up to kFitMaxLdsBytes the
+    // incremental fits of degrees 6, 8, 9 and 11 stacked one or two cells more -- and a round launched for "one degree more than the
+    // host knows" ran two workgroups a CU: 238 us instead of 194)
+    while (gmax > 1 && frLds(degree, gmax, 1) > (weighted ? kFitMaxLdsBytes : kFrFitLdsCap)) --gmax;
     uint32_t spread = (count + 511u) / 512u;
     int cap = gmax;
     if (degree == 2) {  // as fitShape: measured best for degree 2
@@ -527,10 +533,9 @@ __device__ void frBatchBody(const FrDev& d, FrLds& L, uint32_t nQ, uint32_t abov
     //      Thread t owns jobs 4 t .. 4 t + 3.  With several ranks every rank counts only the fits of its own slice: the
     //      slices are contiguous job ranges of (nearly) equal cost, cut where the host scheduler cuts them (builderSelect).
     uint64_t* sCost = sKey;  // (the bitmap is dead) inclusive prefix of the jobs' costs
-    // per-job records of the inline emission (written once the cost prefix is dead): A = H slot | P slot << 16 | degree << 28;
-    // B = coarse | ours << 1 | owner << 2 | depth << 5.  Words 2048.. of sKey: the scans below use the first 2048.
-    uint32_t* sJobA = reinterpret_cast<uint32_t*>(sKey) + 2048;
-    uint16_t* sJobB = reinterpret_cast<uint16_t*>(reinterpret_cast<uint32_t*>(sKey) + 6144);
+    // (INLINE) per-job records for fr_emit_kernel: A = H slot | P slot << 16 | degree << 28; B = coarse | ours << 1 | owner << 2 | depth << 5
+    uint32_t* sJobA = d.jobRecA;
+    uint16_t* sJobB = d.jobRecB;
     {
         int jP[4], jDep[4];
         bool jCoarse[4];
@@ -680,7 +685,7 @@ __device__ void frBatchBody(const FrDev& d, FrLds& L, uint32_t nQ, uint32_t abov
     uint32_t exCnt = 0, exBlk = 0;
     uint64_t exRows = 0, exSmp = 0;
     if (tid < (uint32_t)kFrClasses) exCnt = sCnt[tid] - myCount, exBlk = sBlk[tid] - myBlocks, exRows = sRows[tid] - myRows, exSmp = sSmp[tid] - mySamples;
-    if (!INLINE && tid < (uint32_t)kFrClasses) {
+    if (tid < (uint32_t)kFrClasses) {
         R->cCount[tid] = myCount;
         R->cFirst[tid] = exCnt;
         R->cCursor[tid] = 0;
@@ -710,95 +715,105 @@ __device__ void frBatchBody(const FrDev& d, FrLds& L, uint32_t nQ, uint32_t abov
         if (!INLINE && d.world > 1) *frStatusSlotNext(d, d.rank) = 0.0;  // (inline: the leader, once nobody reads the closing round's errors any more)
     }
     FR_STAMP(7);
-    if (!INLINE) return;
-    // ---- the lists.  Class tables into LDS (the histogram and the scans are dead -- the barrier above): per class the first
-    //      task, the first workgroup, the count, the shape; the arena rows and sample slots before it.
-    uint32_t* tabTask = sHist;
-    uint32_t* tabBlk = sHist + kFrClasses;
-    uint32_t* tabCount = sHist + 2 * kFrClasses;
-    uint32_t* tabShape = sHist + 3 * kFrClasses;
-    uint64_t* tabArena = sKey;
-    uint64_t* tabSample = sKey + kFrClasses;
+    FR_STAMP(8);
+}
+
+// The round's FitTask / FitBlock lists behind the inline batch (fr_round_kernel's leader): the shape classes are in d.rnd, every job's
+// slots and facts in d.jobRecA / B, the batch in d.wBatchIdx.  Workgroup w takes jobs 128 w .. 128 w + 127: one lane per fit, the
+// records through the wave's staging buffer (frStoreRecords) -- first the from-scratch fits of the children (EstimateHImprovement,
+// :814-822; lane 8 j + k is child k of job j, a job's eight tasks are contiguous), then every job's own fit (the coarse degree-2 fit
+// :836-843 or the incremental one :846-851) and where the job's results will lie in the arena; then its share of the workgroup records.
+// (The leader wrote these lists itself at first: 60 k cycles of one CU for a 1024-job round.)
+struct FrEmitLds {
+    uint32_t tabTask[kFrClasses], tabBlk[kFrClasses], tabCount[kFrClasses], tabShape[kFrClasses];
+    uint64_t tabArena[kFrClasses], tabSample[kFrClasses];
+    uint32_t slice[9];
+    uint64_t stage[16][64 * 7];
+};
+__global__ __launch_bounds__(1024) void fr_emit_kernel(FrDev d) {
+    const FrHdr* h = d.hdr;
+    if (h->done) return;
+    const uint32_t nJobs = h->nJobs, nBlocks = h->nBlocks, tid = threadIdx.x;
+    const FrRound* R = d.rnd;
+    __shared__ FrEmitLds E;
     if (tid < (uint32_t)kFrClasses) {
-        tabTask[tid] = exCnt, tabBlk[tid] = exBlk, tabCount[tid] = myCount, tabShape[tid] = (uint32_t)g | ((uint32_t)pl << 8);
-        tabArena[tid] = exRows, tabSample[tid] = exSmp;
+        E.tabTask[tid] = R->cFirst[tid], E.tabBlk[tid] = R->cBlockFirst[tid], E.tabCount[tid] = R->cCount[tid];
+        E.tabShape[tid] = (uint32_t)R->cG[tid] | ((uint32_t)R->cPlanes[tid] << 8);
+        E.tabArena[tid] = R->cArena[tid], E.tabSample[tid] = R->cSample[tid];
     }
-    __syncthreads();
-    // One lane per fit, the records through the wave's staging buffer (frStoreRecords).  First the from-scratch fits of the children
-    // (EstimateHImprovement, :814-822): lane 8 j + k is child k of job j, a job's eight tasks are contiguous.
+    if (tid < 9) E.slice[tid] = h->sliceFirst[tid];
+    const uint64_t arenaBase = R->arenaBase;
     const int wv = (int)(tid >> 6);
     uint64_t* tasks64 = reinterpret_cast<uint64_t*>(d.tasks);
     auto word2 = [](float lo, float hi) { return (uint64_t)__float_as_uint(lo) | ((uint64_t)__float_as_uint(hi) << 32); };
-    for (uint32_t i0 = 0; i0 < 8u * nJobs; i0 += 1024u) {
-        const uint32_t i = i0 + tid, j = i >> 3;
-        const int k = (int)(i & 7u);
-        const bool live = j < nJobs;
-        float bn[3] = {0, 0, 0}, bx[3] = {0, 0, 0};
-        uint32_t ja = 0, jb = 0;
-        if (live) {
-            const hpsdf_node& n = d.nodes[sVal[j]];
-            for (int a = 0; a < 3; ++a) bn[a] = n.aabb_min[a], bx[a] = n.aabb_max[a];
-            ja = sJobA[j], jb = sJobB[j];
-        }
-        const int p = (int)(ja >> 28), dep = (int)(jb >> 5);
-        const bool hasH = live && (jb & 2u) != 0 && (jb & 1u) == 0 && dep < kMaxDepth;
-        const int c = frClass(p, false, dep + 1 <= kMaxDepth ? dep + 1 : kMaxDepth);
-        const uint32_t slot0 = ja & 0xFFFFu;
-        const uint64_t rows = frCoef(p), nq = 4 * (uint64_t)p + 1;
-        float mn[3], mx[3];
-        for (int a = 0; a < 3; ++a) {  // Octree::CornerAABB, :1096-1112
-            const float mid = (bx[a] + bn[a]) * 0.5f;
-            mn[a] = (k >> a) & 1 ? mid : bn[a];
-            mx[a] = (k >> a) & 1 ? bx[a] : mid;
-        }
-        uint64_t w[7];
-        w[0] = word2(mn[0], mn[1]), w[1] = word2(mn[2], mx[0]), w[2] = word2(mx[1], mx[2]);
-        w[3] = arenaBase + tabArena[c] + (uint64_t)(slot0 + (uint32_t)k) * rows;  // outOff
-        w[4] = ~0ull;                                                              // copyOff
-        w[5] = tabSample[c] + (uint64_t)(slot0 + (uint32_t)k) * nq * nq * nq;      // sampleOff
-        w[6] = (uint64_t)(frErrSlotNext(d, L.slice, (jb >> 2) & 7u, live ? j : 0u) + 1u + (uint32_t)k) | ((uint64_t)(dep + 1) << 32) | ((uint64_t)p << 40);
-        frStoreRecords(L.stage[wv], tasks64, w, ((uint64_t)tabTask[c] + slot0) * 7u, hasH, true);
+    // this lane's child fit: job and node first (independent of the tables)
+    const uint32_t jH = blockIdx.x * 128u + (tid >> 3), jP = blockIdx.x * 128u + tid;
+    const int k = (int)(tid & 7u);
+    const bool liveH = jH < nJobs, liveP = tid < 128u && jP < nJobs;
+    float bn[3] = {0, 0, 0}, bx[3] = {0, 0, 0}, pn[3] = {0, 0, 0}, px[3] = {0, 0, 0};
+    uint32_t ja = 0, jb = 0, pa = 0, pb = 0, pIdx = 0;
+    if (liveH) {
+        const hpsdf_node& n = d.nodes[d.wBatchIdx[jH]];
+        for (int a = 0; a < 3; ++a) bn[a] = n.aabb_min[a], bx[a] = n.aabb_max[a];
+        ja = d.jobRecA[jH], jb = d.jobRecB[jH];
     }
-    // ... then every job's own fit (the coarse degree-2 fit :836-843 or the incremental one :846-851), and where the job's results
-    // will lie in the arena
-    for (uint32_t j0 = 0; j0 < nJobs; j0 += 1024u) {
-        const uint32_t j = j0 + tid;
-        const bool live = j < nJobs;
-        float bn[3] = {0, 0, 0}, bx[3] = {0, 0, 0};
-        uint32_t ja = 0, jb = 0, idx = 0;
-        if (live) {
-            idx = sVal[j];
-            const hpsdf_node& n = d.nodes[idx];
-            for (int a = 0; a < 3; ++a) bn[a] = n.aabb_min[a], bx[a] = n.aabb_max[a];
-            ja = sJobA[j], jb = sJobB[j];
+    if (liveP) {
+        pIdx = d.wBatchIdx[jP];
+        const hpsdf_node& n = d.nodes[pIdx];
+        for (int a = 0; a < 3; ++a) pn[a] = n.aabb_min[a], px[a] = n.aabb_max[a];
+        pa = d.jobRecA[jP], pb = d.jobRecB[jP];
+    }
+    __syncthreads();
+    if (blockIdx.x * 128u < nJobs) {
+        {
+            const int p = (int)(ja >> 28), dep = (int)(jb >> 5);
+            const bool hasH = liveH && (jb & 2u) != 0 && (jb & 1u) == 0 && dep < kMaxDepth;
+            const int c = frClass(p, false, dep + 1 <= kMaxDepth ? dep + 1 : kMaxDepth);
+            const uint32_t slot0 = ja & 0xFFFFu;
+            const uint64_t rows = frCoef(p), nq = 4 * (uint64_t)p + 1;
+            float mn[3], mx[3];
+            for (int a = 0; a < 3; ++a) {  // Octree::CornerAABB, :1096-1112
+                const float mid = (bx[a] + bn[a]) * 0.5f;
+                mn[a] = (k >> a) & 1 ? mid : bn[a];
+                mx[a] = (k >> a) & 1 ? bx[a] : mid;
+            }
+            uint64_t w[7];
+            w[0] = word2(mn[0], mn[1]), w[1] = word2(mn[2], mx[0]), w[2] = word2(mx[1], mx[2]);
+            w[3] = arenaBase + E.tabArena[c] + (uint64_t)(slot0 + (uint32_t)k) * rows;  // outOff
+            w[4] = ~0ull;                                                                // copyOff
+            w[5] = E.tabSample[c] + (uint64_t)(slot0 + (uint32_t)k) * nq * nq * nq;      // sampleOff
+            w[6] = (uint64_t)(frErrSlotNext(d, E.slice, (jb >> 2) & 7u, liveH ? jH : 0u) + 1u + (uint32_t)k) | ((uint64_t)(dep + 1) << 32) | ((uint64_t)p << 40);
+            frStoreRecords(E.stage[wv], tasks64, w, ((uint64_t)E.tabTask[c] + slot0) * 7u, hasH, true);
         }
-        const int p = (int)(ja >> 28), dep = (int)(jb >> 5);
-        const bool coarse = (jb & 1u) != 0, ours = (jb & 2u) != 0;
-        const bool hasH = live && ours && !coarse && dep < kMaxDepth, hasP = live && ours && (coarse || p < kMaxDegree - 1);
-        const int deg = coarse ? 2 : (p + 1 <= kMaxDegree ? p + 1 : kMaxDegree);
-        const bool incr = !coarse;
-        const int c = frClass(deg, incr, dep), cH = frClass(p, false, dep + 1 <= kMaxDepth ? dep + 1 : kMaxDepth);
-        const uint32_t slot = (ja >> 16) & 4095u;
-        const uint64_t rows = (incr && !d.weighted) ? frCoef(deg) - frCoef(deg - 1) : frCoef(deg), nq = 4 * (uint64_t)deg + 1;
-        const uint64_t outP = arenaBase + tabArena[c] + (uint64_t)slot * rows;
-        uint64_t w[7];
-        w[0] = word2(bn[0], bn[1]), w[1] = word2(bn[2], bx[0]), w[2] = word2(bx[1], bx[2]);
-        w[3] = outP;
-        // weighted incremental fit: the cell's current array (one segment: the update keeps it that way), :847
-        w[4] = (hasP && d.weighted && incr) ? (d.segOff[(size_t)idx * kFrSegs] & kOffMask) : ~0ull;
-        w[5] = tabSample[c] + (uint64_t)slot * nq * nq * nq;
-        w[6] = (uint64_t)frErrSlotNext(d, L.slice, (jb >> 2) & 7u, live ? j : 0u) | ((uint64_t)dep << 32) | ((uint64_t)deg << 40);
-        frStoreRecords(L.stage[wv], tasks64, w, ((uint64_t)tabTask[c] + slot) * 7u, hasP, false);
-        if (live) {
-            d.wJobP[j] = hasP ? outP : ~0ull;
-            d.wJobH[j] = hasH ? arenaBase + tabArena[cH] + (uint64_t)(ja & 0xFFFFu) * frCoef(p) : ~0ull;
+        if (tid < 128u) {  // (waves 0 and 1)
+            const int p = (int)(pa >> 28), dep = (int)(pb >> 5);
+            const bool coarse = (pb & 1u) != 0, ours = (pb & 2u) != 0;
+            const bool hasH = liveP && ours && !coarse && dep < kMaxDepth, hasP = liveP && ours && (coarse || p < kMaxDegree - 1);
+            const int deg = coarse ? 2 : (p + 1 <= kMaxDegree ? p + 1 : kMaxDegree);
+            const bool incr = !coarse;
+            const int c = frClass(deg, incr, dep), cH = frClass(p, false, dep + 1 <= kMaxDepth ? dep + 1 : kMaxDepth);
+            const uint32_t slot = (pa >> 16) & 4095u;
+            const uint64_t rows = (incr && !d.weighted) ? frCoef(deg) - frCoef(deg - 1) : frCoef(deg), nq = 4 * (uint64_t)deg + 1;
+            const uint64_t outP = arenaBase + E.tabArena[c] + (uint64_t)slot * rows;
+            uint64_t w[7];
+            w[0] = word2(pn[0], pn[1]), w[1] = word2(pn[2], px[0]), w[2] = word2(px[1], px[2]);
+            w[3] = outP;
+            // weighted incremental fit: the cell's current array (one segment: the update keeps it that way), :847
+            w[4] = (hasP && d.weighted && incr) ? (d.segOff[(size_t)pIdx * kFrSegs] & kOffMask) : ~0ull;
+            w[5] = E.tabSample[c] + (uint64_t)slot * nq * nq * nq;
+            w[6] = (uint64_t)frErrSlotNext(d, E.slice, (pb >> 2) & 7u, liveP ? jP : 0u) | ((uint64_t)dep << 32) | ((uint64_t)deg << 40);
+            frStoreRecords(E.stage[wv], tasks64, w, ((uint64_t)E.tabTask[c] + slot) * 7u, hasP, false);
+            if (liveP) {
+                d.wJobP[jP] = hasP ? outP : ~0ull;
+                d.wJobH[jP] = hasH ? arenaBase + E.tabArena[cH] + (uint64_t)(pa & 0xFFFFu) * frCoef(p) : ~0ull;
+            }
         }
     }
-    for (uint32_t b = tid; b < nBlocks; b += 1024) {
+    for (uint32_t b = blockIdx.x * 1024u + tid; b < nBlocks; b += gridDim.x * 1024u) {
         int lo = 0, hi = kFrClasses;  // the last class whose first workgroup is <= b is the one that owns b
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
-            if (tabBlk[mid] <= b)
+            if (E.tabBlk[mid] <= b)
                 lo = mid;
             else
                 hi = mid;
@@ -806,13 +821,13 @@ __device__ void frBatchBody(const FrDev& d, FrLds& L, uint32_t nQ, uint32_t abov
         const int c = lo;
         const int deg = c / kFrDepths / 2;
         const bool incr = (c / kFrDepths) & 1;
-        const uint32_t gg = tabShape[c] & 255u, local = b - tabBlk[c];
+        const uint32_t gg = E.tabShape[c] & 255u, local = b - E.tabBlk[c];
         FitBlock fb;
-        fb.firstTask = tabTask[c] + local * gg;
-        const uint32_t left = tabCount[c] - local * gg;
+        fb.firstTask = E.tabTask[c] + local * gg;
+        const uint32_t left = E.tabCount[c] - local * gg;
         fb.nTasks = (uint16_t)(left < gg ? left : gg);
         fb.degree = (uint8_t)deg;
-        fb.planesPerChunk = (uint8_t)(tabShape[c] >> 8);
+        fb.planesPerChunk = (uint8_t)(E.tabShape[c] >> 8);
         const bool split = frSplit(d.splitFit, deg, incr);
         fb.rowStart = (uint16_t)((incr || split) ? frCoef(deg - 1) : 0);
         fb.rowEnd = (uint16_t)frCoef(deg);
@@ -822,7 +837,6 @@ __device__ void frBatchBody(const FrDev& d, FrLds& L, uint32_t nQ, uint32_t abov
         fb.pad1[0] = 0;
         d.blocks[b] = fb;
     }
-    FR_STAMP(8);
 }
 
 __global__ __launch_bounds__(1024) void fr_batch_kernel(FrDev d) {
@@ -1821,6 +1835,8 @@ struct FrontierWorkspace {
         if (e == hipSuccess) e = hipMalloc((void**)&d.wJobP, kFrJobs * sizeof(uint64_t));
         if (e == hipSuccess) e = hipMalloc((void**)&d.wJobH, kFrJobs * sizeof(uint64_t));
         if (e == hipSuccess) e = hipMalloc((void**)&d.ops, (size_t)kFrJobs * 9 * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc((void**)&d.jobRecA, kFrJobs * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&d.jobRecB, kFrJobs * sizeof(uint16_t));
         if (e == hipSuccess) e = hipMalloc((void**)&d.tasks, kFrTasks * sizeof(FitTask));
         if (e == hipSuccess) e = hipMalloc((void**)&d.blocks, kFrTasks * sizeof(FitBlock));
         if (e == hipSuccess) e = hipMalloc((void**)&d.errs, (size_t)kFrJobs * HPSDF_JOB_HEADER_DOUBLES * sizeof(double));
@@ -1909,7 +1925,7 @@ struct FrontierWorkspace {
         if (device >= 0) (void)hipSetDevice(device);
         for (void* p : {(void*)d.hdr, (void*)d.rnd, (void*)d.nodes, (void*)d.qErr, (void*)d.parent, (void*)d.segOff, (void*)d.segFirst,
                         (void*)d.sub, (void*)d.taken, (void*)d.candA, (void*)d.candB, (void*)d.wBatchIdx, (void*)d.wBatchErr, (void*)d.wJobP,
-                        (void*)d.wJobH, (void*)d.ops, (void*)d.tasks, (void*)d.blocks, (void*)d.errs, (void*)d.store,
+                        (void*)d.wJobH, (void*)d.ops, (void*)d.jobRecA, (void*)d.jobRecB, (void*)d.tasks, (void*)d.blocks, (void*)d.errs, (void*)d.store,
                         (void*)arena, (void*)samples, (void*)tmplNodes, (void*)tmplParent, (void*)tmplSub, (void*)tmplLeaves, (void*)tmplErr,
                         (void*)tmplJobP, (void*)tmplTasks, (void*)tmplBlocks, (void*)d.jobOwner, (void*)d.packPos, (void*)d.pack, (void*)r0Tasks,
                         (void*)r0Blocks, (void*)r0JobP})
@@ -2339,10 +2355,12 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         // From the second round on the fits are launched without waiting for the header (one rank, no host step in between): what they
         // need to know is on the device -- their lists and counts -- and a build that has stopped leaves them nothing to do.  The
         // largest degree may have risen once more than the host knows.
-        const bool blind = rounds >= 1 && pre && world == 1 && !weighted && !frSyncEveryLaunch();
+        static const bool noBlind = std::getenv("HPSDF_FRONTIER_NO_BLIND") != nullptr;  // (for comparisons)
+        const bool blind = rounds >= 1 && pre && world == 1 && !weighted && !frSyncEveryLaunch() && !noBlind;
         if (blind) {
             if (mesh && tooLargeCur) return fail(HPSDF_ERR_UNSUPPORTED, "round too large for the sampled mesh path");
             d.splitFit = dk.splitFit;
+            FR_LAUNCH(fr_emit_kernel, dim3((Kj + 127u) / 128u), dim3(1024), s, dk);
             if ((rc = launchRoundFits(std::min<uint32_t>(knownMaxDeg + 1u, kMaxDegree), splitCur))) return rc;
         }
         if (rounds == 0 && world == 1) {
@@ -2415,6 +2433,11 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         if (world > 1) phase = 2;
         if (injectedFailure(rounds)) return fail(HPSDF_ERR_OUT_OF_MEMORY, "injected failure (HPSDF_TEST_FAIL_RANK)");
         if (mesh && tooLargeCur) return fail(HPSDF_ERR_UNSUPPORTED, "round too large for the sampled mesh path");
+        if (pre && !blind) {
+            FrDev de = d;
+            de.splitFit = dk.splitFit;
+            FR_LAUNCH(fr_emit_kernel, dim3((Kj + 127u) / 128u), dim3(1024), s, de);
+        }
         if (!pre) {  // a large tree: the selection as a grid, then batch and lists (the header's arenaUsed lags one round: bound it)
             FrDev dl = d;
             dl.splitFit = dk.splitFit;
