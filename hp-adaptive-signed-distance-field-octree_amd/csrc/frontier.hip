@@ -93,6 +93,8 @@ struct FrHdr {
     uint32_t chainStamp;  // round + 1 once rTotal holds that round's running total
     uint32_t landed;      // (mirror only) the build's stamp, written when round 0's closing launch starts: the fit before it has finished, so
                           // the rows it wrote into pinned host memory are there
+    uint32_t stored[2];   // (mirror only) the build's stamp once fr_store_kernel's node array / coefficients are in pinned host memory
+    uint32_t storeArrive[2];  // workgroups of fr_store_kernel that have finished a phase
     uint32_t hist1[2048];  // queued nodes per exponent bin (kept by update / batch)
     uint32_t hist2[2048];  // level-1 digits of the candidates of the current selection (grid selection only)
     uint64_t agg[kFrJobs / 128];  // fr_round_kernel: per update workgroup {round stamp, splitting jobs << 16 | P jobs}
@@ -140,9 +142,8 @@ struct FrDev {
     FitTask* tasks;
     FitBlock* blocks;
     double* errs;       // [jobs][9]
-    double* store;      // packed coefficients (ReallocCoeffs)
+    double* store;      // the finished block's coefficients and, behind them, its node array: pinned host memory as the device addresses it
     const double* arena;
-    uint64_t storeCap;
     uint32_t nodeCap, K;
     // multi-rank builds (world > 1): this rank fits a cost-balanced slice of every round's jobs
     int32_t rank, world;
@@ -1151,8 +1152,8 @@ __device__ __forceinline__ void frMirror(const FrDev& d) {
     constexpr uint32_t kRoundWord = offsetof(FrHdr, round) / 4;
     __threadfence();
     __syncthreads();
-    constexpr uint32_t kLandedWord = offsetof(FrHdr, landed) / 4;
-    if (tid < kFrHdrCopyBytes / 4 && tid != kRoundWord && tid != kLandedWord)
+    constexpr uint32_t kLandedWord = offsetof(FrHdr, landed) / 4;  // (landed and stored[] live in the mirror alone)
+    if (tid < kFrHdrCopyBytes / 4 && tid != kRoundWord && (tid < kLandedWord || tid > kLandedWord + 2))
         reinterpret_cast<volatile uint32_t*>(d.hostHdr)[tid] = reinterpret_cast<volatile uint32_t*>(d.hdr)[tid];
     __threadfence_system();
     __syncthreads();
@@ -1454,46 +1455,96 @@ __global__ __launch_bounds__(256) void fr_subtree_kernel(FrDev d) {
 // ancestors-or-self a: the subtree sizes of a's earlier siblings.  Its rows are then gathered from the arena, segment by
 // segment.
 // ---------------------------------------------------------------------------------------------------------------------
+// Workgroup b takes nodes 256 b .. 256 b + 255, in two phases; d.store is pinned HOST memory (ToMemoryBlock's order, :424-456:
+// coefficients, then the node array), written by the stores themselves -- no copy to launch, and the host, which watches
+// FrHdr::stored, moves the node array into the block while the coefficients are still on their way.
+//   1  one lane per node: coeffsStart (lanes walk up alone: the earlier siblings' sizes level by level), the serialised node through
+//      the wave's staging buffer (whole records, in order)
+//   2  the workgroup's leaves' rows: one lane per row -- a prefix sum over the 256 leaves' row counts, a search for the row's leaf, the
+//      segment it lies in -- so that every lane has a load in flight and a leaf's rows leave as one run
 __global__ __launch_bounds__(256) void fr_store_kernel(FrDev d) {
     FrHdr* h = d.hdr;
     if (!h->done || h->overflow) return;
-    const uint32_t n = h->nNodes;
-    const int lane = threadIdx.x & 63;
-    // the serialised node array goes behind the coefficients (ToMemoryBlock's order, :424-456): the block is ONE download
-    uint64_t* nodesOut = reinterpret_cast<uint64_t*>(d.store + h->nCoeffs);
-    for (uint32_t i = (blockIdx.x * 256u + threadIdx.x) >> 6; i < n; i += gridDim.x * 4u) {
-        const hpsdf_node nd = d.nodes[i];
-        const uint64_t* words = reinterpret_cast<const uint64_t*>(&d.nodes[i]);
-        if (nd.degree == kInteriorDegree) {
-            if (lane < 7) nodesOut[(size_t)i * 7 + lane] = words[lane];
-            continue;
-        }
-        uint32_t start = 0;
+    const uint32_t n = h->nNodes, tid = threadIdx.x;
+    const uint64_t nCoeffs = h->nCoeffs;
+    __shared__ uint64_t sStage[4][64 * 7];
+    __shared__ uint32_t sStart[256], sRows[257], sWave[4];
+    const uint32_t i = blockIdx.x * 256u + tid;
+    const bool live = i < n;
+    hpsdf_node nd;
+    nd.child_idx = ~0ull, nd.degree = kInteriorDegree, nd.depth = 0, nd.coeffs_start = 0;
+    if (live) nd = d.nodes[i];
+    const bool leaf = live && nd.degree != kInteriorDegree;
+    uint32_t start = 0;
+    if (leaf) {
         uint32_t a = i;
-        while (a != 0) {  // lanes 0..6 look at the siblings before `a`
+        while (a != 0) {
             const uint32_t par = d.parent[a];
             const uint32_t c0 = (uint32_t)d.nodes[par].child_idx;
-            const uint32_t k = a - c0;
-            uint32_t v = 0;
-            if ((uint32_t)lane < k) {
-                const hpsdf_node& sib = d.nodes[c0 + lane];
-                v = sib.degree == kInteriorDegree ? d.sub[c0 + lane] : frCoef(sib.degree);
+            for (uint32_t sIdx = c0; sIdx < a; ++sIdx) {
+                const uint32_t dg = d.nodes[sIdx].degree;
+                start += dg == kInteriorDegree ? d.sub[sIdx] : frCoef((int)dg);
             }
-            for (int off = 4; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);  // lanes 0..7 hold the sum
-            start += __shfl(v, 0, 64);
             a = par;
         }
-        if (lane == 0) d.nodes[i].coeffs_start = start;
-        if (lane < 7) nodesOut[(size_t)i * 7 + lane] = lane == 4 ? (uint64_t)start : words[lane];  // (word 4: coeffs_start, @32)
-        const int first = d.segFirst[i];
-        for (int s = 0; s <= (int)nd.degree - first; ++s) {
-            const uint32_t r0 = s == 0 ? 0u : frCoef(first + s - 1), r1 = frCoef(first + s);
-            const uint64_t so = d.segOff[(size_t)i * kFrSegs + s];
-            // one rank: straight from the arena; several: from the all-gathered pack buffers (fr_pack_kernel)
-            const double* src = d.world == 1 ? d.arena + (so & kOffMask)
-                                             : d.pack + (size_t)(so >> 56) * d.packStride + d.packPos[(size_t)i * kFrSegs + s];
-            for (uint32_t r = r0 + (uint32_t)lane; r < r1; r += 64) d.store[(size_t)start + r] = src[r - r0];
+    }
+    {
+        uint64_t w[7];
+        const uint64_t* src = reinterpret_cast<const uint64_t*>(&nd);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) w[k] = src[k];
+        if (leaf) w[4] = (uint64_t)start;  // (word 4: coeffs_start, @32)
+        // the wave's 64 nodes are consecutive: one run
+        frStoreRecords(sStage[tid >> 6], reinterpret_cast<uint64_t*>(d.store + nCoeffs), w, (uint64_t)i * 7u, live, false);
+    }
+    sStart[tid] = start;
+    const uint32_t rows = leaf ? frCoef((int)nd.degree) : 0u;
+    // inclusive scan of the row counts over the workgroup
+    uint32_t inc = rows;
+    const int lane = (int)(tid & 63);
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += v;
+    }
+    if (lane == 63) sWave[tid >> 6] = inc;
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0 && atomicAdd(&h->storeArrive[0], 1u) == gridDim.x - 1u) {  // the node array is complete
+        __threadfence_system();
+        *(volatile uint32_t*)&d.hostHdr->stored[0] = d.buildStamp;
+        __threadfence_system();
+    }
+    uint32_t before = 0;
+    for (uint32_t w2 = 0; w2 < (tid >> 6); ++w2) before += sWave[w2];
+    sRows[tid + 1] = before + inc;
+    if (tid == 0) sRows[0] = 0;
+    __syncthreads();
+    const uint32_t total = sRows[256];
+    for (uint32_t e = tid; e < total; e += 256u) {
+        uint32_t lo = 0, hi = 256;  // the leaf whose rows hold element e: the last one with sRows[leaf] <= e
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (sRows[mid] <= e)
+                lo = mid;
+            else
+                hi = mid;
         }
+        const uint32_t node = blockIdx.x * 256u + lo, r = e - sRows[lo];
+        const int first = d.segFirst[node];
+        int sg = 0;  // the segment row r lies in: rows [coef(first + sg - 1), coef(first + sg))
+        while (r >= frCoef(first + sg)) ++sg;
+        const uint32_t r0 = sg == 0 ? 0u : frCoef(first + sg - 1);
+        const uint64_t so = d.segOff[(size_t)node * kFrSegs + sg];
+        // one rank: straight from the arena; several: from the all-gathered pack buffers (fr_pack_kernel)
+        const double* src = d.world == 1 ? d.arena + (so & kOffMask) : d.pack + (size_t)(so >> 56) * d.packStride + d.packPos[(size_t)node * kFrSegs + sg];
+        d.store[(size_t)sStart[lo] + r] = src[r - r0];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0 && atomicAdd(&h->storeArrive[1], 1u) == gridDim.x - 1u) {
+        __threadfence_system();
+        *(volatile uint32_t*)&d.hostHdr->stored[1] = d.buildStamp;
+        __threadfence_system();
     }
 }
 
@@ -1661,7 +1712,7 @@ struct FrontierWorkspace {
     FrDev d{};
     FrHdr* hostHdr = nullptr;  // pinned
     uint32_t nodeCap = 0;
-    uint64_t arenaCap = 0, sampleCap = 0, storeCap = 0;
+    uint64_t arenaCap = 0, sampleCap = 0;
     double* arena = nullptr;
     double* samples = nullptr;
     // Template of the uniformly refined tree (Octree::UniformlyRefine, :112-191) and of round 0, which is the same for
@@ -1760,14 +1811,6 @@ struct FrontierWorkspace {
         const uint64_t nc = (need + (1ull << 20) - 1) & ~((1ull << 20) - 1);  // to the need (GBs at high degrees), not to a power of two
         hipError_t e = grow(&samples, 0, nc, s, false);
         if (e == hipSuccess) sampleCap = nc;
-        return e;
-    }
-    hipError_t ensureStore(uint64_t need, hipStream_t s) {
-        if (need <= storeCap) return hipSuccess;
-        uint64_t nc = storeCap ? storeCap : (1ull << 20);
-        while (nc < need) nc *= 2;
-        hipError_t e = grow(&d.store, 0, nc, s, false);
-        if (e == hipSuccess) storeCap = nc, d.storeCap = nc;
         return e;
     }
     // multi-rank: errs is [world][4096 * 9], plus owners, pack positions, round-0 share
@@ -1917,7 +1960,6 @@ struct FrontierWorkspace {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&forkEv, hipEventDisableTiming);
         if (e == hipSuccess) e = ensureNodes(65536, s);
         if (e == hipSuccess) e = ensureArena(1ull << 22, 0, s);
-        if (e == hipSuccess) e = ensureStore(1ull << 20, s);
         if (e == hipSuccess) e = ensurePinned(4u << 20);
         return e;
     }
@@ -1925,7 +1967,7 @@ struct FrontierWorkspace {
         if (device >= 0) (void)hipSetDevice(device);
         for (void* p : {(void*)d.hdr, (void*)d.rnd, (void*)d.nodes, (void*)d.qErr, (void*)d.parent, (void*)d.segOff, (void*)d.segFirst,
                         (void*)d.sub, (void*)d.taken, (void*)d.candA, (void*)d.candB, (void*)d.wBatchIdx, (void*)d.wBatchErr, (void*)d.wJobP,
-                        (void*)d.wJobH, (void*)d.ops, (void*)d.jobRecA, (void*)d.jobRecB, (void*)d.tasks, (void*)d.blocks, (void*)d.errs, (void*)d.store,
+                        (void*)d.wJobH, (void*)d.ops, (void*)d.jobRecA, (void*)d.jobRecB, (void*)d.tasks, (void*)d.blocks, (void*)d.errs,
                         (void*)arena, (void*)samples, (void*)tmplNodes, (void*)tmplParent, (void*)tmplSub, (void*)tmplLeaves, (void*)tmplErr,
                         (void*)tmplJobP, (void*)tmplTasks, (void*)tmplBlocks, (void*)d.jobOwner, (void*)d.packPos, (void*)d.pack, (void*)r0Tasks,
                         (void*)r0Blocks, (void*)r0JobP})
@@ -2453,11 +2495,14 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         if ((rc = exchange(d.errs, (size_t)strideK * sizeof(double), "a round's errors"))) return rc;
         phase = 0;
     }
+    // ReallocCoeffs, and Octree::ToMemoryBlock (Octree.cpp:424-456: [u64 nCoeffs][f64 x nCoeffs][u64 nNodes][Node x nNodes][Config]): the
+    // device writes coefficients and node array into pinned host memory (fr_store_kernel), the host moves each part into the block
+    // when the mirror says it is there -- the node array while the coefficients are still landing
+    const uint64_t nc = hh->nCoeffs, nn = hh->nNodes;
     {
-        // ReallocCoeffs: the packed store, the node array behind it
-        const uint64_t nc = hh->nCoeffs, nn = hh->nNodes;
-        hipError_t e = ws->ensureStore(nc + 7ull * nn, s);
-        if (e != hipSuccess) return hipFail(e, "coefficient store");
+        hipError_t e = ws->ensurePinned(8 * (size_t)nc + sizeof(hpsdf_node) * (size_t)nn);
+        if (e != hipSuccess) return hipFail(e, "block staging");
+        d.store = ws->pinnedDev;
         FR_LAUNCH(fr_subtree_kernel, dim3(((uint32_t)nn + 255u) / 256u), dim3(256), s, d);
         if (world > 1) {
             // the packed store from one all-gather of the ranks' pack buffers (each rank's own segments in node order)
@@ -2472,29 +2517,36 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
             FR_LAUNCH(fr_pack_kernel, dim3(std::min<uint32_t>(2048u, (knownNodes + 3u) / 4u)), dim3(256), s, d);
             if ((rc = exchange(d.pack, (size_t)stride * sizeof(double), "the packed coefficients"))) return rc;
         }
-        FR_LAUNCH(fr_store_kernel, dim3(std::min<uint32_t>(2048u, ((uint32_t)nn + 3u) / 4u)), dim3(256), s, d);
+        FR_LAUNCH(fr_store_kernel, dim3(((uint32_t)nn + 255u) / 256u), dim3(256), s, d);
     }
-    // Octree::ToMemoryBlock, Octree.cpp:424-456: [u64 nCoeffs][f64 x nCoeffs][u64 nNodes][Node x nNodes][Config]
-    const uint64_t nc = hh->nCoeffs, nn = hh->nNodes;
     const size_t bytes = 8 + 8 * (size_t)nc + 8 + sizeof(hpsdf_node) * (size_t)nn + sizeof(hpsdf_config);
     uint8_t* p = (uint8_t*)std::malloc(bytes);
-    if (!p) return fail(HPSDF_ERR_OUT_OF_MEMORY, "malloc of the memory block failed");
+    if (!p) {
+        (void)hipStreamSynchronize(s);
+        return fail(HPSDF_ERR_OUT_OF_MEMORY, "malloc of the memory block failed");
+    }
     const double tc = now();
-    {
-        hipError_t e = ws->ensurePinned(8 * (size_t)nc + sizeof(hpsdf_node) * (size_t)nn);
-        if (e == hipSuccess) e = hipMemcpyAsync(ws->pinned, d.store, 8 * (size_t)nc + sizeof(hpsdf_node) * (size_t)nn, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) {
-            std::free(p);
-            return hipFail(e, "block download");
+    std::memcpy(p, &nc, 8);
+    std::memcpy(p + 8 + 8 * (size_t)nc, &nn, 8);
+    std::memcpy(p + 16 + 8 * (size_t)nc + sizeof(hpsdf_node) * (size_t)nn, &cfg, sizeof cfg);
+    for (int part = 0; part < 2; ++part) {  // 0: the node array, 1: the coefficients
+        const volatile uint32_t* flag = &hh->stored[part];
+        const double limit = now() + 2.0e3;
+        while (*flag != d.buildStamp && now() < limit) frCpuRelax();
+        if (*flag != d.buildStamp) {  // (two milliseconds of watching, then the ordinary wait: the launch has finished, its stores are there)
+            const hipError_t e = hipStreamSynchronize(s);
+            if (e != hipSuccess) {
+                std::free(p);
+                return hipFail(e, "block download");
+            }
         }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (part == 0)
+            std::memcpy(p + 16 + 8 * (size_t)nc, ws->pinned + 8 * (size_t)nc, sizeof(hpsdf_node) * (size_t)nn);
+        else
+            std::memcpy(p + 8, ws->pinned, 8 * (size_t)nc);
     }
     const double tcopy = now() - tc;
-    std::memcpy(p, &nc, 8);
-    std::memcpy(p + 8, ws->pinned, 8 * (size_t)nc);
-    std::memcpy(p + 8 + 8 * (size_t)nc, &nn, 8);
-    std::memcpy(p + 16 + 8 * (size_t)nc, ws->pinned + 8 * (size_t)nc, sizeof(hpsdf_node) * (size_t)nn);
-    std::memcpy(p + 16 + 8 * (size_t)nc + sizeof(hpsdf_node) * (size_t)nn, &cfg, sizeof cfg);
     *block = p;
     *size = bytes;
     if (stats) {
