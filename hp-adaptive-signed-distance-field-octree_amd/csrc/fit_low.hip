@@ -14,7 +14,8 @@
 // -- 5 x fewer operations than the direct form at degree 4, 13 x at degree 8, no operand to form, and every one of them a fused
 // multiply-add.  On this part the FP64 vector rate equals the FP64 matrix rate (78.6 TFLOP/s either way), and stage 1's output tile is
 // only p <= 11 rows tall (a 16 x 16 x 4 matrix instruction would run 25-70 % full), so the stages run on the vector units: one workgroup
-// per cell, a thread per (j, k) column in stage 1 (coalesced reads of the sample planes), per (a, b, k) in stage 2, per row in stage 3.
+// per cell, a thread per few (j, k) columns in stage 1 (coalesced reads of the sample planes, four planes' loads in flight), per
+// (a, b, k) in stage 2, per row in stage 3.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -29,25 +30,35 @@ namespace {
 __host__ __device__ constexpr int lowCoef(int p) { return p == 6 ? 83 : (p + 1) * (p + 2) * (p + 3) / 6; }  // Utility.h:63-77 (count[6] == 83)
 
 constexpr int kLowThreads = 256;
-constexpr int kLowCols = 4;  // columns of the sample grid a thread carries at once in stage 1 (each table element read once for all of them)
+constexpr int kLowAhead = 4;  // sample planes whose loads a lane has in flight in stage 1
 
 template <int DEG>
 struct LowShape {
     static constexpr int NQ = 4 * DEG + 1, NQ2 = NQ * NQ;
-    // basis indices of one pass of stage 1: as many as keep G1 within 64 KB of LDS
-    static constexpr int AGmax = (64 * 1024) / (NQ2 * 8);
-    static constexpr int AG = AGmax >= DEG ? DEG : (AGmax < 1 ? 1 : AGmax);
+    // columns of the sample grid a thread carries in stage 1: all of them in ONE pass over the planes (column tid + 256 c: a wave's
+    // loads are 512 contiguous bytes).  Four columns whatever the degree (round 4) left degree 8 a second pass with 17 of 256 lanes at
+    // work and degree 6 39 % of its lanes idle.
+    static constexpr int COLS = (NQ2 + kLowThreads - 1) / kLowThreads;
+    // G2[a][b][k] for a + b <= DEG - 1 only: row a holds DEG - a entries
+    static constexpr int PAIRS = DEG * (DEG + 1) / 2;
+    // basis indices of one pass of stage 1: as many as keep the workgroup within 52 KB of LDS (three workgroups a CU: two, with 80 KB,
+    // left a SIMD two waves in front of its global loads), in passes of equal size (7 + 1 at degree 8 read every sample twice for one row)
+    static constexpr int kBudget = 52 * 1024 - (DEG * NQ + PAIRS * NQ) * 8;
+    static constexpr int AGmax = kBudget / (NQ2 * 8) < 1 ? 1 : kBudget / (NQ2 * 8);
+    static constexpr int PASSES = (DEG + AGmax - 1) / AGmax;
+    static constexpr int AG = (DEG + PASSES - 1) / PASSES;
 };
+__host__ __device__ constexpr int lowPair(int deg, int a, int b) { return a * deg - a * (a - 1) / 2 + b; }
 
 template <int DEG>
-__global__ __launch_bounds__(kLowThreads) void fit_low_kernel(const FitTask* __restrict__ tasks, double* __restrict__ arena,
+__global__ __launch_bounds__(kLowThreads, 3) void fit_low_kernel(const FitTask* __restrict__ tasks, double* __restrict__ arena,
                                                               const DeviceTables* __restrict__ T, const double* __restrict__ samples,
                                                               const uint32_t* __restrict__ range, uint32_t first, uint32_t count) {
-    constexpr int NQ = LowShape<DEG>::NQ, NQ2 = LowShape<DEG>::NQ2, AG = LowShape<DEG>::AG;
+    constexpr int NQ = LowShape<DEG>::NQ, NQ2 = LowShape<DEG>::NQ2, AG = LowShape<DEG>::AG, COLS = LowShape<DEG>::COLS;
     constexpr int NROWS = lowCoef(DEG - 1);
-    __shared__ double sA[DEG * NQ];        // A_a[q] = w_q P_a(x_q), a < DEG (Octree::LpX, :988-1004)
-    __shared__ double sG1[AG * NQ2];       // this pass's G1[a][j][k]
-    __shared__ double sG2[DEG * DEG * NQ];  // G2[a][b][k] (a + b <= DEG - 1 used)
+    __shared__ double sA[DEG * NQ];                      // A_a[q] = w_q P_a(x_q), a < DEG (Octree::LpX, :988-1004)
+    __shared__ double sG1[AG * NQ2];                     // this pass's G1[a][j][k]
+    __shared__ double sG2[LowShape<DEG>::PAIRS * NQ];    // G2[a][b][k], a + b <= DEG - 1
     if (range != nullptr) first = range[0], count = range[1];
     if (blockIdx.x >= count) return;
     const FitTask& tk = tasks[first + blockIdx.x];
@@ -67,30 +78,39 @@ __global__ __launch_bounds__(kLowThreads) void fit_low_kernel(const FitTask* __r
     const double* F = samples + tk.sampleOff;
     for (int a0 = 0; a0 < DEG; a0 += AG) {
         const int na = DEG - a0 < AG ? DEG - a0 : AG;
-        // ---- stage 1: G1[a][col] = sum_i A_a[i] F[i][col], col = j * NQ + k
-        for (int c0 = tid * kLowCols; c0 < NQ2; c0 += kLowThreads * kLowCols) {
-            double acc[AG][kLowCols];
+        // ---- stage 1: G1[a][col] = sum_i A_a[i] F[i][col], col = j * NQ + k; this lane's columns are tid, tid + 256, ...
+        {
+            double acc[AG][COLS];
 #pragma unroll
             for (int a = 0; a < AG; ++a)
 #pragma unroll
-                for (int c = 0; c < kLowCols; ++c) acc[a][c] = 0.0;
-#pragma unroll 2
-            for (int i = 0; i < NQ; ++i) {
-                double f[kLowCols];
+                for (int c = 0; c < COLS; ++c) acc[a][c] = 0.0;
+#pragma unroll 1
+            for (int i0 = 0; i0 < NQ; i0 += kLowAhead) {
+                double f[kLowAhead][COLS];
 #pragma unroll
-                for (int c = 0; c < kLowCols; ++c) f[c] = c0 + c < NQ2 ? F[(size_t)i * NQ2 + c0 + c] : 0.0;
+                for (int u = 0; u < kLowAhead; ++u)
 #pragma unroll
-                for (int a = 0; a < AG; ++a) {
-                    const double t = a < na ? sA[(a0 + a) * NQ + i] : 0.0;
+                    for (int c = 0; c < COLS; ++c) {
+                        const int col = tid + c * kLowThreads;
+                        f[u][c] = (i0 + u < NQ && col < NQ2) ? F[(size_t)(i0 + u) * NQ2 + col] : 0.0;
+                    }
 #pragma unroll
-                    for (int c = 0; c < kLowCols; ++c) acc[a][c] = __builtin_fma(t, f[c], acc[a][c]);
-                }
+                for (int u = 0; u < kLowAhead; ++u)
+#pragma unroll
+                    for (int a = 0; a < AG; ++a) {
+                        const double t = (a < na && i0 + u < NQ) ? sA[(a0 + a) * NQ + i0 + u] : 0.0;
+#pragma unroll
+                        for (int c = 0; c < COLS; ++c) acc[a][c] = __builtin_fma(t, f[u][c], acc[a][c]);
+                    }
             }
 #pragma unroll
             for (int a = 0; a < AG; ++a)
 #pragma unroll
-                for (int c = 0; c < kLowCols; ++c)
-                    if (a < na && c0 + c < NQ2) sG1[a * NQ2 + c0 + c] = acc[a][c];
+                for (int c = 0; c < COLS; ++c) {
+                    const int col = tid + c * kLowThreads;
+                    if (a < na && col < NQ2) sG1[a * NQ2 + col] = acc[a][c];
+                }
         }
         __syncthreads();
         // ---- stage 2: G2[a][b][k] = sum_j A_b[j] G1[a][j][k] for b <= DEG - 1 - a
@@ -103,7 +123,7 @@ __global__ __launch_bounds__(kLowThreads) void fit_low_kernel(const FitTask* __r
             double s = 0.0;
 #pragma unroll 4
             for (int j = 0; j < NQ; ++j) s = __builtin_fma(tb[j], g[j * NQ], s);
-            sG2[(a * DEG + b) * NQ + k] = s;
+            sG2[lowPair(DEG, a, b) * NQ + k] = s;
         }
         __syncthreads();
     }
@@ -115,7 +135,7 @@ __global__ __launch_bounds__(kLowThreads) void fit_low_kernel(const FitTask* __r
     const int depth = tk.depth;
     for (int r = tid; r < NROWS; r += kLowThreads) {
         const int a = T->bidx[r][0], b = T->bidx[r][1], c = T->bidx[r][2];
-        const double* g = sG2 + (a * DEG + b) * NQ;
+        const double* g = sG2 + lowPair(DEG, a, b) * NQ;
         const double* tc = sA + c * NQ;
         double s = 0.0;
 #pragma unroll 4

@@ -2244,7 +2244,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
     // ---- what a round needs beyond its lists
     // (later rounds have at most K jobs: smaller parts to all-gather than round 0's 4096)
     const uint32_t stride0 = kFrJobs * HPSDF_JOB_HEADER_DOUBLES + kFrStatusPad, strideK = Kj * HPSDF_JOB_HEADER_DOUBLES + kFrStatusPad;
-    static const uint32_t inlineNodes = [] {
+    const uint32_t inlineNodes = [] {
         const char* e = std::getenv("HPSDF_FRONTIER_INLINE_NODES");  // tests: 0 sends every round through the grid selection
         return e ? (uint32_t)std::strtoul(e, nullptr, 10) : kFrInlineNodes;
     }();
@@ -2311,7 +2311,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
             if (d.fastFit && deg >= 4 && deg <= 11)
                 HPSDF_HIP(launchFitMfma(fs, deg, d.blocks, taskBound, d.tasks, ws->arena, d.errs, ctx->dTables, fdr, rm, &d.hdr->degBlocks[deg][0]));
             else
-                HPSDF_HIP(launchFit(fs, deg <= 5 ? deg : 0, 1, d.blocks, taskBound, fitLdsTable[deg], d.tasks, ws->arena, d.errs, nullptr,
+                HPSDF_HIP(launchFit(fs, deg <= 8 ? deg : 0, 1, d.blocks, taskBound, fitLdsTable[deg], d.tasks, ws->arena, d.errs, nullptr,
                                     ctx->dTables, fdr, rm, &d.hdr->degBlocks[deg][0]));
         }
         for (int k = 0; k < FrontierWorkspace::kSide; ++k)
@@ -2397,7 +2397,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         // From the second round on the fits are launched without waiting for the header (one rank, no host step in between): what they
         // need to know is on the device -- their lists and counts -- and a build that has stopped leaves them nothing to do.  The
         // largest degree may have risen once more than the host knows.
-        static const bool noBlind = std::getenv("HPSDF_FRONTIER_NO_BLIND") != nullptr;  // (for comparisons)
+        const bool noBlind = std::getenv("HPSDF_FRONTIER_NO_BLIND") != nullptr;  // (tests, comparisons)
         const bool blind = rounds >= 1 && pre && world == 1 && !weighted && !frSyncEveryLaunch() && !noBlind;
         if (blind) {
             if (mesh && tooLargeCur) return fail(HPSDF_ERR_UNSUPPORTED, "round too large for the sampled mesh path");

@@ -1965,6 +1965,7 @@ __global__ __launch_bounds__(256) void field_kernel(FieldDev f, const DeviceTabl
 // any-degree version (rows walked in groups of four, nq = 4p+1).
 
 constexpr int kFitThreads = 256;
+constexpr int kFitPiece = 8;  // terms of a row a degree-6..8 body forms at a time
 #ifndef HPSDF_FIT_MIN_WAVES
 #define HPSDF_FIT_MIN_WAVES 4  // waves per SIMD the register allocation must leave room for: <= 128 VGPRs.  Left alone the
                                // degree-2 kernel takes 240 (two waves per SIMD); held to 128 it spills 448 bytes and is 37 % faster
@@ -2211,7 +2212,7 @@ __device__ __forceinline__ void fitBlockBody(const FitBlock blk, const FitTask* 
 #endif
                 for (int j = 0; j < nq; ++j) {
                     const double a1 = a0 * tj[j] * n1a;
-                    if constexpr (DEG > 0) {
+                    if constexpr (DEG > 0 && DEG <= 5) {
                         double lp[NQF];
 #pragma unroll
                         for (int k = 0; k < NQF; ++k) lp[k] = a1 * tkReg[k] * n2a;
@@ -2223,6 +2224,24 @@ __device__ __forceinline__ void fitBlockBody(const FitBlock blk, const FitTask* 
                             for (int k = 0; k < NQF; ++k) f[k] = Fr[k];
 #pragma unroll
                             for (int k = 0; k < NQF; ++k) acc[r] = acc[r] + lp[k] * f[k];
+                        }
+                    } else if constexpr (DEG > 5) {
+                        // degrees 6..8: the thread's P_i2 row still lives in registers (25 / 29 / 33 doubles), the row of samples is
+                        // taken in pieces of kFitPiece so that factors and samples in flight stay within the 128 registers the four
+                        // waves a SIMD leave a lane (terms in the same order: k ascending)
+                        const double* Fr = F + j * nq;
+#pragma unroll
+                        for (int k0 = 0; k0 < NQF; k0 += kFitPiece) {
+                            double lp[kFitPiece], f[kFitPiece];
+#pragma unroll
+                            for (int k = 0; k < kFitPiece; ++k)
+                                if (k0 + k < NQF) f[k] = Fr[k0 + k];
+#pragma unroll
+                            for (int k = 0; k < kFitPiece; ++k)
+                                if (k0 + k < NQF) lp[k] = a1 * tkReg[k0 + k] * n2a;
+#pragma unroll
+                            for (int k = 0; k < kFitPiece; ++k)
+                                if (k0 + k < NQF) acc[0] = acc[0] + lp[k] * f[k];
                         }
                     } else {
                         acc[0] = fitRowAny(acc[0], a1, tk, n2a, F + j * nq, nq);
@@ -2310,6 +2329,9 @@ __global__ __launch_bounds__(kFitThreads, HPSDF_FIT_MIN_WAVES) void fit_multi_ke
         case 3: fitBlockBody<KIND, CSG, 3, 1, LEFT>(blk, tasks, arena, errs, nullptr, T, field, rm, lds); break;
         case 4: fitBlockBody<KIND, CSG, 4, 1, LEFT>(blk, tasks, arena, errs, nullptr, T, field, rm, lds); break;
         case 5: fitBlockBody<KIND, CSG, 5, 1, LEFT>(blk, tasks, arena, errs, nullptr, T, field, rm, lds); break;
+        case 6: fitBlockBody<KIND, CSG, 6, 1, LEFT>(blk, tasks, arena, errs, nullptr, T, field, rm, lds); break;
+        case 7: fitBlockBody<KIND, CSG, 7, 1, LEFT>(blk, tasks, arena, errs, nullptr, T, field, rm, lds); break;
+        case 8: fitBlockBody<KIND, CSG, 8, 1, LEFT>(blk, tasks, arena, errs, nullptr, T, field, rm, lds); break;
         default: fitBlockBody<KIND, CSG, 0, 1, LEFT>(blk, tasks, arena, errs, nullptr, T, field, rm, lds); break;
     }
 }
@@ -2852,6 +2874,9 @@ static void launchFitT(hipStream_t stream, int degree, int cellsPerThread, const
         HPSDF_FIT_CASE(3)
         HPSDF_FIT_CASE(4)
         HPSDF_FIT_CASE(5)
+        HPSDF_FIT_CASE(6)
+        HPSDF_FIT_CASE(7)
+        HPSDF_FIT_CASE(8)
         default:
             HPSDF_FIT_LAUNCH(0, 1);
     }

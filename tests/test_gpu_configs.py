@@ -508,6 +508,25 @@ def test_device_frontier_equals_host_scheduler(H, ctx, monkeypatch, name, target
         assert sgot[k] == swant[k], k
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"HPSDF_FRONTIER_INLINE_NODES": "0"}, {"HPSDF_FRONTIER_NO_BLIND": "1"},
+                                 {"HPSDF_FRONTIER_INLINE_NODES": "0", "HPSDF_FRONTIER_NO_BLIND": "1"}])
+@pytest.mark.parametrize("target,K", [(1e-7, 256), (1e-8, 4096)])
+def test_device_frontier_paths_agree(H, ctx, monkeypatch, env, target, K):
+    """The round kernel's leader selects the next batch itself on trees of up to 65 536 nodes and leaves larger ones to the grid
+    selection (fr_select / fr_batch / fr_tasks_kernel); fits are launched without waiting for the header from the second round on.
+    Either switch thrown the other way gives the same bytes -- and, on two simulated ranks, so does the grid selection."""
+    f = H.Field.union3()
+    want, swant = H.create_block(ctx, H.make_config(target), f, K)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    got, sgot = H.create_block(ctx, H.make_config(target), f, K)
+    assert got == want and sgot == swant
+    if "HPSDF_FRONTIER_INLINE_NODES" in env and K == 256:
+        blocks = _create_on_simulated_ranks(H, 2, H.make_config(target), lambda c: H.Field.union3(), K)
+        assert all(b[0] == want for b in blocks)
+
+
 class _DevBytes:
     def __init__(self, ptr, n):
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 2}
