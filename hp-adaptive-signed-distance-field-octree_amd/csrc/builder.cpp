@@ -257,6 +257,20 @@ int builderJobs(const hpsdf_build* b, hpsdf_job* out) {
     return HPSDF_OK;
 }
 
+// The round's sample buffer (mesh fields: F at every sample; split fits: the values the exact kernel hands to the lower rows' kernel),
+// sized to the need -- gigabytes at high degrees -- not to the next power of two.
+static hipError_t ensureSampleBuffer(hpsdf_ctx* ctx, Workspace& ws, uint64_t need) {
+    if (need <= ws.meshSamplesCap) return hipSuccess;
+    const uint64_t nc = (need + (1ull << 20) - 1) & ~((1ull << 20) - 1);
+    hipError_t e = hipStreamSynchronize(ctx->stream);  // an earlier round's kernels may still read the old buffer
+    if (e != hipSuccess) return e;
+    if (ws.meshSamples) (void)hipFree(ws.meshSamples);
+    ws.meshSamples = nullptr, ws.meshSamplesCap = 0;
+    e = hipMalloc((void**)&ws.meshSamples, nc * sizeof(double));
+    if (e == hipSuccess) ws.meshSamplesCap = nc;
+    return e;
+}
+
 // -----------------------------------------------------------------------------------------------
 // GPU leg of a round: every job of this rank's slice becomes 1 (coarse) or up to 9 cell fits
 // (EstimateHImprovement: 8 children from scratch, Octree.cpp:814-822; EstimatePImprovement: the
@@ -330,8 +344,17 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
             any |= classCount[c] && !((c / kDepths) & 1) && fitSplitSupports(deg, ctx->splitMinDegree);
         }
         splitOn = any && need <= (1ull << 31);
+        // the hand-over buffer of the split fits, BEFORE the workgroup table says "split": if there is no room for it the round is fitted
+        // exactly (the exact fit needs no such buffer) instead of failing the build
+        if (splitOn && !sampled && !meshSampled && ensureSampleBuffer(ctx, ws, need) != hipSuccess) {
+            (void)hipGetLastError();
+            splitOn = false;
+        }
     }
     auto splitClass = [&](int deg, bool incr) { return splitOn && !incr && fitSplitSupports(deg, ctx->splitMinDegree); };
+    b->stats.fit_mode = (uint64_t)ctx->fitMode;
+    for (int c = 0; c < kClasses; ++c)
+        if (splitClass(c / kDepths / 2, (c / kDepths) & 1)) b->stats.split_fits += classCount[c];
 
     // ---- workgroup table
     uint32_t nBlocks = 0;
@@ -512,15 +535,7 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
         HPSDF_HIP(hipMemcpyAsync(ws.blocks.dev, ws.blocks.host, nBlocks * sizeof(FitBlock), hipMemcpyHostToDevice, ctx->stream));
     }
     if ((meshSampled || (splitOn && !sampled)) && nTasks) {  // (split fits of an analytic field leave their values here for the matrix-core kernel)
-        if (sampleNeed > ws.meshSamplesCap) {
-            uint64_t nc = std::max<uint64_t>(ws.meshSamplesCap * 2, 1ull << 22);
-            while (nc < sampleNeed) nc *= 2;
-            HPSDF_HIP(hipStreamSynchronize(ctx->stream));  // an earlier round's kernels may still read the old buffer
-            if (ws.meshSamples) HPSDF_HIP(hipFree(ws.meshSamples));
-            ws.meshSamples = nullptr, ws.meshSamplesCap = 0;
-            HPSDF_HIP(hipMalloc((void**)&ws.meshSamples, nc * sizeof(double)));
-            ws.meshSamplesCap = nc;
-        }
+        HPSDF_HIP(ensureSampleBuffer(ctx, ws, sampleNeed));
         // the tasks of one degree are contiguous (classes are ordered degree-major)
         for (int deg = 0; deg <= kMaxDegree && meshSampled; ++deg) {
             const uint32_t first = classFirst[classOf(deg, false, 0)];

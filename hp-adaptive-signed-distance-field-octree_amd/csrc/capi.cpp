@@ -340,7 +340,7 @@ int hpsdf_ctx_set_split_min_degree(hpsdf_ctx* c, int degree) {
 }
 void hpsdf_set_reduction_order(int left_assoc) { setReductionLeftAssoc(left_assoc); }
 int hpsdf_get_reduction_order(void) { return reductionLeftAssoc(); }
-int hpsdf_ctx_set_fast_fit(hpsdf_ctx* c, int on) { return hpsdf_ctx_set_fit_mode(c, on ? HPSDF_FIT_FAST : HPSDF_FIT_SPLIT); }
+int hpsdf_ctx_set_fast_fit(hpsdf_ctx* c, int on) { return hpsdf_ctx_set_fit_mode(c, on ? HPSDF_FIT_FAST : HPSDF_FIT_EXACT); }
 
 int hpsdf_ctx_synchronize(hpsdf_ctx* c) {
     if (!c) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null ctx");

@@ -79,6 +79,8 @@ struct FrHdr {
                                 // range fit_mfma_low_kernel walks for the rows below the top degree
     uint64_t arenaUsed, sampleUsed, nCoeffs, pad1;
     uint64_t jobs, pRefines, hRefines, dropped, fits, samples;
+    uint64_t splitFits;   // from-scratch fits whose lower rows came from the split's second kernel (hpsdf_build_stats::split_fits)
+    uint32_t splitRound, padR;  // FrDev::splitFit if the round being prepared splits its from-scratch fits, else 0 (decided by the batch)
     double total, target;
     // staging between the decide and update kernels of a round
     uint32_t rP, rH, rD, rMaxDeg;
@@ -154,7 +156,9 @@ struct FrDev {
     double* pack;          // [world][packStride] all-gathered pack buffers (this rank writes its own)
     uint64_t packStride;
     int32_t fastFit;       // degrees >= 4 fitted by fit_mfma.hip: 16 cells per workgroup
-    int32_t splitFit;      // 0, or the lowest degree (.. 11) whose from-scratch fits are split: top-degree rows exact, the rest by fit_mfma_low_kernel
+    int32_t splitFit;      // 0, or the lowest degree (.. 11) whose from-scratch fits are split: top-degree rows exact, the rest by fit_low_kernel.
+                           // Whether a round does split is the batch's decision (FrHdr::splitRound), by the host scheduler's rule
+    uint64_t sampleCap;    // doubles the sample buffer holds (the split's hand-over needs the round's samples to fit)
     // nearness weighting (Octree.cpp:1071-1092, 1209-1247): a fit keeps ONE full coefficient array (an incremental fit
     // carries the old rows over, :847), fit_weight_kernel leaves |mean FApprox| of every fit in `means`, the host turns
     // the means into weights with its libm (pow / exp: what the oracle calls) and fr_weigh_kernel scales the errors
@@ -365,7 +369,8 @@ struct FrLds {
     uint32_t wave[16];
     uint32_t slice[9];
     int t;
-    uint32_t above, c, next, flag, stuck;
+    uint32_t above, c, next, flag, stuck, anySplit;
+    unsigned long long need;
     // per wave: 64 records of 7 words (a FitTask, a serialised node: 56 bytes) on their way to memory.  A lane writes its record's
     // words, the wave reads the 448 words back in order and stores THOSE: runs of whole records instead of 8 bytes every 56
     // (which cost the lists of a 1024-job round 60 k cycles, most of them waiting for the stores to drain)
@@ -650,12 +655,26 @@ __device__ void frBatchBody(const FrDev& d, FrLds& L, uint32_t nQ, uint32_t abov
     uint32_t myCount = 0, myBlocks = 0;
     uint64_t myRows = 0, mySamples = 0;
     int g = 1, pl = 1;
+    // Does this round split its from-scratch fits (HPSDF_FIT_SPLIT)?  The host scheduler's rule (builderCompute): some class of the
+    // round can be split, and the round's samples -- all of them: the buffer is addressed by FitTask::sampleOff -- number at most 2^31
+    // and fit the buffer the host could get.
+    if (tid == 0) L.need = 0, L.anySplit = 0;
+    __syncthreads();
+    if (tid < (uint32_t)kFrClasses && sCount[tid]) {
+        const int deg = (int)tid / kFrDepths / 2;
+        const bool incr = ((int)tid / kFrDepths) & 1;
+        const uint64_t nq = 4 * (uint64_t)deg + 1;
+        atomicAdd(&L.need, (unsigned long long)(nq * nq * nq * sCount[tid]));
+        if (frSplit(d.splitFit, deg, incr)) L.anySplit = 1;
+    }
+    __syncthreads();
+    const int splitFit = (L.anySplit && L.need <= (1ull << 31) && L.need <= d.sampleCap) ? d.splitFit : 0;
     if (tid < (uint32_t)kFrClasses) {
         myCount = sCount[tid];
         if (myCount) {
             const int deg = (int)tid / kFrDepths / 2;
             const bool incr = ((int)tid / kFrDepths) & 1;
-            frShape(deg, incr, myCount, &g, &pl, d.fastFit != 0, d.weighted != 0, d.splitFit);
+            frShape(deg, incr, myCount, &g, &pl, d.fastFit != 0, d.weighted != 0, splitFit);
             myBlocks = (myCount + (uint32_t)g - 1u) / (uint32_t)g;
             const uint64_t nq = 4 * (uint64_t)deg + 1;
             // (a weighted fit owns a full array: the incremental one too)
@@ -704,11 +723,14 @@ __device__ void frBatchBody(const FrDev& d, FrLds& L, uint32_t nQ, uint32_t abov
         h->degBlocks[tid][0] = b0, h->degBlocks[tid][1] = sBlk[hi] - b0;
         // the from-scratch classes of a degree come first (frClass): their tasks are one contiguous run
         h->lowTasks[tid][0] = t0;
-        h->lowTasks[tid][1] = frSplit(d.splitFit, (int)tid, false) ? sCnt[lo + kFrDepths - 1] - t0 : 0u;
+        const uint32_t low = frSplit(splitFit, (int)tid, false) ? sCnt[lo + kFrDepths - 1] - t0 : 0u;
+        h->lowTasks[tid][1] = low;
+        if (low) atomicAdd(reinterpret_cast<unsigned long long*>(&h->splitFits), (unsigned long long)low);
     }
     __syncthreads();  // (every thread has read the header's arenaUsed)
     if (tid == 0) {
         h->nJobs = nJobs, h->nTasks = nTasks, h->nBlocks = nBlocks;
+        h->splitRound = (uint32_t)splitFit;
         h->sampleUsed = smpAll;
         h->fits += nTasks, h->samples += smpAll;
         R->arenaBase = arenaBase;
@@ -829,7 +851,7 @@ __global__ __launch_bounds__(1024) void fr_emit_kernel(FrDev d) {
         fb.nTasks = (uint16_t)(left < gg ? left : gg);
         fb.degree = (uint8_t)deg;
         fb.planesPerChunk = (uint8_t)(E.tabShape[c] >> 8);
-        const bool split = frSplit(d.splitFit, deg, incr);
+        const bool split = frSplit((int)h->splitRound, deg, incr);
         fb.rowStart = (uint16_t)((incr || split) ? frCoef(deg - 1) : 0);
         fb.rowEnd = (uint16_t)frCoef(deg);
         fb.depth = (uint8_t)(c % kFrDepths);
@@ -928,7 +950,7 @@ __global__ __launch_bounds__(256) void fr_tasks_kernel(FrDev d) {
         fb.nTasks = (uint16_t)(left < g ? left : g);
         fb.degree = (uint8_t)deg;
         fb.planesPerChunk = R->cPlanes[c];
-        const bool split = frSplit(d.splitFit, deg, incr);
+        const bool split = frSplit((int)h->splitRound, deg, incr);
         fb.rowStart = (uint16_t)((incr || split) ? frCoef(deg - 1) : 0);
         fb.rowEnd = (uint16_t)frCoef(deg);
         fb.depth = (uint8_t)(c % kFrDepths);
@@ -1337,7 +1359,7 @@ __device__ void frLeadRound(const FrDev& d, FrLds& L, int pre) {
         h->t1 = T, h->above = above;
     }
     FR_STAMP(11);
-    const uint64_t fits0 = h->fits, samples0 = h->samples, arena0 = h->arenaUsed;  // (what a prepared round adds to)
+    const uint64_t fits0 = h->fits, samples0 = h->samples, arena0 = h->arenaUsed, split0 = h->splitFits;  // (what a prepared round adds to)
     __syncthreads();
     if (pre && !done) {
         // ---- the next round's selection, level 0: everything in the exponent bins above T is taken, bin T is the candidate list
@@ -1384,7 +1406,7 @@ __device__ void frLeadRound(const FrDev& d, FrLds& L, int pre) {
             __threadfence();
             total = *(volatile double*)&h->rTotal;
             done = total < target || overflow != 0;
-            if (done && tid == 0) h->fits = fits0, h->samples = samples0, h->arenaUsed = arena0, h->sampleUsed = 0;
+            if (done && tid == 0) h->fits = fits0, h->samples = samples0, h->arenaUsed = arena0, h->sampleUsed = 0, h->splitFits = split0;
         }
     }
     if (tid == 0) {
@@ -2261,16 +2283,20 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         splitOpen = splitMode && degBound >= ctx->splitMinDegree;
         samplesTooLarge = false;
         if (mesh || splitOpen) {
-            const uint64_t need = (uint64_t)Kj * samplesPerJob(degBound);
+            // (the round's own count decides on the device whether it splits -- the host scheduler's rule, FrHdr::splitRound; the host
+            // provides for what the round can need, up to the 2^31 samples a split round may have)
+            uint64_t need = (uint64_t)Kj * samplesPerJob(degBound);
             if (need > (1ull << 31)) {
-                samplesTooLarge = true;  // (a mesh build fails when that round comes; a split round is fitted exactly instead)
-                splitOpen = false;
-            } else if ((e = ws->ensureSamples(need, s)) != hipSuccess) {
+                if (mesh) samplesTooLarge = true;  // (a mesh build fails when that round comes)
+                need = 1ull << 31;
+            }
+            if (!samplesTooLarge && (e = ws->ensureSamples(need, s)) != hipSuccess) {
                 if (mesh) return hipFail(e, "frontier sample buffer");
                 (void)hipGetLastError();  // no room for the hand-over buffer: the exact fit needs none
                 splitOpen = false;
             }
         }
+        d.sampleCap = ws->sampleCap;
         return HPSDF_OK;
     };
     // a round's fits, from the lists the device wrote (kernels.hip; grids are upper bounds)
@@ -2461,6 +2487,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
                 stats->rounds = hh->round, stats->jobs = hh->jobs, stats->p_refines = hh->pRefines, stats->h_refines = hh->hRefines;
                 stats->dropped = hh->dropped, stats->fits = hh->fits, stats->samples = hh->samples;
                 stats->n_nodes = hh->nNodes, stats->n_leaves = hh->nLeaves, stats->n_coeffs = hh->nCoeffs, stats->total_error = hh->total;
+                stats->fit_mode = (uint64_t)ctx->fitMode, stats->split_fits = hh->splitFits;
             }
             if (trace) std::fprintf(stderr, "[frontierCreate] us: total %.0f (waiting for the device %.0f, stopped after round 0)\n", now() - t0, tSync);
             return HPSDF_OK;
@@ -2554,6 +2581,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         stats->rounds = hh->round, stats->jobs = hh->jobs, stats->p_refines = hh->pRefines, stats->h_refines = hh->hRefines;
         stats->dropped = hh->dropped, stats->fits = hh->fits, stats->samples = hh->samples;
         stats->n_nodes = nn, stats->n_leaves = hh->nLeaves, stats->n_coeffs = nc, stats->total_error = hh->total;
+        stats->fit_mode = (uint64_t)ctx->fitMode, stats->split_fits = hh->splitFits;
     }
     hipLaunchKernelGGL(fr_init_kernel, dim3((T.nNodes + 255) / 256), dim3(256), 0, s, initDev(), T0);  // for the next build
     ws->clean = hipGetLastError() == hipSuccess, ws->cleanRank = rank, ws->cleanWorld = world;

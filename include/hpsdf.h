@@ -122,8 +122,10 @@ HPSDF_API int hpsdf_ctx_synchronize(hpsdf_ctx* ctx);
  *   HPSDF_FIT_EXACT: every row by the bit-exact kernel: the canonical bytes (what the CPU oracle produces).
  *   HPSDF_FIT_FAST: every row of every fit of degree >= 4 on the matrix cores.  Errors then agree to ~1e-15 relative only, and
  *     refinement decisions that are exact ties in the reference's arithmetic may fall the other way.
- * hpsdf_ctx_set_fast_fit(ctx, on) = set_fit_mode(on ? HPSDF_FIT_FAST : HPSDF_FIT_SPLIT).  The environment variable
- * HPSDF_FIT_MODE=exact|split|fast sets the mode a new context starts with. */
+ * hpsdf_ctx_set_fast_fit(ctx, on) = set_fit_mode(on ? HPSDF_FIT_FAST : HPSDF_FIT_EXACT): switching the fast fit off gives the canonical
+ * bytes, as it did before the split mode existed (round 5; round 4 sent it to HPSDF_FIT_SPLIT).  The environment variable
+ * HPSDF_FIT_MODE=exact|split|fast sets the mode a new context starts with.  hpsdf_build_stats::fit_mode / split_fits say which bytes a
+ * build returned: split_fits == 0 means the block is the canonical one whatever the mode. */
 enum { HPSDF_FIT_EXACT = 0, HPSDF_FIT_SPLIT = 1, HPSDF_FIT_FAST = 2 };
 HPSDF_API int hpsdf_ctx_set_fit_mode(hpsdf_ctx* ctx, int mode);
 HPSDF_API int hpsdf_ctx_get_fit_mode(hpsdf_ctx* ctx, int* mode);
@@ -289,6 +291,9 @@ typedef struct hpsdf_build_stats {
     uint64_t rounds, jobs, p_refines, h_refines, dropped, fits, samples;
     uint64_t n_nodes, n_leaves, n_coeffs;
     double total_error;
+    uint64_t fit_mode;   /* HPSDF_FIT_* the build ran in */
+    uint64_t split_fits; /* from-scratch fits whose rows below the top degree came from the sum-factorised / matrix-core kernel (HPSDF_FIT_SPLIT,
+                            degree >= split_min_degree); 0: every coefficient is the bit-exact kernel's */
 } hpsdf_build_stats;
 
 HPSDF_API int hpsdf_build_begin(const hpsdf_config* cfg, const hpsdf_build_opts* opts, hpsdf_build** out);

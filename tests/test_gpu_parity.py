@@ -506,7 +506,8 @@ def test_reduction_order_switch_matches_the_oracle(H, O, ctx, golden, left_assoc
         monkeypatch.setenv("HPSDF_HOST_FRONTIER", "0")
         sblk, sst = H.create_block(ctx, hcfg, product_field(H, g["field"]), g["K"])
         a, b = O.parse_block(sblk), O.parse_block(ob)
-        assert np.array_equal(a["degree"], b["degree"]) and np.array_equal(a["childIdx"], b["childIdx"]) and sst == st, case
+        assert np.array_equal(a["degree"], b["degree"]) and np.array_equal(a["childIdx"], b["childIdx"]), case
+        assert all(sst[k] == st[k] for k in st if k not in ("fit_mode", "split_fits")), case
         assert np.abs(a["coeffs"] - b["coeffs"]).max() <= 1e-12, case
         # gradients: kernels (many points), the host-answered scalar calls (<= 32 points) -- and the values, which do not depend on it
         tree = H.DeviceTree(ctx, ob)
