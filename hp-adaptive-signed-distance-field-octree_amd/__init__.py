@@ -108,6 +108,8 @@ _SIGNATURES = {
     "hpsdf_ctx_set_fit_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "hpsdf_ctx_get_fit_mode": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "hpsdf_ctx_set_split_min_degree": (C.c_int, [C.c_void_p, C.c_int]),
+    "hpsdf_set_mesh_face_rule": (None, [C.c_int]),
+    "hpsdf_get_mesh_face_rule": (C.c_int, []),
     "hpsdf_set_reduction_order": (None, [C.c_int]),
     "hpsdf_get_reduction_order": (C.c_int, []),
     "hpsdf_ctx_stream": (C.c_void_p, [C.c_void_p]),
@@ -280,6 +282,17 @@ def set_reduction_order(left_assoc):
 
 def reduction_order():
     return int(lib().hpsdf_get_reduction_order())
+
+
+def set_mesh_face_rule(reference):
+    """Mesh fields: True = the reference's closest-point routine to the letter (its face-case point whatever the weights,
+    Utility.cpp:5-97); False (default) = a face-case point that has left its triangle is replaced by the boundary's closest point, so
+    that every evaluation path gives one answer (include/hpsdf.h).  Process-wide; set it between calls, not during."""
+    lib().hpsdf_set_mesh_face_rule(1 if reference else 0)
+
+
+def mesh_face_rule():
+    return int(lib().hpsdf_get_mesh_face_rule())
 
 
 def make_config(target=1e-10, root_min=(-0.5, -0.5, -0.5), root_max=(0.5, 0.5, 0.5), threads=1, continuity=False):

@@ -294,6 +294,7 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
     if (meshSampled) {
         const char* e = std::getenv("HPSDF_MESH_FUSED");
         if (e && e[0] == '1') meshSampled = false;
+        if (meshFaceRuleReference()) meshSampled = false;  // (the sampler's shared traversal assumes the default face rule)
     }
 
     // ---- pass 1: count the fits of every shape.  A class = (degree, from-scratch | incremental, depth):

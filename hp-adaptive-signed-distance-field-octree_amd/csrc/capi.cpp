@@ -2,6 +2,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <atomic>
+#include <limits>
 #include <cfloat>
 #include <chrono>
 #include <cmath>
@@ -59,6 +60,17 @@ static std::atomic<int> gLeftAssoc{envLeftAssoc()};
 int reductionLeftAssoc() { return gLeftAssoc.load(std::memory_order_relaxed); }
 void setReductionLeftAssoc(int left) { gLeftAssoc.store(left != 0, std::memory_order_relaxed); }
 
+// hpsdf_set_mesh_face_rule(): 0 = a face-case point that has left its triangle is replaced by the boundary's closest point (default: every
+// evaluation path then gives one answer), 1 = the reference's point whatever its weights (Source/Meshing/Utility.cpp:5-97)
+static int envMeshFaceRule() {
+    const char* e = std::getenv("HPSDF_MESH_FACE_RULE");  // "reference" / "1"
+    return e && (e[0] == 'r' || e[0] == 'R' || e[0] == '1');
+}
+static std::atomic<int> gMeshFaceReference{envMeshFaceRule()};
+int meshFaceRuleReference() { return gMeshFaceReference.load(std::memory_order_relaxed); }
+void setMeshFaceRuleReference(int on) { gMeshFaceReference.store(on != 0, std::memory_order_relaxed); }
+float meshFaceTolOfSlack() { return meshFaceRuleReference() ? std::numeric_limits<float>::infinity() : 0.25f; }
+
 int makeFieldDev(const hpsdf_field* f, const double* dSamples, FieldDev* out) {
     std::memset(out, 0, sizeof(*out));
     out->csgOp = -1;
@@ -96,6 +108,7 @@ int makeFieldDev(const hpsdf_field* f, const double* dSamples, FieldDev* out) {
             out->mesh.nTris = f->nTris;
             out->mesh.nNodes = f->nBvhNodes;
             out->mesh.stats = f->dStats;
+            out->mesh.faceTolOfSlack = meshFaceTolOfSlack();
             break;
         default:
             return fail(HPSDF_ERR_INVALID_ARGUMENT, "unknown field kind");
@@ -338,6 +351,8 @@ int hpsdf_ctx_set_split_min_degree(hpsdf_ctx* c, int degree) {
     c->splitMinDegree = degree;
     return HPSDF_OK;
 }
+void hpsdf_set_mesh_face_rule(int reference) { setMeshFaceRuleReference(reference); }
+int hpsdf_get_mesh_face_rule(void) { return meshFaceRuleReference(); }
 void hpsdf_set_reduction_order(int left_assoc) { setReductionLeftAssoc(left_assoc); }
 int hpsdf_get_reduction_order(void) { return reductionLeftAssoc(); }
 int hpsdf_ctx_set_fast_fit(hpsdf_ctx* c, int on) { return hpsdf_ctx_set_fit_mode(c, on ? HPSDF_FIT_FAST : HPSDF_FIT_EXACT); }
@@ -538,7 +553,9 @@ int hpsdf_field_eval_device(hpsdf_ctx* ctx, const hpsdf_field* f, const double* 
     // A plain mesh field goes through the sampler's traversal, 64 consecutive points per walk (meshSignedDistanceWaveQ:
     // dense nodes walked by the wave, sparse subtrees pooled, tests compacted) -- the same bits as the per-point traversal
     // and 4 (random points) to 8 (points sorted by cell) times its speed on a 2 M-triangle mesh.
-    if (fd.kind == kFieldMesh && fd.csgOp < 0)
+    // (Not under hpsdf_set_mesh_face_rule(1): the shared traversal's bounds -- slabs, in-plane rectangles -- bound the DISTANCE to a
+    // triangle, and the reference's face-case point can lie below it; the per-point traversal prunes by boxes alone, as the reference's does.)
+    if (fd.kind == kFieldMesh && fd.csgOp < 0 && !meshFaceRuleReference())
         HPSDF_HIP(launchMeshEvalWave(ctx->stream, fd, dXyz, n, dOut));
     else
         HPSDF_HIP(launchFieldEval(ctx->stream, fd, ctx->dTables, dXyz, n, dOut));
@@ -617,7 +634,9 @@ int hpsdf_field_eval_host(hpsdf_ctx* ctx, const hpsdf_field* f, const double* xy
         std::shared_ptr<hpsdf_field::HostMirror> m;
         const int rc = meshHostMirror(f, &m);
         if (rc) return rc;
-        meshEvalHostPoints(m->dev, xyz, n, out);
+        MeshDev hm = m->dev;
+        hm.faceTolOfSlack = meshFaceTolOfSlack();  // (the rule at the time of the call, as on the device)
+        meshEvalHostPoints(hm, xyz, n, out);
         return HPSDF_OK;
     }
     return hostRoundTrip(
@@ -652,6 +671,8 @@ static int meshWaveDevice(hpsdf_ctx* ctx, const hpsdf_field* f, const double* dX
     FieldDev fd;
     int rc = makeFieldDev(f, nullptr, &fd);
     if (rc) return rc;
+    if (meshFaceRuleReference())
+        return fail(HPSDF_ERR_UNSUPPORTED, "the shared traversal's bounds assume the default face rule (hpsdf_set_mesh_face_rule(0)): use hpsdf_field_eval_* or the scan");
     HPSDF_HIP(launchMeshEvalWave(ctx->stream, fd, dXyz, n, dOut));
     return HPSDF_OK;
 }

@@ -96,6 +96,8 @@ struct MeshDev {
     uint32_t nTris, nNodes;
     uint32_t leafLog2;         // every leaf holds at most 1 << leafLog2 triangles (how the sampler cuts its lower-bound batches)
     uint32_t poolCap;          // (lane, node) pairs the sampler's pool may hold, <= kMeshPoolCap (tests lower it to reach the overflow path)
+    float faceTolOfSlack;      // closestSimplex's face-case tolerance as a fraction of the traversal's slack: 0.25, or +inf under
+                               // hpsdf_set_mesh_face_rule(1) -- the reference's point whatever its weights (Utility.cpp:5-97)
     // traversal statistics (diagnostic builds, -DHPSDF_MESH_STATS_BUILD, and the field created under HPSDF_MESH_STATS=1):
     // [0] wave-wide queries, [1] nodes visited by them, [2] triangle tests issued (wave level), [3] lanes that ran one
     unsigned long long* stats;

@@ -2017,6 +2017,7 @@ bool frontierEligible(const hpsdf_config* cfg, const hpsdf_field* field, uint64_
     if (in->kind == kHostMesh) {
         const char* e = std::getenv("HPSDF_MESH_FUSED");
         if (e && e[0] == '1') return false;
+        if (meshFaceRuleReference()) return false;  // (the sampler's shared traversal assumes the default face rule: builder.cpp fits with the per-point one)
     }
     const uint64_t k = K ? K : HPSDF_DEFAULT_JOBS_PER_ROUND;
     return k <= kFrJobs;

@@ -279,7 +279,7 @@ HPSDF_HD float meshSignedDistance(const MeshDev& m, V3 pt, uint32_t& hint) {
     auto visitTri = [&](uint32_t t) {
         V3 q;
         const float4 tp[3] = {m.triPos[3 * (size_t)t], m.triPos[3 * (size_t)t + 1], m.triPos[3 * (size_t)t + 2]};
-        const int code = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, kMeshTolOfSlack * slack, best, q);
+        const int code = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, m.faceTolOfSlack * slack, best, q);
         const float d = sqnorm(pt - q);
         if (d < best || (d == best && t < bestTri)) {
             best = d;
@@ -367,7 +367,7 @@ __device__ float meshSignedDistanceWave(const MeshDev& m, V3 pt, bool activeIn, 
     auto visitTri = [&](uint32_t t) {
         V3 q;
         const float4 tp[3] = {m.triPos[3 * (size_t)t], m.triPos[3 * (size_t)t + 1], m.triPos[3 * (size_t)t + 2]};
-        const int code = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, kMeshTolOfSlack * slack, best, q);
+        const int code = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, m.faceTolOfSlack * slack, best, q);
         const float d = sqnorm(pt - q);
         if (d < best || (d == best && t < bestTri)) {
             best = d;
@@ -569,7 +569,7 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool activeIn,
         if (on) {
             V3 q;
             const float4 tp[3] = {m.triPos[3 * (size_t)t], m.triPos[3 * (size_t)t + 1], m.triPos[3 * (size_t)t + 2]};
-            closestSimplex(p, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, kMeshTolOfSlack * slack, ownerBest(src), q);  // (a stale best only substitutes more often than needed)
+            closestSimplex(p, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, m.faceTolOfSlack * slack, ownerBest(src), q);  // (a stale best only substitutes more often than needed)
             const float d = sqnorm(p - q);
             atomicMin(&L.best[src], ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)t);
         }
@@ -658,7 +658,7 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool activeIn,
         auto tryTriangle = [&](uint32_t t, uint32_t slot) {
             V3 q;
             const float4 tp[3] = {m.triPos[3 * (size_t)t], m.triPos[3 * (size_t)t + 1], m.triPos[3 * (size_t)t + 2]};
-            const int code = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, kMeshTolOfSlack * slack, best, q);
+            const int code = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, m.faceTolOfSlack * slack, best, q);
             const float d = sqnorm(pt - q);
             const bool better = d < best || (d == best && t < bestTri);
             if (better) best = d, bestTri = t, bestSlot = slot, bestCode = code, rj = rejectBound(d, slack);
@@ -962,7 +962,7 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool activeIn,
         const uint32_t bestTri = (uint32_t)(L.best[lane] & 0xFFFFFFFFull);
         V3 bestQ;
         const float4 tp[3] = {m.triPos[3 * (size_t)bestTri], m.triPos[3 * (size_t)bestTri + 1], m.triPos[3 * (size_t)bestTri + 2]};
-        const int bestCode = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, kMeshTolOfSlack * slack, __builtin_inff(), bestQ);
+        const int bestCode = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, m.faceTolOfSlack * slack, __builtin_inff(), bestQ);
         const V3 nrm = pseudoNormal(m, bestTri, bestCode);
         const V3 d = pt - bestQ;
         const float sign = dot(nrm, d) > 0.0f ? 1.0f : -1.0f;
@@ -2571,7 +2571,7 @@ __global__ __launch_bounds__(256) void mesh_naive_kernel(MeshDev m, const double
     for (uint32_t t = first + (uint32_t)lane; t < last; t += 64u) {
         V3 q;
         const float4 tp[3] = {m.triPos[3 * (size_t)t], m.triPos[3 * (size_t)t + 1], m.triPos[3 * (size_t)t + 2]};
-        closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, kMeshTolOfSlack * slack, best, q);
+        closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, m.faceTolOfSlack * slack, best, q);
         const float d = sqnorm(pt - q);
         if (d < best) best = d, bestTri = t;
     }
@@ -2600,7 +2600,7 @@ __global__ __launch_bounds__(256) void mesh_naive_finish_kernel(MeshDev m, const
     const float slack = meshSlack(m.bvh[0]);
     V3 q;
     const float4 tp[3] = {m.triPos[3 * (size_t)t], m.triPos[3 * (size_t)t + 1], m.triPos[3 * (size_t)t + 2]};
-    const int code = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, kMeshTolOfSlack * slack, __builtin_inff(), q);
+    const int code = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, m.faceTolOfSlack * slack, __builtin_inff(), q);
     const V3 nrm = pseudoNormal(m, t, code);
     const V3 d = pt - q;
     const float sign = dot(nrm, d) > 0.0f ? 1.0f : -1.0f;

@@ -180,6 +180,8 @@ bool hostQueryRay(const hpsdf_tree& t, const double* origin, const double* dir, 
 // innermost non-CSG field and the FieldDev the kernels take
 const hpsdf_field* innermost(const hpsdf_field* f);
 int makeFieldDev(const hpsdf_field* f, const double* dSamples, FieldDev* out);
+int meshFaceRuleReference();  // hpsdf_set_mesh_face_rule(): 1 = the reference's face-case point whatever its weights
+float meshFaceTolOfSlack();   // MeshDev::faceTolOfSlack for launches prepared now
 int reductionLeftAssoc();  // hpsdf_set_reduction_order()
 void setReductionLeftAssoc(int left);
 

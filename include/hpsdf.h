@@ -196,6 +196,16 @@ HPSDF_API int hpsdf_field_eval_host(hpsdf_ctx* ctx, const hpsdf_field* f, const 
  * below (naive scan, per-lane traversal, shared traversal, hpsdf_field_eval_*) agree BIT FOR BIT on every mesh; against the
  * reference's arithmetic they differ exactly at the points where its own value is such an artefact (6 points in 8 000 random
  * meshes x 5 301 points, all on meshes squashed 100 : 1 or more; tests/test_gpu_configs.py::test_needle_meshes_one_answer_on_every_path). */
+/* ... and the way back to the reference's values: hpsdf_set_mesh_face_rule(1) (process-wide, for launches prepared afterwards; the
+ * environment variable HPSDF_MESH_FACE_RULE=reference sets it from the start) makes the closest-point routine return Utility.cpp:5-97's
+ * face-case point unconditionally.  The O(n) scan (hpsdf_field_eval_naive_host) then equals the reference's Mesh::SignedDistanceAtPt(pt),
+ * Mesh.cpp:134-159, operation by operation on every mesh, needles included; hpsdf_field_eval_* and mesh builds use the per-point
+ * traversal, which prunes by boxes only, as the reference's BVH does -- and, like it, may report such an artefact or not depending
+ * on what it pruned.  The shared traversal (hpsdf_field_eval_wave_host, and the sampler of the device-side frontier) bounds distances
+ * to TRIANGLES, which an artefact can undercut: it returns HPSDF_ERR_UNSUPPORTED under this rule, and Create with a mesh field takes
+ * the host scheduler with the per-point traversal inside the fit (what HPSDF_MESH_FUSED=1 selects). */
+HPSDF_API void hpsdf_set_mesh_face_rule(int reference);
+HPSDF_API int hpsdf_get_mesh_face_rule(void);
 /* (Mesh fields: a point with a coordinate that is not a finite number has no closest triangle -- the reference's search ends
  * with bestTri = -1 there and reads out of bounds, Mesh.cpp:139,157 -- and evaluates to a NaN on every entry point below.) */
 /* Mesh::SignedDistanceAtPt(pt) without a BVH (Source/Meshing/Mesh.cpp:42-51 over the O(n) scan :134-159), mesh fields

@@ -35,6 +35,7 @@ hipError_t launchFitMfma(hipStream_t, int, const FitBlock*, uint32_t, const FitT
 bool fitSplitSupports(int, int) { return false; }
 static int gLeft = 0;  // capi.cpp's hpsdf_set_reduction_order(); here from HPSDF_REDUCTION_ORDER (main)
 int reductionLeftAssoc() { return gLeft; }
+int meshFaceRuleReference() { return 0; }
 void setReductionLeftAssoc(int left) { gLeft = left != 0; }
 hipError_t launchFitMfmaLow(hipStream_t, int, const FitTask*, const uint32_t*, uint32_t, uint32_t, uint32_t, double*, const DeviceTables*, const double*,
                             const RootMap&) { return hipErrorNoDevice; }

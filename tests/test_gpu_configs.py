@@ -398,6 +398,63 @@ def test_needle_meshes_one_answer_on_every_path(H, O, ctx, monkeypatch, seed):
     f.close()
 
 
+@pytest.mark.parametrize("seed", [100758, 501177, 200123])
+def test_mesh_face_rule_switch_returns_the_reference_values(H, O, ctx, monkeypatch, seed):
+    """hpsdf_set_mesh_face_rule(1): the closest-point routine returns the reference's face-case point whatever its weights
+    (Utility.cpp:5-97).  On the needle meshes where the default rule differs from the oracle (the test above), the O(n) scan
+    (Mesh.cpp:134-159) is then the oracle's scan BIT FOR BIT; the shared traversal, whose bounds assume the default rule, refuses; the
+    batched evaluation takes the per-point traversal (boxes only, like the reference's BVH: where it differs from the scan it has
+    pruned an artefact, i.e. its value lies ABOVE the scan's); and switching back restores the default's bytes."""
+    from helpers import fuzz_mesh_case, hard_points
+    verts, tris, leaf, host, scale, shift = fuzz_mesh_case(seed)
+    monkeypatch.setenv("HPSDF_MESH_LEAF_TRIS", str(leaf))
+    if host:
+        monkeypatch.setenv("HPSDF_MESH_HOST_BUILD", "1")
+    f = H.Field.mesh(ctx, verts, tris)
+    pts = hard_points(verts, tris, seed)
+    ref = O.MeshField(verts, tris).signed_distance(pts)[0].astype(np.float64)
+    default_scan = f.eval_naive(ctx, pts)
+    assert H.mesh_face_rule() == 0
+    try:
+        H.set_mesh_face_rule(True)
+        assert H.mesh_face_rule() == 1
+        scan = f.eval_naive(ctx, pts)
+        assert np.array_equal(bits(scan), bits(ref))                    # the reference's arithmetic, needles included
+        if seed != 200123:
+            assert not np.array_equal(bits(scan), bits(default_scan))  # (these two meshes are where the rules differ)
+        with pytest.raises(H.HpsdfError):
+            f.eval_wave(ctx, pts)
+        lane, batched = f.eval_lane(ctx, pts), f.eval(ctx, pts)
+        assert np.array_equal(bits(batched), bits(lane))
+        off = np.nonzero(bits(lane) != bits(scan))[0]
+        assert len(off) <= 8 and np.all(np.abs(lane[off]) >= np.abs(scan[off]))
+        few = f.eval(ctx, pts[:2])                                      # (answered on the calling thread: the same traversal)
+        assert np.array_equal(bits(few), bits(lane[:2]))
+    finally:
+        H.set_mesh_face_rule(False)
+    assert np.array_equal(bits(f.eval_naive(ctx, pts)), bits(default_scan))
+    f.close()
+
+
+def test_mesh_create_under_the_reference_face_rule(H, O, ctx):
+    """Create with a mesh field under hpsdf_set_mesh_face_rule(1) runs the host scheduler with the per-point traversal inside the fit
+    (the device-side frontier's sampler assumes the default rule).  On an ordinary mesh the two rules give the same values, so the
+    block is the default's, byte for byte."""
+    from helpers import icosphere
+    v, t = icosphere(3, 0.4)
+    lo, hi = v.min(0) - 0.02, v.max(0) + 0.02
+    f = H.Field.mesh(ctx, v, t)
+    cfg = H.make_config(1e-5, tuple(lo), tuple(hi))
+    want, _ = H.create_block(ctx, cfg, f, 256)
+    try:
+        H.set_mesh_face_rule(True)
+        got, _ = H.create_block(ctx, cfg, f, 256)
+    finally:
+        H.set_mesh_face_rule(False)
+    assert got == want
+    f.close()
+
+
 # ------------------------------------------------------------------ blocks shaped like the reference's (SURVEY H5)
 def _reference_shaped(blk, rng):
     """What Octree::ToMemoryBlock really emits: interior nodes keep a stale heap pointer in basis.coeffs
