@@ -36,13 +36,60 @@ TARGET = 1e-5
 JOBS_PER_ROUND = 1024
 
 
+def counter_record(name, keys):
+    """The counter figures of profiles/<name> (tools/pmc_json.py) if the kernels' source still hashes to what was profiled, else the
+    same keys as null -- a secondary roofline never shows counters of a kernel that has changed since."""
+    import hashlib
+    out = {k: None for k in keys}
+    out["measured_from"] = None
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        rec = json.load(open(path))
+        files = {"mesh_pmc.json": ["kernels.hip", "device_types.hpp", "acosf_host_libm.hpp"],
+                 "fit_pmc.json": ["kernels.hip", "fit_low.hip", "field_eval.hpp", "device_types.hpp"]}[name]
+        h = hashlib.sha256()
+        for f in files:
+            h.update(open(os.path.join(ROOT, "hp-adaptive-signed-distance-field-octree_amd", "csrc", f), "rb").read())
+        cur = h.hexdigest()[:16]
+        out["measured_from"] = {"file": "profiles/" + name, "profile": rec.get("profile"), "source_sha16": rec.get("source_sha16"),
+                                "current_source_sha16": cur, "stale": rec.get("source_sha16") != cur}
+        if rec.get("source_sha16") == cur:
+            for k in keys:
+                out[k] = rec.get(k)
+    except Exception:  # noqa: BLE001  (no record: nulls)
+        pass
+    return out
+
+
+def visible_gpus():
+    """GPUs this process may use, counted WITHOUT a call into the HIP runtime (the launcher must not have initialised the GPU when it
+    starts the ranks): the visibility variables if they are set, else the KFD topology's nodes with compute units; torch's own count
+    (which can go through hipGetDeviceCount on builds without amdsmi) only if neither is there."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    try:
+        import glob
+        n = 0
+        for props in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+            for line in open(props):
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    n += 1
+        if n:
+            return n
+    except Exception:  # noqa: BLE001
+        pass
+    return torch.cuda.device_count()
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run --nproc-per-node N bench.py <same
     arguments>` as a child process (one rank per GPU, rendezvous on 127.0.0.1), pass rank 0's JSON line through and return the
-    child's exit code.  The parent makes no GPU call before or after (device_count() does not initialise the runtime here)."""
+    child's exit code.  The parent makes no GPU call before or after (visible_gpus() reads the environment and sysfs)."""
     import socket
     import subprocess
-    have = torch.cuda.device_count()
+    have = visible_gpus()
     if have < n and os.environ.get("HPSDF_BENCH_SHARE_GPU") != "1":
         print("bench.py: --gpus %d but %d GPU(s) visible (HPSDF_BENCH_SHARE_GPU=1 rehearses the N-rank path on one GPU over gloo)"
               % (n, have), file=sys.stderr)
@@ -337,13 +384,15 @@ def main():
                                        "msamples_per_s": mst["samples"] / ms / 1e3}
             mesh["create_ms"] = mesh.get("create_ms_1e-5")  # the north_star's "2 M-tri mesh at targetError 1e-5"
             # What bounds the sampling leg: mesh_sample_kernel is VALU-issue bound, not HBM bound (8 B written per sample against ~1.4 KB
-            # gathered, mostly from L2 / Infinity Cache).  The issue fraction is a counter figure (SQ_INSTS_VALU x 4 cycles / (GRBM_GUI_ACTIVE
-            # / 8 XCDs x 1024 SIMDs), tools/mesh_pmc.sh) and cannot be read from inside this process: it is the one committed with the
-            # profile named here; the live part is samples/s.
+            # gathered, mostly from L2 / Infinity Cache).  The live part is samples/s; the counter figures (issue fraction = SQ_INSTS_VALU
+            # x 4 cycles / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), lane utilisation, bytes per sample) cannot be read from inside this
+            # process: they are those of profiles/mesh_pmc.json (tools/mesh_pmc.sh), stamped with a hash of the kernels' source and
+            # reported as null when the source has changed since they were taken.
             mesh["roofline"] = {"kernel": "mesh_sample_kernel", "bound": "valu-issue", "unit": "G samples/s",
-                                "achieved": mesh["tree_1e-6"]["msamples_per_s"] / 1e3 if "tree_1e-6" in mesh else None, "frac_valu_issue": 0.77, "lane_utilisation": 0.65,
-                                "valu_insts_per_64_samples": 27500, "fetched_bytes_per_sample": 1400, "written_bytes_per_sample": 20,
-                                "algorithmic_bytes_per_sample": 8, "measured_from": "profiles/r03z_mesh_sample_counters.txt"}
+                                "achieved": mesh["tree_1e-6"]["msamples_per_s"] / 1e3 if "tree_1e-6" in mesh else None,
+                                "algorithmic_bytes_per_sample": 8}
+            mesh["roofline"].update(counter_record("mesh_pmc.json", ("frac_valu_issue", "lane_utilisation", "valu_insts_per_64_samples",
+                                                                     "fetched_bytes_per_sample", "written_bytes_per_sample")))
             del mfield
 
         fit = None
@@ -386,6 +435,10 @@ def main():
                                                   "contraction_only_frac_fp64_peak": flops / fms_c / 1e9 / FP64_PEAK_TFLOPS}
             fast_ctx.close()
             exact_ctx.close()
+            # what bounds the exact fit is VALU issue (the field's instructions and the un-fusable multiplies), not FP64 throughput
+            # counted in FMAs: the issue fraction per degree, from profiles/fit_pmc.json (tools/fit_pmc_all.sh; null when stale)
+            fit["roofline"] = {"bound": "valu-issue", "peak_fp64_tflops": FP64_PEAK_TFLOPS}
+            fit["roofline"].update(counter_record("fit_pmc.json", ("degrees",)))
 
     ms_per_step = wall * 1e3 / args.steps
     value = world * n * args.steps / wall / 1e6  # Mpts/s, whole job

@@ -19,7 +19,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhpsdf.so")
+# (HPSDF_LIBRARY=hooks: lib/libhpsdf_hooks.so, the same library with the tests' fault-injection hook compiled in -- tests/ only)
+LIB_PATH = os.path.join(_HERE, "lib", "libhpsdf_hooks.so" if os.environ.get("HPSDF_LIBRARY") == "hooks" else "libhpsdf.so")
 _LIB = None
 
 OK = 0

@@ -12,6 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libhpsdf.so")
+HOOKS_LIB = os.path.join(LIBDIR, "libhpsdf_hooks.so")
+HOOK_SOURCES = ["frontier.hip", "capi.cpp"]
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
 
 SOURCES = ["kernels.hip", "frontier.hip", "fit_mfma.hip", "fit_low.hip", "mesh_build.hip", "cg.hip", "continuity_asm.hip", "tables.cpp", "builder.cpp", "mesh.cpp", "obj.cpp", "continuity.cpp", "host_query.cpp", "capi.cpp"]
@@ -37,7 +39,7 @@ def hipcc():
 
 
 def stale():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(HOOKS_LIB):
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.join(INCLUDE, h) for h in PUBLIC_HEADERS]
@@ -76,7 +78,33 @@ def build(force=False, verbose=False):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout)
+    build_hooks(cc, objs, verbose)
     return LIB
+
+
+def build_hooks(cc, objs, verbose=False):
+    """lib/libhpsdf_hooks.so: the same library with the fault-injection hook of the multi-rank tests compiled in (-DHPSDF_TEST_HOOKS:
+    HPSDF_TEST_FAIL_RANK makes one rank's share of a round fail).  Only the two sources that hold the hook are compiled again; the
+    production library never parses the variable."""
+    hookdir = os.path.join(HERE, "build", "hooks")
+    os.makedirs(hookdir, exist_ok=True)
+    procs, swapped = [], list(objs)
+    for s in HOOK_SOURCES:
+        obj = os.path.join(hookdir, s + ".o")
+        swapped[SOURCES.index(s)] = obj
+        cmd = [cc] + FLAGS + ["-DHPSDF_TEST_HOOKS"] + FILE_FLAGS.get(s, []) + ["-c", os.path.join(CSRC, s), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed on %s (hooks):\n%s" % (s, out))
+    r = subprocess.run([cc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", HOOKS_LIB] + swapped, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed (hooks):\n" + r.stdout)
+    return HOOKS_LIB
 
 
 if __name__ == "__main__":

@@ -328,8 +328,8 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
     // opt-in fast fit (hpsdf_ctx_set_fast_fit): degrees >= 4 of unweighted, non-CSG fields go to the matrix cores
     const bool fastOn = ctx->fitMode == HPSDF_FIT_FAST && !b->weighted && !meshFused && field->kind != kHostTreeCsg;
     auto fastDeg = [&](int deg) { return fastOn && deg >= 4 && deg <= 11; };
-    // the default (HPSDF_FIT_SPLIT): a from-scratch fit of degree >= 4 is cut in two -- its rows of top degree by the bit-exact kernel
-    // (they alone enter the error, Octree.cpp:1062-1069), the rows below them by fit_mfma_low_kernel from the same samples.  Not for
+    // the default (HPSDF_FIT_SPLIT): a from-scratch fit of degree >= splitMinDegree (6 unless set otherwise) is cut in two -- its rows of top degree by the bit-exact kernel
+    // (they alone enter the error, Octree.cpp:1062-1069), the rows below them by fit_low_kernel (HPSDF_LOW_KERNEL=mfma: fit_mfma_low_kernel) from the same samples.  Not for
     // weighted builds (the weight reads every row) nor for mesh fits that sample inside the fit kernel; a round whose samples would
     // not fit the sample buffer's 16 GB is fitted exactly throughout.
     // (round 0 -- every coarse cell's degree-2 fit -- is never split: the device-side frontier fits it through its own path, and the two

@@ -1377,7 +1377,11 @@ static int createShardedOnHostScheduler(hpsdf_ctx* ctx, const hpsdf_config* cfg,
     // part is its STATUS (0: fine).  A rank whose share of the round failed (localRc: device memory, a launch) still enters the
     // exchange, with its status set, and returns its own error afterwards; the others find the status, and return
     // HPSDF_ERR_STATE instead of waiting in the next collective for a rank that has left.
-    const char* injected = std::getenv("HPSDF_TEST_FAIL_RANK");  // tests: "<rank>:<exchange number>"
+#ifdef HPSDF_TEST_HOOKS  // (lib/libhpsdf_hooks.so, built for tests/: the production library does not look at the variable)
+    const char* injected = std::getenv("HPSDF_TEST_FAIL_RANK");  // "<rank>:<exchange number>"
+#else
+    const char* injected = nullptr;
+#endif
     int exchanges = 0;
     auto exchange = [&](const double* mine, uint64_t count, uint64_t pad, const char* what, int localRc) -> int {
         if (injected && !localRc && std::atoi(injected) == rank && std::strchr(injected, ':') && std::atoi(std::strchr(injected, ':') + 1) == exchanges)

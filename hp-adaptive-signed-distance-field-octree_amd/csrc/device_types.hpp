@@ -142,7 +142,7 @@ struct FitBlock {
     uint16_t rowStart, rowEnd;  // coefficient rows computed: [rowStart,rowEnd)
     uint8_t depth;              // depth of every cell of the workgroup
     uint8_t weighted;           // also produce |mean FApprox| over 100 sample points (nearness weighting)
-    uint8_t split;              // a from-scratch fit cut in two (the default for degrees >= 4): this block is its rows of TOP degree
+    uint8_t split;              // a from-scratch fit cut in two (HPSDF_FIT_SPLIT, the default mode, from degree 6 on: hpsdf_ctx_set_split_min_degree): this block is its rows of TOP degree
                                 // [rowStart, rowEnd), fitted bit-exactly -- they alone enter the error, Octree.cpp:1062-1069 --; the
                                 // task's outOff addresses row 0 of the whole array, the field values are written back to the sample
                                 // buffer, and fit_mfma_low_kernel contracts rows [0, rowStart) from them on the matrix cores

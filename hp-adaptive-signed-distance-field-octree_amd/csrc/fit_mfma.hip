@@ -250,7 +250,7 @@ __global__ __launch_bounds__(64 * MfmaWaves<DEG>::value) void fit_mfma_kernel(co
         mfmaContract<KIND, NTI, KW, LEFT>(blk, tasks, arena, errs, T, field, rm, sT, sR, sW, sNl, sRed);
 }
 
-// The rows below the top degree of the split fits of degree DEG (the default for from-scratch fits of degree >= 4): tasks
+// The rows below the top degree of the split fits of degree DEG (HPSDF_LOW_KERNEL=mfma; degrees >= 4 -- the default lower-rows kernel is fit_low.hip's): tasks
 // [range[0], range[0] + range[1]) are from-scratch fits of degree DEG in any mix of depths, 16 to a workgroup; their field values
 // are in the sample buffer (fit_kernel wrote them back while it fitted the top-degree rows, or the mesh sampler put them there);
 // rows [0, ncoef(DEG - 1)) go to the start of every task's array.  No FitBlock list: a tile is 16 consecutive tasks.

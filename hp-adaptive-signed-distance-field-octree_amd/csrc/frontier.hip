@@ -2109,7 +2109,11 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
     // rank's share fails while one is pending, it still enters that exchange -- with its status slot set (kFrStatusPad) -- before
     // it returns its error: the others then leave with HPSDF_ERR_STATE instead of waiting for a rank that has gone.
     int phase = 0;
-    const char* injected = std::getenv("HPSDF_TEST_FAIL_RANK");  // tests: "<rank>:<round>"
+#ifdef HPSDF_TEST_HOOKS  // (lib/libhpsdf_hooks.so, built for tests/: the production library does not look at the variable)
+    const char* injected = std::getenv("HPSDF_TEST_FAIL_RANK");  // "<rank>:<round>"
+#else
+    const char* injected = nullptr;
+#endif
     auto injectedFailure = [&](int round) {
         return injected && world > 1 && std::atoi(injected) == rank && std::strchr(injected, ':') && std::atoi(std::strchr(injected, ':') + 1) == round;
     };

@@ -41,7 +41,7 @@ constexpr int kMfmaCells = 16;
 bool fitMfmaSupports(int degree, const FieldDev& field);
 hipError_t launchFitMfma(hipStream_t stream, int degree, const FitBlock* dBlocks, uint32_t nBlocks, const FitTask* dTasks, double* dArena,
                          double* dErrs, const DeviceTables* dTables, const FieldDev& field, const RootMap& rm, const uint32_t* dRange = nullptr);
-// The default for from-scratch fits of degree 4..11 ("split", FitBlock::split): the rows of top degree by the bit-exact kernel (which
+// The default mode's from-scratch fits of degree 6..11 ("split", FitBlock::split; the threshold is the context's splitMinDegree): the rows of top degree by the bit-exact kernel (which
 // also leaves the field values in the sample buffer), the rows below it by this launch on the matrix cores -- errors, hence every
 // decision of the build, stay those of the all-exact fit; the lower rows agree with it to ~1e-17.
 int fitSplitDefaultMinDegree();  // 6 unless HPSDF_SPLIT_MIN_DEGREE says otherwise

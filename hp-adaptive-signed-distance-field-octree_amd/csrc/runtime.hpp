@@ -76,7 +76,7 @@ struct hpsdf_ctx {
     hipStream_t stream = nullptr;
     bool ownsStream = false;
     hpsdf::DeviceTables* dTables = nullptr;
-    // hpsdf_ctx_set_fit_mode: how from-scratch fits of degree >= 4 run.  HPSDF_FIT_SPLIT (default): rows of top degree bit-exact, the
+    // hpsdf_ctx_set_fit_mode: how from-scratch fits of higher degree run (split: from splitMinDegree, 6 by default; fast: from 4).  HPSDF_FIT_SPLIT (default): rows of top degree bit-exact, the
     // rows below them on the matrix cores (errors and so every decision canonical); HPSDF_FIT_EXACT: every row bit-exact (the
     // canonical bytes); HPSDF_FIT_FAST: every row of every fit of degree >= 4 on the matrix cores (errors within ~1e-15, ties may flip)
     int fitMode = HPSDF_FIT_SPLIT;

@@ -2,6 +2,8 @@
 deserialiser against blocks shaped like the reference's own, all through the C ABI."""
 import hashlib
 
+import os
+
 import numpy as np
 import pytest
 
@@ -230,19 +232,17 @@ def _ranks_collect(H, world, cfg, make_field, K):
     return out
 
 
-@pytest.mark.parametrize("weighted,fail_at", [(False, 0), (False, 3), (True, 0), (True, 2)])
-def test_a_failing_rank_takes_the_others_out_with_it(H, ctx, monkeypatch, weighted, fail_at):
-    """One rank's share of a round fails on its own (HPSDF_TEST_FAIL_RANK stands in for a device allocation that one GPU cannot
-    serve): it still enters the exchange the others are heading for, with its status set; it returns its own error, every other
-    rank HPSDF_ERR_STATE naming it -- nobody is left waiting in a collective.  Device-side frontier (unweighted) and the host
-    scheduler's sharded rounds (weighted) alike; the contexts build normally afterwards."""
+def _failing_rank_case(weighted, fail_at):
+    """(runs in a process of its own, on lib/libhpsdf_hooks.so: HPSDF_LIBRARY=hooks)"""
+    import hpsdf_loader
+    H = hpsdf_loader.load()
     world, bad = 4, 2
     cfg = H.make_config(1e-7)
     if weighted:
         cfg.nearnessWeighting_type, cfg.nearnessWeighting_strength = 2, 3.0
-    monkeypatch.setenv("HPSDF_TEST_FAIL_RANK", "%d:%d" % (bad, fail_at))
+    os.environ["HPSDF_TEST_FAIL_RANK"] = "%d:%d" % (bad, fail_at)
     out = _ranks_collect(H, world, cfg, lambda c: H.Field.union3(), 256)
-    monkeypatch.delenv("HPSDF_TEST_FAIL_RANK")
+    del os.environ["HPSDF_TEST_FAIL_RANK"]
     for r in range(world):
         assert isinstance(out[r], H.HpsdfError), (r, out[r])
         if r == bad:
@@ -250,8 +250,33 @@ def test_a_failing_rank_takes_the_others_out_with_it(H, ctx, monkeypatch, weight
         else:
             assert out[r].status == H.ERR_STATE and ("rank %d failed" % bad) in str(out[r])
     good = _create_on_simulated_ranks(H, world, cfg, lambda c: H.Field.union3(), 256)
-    one, _ = H.create_block(ctx, cfg, H.Field.union3(), 256)
+    one, _ = H.create_block(H.Context(0), cfg, H.Field.union3(), 256)
     assert all(blk == one for blk, _ in good)
+    print("failing-rank case ok")
+
+
+@pytest.mark.parametrize("weighted,fail_at", [(False, 0), (False, 3), (True, 0), (True, 2)])
+def test_a_failing_rank_takes_the_others_out_with_it(weighted, fail_at):
+    """One rank's share of a round fails on its own (HPSDF_TEST_FAIL_RANK stands in for a device allocation that one GPU cannot
+    serve): it still enters the exchange the others are heading for, with its status set; it returns its own error, every other
+    rank HPSDF_ERR_STATE naming it -- nobody is left waiting in a collective.  Device-side frontier (unweighted) and the host
+    scheduler's sharded rounds (weighted) alike; the contexts build normally afterwards.  The hook that makes a rank fail is compiled
+    into lib/libhpsdf_hooks.so only (-DHPSDF_TEST_HOOKS): the case runs in a process of its own that loads that library, and the
+    production library is shown not to look at the variable."""
+    import subprocess, sys
+    from conftest import ROOT
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_configs as T; T._failing_rank_case(%r, %r)"
+            % (ROOT, os.path.join(ROOT, "tests"), weighted, fail_at))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, HPSDF_LIBRARY="hooks"))
+    assert r.returncode == 0 and "failing-rank case ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_the_production_library_ignores_the_fault_injection_variable(H, ctx, monkeypatch):
+    monkeypatch.setenv("HPSDF_TEST_FAIL_RANK", "1:0")
+    cfg = H.make_config(1e-6)
+    blocks = _create_on_simulated_ranks(H, 2, cfg, lambda c: H.Field.union3(), 256)
+    one, _ = H.create_block(ctx, cfg, H.Field.union3(), 256)
+    assert all(b == one for b, _ in blocks)
 
 
 def _hard_meshes():
@@ -760,6 +785,35 @@ def test_bench_starts_its_own_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["world"] == 2 and out["backend"] == "gloo" and out["value"] > 0
     assert out["exchanges_per_create"] >= 2 and out["create_sharded_ms"] > 0
+
+
+def test_bench_four_ranks_sharing_this_gpu():
+    """The driver's scaling run is `bench.py --gpus N` for N up to 8 on a node this build never sees.  What can be rehearsed on a
+    one-GPU box: the same command with the ranks sharing the card over gloo -- four of them, because the pool allows six processes on a
+    GPU at once and this test runner and the launcher count (five ranks: "7 processes had the GPU open (limit 6)"; eight ranks run as
+    threads in test_create_distributed_*).  bench.py itself asserts that the sharded block equals the replicated one."""
+    import json, os, subprocess, sys, time
+    from conftest import ROOT
+    env = dict(os.environ, HPSDF_BENCH_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1", "--points", "1000000",
+           "--mesh", "7", "--no-fit-bench", "--no-cpu-baseline", "--no-refined", "--no-sorted-ceiling"]
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    wall = time.time() - t0
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["world"] == 4 and out["backend"] == "gloo" and out["value"] > 0
+    assert isinstance(out["exchanges_per_create"], int) and out["exchanges_per_create"] >= 2
+    assert "error" not in out["create_sharded"] and len(out["create_sharded"]["ms_per_rank"]) == 4
+    m = out["mesh_create"]
+    assert m["triangles"] == 327680 and len(m["create_ms_per_rank_1e-5"]) == 4 and len(m["create_ms_per_rank_1e-6"]) == 4
+    assert isinstance(m["exchanges_per_create_1e-6"], int)
+    print("bench.py --gpus 4 on one GPU: %.0f s of wall clock" % wall)
+    assert wall < 600  # (the driver's lease: N real GPUs do each of these legs N times faster than four ranks on one)
 
 
 _NCCL_GATHER = r'''

@@ -46,4 +46,5 @@ if fs and w:
     # FETCH_SIZE / WRITE_SIZE are in KB; gfx950 counts a 128-byte read request as 64 bytes (MI355X_MICROARCH.md): reads doubled
     print("mesh_sample_kernel HBM traffic per sample: fetched %.1f B (counter x 2), written %.1f B" % (2 * fs * 1024 / (w * 64), (ws or 0) * 1024 / (w * 64)))
 PY
+python3 tools/pmc_json.py mesh "$OUT" "$OUT/mesh_pmc.json" "$TAG" > /dev/null && echo "wrote $OUT/mesh_pmc.json (copy to profiles/mesh_pmc.json)"
 tail -2 $OUT/log1.txt
