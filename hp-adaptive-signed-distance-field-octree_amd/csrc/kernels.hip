@@ -1028,6 +1028,43 @@ __device__ __forceinline__ double evalLeafVals(const double (&cv)[NV], double ux
     return f;
 }
 
+// FApprox for the lanes of a wave whose leaves have different degrees <= P, in ONE pass: the basis rows of degree d are the first
+// coeffCount(d) rows of the degree-P basis (Utility.h's table is ordered by total degree) and the sum runs row by row, so the value of
+// a leaf of degree d is the running sum after row coeffCount(d) - 1 -- the very additions evalLeafVals<d> performs, on the same
+// Legendre values (the recurrence is the same for j <= d) -- and each lane keeps the running sum at its own degree's last row.  A wave
+// with degree-2 and degree-3 leaves used to run both bodies one after the other (tools/query_general_floor.py: the polynomial is a
+// fifth of query_general's time); rows beyond a lane's degree multiply whatever its registers hold there: never read.
+template <int P, int NV>
+__device__ __forceinline__ double evalLeafValsMixed(const double (&cv)[NV], double ux, double uy, double uz, int depth, uint32_t degree,
+                                                    const double* sNl, const double* sRec) {
+    constexpr int N = coeffCount(P);
+    static_assert(NV >= N, "coefficient registers");
+    double tx[P + 1], ty[P + 1], tz[P + 1];
+    tx[0] = ty[0] = tz[0] = sNl[depth];
+    double xm2 = 0.0, xm1 = 1.0, ym2 = 0.0, ym1 = 1.0, zm2 = 0.0, zm1 = 1.0;
+#pragma unroll
+    for (int j = 1; j <= P; ++j) {
+        const double r0 = sRec[2 * j], r1 = sRec[2 * j + 1], nl = sNl[j * 11 + depth];
+        const double lx = r0 * ux * xm1 - r1 * xm2;
+        const double ly = r0 * uy * ym1 - r1 * ym2;
+        const double lz = r0 * uz * zm1 - r1 * zm2;
+        xm2 = xm1, xm1 = lx, ym2 = ym1, ym1 = ly, zm2 = zm1, zm1 = lz;
+        tx[j] = lx * nl, ty[j] = ly * nl, tz[j] = lz * nl;
+    }
+    double f = 0.0, mine = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double lp = tx[kBasis.v[i][0]];
+        lp = lp * ty[kBasis.v[i][1]];
+        lp = lp * tz[kBasis.v[i][2]];
+        f = f + cv[i] * lp;
+#pragma unroll
+        for (int dgr = 0; dgr < P; ++dgr)
+            if (i == coeffCount(dgr) - 1) mine = degree == (uint32_t)dgr ? f : mine;
+    }
+    return degree == (uint32_t)P ? f : mine;
+}
+
 // Octree::FApproxWithGradient (Octree.cpp:904-985) for a compile-time degree: the value as FApprox, the "gradient"
 // as the reference forms it -- per axis k the central difference of sum_r c_r * Lhat_{idx[r][k]}(u_k +- eps), i.e. with
 // the other two axes' factors left out (:956-968) -- then normalised.  Same statements, same order as
@@ -1075,6 +1112,60 @@ __device__ __forceinline__ double evalLeafGradVals(const double (&cv)[NV], const
         f = f + cv[r] * lp;
     }
     return f;
+}
+
+// FApproxWithGradient for a wave's mix of degrees <= P in one pass, as evalLeafValsMixed: every running sum -- the two one-sided sums
+// of each axis and the value -- is kept at the last row of the lane's own degree.
+template <int P, int NV>
+__device__ __forceinline__ double evalLeafGradValsMixed(const double (&cv)[NV], const double (&u)[3], int depth, uint32_t degree, const double* sNl,
+                                                        const double* sRec, double (&g)[3], int left) {
+    constexpr int N = coeffCount(P);
+    static_assert(NV >= N, "coefficient registers");
+    const double eps = 0.0001;
+    double L0[3][P + 1];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        double Lp[P + 1], Lm[P + 1];
+        L0[k][0] = Lp[0] = Lm[0] = sNl[depth];
+        double a2 = 0.0, a1 = 1.0, b2 = 0.0, b1 = 1.0, c2 = 0.0, c1 = 1.0;
+#pragma unroll
+        for (int j = 1; j <= P; ++j) {
+            const double r0 = sRec[2 * j], r1 = sRec[2 * j + 1], nl = sNl[j * 11 + depth];
+            const double a0 = r0 * u[k] * a1 - r1 * a2;          // :937
+            const double b0 = r0 * (u[k] + eps) * b1 - r1 * b2;  // :941
+            const double c0 = r0 * (u[k] - eps) * c1 - r1 * c2;  // :945
+            a2 = a1, a1 = a0, b2 = b1, b1 = b0, c2 = c1, c1 = c0;
+            L0[k][j] = a0 * nl, Lp[j] = b0 * nl, Lm[j] = c0 * nl;
+        }
+        double p1 = 0.0, m1 = 0.0, pMine = 0.0, mMine = 0.0;
+#pragma unroll
+        for (int r = 0; r < N; ++r) {  // :956-968
+            p1 = p1 + cv[r] * Lp[kBasis.v[r][k]];
+            m1 = m1 + cv[r] * Lm[kBasis.v[r][k]];
+#pragma unroll
+            for (int dgr = 0; dgr < P; ++dgr)
+                if (r == coeffCount(dgr) - 1) pMine = degree == (uint32_t)dgr ? p1 : pMine, mMine = degree == (uint32_t)dgr ? m1 : mMine;
+        }
+        if (degree != (uint32_t)P) p1 = pMine, m1 = mMine;
+        g[k] = (p1 - m1) / (2.0 * eps);
+    }
+    const double z = left ? sum3<true>(g[0] * g[0], g[1] * g[1], g[2] * g[2]) : sum3<false>(g[0] * g[0], g[1] * g[1], g[2] * g[2]);  // Eigen normalize()
+    if (z > 0.0) {
+        const double nrm = sqrt(z);
+        g[0] = g[0] / nrm, g[1] = g[1] / nrm, g[2] = g[2] / nrm;
+    }
+    double f = 0.0, mine = 0.0;  // :972-984
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+        double lp = L0[0][kBasis.v[r][0]];
+        lp = lp * L0[1][kBasis.v[r][1]];
+        lp = lp * L0[2][kBasis.v[r][2]];
+        f = f + cv[r] * lp;
+#pragma unroll
+        for (int dgr = 0; dgr < P; ++dgr)
+            if (r == coeffCount(dgr) - 1) mine = degree == (uint32_t)dgr ? f : mine;
+    }
+    return degree == (uint32_t)P ? f : mine;
 }
 
 // Legendre recurrence constants (2j-1)/j and (j-1)/j (Include/HP/Utility.h:112-127): IEEE divisions of small
@@ -1436,7 +1527,11 @@ __device__ __forceinline__ uint32_t leafChunks(uint32_t degree) { return ((uint3
 constexpr size_t queryGeneralLdsBytes(int waves, bool ldsTop) {
     return (size_t)waves * 5 * 66 * sizeof(double2) + (size_t)waves * 64 * sizeof(uint32_t) + (ldsTop ? 4096 * sizeof(NodeRec) : 0);
 }
-template <int TOPD, bool DEFER, bool GRAD, int WAVES, bool LDSTOP>
+// LAB (tools/query_general_floor.py, HPSDF_QUERY_LAB=n; results are NOT the tree's values): what the kernel's time is made of, by taking
+// one link of its chain out at a time -- 1: no polynomial (the fetched rows are touched, not evaluated); 2: every lane fetches the leaf
+// of its wave's first lane (the same instructions, but every line after the first is a hit: no gather traffic); 3: no second line for
+// degree-3 leaves; 4: no walk below the top table (the top record is taken for the leaf)
+template <int TOPD, bool DEFER, bool GRAD, int WAVES, bool LDSTOP, int LAB = 0>
 __device__ __forceinline__ void queryGeneralBody(const TreeDev& t, const DeviceTables* __restrict__ T,
                                                  const double* __restrict__ xyz, size_t n, double* __restrict__ out,
                                                  double* __restrict__ grad, uint32_t tilesPerWg,
@@ -1492,6 +1587,9 @@ __device__ __forceinline__ void queryGeneralBody(const TreeDev& t, const DeviceT
         NodeRec rec = LDSTOP ? sTop[code] : t.topRec[code];
         int depth = topDepth;
         double q = 0.25 / (double)(1 << topDepth);  // a quarter of the cell size: from a centre to its children's
+        if constexpr (LAB == 4) {
+            if (rec.b == kInteriorTag) rec.a = 0, rec.b = 2;
+        }
         while (rec.b == kInteriorTag) {              // :674-701 below the complete levels
             const bool ux = p3[0] >= c3[0], uy = p3[1] >= c3[1], uz = p3[2] >= c3[2];
             const uint32_t idx = rec.a + (ux ? 1u : 0u) + (uy ? 2u : 0u) + (uz ? 4u : 0u);
@@ -1512,7 +1610,13 @@ __device__ __forceinline__ void queryGeneralBody(const TreeDev& t, const DeviceT
         // low four bits are free) and chunk count (0 = nothing to fetch)
         sInfo[wave][lane] = rec.a | (coop ? leafChunks(degree) : 0u);
         __builtin_amdgcn_wave_barrier();
-        const bool second = __any(coop && degree == 3u);  // wave-uniform: somebody needs chunks 8..9
+        if constexpr (LAB == 2) {
+            const uint32_t first = sInfo[wave][0];
+            __builtin_amdgcn_wave_barrier();
+            sInfo[wave][lane] = first;
+            __builtin_amdgcn_wave_barrier();
+        }
+        const bool second = LAB != 3 && __any(coop && degree == 3u);  // wave-uniform: somebody needs chunks 8..9
         double cv[20];
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
@@ -1569,23 +1673,20 @@ __device__ __forceinline__ void queryGeneralBody(const TreeDev& t, const DeviceT
         double r = DBL_MAX;  // :668-671
         double g[3] = {0.0, 0.0, 0.0};
         bool defer = false;
-        if (inside) {
+        if (LAB == 1 && inside) {
+            r = (cv[0] + cv[9]) + (cv[16] + cv[19]) + u[0] * u[1] + u[2] + (double)depth;
+        } else if (inside) {
             if constexpr (GRAD) {
-                switch (degree) {
-                    case 0: r = evalLeafGradVals<0>(cv, u, depth, sNl, sRec, g, t.leftAssoc); break;
-                    case 1: r = evalLeafGradVals<1>(cv, u, depth, sNl, sRec, g, t.leftAssoc); break;
-                    case 2: r = evalLeafGradVals<2>(cv, u, depth, sNl, sRec, g, t.leftAssoc); break;
-                    case 3: r = evalLeafGradVals<3>(cv, u, depth, sNl, sRec, g, t.leftAssoc); break;
-                    default: defer = valid; break;
-                }
+                if (degree > 3u)
+                    defer = valid;
+                else
+                    r = evalLeafGradValsMixed<3>(cv, u, depth, degree, sNl, sRec, g, t.leftAssoc);
             } else {
-                switch (degree) {
-                    case 0: r = evalLeafVals<0>(cv, u[0], u[1], u[2], depth, sNl, sRec); break;
-                    case 1: r = evalLeafVals<1>(cv, u[0], u[1], u[2], depth, sNl, sRec); break;
-                    case 2: r = evalLeafVals<2>(cv, u[0], u[1], u[2], depth, sNl, sRec); break;
-                    case 3: r = evalLeafVals<3>(cv, u[0], u[1], u[2], depth, sNl, sRec); break;
-                    default: defer = valid; break;
-                }
+                // one pass for the wave's mix of degrees (evalLeafValsMixed)
+                if (degree > 3u)
+                    defer = valid;
+                else
+                    r = evalLeafValsMixed<3>(cv, u[0], u[1], u[2], depth, degree, sNl, sRec);
             }
         }
         // the next tile's points have had the evaluation's time to arrive: claim them before this tile's stores are issued (a wait
@@ -1628,13 +1729,13 @@ __global__ __launch_bounds__(256) void query_general_kernel(TreeDev t, const Dev
     queryGeneralBody<TOPD, DEFER, false, 4, false>(t, T, xyz, n, out, nullptr, tilesPerWg, deferCount, deferIdx);
 }
 // depth-4 top level: 16 waves per workgroup, thin table in LDS
-template <bool DEFER>
+template <bool DEFER, int LAB = 0>
 __global__ __launch_bounds__(1024) void query_general_lds_kernel(TreeDev t, const DeviceTables* __restrict__ T,
                                                                  const double* __restrict__ xyz, size_t n,
                                                                  double* __restrict__ out, uint32_t tilesPerWg,
                                                                  uint32_t* __restrict__ deferCount,
                                                                  uint32_t* __restrict__ deferIdx) {
-    queryGeneralBody<4, DEFER, false, 16, true>(t, T, xyz, n, out, nullptr, tilesPerWg, deferCount, deferIdx);
+    queryGeneralBody<4, DEFER, false, 16, true, LAB>(t, T, xyz, n, out, nullptr, tilesPerWg, deferCount, deferIdx);
 }
 template <int TOPD, bool DEFER>
 __global__ __launch_bounds__(256, 3) void query_general_grad_kernel(TreeDev t, const DeviceTables* __restrict__ T,
@@ -3003,7 +3104,20 @@ hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables*
         const void* fn = defer ? (const void*)query_general_lds_kernel<true> : (const void*)query_general_lds_kernel<false>;
         const hipError_t ae = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (ae != hipSuccess) return ae;
-        if (defer)
+        const char* labEnv = std::getenv("HPSDF_QUERY_LAB");  // diagnostics: a link of the chain taken out (queryGeneralBody's LAB); values are then not the tree's
+        const int lab = labEnv ? std::atoi(labEnv) : 0;
+        if (lab >= 1 && lab <= 4) {
+            const void* lf = lab == 1 ? (const void*)query_general_lds_kernel<true, 1> : lab == 2 ? (const void*)query_general_lds_kernel<true, 2>
+                           : lab == 3 ? (const void*)query_general_lds_kernel<true, 3> : (const void*)query_general_lds_kernel<true, 4>;
+            const hipError_t le = hipFuncSetAttribute(lf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (le != hipSuccess) return le;
+            switch (lab) {
+                case 1: hipLaunchKernelGGL((query_general_lds_kernel<true, 1>), ggrid, dim3(1024), lds, stream, t, dTables, dXyz, n, dOut, tilesPerWg, dDeferCount, dDeferIdx); break;
+                case 2: hipLaunchKernelGGL((query_general_lds_kernel<true, 2>), ggrid, dim3(1024), lds, stream, t, dTables, dXyz, n, dOut, tilesPerWg, dDeferCount, dDeferIdx); break;
+                case 3: hipLaunchKernelGGL((query_general_lds_kernel<true, 3>), ggrid, dim3(1024), lds, stream, t, dTables, dXyz, n, dOut, tilesPerWg, dDeferCount, dDeferIdx); break;
+                default: hipLaunchKernelGGL((query_general_lds_kernel<true, 4>), ggrid, dim3(1024), lds, stream, t, dTables, dXyz, n, dOut, tilesPerWg, dDeferCount, dDeferIdx); break;
+            }
+        } else if (defer)
             hipLaunchKernelGGL((query_general_lds_kernel<true>), ggrid, dim3(1024), lds, stream, t, dTables, dXyz, n, dOut, tilesPerWg, dDeferCount, dDeferIdx);
         else
             hipLaunchKernelGGL((query_general_lds_kernel<false>), ggrid, dim3(1024), lds, stream, t, dTables, dXyz, n, dOut, tilesPerWg, dDeferCount, dDeferIdx);
