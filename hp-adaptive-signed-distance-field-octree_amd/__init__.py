@@ -109,6 +109,7 @@ _SIGNATURES = {
     "hpsdf_ctx_set_fit_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "hpsdf_ctx_get_fit_mode": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "hpsdf_ctx_set_split_min_degree": (C.c_int, [C.c_void_p, C.c_int]),
+    "hpsdf_field_release_host_copies": (C.c_int, [C.c_void_p]),
     "hpsdf_set_mesh_face_rule": (None, [C.c_int]),
     "hpsdf_get_mesh_face_rule": (C.c_int, []),
     "hpsdf_set_reduction_order": (None, [C.c_int]),

@@ -593,6 +593,14 @@ static bool smallQueriesOnHost() {
     return on;
 }
 
+// What the host copies of a mesh field's arrays weigh, and up to where they are made at all: beyond HPSDF_HOST_MESH_MIRROR_MB (default
+// 512) a call of a few points is a launch like any other -- a mirror of a 2 M-triangle mesh is ~330 MB of pageable memory, fetched
+// behind a device-wide synchronisation (the field's arrays may still be being written on some stream), under the field's lock, and kept
+// until hpsdf_field_release_host_copies() or the field's destruction.
+static size_t meshMirrorBytes(const hpsdf_field* f) {
+    return (size_t)f->nVerts * 12 + (size_t)f->nTris * (12 + 12 + 4 * (size_t)(kTriRecordFloats + kTriPreFloats)) + (size_t)f->nBvhNodes * sizeof(BvhNode);
+}
+static size_t hostMeshMirrorLimit() { static const size_t v = hostLimit("HPSDF_HOST_MESH_MIRROR_MB", 512) << 20; return v; }
 // The host copies of a mesh field's arrays (made once, by the first call of a few points)
 static int meshHostMirror(const hpsdf_field* f, std::shared_ptr<hpsdf_field::HostMirror>* out) {
     std::lock_guard<std::mutex> guard(f->hostMirrorLock);
@@ -624,13 +632,21 @@ static int meshHostMirror(const hpsdf_field* f, std::shared_ptr<hpsdf_field::Hos
     return HPSDF_OK;
 }
 
+int hpsdf_field_release_host_copies(hpsdf_field* f) {
+    if (!f) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null field");
+    std::lock_guard<std::mutex> guard(f->hostMirrorLock);
+    f->hostMirror.reset();  // (calls in flight hold their own reference)
+    return HPSDF_OK;
+}
+
 int hpsdf_field_eval_host(hpsdf_ctx* ctx, const hpsdf_field* f, const double* xyz, size_t n, double* out) {
     HPSDF_TRY
     if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "a device context is required");
     if (!f || (!xyz && n) || (!out && n)) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
     // Mesh::SignedDistanceAtPt(pt, bvh): a call of a few points on a plain mesh field never reaches the device (~57 us as a launch;
     // a user's SDF lambda that calls it per sample -- the reference's own usage, Mesh.cpp:54-63 -- would cost minutes per Create)
-    if (n && n <= hostMeshLimit() && f->kind == kHostMesh && f->nTris >= 1 && f->nBvhNodes >= 1 && smallQueriesOnHost()) {
+    if (n && n <= hostMeshLimit() && f->kind == kHostMesh && f->nTris >= 1 && f->nBvhNodes >= 1 && smallQueriesOnHost() &&
+        meshMirrorBytes(f) <= hostMeshMirrorLimit()) {
         std::shared_ptr<hpsdf_field::HostMirror> m;
         const int rc = meshHostMirror(f, &m);
         if (rc) return rc;
@@ -844,11 +860,24 @@ int hpsdf_tree_upload(hpsdf_ctx* ctx, const void* block, size_t size, hpsdf_tree
         t->dev.rootCentre[a] = (double)((cfg.root_min[a] + cfg.root_max[a]) / 2.0f);  // Octree.cpp:419
         t->dev.rootInvSizes[a] = (double)(1.0f / (cfg.root_max[a] - cfg.root_min[a]));  // Octree.cpp:420
     }
-    t->hNodes = std::move(nodes);  // (validated above: every child index and coefficient range lies inside the block)
-    t->hCoeffs.assign(coeffs, coeffs + nCoeffs);
+    t->paddedCount = padded.size();
     *out = t;
     return HPSDF_OK;
     HPSDF_CATCH
+}
+
+// The host copies a scalar-sized call works from (host_query.cpp), on first use: the device mirror's records and coefficients.
+int hpsdf_tree::hostCopies() const {
+    if (hostReady.load(std::memory_order_acquire)) return HPSDF_OK;
+    std::lock_guard<std::mutex> guard(hostLock);
+    if (hostReady.load(std::memory_order_relaxed)) return HPSDF_OK;
+    HPSDF_HIP(hipSetDevice(device));
+    hRecs.resize(nNodes);
+    hPadded.resize(std::max<uint64_t>(2, paddedCount));
+    HPSDF_HIP(hipMemcpy(hRecs.data(), dNodes, nNodes * sizeof(hpsdf::NodeRec), hipMemcpyDeviceToHost));  // (the upload's copies were synchronous)
+    if (paddedCount) HPSDF_HIP(hipMemcpy(hPadded.data(), dCoeffs, paddedCount * sizeof(double), hipMemcpyDeviceToHost));
+    hostReady.store(true, std::memory_order_release);
+    return HPSDF_OK;
 }
 
 int hpsdf_tree_destroy(hpsdf_tree* t) {
@@ -917,6 +946,7 @@ int hpsdf_query_host(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* xyz, siz
     if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "a device context is required");
     if (!t || (!xyz && n) || (!out && n)) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
     if (n <= hostQueryLimit() && smallQueriesOnHost()) {  // a scalar Query(pt): ~0.05 us here, ~15 us as a launch (host_query.cpp)
+        if (const int hc = t->hostCopies()) return hc;
         for (size_t i = 0; i < n; ++i) out[i] = hostQueryPoint(*t, xyz + 3 * i);
         return HPSDF_OK;
     }
@@ -945,6 +975,7 @@ int hpsdf_query_gradient_host(hpsdf_ctx* ctx, const hpsdf_tree* t, const double*
     if (!t || (n && (!xyz || !out || !grad))) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
     if (n == 0) return HPSDF_OK;
     if (n <= hostGradientLimit() && smallQueriesOnHost()) {
+        if (const int hc = t->hostCopies()) return hc;
         for (size_t i = 0; i < n; ++i) hostQueryPointWithGradient(*t, xyz + 3 * i, out + i, grad + 3 * i);
         return HPSDF_OK;
     }
@@ -992,6 +1023,7 @@ int hpsdf_query_ray_host(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* orig
     if (!t || (n && (!origins || !dirs || !tMax || !hit || !tOut))) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
     if (n == 0) return HPSDF_OK;
     if (n <= hostRayLimit() && smallQueriesOnHost()) {  // a scalar QueryRay(ray, tMax, t): <= 200 host Query steps instead of a launch
+        if (const int hc = t->hostCopies()) return hc;
         for (size_t i = 0; i < n; ++i) hit[i] = hostQueryRay(*t, origins + 3 * i, dirs + 3 * i, tMax[i], tOut + i) ? 1 : 0;
         return HPSDF_OK;
     }

@@ -33,10 +33,10 @@ inline bool descend(const hpsdf_tree& t, const double* xyz, Leaf& L) {
     if (!(fx >= -0.5f && fx <= 0.5f && fy >= -0.5f && fy <= 0.5f && fz >= -0.5f && fz <= 0.5f)) return false;
     double c[3] = {0.0, 0.0, 0.0}, q = 0.25;  // cell centres are exact dyadics: the mid-planes of the f32 boxes
     int depth = 0;
-    const hpsdf_node* nodes = t.hNodes.data();
+    const NodeRec* nodes = t.hRecs.data();  // (interior: a = first child; leaf: a = offset in the line-aligned coefficient mirror, b = degree)
     uint64_t idx = 0;
-    while (nodes[idx].child_idx != ~0ull) {
-        uint64_t next = nodes[idx].child_idx;
+    while (nodes[idx].b == kInteriorTag) {
+        uint64_t next = nodes[idx].a;
         for (int a = 0; a < 3; ++a) {
             const bool up = p[a] >= c[a];
             next += up ? (1ull << a) : 0ull;
@@ -47,8 +47,8 @@ inline bool descend(const hpsdf_tree& t, const double* xyz, Leaf& L) {
         idx = next;
     }
     const double s = (double)(2 << depth);
-    L.co = t.hCoeffs.data() + nodes[idx].coeffs_start;
-    L.degree = nodes[idx].degree;
+    L.co = t.hPadded.data() + nodes[idx].a;
+    L.degree = (int)nodes[idx].b;
     L.depth = depth;
     for (int a = 0; a < 3; ++a) L.u[a] = (p[a] - c[a]) * s;
     return true;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstdint>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -114,8 +115,15 @@ struct hpsdf_tree {
     hpsdf_config config{};
     // the block's node array and packed coefficients as uploaded: calls of a few points are answered from them on the calling
     // thread (host_query.cpp), with the kernels' statements in the kernels' order
-    std::vector<hpsdf_node> hNodes;
-    std::vector<double> hCoeffs;
+    // What calls of a few points are answered from on the calling thread (host_query.cpp): the device mirror's own arrays -- 8-byte node
+    // records, coefficients with every leaf on its own lines -- fetched by the FIRST such call (hostCopies()), not kept by every
+    // tree from its upload on.
+    mutable std::mutex hostLock;
+    mutable std::vector<hpsdf::NodeRec> hRecs;
+    mutable std::vector<double> hPadded;
+    mutable std::atomic<bool> hostReady{false};
+    uint64_t paddedCount = 0;
+    int hostCopies() const;  // HPSDF_OK, or the status of the failed download
 };
 
 enum HostFieldKind { kHostAnalytic = 0, kHostCallback = 1, kHostMesh = 2, kHostTreeCsg = 3 };

@@ -186,6 +186,12 @@ HPSDF_API int hpsdf_field_destroy(hpsdf_field* f);
 HPSDF_API int hpsdf_field_eval_device(hpsdf_ctx* ctx, const hpsdf_field* f, const double* d_xyz, size_t n,
                                       double* d_out);
 HPSDF_API int hpsdf_field_eval_host(hpsdf_ctx* ctx, const hpsdf_field* f, const double* xyz, size_t n, double* out);
+/* Calls of one or two points on a plain mesh field (Mesh::SignedDistanceAtPt(pt, bvh) from a user's SDF lambda) are answered on the
+ * calling thread from host copies of the field's device-built arrays.  The first such call makes them: one device-wide
+ * synchronisation and a download of the whole mesh (vertices, triangles, records, BVH: ~160 bytes a triangle), kept until the field is
+ * destroyed or this call drops them.  Meshes whose copies would exceed HPSDF_HOST_MESH_MIRROR_MB (default 512) are never mirrored:
+ * their small calls are launches. */
+HPSDF_API int hpsdf_field_release_host_copies(hpsdf_field* f);
 /* Mesh fields, the one stated deviation from the reference's closest-point arithmetic (Source/Meshing/Utility.cpp:5-97): its face
  * case returns q = u a + v b + w c whatever the barycentric weights are, and beside the short edges of needle-shaped triangles
  * (its 1e-6 guards are absolute) a weight can be negative enough to put q well outside the triangle -- a distance below the

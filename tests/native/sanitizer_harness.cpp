@@ -276,10 +276,26 @@ int main(int argc, char** argv) {
         uint64_t nc, nn;
         memcpy(&nc, blk.data(), 8);
         memcpy(&nn, blk.data() + 8 + 8 * nc, 8);
+        // (the arrays of the device mirror, as hpsdf_tree_upload lays them out and hpsdf_tree::hostCopies() fetches them: 8-byte node
+        // records, every leaf's coefficients padded to whole 128-byte lines)
         hpsdf_tree tree;
-        tree.hNodes.resize(nn);
-        memcpy(tree.hNodes.data(), blk.data() + 16 + 8 * nc, nn * sizeof(hpsdf_node));
-        tree.hCoeffs.assign((const double*)(blk.data() + 8), (const double*)(blk.data() + 8) + nc);
+        {
+            std::vector<hpsdf_node> nodes(nn);
+            memcpy(nodes.data(), blk.data() + 16 + 8 * nc, nn * sizeof(hpsdf_node));
+            const double* coeffs = (const double*)(blk.data() + 8);
+            tree.hRecs.resize(nn);
+            for (uint64_t i = 0; i < nn; ++i) {
+                if (nodes[i].child_idx != ~0ull) {
+                    tree.hRecs[i].a = (uint32_t)nodes[i].child_idx, tree.hRecs[i].b = hpsdf::kInteriorTag;
+                } else {
+                    const uint64_t cnt = hpsdf::tables().coeffCount[nodes[i].degree];
+                    tree.hRecs[i].a = (uint32_t)tree.hPadded.size(), tree.hRecs[i].b = nodes[i].degree;
+                    tree.hPadded.insert(tree.hPadded.end(), coeffs + nodes[i].coeffs_start, coeffs + nodes[i].coeffs_start + cnt);
+                    tree.hPadded.resize((tree.hPadded.size() + 15) & ~(size_t)15, 0.0);
+                }
+            }
+            tree.hostReady = true;
+        }
         hpsdf_config cfg;
         memcpy(&cfg, blk.data() + 16 + 8 * nc + nn * sizeof(hpsdf_node), sizeof cfg);
         for (int a = 0; a < 3; ++a) {
