@@ -79,7 +79,7 @@ class Job(C.Structure):
 class BuildStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rounds", "jobs", "p_refines", "h_refines", "dropped", "fits", "samples",
                                            "n_nodes", "n_leaves", "n_coeffs")] + [("total_error", C.c_double), ("fit_mode", C.c_uint64),
-                                                                                    ("split_fits", C.c_uint64)]
+                                                                                    ("split_fits", C.c_uint64), ("device_frontier", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -1517,7 +1517,7 @@ int hpsdf_create_distributed(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsd
     // (the device-side frontier packs a segment's owner rank into three bits: more than 8 ranks take the host scheduler's rounds)
     // (... and a weighted incremental fit needs the node's previous rows, which another rank may hold: the host scheduler's
     // sharded rounds hand them over)
-    int rc = (frontierEligible(cfg, field, K) && world <= 8 && cfg->weighting_type == 0)
+    int rc = (frontierEligible(cfg, field, K) && world <= 8)
                  ? frontierCreate(ctx, cfg, field, K, block, size, stats, rank, world, gather, user)
                  : createShardedOnHostScheduler(ctx, cfg, field, K, rank, world, gather, user, block, size, stats);
     std::memset(&g_lastContinuity, 0, sizeof g_lastContinuity);

@@ -81,6 +81,7 @@ struct FrHdr {
     uint64_t jobs, pRefines, hRefines, dropped, fits, samples;
     uint64_t splitFits;   // from-scratch fits whose lower rows came from the split's second kernel (hpsdf_build_stats::split_fits)
     uint32_t splitRound, padR;  // FrDev::splitFit if the round being prepared splits its from-scratch fits, else 0 (decided by the batch)
+    uint64_t roundBase, partStride;  // FrDev::replica: the round's fits write arena rows [roundBase + r partStride, + partStride) on rank r
     double total, target;
     // staging between the decide and update kernels of a round
     uint32_t rP, rH, rD, rMaxDeg;
@@ -113,6 +114,7 @@ static inline void frCpuRelax() {  // the host's spin on the header mirror
 struct FrRound {  // shape classes of the current round (written by fr_batch_kernel, read by fr_tasks_kernel)
     uint32_t cCount[kFrClasses], cFirst[kFrClasses], cCursor[kFrClasses], cBlockFirst[kFrClasses], cBlocks[kFrClasses];
     uint64_t cArena[kFrClasses], cSample[kFrClasses];
+    uint64_t cArenaO[8][kFrClasses];  // FrDev::replica: arena rows before class c within owner o's part of the round
     uint8_t cG[kFrClasses], cPlanes[kFrClasses];
     uint64_t arenaBase;
 };
@@ -165,6 +167,11 @@ struct FrDev {
     uint32_t buildStamp, padB;  // a number of the build (FrHdr::landed)
     double target;         // targetErrorThreshold of the build (the header is initialised before the build is known: FrontierWorkspace::clean)
     int32_t weighted;
+    // Weighted builds on several ranks: every rank's arena is a REPLICA.  An incremental weighted fit carries the cell's previous rows
+    // over (:847), and those may have been fitted anywhere -- so a round's fits are laid out owner by owner at the same offsets on every
+    // rank (FrHdr::roundBase / partStride), every rank fills its own part, and ONE in-place all-gather of the round's part of the arena
+    // (beside the errors') leaves every rank with every row.  Segments then need no owner, the packed store no exchange of its own.
+    int32_t replica;
     double* means;          // [jobs][9], pinned host memory as the device addresses it (written by fit_weight_kernel)
     const double* weights;  // [jobs][9], pinned host memory as the device addresses it (written by the host)
     uint32_t* hostFlag;     // pinned: {jobs of the round, stamp}: "the means are there"
@@ -371,6 +378,8 @@ struct FrLds {
     int t;
     uint32_t above, c, next, flag, stuck, anySplit;
     unsigned long long need;
+    uint32_t countO[8][kFrClasses];  // FrDev::replica: fits per (owner, class)
+    unsigned long long rowsO[8];
     // per wave: 64 records of 7 words (a FitTask, a serialised node: 56 bytes) on their way to memory.  A lane writes its record's
     // words, the wave reads the 448 words back in order and stores THOSE: runs of whole records instead of 8 bytes every 56
     // (which cost the lists of a 1024-job round 60 k cycles, most of them waiting for the stores to drain)
@@ -533,6 +542,8 @@ __device__ void frBatchBody(const FrDev& d, FrLds& L, uint32_t nQ, uint32_t abov
     FR_STAMP(3);
     for (uint32_t i = tid; i < 2048; i += 1024) sHist[i] = 0;
     for (uint32_t c = tid; c < (uint32_t)kFrClasses; c += 1024) sCount[c] = 0;
+    if (d.replica)
+        for (uint32_t c = tid; c < 8u * (uint32_t)kFrClasses; c += 1024) (&L.countO[0][0])[c] = 0;
     if (tid < 9) L.slice[tid] = tid ? nJobs : 0u;
     __syncthreads();
     // ---- the jobs leave the frontier; every job becomes 1 (coarse) or up to 9 cell fits: count them per shape class.
@@ -542,6 +553,9 @@ __device__ void frBatchBody(const FrDev& d, FrLds& L, uint32_t nQ, uint32_t abov
     // (INLINE) per-job records for fr_emit_kernel: A = H slot | P slot << 16 | degree << 28; B = coarse | ours << 1 | owner << 2 | depth << 5
     uint32_t* sJobA = d.jobRecA;
     uint16_t* sJobB = d.jobRecB;
+    // (replica) per job the lists its fits belong to, owner x class (0xFFFF: none): words 2048.. of sKey, behind the scans' 2048
+    uint16_t* sKeyH = reinterpret_cast<uint16_t*>(reinterpret_cast<uint32_t*>(sKey) + 2048);
+    uint16_t* sKeyP = sKeyH + kFrSort;
     {
         int jP[4], jDep[4];
         bool jCoarse[4];
@@ -631,7 +645,13 @@ __device__ void frBatchBody(const FrDev& d, FrLds& L, uint32_t nQ, uint32_t abov
             const bool ours = d.world == 1 || (int)o == d.rank;  // another rank's job: none of its fits here
             const int p = jP[q], dep = jDep[q];
             uint32_t slotH = 0, slotP = 0;
-            if (ours) {
+            if (d.replica) {
+                // every job takes its place in its OWNER's lists, and the same place on every rank -- the arena is laid out alike
+                // everywhere -- so not by an atomic's luck: the keys wait in LDS and one wave hands the slots out in job order (below)
+                const uint32_t none = 0xFFFFu, base = o * (uint32_t)kFrClasses;
+                sKeyH[j] = (uint16_t)((!jCoarse[q] && dep < kMaxDepth) ? base + (uint32_t)frClass(p, false, dep + 1) : none);
+                sKeyP[j] = (uint16_t)(jCoarse[q] ? base + (uint32_t)frClass(2, false, dep) : (p < kMaxDegree - 1 ? base + (uint32_t)frClass(p + 1, true, dep) : none));
+            } else if (ours) {
                 if (jCoarse[q]) {
                     slotP = atomicAdd(&sCount[frClass(2, false, dep)], 1u);  // :836-843
                 } else {
@@ -639,13 +659,46 @@ __device__ void frBatchBody(const FrDev& d, FrLds& L, uint32_t nQ, uint32_t abov
                     if (p < kMaxDegree - 1) slotP = atomicAdd(&sCount[frClass(p + 1, true, dep)], 1u);  // :846-851
                 }
             }
-            if (INLINE) {
+            if (INLINE || d.replica) {
                 sJobA[j] = slotH | (slotP << 16) | ((uint32_t)p << 28);
                 sJobB[j] = (uint16_t)((jCoarse[q] ? 1u : 0u) | (ours ? 2u : 0u) | (o << 2) | ((uint32_t)dep << 5));
             }
         }
     }
     __syncthreads();
+    if (d.replica && tid < 64) {
+        // 64 jobs at a time, in job order: the lanes that share a key take consecutive slots behind the key's running count
+        uint32_t* flat = &L.countO[0][0];
+        for (uint32_t j0 = 0; j0 < nJobs; j0 += 64u) {
+            const uint32_t j = j0 + tid;
+            uint32_t slots[2] = {0u, 0u};
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                const uint32_t key = j < nJobs ? (which == 0 ? sKeyH[j] : sKeyP[j]) : 0xFFFFu, step = which == 0 ? 8u : 1u;
+                bool pending = key != 0xFFFFu;
+                unsigned long long left = __ballot(pending);
+                while (left) {
+                    const uint32_t k0 = __shfl(key, __ffsll((long long)left) - 1, 64);
+                    const unsigned long long m = __ballot(pending && key == k0);
+                    const uint32_t before = flat[k0];
+                    if (pending && key == k0) slots[which] = before + step * (uint32_t)__popcll(m & ((1ull << tid) - 1ull));
+                    __builtin_amdgcn_wave_barrier();
+                    if (tid == (uint32_t)(__ffsll((long long)m) - 1)) flat[k0] = before + step * (uint32_t)__popcll(m);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    pending = pending && key != k0;
+                    left = __ballot(pending);
+                }
+            }
+            if (j < nJobs) sJobA[j] = (sJobA[j] & 0xF0000000u) | slots[0] | (slots[1] << 16);
+        }
+    }
+    __syncthreads();
+    if (d.replica) {  // this rank's own fits: its lists in the owner table
+        for (uint32_t c = tid; c < (uint32_t)kFrClasses; c += 1024) sCount[c] = L.countO[d.rank][c];
+        __syncthreads();
+    }
     FR_STAMP(4);
     for (uint32_t i = tid; i < 2048; i += 1024)
         if (sHist[i]) h->hist1[i] -= sHist[i];
@@ -727,6 +780,14 @@ __device__ void frBatchBody(const FrDev& d, FrLds& L, uint32_t nQ, uint32_t abov
         h->lowTasks[tid][1] = low;
         if (low) atomicAdd(reinterpret_cast<unsigned long long*>(&h->splitFits), (unsigned long long)low);
     }
+    if (d.replica && tid < (uint32_t)d.world) {  // owner tid's part of the round: its classes one after the other (a weighted fit owns a full array)
+        unsigned long long run = 0;
+        for (int c = 0; c < kFrClasses; ++c) {
+            R->cArenaO[tid][c] = run;
+            run += (unsigned long long)L.countO[tid][c] * frCoef(c / kFrDepths / 2);
+        }
+        L.rowsO[tid] = run;
+    }
     __syncthreads();  // (every thread has read the header's arenaUsed)
     if (tid == 0) {
         h->nJobs = nJobs, h->nTasks = nTasks, h->nBlocks = nBlocks;
@@ -734,6 +795,13 @@ __device__ void frBatchBody(const FrDev& d, FrLds& L, uint32_t nQ, uint32_t abov
         h->sampleUsed = smpAll;
         h->fits += nTasks, h->samples += smpAll;
         R->arenaBase = arenaBase;
+        if (d.replica) {
+            unsigned long long stride = 16;
+            for (int r = 0; r < d.world; ++r) stride = L.rowsO[r] > stride ? L.rowsO[r] : stride;
+            stride = (stride + 15ull) & ~15ull;  // equal parts, whole lines
+            h->roundBase = arenaBase, h->partStride = stride;
+            h->arenaUsed = arenaBase + (uint64_t)d.world * stride;
+        } else
         h->arenaUsed = arenaBase + rowsAll;
         if (!INLINE && d.world > 1) *frStatusSlotNext(d, d.rank) = 0.0;  // (inline: the leader, once nobody reads the closing round's errors any more)
     }
@@ -752,6 +820,7 @@ struct FrEmitLds {
     uint64_t tabArena[kFrClasses], tabSample[kFrClasses];
     uint32_t slice[9];
     uint64_t stage[16][64 * 7];
+    uint64_t tabArenaO[8][kFrClasses];  // FrDev::replica
 };
 __global__ __launch_bounds__(1024) void fr_emit_kernel(FrDev d) {
     const FrHdr* h = d.hdr;
@@ -765,7 +834,11 @@ __global__ __launch_bounds__(1024) void fr_emit_kernel(FrDev d) {
         E.tabArena[tid] = R->cArena[tid], E.tabSample[tid] = R->cSample[tid];
     }
     if (tid < 9) E.slice[tid] = h->sliceFirst[tid];
-    const uint64_t arenaBase = R->arenaBase;
+    if (d.replica)
+        for (uint32_t c = tid; c < 8u * (uint32_t)kFrClasses; c += 1024) (&E.tabArenaO[0][0])[c] = (&R->cArenaO[0][0])[c];
+    const uint64_t arenaBase = R->arenaBase, partStride = h->partStride;
+    // rows before slot 0 of class c in the round's part of the arena (replica: within owner o's part)
+    auto arenaOf = [&](uint32_t o, int c) { return d.replica ? arenaBase + (uint64_t)o * partStride + E.tabArenaO[o][c] : arenaBase + E.tabArena[c]; };
     const int wv = (int)(tid >> 6);
     uint64_t* tasks64 = reinterpret_cast<uint64_t*>(d.tasks);
     auto word2 = [](float lo, float hi) { return (uint64_t)__float_as_uint(lo) | ((uint64_t)__float_as_uint(hi) << 32); };
@@ -802,7 +875,7 @@ __global__ __launch_bounds__(1024) void fr_emit_kernel(FrDev d) {
             }
             uint64_t w[7];
             w[0] = word2(mn[0], mn[1]), w[1] = word2(mn[2], mx[0]), w[2] = word2(mx[1], mx[2]);
-            w[3] = arenaBase + E.tabArena[c] + (uint64_t)(slot0 + (uint32_t)k) * rows;  // outOff
+            w[3] = arenaOf((jb >> 2) & 7u, c) + (uint64_t)(slot0 + (uint32_t)k) * rows;  // outOff
             w[4] = ~0ull;                                                                // copyOff
             w[5] = E.tabSample[c] + (uint64_t)(slot0 + (uint32_t)k) * nq * nq * nq;      // sampleOff
             w[6] = (uint64_t)(frErrSlotNext(d, E.slice, (jb >> 2) & 7u, liveH ? jH : 0u) + 1u + (uint32_t)k) | ((uint64_t)(dep + 1) << 32) | ((uint64_t)p << 40);
@@ -812,12 +885,15 @@ __global__ __launch_bounds__(1024) void fr_emit_kernel(FrDev d) {
             const int p = (int)(pa >> 28), dep = (int)(pb >> 5);
             const bool coarse = (pb & 1u) != 0, ours = (pb & 2u) != 0;
             const bool hasH = liveP && ours && !coarse && dep < kMaxDepth, hasP = liveP && ours && (coarse || p < kMaxDegree - 1);
+            // (replica: where ANY rank's results will lie -- the update notes them for every job)
+            const bool anyH = liveP && (ours || d.replica) && !coarse && dep < kMaxDepth, anyP = liveP && (ours || d.replica) && (coarse || p < kMaxDegree - 1);
+            const uint32_t owner = (pb >> 2) & 7u;
             const int deg = coarse ? 2 : (p + 1 <= kMaxDegree ? p + 1 : kMaxDegree);
             const bool incr = !coarse;
             const int c = frClass(deg, incr, dep), cH = frClass(p, false, dep + 1 <= kMaxDepth ? dep + 1 : kMaxDepth);
             const uint32_t slot = (pa >> 16) & 4095u;
             const uint64_t rows = (incr && !d.weighted) ? frCoef(deg) - frCoef(deg - 1) : frCoef(deg), nq = 4 * (uint64_t)deg + 1;
-            const uint64_t outP = arenaBase + E.tabArena[c] + (uint64_t)slot * rows;
+            const uint64_t outP = arenaOf(owner, c) + (uint64_t)slot * rows;
             uint64_t w[7];
             w[0] = word2(pn[0], pn[1]), w[1] = word2(pn[2], px[0]), w[2] = word2(px[1], px[2]);
             w[3] = outP;
@@ -827,8 +903,8 @@ __global__ __launch_bounds__(1024) void fr_emit_kernel(FrDev d) {
             w[6] = (uint64_t)frErrSlotNext(d, E.slice, (pb >> 2) & 7u, liveP ? jP : 0u) | ((uint64_t)dep << 32) | ((uint64_t)deg << 40);
             frStoreRecords(E.stage[wv], tasks64, w, ((uint64_t)E.tabTask[c] + slot) * 7u, hasP, false);
             if (liveP) {
-                d.wJobP[jP] = hasP ? outP : ~0ull;
-                d.wJobH[jP] = hasH ? arenaBase + E.tabArena[cH] + (uint64_t)(pa & 0xFFFFu) * frCoef(p) : ~0ull;
+                d.wJobP[jP] = anyP ? outP : ~0ull;
+                d.wJobH[jP] = anyH ? arenaOf(owner, cH) + (uint64_t)(pa & 0xFFFFu) * frCoef(p) : ~0ull;
             }
         }
     }
@@ -902,9 +978,16 @@ __global__ __launch_bounds__(256) void fr_tasks_kernel(FrDev d) {
         const int depth = k < 8 ? dep + 1 : dep;
         const int c = frClass(deg, incr, depth);
         uint32_t slot = 0;
-        if (mine && (k == 0 || k == 8)) slot = atomicAdd(&R->cCursor[c], k == 0 ? 8u : 1u);
-        slot = __shfl(slot, (lane & ~15) | (k < 8 ? 0 : 8), 64) + (k < 8 ? (uint32_t)k : 0u);
+        if (d.replica) {  // (the batch has noted every job's slots in its owner's lists: d.jobRecA)
+            const uint32_t ja = d.jobRecA[live ? j : 0];
+            slot = k < 8 ? (ja & 0xFFFFu) + (uint32_t)k : (ja >> 16) & 4095u;
+        } else {
+            if (mine && (k == 0 || k == 8)) slot = atomicAdd(&R->cCursor[c], k == 0 ? 8u : 1u);
+            slot = __shfl(slot, (lane & ~15) | (k < 8 ? 0 : 8), 64) + (k < 8 ? (uint32_t)k : 0u);
+        }
         uint64_t outOff = ~0ull;
+        if (d.replica && live && k <= 8 && (k < 8 ? (!coarse && dep < kMaxDepth) : (coarse || p < kMaxDegree - 1)))
+            outOff = arenaBase + (uint64_t)owner * h->partStride + R->cArenaO[owner][c] + (uint64_t)slot * frCoef(deg);
         if (mine) {
             const uint64_t rows = (incr && !d.weighted) ? frCoef(deg) - frCoef(deg - 1) : frCoef(deg);
             const uint64_t nq = 4 * (uint64_t)deg + 1;
@@ -918,7 +1001,7 @@ __global__ __launch_bounds__(256) void fr_tasks_kernel(FrDev d) {
                     t.bmin[a] = n.aabb_min[a], t.bmax[a] = n.aabb_max[a];
                 }
             }
-            outOff = arenaBase + R->cArena[c] + (uint64_t)slot * rows;
+            if (!d.replica) outOff = arenaBase + R->cArena[c] + (uint64_t)slot * rows;
             t.outOff = outOff;
             // weighted incremental fit: the cell's current array (one segment: the update keeps it that way), :847
             t.copyOff = (d.weighted && incr) ? (d.segOff[(size_t)d.batchIdx[j] * kFrSegs] & kOffMask) : ~0ull;
@@ -1117,7 +1200,7 @@ __device__ void frUpdateJobs(const FrDev& d, FrLds& L) {
             // (weighted: the new array holds every row, so it is the node's one and only segment)
             const int first = (coarse || d.weighted) ? np : (int)d.segFirst[idx];
             if (coarse || d.weighted) d.segFirst[idx] = (uint8_t)np;
-            d.segOff[(size_t)idx * kFrSegs + (np - first)] = (d.jobP[j] & kOffMask) | ((uint64_t)owner << 56);
+            d.segOff[(size_t)idx * kFrSegs + (np - first)] = (d.jobP[j] & kOffMask) | ((uint64_t)(d.replica ? 0u : owner) << 56);
             d.nodes[idx].degree = (uint8_t)np;
             const uint64_t bits = (uint64_t)__double_as_longlong(pErr);
             d.qErr[idx] = bits;
@@ -1146,7 +1229,7 @@ __device__ void frUpdateJobs(const FrDev& d, FrLds& L) {
             d.parent[ch] = idx;
             d.sub[ch] = 0;
             d.segFirst[ch] = (uint8_t)p;
-            d.segOff[(size_t)ch * kFrSegs] = ((d.jobH[j] + (uint64_t)sub * frCoef(p)) & kOffMask) | ((uint64_t)owner << 56);
+            d.segOff[(size_t)ch * kFrSegs] = ((d.jobH[j] + (uint64_t)sub * frCoef(p)) & kOffMask) | ((uint64_t)(d.replica ? 0u : owner) << 56);
             const uint64_t bits = (uint64_t)__double_as_longlong(e);
             d.qErr[ch] = bits;
             atomicAdd(&L.hist[frDigit(0, bits, ch)], 1u);
@@ -1558,7 +1641,7 @@ __global__ __launch_bounds__(256) void fr_store_kernel(FrDev d) {
         const uint32_t r0 = sg == 0 ? 0u : frCoef(first + sg - 1);
         const uint64_t so = d.segOff[(size_t)node * kFrSegs + sg];
         // one rank: straight from the arena; several: from the all-gathered pack buffers (fr_pack_kernel)
-        const double* src = d.world == 1 ? d.arena + (so & kOffMask) : d.pack + (size_t)(so >> 56) * d.packStride + d.packPos[(size_t)node * kFrSegs + sg];
+        const double* src = (d.world == 1 || d.replica) ? d.arena + (so & kOffMask) : d.pack + (size_t)(so >> 56) * d.packStride + d.packPos[(size_t)node * kFrSegs + sg];
         d.store[(size_t)sStart[lo] + r] = src[r - r0];
     }
     __threadfence_system();
@@ -1664,14 +1747,14 @@ __global__ void fr_means_done_kernel(FrDev d, uint32_t stamp) {
     f[1] = stamp;
     __threadfence_system();
 }
-__global__ __launch_bounds__(256) void fr_weigh_kernel(FrDev d, uint32_t stride) {  // stride 9: every error of a job; round 0: the first only
+// (base, count: this rank's run of error slots -- on one rank all of them, from 0; on several, rank r's part of the errors)
+__global__ __launch_bounds__(256) void fr_weigh_kernel(FrDev d, uint32_t stride, uint32_t base, uint32_t count) {  // stride 9: every error of a job; round 0: the first only
     const FrHdr* h = d.hdr;
     if (h->done) return;
-    const uint32_t nJobs = h->nJobs;
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= nJobs * 9u) return;
+    if (i >= count) return;
     if (stride == 1u && i % 9u != 0u) return;
-    d.errs[i] = d.errs[i] * d.weights[i];
+    d.errs[base + i] = d.errs[base + i] * d.weights[base + i];
 }
 
 // per-build initialisation: the uniformly refined tree (a copy of the context's template) and the header.  Round 0's
@@ -1768,7 +1851,7 @@ struct FrontierWorkspace {
     uint32_t flagStamp = 0;
     hipError_t ensureWeighting() {
         if (hostMeans) return hipSuccess;
-        const size_t n = (size_t)kFrJobs * HPSDF_JOB_HEADER_DOUBLES;
+        const size_t n = 8 * ((size_t)kFrJobs * HPSDF_JOB_HEADER_DOUBLES + kFrStatusPad);  // (indexed like errs: up to eight ranks' parts)
         hipError_t e = hipHostMalloc((void**)&hostMeans, n * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped);
         if (e == hipSuccess) e = hipHostMalloc((void**)&hostWeights, n * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped);
         if (e == hipSuccess) e = hipHostMalloc((void**)&hostFlag, 64, hipHostMallocCoherent | hipHostMallocMapped);
@@ -1841,7 +1924,8 @@ struct FrontierWorkspace {
     FitTask* r0Tasks = nullptr;
     FitBlock* r0Blocks = nullptr;
     uint64_t* r0JobP = nullptr;
-    int r0Rank = -1, r0World = -1;  // what (rank, world, error stride) the three r0 arrays were built for
+    int r0Rank = -1, r0World = -1;  // what (rank, world, error stride, replica) the three r0 arrays were built for
+    bool r0Replica = false;
     uint32_t r0ErrStride = 0;
     std::vector<FitTask> hostTmplTasks, hostR0Tasks;
     hipError_t ensureRanks(int world, hipStream_t s) {
@@ -2080,15 +2164,16 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
     if (weighted) {
         if (cfg.weighting_type > 2) return fail(HPSDF_ERR_INVALID_ARGUMENT, "unknown nearnessWeighting.type");
         if (!(cfg.weighting_strength > 0.0)) return fail(HPSDF_ERR_INVALID_ARGUMENT, "nearnessWeighting.strength must be > 0");
-        // (on several ranks a weighted incremental fit needs the node's previous rows, which another rank may hold: the
-        // host scheduler's sharded rounds exchange them, capi.cpp)
-        if (world > 1) return fail(HPSDF_ERR_UNSUPPORTED, "weighted builds on several ranks run the host scheduler's rounds");
         const hipError_t e = ws->ensureWeighting();
         if (e != hipSuccess) return hipFail(e, "frontier weighting buffers");
     }
     ws->d.K = Kj;
     ws->d.rank = rank, ws->d.world = world;
     ws->d.weighted = weighted ? 1 : 0;
+    // (on several ranks a weighted incremental fit needs the node's previous rows, which another rank may have fitted: the arenas are
+    // replicas of each other then -- FrDev::replica)
+    const bool replica = weighted && world > 1;
+    ws->d.replica = replica ? 1 : 0;
     ws->d.fastFit = (ctx->fitMode == HPSDF_FIT_FAST && field->kind != kHostTreeCsg && !weighted) ? 1 : 0;
     const bool splitMode = ctx->fitMode == HPSDF_FIT_SPLIT && !weighted;
     ws->d.splitFit = 0;
@@ -2109,6 +2194,23 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
     // rank's share fails while one is pending, it still enters that exchange -- with its status slot set (kFrStatusPad) -- before
     // it returns its error: the others then leave with HPSDF_ERR_STATE instead of waiting for a rank that has gone.
     int phase = 0;
+    // replica: the round's part of the arena while its exchange is still to come -- a failing rank enters it too, so round 0's part is
+    // known before anything can fail (it depends on the template and the world size alone: equal runs of cells, builderSelect's cut)
+    double* arenaPart = nullptr;
+    size_t arenaPartBytes = 0;
+    if (replica) {
+        const uint64_t nL = ws->tmpl.nLeaves;
+        uint32_t start = 0, maxCount = 1;
+        for (int r = 0; r < world; ++r) {
+            uint32_t end = (uint32_t)nL;
+            const uint64_t c = (uint64_t)frCoef(2) * 729ull, total = c * nL;  // (the cut of the round-0 section below)
+            if (r + 1 < world) end = std::min<uint32_t>(std::max<uint32_t>((uint32_t)((total * (uint64_t)(r + 1) / (uint64_t)world + c - 1) / c), start), (uint32_t)nL);
+            maxCount = std::max(maxCount, end - start);
+            start = end;
+        }
+        arenaPart = ws->arena;
+        arenaPartBytes = (size_t)((((uint64_t)maxCount * frCoef(2)) + 15ull) & ~15ull) * sizeof(double);
+    }
 #ifdef HPSDF_TEST_HOOKS  // (lib/libhpsdf_hooks.so, built for tests/: the production library does not look at the variable)
     const char* injected = std::getenv("HPSDF_TEST_FAIL_RANK");  // "<rank>:<round>"
 #else
@@ -2168,7 +2270,9 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
     // host memory) -> the weight, with the HOST's pow / exp (Octree.cpp:1224-1226, :1246: the libm the oracle and the host
     // scheduler call; a device pow would have to match it bit for bit) -> error * weight on the device (:1078-1086).
     // Everything else of the round -- selection, tasks, decision, bookkeeping, packing -- stays where it is.
-    auto applyWeights = [&](const FitBlock* blocks, uint32_t maxBlocks, size_t lds, const FitTask* tasks, const uint32_t* dCount, bool round0) -> int {
+    // (base, nMine: this rank's run of error slots and its jobs of the round)
+    auto applyWeights = [&](const FitBlock* blocks, uint32_t maxBlocks, size_t lds, const FitTask* tasks, const uint32_t* dCount, bool round0, uint32_t base,
+                            uint32_t nMine) -> int {
         HPSDF_HIP(launchFitWeight(s, blocks, maxBlocks, lds, tasks, ws->arena, d.means, ctx->dTables, dCount));
         const uint32_t stamp = ++ws->flagStamp;
         FR_LAUNCH(fr_means_done_kernel, dim3(1), dim3(64), s, d, stamp);
@@ -2183,10 +2287,10 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         }
         const double tw = now();
         tSync += tw - ts;
-        const uint32_t nJobs = std::min<uint32_t>(ws->hostFlag[0], kFrJobs);
+        const uint32_t nJobs = world == 1 ? std::min<uint32_t>(ws->hostFlag[0], kFrJobs) : std::min<uint32_t>(nMine, kFrJobs);
         const double dd = std::sqrt(3.0), strength = cfg.weighting_strength;
-        const double* mean = ws->hostMeans;
-        double* w = ws->hostWeights;
+        const double* mean = ws->hostMeans + base;
+        double* w = ws->hostWeights + base;
         const uint32_t step = round0 ? 9u : 1u;  // round 0: every job is a coarse cell with one fit (slot 0 of its nine)
         for (uint32_t i = 0; i < nJobs * 9u; i += step) {
             if (cfg.weighting_type == 1) {
@@ -2198,7 +2302,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         }
         std::atomic_thread_fence(std::memory_order_release);
         tWeights += now() - tw;
-        FR_LAUNCH(fr_weigh_kernel, dim3((std::max(1u, nJobs) * 9u + 255u) / 256u), dim3(256), s, d, round0 ? 1u : 9u);
+        FR_LAUNCH(fr_weigh_kernel, dim3((std::max(1u, nJobs) * 9u + 255u) / 256u), dim3(256), s, d, round0 ? 1u : 9u, base, nJobs * 9u);
         return HPSDF_OK;
     };
     uint8_t* early = nullptr;  // the block of a build that stops after round 0, begun before the device has finished
@@ -2213,6 +2317,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
     const FitBlock* r0Blocks = ws->tmplBlocks;
     const uint64_t* r0JobP = ws->tmplJobP;
     size_t r0Lds = ws->tmplLds;
+    uint64_t part0 = 0;  // replica: doubles per rank in round 0's part of the arena
     T0.sliceFirst[0] = 0;
     for (int r = 1; r < 9; ++r) T0.sliceFirst[r] = T.nLeaves;
     if (world > 1) {
@@ -2233,18 +2338,25 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         int g = 1, pl = 1;
         frShape(2, false, std::max(1u, count), &g, &pl);
         const uint32_t nBl = (count + (uint32_t)g - 1u) / (uint32_t)g;
-        // this rank's task list, workgroup list and job -> arena map of round 0 depend on (rank, world, error stride) alone:
+        // (replica: rank r's cells at r x part0 -- equal parts for the in-place all-gather -- and every cell's place known everywhere)
+        uint32_t maxCount = 1;
+        for (int r = 0; r < world; ++r) maxCount = std::max(maxCount, T0.sliceFirst[r + 1] - T0.sliceFirst[r]);
+        part0 = ((uint64_t)maxCount * frCoef(2) + 15ull) & ~15ull;
+        // this rank's task list, workgroup list and job -> arena map of round 0 depend on (rank, world, error stride, replica) alone:
         // built and uploaded once, kept on the device for the Creates that follow (no upload, no wait per Create)
-        if (ws->r0Rank != rank || ws->r0World != world || ws->r0ErrStride != ws->d.errStride) {
+        if (ws->r0Rank != rank || ws->r0World != world || ws->r0ErrStride != ws->d.errStride || ws->r0Replica != replica) {
             std::vector<FitTask>& tk = ws->hostR0Tasks;
             tk.assign(ws->hostTmplTasks.begin() + first, ws->hostTmplTasks.begin() + first + count);
             std::vector<uint64_t> jobP(T.nLeaves, ~0ull & kOffMask);
             for (uint32_t q = 0; q < count; ++q) {
-                tk[q].outOff = (uint64_t)q * frCoef(2);
+                tk[q].outOff = (replica ? (uint64_t)rank * part0 : 0ull) + (uint64_t)q * frCoef(2);
                 tk[q].sampleOff = (uint64_t)q * 729;
                 tk[q].errSlot = (uint32_t)rank * ws->d.errStride + q * HPSDF_JOB_HEADER_DOUBLES;
                 jobP[first + q] = tk[q].outOff;
             }
+            if (replica)
+                for (int r = 0; r < world; ++r)
+                    for (uint32_t j = T0.sliceFirst[r]; j < T0.sliceFirst[r + 1]; ++j) jobP[j] = (uint64_t)r * part0 + (uint64_t)(j - T0.sliceFirst[r]) * frCoef(2);
             std::vector<FitBlock> bl(nBl);
             for (uint32_t k = 0; k < bl.size(); ++k) {
                 FitBlock& fb = bl[k];
@@ -2261,12 +2373,12 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
             HPSDF_HIP(hipMemcpyAsync(ws->r0Blocks, bl.data(), bl.size() * sizeof(FitBlock), hipMemcpyHostToDevice, s));
             HPSDF_HIP(hipMemcpyAsync(ws->r0JobP, jobP.data(), jobP.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s));
             HPSDF_HIP(hipStreamSynchronize(s));  // (pageable sources)
-            ws->r0Rank = rank, ws->r0World = world, ws->r0ErrStride = ws->d.errStride;
+            ws->r0Rank = rank, ws->r0World = world, ws->r0ErrStride = ws->d.errStride, ws->r0Replica = replica;
         }
         r0Tasks = ws->r0Tasks, r0Blocks = ws->r0Blocks, r0JobP = ws->r0JobP;
         r0Lds = frLds(2, g, pl);
         T0.nTasks = count, T0.nBlocks = nBl;
-        T0.arenaRows = (uint64_t)count * frCoef(2), T0.samples = (uint64_t)count * 729;
+        T0.arenaRows = replica ? (uint64_t)world * part0 : (uint64_t)count * frCoef(2), T0.samples = (uint64_t)count * 729;
     }
     // ---- what a round needs beyond its lists
     // (later rounds have at most K jobs: smaller parts to all-gather than round 0's 4096)
@@ -2283,7 +2395,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
     auto prepareNext = [&](uint32_t knownNodes, uint64_t knownArena, uint32_t knownMaxDeg) -> int {
         const int degBound = (int)std::min<uint32_t>(knownMaxDeg + 1u, kMaxDegree);
         hipError_t e = ws->ensureNodes(knownNodes + 8u * Kj, s);
-        if (e == hipSuccess) e = ws->ensureArena(knownArena + (uint64_t)Kj * rowsPerJob(degBound), knownArena, s);
+        if (e == hipSuccess) e = ws->ensureArena(knownArena + (replica ? (uint64_t)world * ((uint64_t)Kj * rowsPerJob(degBound) + 16) : (uint64_t)Kj * rowsPerJob(degBound)), knownArena, s);
         if (e != hipSuccess) return hipFail(e, "frontier buffers");
         splitOpen = splitMode && degBound >= ctx->splitMinDegree;
         samplesTooLarge = false;
@@ -2357,7 +2469,8 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
             size_t lds = 0;
             for (int deg = 2; deg <= degHi; ++deg) lds = std::max(lds, fitLdsTable[deg]);
             int rcw;
-            if ((rcw = applyWeights(d.blocks, taskBound, lds, d.tasks, &d.hdr->nBlocks, false))) return rcw;
+            const uint32_t mine = world == 1 ? 0u : hh->sliceFirst[rank + 1] - hh->sliceFirst[rank];  // (one rank: the device says how many)
+            if ((rcw = applyWeights(d.blocks, taskBound, lds, d.tasks, &d.hdr->nBlocks, false, world == 1 ? 0u : (uint32_t)rank * strideK, mine))) return rcw;
         }
         return HPSDF_OK;
     };
@@ -2406,7 +2519,15 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         }
         // (one rank: the rows also go straight into pinned host memory -- if the build stops after this round they are its packed store)
         HPSDF_HIP(launchFit(s, 2, 1, r0Blocks, T0.nBlocks, r0Lds, r0Tasks, ws->arena, d.errs, world == 1 ? ws->pinnedDev : nullptr, ctx->dTables, fdr, rm));
-        if (weighted && (rc = applyWeights(r0Blocks, T0.nBlocks, r0Lds, r0Tasks, nullptr, true))) return rc;
+        if (weighted && (rc = applyWeights(r0Blocks, T0.nBlocks, r0Lds, r0Tasks, nullptr, true, world == 1 ? 0u : (uint32_t)rank * stride0,
+                                           T0.sliceFirst[rank + 1] - T0.sliceFirst[rank])))
+            return rc;
+        if (replica) {
+            arenaPart = ws->arena;
+            if (arenaPartBytes != (size_t)part0 * sizeof(double)) return fail(HPSDF_ERR_STATE, "frontier: round 0's part of the arena");
+            if ((rc = exchange(arenaPart, arenaPartBytes, "round 0's rows"))) return rc;
+            arenaPart = nullptr;
+        }
         if ((rc = exchange(d.errs, (size_t)stride0 * sizeof(double), "round 0"))) return rc;
         phase = 0;
         d.errStride = strideK;  // (of the exchange that comes next: where a failing rank leaves its status)
@@ -2492,7 +2613,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
                 stats->rounds = hh->round, stats->jobs = hh->jobs, stats->p_refines = hh->pRefines, stats->h_refines = hh->hRefines;
                 stats->dropped = hh->dropped, stats->fits = hh->fits, stats->samples = hh->samples;
                 stats->n_nodes = hh->nNodes, stats->n_leaves = hh->nLeaves, stats->n_coeffs = hh->nCoeffs, stats->total_error = hh->total;
-                stats->fit_mode = (uint64_t)ctx->fitMode, stats->split_fits = hh->splitFits;
+                stats->fit_mode = (uint64_t)ctx->fitMode, stats->split_fits = hh->splitFits, stats->device_frontier = 1;
             }
             if (trace) std::fprintf(stderr, "[frontierCreate] us: total %.0f (waiting for the device %.0f, stopped after round 0)\n", now() - t0, tSync);
             return HPSDF_OK;
@@ -2505,6 +2626,9 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
             return fail(HPSDF_ERR_INVALID_ARGUMENT, "the field is not a finite number at some sample point (the build's total error is NaN or infinite)");
         knownNodes = hh->nNodes, knownMaxDeg = hh->maxDegree, knownArena = hh->arenaUsed;
         if (world > 1) phase = 2;
+        // (replica: the round's rows are exchanged too -- from here on a rank that fails enters that exchange as well.  With the grid
+        // selection the part is known only when the batch kernel has run: below)
+        if (replica && pre) arenaPart = ws->arena + hh->roundBase, arenaPartBytes = (size_t)hh->partStride * sizeof(double);
         if (injectedFailure(rounds)) return fail(HPSDF_ERR_OUT_OF_MEMORY, "injected failure (HPSDF_TEST_FAIL_RANK)");
         if (mesh && tooLargeCur) return fail(HPSDF_ERR_UNSUPPORTED, "round too large for the sampled mesh path");
         if (pre && !blind) {
@@ -2518,11 +2642,19 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
             FR_LAUNCH(fr_select_kernel, dim3(std::min<uint32_t>(512u, (knownNodes + 255u) / 256u)), dim3(256), s, dl);
             FR_LAUNCH(fr_batch_kernel, dim3(1), dim3(1024), s, dl);
             FR_LAUNCH(fr_tasks_kernel, dim3((16u * Kj + 255u) / 256u), dim3(256), s, dl);
+            // (replica: where the round's part of the arena lies is the batch kernel's decision, and the exchange below needs it)
+            if (replica) HPSDF_HIP(hipMemcpy(ws->hostHdr, d.hdr, kFrHdrCopyBytes, hipMemcpyDeviceToHost));
         }
         // capacities of the launch that closes this round; the arena may move: nothing that writes it is in flight
-        if ((rc = prepareNext(knownNodes, knownArena + (pre ? 0ull : (uint64_t)Kj * rowsPerJob((int)knownMaxDeg)), knownMaxDeg))) return rc;
+        if ((rc = prepareNext(knownNodes, knownArena + (pre ? 0ull : (uint64_t)(replica ? world : 1) * ((uint64_t)Kj * rowsPerJob((int)knownMaxDeg) + 16)), knownMaxDeg))) return rc;
         d.splitFit = dk.splitFit;
+        if (replica) arenaPart = ws->arena + hh->roundBase, arenaPartBytes = (size_t)hh->partStride * sizeof(double);  // (the arena may have moved)
         if (!blind && (rc = launchRoundFits(knownMaxDeg, splitCur))) return rc;
+        if (replica) {
+            arenaPart = ws->arena + hh->roundBase;  // (the arena may have moved)
+            if ((rc = exchange(arenaPart, arenaPartBytes, "a round's rows"))) return rc;
+            arenaPart = nullptr;
+        }
         if (frSyncEveryLaunch()) std::fprintf(stderr, "[frontier] fits of round %d ... %s\n", rounds, hipGetErrorString(hipStreamSynchronize(s)));
         if ((rc = exchange(d.errs, (size_t)strideK * sizeof(double), "a round's errors"))) return rc;
         phase = 0;
@@ -2536,7 +2668,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         if (e != hipSuccess) return hipFail(e, "block staging");
         d.store = ws->pinnedDev;
         FR_LAUNCH(fr_subtree_kernel, dim3(((uint32_t)nn + 255u) / 256u), dim3(256), s, d);
-        if (world > 1) {
+        if (world > 1 && !replica) {
             // the packed store from one all-gather of the ranks' pack buffers (each rank's own segments in node order)
             FR_LAUNCH(fr_packpos_kernel, dim3(1), dim3(1024), s, d);
             HPSDF_HIP(hipStreamSynchronize(s));
@@ -2586,7 +2718,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         stats->rounds = hh->round, stats->jobs = hh->jobs, stats->p_refines = hh->pRefines, stats->h_refines = hh->hRefines;
         stats->dropped = hh->dropped, stats->fits = hh->fits, stats->samples = hh->samples;
         stats->n_nodes = nn, stats->n_leaves = hh->nLeaves, stats->n_coeffs = nc, stats->total_error = hh->total;
-        stats->fit_mode = (uint64_t)ctx->fitMode, stats->split_fits = hh->splitFits;
+        stats->fit_mode = (uint64_t)ctx->fitMode, stats->split_fits = hh->splitFits, stats->device_frontier = 1;
     }
     hipLaunchKernelGGL(fr_init_kernel, dim3((T.nNodes + 255) / 256), dim3(256), 0, s, initDev(), T0);  // for the next build
     ws->clean = hipGetLastError() == hipSuccess, ws->cleanRank = rank, ws->cleanWorld = world;
@@ -2600,6 +2732,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         const std::string own = hpsdf_last_error();
         const size_t stride = ws->d.errStride;
         const unsigned long long ones = ~0ull;
+        if (arenaPart) (void)gather(gatherUser, ws->arena + (arenaPart - ws->arena), arenaPartBytes, (void*)s);  // (replica: the others exchange the round's rows first)
         if (hipMemcpyAsync(ws->d.errs + (size_t)rank * stride + (stride - 1), &ones, sizeof ones, hipMemcpyHostToDevice, s) == hipSuccess)
             (void)gather(gatherUser, ws->d.errs, stride * sizeof(double), (void*)s);
         (void)hipStreamSynchronize(s);

@@ -310,6 +310,7 @@ typedef struct hpsdf_build_stats {
     uint64_t fit_mode;   /* HPSDF_FIT_* the build ran in */
     uint64_t split_fits; /* from-scratch fits whose rows below the top degree came from the sum-factorised / matrix-core kernel (HPSDF_FIT_SPLIT,
                             degree >= split_min_degree); 0: every coefficient is the bit-exact kernel's */
+    uint64_t device_frontier; /* 1: selection, decision and bookkeeping ran on the device (csrc/frontier.hip); 0: the host scheduler's rounds */
 } hpsdf_build_stats;
 
 HPSDF_API int hpsdf_build_begin(const hpsdf_config* cfg, const hpsdf_build_opts* opts, hpsdf_build** out);

@@ -271,6 +271,30 @@ def test_a_failing_rank_takes_the_others_out_with_it(weighted, fail_at):
     assert r.returncode == 0 and "failing-rank case ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+@pytest.mark.parametrize("wtype,strength,target", [(1, 3.0, 1e-8), (2, 3.0, 1e-10)])
+def test_weighted_build_sharded_through_the_device_frontier(H, ctx, wtype, strength, target):
+    """Nearness-weighted builds (the reference's own test and benchmark configuration, HPUnitTests.cpp:53-58, HPBenchmarks.cpp:34-39) on
+    several ranks run the device-side frontier too (round 5): an incremental weighted fit carries the cell's previous rows over
+    (Octree.cpp:847), which any rank may have fitted, so the ranks' arenas are replicas -- a round's fits laid out owner by owner at
+    the same offsets everywhere, one in-place all-gather of the round's part beside the errors' (FrDev::replica).  Every rank's block
+    is the single-rank block; the statistics say which scheduler ran."""
+    import time
+    cfg = H.make_config(target)
+    cfg.nearnessWeighting_type, cfg.nearnessWeighting_strength = wtype, strength
+    t0 = time.perf_counter()
+    one, st1 = H.create_block(ctx, cfg, H.Field.sphere(), 1024)
+    t1 = time.perf_counter()
+    assert st1["device_frontier"] == 1
+    for world in (2, 4):
+        ta = time.perf_counter()
+        out = _create_on_simulated_ranks(H, world, cfg, lambda c: H.Field.sphere(), 1024)
+        tb = time.perf_counter()
+        for blk, st in out:
+            assert blk == one and st["device_frontier"] == 1 and st["rounds"] == st1["rounds"] and st["jobs"] == st1["jobs"]
+        print("weighted sphere @ %g: one rank %.1f ms, %d simulated ranks (threads on one GPU, contexts and fields included) %.1f ms"
+              % (target, (t1 - t0) * 1e3, world, (tb - ta) * 1e3))
+
+
 def test_the_production_library_ignores_the_fault_injection_variable(H, ctx, monkeypatch):
     monkeypatch.setenv("HPSDF_TEST_FAIL_RANK", "1:0")
     cfg = H.make_config(1e-6)
@@ -624,7 +648,8 @@ def test_split_mode_schedulers_agree_byte_for_byte(H, monkeypatch, target, K):
     want, swant = H.create_block(c, H.make_config(target), f, K)
     monkeypatch.setenv("HPSDF_HOST_FRONTIER", "0")
     got, sgot = H.create_block(c, H.make_config(target), f, K)
-    assert got == want and sgot == swant
+    assert got == want and swant["device_frontier"] == 0 and sgot["device_frontier"] == 1
+    assert all(sgot[k] == swant[k] for k in sgot if k != "device_frontier")
     assert sgot["fit_mode"] == H.FIT_SPLIT and sgot["split_fits"] > 0
     c.set_fast_fit(False)
     assert c.fit_mode() == H.FIT_EXACT
@@ -891,7 +916,7 @@ def test_fast_fit_within_tolerance_of_oracle(H, O, name, target):
 
 def _same_stats(x, y):
     """build statistics but for the two that name the fit mode (hpsdf_build_stats::fit_mode, split_fits)"""
-    return all(x[k] == y[k] for k in x if k not in ("fit_mode", "split_fits"))
+    return all(x[k] == y[k] for k in x if k not in ("fit_mode", "split_fits", "device_frontier"))
 
 
 @pytest.mark.parametrize("name,target,K", [("union3", 1e-8, 1024), ("sphere", 1e-9, 1024), ("union3", 1e-7, 256)])
