@@ -109,6 +109,7 @@ _SIGNATURES = {
     "hpsdf_ctx_set_fit_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "hpsdf_ctx_get_fit_mode": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "hpsdf_ctx_set_split_min_degree": (C.c_int, [C.c_void_p, C.c_int]),
+    "hpsdf_ctx_set_block_allocator": (None, [C.c_void_p] * 4),
     "hpsdf_field_release_host_copies": (C.c_int, [C.c_void_p]),
     "hpsdf_set_mesh_face_rule": (None, [C.c_int]),
     "hpsdf_get_mesh_face_rule": (C.c_int, []),
@@ -306,6 +307,14 @@ def make_config(target=1e-10, root_min=(-0.5, -0.5, -0.5), root_max=(0.5, 0.5, 0
     return c
 
 
+BLOCK_ALLOC = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
+BLOCK_RELEASE = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+_bytes_new = C.pythonapi.PyBytes_FromStringAndSize  # (NULL, n): an uninitialised bytes object of n bytes, ours alone until returned
+_bytes_new.restype, _bytes_new.argtypes = C.py_object, [C.c_void_p, C.c_ssize_t]
+_bytes_ptr = C.pythonapi.PyBytes_AsString
+_bytes_ptr.restype, _bytes_ptr.argtypes = C.c_void_p, [C.py_object]
+
+
 class Context:
     """One GPU + one HIP stream.  stream: raw hipStream_t (int) or None for a library-owned one."""
 
@@ -313,6 +322,33 @@ class Context:
         self.handle = C.c_void_p()
         check(lib().hpsdf_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self.handle)))
         self.device = device
+        # Create writes its block straight into a bytes object (hpsdf_ctx_set_block_allocator): no second copy of the block
+        self._blocks = {}
+
+        def _alloc(size, _user, held=self._blocks):
+            try:
+                obj = _bytes_new(None, size)
+                ptr = _bytes_ptr(obj)
+                held[ptr] = obj
+                return ptr
+            except BaseException:  # noqa: BLE001 -- must not propagate through the C frames: NULL fails the build
+                return None
+
+        def _release(ptr, _user, held=self._blocks):
+            held.pop(ptr, None)
+
+        self._alloc_cb, self._release_cb = BLOCK_ALLOC(_alloc), BLOCK_RELEASE(_release)
+        lib().hpsdf_ctx_set_block_allocator(self.handle, C.cast(self._alloc_cb, C.c_void_p), C.cast(self._release_cb, C.c_void_p), None)
+
+    def _take_block(self, blk, size):
+        """The bytes object behind a block pointer Create returned (or a copy of a malloc'd block)."""
+        obj = self._blocks.pop(blk.value, None)
+        if obj is not None and len(obj) == size:
+            return obj
+        data = C.string_at(blk, size)
+        if obj is None:
+            lib()._libc.free(blk)
+        return data
 
     def set_stream(self, stream):
         check(lib().hpsdf_ctx_set_stream(self.handle, C.c_void_p(stream) if stream else None))
@@ -656,8 +692,11 @@ def create_block(ctx, config, field, K=0):
     blk, sz, st = C.c_void_p(), C.c_size_t(), BuildStats()
     check(lib().hpsdf_create(ctx.handle if ctx is not None else None, C.byref(pod), field.handle, K, C.byref(blk),
                              C.byref(sz), C.byref(st)))
-    data = C.string_at(blk, sz.value)
-    lib()._libc.free(blk)
+    if ctx is None:  # (not reached: Create needs a device)
+        data = C.string_at(blk, sz.value)
+        lib()._libc.free(blk)
+    else:
+        data = ctx._take_block(blk, sz.value)
     return data, st.as_dict()
 
 
@@ -686,9 +725,7 @@ def create_block_distributed(ctx, config, field, K, rank, world, gather):
     if failure:
         raise failure[0]
     check(rc)
-    data = C.string_at(blk, size.value)
-    lib()._libc.free(blk)
-    return data, st.as_dict()
+    return ctx._take_block(blk, size.value), st.as_dict()
 
 
 def continuity_post_process(block, tol=0.0, max_iter=0, threads=0, ctx=None):

@@ -1288,6 +1288,26 @@ int hpsdf_build_get_stats(const hpsdf_build* b, hpsdf_build_stats* out) {
     return HPSDF_OK;
 }
 
+// A block that builderAssemble malloc'd, for a context with its own block allocator (hpsdf_ctx_set_block_allocator): moved there.
+static int adoptBlock(hpsdf_ctx* ctx, void** block, size_t size) {
+    if (!ctx->blockAlloc) return HPSDF_OK;
+    void* q = ctx->allocBlock(size);
+    if (!q) {
+        std::free(*block);
+        *block = nullptr;
+        return fail(HPSDF_ERR_OUT_OF_MEMORY, "the block allocator returned no memory");
+    }
+    std::memcpy(q, *block, size);
+    std::free(*block);
+    *block = q;
+    return HPSDF_OK;
+}
+
+void hpsdf_ctx_set_block_allocator(hpsdf_ctx* ctx, hpsdf_block_alloc_fn alloc, hpsdf_block_release_fn release, void* user) {
+    if (!ctx) return;
+    ctx->blockAlloc = alloc, ctx->blockRelease = alloc ? release : nullptr, ctx->blockUser = alloc ? user : nullptr;
+}
+
 int hpsdf_create(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* field, uint64_t K, void** block,
                  size_t* size, hpsdf_build_stats* stats) {
     HPSDF_TRY
@@ -1301,7 +1321,7 @@ int hpsdf_create(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* fie
             frc = continuityPostProcess(*block, *size, 0.0, 0, 0, &g_lastContinuity, err, ctx);
             if (frc) {
                 setError(err);
-                std::free(*block);
+                ctx->freeBlock(*block);
                 *block = nullptr;
                 *size = 0;
             }
@@ -1353,6 +1373,7 @@ int hpsdf_create(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* fie
         t1 = now();
         const double* packs[1] = {pack.data()};
         if (!rc) rc = builderAssemble(b, packs, block, size);
+        if (!rc) rc = adoptBlock(ctx, block, *size);
         tAsm = now() - t1;
     }
     if (!rc && stats) hpsdf_build_get_stats(b, stats);
@@ -1363,7 +1384,7 @@ int hpsdf_create(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* fie
         rc = continuityPostProcess(*block, *size, 0.0, 0, 0, &g_lastContinuity, err, ctx);
         if (rc) {
             setError(err);
-            std::free(*block);
+            ctx->freeBlock(*block);
             *block = nullptr;
             *size = 0;
         }
@@ -1502,6 +1523,7 @@ static int createShardedOnHostScheduler(hpsdf_ctx* ctx, const hpsdf_config* cfg,
     if ((rc = exchange(mine.data(), b->packCounts[rank], ppad, "the packed coefficients", rc))) return rc;
     for (int r = 0; r < world; ++r) parts[r] = all.data() + (uint64_t)r * stride;
     if ((rc = builderAssemble(b, parts.data(), block, size))) return rc;
+    if ((rc = adoptBlock(ctx, block, *size))) return rc;
     if (stats) hpsdf_build_get_stats(b, stats);
     return HPSDF_OK;
 }
@@ -1526,7 +1548,7 @@ int hpsdf_create_distributed(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsd
         rc = continuityPostProcess(*block, *size, 0.0, 0, 0, &g_lastContinuity, err, ctx);
         if (rc) {
             setError(err);
-            std::free(*block);
+            ctx->freeBlock(*block);
             *block = nullptr;
             *size = 0;
         }

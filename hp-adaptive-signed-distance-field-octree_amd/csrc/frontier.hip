@@ -884,7 +884,7 @@ __global__ __launch_bounds__(1024) void fr_emit_kernel(FrDev d) {
         if (tid < 128u) {  // (waves 0 and 1)
             const int p = (int)(pa >> 28), dep = (int)(pb >> 5);
             const bool coarse = (pb & 1u) != 0, ours = (pb & 2u) != 0;
-            const bool hasH = liveP && ours && !coarse && dep < kMaxDepth, hasP = liveP && ours && (coarse || p < kMaxDegree - 1);
+            const bool hasP = liveP && ours && (coarse || p < kMaxDegree - 1);
             // (replica: where ANY rank's results will lie -- the update notes them for every job)
             const bool anyH = liveP && (ours || d.replica) && !coarse && dep < kMaxDepth, anyP = liveP && (ours || d.replica) && (coarse || p < kMaxDegree - 1);
             const uint32_t owner = (pb >> 2) & 7u;
@@ -1298,30 +1298,78 @@ __device__ double frRunChain(const FrDev& d, FrLds& L, double total, uint32_t nO
     };
     if (loader) loadChunk(0, sOps);
     __syncthreads();
+    if (tid == 0) d.hdr->dbg[15] = __builtin_readcyclecounter();
     for (uint32_t c0 = 0, half = 0; c0 < nOps; c0 += 2048, half ^= 1u) {
         const uint32_t n = nOps - c0 < 2048u ? nOps - c0 : 2048u;
         if (loader) {
             if (c0 + 2048u < nOps) loadChunk(c0 + 2048u, sOps + (half ^ 1u) * 2048u);
         } else if (adder) {
-            // two batches of sixteen operands in registers (the compiler turns them into "read 32, add 32")
+            // Thirty-two operands a turn, in two batches of sixteen registers: while one batch is added (16 dependent additions, ~140
+            // cycles) the other's LDS reads are in flight.  Written out as instructions: from the plain statements the compiler builds
+            // "read 32, wait, add 32" -- every turn then pays the LDS latency in the open, 12.7 cycles an addition instead of 8.6
+            // (tools/chain_lab.hip; the additions are v_add_f64 in the statements' order either way).
             const double* src = sOps + half * 2048u;
             uint32_t q = 0;
             if (n >= 32) {
-                double a[16], b[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) a[k] = src[k];
-                for (; q + 32 <= n; q += 32) {
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) b[k] = src[q + 16 + k];
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) total = total + a[k];
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) a[k] = src[q + 32 + k];  // (at most 32 entries past n: inside the buffer pair)
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) total = total + b[k];
-                }
+                uint32_t addr = (uint32_t)(uintptr_t)src;  // (a shared pointer's low word is its LDS address)
+                uint32_t turns = __builtin_amdgcn_readfirstlane(n >> 5);
+                q = turns << 5;
+                asm volatile(
+                    "ds_read2_b64 v[64:67], %[addr] offset0:0 offset1:1\n"
+                    "ds_read2_b64 v[68:71], %[addr] offset0:2 offset1:3\n"
+                    "ds_read2_b64 v[72:75], %[addr] offset0:4 offset1:5\n"
+                    "ds_read2_b64 v[76:79], %[addr] offset0:6 offset1:7\n"
+                    "ds_read2_b64 v[80:83], %[addr] offset0:8 offset1:9\n"
+                    "ds_read2_b64 v[84:87], %[addr] offset0:10 offset1:11\n"
+                    "ds_read2_b64 v[88:91], %[addr] offset0:12 offset1:13\n"
+                    "ds_read2_b64 v[92:95], %[addr] offset0:14 offset1:15\n"
+                    "1:\n"
+                    "ds_read2_b64 v[96:99], %[addr] offset0:16 offset1:17\n"
+                    "ds_read2_b64 v[100:103], %[addr] offset0:18 offset1:19\n"
+                    "ds_read2_b64 v[104:107], %[addr] offset0:20 offset1:21\n"
+                    "ds_read2_b64 v[108:111], %[addr] offset0:22 offset1:23\n"
+                    "ds_read2_b64 v[112:115], %[addr] offset0:24 offset1:25\n"
+                    "ds_read2_b64 v[116:119], %[addr] offset0:26 offset1:27\n"
+                    "ds_read2_b64 v[120:123], %[addr] offset0:28 offset1:29\n"
+                    "ds_read2_b64 v[124:127], %[addr] offset0:30 offset1:31\n"
+                    "s_waitcnt lgkmcnt(8)\n"
+                    "v_add_f64 %[t], %[t], v[64:65]\nv_add_f64 %[t], %[t], v[66:67]\n"
+                    "v_add_f64 %[t], %[t], v[68:69]\nv_add_f64 %[t], %[t], v[70:71]\n"
+                    "v_add_f64 %[t], %[t], v[72:73]\nv_add_f64 %[t], %[t], v[74:75]\n"
+                    "v_add_f64 %[t], %[t], v[76:77]\nv_add_f64 %[t], %[t], v[78:79]\n"
+                    "v_add_f64 %[t], %[t], v[80:81]\nv_add_f64 %[t], %[t], v[82:83]\n"
+                    "v_add_f64 %[t], %[t], v[84:85]\nv_add_f64 %[t], %[t], v[86:87]\n"
+                    "v_add_f64 %[t], %[t], v[88:89]\nv_add_f64 %[t], %[t], v[90:91]\n"
+                    "v_add_f64 %[t], %[t], v[92:93]\nv_add_f64 %[t], %[t], v[94:95]\n"
+                    // (the next turn's first batch: at most 16 entries past the chunk -- inside the LDS block, never added)
+                    "ds_read2_b64 v[64:67], %[addr] offset0:32 offset1:33\n"
+                    "ds_read2_b64 v[68:71], %[addr] offset0:34 offset1:35\n"
+                    "ds_read2_b64 v[72:75], %[addr] offset0:36 offset1:37\n"
+                    "ds_read2_b64 v[76:79], %[addr] offset0:38 offset1:39\n"
+                    "ds_read2_b64 v[80:83], %[addr] offset0:40 offset1:41\n"
+                    "ds_read2_b64 v[84:87], %[addr] offset0:42 offset1:43\n"
+                    "ds_read2_b64 v[88:91], %[addr] offset0:44 offset1:45\n"
+                    "ds_read2_b64 v[92:95], %[addr] offset0:46 offset1:47\n"
+                    "s_waitcnt lgkmcnt(8)\n"
+                    "v_add_f64 %[t], %[t], v[96:97]\nv_add_f64 %[t], %[t], v[98:99]\n"
+                    "v_add_f64 %[t], %[t], v[100:101]\nv_add_f64 %[t], %[t], v[102:103]\n"
+                    "v_add_f64 %[t], %[t], v[104:105]\nv_add_f64 %[t], %[t], v[106:107]\n"
+                    "v_add_f64 %[t], %[t], v[108:109]\nv_add_f64 %[t], %[t], v[110:111]\n"
+                    "v_add_f64 %[t], %[t], v[112:113]\nv_add_f64 %[t], %[t], v[114:115]\n"
+                    "v_add_f64 %[t], %[t], v[116:117]\nv_add_f64 %[t], %[t], v[118:119]\n"
+                    "v_add_f64 %[t], %[t], v[120:121]\nv_add_f64 %[t], %[t], v[122:123]\n"
+                    "v_add_f64 %[t], %[t], v[124:125]\nv_add_f64 %[t], %[t], v[126:127]\n"
+                    "v_add_u32 %[addr], 0x100, %[addr]\n"
+                    "s_sub_u32 %[turns], %[turns], 1\n"
+                    "s_cmp_lg_u32 %[turns], 0\n"
+                    "s_cbranch_scc1 1b\n"
+                    "s_waitcnt lgkmcnt(0)\n"
+                    : [t] "+v"(total), [addr] "+v"(addr), [turns] "+s"(turns)
+                    :
+                    : "memory", "scc", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
             }
             for (; q < n; ++q) total = total + src[q];
+            if (tid == 0 && c0 == 0) d.hdr->dbg[16] = __builtin_readcyclecounter();
         }
         __syncthreads();
     }
@@ -1372,6 +1420,10 @@ __device__ void frLeadRound(const FrDev& d, FrLds& L, int pre) {
     const uint32_t tid = threadIdx.x, nJobs = h->nJobs, round = h->round, stamp = round + 1u;
     const bool round0 = round == 0;
     const uint32_t nNodes0 = h->nNodes, nQ0 = h->nQueued;
+    // (the counters the close adds to, asked for now -- with the rest of the header, one round trip -- so that the close only stores)
+    const uint64_t jobs0 = h->jobs, pRef0 = h->pRefines, hRef0 = h->hRefines, drop0 = h->dropped, nCoeffs0 = h->nCoeffs;
+    const uint32_t nLeaves0 = h->nLeaves, maxDeg0 = h->maxDegree;
+    const uint64_t fits0 = h->fits, samples0 = h->samples, arena0 = h->arenaUsed, split0 = h->splitFits;  // (what a prepared round adds to)
     const double target = d.target;
     if (tid == 0) L.flag = 0, L.stuck = 0;
     if (tid == 0 && round0) {
@@ -1397,12 +1449,15 @@ __device__ void frLeadRound(const FrDev& d, FrLds& L, int pre) {
     uint32_t overflow = frLoad(&h->overflow) | ((L.stuck || frLoad(&h->stuck)) ? 4u : 0u);
     const uint32_t nQ = nQ0 - (round0 ? 0u : nJobs) + nP + 8u * nH;  // (round 0's batch never sat in the queue)
     const uint32_t nNodes = nNodes0 + 8u * nH;
-    for (uint32_t i = tid; i < 2048; i += 1024) L.hist[i] = frLoad(&h->hist1[i]);
+    // (a build whose total after round 0 says "stop" -- most builds at everyday thresholds -- selects nothing any more: no threshold)
+    const bool stopsHere = round0 && total0 < target;
+    if (!stopsHere)
+        for (uint32_t i = tid; i < 2048; i += 1024) L.hist[i] = frLoad(&h->hist1[i]);
     if (tid == 0) L.c = (round0 || frLoad(&h->chainStamp) == stamp) ? 1u : 0u;
     __syncthreads();
     bool haveTotal = L.c != 0;
     const bool canGoOn = nQ != 0 && overflow == 0;
-    if (canGoOn && nQ > d.K) {
+    if (canGoOn && nQ > d.K && !stopsHere) {
         frThreshold(L.hist, d.K, L.tmp, &L.t, &L.above);
     } else {
         if (tid == 0) L.t = -1, L.above = nQ;
@@ -1432,17 +1487,16 @@ __device__ void frLeadRound(const FrDev& d, FrLds& L, int pre) {
     if (tid == 0) {
         h->nQueued = nQ;
         h->nNodes = nNodes;
-        h->jobs += nJobs, h->pRefines += nP, h->hRefines += nH, h->dropped += nD;
-        h->nLeaves += 7u * nH;
-        h->nCoeffs = (uint64_t)((int64_t)h->nCoeffs + cd);
-        if (md > h->maxDegree) h->maxDegree = md;
+        h->jobs = jobs0 + nJobs, h->pRefines = pRef0 + nP, h->hRefines = hRef0 + nH, h->dropped = drop0 + nD;
+        h->nLeaves = nLeaves0 + 7u * nH;
+        h->nCoeffs = (uint64_t)((int64_t)nCoeffs0 + cd);
+        if (md > maxDeg0) h->maxDegree = md;
         h->round = stamp;
         h->takenCount = 0, h->candCount = 0;
         h->rPad = L.flag;  // a rank that failed this round, + 1
         h->t1 = T, h->above = above;
     }
     FR_STAMP(11);
-    const uint64_t fits0 = h->fits, samples0 = h->samples, arena0 = h->arenaUsed, split0 = h->splitFits;  // (what a prepared round adds to)
     __syncthreads();
     if (pre && !done) {
         // ---- the next round's selection, level 0: everything in the exponent bins above T is taken, bin T is the candidate list
@@ -2308,9 +2362,10 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
     uint8_t* early = nullptr;  // the block of a build that stops after round 0, begun before the device has finished
     bool earlyCopied = false;  // ... its coefficients are in it
     struct FreeEarly {
+        hpsdf_ctx* ctx;
         uint8_t** p;
-        ~FreeEarly() { std::free(*p); }
-    } freeEarly{&early};
+        ~FreeEarly() { ctx->freeBlock(*p); }
+    } freeEarly{ctx, &early};
     // ---- round 0: every cell of the uniformly refined tree, straight from the template
     FrTemplate T0 = T;  // (this rank's share when there are several)
     const FitTask* r0Tasks = ws->tmplTasks;
@@ -2561,7 +2616,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
             // a build that stops here has its packed store in pinned memory already (the fit wrote it there too), and everything else
             // of its block is known in advance: write that part while the device works
             const uint64_t nc0 = T.arenaRows, nn0 = T.nNodes;
-            early = (uint8_t*)std::malloc(8 + 8 * (size_t)nc0 + 8 + sizeof(hpsdf_node) * (size_t)nn0 + sizeof(hpsdf_config));
+            early = (uint8_t*)ctx->allocBlock(8 + 8 * (size_t)nc0 + 8 + sizeof(hpsdf_node) * (size_t)nn0 + sizeof(hpsdf_config));
             if (early) {
                 std::memcpy(early, &nc0, 8);
                 std::memcpy(early + 8 + 8 * (size_t)nc0, &nn0, 8);
@@ -2598,7 +2653,8 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
                 for (int k = 1; k <= 8; ++k) std::fprintf(stderr, " %lld", (long long)(hh->dbg[k] - hh->dbg[k - 1]));
                 std::fprintf(stderr, " | total+commit %lld", (long long)(hh->dbg[12] - hh->dbg[8]));
             }
-            std::fprintf(stderr, " | chain %lld", (long long)(hh->dbg[14] - hh->dbg[13]));
+            std::fprintf(stderr, " | chain %lld (first operands %lld, first 2048 additions %lld)", (long long)(hh->dbg[14] - hh->dbg[13]), (long long)(hh->dbg[15] - hh->dbg[13]),
+                         (long long)(hh->dbg[16] - hh->dbg[15]));
             std::fprintf(stderr, "\n");
         }
         if (rounds == 1 && world == 1 && hh->done && early && hh->nCoeffs == T.arenaRows && hh->nNodes == T.nNodes) {
@@ -2618,7 +2674,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
             if (trace) std::fprintf(stderr, "[frontierCreate] us: total %.0f (waiting for the device %.0f, stopped after round 0)\n", now() - t0, tSync);
             return HPSDF_OK;
         }
-        std::free(early);
+        ctx->freeBlock(early);
         early = nullptr;
         if (hh->done) break;
         // (as builderSelect: a total that is NaN or infinite never falls below the threshold -- the field is not finite somewhere)
@@ -2684,7 +2740,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         FR_LAUNCH(fr_store_kernel, dim3(((uint32_t)nn + 255u) / 256u), dim3(256), s, d);
     }
     const size_t bytes = 8 + 8 * (size_t)nc + 8 + sizeof(hpsdf_node) * (size_t)nn + sizeof(hpsdf_config);
-    uint8_t* p = (uint8_t*)std::malloc(bytes);
+    uint8_t* p = (uint8_t*)ctx->allocBlock(bytes);
     if (!p) {
         (void)hipStreamSynchronize(s);
         return fail(HPSDF_ERR_OUT_OF_MEMORY, "malloc of the memory block failed");
@@ -2700,7 +2756,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         if (*flag != d.buildStamp) {  // (two milliseconds of watching, then the ordinary wait: the launch has finished, its stores are there)
             const hipError_t e = hipStreamSynchronize(s);
             if (e != hipSuccess) {
-                std::free(p);
+                ctx->freeBlock(p);
                 return hipFail(e, "block download");
             }
         }

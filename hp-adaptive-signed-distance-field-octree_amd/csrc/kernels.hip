@@ -256,9 +256,9 @@ HPSDF_HD __forceinline__ float meshSlack(const BvhNode& root) {
     }
     return 2e-6f * fmaxf(sqrtf(e2), big);
 }
-// closestSimplex's face-case tolerance as a fraction of that slack: a point it accepts lies at most this far outside its triangle, so a
-// distance it returns is at most a quarter of the slack (plus the 3 u M of forming q) below the triangle's true distance
-constexpr float kMeshTolOfSlack = 0.25f;
+// (closestSimplex's face-case tolerance is MeshDev::faceTolOfSlack of that slack -- a quarter by default: a point it accepts lies at
+// most that far outside its triangle, so a distance it returns is at most a quarter of the slack, plus the 3 u M of forming q, below
+// the triangle's true distance)
 HPSDF_HD __forceinline__ float rejectBound(float best, float slack) {
     const float r = sqrtf(best) + slack;
     return r * r * 1.00001f;

@@ -1,5 +1,6 @@
 // Host runtime objects behind the opaque handles of include/hpsdf.h.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime_api.h>
 
 #include <cstdint>
@@ -100,6 +101,19 @@ struct hpsdf_ctx {
     uint32_t* dDefer = nullptr;
     uint64_t deferCap = 0;
     uint32_t* dDeferCount = nullptr;
+    // hpsdf_ctx_set_block_allocator: where the memory blocks Create hands out come from (default: malloc / free)
+    void* (*blockAlloc)(size_t, void*) = nullptr;
+    void (*blockRelease)(void*, void*) = nullptr;
+    void* blockUser = nullptr;
+    void* allocBlock(size_t bytes) const { return blockAlloc ? blockAlloc(bytes, blockUser) : std::malloc(bytes); }
+    void freeBlock(void* p) const {  // a block the build began and will not return
+        if (p == nullptr) return;
+        if (blockAlloc) {
+            if (blockRelease) blockRelease(p, blockUser);
+        } else {
+            std::free(p);
+        }
+    }
 };
 
 struct hpsdf_tree {

@@ -395,8 +395,20 @@ HPSDF_API int hpsdf_continuity_matrix_device(hpsdf_ctx* ctx, const void* block, 
 /* stats of the last post-process hpsdf_create ran on this thread (zeros if it ran none) */
 HPSDF_API int hpsdf_continuity_last_stats(hpsdf_continuity_stats* out);
 
+/* Where the memory blocks of hpsdf_create / hpsdf_create_distributed come from.  By default they are malloc'd and the caller frees
+ * them with free() -- MemoryBlock's contract (Utility.h: { size, ptr }, freed by the caller).  A host binding whose own block type
+ * cannot adopt a malloc'd pointer (a Python bytes object, a Go slice, a JVM direct buffer) pays a second copy of the whole block for
+ * that; with an allocator the library writes the block straight into the binding's memory: alloc(size, user) is called in place of
+ * malloc(size) and the returned pointer comes back as *block (NULL: the build fails with HPSDF_ERR_OUT_OF_MEMORY).  A block the
+ * build has begun but will not return (it allocates the block of a build that stops after the first round before it knows that the
+ * build stops there; failures) goes to release(ptr, user).  Both are called on the thread that called Create, during the call.
+ * alloc == NULL restores malloc / free.  (hpsdf_build_assemble always mallocs.) */
+typedef void* (*hpsdf_block_alloc_fn)(size_t size, void* user);
+typedef void (*hpsdf_block_release_fn)(void* block, void* user);
+HPSDF_API void hpsdf_ctx_set_block_allocator(hpsdf_ctx* ctx, hpsdf_block_alloc_fn alloc, hpsdf_block_release_fn release, void* user);
+
 /* whole Create on one GPU: begin .. assemble, then the continuity post-process when
- * cfg->continuity_enforce is set (Octree.cpp:341-344).  *block is malloc'd (caller frees).
+ * cfg->continuity_enforce is set (Octree.cpp:341-344).  *block is malloc'd (caller frees) unless the context has a block allocator.
  * HPSDF_ERR_INVALID_ARGUMENT after the first round if the field is NaN or infinite at a sample point: the total error is then
  * NaN / infinite for good and the reference's loop (Octree.cpp:216) would refine until memory ends. */
 HPSDF_API int hpsdf_create(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* field,

@@ -615,6 +615,67 @@ def test_device_frontier_equals_host_scheduler(H, ctx, monkeypatch, name, target
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("host", ["0", "1"])
+def test_block_allocator_receives_every_block(H, monkeypatch, host):
+    """hpsdf_ctx_set_block_allocator (hpsdf.h): Create writes its MemoryBlock into memory the caller's allocator hands out -- the
+    returned pointer is the allocator's, the bytes are those of a malloc'd block, a block begun and not returned (the one a build
+    that goes on past round 0 prepared) is given back, and with the allocator taken out again blocks are malloc'd as before."""
+    import ctypes as C
+    monkeypatch.setenv("HPSDF_HOST_FRONTIER", host)
+    L = H.lib()
+    ctx = H.Context(0)
+    L.hpsdf_ctx_set_block_allocator(ctx.handle, None, None, None)  # (the Python wrapper installs its own)
+    f = H.Field.union3()
+
+    def create(target):
+        pod = H.make_config(target).to_pod()
+        blk, sz, st = C.c_void_p(), C.c_size_t(), H.BuildStats()
+        H.check(L.hpsdf_create(ctx.handle, C.byref(pod), f.handle, 1024, C.byref(blk), C.byref(sz), C.byref(st)))
+        return blk, sz.value
+
+    want = {}
+    for tg in (1e-5, 1e-7):
+        blk, n = create(tg)
+        want[tg] = C.string_at(blk, n)
+        L._libc.free(blk)
+    live, log = {}, []
+
+    def alloc(size, _user):
+        buf = C.create_string_buffer(size)
+        live[C.addressof(buf)] = buf
+        log.append(("alloc", size))
+        return C.addressof(buf)
+
+    def release(ptr, _user):
+        log.append(("release", len(live.pop(ptr))))
+
+    a, r = H.BLOCK_ALLOC(alloc), H.BLOCK_RELEASE(release)
+    L.hpsdf_ctx_set_block_allocator(ctx.handle, C.cast(a, C.c_void_p), C.cast(r, C.c_void_p), None)
+    for tg in (1e-5, 1e-7):
+        del log[:]
+        blk, n = create(tg)
+        assert blk.value in live and len(live[blk.value]) == n and live.pop(blk.value).raw == want[tg]
+        assert not live, "a block that was not returned was not given back either"
+        assert [e for e in log if e[0] == "alloc"][-1] == ("alloc", n)
+        assert len([e for e in log if e[0] == "alloc"]) == 1 + len([e for e in log if e[0] == "release"])
+    # an allocator that has no memory fails the build, and the library says so
+    none = H.BLOCK_ALLOC(lambda size, _user: None)
+    L.hpsdf_ctx_set_block_allocator(ctx.handle, C.cast(none, C.c_void_p), None, None)
+    pod = H.make_config(1e-7).to_pod()
+    blk, sz = C.c_void_p(), C.c_size_t()
+    rc = L.hpsdf_create(ctx.handle, C.byref(pod), f.handle, 1024, C.byref(blk), C.byref(sz), None)
+    assert rc == H.ERR_OUT_OF_MEMORY and not blk.value
+    L.hpsdf_ctx_set_block_allocator(ctx.handle, None, None, None)
+    blk, n = create(1e-5)
+    assert C.string_at(blk, n) == want[1e-5]
+    L._libc.free(blk)
+    # ... and the wrapper's own allocator: create_block's bytes object is the block itself
+    ctx2 = H.Context(0)
+    got, _ = H.create_block(ctx2, H.make_config(1e-7), f, 1024)
+    assert type(got) is bytes and got == want[1e-7] and not ctx2._blocks
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"HPSDF_FRONTIER_INLINE_NODES": "0"}, {"HPSDF_FRONTIER_NO_BLIND": "1"},
                                  {"HPSDF_FRONTIER_INLINE_NODES": "0", "HPSDF_FRONTIER_NO_BLIND": "1"}])
 @pytest.mark.parametrize("target,K", [(1e-7, 256), (1e-8, 4096)])
