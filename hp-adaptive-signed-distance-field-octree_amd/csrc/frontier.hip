@@ -376,7 +376,7 @@ struct FrLds {
     uint32_t wave[16];
     uint32_t slice[9];
     int t;
-    uint32_t above, c, next, flag, stuck, anySplit;
+    uint32_t above, c, next, flag, stuck, anySplit, early;
     unsigned long long need;
     uint32_t countO[8][kFrClasses];  // FrDev::replica: fits per (owner, class)
     unsigned long long rowsO[8];
@@ -421,8 +421,13 @@ __device__ __forceinline__ double* frStatusSlotNext(const FrDev& d, int r) { ret
 // candidates): the workgroup also writes the round's FitTask / FitBlock lists -- a job's slots are reserved while its fits
 // are counted, the per-job facts wait in LDS, one lane per (job, fit) writes a task.  Otherwise (fr_batch_kernel, behind
 // fr_select_kernel): the histogram sits in the header, the classes go to d.rnd and fr_tasks_kernel follows.
+// watchStamp (INLINE, a round prepared on the assumption that the build goes on): the closing round's number + 1 -- once the batch is
+// chosen the workgroup looks whether the running total has arrived meanwhile and says "stop" (FrHdr::chainStamp == watchStamp and
+// rTotal < d.target); it then returns true with nothing of the header touched (what it wrote -- d.taken, the candidate lists -- is not
+// read after the stop), and the rest of the preparation, more than half of it, is not spent on a round that will not be fitted.
 template <bool INLINE>
-__device__ void frBatchBody(const FrDev& d, FrLds& L, uint32_t nQ, uint32_t above, uint32_t cand, uint32_t taken, uint32_t nNodes) {
+__device__ bool frBatchBody(const FrDev& d, FrLds& L, uint32_t nQ, uint32_t above, uint32_t cand, uint32_t taken, uint32_t nNodes,
+                            uint32_t watchStamp = 0) {
     FrHdr* h = d.hdr;
     FrRound* R = d.rnd;
     const uint32_t tid = threadIdx.x;
@@ -540,12 +545,21 @@ __device__ void frBatchBody(const FrDev& d, FrLds& L, uint32_t nQ, uint32_t abov
         if (nJobs > 1) frBitonic(sKey, sVal, n2);
     }
     FR_STAMP(3);
+    if (INLINE && watchStamp != 0 && tid == 0) {
+        uint32_t early = 0;
+        if (__hip_atomic_load(&h->chainStamp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == watchStamp) {
+            __threadfence();
+            early = *(volatile double*)&h->rTotal < d.target ? 1u : 0u;  // Octree.cpp:216
+        }
+        L.early = early;
+    }
     for (uint32_t i = tid; i < 2048; i += 1024) sHist[i] = 0;
     for (uint32_t c = tid; c < (uint32_t)kFrClasses; c += 1024) sCount[c] = 0;
     if (d.replica)
         for (uint32_t c = tid; c < 8u * (uint32_t)kFrClasses; c += 1024) (&L.countO[0][0])[c] = 0;
     if (tid < 9) L.slice[tid] = tid ? nJobs : 0u;
     __syncthreads();
+    if (INLINE && watchStamp != 0 && L.early) return true;
     // ---- the jobs leave the frontier; every job becomes 1 (coarse) or up to 9 cell fits: count them per shape class.
     //      Thread t owns jobs 4 t .. 4 t + 3.  With several ranks every rank counts only the fits of its own slice: the
     //      slices are contiguous job ranges of (nearly) equal cost, cut where the host scheduler cuts them (builderSelect).
@@ -807,6 +821,7 @@ __device__ void frBatchBody(const FrDev& d, FrLds& L, uint32_t nQ, uint32_t abov
     }
     FR_STAMP(7);
     FR_STAMP(8);
+    return false;
 }
 
 // The round's FitTask / FitBlock lists behind the inline batch (fr_round_kernel's leader): the shape classes are in d.rnd, every job's
@@ -1536,8 +1551,12 @@ __device__ void frLeadRound(const FrDev& d, FrLds& L, int pre) {
         __syncthreads();
         const uint32_t cand = L.c, taken = L.next;
         __syncthreads();
-        frBatchBody<true>(d, L, nQ, above, cand, taken, nNodes);
+        const bool stopped = frBatchBody<true>(d, L, nQ, above, cand, taken, nNodes, haveTotal ? 0u : stamp);
         __syncthreads();
+        if (stopped) {  // the total came while the batch was being chosen, and it says "stop": nothing to take back
+            haveTotal = true, done = true;
+            total = *(volatile double*)&h->rTotal;
+        }
         if (!haveTotal) {
             awaitTotal();
             __threadfence();
