@@ -1633,73 +1633,72 @@ __global__ __launch_bounds__(256) void fr_subtree_kernel(FrDev d) {
 // ancestors-or-self a: the subtree sizes of a's earlier siblings.  Its rows are then gathered from the arena, segment by
 // segment.
 // ---------------------------------------------------------------------------------------------------------------------
-// Workgroup b takes nodes 256 b .. 256 b + 255, in two phases; d.store is pinned HOST memory (ToMemoryBlock's order, :424-456:
+// Workgroup b takes nodes 64 b .. 64 b + 63, in two phases (256 nodes a workgroup left a 12 000-node tree 48 workgroups -- a fifth of
+// the chip's CUs -- and every lane a dozen rows, each behind its own chain of loads: 56 us for 1.9 MB); d.store is pinned HOST memory (ToMemoryBlock's order, :424-456:
 // coefficients, then the node array), written by the stores themselves -- no copy to launch, and the host, which watches
 // FrHdr::stored, moves the node array into the block while the coefficients are still on their way.
-//   1  one lane per node: coeffsStart (lanes walk up alone: the earlier siblings' sizes level by level), the serialised node through
+//   1  the first wave, one lane per node: coeffsStart (lanes walk up alone: the earlier siblings' sizes level by level), the serialised node through
 //      the wave's staging buffer (whole records, in order)
-//   2  the workgroup's leaves' rows: one lane per row -- a prefix sum over the 256 leaves' row counts, a search for the row's leaf, the
+//   2  the workgroup's leaves' rows: one lane per row -- a prefix sum over the 64 leaves' row counts, a search for the row's leaf, the
 //      segment it lies in -- so that every lane has a load in flight and a leaf's rows leave as one run
+constexpr uint32_t kStoreNodes = 64;  // nodes per workgroup of fr_store_kernel (one wave's worth: four times the workgroups of a node per thread)
 __global__ __launch_bounds__(256) void fr_store_kernel(FrDev d) {
     FrHdr* h = d.hdr;
     if (!h->done || h->overflow) return;
     const uint32_t n = h->nNodes, tid = threadIdx.x;
     const uint64_t nCoeffs = h->nCoeffs;
-    __shared__ uint64_t sStage[4][64 * 7];
-    __shared__ uint32_t sStart[256], sRows[257], sWave[4];
-    const uint32_t i = blockIdx.x * 256u + tid;
-    const bool live = i < n;
-    hpsdf_node nd;
-    nd.child_idx = ~0ull, nd.degree = kInteriorDegree, nd.depth = 0, nd.coeffs_start = 0;
-    if (live) nd = d.nodes[i];
-    const bool leaf = live && nd.degree != kInteriorDegree;
-    uint32_t start = 0;
-    if (leaf) {
-        uint32_t a = i;
-        while (a != 0) {
-            const uint32_t par = d.parent[a];
-            const uint32_t c0 = (uint32_t)d.nodes[par].child_idx;
-            for (uint32_t sIdx = c0; sIdx < a; ++sIdx) {
-                const uint32_t dg = d.nodes[sIdx].degree;
-                start += dg == kInteriorDegree ? d.sub[sIdx] : frCoef((int)dg);
+    __shared__ uint64_t sStage[64 * 7];
+    __shared__ uint32_t sStart[kStoreNodes], sRows[kStoreNodes + 1];
+    if (tid < 64) {  // ---- phase 1, the first wave: a lane per node
+        const uint32_t i = blockIdx.x * kStoreNodes + tid;
+        const bool live = i < n;
+        hpsdf_node nd;
+        nd.child_idx = ~0ull, nd.degree = kInteriorDegree, nd.depth = 0, nd.coeffs_start = 0;
+        if (live) nd = d.nodes[i];
+        const bool leaf = live && nd.degree != kInteriorDegree;
+        uint32_t start = 0;
+        if (leaf) {
+            uint32_t a = i;
+            while (a != 0) {
+                const uint32_t par = d.parent[a];
+                const uint32_t c0 = (uint32_t)d.nodes[par].child_idx;
+                for (uint32_t sIdx = c0; sIdx < a; ++sIdx) {
+                    const uint32_t dg = d.nodes[sIdx].degree;
+                    start += dg == kInteriorDegree ? d.sub[sIdx] : frCoef((int)dg);
+                }
+                a = par;
             }
-            a = par;
+        }
+        {
+            uint64_t w[7];
+            const uint64_t* src = reinterpret_cast<const uint64_t*>(&nd);
+#pragma unroll
+            for (int k = 0; k < 7; ++k) w[k] = src[k];
+            if (leaf) w[4] = (uint64_t)start;  // (word 4: coeffs_start, @32)
+            // the wave's 64 nodes are consecutive: one run
+            frStoreRecords(sStage, reinterpret_cast<uint64_t*>(d.store + nCoeffs), w, (uint64_t)i * 7u, live, false);
+        }
+        sStart[tid] = start;
+        // inclusive scan of the row counts over the wave
+        uint32_t inc = leaf ? frCoef((int)nd.degree) : 0u;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(inc, off, 64);
+            if ((int)tid >= off) inc += v;
+        }
+        sRows[tid + 1] = inc;
+        if (tid == 0) sRows[0] = 0;
+        __threadfence_system();
+        if (tid == 0 && atomicAdd(&h->storeArrive[0], 1u) == gridDim.x - 1u) {  // the node array is complete
+            __threadfence_system();
+            *(volatile uint32_t*)&d.hostHdr->stored[0] = d.buildStamp;
+            __threadfence_system();
         }
     }
-    {
-        uint64_t w[7];
-        const uint64_t* src = reinterpret_cast<const uint64_t*>(&nd);
-#pragma unroll
-        for (int k = 0; k < 7; ++k) w[k] = src[k];
-        if (leaf) w[4] = (uint64_t)start;  // (word 4: coeffs_start, @32)
-        // the wave's 64 nodes are consecutive: one run
-        frStoreRecords(sStage[tid >> 6], reinterpret_cast<uint64_t*>(d.store + nCoeffs), w, (uint64_t)i * 7u, live, false);
-    }
-    sStart[tid] = start;
-    const uint32_t rows = leaf ? frCoef((int)nd.degree) : 0u;
-    // inclusive scan of the row counts over the workgroup
-    uint32_t inc = rows;
-    const int lane = (int)(tid & 63);
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t v = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += v;
-    }
-    if (lane == 63) sWave[tid >> 6] = inc;
-    __threadfence_system();
     __syncthreads();
-    if (tid == 0 && atomicAdd(&h->storeArrive[0], 1u) == gridDim.x - 1u) {  // the node array is complete
-        __threadfence_system();
-        *(volatile uint32_t*)&d.hostHdr->stored[0] = d.buildStamp;
-        __threadfence_system();
-    }
-    uint32_t before = 0;
-    for (uint32_t w2 = 0; w2 < (tid >> 6); ++w2) before += sWave[w2];
-    sRows[tid + 1] = before + inc;
-    if (tid == 0) sRows[0] = 0;
-    __syncthreads();
-    const uint32_t total = sRows[256];
+    // ---- phase 2, every wave: a lane per row
+    const uint32_t total = sRows[kStoreNodes];
     for (uint32_t e = tid; e < total; e += 256u) {
-        uint32_t lo = 0, hi = 256;  // the leaf whose rows hold element e: the last one with sRows[leaf] <= e
+        uint32_t lo = 0, hi = kStoreNodes;  // the leaf whose rows hold element e: the last one with sRows[leaf] <= e
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
             if (sRows[mid] <= e)
@@ -1707,7 +1706,7 @@ __global__ __launch_bounds__(256) void fr_store_kernel(FrDev d) {
             else
                 hi = mid;
         }
-        const uint32_t node = blockIdx.x * 256u + lo, r = e - sRows[lo];
+        const uint32_t node = blockIdx.x * kStoreNodes + lo, r = e - sRows[lo];
         const int first = d.segFirst[node];
         int sg = 0;  // the segment row r lies in: rows [coef(first + sg - 1), coef(first + sg))
         while (r >= frCoef(first + sg)) ++sg;
@@ -2756,7 +2755,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
             FR_LAUNCH(fr_pack_kernel, dim3(std::min<uint32_t>(2048u, (knownNodes + 3u) / 4u)), dim3(256), s, d);
             if ((rc = exchange(d.pack, (size_t)stride * sizeof(double), "the packed coefficients"))) return rc;
         }
-        FR_LAUNCH(fr_store_kernel, dim3(((uint32_t)nn + 255u) / 256u), dim3(256), s, d);
+        FR_LAUNCH(fr_store_kernel, dim3(((uint32_t)nn + kStoreNodes - 1u) / kStoreNodes), dim3(256), s, d);
     }
     const size_t bytes = 8 + 8 * (size_t)nc + 8 + sizeof(hpsdf_node) * (size_t)nn + sizeof(hpsdf_config);
     uint8_t* p = (uint8_t*)ctx->allocBlock(bytes);
