@@ -10,22 +10,30 @@
 // the frontier), the parent index and up to 10 coefficient segments (a leaf of degree p that started at degree f owns rows
 // [0, ncoef(f)) from its first fit and one more run of rows per P-refinement: nothing is copied when a degree rises).
 //
-// A round (r >= 1) is TWO launches around its fits (round 5; rounds 2-4 ran six small kernels, ~90 us of their own latencies):
-//   fr_round_kernel    closes round r - 1 and opens round r in one launch of 1 + K / 128 workgroups of 1024 threads:
+// A round (r >= 1) is TWO launches around its fits (round 5; rounds 2-4 ran six small kernels, ~100 us of their own latencies a round):
+//   fr_round_kernel    closes round r - 1 and opens round r in one launch of 2 + K / 128 workgroups of 1024 threads:
 //        workgroups 1.. : eight lanes per job -- the decision (:594-601: improvements :814-825, :846-854), child creation
-//                         (Subdivide / CornerAABB), queue, coefficient counts of the ancestors.  A splitting job's first child is
-//                         nNodes + 8 x (splitting jobs before it): every workgroup publishes its own counts and adds up its
-//                         predecessors' (one hop, no chain), so no single workgroup has to see all jobs first
-//        workgroup 0    : the running total in the reference's order (:253-290), one dependent addition after the other, from the
-//                         dense operand list the others write; when all have arrived: counters, stop rule (:216); then -- trees up
-//                         to kFrInlineNodes -- the NEXT round's selection (top-K of the frontier by (error desc, node index asc) as
-//                         an MSB radix select over the error's bit pattern), the batch in node order, the round's shape classes and
-//                         its FitTask / FitBlock lists, all from LDS; the header's mirror in pinned host memory tells the host
-//   mesh_sample_kernel / fit_multi_kernel   (kernels.hip) over device-written ranges: grids are upper bounds
+//                         (Subdivide / CornerAABB), queue and histogram, the round's additions to the running total as a dense list.
+//                         A splitting job's first child is nNodes + 8 x (splitting jobs before it): every workgroup publishes its
+//                         own counts and adds up its predecessors' (one hop, no chain), so nobody has to see all jobs first
+//        the last one   : the running total in the reference's order (:253-290), one dependent v_add_f64 after the other, the
+//                         operands double-buffered through LDS by twelve loader waves (frRunChain) -- beside everything else:
+//                         nobody waits for it before the next round is prepared
+//        workgroup 0    : when all have arrived: counters, the next selection's threshold bin; then -- trees up to
+//                         HPSDF_FRONTIER_INLINE_NODES -- the NEXT round's selection (top-K of the frontier by (error desc, node index
+//                         asc) as an MSB radix select over the error's bit pattern), the batch in node order, the round's shape
+//                         classes and every job's record, on the assumption that the build goes on; the stop rule (:216) when the
+//                         total has come (a build that stops takes the prepared round out of the header again); the header's
+//                         mirror in pinned host memory tells the host.  Round 0's total (4096 operands that are there when the
+//                         launch starts) it adds up itself
+//   fr_emit_kernel     the round's FitTask / FitBlock lists from the job records (grid: 128 jobs a workgroup, a lane per fit)
+//   mesh_sample_kernel / fit_multi_kernel   (kernels.hip) over device-written ranges: grids are upper bounds.  From the second
+//                      round on both are enqueued without waiting for the header: a build that has stopped leaves them nothing to do
 // Larger trees select with a grid: fr_select_kernel (level 0 against the histogram the updates keep), fr_batch_kernel (one
 // workgroup: remaining digits, exact order, classes), fr_tasks_kernel (grid: the lists).
-//   fr_store_kernel    once the stop rule has fired: ReallocCoeffs -- every leaf's coeffsStart by walking up its
-//                      ancestors, coefficients gathered into the packed store, the node array behind it (one download)
+//   fr_subtree_kernel / fr_store_kernel   once the stop rule has fired: ReallocCoeffs -- the coefficient count of every subtree, every
+//                      leaf's coeffsStart by walking up its ancestors, coefficients and node array written straight into pinned host
+//                      memory in ToMemoryBlock's order (the host copies each part into the block as its flag appears)
 // Round 0 (the 4096 coarse cells) is the same for every build and comes from a template: no selection, no task emission,
 // and if the build stops there (the BASELINE thresholds do) the packed store is the arena itself.
 #include <hip/hip_runtime.h>
@@ -61,8 +69,8 @@ constexpr uint64_t kOffMask = (1ull << 56) - 1;  // a segment's arena offset; th
 constexpr uint32_t kFrSort = 4096;  // bitonic sort capacity (LDS): the fallback ordering of a batch
 constexpr uint32_t kFrExact = 64;   // candidates left when the digit-by-digit refinement hands over to exact ranking
 // Multi-rank builds: the last double of a rank's part of errs is its STATUS for the round's exchange.  A healthy rank zeroes it
-// (fr_init_kernel / fr_tasks_kernel); a rank whose share of the round failed on the host (device memory) sets it to all ones and
-// enters the exchange all the same; fr_round0_kernel / fr_decide_kernel find it and every rank leaves with an error instead of
+// (fr_init_kernel, the round kernel's leader or fr_batch_kernel); a rank whose share of the round failed on the host (device memory) sets it to all ones and
+// enters the exchange all the same; the round kernel's leader finds it (frPeerCheck) and every rank leaves with an error instead of
 // waiting in a later collective for a rank that has gone.
 constexpr uint32_t kFrStatusPad = 8;
 
