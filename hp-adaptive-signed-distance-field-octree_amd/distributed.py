@@ -10,15 +10,16 @@ Create
     (tests/test_distributed_gloo.py, tests/test_gpu_configs.py).
 
     On GPUs the whole loop sits behind the C ABI (hpsdf_create_distributed) and this module only supplies
-    the all-gather.  Fields the GPU evaluates itself (analytic, mesh, tree-CSG) without nearness
-    weighting take the device-side frontier (csrc/frontier.hip): selection, slicing, decision and
-    bookkeeping run on every rank's GPU and the two exchange points are all-gathers of device buffers.
-    Host callbacks and weighted builds run the host scheduler's rounds (the per-round errors then pass
-    through host memory, staged through a device buffer for the all-gather).  A weighted build also
-    hands the arrays each round accepted to every rank (one more all-gather per round): a weighted
-    incremental fit copies the node's previous rows and may run on any rank.  The Python round loop
-    below is the same algorithm over the stepwise C API: the CPU tests drive it (compute= hook), and
-    HPSDF_PYTHON_ROUND_LOOP=1 forces it on GPUs.
+    the all-gather.  Fields the GPU evaluates itself (analytic, mesh, tree-CSG), with or without
+    nearness weighting, take the device-side frontier (csrc/frontier.hip) on up to 8 ranks: selection,
+    slicing, decision and bookkeeping run on every rank's GPU and the exchange points are all-gathers of
+    device buffers.  A weighted build hands the rows each round fitted to every rank (one more
+    all-gather per round, of the round's part of the arena: a weighted incremental fit copies the
+    node's previous rows and may run on any rank) and needs no exchange of packed coefficients at the
+    end.  Host callbacks and more than 8 ranks run the host scheduler's rounds (the per-round errors
+    then pass through host memory, staged through a device buffer for the all-gather).  The Python
+    round loop below is the same algorithm over the stepwise C API: the CPU tests drive it (compute=
+    hook), and HPSDF_PYTHON_ROUND_LOOP=1 forces it on GPUs.
 
 Continuity (config.continuity.enforce)
     The host-side post-process runs on every rank on its identical copy of the assembled block; its
@@ -138,7 +139,7 @@ def create_distributed(ctx, config, field, K=0, group=None, compute=None, policy
     pod = config.to_pod() if hasattr(config, "to_pod") else config
     if on_gpu and world > 1 and os.environ.get("HPSDF_PYTHON_ROUND_LOOP") != "1":
         # the whole sharded build behind the C ABI (hpsdf_create_distributed): the device-side frontier for fields the GPU
-        # evaluates itself without nearness weighting, the host scheduler's rounds for the rest -- both over this all-gather
+        # evaluates itself (weighted or not, up to 8 ranks), the host scheduler's rounds for the rest -- both over this all-gather
         from . import create_block_distributed
         gather = device_allgather(ctx, group)
         block, stats = create_block_distributed(ctx, config, field, K, rank, world, gather)
