@@ -690,8 +690,10 @@ def create_block(ctx, config, field, K=0):
     """Octree::Create on one GPU -> (serialised block bytes, stats dict)."""
     pod = config.to_pod() if isinstance(config, Config) else config
     blk, sz, st = C.c_void_p(), C.c_size_t(), BuildStats()
-    check(lib().hpsdf_create(ctx.handle if ctx is not None else None, C.byref(pod), field.handle, K, C.byref(blk),
-                             C.byref(sz), C.byref(st)))
+    rc = lib().hpsdf_create(ctx.handle if ctx is not None else None, C.byref(pod), field.handle, K, C.byref(blk), C.byref(sz), C.byref(st))
+    if rc and ctx is not None:
+        ctx._blocks.clear()  # (a failed build gave its blocks back; nothing of it is kept)
+    check(rc)
     if ctx is None:  # (not reached: Create needs a device)
         data = C.string_at(blk, sz.value)
         lib()._libc.free(blk)
@@ -722,6 +724,8 @@ def create_block_distributed(ctx, config, field, K, rank, world, gather):
     blk, size, st = C.c_void_p(), C.c_size_t(), BuildStats()
     rc = lib().hpsdf_create_distributed(ctx.handle, C.byref(pod), field.handle, K, rank, world, C.cast(cb, C.c_void_p), None,
                                         C.byref(blk), C.byref(size), C.byref(st))
+    if failure or rc:
+        ctx._blocks.clear()
     if failure:
         raise failure[0]
     check(rc)
