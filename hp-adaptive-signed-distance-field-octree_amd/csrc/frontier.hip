@@ -172,7 +172,8 @@ struct FrDev {
     // nearness weighting (Octree.cpp:1071-1092, 1209-1247): a fit keeps ONE full coefficient array (an incremental fit
     // carries the old rows over, :847), fit_weight_kernel leaves |mean FApprox| of every fit in `means`, the host turns
     // the means into weights with its libm (pow / exp: what the oracle calls) and fr_weigh_kernel scales the errors
-    uint32_t buildStamp, padB;  // a number of the build (FrHdr::landed)
+    uint32_t buildStamp;  // a number of the build (FrHdr::landed)
+    uint32_t stamps;      // HPSDF_TRACE: the one-workgroup kernels leave their phases' times in FrHdr::dbg (a store a phase, and the next barrier waits for it)
     double target;         // targetErrorThreshold of the build (the header is initialised before the build is known: FrontierWorkspace::clean)
     int32_t weighted;
     // Weighted builds on several ranks: every rank's arena is a REPLICA.  An incremental weighted fit carries the cell's previous rows
@@ -414,7 +415,7 @@ __device__ __forceinline__ void frStoreRecords(uint64_t* st, uint64_t* dst64, co
     }
     __builtin_amdgcn_wave_barrier();
 }
-#define FR_STAMP(k) do { if (threadIdx.x == 0) d.hdr->dbg[k] = __builtin_readcyclecounter(); } while (0)
+#define FR_STAMP(k) do { if (d.stamps && threadIdx.x == 0) d.hdr->dbg[k] = __builtin_readcyclecounter(); } while (0)
 
 // where job j's 9 errors go in the round being prepared (frErrSlot's rule with the coming round's stride), and that round's status slot
 __device__ __forceinline__ uint32_t frErrSlotNext(const FrDev& d, const uint32_t* slice, uint32_t owner, uint32_t j) {
@@ -582,20 +583,35 @@ __device__ bool frBatchBody(const FrDev& d, FrLds& L, uint32_t nQ, uint32_t abov
         int jP[4], jDep[4];
         bool jCoarse[4];
         uint64_t own = 0;
+        // (every job's error and node record asked for before anything is stored: with the stores in between the four jobs' loads
+        // went out one after the other -- the compiler must assume that a store to qErr changes the next job's load -- 14 k cycles)
+        uint32_t jIdx[4];
+        uint64_t jBits[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint32_t j = tid * 4u + (uint32_t)q;
-            jP[q] = 0, jDep[q] = 0, jCoarse[q] = false;
+            jP[q] = 0, jDep[q] = 0, jCoarse[q] = false, jIdx[q] = 0, jBits[q] = 0;
+            if (j < nJobs) jIdx[q] = sVal[j];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t j = tid * 4u + (uint32_t)q;
             if (j >= nJobs) continue;
-            const uint32_t idx = sVal[j];
-            const uint64_t bits = d.qErr[idx];
+            jBits[q] = d.qErr[jIdx[q]];
+            const hpsdf_node& n = d.nodes[jIdx[q]];
+            jP[q] = n.degree, jDep[q] = n.depth;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t j = tid * 4u + (uint32_t)q;
+            if (j >= nJobs) continue;
+            const uint32_t idx = jIdx[q];
+            const uint64_t bits = jBits[q];
             const double e = __longlong_as_double((long long)bits);
             d.wBatchIdx[j] = idx;
             d.wBatchErr[j] = e;
             d.qErr[idx] = kNotQueued;
             atomicAdd(&sHist[frDigit(0, bits, idx)], 1u);
-            const hpsdf_node& n = d.nodes[idx];
-            jP[q] = n.degree, jDep[q] = n.depth;
             jCoarse[q] = fabs(e - HPSDF_INITIAL_NODE_ERR) < DBL_EPSILON;  // coarse, Octree.cpp:806,831
             own += frJobCost(jP[q], jDep[q], jCoarse[q]);
         }
@@ -763,14 +779,25 @@ __device__ bool frBatchBody(const FrDev& d, FrLds& L, uint32_t nQ, uint32_t abov
     uint64_t* sSmp = sKey + 512;
     uint32_t* sCnt = sTmp;
     uint32_t* sBlk = sTmp + 512;
-    if (tid < 512) sCnt[tid] = myCount, sBlk[tid] = myBlocks, sRows[tid] = myRows, sSmp[tid] = mySamples;
-    __syncthreads();
-    for (uint32_t off = 1; off < 512; off <<= 1) {
-        uint32_t a = 0, b = 0;
-        uint64_t r = 0, sm = 0;
-        if (tid < 512 && tid >= off) a = sCnt[tid - off], b = sBlk[tid - off], r = sRows[tid - off], sm = sSmp[tid - off];
+    {
+        // inclusive scans of the four per-class figures over the first 512 threads: inside a wave by shuffles, the eight wave totals
+        // through LDS (two barriers; a Hillis-Steele scan over LDS was nine steps of two)
+        uint32_t a = myCount, b = myBlocks;
+        uint64_t r = myRows, sm = mySamples;
+        const int lane = (int)(tid & 63);
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t a2 = __shfl_up(a, off, 64), b2 = __shfl_up(b, off, 64);
+            const uint64_t r2 = (uint64_t)__shfl_up((long long)r, off, 64), s2 = (uint64_t)__shfl_up((long long)sm, off, 64);
+            if (lane >= off) a += a2, b += b2, r += r2, sm += s2;
+        }
+        uint32_t* wCnt = L.wave;                                   // [8] + [8]
+        uint64_t* wRow = reinterpret_cast<uint64_t*>(sKey + 1024);  // [8] + [8] (behind the scans' 1024 slots)
+        if (tid < 512 && lane == 63) wCnt[tid >> 6] = a, wCnt[8 + (tid >> 6)] = b, wRow[tid >> 6] = r, wRow[8 + (tid >> 6)] = sm;
         __syncthreads();
-        if (tid < 512) sCnt[tid] += a, sBlk[tid] += b, sRows[tid] += r, sSmp[tid] += sm;
+        if (tid < 512) {
+            for (uint32_t w = 0; w < (tid >> 6); ++w) a += wCnt[w], b += wCnt[8 + w], r += wRow[w], sm += wRow[8 + w];
+            sCnt[tid] = a, sBlk[tid] = b, sRows[tid] = r, sSmp[tid] = sm;
+        }
         __syncthreads();
     }
     FR_STAMP(6);
@@ -1321,7 +1348,7 @@ __device__ double frRunChain(const FrDev& d, FrLds& L, double total, uint32_t nO
     };
     if (loader) loadChunk(0, sOps);
     __syncthreads();
-    if (tid == 0) d.hdr->dbg[15] = __builtin_readcyclecounter();
+    if (d.stamps && tid == 0) d.hdr->dbg[15] = __builtin_readcyclecounter();
     for (uint32_t c0 = 0, half = 0; c0 < nOps; c0 += 2048, half ^= 1u) {
         const uint32_t n = nOps - c0 < 2048u ? nOps - c0 : 2048u;
         if (loader) {
@@ -1392,7 +1419,7 @@ __device__ double frRunChain(const FrDev& d, FrLds& L, double total, uint32_t nO
                     : "memory", "scc", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
             }
             for (; q < n; ++q) total = total + src[q];
-            if (tid == 0 && c0 == 0) d.hdr->dbg[16] = __builtin_readcyclecounter();
+            if (d.stamps && tid == 0 && c0 == 0) d.hdr->dbg[16] = __builtin_readcyclecounter();
         }
         __syncthreads();
     }
@@ -1421,10 +1448,10 @@ __device__ void frChainTotal(const FrDev& d, FrLds& L) {
     __threadfence();
     uint32_t nOps = frLoad(&h->rP) + 9u * frLoad(&h->rH);
     if (L.stuck) nOps = 0;
-    if (tid == 0) h->dbg[13] = __builtin_readcyclecounter();
+    if (d.stamps && tid == 0) h->dbg[13] = __builtin_readcyclecounter();
     total = frRunChain(d, L, total, nOps, false);
     if (tid == 0) {
-        h->dbg[14] = __builtin_readcyclecounter();
+        if (d.stamps) h->dbg[14] = __builtin_readcyclecounter();
         if (L.stuck) atomicExch(&h->stuck, 1u);
         h->rTotal = total;
         __threadfence();
@@ -1458,9 +1485,9 @@ __device__ void frLeadRound(const FrDev& d, FrLds& L, int pre) {
     FR_STAMP(9);
     double total0 = 0.0;
     if (round0) {  // the round's total, here and now: every cell's (newErr - initialErr) in cell order
-        if (tid == 0) h->dbg[13] = __builtin_readcyclecounter();
+        if (d.stamps && tid == 0) h->dbg[13] = __builtin_readcyclecounter();
         total0 = frRunChain(d, L, h->total, nJobs, true);
-        if (tid == 0) h->dbg[14] = __builtin_readcyclecounter();
+        if (d.stamps && tid == 0) h->dbg[14] = __builtin_readcyclecounter();
     }
     if (tid == 0 && !frWaitAtLeast(&h->arrive, gridDim.x - 1u)) L.stuck = 1;  // (the update workgroups, and the last one's "header read")
     __syncthreads();
@@ -2578,6 +2605,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
 
     d.errStride = stride0, d.errStrideNext = strideK;
     d.buildStamp = ++ws->buildStamp ? ws->buildStamp : ++ws->buildStamp;  // (never 0)
+    d.stamps = trace ? 1u : 0u;
     ws->hostHdr->round = 0, ws->hostHdr->done = 0;  // (the mirror still shows the previous build's last round: the waits below watch it)
     auto initDev = [&] {  // what fr_init_kernel sees: the arrays as they are now, round 0's stride (where this rank's status for round 0's exchange lies)
         FrDev di = d;
