@@ -483,6 +483,11 @@ class Field:
         return dict(zip(("wave_queries", "node_visits", "tri_tests", "tri_test_lanes", "leaf_pairs", "bound_batches", "closest_batches",
                          "seed_exact"), (int(v) for v in out)))
 
+    def release_host_copies(self):
+        """Drops the host-side copies of a mesh field's arrays that calls of one or two points are answered from (they come back with
+        the next such call)."""
+        check(lib().hpsdf_field_release_host_copies(self.handle))
+
     def close(self):
         if self.handle:
             lib().hpsdf_field_destroy(self.handle)

@@ -281,6 +281,9 @@ def test_mesh_scalar_calls_answered_on_the_host_equal_the_kernels(H, O, ctx, mon
         assert np.array_equal(bits(two), bits(want)), k
         some = np.concatenate([f.eval(ctx, pts[i:i + 32]) for i in range(0, len(pts), 32)])  # from three points on: one launch a call
         assert np.array_equal(bits(some), bits(want)), k
+        f.release_host_copies()                             # the copies go, the next scalar call fetches them again
+        again = np.concatenate([f.eval(ctx, pts[i:i + 1]) for i in range(0, len(pts), 7)])
+        assert np.array_equal(bits(again), bits(want[::7])), k
         f.close()
 
 
