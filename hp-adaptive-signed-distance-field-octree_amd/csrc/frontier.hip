@@ -415,6 +415,20 @@ __device__ __forceinline__ void frStoreRecords(uint64_t* st, uint64_t* dst64, co
     }
     __builtin_amdgcn_wave_barrier();
 }
+__device__ __forceinline__ uint32_t frLoad(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Hand-offs between workgroups (MI355X_MICROARCH.md, "Valid forms"): the producer's waves drain their stores at the workgroup's barrier,
+// ONE lane releases (the XCD's L2 is written back once, not once a wave: sixteen waves fencing cost two to four times one lane's fence)
+// and then signals with a relaxed atomic; the consumer polls relaxed, ONE lane acquires when the poll has matched, the workgroup's
+// barrier holds the other waves until the invalidate has completed, then plain loads.  The waits behind the fences are written out: the
+// compiler may drop the one after the write-back when it thinks the wave has nothing in flight.
+__device__ __forceinline__ void frRelease() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void frAcquire() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 #define FR_STAMP(k) do { if (d.stamps && threadIdx.x == 0) d.hdr->dbg[k] = __builtin_readcyclecounter(); } while (0)
 
 // where job j's 9 errors go in the round being prepared (frErrSlot's rule with the coming round's stride), and that round's status slot
@@ -556,8 +570,8 @@ __device__ bool frBatchBody(const FrDev& d, FrLds& L, uint32_t nQ, uint32_t abov
     FR_STAMP(3);
     if (INLINE && watchStamp != 0 && tid == 0) {
         uint32_t early = 0;
-        if (__hip_atomic_load(&h->chainStamp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == watchStamp) {
-            __threadfence();
+        if (frLoad(&h->chainStamp) == watchStamp) {
+            frAcquire();
             early = *(volatile double*)&h->rTotal < d.target ? 1u : 0u;  // Octree.cpp:216
         }
         L.early = early;
@@ -1100,18 +1114,15 @@ __global__ __launch_bounds__(256) void fr_tasks_kernel(FrDev d) {
 constexpr uint32_t kFrInlineNodes = 65536;  // trees up to here are selected by the closing workgroup itself (64 passes of 1024 lanes)
 constexpr unsigned long long kFrWaitTicks = 200000000ull;  // two seconds of the 100 MHz clock: a wait this long means a workgroup is gone
 
-__device__ __forceinline__ uint32_t frLoad(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// one lane waits until *p >= want (the counter's writers fence before they add); false: the wait ran out
+// one lane waits until *p >= want, then acquires (the counter's writers release before they add); false: the wait ran out
 __device__ bool frWaitAtLeast(const uint32_t* p, uint32_t want) {
-    if (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
     const unsigned long long t0 = wall_clock64();
-    for (;;) {
-        for (int k = 0; k < 64; ++k) {
-            if (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
-            __builtin_amdgcn_s_sleep(1);
-        }
-        if (wall_clock64() - t0 > kFrWaitTicks) return false;
+    while (frLoad(p) < want) {
+        for (int k = 0; k < 64 && frLoad(p) < want; ++k) __builtin_amdgcn_s_sleep(1);
+        if (frLoad(p) < want && wall_clock64() - t0 > kFrWaitTicks) return false;
     }
+    frAcquire();
+    return true;
 }
 
 // Workgroups 1 .. gridDim.x - 2: 128 jobs each, eight lanes per job.
@@ -1293,11 +1304,11 @@ __device__ void frUpdateJobs(const FrDev& d, FrLds& L) {
     __syncthreads();
     for (uint32_t i = tid; i < 2048; i += 1024)
         if (L.hist[i]) atomicAdd(&h->hist1[i], L.hist[i]);
-    __threadfence();
-    __syncthreads();
+    __syncthreads();  // (every wave's stores and atomics have drained)
     if (tid == 0) {
-        if (!round0) atomicAdd(&h->opsArrive, 1u);
-        atomicAdd(&h->arrive, 1u);
+        frRelease();
+        if (!round0) __hip_atomic_fetch_add(&h->opsArrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&h->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1305,16 +1316,16 @@ __device__ void frUpdateJobs(const FrDev& d, FrLds& L) {
 __device__ __forceinline__ void frMirror(const FrDev& d) {
     const uint32_t tid = threadIdx.x;
     constexpr uint32_t kRoundWord = offsetof(FrHdr, round) / 4;
-    __threadfence();
-    __syncthreads();
+    __syncthreads();  // (the header's writers have drained their stores; the copy reads past the L1)
     constexpr uint32_t kLandedWord = offsetof(FrHdr, landed) / 4;  // (landed and stored[] live in the mirror alone)
     if (tid < kFrHdrCopyBytes / 4 && tid != kRoundWord && (tid < kLandedWord || tid > kLandedWord + 2))
         reinterpret_cast<volatile uint32_t*>(d.hostHdr)[tid] = reinterpret_cast<volatile uint32_t*>(d.hdr)[tid];
-    __threadfence_system();
-    __syncthreads();
+    __syncthreads();  // (... and the copying waves theirs)
     if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: the words above are in host memory before the round word is
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         reinterpret_cast<volatile uint32_t*>(d.hostHdr)[kRoundWord] = reinterpret_cast<volatile uint32_t*>(d.hdr)[kRoundWord];
-        __threadfence_system();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 }
 
@@ -1441,11 +1452,10 @@ __device__ void frChainTotal(const FrDev& d, FrLds& L) {
     if (tid == 0) L.stuck = 0;
     __syncthreads();
     // (the header has been read: the leader may rewrite it.  The round's counters it leaves alone until this workgroup has finished.)
-    if (tid == 0) __hip_atomic_fetch_add(&h->arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_fetch_add(&h->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (nothing is published: "I have read")
     if (round0) return;
-    if (tid == 0 && !frWaitAtLeast(&h->opsArrive, gridDim.x - 2u)) L.stuck = 1;
+    if (tid == 0 && !frWaitAtLeast(&h->opsArrive, gridDim.x - 2u)) L.stuck = 1;  // (acquires)
     __syncthreads();
-    __threadfence();
     uint32_t nOps = frLoad(&h->rP) + 9u * frLoad(&h->rH);
     if (L.stuck) nOps = 0;
     if (d.stamps && tid == 0) h->dbg[13] = __builtin_readcyclecounter();
@@ -1454,8 +1464,8 @@ __device__ void frChainTotal(const FrDev& d, FrLds& L) {
         if (d.stamps) h->dbg[14] = __builtin_readcyclecounter();
         if (L.stuck) atomicExch(&h->stuck, 1u);
         h->rTotal = total;
-        __threadfence();
-        __hip_atomic_store(&h->chainStamp, stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        frRelease();
+        __hip_atomic_store(&h->chainStamp, stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1489,9 +1499,8 @@ __device__ void frLeadRound(const FrDev& d, FrLds& L, int pre) {
         total0 = frRunChain(d, L, h->total, nJobs, true);
         if (d.stamps && tid == 0) h->dbg[14] = __builtin_readcyclecounter();
     }
-    if (tid == 0 && !frWaitAtLeast(&h->arrive, gridDim.x - 1u)) L.stuck = 1;  // (the update workgroups, and the last one's "header read")
+    if (tid == 0 && !frWaitAtLeast(&h->arrive, gridDim.x - 1u)) L.stuck = 1;  // (the update workgroups, and the last one's "header read"; acquires)
     __syncthreads();
-    __threadfence();
     FR_STAMP(10);
     // ---- the round closes
     const uint32_t nP = frLoad(&h->rP), nH = frLoad(&h->rH), nD = frLoad(&h->rD), md = frLoad(&h->rMaxDeg);
@@ -1503,7 +1512,11 @@ __device__ void frLeadRound(const FrDev& d, FrLds& L, int pre) {
     const bool stopsHere = round0 && total0 < target;
     if (!stopsHere)
         for (uint32_t i = tid; i < 2048; i += 1024) L.hist[i] = frLoad(&h->hist1[i]);
-    if (tid == 0) L.c = (round0 || frLoad(&h->chainStamp) == stamp) ? 1u : 0u;
+    if (tid == 0) {
+        const bool there = !round0 && frLoad(&h->chainStamp) == stamp;
+        if (there) frAcquire();  // (rTotal is read below)
+        L.c = (round0 || there) ? 1u : 0u;
+    }
     __syncthreads();
     bool haveTotal = L.c != 0;
     const bool canGoOn = nQ != 0 && overflow == 0;
@@ -1529,8 +1542,7 @@ __device__ void frLeadRound(const FrDev& d, FrLds& L, int pre) {
         if (round0) {
             total = total0;
         } else {
-            __threadfence();
-            total = *(volatile double*)&h->rTotal;
+            total = *(volatile double*)&h->rTotal;  // (behind the acquire of whoever saw the stamp, and a barrier)
         }
         done = total < target || !canGoOn || overflow != 0;  // Octree.cpp:216
     }
@@ -1594,7 +1606,6 @@ __device__ void frLeadRound(const FrDev& d, FrLds& L, int pre) {
         }
         if (!haveTotal) {
             awaitTotal();
-            __threadfence();
             total = *(volatile double*)&h->rTotal;
             done = total < target || overflow != 0;
             if (done && tid == 0) h->fits = fits0, h->samples = samples0, h->arenaUsed = arena0, h->sampleUsed = 0, h->splitFits = split0;
@@ -1722,11 +1733,14 @@ __global__ __launch_bounds__(256) void fr_store_kernel(FrDev d) {
         }
         sRows[tid + 1] = inc;
         if (tid == 0) sRows[0] = 0;
-        __threadfence_system();
-        if (tid == 0 && atomicAdd(&h->storeArrive[0], 1u) == gridDim.x - 1u) {  // the node array is complete
-            __threadfence_system();
-            *(volatile uint32_t*)&d.hostHdr->stored[0] = d.buildStamp;
-            __threadfence_system();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this wave's stores have left)
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: they are in host memory before the count says so
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (atomicAdd(&h->storeArrive[0], 1u) == gridDim.x - 1u) {  // the node array is complete
+                *(volatile uint32_t*)&d.hostHdr->stored[0] = d.buildStamp;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         }
     }
     __syncthreads();
@@ -1751,12 +1765,14 @@ __global__ __launch_bounds__(256) void fr_store_kernel(FrDev d) {
         const double* src = (d.world == 1 || d.replica) ? d.arena + (so & kOffMask) : d.pack + (size_t)(so >> 56) * d.packStride + d.packPos[(size_t)node * kFrSegs + sg];
         d.store[(size_t)sStart[lo] + r] = src[r - r0];
     }
-    __threadfence_system();
-    __syncthreads();
-    if (tid == 0 && atomicAdd(&h->storeArrive[1], 1u) == gridDim.x - 1u) {
-        __threadfence_system();
-        *(volatile uint32_t*)&d.hostHdr->stored[1] = d.buildStamp;
-        __threadfence_system();
+    __syncthreads();  // (every wave's stores have left)
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (atomicAdd(&h->storeArrive[1], 1u) == gridDim.x - 1u) {
+            *(volatile uint32_t*)&d.hostHdr->stored[1] = d.buildStamp;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     }
 }
 
