@@ -1647,11 +1647,13 @@ __global__ __launch_bounds__(1024) void fr_round_kernel(FrDev d, int pre) {
 __global__ __launch_bounds__(256) void fr_subtree_kernel(FrDev d) {
     const FrHdr* h = d.hdr;
     if (!h->done || h->overflow) return;
-    // The first three levels below the root -- nodes 1 .. 584 of the uniformly refined tree -- are ancestors of everything: a
-    // workgroup (256 consecutive nodes, i.e. relatives) adds its leaves up in LDS first and touches each of them once (every leaf
-    // for itself: ten thousand atomics on the same eight words, 131 us)
-    __shared__ uint32_t sTop[1024];
-    for (uint32_t k = threadIdx.x; k < 1024; k += 256) sTop[k] = 0;
+    // The uniformly refined tree's own nodes -- indices below 4681, levels 0 to 4 -- are ancestors of everything: a workgroup (256
+    // consecutive nodes, i.e. relatives) adds its leaves up in LDS first and touches each of them once (every leaf for itself: ten
+    // thousand atomics on the same eight words, 131 us; the first three levels alone in LDS: 21 us -- the eight children of a split
+    // depth-4 cell still met at their parent's word)
+    constexpr uint32_t kTop = 4736;  // >= (8^5 - 1) / 7 = 4681
+    __shared__ uint32_t sTop[kTop];
+    for (uint32_t k = threadIdx.x; k < kTop; k += 256) sTop[k] = 0;
     __syncthreads();
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < h->nNodes) {
@@ -1660,7 +1662,7 @@ __global__ __launch_bounds__(256) void fr_subtree_kernel(FrDev d) {
             const uint32_t c = frCoef((int)deg);
             uint32_t a = d.parent[i];
             while (a != 0) {
-                if (a < 1024u)
+                if (a < kTop)
                     atomicAdd(&sTop[a], c);
                 else
                     atomicAdd(&d.sub[a], c);
@@ -1669,7 +1671,7 @@ __global__ __launch_bounds__(256) void fr_subtree_kernel(FrDev d) {
         }
     }
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < 1024; k += 256)
+    for (uint32_t k = threadIdx.x; k < kTop; k += 256)
         if (sTop[k]) atomicAdd(&d.sub[k], sTop[k]);
 }
 
