@@ -116,27 +116,44 @@ __device__ __forceinline__ void spmvChunk(const CgDev& d, const double* __restri
 // the rows look like -- parks the products in LDS, and the rows whose first entry lies in that range are then summed from
 // LDS, a thread per row, strictly left to right: the same sums, bit for bit.  The chunk sums of in . out need all 256 rows
 // of a chunk, which no longer sit in one workgroup: cg_dot_kernel forms them afterwards.
+constexpr int kCgPer = (int)((kCgEntriesPerWg + kCgRowTail) / 1024);  // entries a thread of the entry-cut SpMV fetches
+struct SpmvFetched {  // a thread's entries and the vector's values at their columns: everything the products need but beta
+    double v[kCgPer], a[kCgPer], b[kCgPer];
+    uint32_t rs, re;
+};
+// the fetches of the entry-cut SpMV: they do not depend on beta, so step 1 asks for them BEFORE it sums the chunk sums that give beta
+// (two dependent trips to memory that used to follow the reduction's two)
 template <bool FUSED>
-__device__ __forceinline__ void spmvEntries(const CgDev& d, const double* __restrict__ in, const double* __restrict__ pOld, double beta,
-                                            double* __restrict__ pNew, double shift, double* __restrict__ out, double* sProd /* kCgEntriesPerWg + kCgRowTail */) {
-    const uint32_t w = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ SpmvFetched spmvFetch(const CgDev& d, const double* __restrict__ in, const double* __restrict__ pOld, uint32_t w) {
+    const uint32_t tid = threadIdx.x;
     const uint64_t e0 = (uint64_t)w * kCgEntriesPerWg, nnz = d.rowPtr[d.n];
-    auto value = [&](uint64_t j) { return FUSED ? in[j] + beta * pOld[j] : in[j]; };
-    constexpr int kPer = (int)((kCgEntriesPerWg + kCgRowTail) / 1024);
-    double v[kPer];
-    uint32_t c[kPer];
+    SpmvFetched f;
+    uint32_t c[kCgPer];
 #pragma unroll
-    for (int k = 0; k < kPer; ++k) {
+    for (int k = 0; k < kCgPer; ++k) {
         const uint64_t e = e0 + tid + (uint64_t)k * 1024;
         const bool on = e < nnz;
-        v[k] = on ? d.val[e] : 0.0;
+        f.v[k] = on ? d.val[e] : 0.0;
         c[k] = on ? d.col[e] : 0u;
     }
-    const uint32_t rs = d.wgRow[w], re = d.wgRow[w + 1];
+    f.rs = d.wgRow[w], f.re = d.wgRow[w + 1];
 #pragma unroll
-    for (int k = 0; k < kPer; ++k) sProd[tid + k * 1024] = v[k] * value(c[k]);
+    for (int k = 0; k < kCgPer; ++k) {
+        f.a[k] = in[c[k]];
+        f.b[k] = FUSED ? pOld[c[k]] : 0.0;
+    }
+    return f;
+}
+template <bool FUSED>
+__device__ __forceinline__ void spmvEntries(const CgDev& d, const SpmvFetched& f, const double* __restrict__ in, const double* __restrict__ pOld, double beta,
+                                            double* __restrict__ pNew, double shift, double* __restrict__ out, double* sProd /* kCgEntriesPerWg + kCgRowTail */, uint32_t w) {
+    const uint32_t tid = threadIdx.x;
+    const uint64_t e0 = (uint64_t)w * kCgEntriesPerWg;
+    auto value = [&](uint64_t j) { return FUSED ? in[j] + beta * pOld[j] : in[j]; };
+#pragma unroll
+    for (int k = 0; k < kCgPer; ++k) sProd[tid + k * 1024] = f.v[k] * (FUSED ? f.a[k] + beta * f.b[k] : f.a[k]);
     __syncthreads();
-    for (uint32_t r = rs + tid; r < re; r += 1024u) {
+    for (uint32_t r = f.rs + tid; r < f.re; r += 1024u) {
         const uint32_t a = (uint32_t)(d.rowPtr[r] - e0), b = (uint32_t)(d.rowPtr[r + 1] - e0);
         const double pi = value(r);
         if (FUSED) pNew[r] = pi;
@@ -258,16 +275,18 @@ __global__ __launch_bounds__(1024, 8) void cg_step1e_kernel(CgDev d, int k) {
     if (d.s->done) return;
     double* const P[2] = {d.p, d.rhs};
     if (k == 0) {
-        spmvEntries<false>(d, d.p, nullptr, 0.0, nullptr, d.s->lambda, d.tmp, sProd);
+        spmvEntries<false>(d, spmvFetch<false>(d, d.p, nullptr, blockIdx.x), d.p, nullptr, 0.0, nullptr, d.s->lambda, d.tmp, sProd, blockIdx.x);
         return;
     }
+    const SpmvFetched f = spmvFetch<true>(d, d.z, P[(k - 1) & 1], blockIdx.x);  // (in flight while the chunk sums are added up)
     double beta;
     if (!cgOpenIteration(d, k, sProd, blockIdx.x == 0, beta)) return;
-    spmvEntries<true>(d, d.z, P[(k - 1) & 1], beta, P[k & 1], d.s->lambda, d.tmp, sProd);
+    spmvEntries<true>(d, f, d.z, P[(k - 1) & 1], beta, P[k & 1], d.s->lambda, d.tmp, sProd, blockIdx.x);
 }
 __global__ __launch_bounds__(1024, 8) void cg_spmv_aux_e_kernel(CgDev d, int which) {
     __shared__ double sProd[kCgEntriesPerWg + kCgRowTail];
-    spmvEntries<false>(d, which == 0 ? d.c : d.x, nullptr, 0.0, nullptr, which == 1 ? d.s->lambda : 0.0, d.tmp, sProd);
+    const double* in = which == 0 ? d.c : d.x;
+    spmvEntries<false>(d, spmvFetch<false>(d, in, nullptr, blockIdx.x), in, nullptr, 0.0, nullptr, which == 1 ? d.s->lambda : 0.0, d.tmp, sProd, blockIdx.x);
 }
 
 // after the last iteration of a batch: has the loop ended?  (one workgroup; the next batch's first kernel would find out
@@ -364,18 +383,21 @@ __global__ __launch_bounds__(256) void cg_scalar_aux_kernel(CgDev d, int which) 
 __global__ __launch_bounds__(256) void cg_step2_kernel(CgDev d, int k) {
     __shared__ double sh[514];
     if (d.s->done) return;
-    double pAp, unused;
-    sumChunksAll<false>(d.nChunks, d.partA, nullptr, sh, pAp, unused);
-    const double alpha = d.s->absRing[k & 1] / pAp;
     const double* p = (k & 1) ? d.rhs : d.p;
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const bool live = i < d.n;
+    // (this row's operands, asked for before the chunk sums are added up: they do not depend on alpha)
+    double pi = 0.0, xi = 0.0, ri = 0.0, ti = 0.0, di = 0.0;
+    if (live) pi = p[i], xi = d.x[i], ri = d.r[i], ti = d.tmp[i], di = d.dinv[i];
+    double pAp, unused;
+    sumChunksAll<false>(d.nChunks, d.partA, nullptr, sh, pAp, unused);
+    const double alpha = d.s->absRing[k & 1] / pAp;
     double rr = 0.0, rz = 0.0;
     if (live) {
-        d.x[i] += alpha * p[i];
-        const double r = d.r[i] - alpha * d.tmp[i];
+        d.x[i] = xi + alpha * pi;
+        const double r = ri - alpha * ti;
         d.r[i] = r;
-        const double z = d.dinv[i] * r;
+        const double z = di * r;
         d.z[i] = z;
         rr = r * r;
         rz = r * z;
