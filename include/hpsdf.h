@@ -428,13 +428,15 @@ HPSDF_API int hpsdf_create(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_
  * rank's d_buf must hold all `world` parts.  It returns 0 on success.  With RCCL this is one call,
  *     ncclAllGather((char*)d_buf + rank * n, d_buf, n, ncclChar, comm, stream)      (include/hpsdf_rccl.hpp);
  * the library itself does not link RCCL.
- * Fields the device evaluates itself, without nearness weighting, run the device-side frontier (slices cut, errors
- * decided and the tree updated on every rank's GPU).  Host callbacks, nearness-weighted configs, logging and K > 4096 run
- * the host scheduler's rounds, sharded the same way: the exchanges are staged through a device buffer for the same
- * `gather`, and a weighted build also hands the arrays each round accepted to every rank (hpsdf_build_rows_*).
+ * Fields the device evaluates itself run the device-side frontier on up to 8 ranks (slices cut, errors decided and the tree
+ * updated on every rank's GPU).  A nearness-weighted config does too (round 5): a weighted fit reads the cell's earlier rows, so
+ * the round's part of the coefficient arena is laid out alike on every rank and exchanged as well -- one more call of `gather`
+ * a round, in front of the errors' -- and nothing is exchanged at the end.  Host callbacks, logging, K > 4096 and worlds beyond 8
+ * run the host scheduler's rounds, sharded the same way (same bytes): the exchanges are staged through a device buffer for the
+ * same `gather`, and a weighted build hands the arrays each round accepted to every rank (hpsdf_build_rows_*).
  * The stepwise hpsdf_build_* calls expose the same loop to callers with a transport of their own.
- * Fields the device evaluates itself run the device-side frontier on up to 8 ranks when the config has no nearness weighting;
- * weighted configs on several ranks and worlds beyond 8 run the host scheduler's sharded rounds (same bytes).
+ * stats: everything describes the whole build and is the same on every rank, except `fits` and `samples`, which count the rank's
+ * own share (their sums over the ranks are the single-rank figures).
  * FAILURES: a rank whose share of a round fails on its own (device memory one GPU cannot serve) still enters the exchange the
  * other ranks are heading for, with a status word set in its part of the exchanged buffer, and then returns its error; every
  * other rank finds the status after the exchange and returns HPSDF_ERR_STATE naming the rank -- nobody is left waiting in a
