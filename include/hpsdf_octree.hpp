@@ -322,8 +322,8 @@ class Octree {
     /// Additive: Create() over `world` GPUs of one node -- one Octree per GPU (SetDevice), every rank calls Create with
     /// the same config and field; `gather` is the in-place all-gather of hpsdf_create_distributed (for RCCL:
     /// hpsdf_rccl::AllGather with an hpsdf_rccl::Comm as `user`, include/hpsdf_rccl.hpp).  Every rank ends with the
-    /// identical tree.  Works for every field and config: device-evaluated fields without nearness weighting take the
-    /// device-side frontier, std::function fields and weighted configs the host scheduler, sharded over the same gather.
+    /// identical tree.  Works for every field and config: device-evaluated fields (weighted configs included) take the
+    /// device-side frontier on up to 8 ranks, std::function fields the host scheduler, sharded over the same gather.
     void SetRanks(int rank, int world, hpsdf_allgather_fn gather, void* user) {
         rank_ = rank, world_ = world, gather_ = gather, gatherUser_ = user;
     }
