@@ -768,6 +768,45 @@ def _create_on_simulated_ranks(H, world, cfg, make_field, K):
     return out
 
 
+@pytest.mark.parametrize("seed", [3, 11, 29, 1007, 1044, 5132])
+def test_random_builds_on_simulated_ranks(H, ctx, seed):
+    """tools/fuzz_ranks.py's sweep in small: a random CSG field, root box, threshold, round size, weighting (none / Polynomial /
+    Exponential) and world size 2..4 -- every rank's block equals the single-rank block, the statistics too (a rank counts its own
+    fits and samples: their sums are the single-rank figures).  Weighted builds take the device frontier's replica mode."""
+    rng = np.random.default_rng(seed)
+    spec = []
+    for k in range(int(rng.integers(1, 4))):
+        kind = int(rng.integers(0, 4))
+        c = rng.uniform(-0.3, 0.3, 3)
+        if kind == H.PRIM_SPHERE:
+            par = list(c) + [float(rng.uniform(0.08, 0.35))]
+        elif kind == H.PRIM_BOX:
+            par = list(c) + list(rng.uniform(0.05, 0.25, 3))
+        elif kind == H.PRIM_TORUS_Y:
+            par = list(c) + [float(rng.uniform(0.1, 0.25)), float(rng.uniform(0.03, 0.08))]
+        else:
+            nrm = rng.normal(size=3)
+            nrm /= np.linalg.norm(nrm)
+            par = list(nrm) + [float(rng.uniform(-0.2, 0.2))]
+        spec.append((kind, H.OP_UNION if k == 0 else int(rng.integers(0, 3)), [float(x) for x in par]))
+    lo = tuple(float(x) for x in (-0.5 + rng.uniform(-0.2, 0.2, 3)).astype(np.float32))
+    hi = tuple(float(x) for x in (0.5 + rng.uniform(-0.2, 0.3, 3)).astype(np.float32))
+    target = float(rng.choice([1e-5, 1e-6, 3e-7, 1e-7, 3e-8]))
+    K = int(rng.choice([64, 256, 1024, 4096]))
+    wtype = int(rng.choice([0, 1, 2, 2]))
+    world = int(rng.integers(2, 5))
+    cfg = H.make_config(target, lo, hi)
+    if wtype:
+        cfg.nearnessWeighting_type, cfg.nearnessWeighting_strength = wtype, float(rng.choice([2.0, 3.0]))
+    one, st = H.create_block(ctx, cfg, H.Field.analytic(spec), K)
+    res = _create_on_simulated_ranks(H, world, cfg, lambda c: H.Field.analytic(spec), K)
+    keys = ("rounds", "jobs", "p_refines", "h_refines", "dropped", "n_nodes", "n_leaves", "n_coeffs", "total_error")
+    for blk, s in res:
+        assert blk == one
+        assert all(s[k] == st[k] for k in keys) and s["device_frontier"] == 1
+    assert sum(s["fits"] for _, s in res) == st["fits"] and sum(s["samples"] for _, s in res) == st["samples"]
+
+
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_create_distributed_device_frontier_byte_identical(H, ctx, world):
     """The sharded build of the C ABI (hpsdf_create_distributed: slices cut on the device, one all-gather per round, one
