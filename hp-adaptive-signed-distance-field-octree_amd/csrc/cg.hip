@@ -291,22 +291,30 @@ __global__ __launch_bounds__(1024, 8) void cg_spmv_aux_e_kernel(CgDev d, int whi
 
 // after the last iteration of a batch: has the loop ended?  (one workgroup; the next batch's first kernel would find out
 // the same, one launch and one host round trip later)
-__global__ __launch_bounds__(64) void cg_check_kernel(CgDev d, int k) {
+__global__ __launch_bounds__(64) void cg_check_kernel(CgDev d, int k, uint32_t stamp) {
     __shared__ double tile[514];
-    if (d.s->done) return;
-    double rr, rz;
-    sumChunksAll<true>(d.nChunks, d.partB, d.partC, tile, rr, rz);
-    if (threadIdx.x != 0) return;
     CgScalars& s = *d.s;
-    if (rr < s.threshold) {
-        s.resNorm2 = rr;
-        s.done = 1;
-    } else if (k >= s.maxIter) {
-        s.resNorm2 = rr;
-        s.absNew = rz;
-        s.beta = rz / s.absRing[(k - 1) & 1];
-        s.it = k;
-        s.done = 2;
+    if (!s.done) {  // (uniform)
+        double rr, rz;
+        sumChunksAll<true>(d.nChunks, d.partB, d.partC, tile, rr, rz);
+        if (threadIdx.x == 0) {
+            if (rr < s.threshold) {
+                s.resNorm2 = rr;
+                s.done = 1;
+            } else if (k >= s.maxIter) {
+                s.resNorm2 = rr;
+                s.absNew = rz;
+                s.beta = rz / s.absRing[(k - 1) & 1];
+                s.it = k;
+                s.done = 2;
+            }
+        }
+    }
+    if (threadIdx.x == 0 && d.hostFlag != nullptr) {  // tell the host (which watches these words) that the batch is over, and how
+        d.hostFlag[0] = (uint32_t)s.done;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        d.hostFlag[1] = stamp;
     }
 }
 
@@ -445,7 +453,7 @@ hipError_t launchCgFinish(hipStream_t stream, const CgDev& d) {
     return hipGetLastError();
 }
 
-hipError_t launchCgIterations(hipStream_t stream, const CgDev& d, int firstIteration, int iterations) {
+hipError_t launchCgIterations(hipStream_t stream, const CgDev& d, int firstIteration, int iterations, uint32_t stamp) {
     if (d.n == 0 || iterations <= 0) return hipSuccess;
     if (d.nChunks != (d.n + kCgChunk - 1) / kCgChunk) return hipErrorInvalidValue;
     const dim3 wide((unsigned)d.nChunks), one(1);
@@ -458,7 +466,7 @@ hipError_t launchCgIterations(hipStream_t stream, const CgDev& d, int firstItera
         }
         hipLaunchKernelGGL(cg_step2_kernel, wide, dim3(256), 0, stream, d, k);
     }
-    hipLaunchKernelGGL(cg_check_kernel, one, dim3(64), 0, stream, d, firstIteration + iterations);
+    hipLaunchKernelGGL(cg_check_kernel, one, dim3(64), 0, stream, d, firstIteration + iterations, stamp);
     return hipGetLastError();
 }
 

@@ -664,11 +664,14 @@ struct Keep {
     char* dBase = nullptr;
     uint64_t dCap = 0;
     int device = -1;
+    uint32_t* pinFlag = nullptr;  // two words of pinned host memory the solve's check kernel writes (CgDev::hostFlag)
+    uint32_t flagStamp = 0;
     ~Keep() {
         if (dBase) {
             (void)hipSetDevice(device);
             (void)hipFree(dBase);
         }
+        if (pinFlag) (void)hipHostFree(pinFlag);
     }
 };
 
@@ -724,6 +727,7 @@ static int solveOnDevice(hpsdf_ctx* ctx, Keep& keep, const ContinuityDeviceMatri
         return q;
     };
     CgDev d;
+    d.hostFlag = nullptr;
     d.n = n, d.nChunks = nChunks;
     double* dC = (double*)take(n * 8);
     d.c = dC;
@@ -760,10 +764,32 @@ static int solveOnDevice(hpsdf_ctx* ctx, Keep& keep, const ContinuityDeviceMatri
     if (e == hipSuccess) e = launchCgStart(stm, d);
     if (e == hipSuccess && trace) e = hipStreamSynchronize(stm);
     const double tt2 = nowMs();
+    // Batches of 16 iterations; whether the loop has ended the check kernel behind each batch writes into two words of pinned host
+    // memory, which the host watches (~3 us; waking up from hipStreamSynchronize ~20, seven times a solve) -- two milliseconds of
+    // watching, then the ordinary wait.
+    if (e == hipSuccess && !keep.pinFlag && hipHostMalloc((void**)&keep.pinFlag, 64, hipHostMallocDefault) != hipSuccess) keep.pinFlag = nullptr;
+    uint32_t* dFlag = nullptr;
+    if (keep.pinFlag && hipHostGetDevicePointer((void**)&dFlag, keep.pinFlag, 0) != hipSuccess) dFlag = nullptr;
+    d.hostFlag = dFlag;
     for (int k0 = 0; e == hipSuccess; k0 += 16) {
-        e = launchCgIterations(stm, d, k0, 16);
-        if (e == hipSuccess) e = hipMemcpyAsync(&s, d.s, sizeof s, hipMemcpyDeviceToHost, stm);
-        if (e == hipSuccess) e = hipStreamSynchronize(stm);
+        const uint32_t stamp = ++keep.flagStamp ? keep.flagStamp : ++keep.flagStamp;
+        e = launchCgIterations(stm, d, k0, 16, stamp);
+        if (e != hipSuccess) break;
+        bool seen = false;
+        if (dFlag) {
+            const volatile uint32_t* f = keep.pinFlag;
+            const double limit = nowMs() + 2.0;
+            while (f[1] != stamp && nowMs() < limit) __builtin_ia32_pause();
+            if (f[1] == stamp) {
+                std::atomic_thread_fence(std::memory_order_acquire);
+                s.done = (int32_t)f[0];
+                seen = true;
+            }
+        }
+        if (!seen) {
+            e = hipMemcpyAsync(&s, d.s, sizeof s, hipMemcpyDeviceToHost, stm);
+            if (e == hipSuccess) e = hipStreamSynchronize(stm);
+        }
         if (e != hipSuccess || s.done) break;
     }
     const double tt3 = nowMs();

@@ -139,9 +139,12 @@ struct CgDev {
     double *dinv, *rhs;
     double *x, *r, *p, *z, *tmp, *partA, *partB, *partC;
     CgScalars* s;
+    // pinned host memory the device writes at the end of a batch of iterations ([0] = CgScalars::done, [1] = the batch's stamp): the host
+    // watches it instead of waking up from hipStreamSynchronize (null: no mirror)
+    volatile uint32_t* hostFlag;
 };
 hipError_t launchCgStart(hipStream_t stream, const CgDev& d);   // setup, jump energy before, first residual, threshold
-hipError_t launchCgIterations(hipStream_t stream, const CgDev& d, int firstIteration, int iterations);
+hipError_t launchCgIterations(hipStream_t stream, const CgDev& d, int firstIteration, int iterations, uint32_t stamp = 0);
 hipError_t launchCgFinish(hipStream_t stream, const CgDev& d);  // jump energy after
 hipError_t launchPack(hipStream_t stream, const PackItem* dItems, uint32_t nItems, const double* dArena, double* dOut);
 

@@ -39,7 +39,7 @@ int meshFaceRuleReference() { return 0; }
 void setReductionLeftAssoc(int left) { gLeft = left != 0; }
 hipError_t launchFitMfmaLow(hipStream_t, int, const FitTask*, const uint32_t*, uint32_t, uint32_t, uint32_t, double*, const DeviceTables*, const double*,
                             const RootMap&) { return hipErrorNoDevice; }
-hipError_t launchCgIterations(hipStream_t, const CgDev&, int, int) { return hipErrorNoDevice; }
+hipError_t launchCgIterations(hipStream_t, const CgDev&, int, int, uint32_t) { return hipErrorNoDevice; }
 hipError_t launchCgStart(hipStream_t, const CgDev&) { return hipErrorNoDevice; }
 hipError_t launchCgFinish(hipStream_t, const CgDev&) { return hipErrorNoDevice; }
 ContinuityDeviceMatrix::~ContinuityDeviceMatrix() {}
