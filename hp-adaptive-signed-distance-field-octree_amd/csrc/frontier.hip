@@ -1442,7 +1442,7 @@ __device__ double frRunChain(const FrDev& d, FrLds& L, double total, uint32_t nO
 // The last workgroup: the running total of rounds >= 1, beside everything else -- nobody waits for it before the next round is
 // prepared: the leader only needs the total for the stop rule.  (Round 0's total the leader adds up itself: its operands are there when
 // the launch starts, and most builds at everyday thresholds end with it -- no hand-over on their critical path.)
-__device__ void frChainTotal(const FrDev& d, FrLds& L) {
+__device__ void frChainTotal(const FrDev& d, FrLds& L, bool chain0) {
     FrHdr* h = d.hdr;
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
     if (wave != 0 && (wave & 3u) == 0) return;  // (whole waves: the barriers below count the waves that are still there)
@@ -1452,14 +1452,18 @@ __device__ void frChainTotal(const FrDev& d, FrLds& L) {
     if (tid == 0) L.stuck = 0;
     __syncthreads();
     // (the header has been read: the leader may rewrite it.  The round's counters it leaves alone until this workgroup has finished.)
+    const uint32_t nJobs0 = h->nJobs;
     if (tid == 0) __hip_atomic_fetch_add(&h->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (nothing is published: "I have read")
-    if (round0) return;
-    if (tid == 0 && !frWaitAtLeast(&h->opsArrive, gridDim.x - 2u)) L.stuck = 1;  // (acquires)
-    __syncthreads();
-    uint32_t nOps = frLoad(&h->rP) + 9u * frLoad(&h->rH);
-    if (L.stuck) nOps = 0;
+    if (round0 && !chain0) return;
+    uint32_t nOps = nJobs0;  // round 0: every cell's (newErr - initialErr), there since the launch began
+    if (!round0) {
+        if (tid == 0 && !frWaitAtLeast(&h->opsArrive, gridDim.x - 2u)) L.stuck = 1;  // (acquires)
+        __syncthreads();
+        nOps = frLoad(&h->rP) + 9u * frLoad(&h->rH);
+        if (L.stuck) nOps = 0;
+    }
     if (d.stamps && tid == 0) h->dbg[13] = __builtin_readcyclecounter();
-    total = frRunChain(d, L, total, nOps, false);
+    total = frRunChain(d, L, total, nOps, round0);
     if (tid == 0) {
         if (d.stamps) h->dbg[14] = __builtin_readcyclecounter();
         if (L.stuck) atomicExch(&h->stuck, 1u);
@@ -1475,7 +1479,7 @@ __device__ void frChainTotal(const FrDev& d, FrLds& L) {
 // build that stops takes the prepared round's entries out of the header again (what else the preparation touched -- queue marks,
 // histogram, lists -- is not read after the stop).  Last the header's mirror in pinned host memory (the host watches the round
 // word: no copy).
-__device__ void frLeadRound(const FrDev& d, FrLds& L, int pre) {
+__device__ void frLeadRound(const FrDev& d, FrLds& L, int pre, bool chain0) {
     FrHdr* h = d.hdr;
     const uint32_t tid = threadIdx.x, nJobs = h->nJobs, round = h->round, stamp = round + 1u;
     const bool round0 = round == 0;
@@ -1494,7 +1498,8 @@ __device__ void frLeadRound(const FrDev& d, FrLds& L, int pre) {
     frPeerCheck(d, &L.flag);
     FR_STAMP(9);
     double total0 = 0.0;
-    if (round0) {  // the round's total, here and now: every cell's (newErr - initialErr) in cell order
+    const bool ownChain = round0 && !chain0;
+    if (ownChain) {  // the round's total, here and now: every cell's (newErr - initialErr) in cell order
         if (d.stamps && tid == 0) h->dbg[13] = __builtin_readcyclecounter();
         total0 = frRunChain(d, L, h->total, nJobs, true);
         if (d.stamps && tid == 0) h->dbg[14] = __builtin_readcyclecounter();
@@ -1509,13 +1514,13 @@ __device__ void frLeadRound(const FrDev& d, FrLds& L, int pre) {
     const uint32_t nQ = nQ0 - (round0 ? 0u : nJobs) + nP + 8u * nH;  // (round 0's batch never sat in the queue)
     const uint32_t nNodes = nNodes0 + 8u * nH;
     // (a build whose total after round 0 says "stop" -- most builds at everyday thresholds -- selects nothing any more: no threshold)
-    const bool stopsHere = round0 && total0 < target;
+    const bool stopsHere = ownChain && total0 < target;
     if (!stopsHere)
         for (uint32_t i = tid; i < 2048; i += 1024) L.hist[i] = frLoad(&h->hist1[i]);
     if (tid == 0) {
-        const bool there = !round0 && frLoad(&h->chainStamp) == stamp;
+        const bool there = !ownChain && frLoad(&h->chainStamp) == stamp;
         if (there) frAcquire();  // (rTotal is read below)
-        L.c = (round0 || there) ? 1u : 0u;
+        L.c = (ownChain || there) ? 1u : 0u;
     }
     __syncthreads();
     bool haveTotal = L.c != 0;
@@ -1539,7 +1544,7 @@ __device__ void frLeadRound(const FrDev& d, FrLds& L, int pre) {
     double total = 0.0;
     bool done = false;
     if (haveTotal) {
-        if (round0) {
+        if (ownChain) {
             total = total0;
         } else {
             total = *(volatile double*)&h->rTotal;  // (behind the acquire of whoever saw the stamp, and a barrier)
@@ -1629,13 +1634,18 @@ __device__ void frLeadRound(const FrDev& d, FrLds& L, int pre) {
     frMirror(d);
 }
 
-__global__ __launch_bounds__(1024) void fr_round_kernel(FrDev d, int pre) {
+// flags: bit 0 = the leader prepares the next round itself (trees up to HPSDF_FRONTIER_INLINE_NODES); bit 1 = round 0's running total is
+// added up by the last workgroup, beside the leader's preparation, like every later round's (the host sets it when this context's last
+// build went on past round 0: the leader adding it up itself is the shorter way only for a build that stops there)
+__global__ __launch_bounds__(1024) void fr_round_kernel(FrDev d, int flags) {
+    const int pre = flags & 1;
+    const bool chain0 = (flags & 2) != 0;
     if (d.hdr->done) return;  // (set by an earlier launch: uniform over the grid -- this launch's leader sets it only after every workgroup has arrived)
     __shared__ FrLds L;
     if (blockIdx.x == 0)
-        frLeadRound(d, L, pre);
+        frLeadRound(d, L, pre, chain0);
     else if (blockIdx.x == gridDim.x - 1u)
-        frChainTotal(d, L);
+        frChainTotal(d, L, chain0);
     else
         frUpdateJobs(d, L);
 }
@@ -1962,6 +1972,7 @@ struct FrontierWorkspace {
     // fr_init_kernel has run for (cleanRank, cleanWorld) and nothing since: a build that ends well leaves the workspace ready for the
     // next one (the launch runs while the host hands the block over), so a Create starts with its first fit
     bool clean = false;
+    bool lastWentOn = false;  // this context's last build went on past round 0 (fr_round_kernel's flag bit 1: a guess about timing, never about results)
     int cleanRank = -1, cleanWorld = -1;
     uint32_t buildStamp = 0;
     std::vector<hpsdf_node> hostNodesAfterRound0;  // the node array of a tree that stops after round 0, serialised
@@ -2672,7 +2683,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
             dk.batchIdx = ws->tmplLeaves, dk.batchErr = ws->tmplErr, dk.jobP = r0JobP, dk.jobH = r0JobP;
             dk.errStride = stride0;
         }
-        FR_LAUNCH(fr_round_kernel, dim3(2 + ((rounds == 0 ? T.nLeaves : Kj) + 127u) / 128u), dim3(1024), s, dk, pre ? 1 : 0);
+        FR_LAUNCH(fr_round_kernel, dim3(2 + ((rounds == 0 ? T.nLeaves : Kj) + 127u) / 128u), dim3(1024), s, dk, (pre ? 1 : 0) | (ws->lastWentOn && pre ? 2 : 0));
         // From the second round on the fits are launched without waiting for the header (one rank, no host step in between): what they
         // need to know is on the device -- their lists and counts -- and a build that has stopped leaves them nothing to do.  The
         // largest degree may have risen once more than the host knows.
@@ -2733,6 +2744,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
             if (!earlyCopied) std::memcpy(early + 8, ws->pinned, 8 * (size_t)T.arenaRows);
             hipLaunchKernelGGL(fr_init_kernel, dim3((T.nNodes + 255) / 256), dim3(256), 0, s, initDev(), T0);  // for the next build
             ws->clean = hipGetLastError() == hipSuccess, ws->cleanRank = rank, ws->cleanWorld = world;
+            ws->lastWentOn = false;
             *block = early;
             *size = 8 + 8 * (size_t)T.arenaRows + 8 + sizeof(hpsdf_node) * (size_t)T.nNodes + sizeof(hpsdf_config);
             early = nullptr;
@@ -2850,6 +2862,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
     }
     hipLaunchKernelGGL(fr_init_kernel, dim3((T.nNodes + 255) / 256), dim3(256), 0, s, initDev(), T0);  // for the next build
     ws->clean = hipGetLastError() == hipSuccess, ws->cleanRank = rank, ws->cleanWorld = world;
+    ws->lastWentOn = rounds > 1;
     if (trace)
         std::fprintf(stderr, "[frontierCreate] us: total %.0f (waiting for the device %.0f over %d rounds, weights on the host %.0f, block download %.0f)\n",
                      now() - t0, tSync, rounds, tWeights, tcopy);
