@@ -1111,7 +1111,9 @@ __global__ __launch_bounds__(256) void fr_tasks_kernel(FrDev d) {
 // ---------------------------------------------------------------------------------------------------------------------
 // fr_round_kernel: closes a round (Octree.cpp:243-299 in node-index order, :594-601 per job, :216) and opens the next
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr uint32_t kFrInlineNodes = 65536;  // trees up to here are selected by the closing workgroup itself (64 passes of 1024 lanes)
+constexpr uint32_t kFrInlineNodes = 131072;  // trees up to here are selected by the closing workgroup itself (128 passes of 1024 lanes; its bitmap
+                                             // holds 262 144 nodes.  65 536 sent union3 @ 4.5e-9, K = 4096 -- 58 k nodes + 32 k of room for a round -- to the
+                                             // grid selection in its last rounds: 5.8 ms against 4.5)
 constexpr unsigned long long kFrWaitTicks = 200000000ull;  // two seconds of the 100 MHz clock: a wait this long means a workgroup is gone
 
 // one lane waits until *p >= want, then acquires (the counter's writers release before they add); false: the wait ran out

@@ -680,7 +680,7 @@ def test_block_allocator_receives_every_block(H, monkeypatch, host):
                                  {"HPSDF_FRONTIER_INLINE_NODES": "0", "HPSDF_FRONTIER_NO_BLIND": "1"}])
 @pytest.mark.parametrize("target,K", [(1e-7, 256), (1e-8, 4096)])
 def test_device_frontier_paths_agree(H, ctx, monkeypatch, env, target, K):
-    """The round kernel's leader selects the next batch itself on trees of up to 65 536 nodes and leaves larger ones to the grid
+    """The round kernel's leader selects the next batch itself on trees of up to 131 072 nodes and leaves larger ones to the grid
     selection (fr_select / fr_batch / fr_tasks_kernel); fits are launched without waiting for the header from the second round on.
     Either switch thrown the other way gives the same bytes -- and, on two simulated ranks, so does the grid selection."""
     f = H.Field.union3()
