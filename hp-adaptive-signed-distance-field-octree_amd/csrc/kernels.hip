@@ -3042,7 +3042,7 @@ hipError_t launchFit(hipStream_t stream, int degree, int cellsPerThread, const F
 
 static unsigned gridFor(size_t n) {
     size_t blocks = (n + 255) / 256;
-    const size_t cap = kQueryMaxGrid;  // grid-stride beyond this
+    const size_t cap = kQueryMaxGrid;  // grid-stride beyond this (the headline kernel: 512 ... 39 063 workgroups for 10 M points measured, flat from 4096 up)
     return (unsigned)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
 }
 
@@ -3095,7 +3095,12 @@ hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables*
     const bool big = !dGrad && t.topDepth == 4 && std::getenv("HPSDF_QUERY_NO_LDSTOP") == nullptr;
     const unsigned tile = big ? 1024u : 256u;
     const size_t nTiles = (n + tile - 1) / tile;
-    const unsigned nWg = (unsigned)std::min<size_t>(nTiles, big ? 2048u : kQueryMaxGrid);
+    // The 16-wave workgroups stage the 32 KB thin table (and the basis tables) into LDS before their first tile: with 2048 of them -- eight
+    // generations on 256 CUs, five tiles each -- that start was a tenth of the kernel (207 -> 194 us for 10 M points on union3 @ 1e-7 with
+    // one workgroup a CU, 39 tiles each).  HPSDF_QUERY_GENERAL_WGS / _GRID: tuning knobs.
+    static const unsigned bigWgs = [] { const char* e = std::getenv("HPSDF_QUERY_GENERAL_WGS"); return e ? (unsigned)std::max(1, std::atoi(e)) : 256u; }();
+    static const unsigned smallWgs = [] { const char* e = std::getenv("HPSDF_QUERY_GENERAL_GRID"); return e ? (unsigned)std::max(1, std::min((int)kQueryMaxGrid, std::atoi(e))) : kQueryMaxGrid; }();
+    const unsigned nWg = (unsigned)std::min<size_t>(nTiles, big ? bigWgs : smallWgs);
     const uint32_t tilesPerWg = (uint32_t)((nTiles + nWg - 1) / nWg);  // tiles b, b + G, ... of workgroup b
     const dim3 ggrid(nWg);
     const size_t lds = queryGeneralLdsBytes(big ? 16 : 4, big);
@@ -3149,7 +3154,7 @@ hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables*
         // the per-workgroup lists are short and ragged: scan their lengths, then walk their concatenation densely
         uint32_t* dOffsets = dDeferCount + kQueryMaxGrid;
         hipLaunchKernelGGL(defer_scan_kernel, dim3(1), dim3(1024), 0, stream, dDeferCount, nWg, dOffsets);
-        const dim3 dgrid(std::min<unsigned>(nWg, 1024u));
+        const dim3 dgrid(1024u);  // (grid-stride over the scanned lists: the lists' number, nWg, does not bound it)
         const uint32_t slotsPerWg = tilesPerWg * (tile / 256u);  // deferredPoint() counts in runs of 256
         if (dGrad)
             hipLaunchKernelGGL(query_grad_deep_kernel, dgrid, block, 0, stream, t, dTables, dXyz, dOut, dGrad, slotsPerWg, nWg,
