@@ -1387,6 +1387,8 @@ __device__ __forceinline__ void queryTopBody(const TreeDev& t, const double* __r
         const size_t i = base + threadIdx.x;
         const bool valid = i < n;
         const size_t il = valid ? i : n - 1;
+        // (plain loads: non-temporal ones, 3 x 8 bytes or 16 + 8, cost the kernel 30 us -- neighbouring lanes share the points' lines, and
+        // without the caches every lane fetches them for itself; the RESULTS leave non-temporally: below)
         const double x = xyz[3 * il], y = xyz[3 * il + 1], z = xyz[3 * il + 2];
         // Octree.cpp:665
         const double p3[3] = {(x - t.rootCentre[0]) * t.rootInvSizes[0], (y - t.rootCentre[1]) * t.rootInvSizes[1],
@@ -1465,8 +1467,12 @@ __device__ __forceinline__ void queryTopBody(const TreeDev& t, const double* __r
                     r = evalLeafGradVals<0>(cv, u, topDepth, sNl, sRec, g, t.leftAssoc);
             }
             if (valid) {
-                out[i] = r;
-                if (inside) grad[3 * i] = g[0], grad[3 * i + 1] = g[1], grad[3 * i + 2] = g[2];
+                __builtin_nontemporal_store(r, &out[i]);
+                if (inside) {
+                    __builtin_nontemporal_store(g[0], &grad[3 * i]);
+                    __builtin_nontemporal_store(g[1], &grad[3 * i + 1]);
+                    __builtin_nontemporal_store(g[2], &grad[3 * i + 2]);
+                }
             }
         } else {
             if (inside) {
@@ -1480,7 +1486,7 @@ __device__ __forceinline__ void queryTopBody(const TreeDev& t, const double* __r
                 else
                     r = evalLeafTop<0>(cv, ux, uy, uz, t.nlTop);
             }
-            if (valid) out[i] = r;
+            if (valid) __builtin_nontemporal_store(r, &out[i]);
         }
     }
 }
@@ -1640,10 +1646,11 @@ __device__ __forceinline__ void queryGeneralBody(const TreeDev& t, const DeviceT
                 // order, so "all but the two youngest" (vmcnt(2)) is exactly "the coefficients are in LDS", and the two point loads
                 // stay in flight across the read-back and the evaluation (written out as instructions: the count in the wait must be
                 // the number of loads, which the compiler is free to merge or split; the values are claimed further down, before the
-                // stores, by a wait of their own)
+                // stores, by a wait of their own).  Plain loads: until the end of round 5 these carried `nt`, which made every lane fetch the
+                // lines its neighbours share for itself -- 193 -> 168 us on union3 @ 1e-7 without it.  The results do leave non-temporally.
                 const size_t in = nextBase + threadIdx.x;
                 const double* np = xyz + 3 * (in < n ? in : n - 1);
-                asm volatile("global_load_dwordx4 %0, %2, off nt\n\tglobal_load_dwordx2 %1, %2, off offset:16 nt\n\ts_waitcnt vmcnt(2)"
+                asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx2 %1, %2, off offset:16\n\ts_waitcnt vmcnt(2)"
                              : "=&v"(nxy), "=&v"(nz)
                              : "v"(np)
                              : "memory");
@@ -1703,9 +1710,13 @@ __device__ __forceinline__ void queryGeneralBody(const TreeDev& t, const DeviceT
             }
         }
         if (valid && !defer) {
-            out[i] = r;
+            __builtin_nontemporal_store(r, &out[i]);
             if constexpr (GRAD) {
-                if (inside) grad[3 * i] = g[0], grad[3 * i + 1] = g[1], grad[3 * i + 2] = g[2];
+                if (inside) {
+                    __builtin_nontemporal_store(g[0], &grad[3 * i]);
+                    __builtin_nontemporal_store(g[1], &grad[3 * i + 1]);
+                    __builtin_nontemporal_store(g[2], &grad[3 * i + 2]);
+                }
             }
         }
     }
