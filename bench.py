@@ -478,7 +478,7 @@ def main():
             import hashlib
             src = os.path.join(ROOT, "hp-adaptive-signed-distance-field-octree_amd", "csrc", "kernels.hip")
             text = open(src).read()
-            a_ = text.index("template <int TOPD, bool DEDUPE>")
+            a_ = text.index("template <int TOPD, bool DEDUPE, bool GRAD>")
             b_ = text.index("// 16-byte chunks a leaf of degree d occupies")
             qsha = hashlib.sha256(text[a_:b_].encode()).hexdigest()[:16]
             traffic_from = {"profile": rec.get("profile"), "query_kernel_sha16": rec.get("query_kernel_sha16"),

@@ -5,6 +5,7 @@ set -u
 TAG=${1:-r01}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
+rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write  # (a merged gpurun_out/ may hold an earlier call's files: the summary must read this call's)
 cd /tmp && export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 # the trace pass runs bench.py exactly as the driver does (default flags): the kernel averages of the summary are those of the bench line
