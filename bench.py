@@ -140,6 +140,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--points", type=int, default=N_POINTS, help="query points per GPU")
+    ap.add_argument("--batches", type=int, default=4, help="distinct point batches the timed Query steps walk through (1 = the same "
+                    "batch every step, which the 256 MB Infinity Cache then holds)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fit-bench", action="store_true", help="skip the steady-state fit micro-benchmark (fit_microbench)")
     ap.add_argument("--no-refined", action="store_true",
@@ -225,12 +227,20 @@ def main():
         n = args.points
         pts = splitmix64_points(n, seed=12345 + rank)
         d_xyz = torch.from_numpy(pts).cuda()
+        # The timed steps walk through several DISTINCT batches of the same shape: one batch of 10 M points is 240 MB, and since the
+        # results leave with non-temporal stores (round 5) nothing displaces it from the 256 MB Infinity Cache between launches -- a
+        # step over the same batch again then reads its points from that cache (+ 22 %: `repeated_batch` below), which is not what
+        # the HBM roofline names.  Four batches (960 MB) cannot be held; `value` is the rate of points that come from HBM.
+        batches = [d_xyz] + [torch.from_numpy(splitmix64_points(n, seed=12345 + rank + 7919 * b)).cuda() for b in range(1, max(1, args.batches))]
         d_out = torch.empty(n, dtype=torch.float64, device="cuda")
         tree = H.DeviceTree(ctx, block)
         torch.cuda.synchronize()
+        turn = [0]
 
         def step():
-            tree.query_device(d_xyz.data_ptr(), n, d_out.data_ptr())
+            b = batches[turn[0] % len(batches)]
+            turn[0] += 1
+            tree.query_device(b.data_ptr(), n, d_out.data_ptr())
 
         for _ in range(args.warmup):
             step()
@@ -254,7 +264,19 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall = float(t.item())
 
-        # sanity: the timed output is the real answer (spot parity against the oracle on rank 0)
+        # the same kernel over ONE batch again and again (what rounds 1-4 timed; see above)
+        def again():
+            tree.query_device(d_xyz.data_ptr(), n, d_out.data_ptr())
+        for _ in range(3):
+            again()
+        r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        r0.record(stream)
+        for _ in range(20):
+            again()
+        r1.record(stream)
+        torch.cuda.synchronize()
+        repeated_ms = r0.elapsed_time(r1) / 20
+        # sanity: the output is the real answer (spot parity against the oracle on rank 0; d_out now holds the first batch's values)
         got = d_out[:: max(1, n // 2000)].cpu().numpy()
 
         # ---------------- Create() with the frontier sharded over the ranks (one all-gather per round).  Behind the headline leg and
@@ -274,21 +296,28 @@ def main():
         # locality ceiling: the same points sorted by depth-4 cell, so neighbouring lanes share tree lines
         sorted_ms = None
         if rank == 0 and not args.no_sorted_ceiling:
-            cell = ((d_xyz + 0.5) * 16.0).floor().clamp_(0, 15).to(torch.int64)
-            order = torch.argsort(cell[:, 0] * 256 + cell[:, 1] * 16 + cell[:, 2])
-            d_sorted = d_xyz[order].contiguous()
+            def by_cell(x):
+                cell = ((x + 0.5) * 16.0).floor().clamp_(0, 15).to(torch.int64)
+                o = torch.argsort(cell[:, 0] * 256 + cell[:, 1] * 16 + cell[:, 2])
+                return x[o].contiguous(), o
+
+            d_sorted, order = by_cell(d_xyz)
+            sorted_batches = [d_sorted] + [by_cell(b)[0] for b in batches[1:]]  # (walked in turn, as the headline leg's)
             d_out2 = torch.empty_like(d_out)
             torch.cuda.synchronize()
-            tree.query_device(d_sorted.data_ptr(), n, d_out2.data_ptr())
+            for b in sorted_batches:
+                tree.query_device(b.data_ptr(), n, d_out2.data_ptr())
             s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s0.record(stream)
-            for _ in range(5):
-                tree.query_device(d_sorted.data_ptr(), n, d_out2.data_ptr())
+            for i in range(8):
+                tree.query_device(sorted_batches[(i + 1) % len(sorted_batches)].data_ptr(), n, d_out2.data_ptr())
             s1.record(stream)
+            tree.query_device(d_sorted.data_ptr(), n, d_out2.data_ptr())
             torch.cuda.synchronize()
-            sorted_ms = s0.elapsed_time(s1) / 5
+            sorted_ms = s0.elapsed_time(s1) / 8
+            del sorted_batches
             assert torch.equal(d_out2, d_out[order]), "sorted-point Query differs from the unsorted one"
-            del d_sorted, d_out2, order, cell
+            del d_sorted, d_out2, order
 
         # Beyond the headline config: the same points against a tree the hp-refinement has actually worked on
         # (union3 @ 1e-7: ~12 k nodes, degrees 2-4, depths 4-6) -- Query goes through
@@ -320,12 +349,19 @@ def main():
                 torch.cuda.synchronize()
                 return a.elapsed_time(b) / reps
 
-            q_ms = timed(lambda: tree_r.query_device(d_xyz.data_ptr(), n, d_out2.data_ptr()))
+            def nxt():  # (the batches in turn, as the headline leg)
+                b = batches[turn[0] % len(batches)]
+                turn[0] += 1
+                return b.data_ptr()
+
+            q_ms = timed(lambda: tree_r.query_device(nxt(), n, d_out2.data_ptr()), reps=8)
+            tree_r.query_device(d_xyz.data_ptr(), n, d_out2.data_ptr())
+            torch.cuda.synchronize()
             got_r = d_out2[:: max(1, n // 2000)].cpu().numpy()
-            g_ms = timed(lambda: H.check(L.hpsdf_query_gradient_device(ctx.handle, tree_r.handle, C.c_void_p(d_xyz.data_ptr()), n,
-                                                                      C.c_void_p(d_out2.data_ptr()), C.c_void_p(d_grad.data_ptr()))))
-            gc_ms = timed(lambda: H.check(L.hpsdf_query_gradient_device(ctx.handle, tree.handle, C.c_void_p(d_xyz.data_ptr()), n,
-                                                                       C.c_void_p(d_out2.data_ptr()), C.c_void_p(d_grad.data_ptr()))))
+            g_ms = timed(lambda: H.check(L.hpsdf_query_gradient_device(ctx.handle, tree_r.handle, C.c_void_p(nxt()), n,
+                                                                      C.c_void_p(d_out2.data_ptr()), C.c_void_p(d_grad.data_ptr()))), reps=8)
+            gc_ms = timed(lambda: H.check(L.hpsdf_query_gradient_device(ctx.handle, tree.handle, C.c_void_p(nxt()), n,
+                                                                       C.c_void_p(d_out2.data_ptr()), C.c_void_p(d_grad.data_ptr()))), reps=8)
             refined = {"tree": "union3 @ 1e-7, K=%d: %d nodes, %d leaves, %d coeffs, max degree %d, max depth %d"
                                % (JOBS_PER_ROUND, st_r["n_nodes"], st_r["n_leaves"], st_r["n_coeffs"], tree_r.info()["max_degree"],
                                   tree_r.info()["max_depth"]),
@@ -499,7 +535,13 @@ def main():
         "exchanges_per_create": None if create_sharded is None else create_sharded.get("exchanges_per_create"),
         "config": {"workload": "BASELINE configs[1]: union(sphere,box,torus) analytic SDF, targetError=1e-5, "
                                "continuity off, %d random Query() points per GPU" % n,
-                   "jobs_per_round": JOBS_PER_ROUND, "points_per_gpu": n, "sharding": "replicated tree, points split"},
+                   "jobs_per_round": JOBS_PER_ROUND, "points_per_gpu": n, "sharding": "replicated tree, points split",
+                   "point_batches": len(batches)},
+        # one batch queried again and again: its 240 MB stay in the 256 MB Infinity Cache between launches (results bypass it), so this
+        # is NOT an HBM figure -- reported because rounds 1-4 timed it this way and a caller re-querying one batch sees it
+        "repeated_batch": {"avg_launch_ms": repeated_ms, "mpts_per_s": n / repeated_ms / 1e3,
+                           "algorithmic_gbps": 32.0 * n / (repeated_ms * 1e-3) / 1e9,
+                           "note": "points served from the Infinity Cache; not priced against HBM"},
         "create_ms": create_ms, "create_sharded_ms": create_sharded_ms, "create_sharded": create_sharded,
         "create": {"nodes": stats["n_nodes"], "leaves": stats["n_leaves"], "coeffs": stats["n_coeffs"],
                    "rounds": stats["rounds"], "jobs": stats["jobs"], "fits": stats["fits"], "samples": stats["samples"],

@@ -1523,7 +1523,8 @@ __device__ __forceinline__ uint32_t leafChunks(uint32_t degree) { return ((uint3
 // Leaves of degree > 3 are rare at the thresholds in use (a few dozen among thousands): DEFER appends their points to
 // the workgroup's own run of deferIdx (an LDS counter, no global atomic -- one global atomic per wave serialised
 // the first version of this at 2 ms per 10 M points) and query_deep_kernel finishes them lane by lane; keeping
-// that code out of this kernel keeps it at ~100 VGPRs.
+// that code out of this kernel's loop keeps the loop at ~100 VGPRs (the 16-wave kernel has room up to 128, and finishes degrees 4-5
+// itself behind its last tile: DEEP below).
 // GRAD: QueryWithGradient (Octree.cpp:749-789) -- the same walk and fetch, value and "gradient" evaluated together;
 // rows of grad for points outside the root are left untouched, as the reference leaves its output argument.
 // WAVES: waves per workgroup (tile = 64 WAVES points).  LDSTOP (depth-4 top level only): the thin top table, 32 KB,
@@ -1537,7 +1538,11 @@ constexpr size_t queryGeneralLdsBytes(int waves, bool ldsTop) {
 // one link of its chain out at a time -- 1: no polynomial (the fetched rows are touched, not evaluated); 2: every lane fetches the leaf
 // of its wave's first lane (the same instructions, but every line after the first is a hit: no gather traffic); 3: no second line for
 // degree-3 leaves; 4: no walk below the top table (the top record is taken for the leaf)
-template <int TOPD, bool DEFER, bool GRAD, int WAVES, bool LDSTOP, int LAB = 0>
+// DEEP > 0 (values only, trees whose degrees stop at DEEP): the workgroup finishes its own deferred points behind its last tile, one lane
+// each with queryPoint<DEEP> -- the lists are per workgroup, so nothing has to be scanned or waited for across workgroups, and the scan
+// launch and the second pass (with the two kernel boundaries they bring: ~15 us behind a 176 us kernel for 10 M points on union3 @ 1e-7)
+// are not launched at all.
+template <int TOPD, bool DEFER, bool GRAD, int WAVES, bool LDSTOP, int LAB = 0, int DEEP = 0>
 __device__ __forceinline__ void queryGeneralBody(const TreeDev& t, const DeviceTables* __restrict__ T,
                                                  const double* __restrict__ xyz, size_t n, double* __restrict__ out,
                                                  double* __restrict__ grad, uint32_t tilesPerWg,
@@ -1720,7 +1725,15 @@ __device__ __forceinline__ void queryGeneralBody(const TreeDev& t, const DeviceT
             }
         }
     }
-    if constexpr (DEFER) {
+    if constexpr (DEFER && DEEP > 0) {
+        static_assert(!GRAD, "the fused second pass writes values only");
+        __syncthreads();  // every wave's indices are written (and visible inside the workgroup), the count is final
+        const uint32_t nd = sDeferred;
+        for (uint32_t j = threadIdx.x; j < nd; j += TILE) {
+            const size_t i = deferIdx[segStart + j];
+            __builtin_nontemporal_store(queryPoint<DEEP>(t, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], sNl, sRec), &out[i]);
+        }
+    } else if constexpr (DEFER) {
         __syncthreads();
         if (threadIdx.x == 0) deferCount[blockIdx.x] = sDeferred;
     }
@@ -1740,13 +1753,13 @@ __global__ __launch_bounds__(256) void query_general_kernel(TreeDev t, const Dev
     queryGeneralBody<TOPD, DEFER, false, 4, false>(t, T, xyz, n, out, nullptr, tilesPerWg, deferCount, deferIdx);
 }
 // depth-4 top level: 16 waves per workgroup, thin table in LDS
-template <bool DEFER, int LAB = 0>
+template <bool DEFER, int LAB = 0, int DEEP = 0>
 __global__ __launch_bounds__(1024) void query_general_lds_kernel(TreeDev t, const DeviceTables* __restrict__ T,
                                                                  const double* __restrict__ xyz, size_t n,
                                                                  double* __restrict__ out, uint32_t tilesPerWg,
                                                                  uint32_t* __restrict__ deferCount,
                                                                  uint32_t* __restrict__ deferIdx) {
-    queryGeneralBody<4, DEFER, false, 16, true, LAB>(t, T, xyz, n, out, nullptr, tilesPerWg, deferCount, deferIdx);
+    queryGeneralBody<4, DEFER, false, 16, true, LAB, DEEP>(t, T, xyz, n, out, nullptr, tilesPerWg, deferCount, deferIdx);
 }
 template <int TOPD, bool DEFER>
 __global__ __launch_bounds__(256, 3) void query_general_grad_kernel(TreeDev t, const DeviceTables* __restrict__ T,
@@ -3102,7 +3115,7 @@ hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables*
         }
         return hipGetLastError();
     }
-    const bool defer = t.maxDegree > 3;
+    bool defer = t.maxDegree > 3;
     const bool big = !dGrad && t.topDepth == 4 && std::getenv("HPSDF_QUERY_NO_LDSTOP") == nullptr;
     const unsigned tile = big ? 1024u : 256u;
     const size_t nTiles = (n + tile - 1) / tile;
@@ -3133,6 +3146,12 @@ hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables*
                 case 3: hipLaunchKernelGGL((query_general_lds_kernel<true, 3>), ggrid, dim3(1024), lds, stream, t, dTables, dXyz, n, dOut, tilesPerWg, dDeferCount, dDeferIdx); break;
                 default: hipLaunchKernelGGL((query_general_lds_kernel<true, 4>), ggrid, dim3(1024), lds, stream, t, dTables, dXyz, n, dOut, tilesPerWg, dDeferCount, dDeferIdx); break;
             }
+        } else if (defer && t.maxDegree <= 5 && std::getenv("HPSDF_QUERY_TWO_PASS") == nullptr) {
+            // degrees 4 and 5 are finished by the workgroup that met them (DEEP): one launch
+            const hipError_t fe = hipFuncSetAttribute((const void*)query_general_lds_kernel<true, 0, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (fe != hipSuccess) return fe;
+            hipLaunchKernelGGL((query_general_lds_kernel<true, 0, 5>), ggrid, dim3(1024), lds, stream, t, dTables, dXyz, n, dOut, tilesPerWg, dDeferCount, dDeferIdx);
+            defer = false;
         } else if (defer)
             hipLaunchKernelGGL((query_general_lds_kernel<true>), ggrid, dim3(1024), lds, stream, t, dTables, dXyz, n, dOut, tilesPerWg, dDeferCount, dDeferIdx);
         else

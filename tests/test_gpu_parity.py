@@ -886,6 +886,13 @@ def test_query_refined_trees_many_points_bitwise(H, O, ctx, golden, case):
     got, want = tree.query(pts), ot.query(pts)
     assert np.array_equal(bits(got), bits(want))
     assert (got == DBL_MAX).sum() > 100
+    # (that was one launch: degrees 4-5 are finished by the workgroup that met them; the scan + second-pass route, which trees with
+    # higher degrees take, on the same tree)
+    os.environ["HPSDF_QUERY_TWO_PASS"] = "1"
+    try:
+        assert np.array_equal(bits(tree.query(pts)), bits(want))
+    finally:
+        del os.environ["HPSDF_QUERY_TWO_PASS"]
     gv, gg = tree.query_with_gradient(pts[:700_001])
     wv, wg = ot.query_with_gradient(pts[:700_001])
     assert np.array_equal(bits(gv), bits(wv)) and np.array_equal(bits(gg), bits(wg))
