@@ -1930,8 +1930,58 @@ __global__ __launch_bounds__(64) void query_grad_few_kernel(TreeDev t, const Dev
 }
 
 // Octree::QueryWithGradient + FApproxWithGradient (Octree.cpp:749-789, 904-985), any degree, one lane per point:
+// QueryWithGradient for one point whose leaf has degree 4 or 5, with the degree at compile time: the walk of queryPointWithGradient,
+// then the leaf's coefficients into registers and evalLeafGradVals<P> -- the statements of the any-degree loop above, unrolled, its
+// tables of basis values in registers instead of 936 bytes of scratch indexed through kBasis (the dense pass over union3 @ 1e-7's
+// deferred points: 64 -> 20 us).  Any other degree goes through the any-degree code.
+template <int P>
+__device__ __forceinline__ void leafGradFixed(const TreeDev& t, const double* __restrict__ co, const double (&u)[3], int depth, size_t i,
+                                              double* __restrict__ out, double* __restrict__ grad, const double* sNl, const double* sRec) {
+    constexpr int N = coeffCount(P);
+    double cv[N];
+#pragma unroll
+    for (int r = 0; r < N; ++r) cv[r] = co[r];
+    double g[3];
+    out[i] = evalLeafGradVals<P>(cv, u, depth, sNl, sRec, g, t.leftAssoc);
+    grad[3 * i] = g[0], grad[3 * i + 1] = g[1], grad[3 * i + 2] = g[2];
+}
+__device__ __forceinline__ void queryPointWithGradient45(const TreeDev& t, size_t i, const double* __restrict__ xyz, double* __restrict__ out,
+                                                         double* __restrict__ grad, const double* sNl, const double* sRec) {
+    const double p[3] = {(xyz[3 * i] - t.rootCentre[0]) * t.rootInvSizes[0], (xyz[3 * i + 1] - t.rootCentre[1]) * t.rootInvSizes[1],
+                         (xyz[3 * i + 2] - t.rootCentre[2]) * t.rootInvSizes[2]};
+    const float fx = (float)p[0], fy = (float)p[1], fz = (float)p[2];
+    if (!(fx >= -0.5f && fx <= 0.5f && fy >= -0.5f && fy <= 0.5f && fz >= -0.5f && fz <= 0.5f)) {
+        out[i] = DBL_MAX;
+        return;
+    }
+    double c[3] = {0.0, 0.0, 0.0}, q = 0.25;
+    int depth = 0;
+    NodeRec rec = t.nodes[0];
+    while (rec.b == kInteriorTag) {  // :674-701
+        uint32_t idx = rec.a;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const bool up = p[a] >= c[a];
+            idx += up ? (1u << a) : 0u;
+            c[a] = up ? c[a] + q : c[a] - q;
+        }
+        q = q * 0.5;
+        ++depth;
+        rec = t.nodes[idx];
+    }
+    const double s = (double)(2 << depth);
+    const double u[3] = {(p[0] - c[0]) * s, (p[1] - c[1]) * s, (p[2] - c[2]) * s};  // :907
+    if (rec.b == 4u)
+        leafGradFixed<4>(t, t.coeffs + rec.a, u, depth, i, out, grad, sNl, sRec);
+    else if (rec.b == 5u)
+        leafGradFixed<5>(t, t.coeffs + rec.a, u, depth, i, out, grad, sNl, sRec);
+    else
+        queryPointWithGradient(t, i, xyz, out, grad, sNl, sRec);
+}
+
 // the second pass of the gradient query for the points query_general_kernel<.., GRAD> deferred (leaves of degree > 3).
-// Dense over the concatenation of the per-workgroup lists, like query_deep_kernel.
+// Dense over the concatenation of the per-workgroup lists, like query_deep_kernel.  FIXED45: the tree's degrees stop at 5.
+template <bool FIXED45>
 __global__ __launch_bounds__(256) void query_grad_deep_kernel(TreeDev t, const DeviceTables* __restrict__ T,
                                                               const double* __restrict__ xyz, double* __restrict__ out,
                                                               double* __restrict__ grad, uint32_t tilesPerWg, uint32_t nWg,
@@ -1945,7 +1995,10 @@ __global__ __launch_bounds__(256) void query_grad_deep_kernel(TreeDev t, const D
     __syncthreads();
     for (uint32_t jj = blockIdx.x * blockDim.x + threadIdx.x; jj < total; jj += gridDim.x * blockDim.x) {
         const size_t i = deferredPoint(jj, offsets, nWg, tilesPerWg, deferIdx);
-        queryPointWithGradient(t, i, xyz, out, grad, sNl, sRec);
+        if constexpr (FIXED45)
+            queryPointWithGradient45(t, i, xyz, out, grad, sNl, sRec);
+        else
+            queryPointWithGradient(t, i, xyz, out, grad, sNl, sRec);
     }
 }
 
@@ -3186,8 +3239,11 @@ hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables*
         hipLaunchKernelGGL(defer_scan_kernel, dim3(1), dim3(1024), 0, stream, dDeferCount, nWg, dOffsets);
         const dim3 dgrid(1024u);  // (grid-stride over the scanned lists: the lists' number, nWg, does not bound it)
         const uint32_t slotsPerWg = tilesPerWg * (tile / 256u);  // deferredPoint() counts in runs of 256
-        if (dGrad)
-            hipLaunchKernelGGL(query_grad_deep_kernel, dgrid, block, 0, stream, t, dTables, dXyz, dOut, dGrad, slotsPerWg, nWg,
+        if (dGrad && t.maxDegree <= 5)
+            hipLaunchKernelGGL((query_grad_deep_kernel<true>), dgrid, block, 0, stream, t, dTables, dXyz, dOut, dGrad, slotsPerWg, nWg,
+                               dOffsets, dDeferIdx);
+        else if (dGrad)
+            hipLaunchKernelGGL((query_grad_deep_kernel<false>), dgrid, block, 0, stream, t, dTables, dXyz, dOut, dGrad, slotsPerWg, nWg,
                                dOffsets, dDeferIdx);
         else if (t.maxDegree <= 5)
             hipLaunchKernelGGL((query_deep_kernel<5>), dgrid, block, 0, stream, t, dTables, dXyz, dOut, slotsPerWg, nWg, dOffsets, dDeferIdx);

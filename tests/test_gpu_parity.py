@@ -705,6 +705,15 @@ def test_query_with_gradient_bitwise(H, O, ctx, golden):
     p2 = rng.uniform(-0.5, 0.5, (3000, 3))
     a, b = H.DeviceTree(ctx, blk).query_with_gradient(p2), O.Tree.from_block(blk).query_with_gradient(p2)
     assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(bits(a[1]), bits(b[1]))
+    # degrees that stop at 5: the deferred points' second pass with the degree at compile time (degree 4 and degree 5 leaves, both depths)
+    for degs in ([5, 4, 3, 5, 2, 4, 5, 1], [4, 4, 2, 3, 4, 0, 3, 4]):
+        for depth in (1, 2):
+            blk = synthetic_block(rng, degs, depth=depth)
+            dt = H.DeviceTree(ctx, blk)
+            assert dt.info()["max_degree"] == max(degs)
+            a, b = dt.query_with_gradient(p2), O.Tree.from_block(blk).query_with_gradient(p2)
+            assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(bits(a[1]), bits(b[1]))
+            assert np.array_equal(bits(dt.query(p2)), bits(a[0]))
     # trees whose leaves all sit in the top table with degree <= 2 (the BASELINE thresholds' trees) take query_grad_kernel, one line a
     # point like Query: the two headline trees (top level at depth 4), and synthetic ones with the top level elsewhere and degrees 0..2
     cases = [O.Tree.create(O.default_config(golden["blocks"][c]["target"]), oracle_field(O, golden["blocks"][c]["field"]), 1024).to_block()
