@@ -541,7 +541,9 @@ def main():
         # is NOT an HBM figure -- reported because rounds 1-4 timed it this way and a caller re-querying one batch sees it
         "repeated_batch": {"avg_launch_ms": repeated_ms, "mpts_per_s": n / repeated_ms / 1e3,
                            "algorithmic_gbps": 32.0 * n / (repeated_ms * 1e-3) / 1e9,
-                           "note": "points served from the Infinity Cache; not priced against HBM"},
+                           "note": "one 10 M batch queried again and again, as rounds 1-4 timed `value` (r04: 90.4 Gpts/s with plain result stores): "
+                                   "the points are served from the Infinity Cache, so this is not priced against HBM; `value` walks "
+                                   "config.point_batches distinct batches"},
         "create_ms": create_ms, "create_sharded_ms": create_sharded_ms, "create_sharded": create_sharded,
         "create": {"nodes": stats["n_nodes"], "leaves": stats["n_leaves"], "coeffs": stats["n_coeffs"],
                    "rounds": stats["rounds"], "jobs": stats["jobs"], "fits": stats["fits"], "samples": stats["samples"],
