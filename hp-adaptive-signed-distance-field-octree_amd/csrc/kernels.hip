@@ -3119,7 +3119,8 @@ hipError_t launchFit(hipStream_t stream, int degree, int cellsPerThread, const F
 
 static unsigned gridFor(size_t n) {
     size_t blocks = (n + 255) / 256;
-    const size_t cap = kQueryMaxGrid;  // grid-stride beyond this (the headline kernel: 512 ... 39 063 workgroups for 10 M points measured, flat from 4096 up)
+    static const size_t capEnv = [] { const char* e = std::getenv("HPSDF_QUERY_GRID"); return e ? (size_t)std::max(1, std::atoi(e)) : (size_t)0; }();  // tuning knob
+    const size_t cap = capEnv ? capEnv : kQueryMaxGrid;  // grid-stride beyond this (the headline kernel: 512 ... 39 063 workgroups for 10 M points measured, flat from 4096 up)
     return (unsigned)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
 }
 
