@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void read_only(const double2* __restrict__ xyz
 // query_kernel fetches it (in step k the 8 lanes of a group bring 6 x 16 bytes of the line of the group's k-th point into LDS; two
 // passes of four steps).  MODE 0: the gather alone (the line is chosen by a hash of the point's INDEX; no point is read).  MODE 1: the
 // stream and the gather side by side, independent of each other (the points are read and added up, the line still comes from the
-// index).  MODE 2: as the product -- the line is chosen by the point's own bits, so a tile's gather waits for its points.
+// index).  MODE 2: as the product -- the line is chosen by the point's own bits, so a tile's gather waits for its points.  MODE 3: MODE 2
+// with non-temporal point loads.
 template <int MODE>
 __global__ __launch_bounds__(256, 7) void gather(const double* __restrict__ xyz, const char* __restrict__ table, size_t n,
                                                  double* __restrict__ out) {
@@ -59,9 +60,11 @@ __global__ __launch_bounds__(256, 7) void gather(const double* __restrict__ xyz,
         double acc = 0.0;
         uint32_t code = (uint32_t)((il * 2654435761ull) >> 13) & 4095u;
         if (MODE >= 1) {
-            const double x = xyz[3 * il], y = xyz[3 * il + 1], z = xyz[3 * il + 2];
+            const double x = MODE == 3 ? __builtin_nontemporal_load(&xyz[3 * il]) : xyz[3 * il],
+                         y = MODE == 3 ? __builtin_nontemporal_load(&xyz[3 * il + 1]) : xyz[3 * il + 1],
+                         z = MODE == 3 ? __builtin_nontemporal_load(&xyz[3 * il + 2]) : xyz[3 * il + 2];
             acc = x + y + z;
-            if (MODE == 2) code = (uint32_t)(__double_as_longlong(x * 4096.0 + y * 64.0 + z) >> 30) & 4095u;
+            if (MODE >= 2) code = (uint32_t)(__double_as_longlong(x * 4096.0 + y * 64.0 + z) >> 30) & 4095u;
         }
         uint32_t ck[8];
 #pragma unroll
@@ -184,7 +187,7 @@ int main(int argc, char** argv) {
     char* dtable;
     CK(hipMalloc(&dtable, 4096 * 128));
     CK(hipMemcpy(dtable, h.data(), 4096 * 128, hipMemcpyHostToDevice));
-    for (int variant = 0; variant < 6; ++variant) {
+    for (int variant = 0; variant < 7; ++variant) {
         for (int cyc = 1; cyc >= 0; --cyc) {
             auto launch = [&](int k) {
                 const double* x = dx[cyc ? k % nb : 0];
@@ -198,8 +201,10 @@ int main(int argc, char** argv) {
                     hipLaunchKernelGGL(gather<0>, grid, block, 0, 0, x, dtable, n, dout);
                 else if (variant == 4)
                     hipLaunchKernelGGL(gather<1>, grid, block, 0, 0, x, dtable, n, dout);
-                else
+                else if (variant == 5)
                     hipLaunchKernelGGL(gather<2>, grid, block, 0, 0, x, dtable, n, dout);
+                else
+                    hipLaunchKernelGGL(gather<3>, grid, block, 0, 0, x, dtable, n, dout);
             };
             for (int k = 0; k < 8; ++k) launch(k);
             CK(hipEventRecord(e0, 0));
@@ -215,7 +220,8 @@ int main(int argc, char** argv) {
                    : variant == 2 ? "reads only, 16 bytes a lane (24 B a point)"
                    : variant == 3 ? "row gather alone (line by the point's index; 8 B out)"
                    : variant == 4 ? "stream + row gather, independent (line by the index)"
-                                  : "stream + row gather, dependent (line by the point: the product)",
+                   : variant == 5 ? "stream + row gather, dependent (line by the point: the product)"
+                                  : "the same with non-temporal point loads",
                    cyc ? "four batches in turn:" : "one batch repeated:", us, bytes / us / 1e6, bytes / us / 1e6 / 8.0);
         }
     }
