@@ -534,7 +534,8 @@ def main():
         "world": world, "backend": backend,
         "exchanges_per_create": None if create_sharded is None else create_sharded.get("exchanges_per_create"),
         "config": {"workload": "BASELINE configs[1]: union(sphere,box,torus) analytic SDF, targetError=1e-5, "
-                               "continuity off, %d random Query() points per GPU" % n,
+                               "continuity off, %d random Query() points per GPU a step; the steps walk %d distinct batches in turn, so "
+                               "the points come from HBM and not from the 256 MB Infinity Cache" % (n, len(batches)),
                    "jobs_per_round": JOBS_PER_ROUND, "points_per_gpu": n, "sharding": "replicated tree, points split",
                    "point_batches": len(batches)},
         # one batch queried again and again: its 240 MB stay in the 256 MB Infinity Cache between launches (results bypass it), so this
