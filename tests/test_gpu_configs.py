@@ -886,6 +886,9 @@ def test_bench_two_ranks_sharing_this_gpu():
     assert out["mesh_create"]["n_gpus"] == 2 and out["mesh_create"]["create_ms_1e-6"] > 0
     for k in ("roofline", "config", "metric", "unit", "ms_per_step", "dtype"):
         assert k in out
+    # the timed steps walk distinct batches (points from HBM); the one-batch loop of rounds 1-4 is reported beside them, not as `value`
+    assert out["config"]["point_batches"] == 4 and out["repeated_batch"]["avg_launch_ms"] > 0
+    assert out["roofline"]["bound"] == "hbm" and 0 < out["roofline"]["frac"] < 1
 
 
     assert len(out["create_sharded"]["ms_per_rank"]) == 2 and out["create_sharded"]["exchanges_per_create"] >= 2
