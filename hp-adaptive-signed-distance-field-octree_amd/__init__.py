@@ -19,8 +19,12 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# (HPSDF_LIBRARY=hooks: lib/libhpsdf_hooks.so, the same library with the tests' fault-injection hook compiled in -- tests/ only)
-LIB_PATH = os.path.join(_HERE, "lib", "libhpsdf_hooks.so" if os.environ.get("HPSDF_LIBRARY") == "hooks" else "libhpsdf.so")
+# (HPSDF_LIBRARY=hooks: lib/libhpsdf_hooks.so, the same library with the tests' fault-injection hook compiled in -- tests/ only;
+#  HPSDF_LIBRARY=lab: lib/libhpsdf_lab.so, made on demand by `build.py --lab` for tools/query_general_floor.py -- its Query lab kernels
+#  return values that are not the tree's)
+#  (any other name: lib/libhpsdf_<name>.so, a measurement variant made by `build.py --variant=<name>:<flags>`)
+_WHICH = os.environ.get("HPSDF_LIBRARY", "")
+LIB_PATH = os.path.join(_HERE, "lib", "libhpsdf_%s.so" % _WHICH if _WHICH else "libhpsdf.so")
 _LIB = None
 
 OK = 0
@@ -32,6 +36,8 @@ ERR_UNSUPPORTED = 5
 ERR_STATE = 6
 ERR_OUT_OF_MEMORY = 7
 ERR_OPEN_MESH = 8
+ERR_BUILD_LIMIT = 9
+ABI_VERSION = 4  # HPSDF_ABI_VERSION this binding was written against (lib() refuses a library built with another)
 PRIM_SPHERE, PRIM_BOX, PRIM_TORUS_Y, PRIM_PLANE = 0, 1, 2, 3
 OP_UNION, OP_INTERSECT, OP_SUBTRACT = 0, 1, 2
 JOB_HEADER_DOUBLES = 9
@@ -116,6 +122,13 @@ _SIGNATURES = {
     "hpsdf_set_reduction_order": (None, [C.c_int]),
     "hpsdf_get_reduction_order": (C.c_int, []),
     "hpsdf_ctx_stream": (C.c_void_p, [C.c_void_p]),
+    "hpsdf_abi_version": (C.c_int, []),
+    "hpsdf_ctx_set_reduction_order": (C.c_int, [C.c_void_p, C.c_int]),
+    "hpsdf_ctx_get_reduction_order": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "hpsdf_ctx_set_mesh_face_rule": (C.c_int, [C.c_void_p, C.c_int]),
+    "hpsdf_ctx_get_mesh_face_rule": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "hpsdf_ctx_set_build_limits": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64]),
+    "hpsdf_ctx_get_build_limits": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "hpsdf_field_create_analytic": (C.c_int, [C.POINTER(Prim), C.c_int, C.POINTER(C.c_void_p)]),
     "hpsdf_field_create_callback": (C.c_int, [CALLBACK, C.c_void_p, C.POINTER(C.c_void_p)]),
     "hpsdf_field_create_mesh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
@@ -206,6 +219,8 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        if L.hpsdf_abi_version() != ABI_VERSION:  # (structs are handed over by size: a library of another ABI would write past them)
+            raise ImportError("libhpsdf.so has ABI version %d, this binding was written against %d: rebuild the library" % (L.hpsdf_abi_version(), ABI_VERSION))
         L._libc = C.CDLL(None)
         L._libc.free.argtypes = [C.c_void_p]
         _LIB = L
@@ -352,6 +367,35 @@ class Context:
 
     def set_stream(self, stream):
         check(lib().hpsdf_ctx_set_stream(self.handle, C.c_void_p(stream) if stream else None))
+
+    def set_reduction_order(self, left_assoc):
+        """This context's own reduction order (True / False), or None to follow the process-wide setting again (hpsdf.h)."""
+        check(lib().hpsdf_ctx_set_reduction_order(self.handle, -1 if left_assoc is None else (1 if left_assoc else 0)))
+
+    def reduction_order(self):
+        v = C.c_int()
+        check(lib().hpsdf_ctx_get_reduction_order(self.handle, C.byref(v)))
+        return v.value
+
+    def set_mesh_face_rule(self, reference):
+        """This context's own mesh face rule (True = the reference's), or None to follow the process-wide rule again."""
+        check(lib().hpsdf_ctx_set_mesh_face_rule(self.handle, -1 if reference is None else (1 if reference else 0)))
+
+    def mesh_face_rule(self):
+        v = C.c_int()
+        check(lib().hpsdf_ctx_get_mesh_face_rule(self.handle, C.byref(v)))
+        return v.value
+
+    def set_build_limits(self, max_nodes=0, max_bytes=0):
+        """Bounds on a Create (hpsdf_ctx_set_build_limits): 0 = the default (no bound on nodes; bytes: a quarter of the free device
+        memory), None = no limit.  A build that crosses one raises HpsdfError with status ERR_BUILD_LIMIT."""
+        none = (1 << 64) - 1
+        check(lib().hpsdf_ctx_set_build_limits(self.handle, none if max_nodes is None else int(max_nodes), none if max_bytes is None else int(max_bytes)))
+
+    def build_limits(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        check(lib().hpsdf_ctx_get_build_limits(self.handle, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def set_fast_fit(self, on=True):
         """Every row of every fit of degree >= 4 on the matrix cores (FIT_FAST; errors then only agree to ~1e-15)."""

@@ -107,5 +107,50 @@ def build_hooks(cc, objs, verbose=False):
     return HOOKS_LIB
 
 
+LAB_LIB = os.path.join(LIBDIR, "libhpsdf_lab.so")
+
+
+def build_variant(name, flags, sources=("kernels.hip",), verbose=False):
+    """lib/libhpsdf_<name>.so: the library with `sources` compiled again under extra `flags` -- lab and measurement builds, made ON
+    DEMAND only (neither build() nor the tests make or load them; HPSDF_LIBRARY=<name> selects one in the Python loader)."""
+    lib = build()
+    cc = hipcc()
+    out = os.path.join(LIBDIR, "libhpsdf_%s.so" % name)
+    if os.path.exists(out) and os.path.getmtime(out) > os.path.getmtime(lib):
+        return out
+    vdir = os.path.join(HERE, "build", "variant_" + name)
+    os.makedirs(vdir, exist_ok=True)
+    objs = [os.path.join(HERE, "build", s + ".o") for s in SOURCES]
+    procs = []
+    for s in sources:
+        obj = os.path.join(vdir, s + ".o")
+        objs[SOURCES.index(s)] = obj
+        cmd = [cc] + FLAGS + list(flags) + FILE_FLAGS.get(s, []) + ["-c", os.path.join(CSRC, s), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for s, p in procs:
+        o, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed on %s (%s):\n%s" % (s, name, o))
+    r = subprocess.run([cc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", out] + objs, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed (%s):\n%s" % (name, r.stdout))
+    return out
+
+
+def build_lab(verbose=False):
+    """lib/libhpsdf_lab.so (python build.py --lab; tools/query_general_floor.py): the library with the Query lab kernels compiled in
+    (-DHPSDF_QUERY_LAB_BUILD: HPSDF_QUERY_LAB=1..4 takes one link out of query_general_lds_kernel's chain -- the values it returns are
+    then not the tree's).  The production library holds no such kernel and does not read the variable (tests/test_product_cpu.py)."""
+    return build_variant("lab", ["-DHPSDF_QUERY_LAB_BUILD"], verbose=verbose)
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--lab" in sys.argv:
+        print(build_lab(verbose=True))
+    for a in sys.argv[1:]:  # --variant=name:-DFLAG,-DFLAG2   (kernels.hip compiled again under the flags)
+        if a.startswith("--variant="):
+            name, _, fl = a[len("--variant="):].partition(":")
+            print(build_variant(name, [f for f in fl.split(",") if f], verbose=True))

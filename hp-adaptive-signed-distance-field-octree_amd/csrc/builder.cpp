@@ -294,7 +294,7 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
     if (meshSampled) {
         const char* e = std::getenv("HPSDF_MESH_FUSED");
         if (e && e[0] == '1') meshSampled = false;
-        if (meshFaceRuleReference()) meshSampled = false;  // (the sampler's shared traversal assumes the default face rule)
+        if (meshFaceRuleReference(ctx)) meshSampled = false;  // (the sampler's shared traversal assumes the default face rule)
     }
 
     // ---- pass 1: count the fits of every shape.  A class = (degree, from-scratch | incremental, depth):
@@ -316,6 +316,21 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
     std::vector<uint32_t> classFirst(kClasses + 1, 0);
     for (int c = 0; c < kClasses; ++c) classFirst[c + 1] = classFirst[c] + classCount[c];
     const uint32_t nTasks = classFirst[kClasses];
+    {   // hpsdf_ctx_set_build_limits: this round against the context's bounds, before anything is allocated for it (the tree lives in
+        // host memory with this scheduler: the device holds the coefficient arena and the round's samples)
+        uint64_t rows = 0, samples = 0;
+        for (int c = 0; c < kClasses; ++c) {
+            const int deg = c / kDepths / 2;
+            const uint64_t nq = 4 * (uint64_t)deg + 1;
+            rows += (uint64_t)classCount[c] * T.coeffCount[deg];
+            samples += (uint64_t)classCount[c] * nq * nq * nq;
+        }
+        if (!sampled && !meshSampled && ctx->fitMode != HPSDF_FIT_SPLIT) samples = 0;  // (no sample buffer then)
+        const uint64_t bytes = (b->arenaUsed + rows + std::min<uint64_t>(samples, 1ull << 31)) * sizeof(double);
+        const uint64_t held = (ws.arenaCap + ws.meshSamplesCap) * sizeof(double);
+        const int lrc = checkBuildLimits(ctx, b->nodes.size(), bytes, held, &b->measuredLimit, b->stats.rounds, b->total, b->cfg.target_error_threshold);
+        if (lrc) return lrc;
+    }
     if (meshSampled) {
         uint64_t need = 0;
         for (int c = 0; c < kClasses; ++c) {
@@ -524,7 +539,7 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
 
     FieldDev fd;
     int rc;
-    if ((rc = makeFieldDev(field, dSamples, &fd))) return rc;
+    if ((rc = makeFieldDev(ctx, field, dSamples, &fd))) return rc;
     RootMap rm;
     for (int a = 0; a < 3; ++a) {
         rm.bounds[a] = (double)(b->cfg.root_max[a] - b->cfg.root_min[a]);          // Octree.cpp:324
@@ -588,7 +603,7 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
         for (int deg = std::max(2, ctx->splitMinDegree); deg <= 11; ++deg) {
             const uint32_t first = classFirst[classOf(deg, false, 0)], count = classFirst[classOf(deg, true, 0)] - first;
             if (count)
-                HPSDF_HIP(launchFitMfmaLow(ctx->stream, deg, ws.tasks.dev, nullptr, first, count, 0u, ws.arena, ctx->dTables, fd.samples, rm));
+                HPSDF_HIP(launchFitMfmaLow(ctx->stream, deg, ws.tasks.dev, nullptr, first, count, 0u, ws.arena, ctx->dTables, fd.samples, rm, fd.leftAssoc));
         }
     b->computed = true;
     return HPSDF_OK;

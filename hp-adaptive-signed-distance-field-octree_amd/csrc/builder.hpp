@@ -78,6 +78,7 @@ struct hpsdf_build {
     hpsdf::Workspace* ws = nullptr;
     bool ownsWs = false;
     uint64_t arenaUsed = 0;
+    uint64_t measuredLimit = 0;  // hpsdf_ctx_set_build_limits' default bound on bytes, measured at most once per build (checkBuildLimits)
     std::vector<double> hostStore;  // injected coefficients
 
     // ---- layout (after the last round)

@@ -57,7 +57,7 @@ static int envLeftAssoc() {
     return e && (e[0] == 'l' || e[0] == 'L' || e[0] == '1');
 }
 static std::atomic<int> gLeftAssoc{envLeftAssoc()};
-int reductionLeftAssoc() { return gLeftAssoc.load(std::memory_order_relaxed); }
+int reductionLeftAssoc(const hpsdf_ctx* ctx) { return ctx && ctx->reductionOrder >= 0 ? ctx->reductionOrder : gLeftAssoc.load(std::memory_order_relaxed); }
 void setReductionLeftAssoc(int left) { gLeftAssoc.store(left != 0, std::memory_order_relaxed); }
 
 // hpsdf_set_mesh_face_rule(): 0 = a face-case point that has left its triangle is replaced by the boundary's closest point (default: every
@@ -67,11 +67,39 @@ static int envMeshFaceRule() {
     return e && (e[0] == 'r' || e[0] == 'R' || e[0] == '1');
 }
 static std::atomic<int> gMeshFaceReference{envMeshFaceRule()};
-int meshFaceRuleReference() { return gMeshFaceReference.load(std::memory_order_relaxed); }
+int meshFaceRuleReference(const hpsdf_ctx* ctx) { return ctx && ctx->meshFaceRule >= 0 ? ctx->meshFaceRule : gMeshFaceReference.load(std::memory_order_relaxed); }
 void setMeshFaceRuleReference(int on) { gMeshFaceReference.store(on != 0, std::memory_order_relaxed); }
-float meshFaceTolOfSlack() { return meshFaceRuleReference() ? std::numeric_limits<float>::infinity() : 0.25f; }
+float meshFaceTolOfSlack(const hpsdf_ctx* ctx) { return meshFaceRuleReference(ctx) ? std::numeric_limits<float>::infinity() : 0.25f; }
 
-int makeFieldDev(const hpsdf_field* f, const double* dSamples, FieldDev* out) {
+int checkBuildLimits(const hpsdf_ctx* ctx, uint64_t nodes, uint64_t bytes, uint64_t held, uint64_t* measured, uint64_t rounds, double total, double target) {
+    constexpr uint64_t kNone = ~0ull, kMeasureFrom = 256ull << 20;
+    const uint64_t maxNodes = ctx->limitNodes ? ctx->limitNodes : kNone;
+    uint64_t maxBytes = ctx->limitBytes ? ctx->limitBytes : kNone;
+    const char* how = "hpsdf_ctx_set_build_limits";
+    if (ctx->limitBytes == 0 && bytes > kMeasureFrom) {  // the default: a quarter of what the device can give this build
+        if (*measured == 0) {
+            size_t freeB = 0, totalB = 0;
+            if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) {
+                (void)hipGetLastError();
+                freeB = 0;
+            }
+            *measured = std::max<uint64_t>(kMeasureFrom, ((uint64_t)freeB + held) / 4);
+        }
+        maxBytes = *measured;
+        how = "the default: a quarter of the device memory that was free";
+    }
+    if (nodes <= maxNodes && bytes <= maxBytes) return HPSDF_OK;
+    char msg[640];
+    std::snprintf(msg, sizeof msg,
+                  "build limit: after %llu rounds the tree has %llu nodes (limit %s%llu) and the next round needs %.3f GiB of device memory (limit %.3f GiB, %s); "
+                  "total error %.3e against the threshold %.3e -- the threshold may be below what the error estimate reaches on this field. "
+                  "hpsdf_ctx_set_build_limits(ctx, max_nodes, max_bytes) raises the limits (UINT64_MAX: none)",
+                  (unsigned long long)rounds, (unsigned long long)nodes, maxNodes == kNone ? "none, " : "", (unsigned long long)(maxNodes == kNone ? 0 : maxNodes),
+                  (double)bytes / (double)(1ull << 30), maxBytes == kNone ? 0.0 : (double)maxBytes / (double)(1ull << 30), maxBytes == kNone ? "none" : how, total, target);
+    return fail(HPSDF_ERR_BUILD_LIMIT, msg);
+}
+
+int makeFieldDev(const hpsdf_ctx* ctx, const hpsdf_field* f, const double* dSamples, FieldDev* out) {
     std::memset(out, 0, sizeof(*out));
     out->csgOp = -1;
     if (f->kind == kHostTreeCsg) {
@@ -108,12 +136,12 @@ int makeFieldDev(const hpsdf_field* f, const double* dSamples, FieldDev* out) {
             out->mesh.nTris = f->nTris;
             out->mesh.nNodes = f->nBvhNodes;
             out->mesh.stats = f->dStats;
-            out->mesh.faceTolOfSlack = meshFaceTolOfSlack();
+            out->mesh.faceTolOfSlack = meshFaceTolOfSlack(ctx);
             break;
         default:
             return fail(HPSDF_ERR_INVALID_ARGUMENT, "unknown field kind");
     }
-    out->leftAssoc = reductionLeftAssoc();
+    out->leftAssoc = reductionLeftAssoc(ctx);
     return HPSDF_OK;
 }
 
@@ -220,7 +248,8 @@ int hostCall(hpsdf_ctx* ctx, HostArray* arrays, int nArrays, Run&& run) {
 extern "C" {
 
 const char* hpsdf_last_error(void) { return g_lastError.c_str(); }
-const char* hpsdf_version(void) { return "hpsdf-gfx950 0.3"; }  // (minor = the round the ABI last grew in)
+const char* hpsdf_version(void) { return "hpsdf-gfx950 0.4"; }  // (minor = HPSDF_ABI_VERSION)
+int hpsdf_abi_version(void) { return HPSDF_ABI_VERSION; }
 
 int hpsdf_config_default(hpsdf_config* c) {
     if (!c) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null config");
@@ -345,6 +374,17 @@ int hpsdf_ctx_get_fit_mode(hpsdf_ctx* c, int* mode) {
     *mode = c->fitMode;
     return HPSDF_OK;
 }
+int hpsdf_ctx_set_build_limits(hpsdf_ctx* c, uint64_t max_nodes, uint64_t max_bytes) {
+    if (!c) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null context");
+    c->limitNodes = max_nodes, c->limitBytes = max_bytes;
+    return HPSDF_OK;
+}
+int hpsdf_ctx_get_build_limits(const hpsdf_ctx* c, uint64_t* max_nodes, uint64_t* max_bytes) {
+    if (!c) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null context");
+    if (max_nodes) *max_nodes = c->limitNodes;
+    if (max_bytes) *max_bytes = c->limitBytes;
+    return HPSDF_OK;
+}
 int hpsdf_ctx_set_split_min_degree(hpsdf_ctx* c, int degree) {
     if (!c) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null context");
     if (degree < 2 || degree > 12) return fail(HPSDF_ERR_INVALID_ARGUMENT, "split_min_degree: 2..12 (12 = never split)");
@@ -352,9 +392,32 @@ int hpsdf_ctx_set_split_min_degree(hpsdf_ctx* c, int degree) {
     return HPSDF_OK;
 }
 void hpsdf_set_mesh_face_rule(int reference) { setMeshFaceRuleReference(reference); }
-int hpsdf_get_mesh_face_rule(void) { return meshFaceRuleReference(); }
+int hpsdf_get_mesh_face_rule(void) { return meshFaceRuleReference(nullptr); }
 void hpsdf_set_reduction_order(int left_assoc) { setReductionLeftAssoc(left_assoc); }
-int hpsdf_get_reduction_order(void) { return reductionLeftAssoc(); }
+int hpsdf_get_reduction_order(void) { return reductionLeftAssoc(nullptr); }
+// per context (-1: follow the process-wide setting above)
+int hpsdf_ctx_set_reduction_order(hpsdf_ctx* c, int left_assoc) {
+    if (!c) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null context");
+    if (left_assoc < -1 || left_assoc > 1) return fail(HPSDF_ERR_INVALID_ARGUMENT, "reduction order: -1 (the process-wide setting), 0 or 1");
+    c->reductionOrder = left_assoc;
+    return HPSDF_OK;
+}
+int hpsdf_ctx_get_reduction_order(const hpsdf_ctx* c, int* left_assoc) {
+    if (!c || !left_assoc) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    *left_assoc = reductionLeftAssoc(c);
+    return HPSDF_OK;
+}
+int hpsdf_ctx_set_mesh_face_rule(hpsdf_ctx* c, int reference) {
+    if (!c) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null context");
+    if (reference < -1 || reference > 1) return fail(HPSDF_ERR_INVALID_ARGUMENT, "mesh face rule: -1 (the process-wide setting), 0 or 1");
+    c->meshFaceRule = reference;
+    return HPSDF_OK;
+}
+int hpsdf_ctx_get_mesh_face_rule(const hpsdf_ctx* c, int* reference) {
+    if (!c || !reference) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
+    *reference = meshFaceRuleReference(c);
+    return HPSDF_OK;
+}
 int hpsdf_ctx_set_fast_fit(hpsdf_ctx* c, int on) { return hpsdf_ctx_set_fit_mode(c, on ? HPSDF_FIT_FAST : HPSDF_FIT_EXACT); }
 
 int hpsdf_ctx_synchronize(hpsdf_ctx* c) {
@@ -548,14 +611,14 @@ int hpsdf_field_eval_device(hpsdf_ctx* ctx, const hpsdf_field* f, const double* 
     if (innermost(f)->kind == kHostCallback) return fail(HPSDF_ERR_UNSUPPORTED, "callback fields are evaluated on the host");
     HPSDF_HIP(hipSetDevice(ctx->device));
     FieldDev fd;
-    int rc = makeFieldDev(f, nullptr, &fd);
+    int rc = makeFieldDev(ctx, f, nullptr, &fd);
     if (rc) return rc;
     // A plain mesh field goes through the sampler's traversal, 64 consecutive points per walk (meshSignedDistanceWaveQ:
     // dense nodes walked by the wave, sparse subtrees pooled, tests compacted) -- the same bits as the per-point traversal
     // and 4 (random points) to 8 (points sorted by cell) times its speed on a 2 M-triangle mesh.
     // (Not under hpsdf_set_mesh_face_rule(1): the shared traversal's bounds -- slabs, in-plane rectangles -- bound the DISTANCE to a
     // triangle, and the reference's face-case point can lie below it; the per-point traversal prunes by boxes alone, as the reference's does.)
-    if (fd.kind == kFieldMesh && fd.csgOp < 0 && !meshFaceRuleReference())
+    if (fd.kind == kFieldMesh && fd.csgOp < 0 && !meshFaceRuleReference(ctx))
         HPSDF_HIP(launchMeshEvalWave(ctx->stream, fd, dXyz, n, dOut));
     else
         HPSDF_HIP(launchFieldEval(ctx->stream, fd, ctx->dTables, dXyz, n, dOut));
@@ -651,7 +714,7 @@ int hpsdf_field_eval_host(hpsdf_ctx* ctx, const hpsdf_field* f, const double* xy
         const int rc = meshHostMirror(f, &m);
         if (rc) return rc;
         MeshDev hm = m->dev;
-        hm.faceTolOfSlack = meshFaceTolOfSlack();  // (the rule at the time of the call, as on the device)
+        hm.faceTolOfSlack = meshFaceTolOfSlack(ctx);  // (the rule at the time of the call, as on the device)
         meshEvalHostPoints(hm, xyz, n, out);
         return HPSDF_OK;
     }
@@ -668,7 +731,7 @@ static int meshNaiveDevice(hpsdf_ctx* ctx, const hpsdf_field* f, const double* d
     if (f->kind != kHostMesh) return fail(HPSDF_ERR_INVALID_ARGUMENT, "the linear scan is defined for mesh fields");
     HPSDF_HIP(hipSetDevice(ctx->device));
     FieldDev fd;
-    int rc = makeFieldDev(f, nullptr, &fd);
+    int rc = makeFieldDev(ctx, f, nullptr, &fd);
     if (rc) return rc;
     // tiny calls run on the pinned host buffer as the device sees it (hostCall): the scan's atomics then go to the device-side
     // staging buffer, which such a call leaves unused and which holds the call's arrays (32 bytes a point) at least
@@ -685,9 +748,9 @@ static int meshWaveDevice(hpsdf_ctx* ctx, const hpsdf_field* f, const double* dX
     if (f->kind != kHostMesh) return fail(HPSDF_ERR_INVALID_ARGUMENT, "the shared traversal is defined for mesh fields");
     HPSDF_HIP(hipSetDevice(ctx->device));
     FieldDev fd;
-    int rc = makeFieldDev(f, nullptr, &fd);
+    int rc = makeFieldDev(ctx, f, nullptr, &fd);
     if (rc) return rc;
-    if (meshFaceRuleReference())
+    if (meshFaceRuleReference(ctx))
         return fail(HPSDF_ERR_UNSUPPORTED, "the shared traversal's bounds assume the default face rule (hpsdf_set_mesh_face_rule(0)): use hpsdf_field_eval_* or the scan");
     HPSDF_HIP(launchMeshEvalWave(ctx->stream, fd, dXyz, n, dOut));
     return HPSDF_OK;
@@ -708,7 +771,7 @@ static int meshLaneDevice(hpsdf_ctx* ctx, const hpsdf_field* f, const double* dX
     if (f->kind != kHostMesh) return fail(HPSDF_ERR_INVALID_ARGUMENT, "the per-point traversal is defined for mesh fields");
     HPSDF_HIP(hipSetDevice(ctx->device));
     FieldDev fd;
-    int rc = makeFieldDev(f, nullptr, &fd);
+    int rc = makeFieldDev(ctx, f, nullptr, &fd);
     if (rc) return rc;
     HPSDF_HIP(launchFieldEval(ctx->stream, fd, ctx->dTables, dXyz, n, dOut));
     return HPSDF_OK;
@@ -926,7 +989,7 @@ static int queryDevice(hpsdf_ctx* ctx, const hpsdf_tree* t, const double* dXyz, 
             }
         }
         TreeDev td = t->dev;
-        td.leftAssoc = reductionLeftAssoc();
+        td.leftAssoc = reductionLeftAssoc(ctx);
         HPSDF_HIP(launchQuery(ctx->stream, td, ctx->dTables, dXyz + 3 * off, m, dOut + off, dGrad ? dGrad + 3 * off : nullptr,
                               t->allInline, ctx->dDeferCount, ctx->dDefer));
     }
@@ -976,7 +1039,7 @@ int hpsdf_query_gradient_host(hpsdf_ctx* ctx, const hpsdf_tree* t, const double*
     if (n == 0) return HPSDF_OK;
     if (n <= hostGradientLimit() && smallQueriesOnHost()) {
         if (const int hc = t->hostCopies()) return hc;
-        for (size_t i = 0; i < n; ++i) hostQueryPointWithGradient(*t, xyz + 3 * i, out + i, grad + 3 * i);
+        for (size_t i = 0; i < n; ++i) hostQueryPointWithGradient(*t, xyz + 3 * i, out + i, grad + 3 * i, reductionLeftAssoc(ctx));
         return HPSDF_OK;
     }
     // rows of points outside the root keep what the caller passed in (the reference leaves its output untouched)
@@ -1313,7 +1376,7 @@ int hpsdf_create(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* fie
     HPSDF_TRY
     if (!ctx) return fail(HPSDF_ERR_NO_DEVICE, "Create runs on the GPU: a device context is required");
     if (!cfg || !field || !block || !size) return fail(HPSDF_ERR_INVALID_ARGUMENT, "null argument");
-    if (frontierEligible(cfg, field, K)) {  // frontier, decision and bookkeeping on the device (frontier.hip)
+    if (frontierEligible(ctx, cfg, field, K)) {  // frontier, decision and bookkeeping on the device (frontier.hip)
         int frc = frontierCreate(ctx, cfg, field, K, block, size, stats);
         std::memset(&g_lastContinuity, 0, sizeof g_lastContinuity);
         if (!frc && cfg->continuity_enforce) {  // Octree.cpp:341-344
@@ -1433,12 +1496,12 @@ static int createShardedOnHostScheduler(hpsdf_ctx* ctx, const hpsdf_config* cfg,
 #ifdef HPSDF_TEST_HOOKS  // (lib/libhpsdf_hooks.so, built for tests/: the production library does not look at the variable)
     const char* injected = std::getenv("HPSDF_TEST_FAIL_RANK");  // "<rank>:<exchange number>"
 #else
-    const char* injected = nullptr;
+    constexpr const char* injected = nullptr;  // (the statements that look at it fold away: the production library holds no trace of the hook)
 #endif
     int exchanges = 0;
     auto exchange = [&](const double* mine, uint64_t count, uint64_t pad, const char* what, int localRc) -> int {
         if (injected && !localRc && std::atoi(injected) == rank && std::strchr(injected, ':') && std::atoi(std::strchr(injected, ':') + 1) == exchanges)
-            localRc = fail(HPSDF_ERR_OUT_OF_MEMORY, "injected failure (HPSDF_TEST_FAIL_RANK)");
+            localRc = fail(HPSDF_ERR_OUT_OF_MEMORY, kInjectedFailureMsg);
         ++exchanges;
         std::string ownError = localRc ? std::string(hpsdf_last_error()) : std::string();
         stride = pad + 1;
@@ -1539,7 +1602,7 @@ int hpsdf_create_distributed(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsd
     // (the device-side frontier packs a segment's owner rank into three bits: more than 8 ranks take the host scheduler's rounds)
     // (... and a weighted incremental fit needs the node's previous rows, which another rank may hold: the host scheduler's
     // sharded rounds hand them over)
-    int rc = (frontierEligible(cfg, field, K) && world <= 8)
+    int rc = (frontierEligible(ctx, cfg, field, K) && world <= 8)
                  ? frontierCreate(ctx, cfg, field, K, block, size, stats, rank, world, gather, user)
                  : createShardedOnHostScheduler(ctx, cfg, field, K, rank, world, gather, user, block, size, stats);
     std::memset(&g_lastContinuity, 0, sizeof g_lastContinuity);
@@ -1642,7 +1705,7 @@ static int benchFit(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* 
     bool fast = false, split = false;
     {
         FieldDev probe;
-        if (ctx->fitMode == HPSDF_FIT_FAST && makeFieldDev(field, nullptr, &probe) == HPSDF_OK && fitMfmaSupports(degree, probe)) fast = true;
+        if (ctx->fitMode == HPSDF_FIT_FAST && makeFieldDev(ctx, field, nullptr, &probe) == HPSDF_OK && fitMfmaSupports(degree, probe)) fast = true;
         // the default: top-degree rows exact, the rows below them on the matrix cores from the samples the exact kernel leaves
         if (ctx->fitMode == HPSDF_FIT_SPLIT && fitSplitSupports(degree, ctx->splitMinDegree) && innermost(field)->kind != kHostMesh) split = true;
     }
@@ -1697,7 +1760,7 @@ static int benchFit(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* 
     if (e == hipSuccess) e = hipEventCreate(&e1);
     FieldDev fd;
     RootMap rm;
-    if (e == hipSuccess) rc = makeFieldDev(field, nullptr, &fd);
+    if (e == hipSuccess) rc = makeFieldDev(ctx, field, nullptr, &fd);
     for (int a = 0; a < 3; ++a) {
         rm.bounds[a] = (double)(cfg->root_max[a] - cfg->root_min[a]);
         rm.centre[a] = (double)((cfg->root_min[a] + cfg->root_max[a]) / 2.0f);
@@ -1709,7 +1772,7 @@ static int benchFit(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* 
             if (fast) return launchFitMfma(ctx->stream, degree, dB, (uint32_t)blocks.size(), dT, dA, dE, ctx->dTables, fd, rm);
             hipError_t le = launchFit(ctx->stream, degree, shape.cellsPerThread, dB, (uint32_t)blocks.size(), lds, dT, dA, dE, nullptr, ctx->dTables, fd, rm);
             if (le == hipSuccess && split)
-                le = launchFitMfmaLow(ctx->stream, degree, dT, nullptr, 0u, (uint32_t)nCells, 0u, dA, ctx->dTables, dS, rm);
+                le = launchFitMfmaLow(ctx->stream, degree, dT, nullptr, 0u, (uint32_t)nCells, 0u, dA, ctx->dTables, dS, rm, fd.leftAssoc);
             return le;
         };
         e = launch();  // warm-up

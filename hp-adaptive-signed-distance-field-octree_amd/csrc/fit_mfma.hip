@@ -362,7 +362,7 @@ bool fitSplitSupports(int degree, int minDegree) { return degree >= (minDegree <
 // Rows [0, ncoef(degree - 1)) of the split fits of `degree` (2..11) from the sample buffer; the tasks are [dRange[0], +dRange[1]) when
 // dRange is given (device-written; the grid then covers maxTasks), else [first, first + count).
 hipError_t launchFitMfmaLow(hipStream_t stream, int degree, const FitTask* dTasks, const uint32_t* dRange, uint32_t first, uint32_t count,
-                            uint32_t maxTasks, double* dArena, const DeviceTables* dTables, const double* dSamples, const RootMap& rm) {
+                            uint32_t maxTasks, double* dArena, const DeviceTables* dTables, const double* dSamples, const RootMap& rm, int leftAssoc) {
     const uint32_t n = dRange ? maxTasks : count;
     if (n == 0) return hipSuccess;
     // The default: the sum-factorised kernel of fit_low.hip (three one-axis contractions on the vector units).  HPSDF_LOW_KERNEL=mfma keeps
@@ -373,7 +373,7 @@ hipError_t launchFitMfmaLow(hipStream_t stream, int degree, const FitTask* dTask
     if (!fitSplitSupports(degree, 4) || dSamples == nullptr) return hipErrorInvalidValue;
     FieldDev fd;
     std::memset(&fd, 0, sizeof fd);
-    fd.kind = kFieldSamples, fd.csgOp = -1, fd.samples = dSamples, fd.leftAssoc = reductionLeftAssoc();
+    fd.kind = kFieldSamples, fd.csgOp = -1, fd.samples = dSamples, fd.leftAssoc = leftAssoc;
     const unsigned grid = (n + (uint32_t)kMfmaCells - 1u) / (uint32_t)kMfmaCells;
 #define HPSDF_LOW_CASE(D)                                                                                                                  \
     case D:                                                                                                                                \

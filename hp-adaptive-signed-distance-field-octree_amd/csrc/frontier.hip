@@ -2022,6 +2022,9 @@ struct FrontierWorkspace {
         *p = np;
         return e;
     }
+    // device bytes per node of capacity (ensureNodes' arrays; hpsdf_ctx_set_build_limits counts with it)
+    static constexpr uint64_t kBytesPerNode = sizeof(hpsdf_node) + sizeof(uint64_t) /* qErr */ + 2 * sizeof(uint32_t) /* parent, segFirst */ +
+                                              (uint64_t)kFrSegs * sizeof(uint64_t) /* segOff */ + sizeof(uint64_t) /* sub */ + 2 * sizeof(uint32_t) /* candA, candB */;
     hipError_t ensureNodes(uint32_t need, hipStream_t s) {
         if (need <= nodeCap) return hipSuccess;
         uint32_t nc = nodeCap ? nodeCap : 65536u;
@@ -2229,7 +2232,7 @@ struct FrontierWorkspace {
     }
 };
 
-bool frontierEligible(const hpsdf_config* cfg, const hpsdf_field* field, uint64_t K) {
+bool frontierEligible(const hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* field, uint64_t K) {
     if (const char* e = std::getenv("HPSDF_HOST_FRONTIER"))
         if (e[0] == '1') return false;
     if (cfg->weighting_type > 2) return false;    // (unknown weighting: the host scheduler reports it)
@@ -2239,7 +2242,7 @@ bool frontierEligible(const hpsdf_config* cfg, const hpsdf_field* field, uint64_
     if (in->kind == kHostMesh) {
         const char* e = std::getenv("HPSDF_MESH_FUSED");
         if (e && e[0] == '1') return false;
-        if (meshFaceRuleReference()) return false;  // (the sampler's shared traversal assumes the default face rule: builder.cpp fits with the per-point one)
+        if (meshFaceRuleReference(ctx)) return false;  // (the sampler's shared traversal assumes the default face rule: builder.cpp fits with the per-point one)
     }
     const uint64_t k = K ? K : HPSDF_DEFAULT_JOBS_PER_ROUND;
     return k <= kFrJobs;
@@ -2333,8 +2336,11 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
     // it returns its error: the others then leave with HPSDF_ERR_STATE instead of waiting for a rank that has gone.
     int phase = 0;
     // replica: the round's part of the arena while its exchange is still to come -- a failing rank enters it too, so round 0's part is
-    // known before anything can fail (it depends on the template and the world size alone: equal runs of cells, builderSelect's cut)
-    double* arenaPart = nullptr;
+    // known before anything can fail (it depends on the template and the world size alone: equal runs of cells, builderSelect's cut).
+    // Kept as an OFFSET into the arena (doubles) and a size: the arena can move between the moment the part is known and the moment a
+    // failure sends this rank into the exchange (ensureArena reallocates), and a pointer taken earlier would then name freed memory.
+    bool partPending = false;
+    uint64_t partOff = 0;
     size_t arenaPartBytes = 0;
     if (replica) {
         const uint64_t nL = ws->tmpl.nLeaves;
@@ -2346,13 +2352,13 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
             maxCount = std::max(maxCount, end - start);
             start = end;
         }
-        arenaPart = ws->arena;
+        partPending = true, partOff = 0;
         arenaPartBytes = (size_t)((((uint64_t)maxCount * frCoef(2)) + 15ull) & ~15ull) * sizeof(double);
     }
 #ifdef HPSDF_TEST_HOOKS  // (lib/libhpsdf_hooks.so, built for tests/: the production library does not look at the variable)
     const char* injected = std::getenv("HPSDF_TEST_FAIL_RANK");  // "<rank>:<round>"
 #else
-    const char* injected = nullptr;
+    constexpr const char* injected = nullptr;  // (the statements that look at it fold away: the production library holds no trace of the hook)
 #endif
     auto injectedFailure = [&](int round) {
         return injected && world > 1 && std::atoi(injected) == rank && std::strchr(injected, ':') && std::atoi(std::strchr(injected, ':') + 1) == round;
@@ -2361,8 +2367,8 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
     FieldDev fd;
     int rc;
     if (world > 1) phase = 1;
-    if ((rc = makeFieldDev(field, nullptr, &fd))) return rc;
-    if (injectedFailure(0)) return fail(HPSDF_ERR_OUT_OF_MEMORY, "injected failure (HPSDF_TEST_FAIL_RANK)");
+    if ((rc = makeFieldDev(ctx, field, nullptr, &fd))) return rc;
+    if (injectedFailure(0)) return fail(HPSDF_ERR_OUT_OF_MEMORY, kInjectedFailureMsg);
     RootMap rm;
     for (int a = 0; a < 3; ++a) {
         rm.bounds[a] = (double)(cfg.root_max[a] - cfg.root_min[a]);          // Octree.cpp:324
@@ -2531,10 +2537,23 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
     // after round r - 1 (whose largest degree can have risen by one since).  Also decides whether round r + 1's from-scratch fits
     // are split (ctx->fitMode): they are unless the sample buffer they hand their field values over in cannot be had.
     bool splitOpen = false, samplesTooLarge = false;
-    auto prepareNext = [&](uint32_t knownNodes, uint64_t knownArena, uint32_t knownMaxDeg) -> int {
+    uint64_t measuredLimit = 0;  // (hpsdf_ctx_set_build_limits' default, measured at most once per Create: checkBuildLimits)
+    auto prepareNext = [&](uint32_t knownNodes, uint64_t knownArena, uint32_t knownMaxDeg, int roundsDone) -> int {
         const int degBound = (int)std::min<uint32_t>(knownMaxDeg + 1u, kMaxDegree);
-        hipError_t e = ws->ensureNodes(knownNodes + 8u * Kj, s);
-        if (e == hipSuccess) e = ws->ensureArena(knownArena + (replica ? (uint64_t)world * ((uint64_t)Kj * rowsPerJob(degBound) + 16) : (uint64_t)Kj * rowsPerJob(degBound)), knownArena, s);
+        const uint64_t needNodes = (uint64_t)knownNodes + 8ull * Kj;
+        const uint64_t needArena = knownArena + (replica ? (uint64_t)world * ((uint64_t)Kj * rowsPerJob(degBound) + 16) : (uint64_t)Kj * rowsPerJob(degBound));
+        {   // hpsdf_ctx_set_build_limits: the round about to open against the context's bounds -- before anything is allocated for it, so
+            // that a runaway build ends here with its statistics in the message instead of minutes later in a failed hipMalloc
+            const uint64_t needSamples = (mesh || (splitMode && degBound >= ctx->splitMinDegree)) ? std::min<uint64_t>((uint64_t)Kj * samplesPerJob(degBound), 1ull << 31) : 0ull;
+            const uint64_t bytes = needNodes * FrontierWorkspace::kBytesPerNode + (needArena + needSamples) * sizeof(double);
+            const uint64_t held = (uint64_t)ws->nodeCap * FrontierWorkspace::kBytesPerNode + (ws->arenaCap + ws->sampleCap) * sizeof(double);
+            const int lrc = checkBuildLimits(ctx, knownNodes, bytes, held, &measuredLimit, (uint64_t)roundsDone, roundsDone ? hh->total : 8.0 * 8.0 * 8.0 * 8.0 * HPSDF_INITIAL_NODE_ERR,
+                                             cfg.target_error_threshold);
+            if (lrc) return lrc;
+        }
+        if (needNodes > 0xFFFFFFF0ull) return fail(HPSDF_ERR_BUILD_LIMIT, "build limit: the device-side frontier indexes nodes with 32 bits");
+        hipError_t e = ws->ensureNodes((uint32_t)needNodes, s);
+        if (e == hipSuccess) e = ws->ensureArena(needArena, knownArena, s);
         if (e != hipSuccess) return hipFail(e, "frontier buffers");
         splitOpen = splitMode && degBound >= ctx->splitMinDegree;
         samplesTooLarge = false;
@@ -2603,7 +2622,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
             }
         if (splitRound)  // the rows below the top degree of the split fits, from the samples the exact kernel left (H children: degree <= knownMaxDeg)
             for (int deg = std::max(2, ctx->splitMinDegree); deg <= (int)std::min<uint32_t>(knownMaxDeg, 11u); ++deg)
-                HPSDF_HIP(launchFitMfmaLow(s, deg, d.tasks, &d.hdr->lowTasks[deg][0], 0u, 0u, 8u * Kj, ws->arena, ctx->dTables, ws->samples, rm));
+                HPSDF_HIP(launchFitMfmaLow(s, deg, d.tasks, &d.hdr->lowTasks[deg][0], 0u, 0u, 8u * Kj, ws->arena, ctx->dTables, ws->samples, rm, fd.leftAssoc));
         if (weighted) {
             size_t lds = 0;
             for (int deg = 2; deg <= degHi; ++deg) lds = std::max(lds, fitLdsTable[deg]);
@@ -2647,7 +2666,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         hipError_t e = ws->ensureArena(std::max<uint64_t>(1, T0.arenaRows), 0, s);
         if (e == hipSuccess && mesh) e = ws->ensureSamples(std::max<uint64_t>(1, T0.samples), s);
         if (e != hipSuccess) return hipFail(e, "frontier buffers");
-        if ((rc = prepareNext(T.nNodes, T0.arenaRows, 2u))) return rc;
+        if ((rc = prepareNext(T.nNodes, T0.arenaRows, 2u, 0))) return rc;
         d.target = cfg.target_error_threshold;
         if (!ws->clean || ws->cleanRank != rank || ws->cleanWorld != world) FR_LAUNCH(fr_init_kernel, dim3((T.nNodes + 255) / 256), dim3(256), s, initDev(), T0);
         ws->clean = false;
@@ -2663,10 +2682,9 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
                                            T0.sliceFirst[rank + 1] - T0.sliceFirst[rank])))
             return rc;
         if (replica) {
-            arenaPart = ws->arena;
             if (arenaPartBytes != (size_t)part0 * sizeof(double)) return fail(HPSDF_ERR_STATE, "frontier: round 0's part of the arena");
-            if ((rc = exchange(arenaPart, arenaPartBytes, "round 0's rows"))) return rc;
-            arenaPart = nullptr;
+            partPending = false;  // (entered: a gather that fails is the callback's failure, not a reason to enter it again)
+            if ((rc = exchange(ws->arena, arenaPartBytes, "round 0's rows"))) return rc;
         }
         if ((rc = exchange(d.errs, (size_t)stride0 * sizeof(double), "round 0"))) return rc;
         phase = 0;
@@ -2770,32 +2788,39 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         if (world > 1) phase = 2;
         // (replica: the round's rows are exchanged too -- from here on a rank that fails enters that exchange as well.  With the grid
         // selection the part is known only when the batch kernel has run: below)
-        if (replica && pre) arenaPart = ws->arena + hh->roundBase, arenaPartBytes = (size_t)hh->partStride * sizeof(double);
-        if (injectedFailure(rounds)) return fail(HPSDF_ERR_OUT_OF_MEMORY, "injected failure (HPSDF_TEST_FAIL_RANK)");
-        if (mesh && tooLargeCur) return fail(HPSDF_ERR_UNSUPPORTED, "round too large for the sampled mesh path");
-        if (pre && !blind) {
-            FrDev de = d;
-            de.splitFit = dk.splitFit;
-            FR_LAUNCH(fr_emit_kernel, dim3((Kj + 127u) / 128u), dim3(1024), s, de);
-        }
+        if (replica && pre) partPending = true, partOff = hh->roundBase, arenaPartBytes = (size_t)hh->partStride * sizeof(double);
         if (!pre) {  // a large tree: the selection as a grid, then batch and lists (the header's arenaUsed lags one round: bound it)
             FrDev dl = d;
             dl.splitFit = dk.splitFit;
             FR_LAUNCH(fr_select_kernel, dim3(std::min<uint32_t>(512u, (knownNodes + 255u) / 256u)), dim3(256), s, dl);
             FR_LAUNCH(fr_batch_kernel, dim3(1), dim3(1024), s, dl);
             FR_LAUNCH(fr_tasks_kernel, dim3((16u * Kj + 255u) / 256u), dim3(256), s, dl);
-            // (replica: where the round's part of the arena lies is the batch kernel's decision, and the exchange below needs it)
-            if (replica) HPSDF_HIP(hipMemcpy(ws->hostHdr, d.hdr, kFrHdrCopyBytes, hipMemcpyDeviceToHost));
+            if (replica) {
+                // Where the round's part of the arena lies is the batch kernel's decision, and the exchange below needs it.  The
+                // context's stream does not synchronise with the null stream (hipStreamNonBlocking): a plain hipMemcpy right behind the
+                // launches would fetch the PREVIOUS round's roundBase / partStride.  Wait for the three kernels, then fetch.
+                HPSDF_HIP(hipStreamSynchronize(s));
+                HPSDF_HIP(hipMemcpy(ws->hostHdr, d.hdr, kFrHdrCopyBytes, hipMemcpyDeviceToHost));
+                partPending = true, partOff = hh->roundBase, arenaPartBytes = (size_t)hh->partStride * sizeof(double);
+            }
+        }
+        // (a rank whose share fails from here on knows which exchanges the others are heading for, and how large their parts are: with
+        // the grid selection that is only true once the batch kernel has spoken, hence the order.  A failed launch of the three
+        // selection kernels themselves -- a lost device, not a full one -- is not covered: that rank enters the errors' exchange alone.)
+        if (injectedFailure(rounds)) return fail(HPSDF_ERR_OUT_OF_MEMORY, kInjectedFailureMsg);
+        if (mesh && tooLargeCur) return fail(HPSDF_ERR_UNSUPPORTED, "round too large for the sampled mesh path");
+        if (pre && !blind) {
+            FrDev de = d;
+            de.splitFit = dk.splitFit;
+            FR_LAUNCH(fr_emit_kernel, dim3((Kj + 127u) / 128u), dim3(1024), s, de);
         }
         // capacities of the launch that closes this round; the arena may move: nothing that writes it is in flight
-        if ((rc = prepareNext(knownNodes, knownArena + (pre ? 0ull : (uint64_t)(replica ? world : 1) * ((uint64_t)Kj * rowsPerJob((int)knownMaxDeg) + 16)), knownMaxDeg))) return rc;
+        if ((rc = prepareNext(knownNodes, knownArena + (pre ? 0ull : (uint64_t)(replica ? world : 1) * ((uint64_t)Kj * rowsPerJob((int)knownMaxDeg) + 16)), knownMaxDeg, rounds))) return rc;
         d.splitFit = dk.splitFit;
-        if (replica) arenaPart = ws->arena + hh->roundBase, arenaPartBytes = (size_t)hh->partStride * sizeof(double);  // (the arena may have moved)
         if (!blind && (rc = launchRoundFits(knownMaxDeg, splitCur))) return rc;
         if (replica) {
-            arenaPart = ws->arena + hh->roundBase;  // (the arena may have moved)
-            if ((rc = exchange(arenaPart, arenaPartBytes, "a round's rows"))) return rc;
-            arenaPart = nullptr;
+            partPending = false;
+            if ((rc = exchange(ws->arena + partOff, arenaPartBytes, "a round's rows"))) return rc;  // (the arena may have moved: offset, not pointer)
         }
         if (frSyncEveryLaunch()) std::fprintf(stderr, "[frontier] fits of round %d ... %s\n", rounds, hipGetErrorString(hipStreamSynchronize(s)));
         if ((rc = exchange(d.errs, (size_t)strideK * sizeof(double), "a round's errors"))) return rc;
@@ -2875,7 +2900,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         const std::string own = hpsdf_last_error();
         const size_t stride = ws->d.errStride;
         const unsigned long long ones = ~0ull;
-        if (arenaPart) (void)gather(gatherUser, ws->arena + (arenaPart - ws->arena), arenaPartBytes, (void*)s);  // (replica: the others exchange the round's rows first)
+        if (partPending) (void)gather(gatherUser, ws->arena + partOff, arenaPartBytes, (void*)s);  // (replica: the others exchange the round's rows first)
         if (hipMemcpyAsync(ws->d.errs + (size_t)rank * stride + (stride - 1), &ones, sizeof ones, hipMemcpyHostToDevice, s) == hipSuccess)
             (void)gather(gatherUser, ws->d.errs, stride * sizeof(double), (void*)s);
         (void)hipStreamSynchronize(s);

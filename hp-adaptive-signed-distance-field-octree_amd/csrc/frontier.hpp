@@ -9,7 +9,7 @@
 
 namespace hpsdf {
 
-bool frontierEligible(const hpsdf_config* cfg, const hpsdf_field* field, uint64_t K);
+bool frontierEligible(const hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* field, uint64_t K);
 // the whole build up to the serialised block (malloc'd); the continuity post-process is the caller's
 // rank / world / gather: this rank's part of a build sharded over `world` ranks (hpsdf_create_distributed)
 int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfg, const hpsdf_field* field, uint64_t K, void** block, size_t* size,

@@ -83,7 +83,7 @@ double hostQueryPoint(const hpsdf_tree& t, const double* xyz) {
 }
 
 // Octree::QueryWithGradient + FApproxWithGradient (Octree.cpp:749-789, 904-985).  Outside the root: *out = DBL_MAX, grad untouched.
-void hostQueryPointWithGradient(const hpsdf_tree& t, const double* xyz, double* out, double* grad) {
+void hostQueryPointWithGradient(const hpsdf_tree& t, const double* xyz, double* out, double* grad, int leftAssoc) {
     Leaf L;
     if (!descend(t, xyz, L)) {
         *out = DBL_MAX;
@@ -116,7 +116,7 @@ void hostQueryPointWithGradient(const hpsdf_tree& t, const double* xyz, double* 
         g[k] = (p1 - m1) / (2.0 * eps);
     }
     const double g2[3] = {g[0] * g[0], g[1] * g[1], g[2] * g[2]};
-    const double z = reductionLeftAssoc() ? (g2[0] + g2[1]) + g2[2] : g2[0] + (g2[1] + g2[2]);  // Eigen normalize()
+    const double z = leftAssoc ? (g2[0] + g2[1]) + g2[2] : g2[0] + (g2[1] + g2[2]);  // Eigen normalize()
     if (z > 0.0) {
         const double nrm = std::sqrt(z);
         g[0] = g[0] / nrm, g[1] = g[1] / nrm, g[2] = g[2] / nrm;

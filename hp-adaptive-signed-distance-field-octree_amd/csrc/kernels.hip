@@ -499,6 +499,9 @@ __device__ __forceinline__ BvhNode loadNodeUniform(const BvhNode* base, int32_t 
 // ~sqrt(D H) of its foot point, at every level of the tree; the slab of a smooth patch is thin and leaves the patches within
 // ~H.  The per-lane descent that seeds the bounds follows the smaller of the two children's combined bounds and so ends in
 // the leaf under the sample (by boxes alone: a few triangles off, and everything in between passes the lower-bound test).
+#ifndef HPSDF_MESH_ABL
+#define HPSDF_MESH_ABL 0  // lab builds only (tools/mesh_ablation.sh): what the sampler's phases cost, by leaving one out or running it twice
+#endif
 constexpr uint32_t kMeshPoolCap = 256;  // (lane, node) pairs a wave's pool holds
 #ifndef HPSDF_MESH_SPARSE
 #define HPSDF_MESH_SPARSE 16            // a child that at most this many lanes want goes to the pool instead of being walked by the wave
@@ -572,6 +575,15 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool activeIn,
             closestSimplex(p, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, m.faceTolOfSlack * slack, ownerBest(src), q);  // (a stale best only substitutes more often than needed)
             const float d = sqnorm(p - q);
             atomicMin(&L.best[src], ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)t);
+#if HPSDF_MESH_ABL == 5  // (lab: the closest-point test twice -- what the batches cost is the difference)
+            {
+                V3 p2 = p, q2;
+                asm volatile("" : "+v"(p2.x));
+                closestSimplex(p2, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, m.faceTolOfSlack * slack, ownerBest(src), q2);
+                const float d2 = sqnorm(p2 - q2);
+                asm volatile("" ::"v"(d2));
+            }
+#endif
         }
         __builtin_amdgcn_wave_barrier();
         const float best = ownerBest(lane);
@@ -603,6 +615,14 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool activeIn,
             const TriPre rec = loadTriPre(m, slot);
             tri = triPreTriangle(rec);
             pass = !(triLowerBound2(p, rec) > rj);  // (a NaN passes)
+#if HPSDF_MESH_ABL == 6  // (lab: the lower-bound test twice)
+            {
+                V3 p2 = p;
+                asm volatile("" : "+v"(p2.x));
+                const float lb2 = triLowerBound2(p2, rec);
+                asm volatile("" ::"v"(lb2));
+            }
+#endif
         }
         const unsigned long long pb = __ballot(pass);
         if (pass) {
@@ -930,11 +950,13 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool activeIn,
         while (aCount) boundBatch(aCount < perBatch ? aCount : perBatch);
         if (bCount) closestBatch(bCount);
     };
+#if HPSDF_MESH_ABL != 2  // (lab 2: seeds only)
     walk(active, (uint32_t)HPSDF_MESH_SPARSE);
     {
         const bool again = L.redo[lane] != 0;
         if (__ballot(again) != 0ull) walk(again, 0u);
     }
+#endif
 #ifdef HPSDF_MESH_STATS_BUILD
 #ifndef HPSDF_MESH_VISIT_HIST
     nSeedExact = (unsigned)__popcll(__ballot(active && seedBest == ownerBest(lane)));
@@ -962,11 +984,23 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool activeIn,
         const uint32_t bestTri = (uint32_t)(L.best[lane] & 0xFFFFFFFFull);
         V3 bestQ;
         const float4 tp[3] = {m.triPos[3 * (size_t)bestTri], m.triPos[3 * (size_t)bestTri + 1], m.triPos[3 * (size_t)bestTri + 2]};
+#if HPSDF_MESH_ABL == 1  // (lab: no recomputation of the winner's closest point, no pseudo-normal)
+        (void)tp, (void)bestQ;
+        r = sqrtf(ownerBest(lane));
+#elif HPSDF_MESH_ABL == 9  // (lab: the closest point, but the face normal for every case)
+        const int bestCode = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, m.faceTolOfSlack * slack, __builtin_inff(), bestQ);
+        (void)bestCode;
+        const V3 nrm = pseudoNormal(m, bestTri, 8);
+        const V3 d = pt - bestQ;
+        const float sign = dot(nrm, d) > 0.0f ? 1.0f : -1.0f;
+        r = sign * sqrtf(sqnorm(d));
+#else
         const int bestCode = closestSimplex(pt, V3{tp[0].x, tp[0].y, tp[0].z}, V3{tp[0].w, tp[1].x, tp[1].y}, V3{tp[1].z, tp[1].w, tp[2].x}, V3{tp[2].y, tp[2].z, tp[2].w}, m.faceTolOfSlack * slack, __builtin_inff(), bestQ);
         const V3 nrm = pseudoNormal(m, bestTri, bestCode);
         const V3 d = pt - bestQ;
         const float sign = dot(nrm, d) > 0.0f ? 1.0f : -1.0f;
         r = sign * sqrtf(sqnorm(d));
+#endif
     }
     return r;
 }
@@ -3187,9 +3221,16 @@ hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables*
         const void* fn = defer ? (const void*)query_general_lds_kernel<true> : (const void*)query_general_lds_kernel<false>;
         const hipError_t ae = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (ae != hipSuccess) return ae;
-        const char* labEnv = std::getenv("HPSDF_QUERY_LAB");  // diagnostics: a link of the chain taken out (queryGeneralBody's LAB); values are then not the tree's
-        const int lab = labEnv ? std::atoi(labEnv) : 0;
+#ifdef HPSDF_QUERY_LAB_BUILD
+        // lib/libhpsdf_lab.so only (build.py --lab; tools/query_general_floor.py): a link of the chain taken out (queryGeneralBody's LAB).
+        // The values are then NOT the tree's, which is why the production library neither reads the variable nor holds these kernels.
+        const char* labEnv = std::getenv("HPSDF_QUERY_LAB");
+        const int lab = labEnv && dDeferCount && dDeferIdx ? std::atoi(labEnv) : 0;  // (the LAB kernels are DEFER instantiations: they need the lists)
+#else
+        constexpr int lab = 0;
+#endif
         if (lab >= 1 && lab <= 4) {
+#ifdef HPSDF_QUERY_LAB_BUILD
             const void* lf = lab == 1 ? (const void*)query_general_lds_kernel<true, 1> : lab == 2 ? (const void*)query_general_lds_kernel<true, 2>
                            : lab == 3 ? (const void*)query_general_lds_kernel<true, 3> : (const void*)query_general_lds_kernel<true, 4>;
             const hipError_t le = hipFuncSetAttribute(lf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -3200,6 +3241,7 @@ hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables*
                 case 3: hipLaunchKernelGGL((query_general_lds_kernel<true, 3>), ggrid, dim3(1024), lds, stream, t, dTables, dXyz, n, dOut, tilesPerWg, dDeferCount, dDeferIdx); break;
                 default: hipLaunchKernelGGL((query_general_lds_kernel<true, 4>), ggrid, dim3(1024), lds, stream, t, dTables, dXyz, n, dOut, tilesPerWg, dDeferCount, dDeferIdx); break;
             }
+#endif
         } else if (defer && t.maxDegree <= 5 && std::getenv("HPSDF_QUERY_TWO_PASS") == nullptr) {
             // degrees 4 and 5 are finished by the workgroup that met them (DEEP): one launch
             const hipError_t fe = hipFuncSetAttribute((const void*)query_general_lds_kernel<true, 0, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -49,7 +49,7 @@ bool fitSplitSupports(int degree, int minDegree);
 hipError_t launchFitLow(hipStream_t stream, int degree, const FitTask* dTasks, const uint32_t* dRange, uint32_t first, uint32_t count,
                         uint32_t maxTasks, double* dArena, const DeviceTables* dTables, const double* dSamples);  // fit_low.hip
 hipError_t launchFitMfmaLow(hipStream_t stream, int degree, const FitTask* dTasks, const uint32_t* dRange, uint32_t first, uint32_t count,
-                            uint32_t maxTasks, double* dArena, const DeviceTables* dTables, const double* dSamples, const RootMap& rm);
+                            uint32_t maxTasks, double* dArena, const DeviceTables* dTables, const double* dSamples, const RootMap& rm, int leftAssoc);
 hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dXyz, size_t n,
                        double* dOut, double* dGrad, bool allInline, uint32_t* dDeferCount, uint32_t* dDeferIdx);
 hipError_t launchQueryRay(hipStream_t stream, const TreeDev& t, const DeviceTables* dTables, const double* dOrigins,
@@ -67,9 +67,6 @@ hipError_t sortPairsU32(hipStream_t stream, void* tmp, size_t& tmpBytes, const u
 hipMemPool_t meshPool(int dev);
 void meshPoolTrim(int dev);
 
-// hpsdf_set_reduction_order(): 0 = Eigen's 3-vector reductions as a . (b . c) (default), 1 = (a . b) . c.  Process-wide; read when
-// a launch is prepared (capi.cpp).
-int reductionLeftAssoc();
 // a few points of a plain mesh field on the calling thread; hm: HOST copies of the field's arrays
 void meshEvalHostPoints(const MeshDev& hm, const double* xyz, size_t n, double* out);
 // dKeys: n x 8 bytes of DEVICE memory for the per-point (distance, triangle) keys, or nullptr when dOut itself is device memory

@@ -83,6 +83,14 @@ struct hpsdf_ctx {
     // canonical bytes); HPSDF_FIT_FAST: every row of every fit of degree >= 4 on the matrix cores (errors within ~1e-15, ties may flip)
     int fitMode = HPSDF_FIT_SPLIT;
     int splitMinDegree = 6;  // HPSDF_FIT_SPLIT: from-scratch fits of this degree and above are split (hpsdf_ctx_set_split_min_degree)
+    // hpsdf_ctx_set_reduction_order / hpsdf_ctx_set_mesh_face_rule: -1 = this context follows the process-wide setting
+    // (hpsdf_set_reduction_order / hpsdf_set_mesh_face_rule, which stand for the reference's build flags), 0 / 1 = its own.  Two
+    // Octrees of one process can differ in them; read when a launch is prepared, like the process-wide ones.
+    int reductionOrder = -1;
+    int meshFaceRule = -1;
+    // hpsdf_ctx_set_build_limits: a Create whose tree outgrows either bound when a round opens is refused with
+    // HPSDF_ERR_BUILD_LIMIT (0 = the default: a share of the device's free memory; UINT64_MAX = none)
+    uint64_t limitNodes = 0, limitBytes = 0;
     hpsdf::Workspace ws;
     // Scratch of the *_host entry points (host arrays in, host arrays out): one device buffer and one pinned buffer,
     // kept across calls -- a scalar Query(pt) through the C++ drop-in must not pay two hipMalloc/hipFree pairs.
@@ -196,15 +204,26 @@ constexpr size_t kHostRays = 32;            // QueryRay
 constexpr size_t kHostMeshPoints = 2;       // mesh signed distance (hpsdf_field_eval_host on a plain mesh field): ~23-50 us a point on the host, a launch
                                             // round trip ~55 us + ~3 us a point -- from three points on the device is the faster one
 double hostQueryPoint(const hpsdf_tree& t, const double* xyz);
-void hostQueryPointWithGradient(const hpsdf_tree& t, const double* xyz, double* out, double* grad);
+void hostQueryPointWithGradient(const hpsdf_tree& t, const double* xyz, double* out, double* grad, int leftAssoc);
 bool hostQueryRay(const hpsdf_tree& t, const double* origin, const double* dir, double tMax, double* tOut);
 
 // innermost non-CSG field and the FieldDev the kernels take
 const hpsdf_field* innermost(const hpsdf_field* f);
-int makeFieldDev(const hpsdf_field* f, const double* dSamples, FieldDev* out);
-int meshFaceRuleReference();  // hpsdf_set_mesh_face_rule(): 1 = the reference's face-case point whatever its weights
-float meshFaceTolOfSlack();   // MeshDev::faceTolOfSlack for launches prepared now
-int reductionLeftAssoc();  // hpsdf_set_reduction_order()
+#ifdef HPSDF_TEST_HOOKS
+constexpr const char* kInjectedFailureMsg = "injected failure (HPSDF_TEST_FAIL_RANK)";
+#else
+constexpr const char* kInjectedFailureMsg = "injected failure";  // (unreachable: the hook is not compiled in)
+#endif
+int makeFieldDev(const hpsdf_ctx* ctx, const hpsdf_field* f, const double* dSamples, FieldDev* out);
+// hpsdf_ctx_set_build_limits, checked by both schedulers when a round opens.  nodes: the tree's; bytes: the device memory this rank's
+// build state needs for the round about to open; held: what its buffers hold now (counted as available when the default limit is
+// measured); *measured: the build's cache of that measurement (0 = not taken yet; one hipMemGetInfo per Create, and only once a build
+// needs more than 256 MiB).  HPSDF_OK, or HPSDF_ERR_BUILD_LIMIT with the message set.
+int checkBuildLimits(const hpsdf_ctx* ctx, uint64_t nodes, uint64_t bytes, uint64_t held, uint64_t* measured, uint64_t rounds, double total, double target);
+// the two semantic switches as a context sees them: its own setting, or the process-wide one when it has none (ctx may be null)
+int meshFaceRuleReference(const hpsdf_ctx* ctx);  // hpsdf_[ctx_]set_mesh_face_rule(): 1 = the reference's face-case point whatever its weights
+float meshFaceTolOfSlack(const hpsdf_ctx* ctx);   // MeshDev::faceTolOfSlack for launches prepared now
+int reductionLeftAssoc(const hpsdf_ctx* ctx);     // hpsdf_[ctx_]set_reduction_order()
 void setReductionLeftAssoc(int left);
 
 // host mesh preparation (mesh.cpp)

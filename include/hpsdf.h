@@ -41,8 +41,21 @@ typedef enum hpsdf_status {
     HPSDF_ERR_UNSUPPORTED = 5,
     HPSDF_ERR_STATE = 6,          /* call sequence violated */
     HPSDF_ERR_OUT_OF_MEMORY = 7,
-    HPSDF_ERR_OPEN_MESH = 8       /* Mesh::CreateHalfEdges would return false (Mesh.cpp:121-128) */
+    HPSDF_ERR_OPEN_MESH = 8,      /* Mesh::CreateHalfEdges would return false (Mesh.cpp:121-128) */
+    HPSDF_ERR_BUILD_LIMIT = 9     /* Create stopped: the tree outgrew hpsdf_ctx_set_build_limits (ABI 4) */
 } hpsdf_status;
+
+/* ---- ABI version ------------------------------------------------------------
+ * Bumped whenever a struct of this header changes size or an entry point changes meaning; additions of entry points alone do not
+ * bump it.  hpsdf_abi_version() is what the loaded library was built with: a binding compares it with the HPSDF_ABI_VERSION it was
+ * compiled against before it hands the library a struct (include/hpsdf_octree.hpp does, and throws on a mismatch).
+ *   3 (round 5): hpsdf_build_stats grew from 88 to 112 bytes (fit_mode, split_fits, device_frontier) -- hpsdf_create,
+ *                hpsdf_create_distributed and hpsdf_build_get_stats write all 112; hpsdf_ctx_set_fast_fit(ctx, 0) selects
+ *                HPSDF_FIT_EXACT (it left HPSDF_FIT_SPLIT on in ABI 2).
+ *   4 (round 6): HPSDF_ERR_BUILD_LIMIT; no struct changed.  hpsdf_build_stats is FROZEN at 112 bytes from here on: anything new a
+ *                build has to report comes through a getter of its own (hpsdf_ctx_get_build_limits, ...). */
+#define HPSDF_ABI_VERSION 4
+HPSDF_API int hpsdf_abi_version(void);
 
 /* ---- constants: Include/HP/Consts.h:7-8, Include/HP/Octree.h:89 ----------- */
 #define HPSDF_BASIS_MAX_DEGREE 12
@@ -144,6 +157,26 @@ HPSDF_API int hpsdf_ctx_set_fast_fit(hpsdf_ctx* ctx, int on);
  * value (tests/test_gpu_parity.py::test_reduction_order_switch_matches_the_oracle).  HPSDF_REDUCTION_ORDER=left sets it at load. */
 HPSDF_API void hpsdf_set_reduction_order(int left_assoc);
 HPSDF_API int hpsdf_get_reduction_order(void);
+/* The same switch for ONE context (round 6): -1 = follow the process-wide setting above (the default), 0 / 1 = this context's own,
+ * for every launch it prepares afterwards -- fits, field evaluation, gradient queries, the host-answered scalar calls made through it.
+ * Two Octrees of one process can then differ (say, one per reference build being compared against).  _get returns the value in effect. */
+HPSDF_API int hpsdf_ctx_set_reduction_order(hpsdf_ctx* ctx, int left_assoc);
+HPSDF_API int hpsdf_ctx_get_reduction_order(const hpsdf_ctx* ctx, int* left_assoc);
+/* Runaway builds.  The reference's loop (Octree.cpp:212-216) ends when the total error falls below the threshold or the queue is
+ * empty; a threshold below what the error estimate can reach on a field (the default Config()'s 1e-10 on most fields, Config.cpp:7)
+ * refines towards depth 10 and degree 12 everywhere, and the reference grows its heap until host memory ends.  Here such a build used to
+ * end with HPSDF_ERR_OUT_OF_MEMORY when a device allocation finally failed -- minutes later on a 288 GB device.  Limits, checked when
+ * a round opens, by both schedulers and by every rank of a sharded build:
+ *   max_nodes: the tree's node count (identical on every rank, so every rank stops in the same round);
+ *   max_bytes: the device memory this rank's build state needs for the round about to open (node arrays, coefficient arena, sample
+ *              buffer -- capacities grow by doubling, so the allocation can reach twice this).
+ * 0 = the default: no bound on nodes; bytes = a quarter of the device memory that is free when the build first needs more than
+ * 256 MiB (measured then, once per Create; nothing is measured for builds that stay below, i.e. for every BASELINE config).
+ * UINT64_MAX = no limit.  A build that crosses a limit returns HPSDF_ERR_BUILD_LIMIT; hpsdf_last_error() names rounds, nodes,
+ * bytes, both limits, and the total error against the threshold.  No block is returned.  On several ranks a rank that stops on its
+ * bytes alone takes the others out through the FAILURES protocol of hpsdf_create_distributed. */
+HPSDF_API int hpsdf_ctx_set_build_limits(hpsdf_ctx* ctx, uint64_t max_nodes, uint64_t max_bytes);
+HPSDF_API int hpsdf_ctx_get_build_limits(const hpsdf_ctx* ctx, uint64_t* max_nodes, uint64_t* max_bytes);
 HPSDF_API void* hpsdf_ctx_stream(hpsdf_ctx* ctx);
 
 /* ---- fields: the callback F of Octree::Create (Include/HP/Octree.h:50) ------ */
@@ -212,6 +245,9 @@ HPSDF_API int hpsdf_field_release_host_copies(hpsdf_field* f);
  * the host scheduler with the per-point traversal inside the fit (what HPSDF_MESH_FUSED=1 selects). */
 HPSDF_API void hpsdf_set_mesh_face_rule(int reference);
 HPSDF_API int hpsdf_get_mesh_face_rule(void);
+/* ... per context (round 6): -1 = follow the process-wide rule (default), 0 / 1 = this context's own, for the launches it prepares. */
+HPSDF_API int hpsdf_ctx_set_mesh_face_rule(hpsdf_ctx* ctx, int reference);
+HPSDF_API int hpsdf_ctx_get_mesh_face_rule(const hpsdf_ctx* ctx, int* reference);
 /* (Mesh fields: a point with a coordinate that is not a finite number has no closest triangle -- the reference's search ends
  * with bestTri = -1 there and reads out of bounds, Mesh.cpp:139,157 -- and evaluates to a NaN on every entry point below.) */
 /* Mesh::SignedDistanceAtPt(pt) without a BVH (Source/Meshing/Mesh.cpp:42-51 over the O(n) scan :134-159), mesh fields
@@ -303,7 +339,7 @@ typedef struct hpsdf_job { /* one popped heap entry (BuildThreadPool::Input, Bui
 
 #define HPSDF_JOB_HEADER_DOUBLES 9 /* p_err, h_err[0..7] */
 
-typedef struct hpsdf_build_stats {
+typedef struct hpsdf_build_stats { /* 112 bytes since ABI 3, frozen (see HPSDF_ABI_VERSION) */
     uint64_t rounds, jobs, p_refines, h_refines, dropped, fits, samples;
     uint64_t n_nodes, n_leaves, n_coeffs;
     double total_error;

@@ -316,6 +316,27 @@ class Octree {
         fitMode_ = mode;
     }
     void SetFastFit(bool on) { SetFitMode(on ? HPSDF_FIT_FAST : HPSDF_FIT_SPLIT); }
+    /// Additive: bounds on Create (hpsdf_ctx_set_build_limits).  The reference's build has none: a threshold below what the error
+    /// estimate reaches on a field -- the default Config()'s 1e-10 on most -- refines until memory ends.  0 = the default (nodes:
+    /// unbounded; bytes: a quarter of the free device memory), UINT64_MAX = none.  A Create that crosses a limit throws SDF::Error
+    /// with status HPSDF_ERR_BUILD_LIMIT and a message that names rounds, nodes, bytes and the error reached.
+    void SetBuildLimits(uint64_t maxNodes, uint64_t maxBytes) {
+        ensureCtx();
+        check(hpsdf_ctx_set_build_limits(ctx_, maxNodes, maxBytes));
+        limitNodes_ = maxNodes, limitBytes_ = maxBytes;
+    }
+    /// Additive, this object only (hpsdf_ctx_set_reduction_order / hpsdf_ctx_set_mesh_face_rule): -1 = follow the process-wide
+    /// setting, 0 / 1 = this Octree's own.  Two Octrees of one process can differ.
+    void SetReductionOrderHere(int leftAssoc) {
+        ensureCtx();
+        check(hpsdf_ctx_set_reduction_order(ctx_, leftAssoc));
+        reductionOrder_ = leftAssoc;
+    }
+    void SetMeshFaceRuleHere(int reference) {
+        ensureCtx();
+        check(hpsdf_ctx_set_mesh_face_rule(ctx_, reference));
+        meshFaceRule_ = reference;
+    }
     /// Additive, process-wide (hpsdf_set_reduction_order): Eigen's Vector3d prod() / norm() / normalize() as (a . b) . c -- what an SSE2
     /// build of Eigen computes, by our reading -- instead of a . (b . c); set it once, before any Create / Query, to match your build.
     static void SetReductionOrder(bool leftAssoc) { hpsdf_set_reduction_order(leftAssoc ? 1 : 0); }
@@ -491,8 +512,15 @@ class Octree {
     }
     void ensureCtx() const {
         if (!ctx_) {
+            // (this header hands the library structs by size: refuse a library built with another hpsdf.h -- HPSDF_ABI_VERSION)
+            if (hpsdf_abi_version() != HPSDF_ABI_VERSION)
+                throw Error(HPSDF_ERR_STATE, "libhpsdf.so has ABI version " + std::to_string(hpsdf_abi_version()) + ", this program was compiled against " +
+                                                 std::to_string(HPSDF_ABI_VERSION) + " (include/hpsdf.h): recompile one of them");
             check(hpsdf_ctx_create(device_, stream_, &ctx_));
             if (fitMode_ >= 0) check(hpsdf_ctx_set_fit_mode(ctx_, fitMode_));  // (a copy keeps the mode its source was given)
+            if (limitNodes_ || limitBytes_) check(hpsdf_ctx_set_build_limits(ctx_, limitNodes_, limitBytes_));
+            if (reductionOrder_ >= 0) check(hpsdf_ctx_set_reduction_order(ctx_, reductionOrder_));
+            if (meshFaceRule_ >= 0) check(hpsdf_ctx_set_mesh_face_rule(ctx_, meshFaceRule_));
         }
     }
     void dropTree() {
@@ -571,6 +599,8 @@ class Octree {
         rank_ = o.rank_, world_ = o.world_;
         gather_ = o.gather_, gatherUser_ = o.gatherUser_;
         fitMode_ = o.fitMode_;
+        limitNodes_ = o.limitNodes_, limitBytes_ = o.limitBytes_;
+        reductionOrder_ = o.reductionOrder_, meshFaceRule_ = o.meshFaceRule_;
         config_ = o.config_;
         stats_ = o.stats_;
         continuity_ = o.continuity_;
@@ -604,6 +634,8 @@ class Octree {
     uint64_t jobsPerRound_ = 0;
     int rank_ = 0, world_ = 1;
     int fitMode_ = -1;  // -1: the context's default
+    uint64_t limitNodes_ = 0, limitBytes_ = 0;      // SetBuildLimits (0: the library's defaults)
+    int reductionOrder_ = -1, meshFaceRule_ = -1;  // Set...Here (-1: the process-wide settings)
     hpsdf_allgather_fn gather_ = nullptr;
     void* gatherUser_ = nullptr;
     mutable hpsdf_ctx* ctx_ = nullptr;

@@ -194,12 +194,15 @@ def test_field_that_is_not_finite_fails_the_build(H, ctx):
     assert st["n_nodes"] == 4681
 
 
-def _ranks_collect(H, world, cfg, make_field, K):
+def _ranks_collect(H, world, cfg, make_field, K, setup=None):
     """As _create_on_simulated_ranks, but every rank's outcome (block or exception) is returned and a rank left waiting in an
-    exchange shows as a broken barrier after a minute instead of hanging the test."""
+    exchange shows as a broken barrier after a minute instead of hanging the test.  setup(rank, ctx): per-rank context settings."""
     import threading
     import torch
     ctxs = [H.Context(0) for _ in range(world)]
+    if setup:
+        for r, c in enumerate(ctxs):
+            setup(r, c)
     fields = [make_field(c) for c in ctxs]
     barrier = threading.Barrier(world, timeout=60)
     bufs, out = [None] * world, [None] * world
@@ -232,8 +235,9 @@ def _ranks_collect(H, world, cfg, make_field, K):
     return out
 
 
-def _failing_rank_case(weighted, fail_at):
-    """(runs in a process of its own, on lib/libhpsdf_hooks.so: HPSDF_LIBRARY=hooks)"""
+def _failing_rank_case(weighted, fail_at, expect_device_frontier):
+    """(runs in a process of its own, on lib/libhpsdf_hooks.so: HPSDF_LIBRARY=hooks; the scheduler / selection path under test comes
+    with the environment: HPSDF_FRONTIER_INLINE_NODES=0, HPSDF_HOST_FRONTIER=1)"""
     import hpsdf_loader
     H = hpsdf_loader.load()
     world, bad = 4, 2
@@ -252,22 +256,33 @@ def _failing_rank_case(weighted, fail_at):
     good = _create_on_simulated_ranks(H, world, cfg, lambda c: H.Field.union3(), 256)
     one, _ = H.create_block(H.Context(0), cfg, H.Field.union3(), 256)
     assert all(blk == one for blk, _ in good)
+    assert all(st["device_frontier"] == expect_device_frontier for _, st in good), [st["device_frontier"] for _, st in good]
     print("failing-rank case ok")
 
 
-@pytest.mark.parametrize("weighted,fail_at", [(False, 0), (False, 3), (True, 0), (True, 2)])
-def test_a_failing_rank_takes_the_others_out_with_it(weighted, fail_at):
+@pytest.mark.parametrize("weighted,fail_at,env", [
+    (False, 0, {}), (False, 3, {}), (True, 0, {}), (True, 2, {}),
+    # the grid selection (trees beyond HPSDF_FRONTIER_INLINE_NODES): the round's part of the arena is the batch kernel's decision
+    (False, 3, {"HPSDF_FRONTIER_INLINE_NODES": "0"}), (True, 0, {"HPSDF_FRONTIER_INLINE_NODES": "0"}),
+    (True, 1, {"HPSDF_FRONTIER_INLINE_NODES": "0"}), (True, 3, {"HPSDF_FRONTIER_INLINE_NODES": "0"}),
+    # the host scheduler's sharded rounds (what callbacks, logging builds and more than 8 ranks run)
+    (False, 2, {"HPSDF_HOST_FRONTIER": "1"}), (True, 2, {"HPSDF_HOST_FRONTIER": "1"})])
+def test_a_failing_rank_takes_the_others_out_with_it(weighted, fail_at, env):
     """One rank's share of a round fails on its own (HPSDF_TEST_FAIL_RANK stands in for a device allocation that one GPU cannot
-    serve): it still enters the exchange the others are heading for, with its status set; it returns its own error, every other
-    rank HPSDF_ERR_STATE naming it -- nobody is left waiting in a collective.  Device-side frontier (unweighted) and the host
-    scheduler's sharded rounds (weighted) alike; the contexts build normally afterwards.  The hook that makes a rank fail is compiled
-    into lib/libhpsdf_hooks.so only (-DHPSDF_TEST_HOOKS): the case runs in a process of its own that loads that library, and the
+    serve): it still enters the exchange(s) the others are heading for, with its status set; it returns its own error, every other
+    rank HPSDF_ERR_STATE naming it -- nobody is left waiting in a collective.  Unweighted and weighted builds on the device-side
+    frontier (the weighted ones in its replica mode: the round's rows are exchanged in front of the errors, and the failing rank has
+    to enter that exchange too, with the size the others use), both with the inline selection and with the grid selection
+    (HPSDF_FRONTIER_INLINE_NODES=0, where that size is only known once fr_batch_kernel has run), and the host scheduler's sharded
+    rounds (HPSDF_HOST_FRONTIER=1); the contexts build normally afterwards.  The hook that makes a rank fail is compiled into
+    lib/libhpsdf_hooks.so only (-DHPSDF_TEST_HOOKS): the case runs in a process of its own that loads that library, and the
     production library is shown not to look at the variable."""
     import subprocess, sys
     from conftest import ROOT
-    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_configs as T; T._failing_rank_case(%r, %r)"
-            % (ROOT, os.path.join(ROOT, "tests"), weighted, fail_at))
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, HPSDF_LIBRARY="hooks"))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_configs as T; T._failing_rank_case(%r, %r, %r)"
+            % (ROOT, os.path.join(ROOT, "tests"), weighted, fail_at, 0 if env.get("HPSDF_HOST_FRONTIER") else 1))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HPSDF_LIBRARY="hooks", **env))
     assert r.returncode == 0 and "failing-rank case ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
@@ -293,6 +308,24 @@ def test_weighted_build_sharded_through_the_device_frontier(H, ctx, wtype, stren
             assert blk == one and st["device_frontier"] == 1 and st["rounds"] == st1["rounds"] and st["jobs"] == st1["jobs"]
         print("weighted sphere @ %g: one rank %.1f ms, %d simulated ranks (threads on one GPU, contexts and fields included) %.1f ms"
               % (target, (t1 - t0) * 1e3, world, (tb - ta) * 1e3))
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_weighted_build_sharded_with_the_grid_selection(H, ctx, monkeypatch, world):
+    """The same replica mode when the selection runs as a grid (trees beyond HPSDF_FRONTIER_INLINE_NODES; forced here with 0): the
+    round's part of the arena (FrHdr::roundBase / partStride) is then fr_batch_kernel's decision and the host fetches it -- behind a
+    wait for the context's stream, which does not order itself against the null stream (without the wait the copy
+    returned the previous round's part and the ranks gathered the wrong slice).  Polynomial weighting on union3 @ 1e-7 with 256 jobs a
+    round: seventeen rounds whose parts all differ."""
+    cfg = H.make_config(1e-7)
+    cfg.nearnessWeighting_type, cfg.nearnessWeighting_strength = 1, 2.0
+    one, st1 = H.create_block(ctx, cfg, H.Field.union3(), 256)
+    monkeypatch.setenv("HPSDF_FRONTIER_INLINE_NODES", "0")
+    again, st2 = H.create_block(ctx, cfg, H.Field.union3(), 256)
+    assert again == one and st2["device_frontier"] == 1
+    out = _create_on_simulated_ranks(H, world, cfg, lambda c: H.Field.union3(), 256)
+    for blk, st in out:
+        assert blk == one and st["device_frontier"] == 1 and st["rounds"] == st1["rounds"] and st["jobs"] == st1["jobs"]
 
 
 def test_the_production_library_ignores_the_fault_injection_variable(H, ctx, monkeypatch):
@@ -1137,3 +1170,118 @@ def test_fast_fit_on_a_sampled_field(H, O, ctx):
     assert np.abs(a["coeffs"] - b["coeffs"]).max() <= TOL
 
     fast.close()
+
+
+@pytest.mark.parametrize("host", ["0", "1"])
+def test_build_limits_stop_a_runaway_build(H, ctx, golden, monkeypatch, host):
+    """hpsdf_ctx_set_build_limits (round 6).  The reference's loop has no bound (Octree.cpp:212-216): a threshold below what the error
+    estimate reaches -- the default Config()'s 1e-10 on most fields -- refines until memory ends, and until round 6 such a build ended
+    here minutes later in a failed hipMalloc.  With a limit on nodes or on bytes the build is refused when the round that crosses it
+    opens, with HPSDF_ERR_BUILD_LIMIT and a message that says how far it got; no block comes back; the context builds normally
+    afterwards.  Device-side frontier and host scheduler alike."""
+    monkeypatch.setenv("HPSDF_HOST_FRONTIER", host)
+    c = H.Context(0)
+    assert c.build_limits() == (0, 0)
+    cfg = H.make_config(1e-8)  # union3 @ 1e-8, K = 1024: 35 545 nodes in 11 rounds
+    c.set_build_limits(max_nodes=20000)
+    with pytest.raises(H.HpsdfError) as e:
+        H.create_block(c, cfg, H.Field.union3(), 1024)
+    assert e.value.status == H.ERR_BUILD_LIMIT and "nodes (limit 20000)" in str(e.value) and "rounds" in str(e.value), str(e.value)
+    c.set_build_limits(max_bytes=3 << 20)
+    with pytest.raises(H.HpsdfError) as e:
+        H.create_block(c, cfg, H.Field.union3(), 1024)
+    assert e.value.status == H.ERR_BUILD_LIMIT and "GiB of device memory" in str(e.value) and "hpsdf_ctx_set_build_limits" in str(e.value), str(e.value)
+    # a limit the build stays under changes nothing; nor does "none"
+    g = golden["blocks"]["A1_union3_1e-7_K1024"]
+    for limits in ((50000, 1 << 30), (None, None), (0, 0)):
+        c.set_build_limits(*limits)
+        blk, st = H.create_block(c, H.make_config(1e-7), H.Field.union3(), 1024)
+        assert hashlib.sha256(blk).hexdigest() == g["block_sha256"] and st["device_frontier"] == (0 if host == "1" else 1)
+    c.close()
+
+
+def test_build_limits_on_simulated_ranks(H):
+    """The same on two ranks: a bound on nodes stops every rank in the same round (the tree is replicated) -- each returns
+    HPSDF_ERR_BUILD_LIMIT itself; a bound on bytes that only ONE rank has takes the other out through the failing-rank protocol
+    (HPSDF_ERR_STATE naming it).  Nobody waits in a collective (the barrier of _ranks_collect would break after a minute)."""
+    cfg = H.make_config(1e-8)
+    out = _ranks_collect(H, 2, cfg, lambda c: H.Field.union3(), 1024, setup=lambda r, c: c.set_build_limits(max_nodes=20000))
+    for r in range(2):
+        assert isinstance(out[r], H.HpsdfError) and out[r].status == H.ERR_BUILD_LIMIT, (r, out[r])
+    out = _ranks_collect(H, 2, cfg, lambda c: H.Field.union3(), 1024, setup=lambda r, c: c.set_build_limits(max_bytes=(3 << 20) if r == 1 else 0))
+    assert isinstance(out[1], H.HpsdfError) and out[1].status == H.ERR_BUILD_LIMIT, out[1]
+    assert isinstance(out[0], H.HpsdfError) and out[0].status == H.ERR_STATE and "rank 1 failed" in str(out[0]), out[0]
+    # weighted (the device frontier's replica mode: two exchanges a round)
+    w = H.make_config(1e-8)
+    w.nearnessWeighting_type, w.nearnessWeighting_strength = 2, 3.0
+    out = _ranks_collect(H, 2, w, lambda c: H.Field.union3(), 1024, setup=lambda r, c: c.set_build_limits(max_bytes=(3 << 20) if r == 1 else 0))
+    assert isinstance(out[1], H.HpsdfError) and out[1].status == H.ERR_BUILD_LIMIT, out[1]
+    assert isinstance(out[0], H.HpsdfError) and out[0].status == H.ERR_STATE and "rank 1 failed" in str(out[0]), out[0]
+
+
+def test_two_contexts_differ_in_reduction_order_and_face_rule(H, O, golden):
+    """hpsdf_ctx_set_reduction_order / hpsdf_ctx_set_mesh_face_rule (round 6): the two semantic switches per context -- the process-wide
+    setters stay as the default a context follows until it is given its own.  Two contexts of ONE process build the C2 block under
+    different reduction orders, interleaved: each equals the oracle under its own order, call after call; gradients likewise; and two
+    contexts evaluate one needle mesh under the two face rules."""
+    from helpers import fuzz_mesh_case, hard_points
+    g = golden["blocks"]["C2_union3_1e-5"]
+    a, b = H.Context(0), H.Context(0)
+    for c in (a, b):
+        c.set_fit_mode(H.FIT_EXACT)
+    assert H.reduction_order() == 0 and a.reduction_order() == 0 and b.reduction_order() == 0
+    b.set_reduction_order(True)
+    assert b.reduction_order() == 1 and a.reduction_order() == 0 and H.reduction_order() == 0
+    cfg = H.make_config(g["target"], g["root_min"], g["root_max"])
+    O.set_reduction_order(1)
+    try:
+        ot_left = O.Tree.create(O.default_config(g["target"], g["root_min"], g["root_max"]), O.union3_field(), g["K"])
+        left = ot_left.to_block()
+        qp = O.splitmix64_points(20000, seed=5)
+        init = np.full((len(qp), 3), 7.0)
+        lv, lg = ot_left.query_with_gradient(qp, init)
+    finally:
+        O.set_reduction_order(0)
+    assert hashlib.sha256(left).hexdigest() != g["block_sha256"]
+    for _ in range(2):
+        for host in ("0", "1"):
+            os.environ["HPSDF_HOST_FRONTIER"] = host
+            try:
+                assert hashlib.sha256(H.create_block(a, cfg, H.Field.union3(), g["K"])[0]).hexdigest() == g["block_sha256"]
+                assert H.create_block(b, cfg, H.Field.union3(), g["K"])[0] == left
+            finally:
+                del os.environ["HPSDF_HOST_FRONTIER"]
+    # the gradient's normalize(): one block, two contexts (kernels, and the calls of <= 32 points answered on the calling thread)
+    ta, tb = H.DeviceTree(a, left), H.DeviceTree(b, left)
+    bv, bg = tb.query_with_gradient(qp, init)
+    av, ag = ta.query_with_gradient(qp, init)
+    assert np.array_equal(bits(bv), bits(lv)) and np.array_equal(bits(bg), bits(lg))
+    assert np.array_equal(bits(av), bits(lv)) and not np.array_equal(bits(ag), bits(lg))
+    sv, sg = tb.query_with_gradient(qp[:32], init[:32])
+    assert np.array_equal(bits(sg), bits(lg[:32]))
+    # following the process-wide setting again
+    b.set_reduction_order(None)
+    assert b.reduction_order() == 0
+    assert hashlib.sha256(H.create_block(b, cfg, H.Field.union3(), g["K"])[0]).hexdigest() == g["block_sha256"]
+    # the mesh face rule: one needle mesh, one field, two contexts
+    verts, tris, leaf, host, scale, shift = fuzz_mesh_case(100758)
+    os.environ["HPSDF_MESH_LEAF_TRIS"] = str(leaf)
+    if host:
+        os.environ["HPSDF_MESH_HOST_BUILD"] = "1"
+    try:
+        f = H.Field.mesh(a, verts, tris)
+    finally:
+        del os.environ["HPSDF_MESH_LEAF_TRIS"]
+        os.environ.pop("HPSDF_MESH_HOST_BUILD", None)
+    pts = hard_points(verts, tris, 100758)
+    ref = O.MeshField(verts, tris).signed_distance(pts)[0].astype(np.float64)
+    b.set_mesh_face_rule(True)
+    assert b.mesh_face_rule() == 1 and a.mesh_face_rule() == 0 and H.mesh_face_rule() == 0
+    da, db = f.eval_naive(a, pts), f.eval_naive(b, pts)
+    assert np.array_equal(bits(db), bits(ref)) and not np.array_equal(bits(da), bits(ref))
+    assert np.array_equal(bits(f.eval_naive(a, pts)), bits(da))
+    with pytest.raises(H.HpsdfError):
+        f.eval_wave(b, pts)
+    f.eval_wave(a, pts)
+    f.close()
+    a.close(); b.close()

@@ -203,3 +203,36 @@ def test_obj_loader_and_reference_mesh_fixture(H, O, tmp_path):
     d = np.load(os.path.join(ROOT, "tests", "golden", "halfedge_fail_mesh.npz"))
     assert d["verts"].shape == (11422, 3) and d["tris"].shape == (22840, 3)
     O.MeshField(d["verts"], d["tris"].astype(np.uint64))
+
+
+def test_every_environment_variable_is_documented():
+    """INTEGRATION.md section F lists every HPSDF_* variable the library, its headers and the Python package read -- what each changes and
+    whether results can differ (36 names, 3 documented).  A name read in the code and missing from the table fails
+    here; so does a table row the code no longer reads."""
+    import glob
+    pkg = os.path.join(ROOT, "hp-adaptive-signed-distance-field-octree_amd")
+    files = glob.glob(os.path.join(pkg, "csrc", "*")) + glob.glob(os.path.join(ROOT, "include", "*.h*")) + glob.glob(os.path.join(pkg, "*.py")) + [os.path.join(ROOT, "bench.py")]
+    read = set()
+    for f in files:
+        read |= set(re.findall(r'"(HPSDF_[A-Z0-9_]+)"', open(f, errors="replace").read()))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = doc[doc.index("## F. Every environment variable"):]
+    listed = set(re.findall(r"`(HPSDF_[A-Z0-9_]+)`", sec))
+    api_constants = {n for n in listed if n.startswith(("HPSDF_FIT_EXACT", "HPSDF_FIT_SPLIT", "HPSDF_FIT_FAST", "HPSDF_ERR_"))}
+    assert read - listed == set(), "read by the code, missing from INTEGRATION.md section F: %s" % sorted(read - listed)
+    stale = listed - read - api_constants - {"HPSDF_MESH_STATS_BUILD", "HPSDF_TEST_HOOKS", "HPSDF_QUERY_LAB_BUILD"}
+    assert stale == set(), "listed in INTEGRATION.md section F, read nowhere: %s" % sorted(stale)
+
+
+def test_production_library_holds_no_lab_or_fault_injection_code(H):
+    """Diagnostics that return wrong answers on purpose (HPSDF_QUERY_LAB: Query with a link of its chain removed) and the tests' fault
+    injection (HPSDF_TEST_FAIL_RANK) are compiled into libraries of their own (build.py --lab, libhpsdf_hooks.so); the production
+    library contains neither the variables' names nor the lab kernels."""
+    blob = open(os.path.join(os.path.dirname(H.LIB_PATH), "libhpsdf.so"), "rb").read()
+    assert b"HPSDF_QUERY_LAB" not in blob and b"HPSDF_TEST_FAIL_RANK" not in blob
+    hooks = open(os.path.join(os.path.dirname(H.LIB_PATH), "libhpsdf_hooks.so"), "rb").read()
+    assert b"HPSDF_TEST_FAIL_RANK" in hooks and b"HPSDF_QUERY_LAB" not in hooks
+    assert H.lib().hpsdf_abi_version() == H.ABI_VERSION
+    hdr = open(os.path.join(ROOT, "include", "hpsdf.h")).read()
+    assert int(re.search(r"#define HPSDF_ABI_VERSION (\d+)", hdr).group(1)) == H.ABI_VERSION
+    assert C.sizeof(H.BuildStats) == 112  # frozen since ABI 3 (include/hpsdf.h)

@@ -6,6 +6,12 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np, torch
+# the lab kernels live in lib/libhpsdf_lab.so only (round 6: the production library neither holds them nor reads HPSDF_QUERY_LAB);
+# build it on demand -- BEFORE anything touches the GPU -- and load it instead of libhpsdf.so
+import importlib.util
+_spec = importlib.util.spec_from_file_location("hpsdf_build", os.path.join(ROOT, "hp-adaptive-signed-distance-field-octree_amd", "build.py"))
+_b = importlib.util.module_from_spec(_spec); _spec.loader.exec_module(_b); _b.build_lab()
+os.environ["HPSDF_LIBRARY"] = "lab"
 import hpsdf_loader
 import oracle as O
 H = hpsdf_loader.load()
