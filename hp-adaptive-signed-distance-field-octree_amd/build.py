@@ -150,7 +150,8 @@ if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     if "--lab" in sys.argv:
         print(build_lab(verbose=True))
-    for a in sys.argv[1:]:  # --variant=name:-DFLAG,-DFLAG2   (kernels.hip compiled again under the flags)
+    for a in sys.argv[1:]:  # --variant=name:-DFLAG,-DFLAG2[:source.hip,source2.hip]   (default: kernels.hip compiled again under the flags)
         if a.startswith("--variant="):
-            name, _, fl = a[len("--variant="):].partition(":")
-            print(build_variant(name, [f for f in fl.split(",") if f], verbose=True))
+            name, _, rest = a[len("--variant="):].partition(":")
+            fl, _, srcs = rest.partition(":")
+            print(build_variant(name, [f for f in fl.split(",") if f], tuple(x for x in srcs.split(",") if x) or ("kernels.hip",), verbose=True))

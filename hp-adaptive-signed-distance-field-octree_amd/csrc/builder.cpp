@@ -325,7 +325,7 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
             rows += (uint64_t)classCount[c] * T.coeffCount[deg];
             samples += (uint64_t)classCount[c] * nq * nq * nq;
         }
-        if (!sampled && !meshSampled && ctx->fitMode != HPSDF_FIT_SPLIT) samples = 0;  // (no sample buffer then)
+        if (!sampled && !meshSampled) samples = 0;  // (the hand-over buffer of split fits is optional: ensureSampleBuffer's failure makes the round exact)
         const uint64_t bytes = (b->arenaUsed + rows + std::min<uint64_t>(samples, 1ull << 31)) * sizeof(double);
         const uint64_t held = (ws.arenaCap + ws.meshSamplesCap) * sizeof(double);
         const int lrc = checkBuildLimits(ctx, b->nodes.size(), bytes, held, &b->measuredLimit, b->stats.rounds, b->total, b->cfg.target_error_threshold);

@@ -71,23 +71,26 @@ int meshFaceRuleReference(const hpsdf_ctx* ctx) { return ctx && ctx->meshFaceRul
 void setMeshFaceRuleReference(int on) { gMeshFaceReference.store(on != 0, std::memory_order_relaxed); }
 float meshFaceTolOfSlack(const hpsdf_ctx* ctx) { return meshFaceRuleReference(ctx) ? std::numeric_limits<float>::infinity() : 0.25f; }
 
-int checkBuildLimits(const hpsdf_ctx* ctx, uint64_t nodes, uint64_t bytes, uint64_t held, uint64_t* measured, uint64_t rounds, double total, double target) {
+uint64_t buildByteLimit(const hpsdf_ctx* ctx, uint64_t bytes, uint64_t held, uint64_t* measured) {
     constexpr uint64_t kNone = ~0ull, kMeasureFrom = 256ull << 20;
-    const uint64_t maxNodes = ctx->limitNodes ? ctx->limitNodes : kNone;
-    uint64_t maxBytes = ctx->limitBytes ? ctx->limitBytes : kNone;
-    const char* how = "hpsdf_ctx_set_build_limits";
-    if (ctx->limitBytes == 0 && bytes > kMeasureFrom) {  // the default: a quarter of what the device can give this build
-        if (*measured == 0) {
-            size_t freeB = 0, totalB = 0;
-            if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) {
-                (void)hipGetLastError();
-                freeB = 0;
-            }
-            *measured = std::max<uint64_t>(kMeasureFrom, ((uint64_t)freeB + held) / 4);
+    if (ctx->limitBytes) return ctx->limitBytes;
+    if (bytes <= kMeasureFrom) return kNone;  // (nothing is measured for builds that stay small: every BASELINE config)
+    if (*measured == 0) {  // the default: 1/256 of what the device could give this build, at least 1 GiB
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) {
+            (void)hipGetLastError();
+            freeB = 0;
         }
-        maxBytes = *measured;
-        how = "the default: a quarter of the device memory that was free";
+        *measured = std::max<uint64_t>(1ull << 30, ((uint64_t)freeB + held) / 256);
     }
+    return *measured;
+}
+
+int checkBuildLimits(const hpsdf_ctx* ctx, uint64_t nodes, uint64_t bytes, uint64_t held, uint64_t* measured, uint64_t rounds, double total, double target) {
+    constexpr uint64_t kNone = ~0ull;
+    const uint64_t maxNodes = ctx->limitNodes ? ctx->limitNodes : kNone;
+    const uint64_t maxBytes = buildByteLimit(ctx, bytes, held, measured);
+    const char* how = ctx->limitBytes ? "hpsdf_ctx_set_build_limits" : "the default: 1/256 of the device memory that was free, at least 1 GiB";
     if (nodes <= maxNodes && bytes <= maxBytes) return HPSDF_OK;
     char msg[640];
     std::snprintf(msg, sizeof msg,
@@ -126,6 +129,7 @@ int makeFieldDev(const hpsdf_ctx* ctx, const hpsdf_field* f, const double* dSamp
             out->mesh.halfEdges = f->dHalfEdges;
             out->mesh.triPos = reinterpret_cast<const float4*>(f->dTriPos);
             out->mesh.triPre = reinterpret_cast<const float4*>(f->dTriPre);
+            out->mesh.slotTri = f->dSlotTri;
             out->mesh.bvh = f->dBvh;
             out->mesh.slabs = f->dSlabs;
             out->mesh.leafLog2 = f->leafLog2;
@@ -661,7 +665,7 @@ static bool smallQueriesOnHost() {
 // behind a device-wide synchronisation (the field's arrays may still be being written on some stream), under the field's lock, and kept
 // until hpsdf_field_release_host_copies() or the field's destruction.
 static size_t meshMirrorBytes(const hpsdf_field* f) {
-    return (size_t)f->nVerts * 12 + (size_t)f->nTris * (12 + 12 + 4 * (size_t)(kTriRecordFloats + kTriPreFloats)) + (size_t)f->nBvhNodes * sizeof(BvhNode);
+    return (size_t)f->nVerts * 12 + (size_t)f->nTris * (12 + 12 + 4 + 4 * (size_t)(kTriRecordFloats + kTriPreFloats)) + (size_t)f->nBvhNodes * sizeof(BvhNode);
 }
 static size_t hostMeshMirrorLimit() { static const size_t v = hostLimit("HPSDF_HOST_MESH_MIRROR_MB", 512) << 20; return v; }
 // The host copies of a mesh field's arrays (made once, by the first call of a few points)
@@ -682,11 +686,16 @@ static int meshHostMirror(const hpsdf_field* f, std::shared_ptr<hpsdf_field::Hos
         HPSDF_HIP(hipMemcpy(m->halfEdges.data(), f->dHalfEdges, m->halfEdges.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         HPSDF_HIP(hipMemcpy(m->triPos.data(), f->dTriPos, m->triPos.size() * sizeof(float), hipMemcpyDeviceToHost));
         HPSDF_HIP(hipMemcpy(m->triPre.data(), f->dTriPre, m->triPre.size() * sizeof(float), hipMemcpyDeviceToHost));
+        if (f->dSlotTri) {
+            m->slotTri.resize(f->nTris);
+            HPSDF_HIP(hipMemcpy(m->slotTri.data(), f->dSlotTri, m->slotTri.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        }
         if (f->nBvhNodes) HPSDF_HIP(hipMemcpy(m->bvh.data(), f->dBvh, (size_t)f->nBvhNodes * sizeof(BvhNode), hipMemcpyDeviceToHost));
         MeshDev& d = m->dev;
         d.verts = m->verts.data(), d.tris = m->tris.data(), d.halfEdges = m->halfEdges.data();
         d.triPos = reinterpret_cast<const float4*>(m->triPos.data());
         d.triPre = reinterpret_cast<const float4*>(m->triPre.data());
+        d.slotTri = f->dSlotTri ? m->slotTri.data() : nullptr;
         d.bvh = m->bvh.data(), d.slabs = nullptr;  // (the per-point traversal uses boxes and triangle records only)
         d.nTris = f->nTris, d.nNodes = f->nBvhNodes, d.leafLog2 = f->leafLog2, d.poolCap = 0, d.stats = nullptr;
         f->hostMirror = m;

@@ -2544,7 +2544,10 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         const uint64_t needArena = knownArena + (replica ? (uint64_t)world * ((uint64_t)Kj * rowsPerJob(degBound) + 16) : (uint64_t)Kj * rowsPerJob(degBound));
         {   // hpsdf_ctx_set_build_limits: the round about to open against the context's bounds -- before anything is allocated for it, so
             // that a runaway build ends here with its statistics in the message instead of minutes later in a failed hipMalloc
-            const uint64_t needSamples = (mesh || (splitMode && degBound >= ctx->splitMinDegree)) ? std::min<uint64_t>((uint64_t)Kj * samplesPerJob(degBound), 1ull << 31) : 0ull;
+            // (a mesh build cannot do without its sample buffer; the hand-over buffer of split fits -- at most 2^31 samples, 16 GiB, whatever
+            // the tree's size -- is not part of what grows without bound and is not counted: counting it would make the two schedulers'
+            // split decisions depend on the limit, and they promise the same bytes)
+            const uint64_t needSamples = mesh ? std::min<uint64_t>((uint64_t)Kj * samplesPerJob(degBound), 1ull << 31) : 0ull;
             const uint64_t bytes = needNodes * FrontierWorkspace::kBytesPerNode + (needArena + needSamples) * sizeof(double);
             const uint64_t held = (uint64_t)ws->nodeCap * FrontierWorkspace::kBytesPerNode + (ws->arenaCap + ws->sampleCap) * sizeof(double);
             const int lrc = checkBuildLimits(ctx, knownNodes, bytes, held, &measuredLimit, (uint64_t)roundsDone, roundsDone ? hh->total : 8.0 * 8.0 * 8.0 * 8.0 * HPSDF_INITIAL_NODE_ERR,

@@ -202,26 +202,30 @@ HPSDF_HD V3 pseudoNormal(const MeshDev& m, uint32_t t, int code) {
 // A leaf reference (BvhNode::c0 / c1 < 0): its first slot and how many, and the triangle a slot holds.
 HPSDF_HD __forceinline__ uint32_t leafFirst(int32_t c) { return (uint32_t)~c >> kMeshLeafShift; }
 HPSDF_HD __forceinline__ uint32_t leafCount(int32_t c) { return ((uint32_t)~c & (kMeshLeafMax - 1u)) + 1u; }
-// A triPre record (three float4 per leaf slot): g.xyz hu | n.xyz hv | u.xyz triangle -- the triangle lies in the plane through g
-// across the unit normal n, inside the rectangle |u . (x - g)| <= hu, |v . (x - g)| <= hv of that plane (u a unit vector along its
-// longest edge, v = n x u).  n = u = 0, hu = 0, hv = rho degrades it to the ball of radius rho around g (slivers whose normal cancels).
+// A triPre record (four float4 per leaf slot, one 64-byte line): a.xyz n.x | n.yz mab.xy | mab.z mbc.xyz | mca.xyz obc -- the triangle
+// lies in the plane through its vertex a across the unit normal n, on the inner side of three planes across the unit in-plane vectors
+// mab, mbc, mca (the outward normals of its edges; ab's and ca's pass through a, bc's lies obc beyond it): its PRISM.  All zeros
+// but a: "no bound" (slivers whose normal cancels, records that failed their own check in mesh_tripre_kernel): the test passes.
 struct TriPre {
-    float4 g, n, u;
+    float4 r0, r1, r2, r3;
 };
 HPSDF_HD __forceinline__ TriPre loadTriPre(const MeshDev& m, uint32_t slot) {
-    return TriPre{m.triPre[3 * (size_t)slot], m.triPre[3 * (size_t)slot + 1], m.triPre[3 * (size_t)slot + 2]};
+    return TriPre{m.triPre[4 * (size_t)slot], m.triPre[4 * (size_t)slot + 1], m.triPre[4 * (size_t)slot + 2], m.triPre[4 * (size_t)slot + 3]};
 }
-HPSDF_HD __forceinline__ uint32_t triPreTriangle(const TriPre& r) { return hpsdfAcosfWord(r.u.w); }
-HPSDF_HD __forceinline__ uint32_t slotTriangle(const MeshDev& m, uint32_t slot) { return hpsdfAcosfWord(m.triPre[3 * (size_t)slot + 2].w); }
+HPSDF_HD __forceinline__ uint32_t slotTriangle(const MeshDev& m, uint32_t slot) { return m.slotTri ? m.slotTri[slot] : slot; }
 
-// The lower-bound test on a triPre record: with s = n . (p - g) and a = u . (p - g) the squared distance of p from the triangle is
-// at least s^2 + max(|a| - hu, 0)^2 + max(sqrt(|p - g|^2 - s^2 - a^2) - hv, 0)^2 -- two dozen instructions against the two hundred
-// of the closest-point test.  (Until the middle of round 3 the triangle was bounded by a circle in its plane; the rectangle costs
-// five instructions more and has half the area for the 4 : 1 triangles of a stretched grid: 17 -> 10 candidates per sample on
-// the displaced torus with the final distance known; no change on equilateral triangles.)
+// The lower-bound test on a triPre record (round 6): with dx = p - a, s = n . dx and e = the largest of mab . dx, mbc . dx - obc,
+// mca . dx the squared distance of p from the triangle is at least s^2 + max(e, 0)^2 -- EXACT when the closest point lies in the face
+// (e <= 0: the distance from the plane) or on an edge (the distance from that edge's line), an underestimate only where it is a
+// corner; 21 instructions against the two hundred of the closest-point test.
+// (Rounds 3-5 bounded the triangle by its RECTANGLE in its own plane: s^2 + the rectangle's excess.  For a sample at distance D
+// above a surface of curvature radius R that admits every triangle whose centre lies within ~(1 + sqrt(D / (R + D))) half-extents of
+// the foot point -- the neighbours' planes pass BELOW the foot point's, and the rectangle's near rim gains what the plane loses --:
+// 22 triangles a sample went on to the closest-point test on the 2.1 M-triangle torus with the final distance known.  The prism's edge
+// planes cut that to the triangles that really tie: the foot point's own, two on an edge, the fan around a corner.)
 // A box only says "the triangle is somewhere in here": for a sample at distance D from a surface tessellated at size h every
 // triangle whose box dips into the ball passes the box test, a patch ~sqrt(2 D h) wide (~300 triangles per sample on a
-// 1.3 M-triangle sphere); the plane-and-rectangle bound leaves the ones within ~h.
+// 1.3 M-triangle sphere).
 // A triangle is dropped only if the bound exceeds the best distance by `slack` = 2e-6 of the mesh's scale (its extent, or
 // its largest coordinate if that is larger: f32 positions round at that scale; meshSlack has the error budget) and by
 // 5e-6 of itself -- so the winner is still exactly the exhaustive scan's (test_mesh_bvh_equals_linear_scan_bitwise, the
@@ -231,19 +235,19 @@ HPSDF_HD __forceinline__ uint32_t slotTriangle(const MeshDev& m, uint32_t slot) 
 // slack they are compared with is four orders of magnitude wider than either.)
 HPSDF_HD __forceinline__ float dotF(V3 a, V3 b) { return __builtin_fmaf(a.x, b.x, __builtin_fmaf(a.y, b.y, a.z * b.z)); }
 HPSDF_HD __forceinline__ float triLowerBound2(V3 p, const TriPre& r) {
-    const V3 dx = p - V3{r.g.x, r.g.y, r.g.z};
-    const float sd = dotF(V3{r.n.x, r.n.y, r.n.z}, dx), ad = dotF(V3{r.u.x, r.u.y, r.u.z}, dx);
-    const float lat2 = __builtin_fmaf(-ad, ad, __builtin_fmaf(-sd, sd, dotF(dx, dx)));
-    const float ou = fmaxf(fabsf(ad) - r.g.w, 0.0f);
-    const float ov = fmaxf(boundSqrt(fmaxf(lat2, 0.0f)) - r.n.w, 0.0f);
-    return __builtin_fmaf(ov, ov, __builtin_fmaf(ou, ou, sd * sd));
+    const V3 dx = p - V3{r.r0.x, r.r0.y, r.r0.z};
+    const float sd = dotF(V3{r.r0.w, r.r1.x, r.r1.y}, dx);
+    const float e1 = dotF(V3{r.r1.z, r.r1.w, r.r2.x}, dx), e2 = dotF(V3{r.r2.y, r.r2.z, r.r2.w}, dx) - r.r3.w, e3 = dotF(V3{r.r3.x, r.r3.y, r.r3.z}, dx);
+    const float e = fmaxf(fmaxf(e1, e2), fmaxf(e3, 0.0f));
+    return __builtin_fmaf(e, e, sd * sd);
 }
 // The slack (a distance) a lower bound must exceed the best distance by before anything is dropped.  What it has to cover
 // (u = 2^-24, D the distance, M the largest coordinate; every f32 subtraction p - g is relatively exact, so most errors
 // scale with D and are absorbed by rejectBound's factor 1.00001 on the square, i.e. 5e-6 D):
 //   the reference's closest point q = a + t ab (or (u a + v b) + w c) is rounded where it is formed: <= 3 u M off the
 //     triangle, so its distance may come out that much below the true one                                  1.8e-7 M
-//   the record's plane misses the triangle's vertices by e <= 4e-7 of the scale (mesh_tripre_kernel checks) 4.0e-7 M
+//   the record's planes miss the triangle's vertices by <= 3e-7 of the scale each (mesh_tripre_kernel checks;
+//     across and within the plane together: sqrt 2 of that)                                                 4.3e-7 M
 //   n . (p - g), |p - g|^2 - (n . (p - g))^2, |n| - 1: ~16 u D                                              (factor)
 // 2e-6 of the scale is three and a half times their sum.  (Round 2 ran with 2e-5; the margin it adds around every foot
 // point, sqrt(2 D slack), was most of what the samples far from the surface queued: a triangle's width and more.)
@@ -292,7 +296,7 @@ HPSDF_HD float meshSignedDistance(const MeshDev& m, V3 pt, uint32_t& hint) {
     auto visitLeaf = [&](int32_t c) {
         for (uint32_t k = 0, first = leafFirst(c), cnt = leafCount(c); k < cnt; ++k) {
             const TriPre rec = loadTriPre(m, first + k);
-            if (!(triLowerBound2(pt, rec) > reject)) visitTri(triPreTriangle(rec));
+            if (!(triLowerBound2(pt, rec) > reject)) visitTri(slotTriangle(m, first + k));
         }
     };
     auto boxDist = [&](const float* lo, const float* hi) {
@@ -381,7 +385,7 @@ __device__ float meshSignedDistanceWave(const MeshDev& m, V3 pt, bool activeIn, 
     auto visitLeaf = [&](int32_t c) {
         for (uint32_t k = 0, first = leafFirst(c), cnt = leafCount(c); k < cnt; ++k) {
             const TriPre rec = loadTriPre(m, first + k);
-            if (!(triLowerBound2(pt, rec) > reject)) visitTri(triPreTriangle(rec));
+            if (!(triLowerBound2(pt, rec) > reject)) visitTri(slotTriangle(m, first + k));
         }
     };
     auto boxDist = [&](const float* lo, const float* hi) {  // clamp = median of (p, lo, hi): lo <= hi in every box
@@ -613,8 +617,8 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool activeIn,
         uint32_t tri = 0u;
         if (on) {
             const TriPre rec = loadTriPre(m, slot);
-            tri = triPreTriangle(rec);
             pass = !(triLowerBound2(p, rec) > rj);  // (a NaN passes)
+            if (pass) tri = slotTriangle(m, slot);
 #if HPSDF_MESH_ABL == 6  // (lab: the lower-bound test twice)
             {
                 V3 p2 = p;
@@ -719,7 +723,7 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool activeIn,
                 const uint32_t k = (uint32_t)__ffs((int)restMask) - 1u;
                 restMask &= restMask - 1u;
                 const TriPre rec = loadTriPre(m, seedFirst + k);
-                if (!(triLowerBound2(pt, rec) > rj)) tryTriangle(triPreTriangle(rec), seedFirst + k);
+                if (!(triLowerBound2(pt, rec) > rj)) tryTriangle(slotTriangle(m, seedFirst + k), seedFirst + k);
             }
         }
         for (int pass = 0; pass < HPSDF_SEED_EXCHANGE; ++pass) {
@@ -733,10 +737,10 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool activeIn,
                 if (active && slot != 0xFFFFFFFFu && slot != bestSlot) {
                     const TriPre rec = loadTriPre(m, slot);
                     const float lb = triLowerBound2(pt, rec);
-                    if (lb < candLb && !(lb > rj)) candLb = lb, candSlot = slot, candTri = triPreTriangle(rec);
+                    if (lb < candLb && !(lb > rj)) candLb = lb, candSlot = slot;
                 }
             }
-            if (candSlot != 0xFFFFFFFFu) tryTriangle(candTri, candSlot);
+            if (candSlot != 0xFFFFFFFFu) candTri = slotTriangle(m, candSlot), tryTriangle(candTri, candSlot);
         }
         {
             // (one triangle per lane and step: at a corner the edge that starts there first, and if that does not help the
@@ -1150,7 +1154,8 @@ __device__ __forceinline__ double evalLeafGradVals(const double (&cv)[NV], const
 
 // FApproxWithGradient for a wave's mix of degrees <= P in one pass, as evalLeafValsMixed: every running sum -- the two one-sided sums
 // of each axis and the value -- is kept at the last row of the lane's own degree.
-template <int P, int NV>
+// (NODIV: lab builds only, tools/query_general_floor.py -- the six IEEE divisions and the square root left out)
+template <int P, int NV, bool NODIV = false>
 __device__ __forceinline__ double evalLeafGradValsMixed(const double (&cv)[NV], const double (&u)[3], int depth, uint32_t degree, const double* sNl,
                                                         const double* sRec, double (&g)[3], int left) {
     constexpr int N = coeffCount(P);
@@ -1181,12 +1186,17 @@ __device__ __forceinline__ double evalLeafGradValsMixed(const double (&cv)[NV], 
                 if (r == coeffCount(dgr) - 1) pMine = degree == (uint32_t)dgr ? p1 : pMine, mMine = degree == (uint32_t)dgr ? m1 : mMine;
         }
         if (degree != (uint32_t)P) p1 = pMine, m1 = mMine;
-        g[k] = (p1 - m1) / (2.0 * eps);
+        if constexpr (NODIV)
+            g[k] = p1 - m1;
+        else
+            g[k] = (p1 - m1) / (2.0 * eps);
     }
-    const double z = left ? sum3<true>(g[0] * g[0], g[1] * g[1], g[2] * g[2]) : sum3<false>(g[0] * g[0], g[1] * g[1], g[2] * g[2]);  // Eigen normalize()
-    if (z > 0.0) {
-        const double nrm = sqrt(z);
-        g[0] = g[0] / nrm, g[1] = g[1] / nrm, g[2] = g[2] / nrm;
+    if constexpr (!NODIV) {
+        const double z = left ? sum3<true>(g[0] * g[0], g[1] * g[1], g[2] * g[2]) : sum3<false>(g[0] * g[0], g[1] * g[1], g[2] * g[2]);  // Eigen normalize()
+        if (z > 0.0) {
+            const double nrm = sqrt(z);
+            g[0] = g[0] / nrm, g[1] = g[1] / nrm, g[2] = g[2] / nrm;
+        }
     }
     double f = 0.0, mine = 0.0;  // :972-984
 #pragma unroll
@@ -1416,6 +1426,7 @@ __device__ __forceinline__ void queryTopBody(const TreeDev& t, const double* __r
     // 32 bytes of padding: a lane reads row (sub & 3), so without it the four lanes of a group hit the same banks
     // one kilobyte apart (measured: 70 % of the LDS cycles were bank conflicts).
     __shared__ double2 sRows[4][4][66];
+    __shared__ uint32_t sRunCell[4][64];  // ordered input: the cell of every run of equal cells in the wave (below)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane & ~7, sub = lane & 7;
     for (size_t base = (size_t)blockIdx.x * 256; base < n; base += (size_t)gridDim.x * 256) {
         const size_t i = base + threadIdx.x;
@@ -1442,13 +1453,79 @@ __device__ __forceinline__ void queryTopBody(const TreeDev& t, const double* __r
         // point is the first of the group in its cell, and every lane reads the row of the first point of its own cell
         // (coherent point sets -- grids, slices, rays -- move a fraction of the lines; random points lose nothing but a
         // few compares: the kernel is bound by the L2 -> CU line traffic).
+        uint2 hdr = make_uint2(0u, 0u);
+        double cv[10];
+        // ORDERED INPUT (round 6).  Grids, slices, rays and cell-sorted point sets arrive as RUNS of consecutive points in one cell: a
+        // lane opens a run if its cell differs from the lane's before it.  With at most 32 runs in the wave -- random points have 64 --
+        // the wave needs one row per RUN, not one per point or per group of eight: the lanes that open a run publish its cell, step s
+        // fetches the rows of runs 8s .. 8s + 7 (eight lanes a row, as ever), and every lane reads back the row of its own run; four steps at
+        // most, one for a wave that crosses a handful of cells, and no second pass.  A wave that lies in ONE cell altogether -- the rule in
+        // cell-sorted sets, 2 441 points a cell at 10 M points -- asks for its row through the scalar cache and evaluates from SGPRs: no
+        // LDS, no vector memory at all.  The rows are the same bytes whichever way they come, so the values are too
+        // (test_query_ordered_point_sets_bitwise).  What the group-wise dedupe of rounds 1-5 cost such sets was its bookkeeping: eight
+        // shuffles and ~60 compares a tile on a kernel whose arithmetic is 228 vector instructions a tile and which, on ordered input, is
+        // bound by exactly that.
+        bool viaRuns = false;
+        if (DEDUPE) {
+            const uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp((int)code, (int)code, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            const bool opens = lane == 0 || before != code;
+            const unsigned long long heads = __ballot(opens);
+            const int nRuns = __popcll(heads);  // wave-uniform
+            if (nRuns == 1) {
+                const uint32_t cell = (uint32_t)__builtin_amdgcn_readfirstlane((int)code);
+                typedef const __attribute__((address_space(4))) uint32_t* ConstWords;
+                const ConstWords w = (ConstWords)(uintptr_t)(t.top + cell);
+                hdr = make_uint2(w[0], w[1]);
+#pragma unroll
+                for (int c = 0; c < 10; ++c) cv[c] = __longlong_as_double((long long)(((unsigned long long)w[5 + 2 * c] << 32) | (unsigned long long)w[4 + 2 * c]));
+                viaRuns = true;
+            } else if (nRuns <= 32) {
+                // (the wave's row of sRunCell from an index the compiler cannot see through: hoisted out of the tile loop, that address is
+                // one register more than the kernel's seven waves a SIMD leave it, and it went to scratch)
+                uint32_t waveV = (uint32_t)threadIdx.x >> 6;
+                asm volatile("" : "+v"(waveV));
+                uint32_t* runCell = sRunCell[waveV];
+                const uint32_t myRun = __builtin_amdgcn_mbcnt_hi((uint32_t)(heads >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)heads, 0u)) + (opens ? 1u : 0u) - 1u;
+                if (opens) runCell[myRun] = code;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const int nSteps = (nRuns + 7) >> 3;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (k < nSteps) {
+                        const int run = 8 * k + (lane >> 3);
+                        if (run < nRuns && sub < 6) {  // bytes 96..127 of an entry are padding
+                            const char* src = reinterpret_cast<const char*>(t.top + runCell[run]) + sub * 16;
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                             (__attribute__((address_space(3))) void*)&sRows[wave][k][0], 16, 0, 0);
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                {
+                    const double2* row = &sRows[wave][myRun >> 3][(myRun & 7u) * 8u];
+                    hdr = *reinterpret_cast<const uint2*>(row);
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) {
+                        const double2 v = row[1 + c];
+                        cv[2 * c] = v.x;
+                        cv[2 * c + 1] = v.y;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();  // the window is rewritten by the next tile
+                viaRuns = true;
+            }
+        }
+        if (!viaRuns) {
         uint32_t ck[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) ck[k] = __shfl(code, grp | k, 64);
         int firstOfMine = sub;  // first point of the group in this lane's cell
         uint32_t needMask = 0xFFu;  // bit k: point k is the first of its cell in the group
         // wave-uniform gate: on random points (almost) no wave has two neighbouring lanes in one cell and the
-        // bookkeeping below is skipped; on ordered point sets (almost) every wave has
+        // bookkeeping below is skipped; on point sets with SOME order (more than 32 runs, yet neighbours that share cells) it pays
         if (DEDUPE && __any(__shfl_xor(code, 1, 64) == code)) {
 #pragma unroll
             for (int k = 7; k >= 0; --k) firstOfMine = ck[k] == code ? k : firstOfMine;
@@ -1461,8 +1538,6 @@ __device__ __forceinline__ void queryTopBody(const TreeDev& t, const double* __r
                 needMask |= seen ? 0u : (1u << k);
             }
         }
-        uint2 hdr = make_uint2(0u, 0u);
-        double cv[10];
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -1486,6 +1561,7 @@ __device__ __forceinline__ void queryTopBody(const TreeDev& t, const double* __r
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();  // the window is rewritten by the next pass / tile
+        }
         }
         double r = DBL_MAX;  // :668-671 outside the root
         if constexpr (GRAD) {
@@ -1513,12 +1589,17 @@ __device__ __forceinline__ void queryTopBody(const TreeDev& t, const double* __r
                 // :862  unitPt = (pt - centre) * (2 << depth)
                 const double s = (double)(2 << topDepth);
                 const double ux = (p3[0] - c3[0]) * s, uy = (p3[1] - c3[1]) * s, uz = (p3[2] - c3[2]) * s;
+                // (the normalisation factors through a barrier the optimiser cannot see through: it hoists nl[0]^2 and nl[0]^3 out of the
+                // tile loop otherwise, into registers that the kernel's seven waves a SIMD do not have -- they went to scratch and came
+                // back once a tile; one multiply a tile is cheaper than one memory operation)
+                double nlT[3] = {t.nlTop[0], t.nlTop[1], t.nlTop[2]};
+                asm volatile("" : "+s"(nlT[0]));
                 if (hdr.y == 2u)
-                    r = evalLeafTop<2>(cv, ux, uy, uz, t.nlTop);
+                    r = evalLeafTop<2>(cv, ux, uy, uz, nlT);
                 else if (hdr.y == 1u)
-                    r = evalLeafTop<1>(cv, ux, uy, uz, t.nlTop);
+                    r = evalLeafTop<1>(cv, ux, uy, uz, nlT);
                 else
-                    r = evalLeafTop<0>(cv, ux, uy, uz, t.nlTop);
+                    r = evalLeafTop<0>(cv, ux, uy, uz, nlT);
             }
             if (valid) __builtin_nontemporal_store(r, &out[i]);
         }
@@ -1653,7 +1734,78 @@ __device__ __forceinline__ void queryGeneralBody(const TreeDev& t, const DeviceT
         const double u[3] = {(p3[0] - c3[0]) * sc, (p3[1] - c3[1]) * sc, (p3[2] - c3[2]) * sc};
         // what the fetching lanes need to know about this lane's leaf: block offset (a multiple of 16 doubles, so its
         // low four bits are free) and chunk count (0 = nothing to fetch)
-        sInfo[wave][lane] = rec.a | (coop ? leafChunks(degree) : 0u);
+        const uint32_t infoMine = rec.a | (coop ? leafChunks(degree) : 0u);
+        double cv[20];
+        // ORDERED INPUT (round 6; as in queryTopBody).  Grids, slices, rays and sorted point sets reach this kernel as RUNS of consecutive
+        // points in one leaf.  With at most 32 runs in the wave (random points: 64) the wave fetches one block per RUN in ONE pass -- step s
+        // the first lines of runs 8s .. 8s + 7, one more step the second lines of up to 32 degree-3 leaves, two lanes each -- and every
+        // lane reads back its run's block: one round trip to L2 instead of two on this kernel's chain of dependent round trips, and a
+        // quarter of the window's traffic.  The same bytes whichever way they come (test_query_ordered_point_sets_bitwise).
+        bool viaRuns = false;
+        if constexpr (LAB == 0) {
+            const uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp((int)infoMine, (int)infoMine, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            const bool opens = lane == 0 || before != infoMine;
+            const unsigned long long heads = __ballot(opens);
+            const int nRuns = __popcll(heads);  // wave-uniform
+            if (nRuns <= 32) {
+                viaRuns = true;
+                const uint32_t myRun = __builtin_amdgcn_mbcnt_hi((uint32_t)(heads >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)heads, 0u)) + (opens ? 1u : 0u) - 1u;
+                if (opens) sInfo[wave][myRun] = infoMine;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const int nSteps = (nRuns + 7) >> 3;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (k < nSteps) {
+                        const int run = 8 * k + (lane >> 3);
+                        const uint32_t inf = run < nRuns ? sInfo[wave][run] : 0u;
+                        const char* src = reinterpret_cast<const char*>(t.coeffs) + (size_t)(inf & ~15u) * 8u + (uint32_t)sub * 16u;
+                        if ((uint32_t)sub < (inf & 15u))
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                             (__attribute__((address_space(3))) void*)&sRows[wave][k][0], 16, 0, 0);
+                    }
+                }
+                if (__any(coop && degree == 3u)) {  // chunks 8..9 of the runs' degree-3 leaves: two lanes a run
+                    const int run = lane >> 1;
+                    const uint32_t inf = run < nRuns ? sInfo[wave][run] : 0u;
+                    const char* src = reinterpret_cast<const char*>(t.coeffs) + (size_t)(inf & ~15u) * 8u + (8u + (uint32_t)(lane & 1)) * 16u;
+                    if ((inf & 15u) > 8u)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                         (__attribute__((address_space(3))) void*)&sRows[wave][4][0], 16, 0, 0);
+                }
+                if (more) {  // the next tile's points behind the fetch, as below
+                    const size_t in = nextBase + threadIdx.x;
+                    const double* np = xyz + 3 * (in < n ? in : n - 1);
+                    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx2 %1, %2, off offset:16\n\ts_waitcnt vmcnt(2)"
+                                 : "=&v"(nxy), "=&v"(nz)
+                                 : "v"(np)
+                                 : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_wave_barrier();
+                {
+                    const double2* row = &sRows[wave][myRun >> 3][(myRun & 7u) * 8u];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const double2 v = row[c];
+                        cv[2 * c] = v.x;
+                        cv[2 * c + 1] = v.y;
+                    }
+                    const double2* tail = &sRows[wave][4][2u * myRun];
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const double2 v = tail[c];
+                        cv[16 + 2 * c] = v.x;
+                        cv[16 + 2 * c + 1] = v.y;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();  // the window is rewritten by the next tile
+            }
+        }
+        if (!viaRuns) {
+        sInfo[wave][lane] = infoMine;
         __builtin_amdgcn_wave_barrier();
         if constexpr (LAB == 2) {
             const uint32_t first = sInfo[wave][0];
@@ -1662,7 +1814,6 @@ __device__ __forceinline__ void queryGeneralBody(const TreeDev& t, const DeviceT
             __builtin_amdgcn_wave_barrier();
         }
         const bool second = LAB != 3 && __any(coop && degree == 3u);  // wave-uniform: somebody needs chunks 8..9
-        double cv[20];
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -1716,6 +1867,7 @@ __device__ __forceinline__ void queryGeneralBody(const TreeDev& t, const DeviceT
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();  // the window is rewritten by the next pass / tile
         }
+        }
         double r = DBL_MAX;  // :668-671
         double g[3] = {0.0, 0.0, 0.0};
         bool defer = false;
@@ -1725,8 +1877,10 @@ __device__ __forceinline__ void queryGeneralBody(const TreeDev& t, const DeviceT
             if constexpr (GRAD) {
                 if (degree > 3u)
                     defer = valid;
+                else if constexpr (LAB == 5)  // (lab: the gradient kernel with the value's arithmetic only -- what the six one-sided sums, the divisions and the square root cost)
+                    r = evalLeafValsMixed<3>(cv, u[0], u[1], u[2], depth, degree, sNl, sRec), g[0] = r, g[1] = u[1], g[2] = u[2];
                 else
-                    r = evalLeafGradValsMixed<3>(cv, u, depth, degree, sNl, sRec, g, t.leftAssoc);
+                    r = evalLeafGradValsMixed<3, 20, LAB == 6>(cv, u, depth, degree, sNl, sRec, g, t.leftAssoc);
             } else {
                 // one pass for the wave's mix of degrees (evalLeafValsMixed)
                 if (degree > 3u)
@@ -1795,13 +1949,13 @@ __global__ __launch_bounds__(1024) void query_general_lds_kernel(TreeDev t, cons
                                                                  uint32_t* __restrict__ deferIdx) {
     queryGeneralBody<4, DEFER, false, 16, true, LAB, DEEP>(t, T, xyz, n, out, nullptr, tilesPerWg, deferCount, deferIdx);
 }
-template <int TOPD, bool DEFER>
+template <int TOPD, bool DEFER, int LAB = 0>
 __global__ __launch_bounds__(256, 3) void query_general_grad_kernel(TreeDev t, const DeviceTables* __restrict__ T,
                                                                     const double* __restrict__ xyz, size_t n,
                                                                     double* __restrict__ out, double* __restrict__ grad,
                                                                     uint32_t tilesPerWg, uint32_t* __restrict__ deferCount,
                                                                     uint32_t* __restrict__ deferIdx) {
-    queryGeneralBody<TOPD, DEFER, true, 4, false>(t, T, xyz, n, out, grad, tilesPerWg, deferCount, deferIdx);
+    queryGeneralBody<TOPD, DEFER, true, 4, false, LAB>(t, T, xyz, n, out, grad, tilesPerWg, deferCount, deferIdx);
 }
 
 // Exclusive scan of the per-workgroup deferred counts (nWg <= 8192): offsets[b] = points deferred by workgroups
@@ -2950,85 +3104,75 @@ __global__ __launch_bounds__(256) void mesh_tripos_kernel(const float* __restric
     triPos[3 * t + 2] = make_float4(c.z, n.x, n.y, n.z);
 }
 
-// MeshDev::triPre: per leaf slot the data of the lower-bound test (triLowerBound2) and the triangle's index: the unit normal n,
-// a unit vector u along the longest edge, the centre g of the triangle's bounding rectangle in the (u, n x u) frame and the
-// rectangle's half-extents.  The bound is valid for ANY orthonormal n, u as long as every point x of the triangle has
-// |n . (x - g)| <= e, |u . (x - g)| <= hu and sqrt(|x - g|^2 - (n . (x - g))^2 - (u . (x - g))^2) <= hv -- all three are convex in x,
-// so the vertices decide, and all three are MEASURED here against the g that is stored, with the arithmetic of the test.  When e
-// is not negligible (slivers, whose cross product cancels) or the frame is not orthonormal to 1e-6, n and u are set to zero and hv
-// to the largest distance of a vertex from g, which turns the test into the ball's bound |p - g| - rho.  What is left of e
-// (<= 4e-7 of the mesh's scale) and of the frame's rounding is covered by the caller's slack (2e-6 of that scale: meshSlack).
+// MeshDev::triPre: per leaf slot the triangle's PRISM (triLowerBound2): vertex a, the unit normal n and the unit in-plane outward
+// normals of the three edges, mab = ab x n, mbc = bc x n, mca = ca x n (normalised), with obc = mbc . (b - a).  The bound is valid for ANY
+// unit n and any unit m perpendicular to it as long as every point x of the triangle has |n . (x - a)| <= e and m . (x - a) <= offset + e
+// -- all linear in x, so the vertices decide, and every one of these is MEASURED here with the arithmetic of the test.  A record whose
+// residuals exceed 3e-7 of the mesh's scale (slivers, whose cross product cancels) or whose frame is not orthonormal to 1e-6 is zeroed
+// ("no bound": the test passes and the closest-point routine decides).  What is left of the residuals -- across the plane and within
+// it together at most sqrt 2 x 3e-7 of the scale -- is covered by the caller's slack (2e-6 of that scale: meshSlack).
+// slotTriOut (device builds): which triangle the slot holds, kept with the field (MeshDev::slotTri).
 __global__ __launch_bounds__(256) void mesh_tripre_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ tris,
-                                                          const uint32_t* __restrict__ slotTri, uint64_t nTris, float4* __restrict__ triPre) {
+                                                          const uint32_t* __restrict__ slotTri, uint64_t nTris, float4* __restrict__ triPre,
+                                                          uint32_t* __restrict__ slotTriOut) {
     const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (s >= nTris) return;
     const uint32_t t = slotTri ? slotTri[s] : (uint32_t)s;
+    if (slotTriOut) slotTriOut[s] = t;
     const uint32_t ia = tris[3 * (size_t)t], ib = tris[3 * (size_t)t + 1], ic = tris[3 * (size_t)t + 2];
     const V3 a = {verts[3 * (size_t)ia], verts[3 * (size_t)ia + 1], verts[3 * (size_t)ia + 2]};
     const V3 b = {verts[3 * (size_t)ib], verts[3 * (size_t)ib + 1], verts[3 * (size_t)ib + 2]};
     const V3 c = {verts[3 * (size_t)ic], verts[3 * (size_t)ic + 1], verts[3 * (size_t)ic + 2]};
     const V3 ab = b - a, ac = c - a, bc = c - b;
-    const float lab = sqnorm(ab), lac = sqnorm(ac), lbc = sqnorm(bc);
     const V3 n = cross(ab, ac);
     const float inf = __builtin_inff();
-    // the frame: n, u along the longest edge, v = n x u; the rectangle's centre from the vertices' (u, v) ranges about a
-    const V3 le = lab >= lac && lab >= lbc ? ab : (lac >= lbc ? ac : bc);
-    const float len = sqrtf(sqnorm(n)), ll = sqrtf(sqnorm(le));
-    V3 nh = {0.0f, 0.0f, 0.0f}, uh = {0.0f, 0.0f, 0.0f};
-    const float third = 1.0f / 3.0f;
-    V3 g = third * (a + (b + c));
-    bool framed = len > 0.0f && len < inf && ll > 0.0f && ll < inf;
+    const float len = sqrtf(sqnorm(n));
+    V3 nh = {0.0f, 0.0f, 0.0f}, m1 = nh, m2 = nh, m3 = nh;
+    float obc = 0.0f;
+    bool framed = len > 0.0f && len < inf;
     if (framed) {
         nh = (1.0f / len) * n;
-        uh = (1.0f / ll) * le;
-        const V3 vh = cross(nh, uh);
-        const float ub = dot(uh, ab), uc = dot(uh, ac), vb = dot(vh, ab), vc = dot(vh, ac);  // (vertex a sits at (0, 0))
-        const float um = 0.5f * (fminf(0.0f, fminf(ub, uc)) + fmaxf(0.0f, fmaxf(ub, uc)));
-        const float vm = 0.5f * (fminf(0.0f, fminf(vb, vc)) + fmaxf(0.0f, fmaxf(vb, vc)));
-        g = a + (um * uh + vm * vh);
-        framed = fabsf(sqnorm(nh) - 1.0f) <= 1e-6f && fabsf(sqnorm(uh) - 1.0f) <= 1e-6f && fabsf(dot(nh, uh)) <= 1e-6f;
+        // outward in the triangle's plane: ab x n points away from c (ab x (ab x ac) = ab (ab . ac) - ac |ab|^2)
+        const V3 x1 = cross(ab, nh), x2 = cross(bc, nh), x3 = cross(V3{0.0f, 0.0f, 0.0f} - ac, nh);
+        const float l1 = sqrtf(sqnorm(x1)), l2 = sqrtf(sqnorm(x2)), l3 = sqrtf(sqnorm(x3));
+        framed = l1 > 0.0f && l1 < inf && l2 > 0.0f && l2 < inf && l3 > 0.0f && l3 < inf;
+        if (framed) {
+            m1 = (1.0f / l1) * x1, m2 = (1.0f / l2) * x2, m3 = (1.0f / l3) * x3;
+            // the scale the caller's slack is proportional to is at least this (the mesh's extent or its largest coordinate)
+            const float rho = sqrtf(fmaxf(sqnorm(ab), sqnorm(ac)));
+            const float scale = fmaxf(rho, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fabsf(a.z)));
+            const float tol = 3e-7f * scale;
+            // the vertices against every plane, with the test's own arithmetic (vertex a sits at dx = 0)
+            const float sb = dotF(nh, ab), sc = dotF(nh, ac);
+            const float e1b = dotF(m1, ab), e1c = dotF(m1, ac);
+            const float e2b = dotF(m2, ab), e2c = dotF(m2, ac);
+            const float e3b = dotF(m3, ab), e3c = dotF(m3, ac);
+            obc = fmaxf(e2b, e2c);
+            const bool unit = fabsf(sqnorm(nh) - 1.0f) <= 1e-6f && fabsf(sqnorm(m1) - 1.0f) <= 1e-6f && fabsf(sqnorm(m2) - 1.0f) <= 1e-6f &&
+                              fabsf(sqnorm(m3) - 1.0f) <= 1e-6f && fabsf(dot(nh, m1)) <= 1e-6f && fabsf(dot(nh, m2)) <= 1e-6f && fabsf(dot(nh, m3)) <= 1e-6f;
+            framed = unit && fabsf(sb) <= tol && fabsf(sc) <= tol && e1b <= tol && e1c <= tol && e3b <= tol && e3c <= tol && obc >= -tol && obc < inf &&
+                     rho < inf;
+        }
     }
-    const V3 da = a - g, db = b - g, dc = c - g;
-    const float ra = sqnorm(da), rb = sqnorm(db), rcq = sqnorm(dc);
-    const float rho = sqrtf(fmaxf(ra, fmaxf(rb, rcq))) * 1.00001f + 1e-30f;
-    // the scale the caller's slack is proportional to is at least this (the mesh's extent or its largest coordinate)
-    const float scale = fmaxf(rho, fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fabsf(g.z)));
-    float hu = 0.0f, hv = rho;
-    if (framed) {
-        const float sa = dot(nh, da), sb = dot(nh, db), sc = dot(nh, dc);
-        const float ua = dot(uh, da), ub = dot(uh, db), uc = dot(uh, dc);
-        const float e = fmaxf(fabsf(sa), fmaxf(fabsf(sb), fabsf(sc)));
-        const float wa = sqrtf(fmaxf(ra - sa * sa - ua * ua, 0.0f)), wb = sqrtf(fmaxf(rb - sb * sb - ub * ub, 0.0f)),
-                    wc = sqrtf(fmaxf(rcq - sc * sc - uc * uc, 0.0f));
-        // The rectangle holds the TRIANGLE (measured above, with allowances for its own rounding).  What the closest-point routine
-        // returns for the triangle lies within a quarter of the traversal's slack of it: closestSimplex does not take a face-case
-        // point farther outside than that (until round 4 the rectangle was widened by a "play" of 1e-6 longest edge / sin(smallest
-        // angle) instead, an estimate of how far the reference's barycentric quotients can throw q: it did not hold on needles).
-        hu = fmaxf(fabsf(ua), fmaxf(fabsf(ub), fabsf(uc))) * 1.00001f + 4e-7f * scale;
-        // (hv also takes 1e-3 hu: the test forms the in-plane distance across u as sqrt(|d|^2 - s^2 - a^2), whose cancellation leaves up to
-        // sqrt(2 ulp) |d| = 3.5e-4 |d| where the true value is nearly zero -- beside a needle that is more than its width; past ~3 hu from
-        // g the excess is below 1e-6 of the bound itself, which rejectBound's factor covers)
-        hv = fmaxf(wa, fmaxf(wb, wc)) * 1.00001f + 4e-7f * scale + 1e-3f * hu;
-        framed = e <= 4e-7f * scale && hu < inf && hv < inf;
+    if (!framed) {  // "no bound": s = 0 and e = 0 whatever the point (non-finite input: NaN, which passes as well)
+        nh = V3{0.0f, 0.0f, 0.0f}, m1 = nh, m2 = nh, m3 = nh;
+        obc = 0.0f;
     }
-    if (!framed || !(rho < inf)) {  // (non-finite input: the bound degenerates to "always passes" via NaN)
-        nh = V3{0.0f, 0.0f, 0.0f}, uh = V3{0.0f, 0.0f, 0.0f};
-        hu = 0.0f, hv = rho;
-    }
-    triPre[3 * s] = make_float4(g.x, g.y, g.z, hu);
-    triPre[3 * s + 1] = make_float4(nh.x, nh.y, nh.z, hv);
-    triPre[3 * s + 2] = make_float4(uh.x, uh.y, uh.z, __uint_as_float(t));
+    triPre[4 * s] = make_float4(a.x, a.y, a.z, nh.x);
+    triPre[4 * s + 1] = make_float4(nh.y, nh.z, m1.x, m1.y);
+    triPre[4 * s + 2] = make_float4(m1.z, m2.x, m2.y, m2.z);
+    triPre[4 * s + 3] = make_float4(m3.x, m3.y, m3.z, obc);
 }
 
 hipError_t launchMeshTriPos(hipStream_t stream, const float* dVerts, const uint32_t* dTris, uint64_t nTris, float* dTriPos,
-                            const uint32_t* dSlotTri, float* dTriPre) {
+                            const uint32_t* dSlotTri, float* dTriPre, uint32_t* dSlotTriOut) {
     if (nTris == 0) return hipSuccess;
     if (dTriPos)
         hipLaunchKernelGGL(mesh_tripos_kernel, dim3((unsigned)((nTris + 255) / 256)), dim3(256), 0, stream, dVerts, dTris, nTris,
                            reinterpret_cast<float4*>(dTriPos));
     if (dTriPre)
         hipLaunchKernelGGL(mesh_tripre_kernel, dim3((unsigned)((nTris + 255) / 256)), dim3(256), 0, stream, dVerts, dTris, dSlotTri, nTris,
-                           reinterpret_cast<float4*>(dTriPre));
+                           reinterpret_cast<float4*>(dTriPre), dSlotTriOut);
     return hipGetLastError();
 }
 
@@ -3253,6 +3397,18 @@ hipError_t launchQuery(hipStream_t stream, const TreeDev& t, const DeviceTables*
         else
             hipLaunchKernelGGL((query_general_lds_kernel<false>), ggrid, dim3(1024), lds, stream, t, dTables, dXyz, n, dOut, tilesPerWg, dDeferCount, dDeferIdx);
     } else {
+#ifdef HPSDF_QUERY_LAB_BUILD  // (lib/libhpsdf_lab.so only: the gradient kernel with a link taken out -- values NOT the tree's)
+        {
+            const char* labEnv = std::getenv("HPSDF_QUERY_LAB");
+            const int glab = labEnv && dGrad && dDeferCount && dDeferIdx && t.topDepth == 4 ? std::atoi(labEnv) : 0;
+#define HPSDF_GRAD_LAB(L) case L: hipLaunchKernelGGL((query_general_grad_kernel<4, true, L>), ggrid, block, lds, stream, t, dTables, dXyz, n, dOut, dGrad, tilesPerWg, dDeferCount, dDeferIdx); return hipGetLastError();
+            switch (glab) {
+                HPSDF_GRAD_LAB(1) HPSDF_GRAD_LAB(2) HPSDF_GRAD_LAB(3) HPSDF_GRAD_LAB(4) HPSDF_GRAD_LAB(5) HPSDF_GRAD_LAB(6)
+                default: break;
+            }
+#undef HPSDF_GRAD_LAB
+        }
+#endif
 #define HPSDF_QUERY_GENERAL(TOPD, DF)                                                                               \
     do {                                                                                                            \
         if (dGrad)                                                                                                  \

@@ -207,9 +207,12 @@ __global__ __launch_bounds__(256) void mb_fit_kernel(const uint32_t* __restrict_
 // is a few ulps of the mesh's extent and belongs to the traversal's slack (2e-6 of that extent, meshSlack).  The bound is valid for ANY n of unit length: how n was chosen only
 // decides how thin the slab is (a patch that bends back on itself gets a thick one and is pruned by its ball and box alone).
 // Children of more than kSlabMaxTris triangles get the ball around their box and e = -1, "no slab": up there the boxes
-// decide, a wave would loop for too long, and a surface is rarely flat at that scale.
+// decide and a wave would loop for too long.  (1024 until round 6, on the argument that a surface is rarely flat at that scale: it
+// need not be flat, only flatter than its box is thick, and the walk's dense visits are mostly ABOVE that size -- 131 072: Create on
+// the 2.1 M-triangle torus at 1e-6 32.7 -> 31.9 ms, on the 1.3 M-triangle icosphere 12.3 -> 11.4, preparation unchanged; a million: the same,
+// and the largest nodes' waves double the preparation: profiles/r06_mesh_steps.txt)
 #ifndef HPSDF_SLAB_MAX_TRIS
-#define HPSDF_SLAB_MAX_TRIS 1024
+#define HPSDF_SLAB_MAX_TRIS 131072
 #endif
 constexpr int kSlabMaxTris = HPSDF_SLAB_MAX_TRIS;
 __device__ __forceinline__ float mbWaveSum(float v) {
@@ -433,6 +436,7 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
         const size_t oVerts = carve(fb, 3 * nVerts * sizeof(float)), oTris = carve(fb, nCorners * sizeof(uint32_t)),
                      oTriPos = carve(fb, (size_t)nTris * kTriRecordFloats * sizeof(float)),
                      oTriPre = carve(fb, (size_t)nTris * kTriPreFloats * sizeof(float)), oHe = carve(fb, nCorners * sizeof(uint32_t)),
+                     oSlotTri = carve(fb, (size_t)nTris * sizeof(uint32_t)),
                      oBvh = carve(fb, (size_t)(n - 1) * sizeof(BvhNode)), oSlab = carve(fb, (size_t)(n - 1) * sizeof(NodeSlab));
         size_t tb = 0;
         const size_t oT64 = carve(tb, nCorners * sizeof(uint64_t)), oBox = carve(tb, 6 * nTris * sizeof(float)),
@@ -465,6 +469,7 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
             f->dBlock = fieldBlock;
             f->dVerts = (float*)(fieldBlock + oVerts), f->dTris = (uint32_t*)(fieldBlock + oTris), f->dTriPos = (float*)(fieldBlock + oTriPos);
             f->dTriPre = (float*)(fieldBlock + oTriPre);
+            f->dSlotTri = (uint32_t*)(fieldBlock + oSlotTri);
             f->dHalfEdges = (uint32_t*)(fieldBlock + oHe), f->dBvh = (BvhNode*)(fieldBlock + oBvh);
             f->dSlabs = (NodeSlab*)(fieldBlock + oSlab);
             dRanges = (int32_t*)(tempBlock + oRan);
@@ -482,7 +487,7 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
         if (fieldBlock) (void)hipFree(fieldBlock);
         fieldBlock = nullptr;
         f->dBlock = nullptr;
-        f->dVerts = nullptr, f->dTris = nullptr, f->dTriPos = nullptr, f->dTriPre = nullptr, f->dHalfEdges = nullptr, f->dBvh = nullptr;
+        f->dVerts = nullptr, f->dTris = nullptr, f->dTriPos = nullptr, f->dTriPre = nullptr, f->dSlotTri = nullptr, f->dHalfEdges = nullptr, f->dBvh = nullptr;
         f->dSlabs = nullptr;
     };
     const double t1 = now();
@@ -542,7 +547,7 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
     hipLaunchKernelGGL(mb_boxes_kernel, dim3(gt), dim3(256), 0, s, f->dTriPos, (uint32_t)nTris, dTriBox, dFlags);
     hipLaunchKernelGGL(mb_morton_kernel, dim3(gt), dim3(256), 0, s, dTriBox, (uint32_t)nTris, dFlags, dKeys, dIds);
     if (e == hipSuccess) e = rocprim::radix_sort_pairs(dSortTmp, sortTmpBytes, dKeys, dKeysOut, dIds, dIdsOut, (size_t)nTris, 0, 63, s);
-    if (e == hipSuccess) e = launchMeshTriPos(s, f->dVerts, f->dTris, nTris, nullptr, dIdsOut, f->dTriPre);  // slot order = sorted order
+    if (e == hipSuccess) e = launchMeshTriPos(s, f->dVerts, f->dTris, nTris, nullptr, dIdsOut, f->dTriPre, f->dSlotTri);  // slot order = sorted order
     hipLaunchKernelGGL(mb_hierarchy_kernel, dim3(gt), dim3(256), 0, s, dKeysOut, n, leafTris, f->dBvh, dParent, dRanges);
     hipLaunchKernelGGL(mb_fit_kernel, dim3(gt), dim3(256), 0, s, dIdsOut, dTriBox, n, f->dBvh, dParent, dArrived);
     if (!noSlabs)

@@ -162,6 +162,7 @@ struct hpsdf_field {
     uint32_t* dTris = nullptr;
     float* dTriPos = nullptr;
     float* dTriPre = nullptr;
+    uint32_t* dSlotTri = nullptr;  // device-built meshes (part of dBlock): the triangle of every leaf slot; nullptr: slot = triangle
     uint32_t* dHalfEdges = nullptr;
     hpsdf::BvhNode* dBvh = nullptr;
     hpsdf::NodeSlab* dSlabs = nullptr;  // device-built meshes only (part of dBlock)
@@ -173,7 +174,7 @@ struct hpsdf_field {
     // SDF lambda costs decides whether code written against the reference is usable as it is
     struct HostMirror {
         std::vector<float> verts, triPos, triPre;
-        std::vector<uint32_t> tris, halfEdges;
+        std::vector<uint32_t> tris, halfEdges, slotTri;
         std::vector<hpsdf::BvhNode> bvh;
         hpsdf::MeshDev dev{};
     };
@@ -216,9 +217,12 @@ constexpr const char* kInjectedFailureMsg = "injected failure";  // (unreachable
 #endif
 int makeFieldDev(const hpsdf_ctx* ctx, const hpsdf_field* f, const double* dSamples, FieldDev* out);
 // hpsdf_ctx_set_build_limits, checked by both schedulers when a round opens.  nodes: the tree's; bytes: the device memory this rank's
-// build state needs for the round about to open; held: what its buffers hold now (counted as available when the default limit is
+// build state needs for the round about to open -- node arrays, coefficient arena, a mesh build's sample buffer; NOT the hand-over buffer
+// of split fits (bounded by 2^31 samples whatever the tree's size: it is not what runs away);
+// held: what the build's buffers hold now (counted as available when the default limit is
 // measured); *measured: the build's cache of that measurement (0 = not taken yet; one hipMemGetInfo per Create, and only once a build
 // needs more than 256 MiB).  HPSDF_OK, or HPSDF_ERR_BUILD_LIMIT with the message set.
+uint64_t buildByteLimit(const hpsdf_ctx* ctx, uint64_t bytes, uint64_t held, uint64_t* measured);  // the bound on bytes in effect (UINT64_MAX: none)
 int checkBuildLimits(const hpsdf_ctx* ctx, uint64_t nodes, uint64_t bytes, uint64_t held, uint64_t* measured, uint64_t rounds, double total, double target);
 // the two semantic switches as a context sees them: its own setting, or the process-wide one when it has none (ctx may be null)
 int meshFaceRuleReference(const hpsdf_ctx* ctx);  // hpsdf_[ctx_]set_mesh_face_rule(): 1 = the reference's face-case point whatever its weights

@@ -170,8 +170,11 @@ HPSDF_API int hpsdf_ctx_get_reduction_order(const hpsdf_ctx* ctx, int* left_asso
  *   max_nodes: the tree's node count (identical on every rank, so every rank stops in the same round);
  *   max_bytes: the device memory this rank's build state needs for the round about to open (node arrays, coefficient arena, sample
  *              buffer -- capacities grow by doubling, so the allocation can reach twice this).
- * 0 = the default: no bound on nodes; bytes = a quarter of the device memory that is free when the build first needs more than
- * 256 MiB (measured then, once per Create; nothing is measured for builds that stay below, i.e. for every BASELINE config).
+ * 0 = the default: no bound on nodes; bytes = 1/256 of the device memory that is free when the build first needs more than
+ * 256 MiB, at least 1 GiB (measured then, once per Create; nothing is measured for builds that stay below, i.e. for every BASELINE
+ * config; 1.1 GiB on an idle MI355X -- a tree of several hundred thousand nodes, which the runaway builds on file reach within a second or two:
+ * profiles/r06_default_config.txt).  The hand-over buffer of split fits (HPSDF_FIT_SPLIT) does not count: it is bounded by 2^31 samples
+ * (16 GiB) whatever the tree's size.
  * UINT64_MAX = no limit.  A build that crosses a limit returns HPSDF_ERR_BUILD_LIMIT; hpsdf_last_error() names rounds, nodes,
  * bytes, both limits, and the total error against the threshold.  No block is returned.  On several ranks a rank that stops on its
  * bytes alone takes the others out through the FAILURES protocol of hpsdf_create_distributed. */

@@ -907,6 +907,43 @@ def test_query_refined_trees_many_points_bitwise(H, O, ctx, golden, case):
     assert np.array_equal(bits(gv), bits(wv)) and np.array_equal(bits(gg), bits(wg))
 
 
+@pytest.mark.parametrize("case,root", [("C2_union3_1e-5", None), ("D1_sphere075_customroot_1e-6", "custom")])
+def test_query_ordered_point_sets_bitwise(H, O, ctx, golden, case, root):
+    """query_kernel's paths for ORDERED input (round 6): a wave whose 64 points lie in one cell takes its row through the scalar cache; a
+    wave with 2..32 runs of equal cells fetches one row a run; everything else goes the way random points go.  All of them return
+    the tree's values bit for bit: whole waves in one cell (cell-sorted), z-fastest grids (a handful of runs a wave), runs of exactly
+    2 (32 runs: the run path's four steps) and of 1-2 (33+ runs: the other path), runs that straddle tiles, points outside the root
+    and NaNs inside runs, a ragged tail; Query and QueryWithGradient (the same body) alike."""
+    g = golden["blocks"][case]
+    ot = O.Tree.create(O.default_config(g["target"], g["root_min"], g["root_max"]), oracle_field(O, g["field"]), g["K"])
+    tree = H.DeviceTree(ctx, ot.to_block())
+    lo, hi = np.array(g["root_min"], np.float64), np.array(g["root_max"], np.float64)
+    rng = np.random.default_rng(21)
+    rnd = lo + (O.splitmix64_points(300_000, seed=9) + 0.5) * (hi - lo)
+    cell = np.clip(np.floor((rnd - lo) / (hi - lo) * 16.0), 0, 15).astype(np.int64)
+    key = cell[:, 0] + 16 * (cell[:, 1] + 16 * cell[:, 2])
+    srt = rnd[np.argsort(key, kind="stable")]                                   # ~73 points a cell: most waves lie in one cell
+    m = 97
+    ax = [lo[a] + (np.arange(m) + 0.5) / m * (hi[a] - lo[a]) for a in range(3)]
+    grid = np.stack(np.meshgrid(ax[0], ax[1], ax[2], indexing="ij"), -1).reshape(-1, 3)   # z fastest: ~6 points a cell and run
+    pairs = np.repeat(rnd[:100_000], 2, axis=0)                                 # runs of exactly 2: 32 runs a wave
+    mixed = np.repeat(rnd[100_000:160_000], rng.integers(1, 3, 60_000), axis=0)  # runs of 1 or 2: ~43 runs a wave
+    long_runs = np.repeat(rnd[:3000], rng.integers(1, 200, 3000), axis=0)       # runs that straddle waves and tiles
+    sets = {"cell-sorted": srt, "grid": grid, "pairs": pairs, "mixed": mixed, "long runs": long_runs, "random": rnd}
+    for name, pts in sets.items():
+        pts = pts.copy()
+        pts[5::997] = lo - 0.25 * (hi - lo)          # outside the root, inside runs
+        pts[11::4999, 1] = np.nan
+        pts = pts[:len(pts) - 37]                    # a ragged last tile
+        got, want = tree.query(pts), ot.query(pts)
+        assert np.array_equal(bits(got), bits(want)), name
+        init = np.full((len(pts), 3), 7.0)
+        gv, gg = tree.query_with_gradient(pts, init)
+        wv, wg = ot.query_with_gradient(pts, init)
+        assert np.array_equal(bits(gv), bits(wv)) and np.array_equal(bits(gg), bits(wg)), name
+    assert (tree.info()["n_nodes"] == 4681) == (root is None)  # (C2: every leaf inline, query_kernel; D1: a refined tree, the any-tree kernel)
+
+
 def test_query_down_to_max_depth_bitwise(H, O, ctx):
     """TREE_MAX_DEPTH = 10 (Consts.h:8): a chain of splits towards the (+,+,+) corner, leaves of degree 0-5 at every
     depth 1..10 -- the walk below the (here 1-level) top table, cooperative and deferred leaves side by side."""

@@ -78,6 +78,32 @@ with torch.cuda.stream(stream):
     torch.cuda.synchronize()
     gus = e0.elapsed_time(e1) / 10 * 1e3
     print("  %-74s %7.1f us  (%.3f of HBM peak at 56 B a point)" % ("QueryWithGradient, as it is", gus, 56.0 * n / (gus * 1e-6) / 8e12))
+
+    def timed_grad(pp):
+        c2 = lambda: H.check(H.lib().hpsdf_query_gradient_device(ctx.handle, tree.handle, C.c_void_p(pp.data_ptr()), n, C.c_void_p(gout.data_ptr()), C.c_void_p(grad.data_ptr())))
+        torch.cuda.synchronize()
+        for _ in range(2):
+            c2()
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record(stream)
+        for _ in range(10):
+            c2()
+        a1.record(stream)
+        torch.cuda.synchronize()
+        return a0.elapsed_time(a1) / 10 * 1e3
+
+    # the gradient kernel (query_general_grad_kernel, 4 waves a workgroup, 3 a SIMD) link by link; in the lab runs the second pass over the
+    # deferred points (degree 4: ~20 us of the figure above) is not launched at all
+    gnames = {5: "the value's arithmetic only (no one-sided sums, no divisions, no square root)", 6: "the six IEEE divisions and the square root left out",
+              1: "no polynomial at all: the fetched rows are touched, not evaluated", 2: "every lane fetches its wave's first leaf: no gather traffic",
+              3: "no second line for degree-3 leaves", 4: "no walk below the top table"}
+    for lab in (5, 6, 1, 2, 3, 4):
+        os.environ["HPSDF_QUERY_LAB"] = str(lab)
+        us = timed_grad(rnd)
+        print("  %-74s %7.1f us  (%+5.1f %%)" % ("gradient: " + gnames[lab], us, (us - gus) / gus * 100), flush=True)
+    del os.environ["HPSDF_QUERY_LAB"]
+    us = timed_grad(srt)
+    print("  %-74s %7.1f us  (%+5.1f %%)" % ("gradient: the points in the leaves' order", us, (us - gus) / gus * 100))
     hb, _ = H.create_block(ctx, H.make_config(1e-5), H.Field.union3(), 1024)
     ht = H.DeviceTree(ctx, hb)
     us_top, _ = timed(ht, rnd)
