@@ -59,7 +59,8 @@ def counter_record(name, keys):
     try:
         rec = json.load(open(path))
         files = {"mesh_pmc.json": ["kernels.hip", "device_types.hpp", "acosf_host_libm.hpp"],
-                 "fit_pmc.json": ["kernels.hip", "fit_low.hip", "field_eval.hpp", "device_types.hpp"]}[name]
+                 "fit_pmc.json": ["kernels.hip", "fit_low.hip", "field_eval.hpp", "device_types.hpp"],
+                 "fit_mfma_pmc.json": ["fit_mfma.hip", "field_eval.hpp", "device_types.hpp"]}[name]
         h = hashlib.sha256()
         for f in files:
             h.update(open(os.path.join(ROOT, "hp-adaptive-signed-distance-field-octree_amd", "csrc", f), "rb").read())
@@ -491,6 +492,15 @@ def main():
             # counted in FMAs: the issue fraction per degree, from profiles/fit_pmc.json (tools/fit_pmc_all.sh; null when stale)
             fit["roofline"] = {"bound": "valu-issue", "peak_fp64_tflops": FP64_PEAK_TFLOPS}
             fit["roofline"].update(counter_record("fit_pmc.json", ("degrees",)))
+            # the matrix-core fit's utilisation from counters (north_star: "MFMA utilisation for the fit against gfx950 peak"):
+            # SQ_VALU_MFMA_BUSY_CYCLES against the kernel's active cycles, profiles/fit_mfma_pmc.json (tools/fit_mfma_pmc.sh; null when stale)
+            mf = counter_record("fit_mfma_pmc.json", ("degrees",))
+            for p in (4, 6, 8):
+                d = (mf.get("degrees") or {}).get("p%d" % p) or {}
+                if "fast_fit" in fit.get("p%d" % p, {}):
+                    fit["p%d" % p]["fast_fit"]["mfma_busy"] = (d.get("union3") or {}).get("mfma_busy")
+                    fit["p%d" % p]["fast_fit"]["contraction_only_mfma_busy"] = (d.get("plane") or {}).get("mfma_busy")
+            fit["fast_fit_counters"] = mf["measured_from"]
 
     ms_per_step = wall * 1e3 / args.steps
     value = world * n * args.steps / wall / 1e6  # Mpts/s, whole job

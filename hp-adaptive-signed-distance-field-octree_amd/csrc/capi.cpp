@@ -129,7 +129,6 @@ int makeFieldDev(const hpsdf_ctx* ctx, const hpsdf_field* f, const double* dSamp
             out->mesh.halfEdges = f->dHalfEdges;
             out->mesh.triPos = reinterpret_cast<const float4*>(f->dTriPos);
             out->mesh.triPre = reinterpret_cast<const float4*>(f->dTriPre);
-            out->mesh.slotTri = f->dSlotTri;
             out->mesh.bvh = f->dBvh;
             out->mesh.slabs = f->dSlabs;
             out->mesh.leafLog2 = f->leafLog2;
@@ -345,6 +344,10 @@ int hpsdf_ctx_create(int device, void* stream, hpsdf_ctx** out) {
 int hpsdf_ctx_destroy(hpsdf_ctx* c) {
     if (!c) return HPSDF_OK;
     (void)hipSetDevice(c->device);
+    // (nothing of this context's may still be running when its buffers go: a build leaves its tables' reset on the stream for the next
+    // one, and pinned host memory the device writes -- the header's mirror -- is freed below)
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipGetLastError();
     if (c->dTables) (void)hipFree(c->dTables);
     if (c->hostDev) (void)hipFree(c->hostDev);
     if (c->hostPin) (void)hipHostFree(c->hostPin);
@@ -665,7 +668,7 @@ static bool smallQueriesOnHost() {
 // behind a device-wide synchronisation (the field's arrays may still be being written on some stream), under the field's lock, and kept
 // until hpsdf_field_release_host_copies() or the field's destruction.
 static size_t meshMirrorBytes(const hpsdf_field* f) {
-    return (size_t)f->nVerts * 12 + (size_t)f->nTris * (12 + 12 + 4 + 4 * (size_t)(kTriRecordFloats + kTriPreFloats)) + (size_t)f->nBvhNodes * sizeof(BvhNode);
+    return (size_t)f->nVerts * 12 + (size_t)f->nTris * (12 + 12 + 4 * (size_t)(kTriRecordFloats + kTriPreFloats)) + (size_t)f->nBvhNodes * sizeof(BvhNode);
 }
 static size_t hostMeshMirrorLimit() { static const size_t v = hostLimit("HPSDF_HOST_MESH_MIRROR_MB", 512) << 20; return v; }
 // The host copies of a mesh field's arrays (made once, by the first call of a few points)
@@ -686,16 +689,11 @@ static int meshHostMirror(const hpsdf_field* f, std::shared_ptr<hpsdf_field::Hos
         HPSDF_HIP(hipMemcpy(m->halfEdges.data(), f->dHalfEdges, m->halfEdges.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         HPSDF_HIP(hipMemcpy(m->triPos.data(), f->dTriPos, m->triPos.size() * sizeof(float), hipMemcpyDeviceToHost));
         HPSDF_HIP(hipMemcpy(m->triPre.data(), f->dTriPre, m->triPre.size() * sizeof(float), hipMemcpyDeviceToHost));
-        if (f->dSlotTri) {
-            m->slotTri.resize(f->nTris);
-            HPSDF_HIP(hipMemcpy(m->slotTri.data(), f->dSlotTri, m->slotTri.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        }
         if (f->nBvhNodes) HPSDF_HIP(hipMemcpy(m->bvh.data(), f->dBvh, (size_t)f->nBvhNodes * sizeof(BvhNode), hipMemcpyDeviceToHost));
         MeshDev& d = m->dev;
         d.verts = m->verts.data(), d.tris = m->tris.data(), d.halfEdges = m->halfEdges.data();
         d.triPos = reinterpret_cast<const float4*>(m->triPos.data());
         d.triPre = reinterpret_cast<const float4*>(m->triPre.data());
-        d.slotTri = f->dSlotTri ? m->slotTri.data() : nullptr;
         d.bvh = m->bvh.data(), d.slabs = nullptr;  // (the per-point traversal uses boxes and triangle records only)
         d.nTris = f->nTris, d.nNodes = f->nBvhNodes, d.leafLog2 = f->leafLog2, d.poolCap = 0, d.stats = nullptr;
         f->hostMirror = m;

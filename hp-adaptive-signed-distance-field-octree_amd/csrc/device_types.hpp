@@ -86,10 +86,9 @@ struct MeshDev {
     const uint32_t* tris;      // 3 vertex ids per triangle
     const float4* triPos;      // 3 x float4 per triangle: its 9 vertex coordinates and its normal, gathered: a closest-point test is ONE
                                // fetch instead of a chain of index -> vertex fetches (same values, same arithmetic)
-    const float4* triPre;      // 4 x float4 per leaf SLOT (one 64-byte line): vertex a, the unit normal, and the three unit in-plane outward
-                               // normals of the edges ab, bc, ca (with bc's offset from a): the triangle's PRISM -- a lower bound of the
-                               // distance in ~21 instructions that is exact wherever the closest point lies in the face or on an edge
-    const uint32_t* slotTri;   // which triangle a leaf slot holds (nullptr: slot s = triangle s, the host build's one-triangle leaves)
+    const float4* triPre;      // 3 x float4 per leaf SLOT: the centre g and the half-extents of the triangle's bounding rectangle in its
+                               // own plane, the unit normal, a unit vector along the longest edge, and the triangle's index (bits
+                               // in .w of the third): a lower bound of the distance in ~24 instructions, and the slot -> triangle map
     const uint32_t* halfEdges; // twin half-edge per half-edge (Mesh.h:74)
     const BvhNode* bvh;        // node 0 is the root
     const NodeSlab* slabs;     // per BVH node, for each child: its triangles lie within e of the plane through g across the unit

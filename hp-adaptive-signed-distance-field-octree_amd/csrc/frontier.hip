@@ -2904,9 +2904,21 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
         const size_t stride = ws->d.errStride;
         const unsigned long long ones = ~0ull;
         if (partPending) (void)gather(gatherUser, ws->arena + partOff, arenaPartBytes, (void*)s);  // (replica: the others exchange the round's rows first)
-        if (hipMemcpyAsync(ws->d.errs + (size_t)rank * stride + (stride - 1), &ones, sizeof ones, hipMemcpyHostToDevice, s) == hipSuccess)
+        // (this rank's errors of the round were never written: zeros instead of whatever the buffer held -- the others' round kernels
+        // read every job's errors before their leader looks at the status)
+        if (hipMemsetAsync(ws->d.errs + (size_t)rank * stride, 0, stride * sizeof(double), s) == hipSuccess &&
+            hipMemcpyAsync(ws->d.errs + (size_t)rank * stride + (stride - 1), &ones, sizeof ones, hipMemcpyHostToDevice, s) == hipSuccess)
             (void)gather(gatherUser, ws->d.errs, stride * sizeof(double), (void*)s);
         (void)hipStreamSynchronize(s);
+        return fail(rcBody, own);
+    }
+    if (rcBody) {
+        // A build that fails leaves nothing in flight: the round kernel's leader publishes the round number -- which is what the host
+        // watches -- BEFORE it prepares the next round, so a failure noticed right there (another rank's status, an overflow) would
+        // otherwise return with that kernel still writing the header's mirror and the lists, into buffers the caller may free next.
+        const std::string own = hpsdf_last_error();
+        (void)hipStreamSynchronize(s);
+        (void)hipGetLastError();
         return fail(rcBody, own);
     }
     return rcBody;

@@ -202,30 +202,26 @@ HPSDF_HD V3 pseudoNormal(const MeshDev& m, uint32_t t, int code) {
 // A leaf reference (BvhNode::c0 / c1 < 0): its first slot and how many, and the triangle a slot holds.
 HPSDF_HD __forceinline__ uint32_t leafFirst(int32_t c) { return (uint32_t)~c >> kMeshLeafShift; }
 HPSDF_HD __forceinline__ uint32_t leafCount(int32_t c) { return ((uint32_t)~c & (kMeshLeafMax - 1u)) + 1u; }
-// A triPre record (four float4 per leaf slot, one 64-byte line): a.xyz n.x | n.yz mab.xy | mab.z mbc.xyz | mca.xyz obc -- the triangle
-// lies in the plane through its vertex a across the unit normal n, on the inner side of three planes across the unit in-plane vectors
-// mab, mbc, mca (the outward normals of its edges; ab's and ca's pass through a, bc's lies obc beyond it): its PRISM.  All zeros
-// but a: "no bound" (slivers whose normal cancels, records that failed their own check in mesh_tripre_kernel): the test passes.
+// A triPre record (three float4 per leaf slot): g.xyz hu | n.xyz hv | u.xyz triangle -- the triangle lies in the plane through g
+// across the unit normal n, inside the rectangle |u . (x - g)| <= hu, |v . (x - g)| <= hv of that plane (u a unit vector along its
+// longest edge, v = n x u).  n = u = 0, hu = 0, hv = rho degrades it to the ball of radius rho around g (slivers whose normal cancels).
 struct TriPre {
-    float4 r0, r1, r2, r3;
+    float4 g, n, u;
 };
 HPSDF_HD __forceinline__ TriPre loadTriPre(const MeshDev& m, uint32_t slot) {
-    return TriPre{m.triPre[4 * (size_t)slot], m.triPre[4 * (size_t)slot + 1], m.triPre[4 * (size_t)slot + 2], m.triPre[4 * (size_t)slot + 3]};
+    return TriPre{m.triPre[3 * (size_t)slot], m.triPre[3 * (size_t)slot + 1], m.triPre[3 * (size_t)slot + 2]};
 }
-HPSDF_HD __forceinline__ uint32_t slotTriangle(const MeshDev& m, uint32_t slot) { return m.slotTri ? m.slotTri[slot] : slot; }
+HPSDF_HD __forceinline__ uint32_t triPreTriangle(const TriPre& r) { return hpsdfAcosfWord(r.u.w); }
+HPSDF_HD __forceinline__ uint32_t slotTriangle(const MeshDev& m, uint32_t slot) { return hpsdfAcosfWord(m.triPre[3 * (size_t)slot + 2].w); }
 
-// The lower-bound test on a triPre record (round 6): with dx = p - a, s = n . dx and e = the largest of mab . dx, mbc . dx - obc,
-// mca . dx the squared distance of p from the triangle is at least s^2 + max(e, 0)^2 -- EXACT when the closest point lies in the face
-// (e <= 0: the distance from the plane) or on an edge (the distance from that edge's line), an underestimate only where it is a
-// corner; 21 instructions against the two hundred of the closest-point test.
-// (Rounds 3-5 bounded the triangle by its RECTANGLE in its own plane: s^2 + the rectangle's excess.  For a sample at distance D
-// above a surface of curvature radius R that admits every triangle whose centre lies within ~(1 + sqrt(D / (R + D))) half-extents of
-// the foot point -- the neighbours' planes pass BELOW the foot point's, and the rectangle's near rim gains what the plane loses --:
-// 22 triangles a sample went on to the closest-point test on the 2.1 M-triangle torus with the final distance known.  The prism's edge
-// planes cut that to the triangles that really tie: the foot point's own, two on an edge, the fan around a corner.)
+// The lower-bound test on a triPre record: with s = n . (p - g) and a = u . (p - g) the squared distance of p from the triangle is
+// at least s^2 + max(|a| - hu, 0)^2 + max(sqrt(|p - g|^2 - s^2 - a^2) - hv, 0)^2 -- two dozen instructions against the two hundred
+// of the closest-point test.  (Until the middle of round 3 the triangle was bounded by a circle in its plane; the rectangle costs
+// five instructions more and has half the area for the 4 : 1 triangles of a stretched grid: 17 -> 10 candidates per sample on
+// the displaced torus with the final distance known; no change on equilateral triangles.)
 // A box only says "the triangle is somewhere in here": for a sample at distance D from a surface tessellated at size h every
 // triangle whose box dips into the ball passes the box test, a patch ~sqrt(2 D h) wide (~300 triangles per sample on a
-// 1.3 M-triangle sphere).
+// 1.3 M-triangle sphere); the plane-and-rectangle bound leaves the ones within ~h.
 // A triangle is dropped only if the bound exceeds the best distance by `slack` = 2e-6 of the mesh's scale (its extent, or
 // its largest coordinate if that is larger: f32 positions round at that scale; meshSlack has the error budget) and by
 // 5e-6 of itself -- so the winner is still exactly the exhaustive scan's (test_mesh_bvh_equals_linear_scan_bitwise, the
@@ -235,19 +231,19 @@ HPSDF_HD __forceinline__ uint32_t slotTriangle(const MeshDev& m, uint32_t slot) 
 // slack they are compared with is four orders of magnitude wider than either.)
 HPSDF_HD __forceinline__ float dotF(V3 a, V3 b) { return __builtin_fmaf(a.x, b.x, __builtin_fmaf(a.y, b.y, a.z * b.z)); }
 HPSDF_HD __forceinline__ float triLowerBound2(V3 p, const TriPre& r) {
-    const V3 dx = p - V3{r.r0.x, r.r0.y, r.r0.z};
-    const float sd = dotF(V3{r.r0.w, r.r1.x, r.r1.y}, dx);
-    const float e1 = dotF(V3{r.r1.z, r.r1.w, r.r2.x}, dx), e2 = dotF(V3{r.r2.y, r.r2.z, r.r2.w}, dx) - r.r3.w, e3 = dotF(V3{r.r3.x, r.r3.y, r.r3.z}, dx);
-    const float e = fmaxf(fmaxf(e1, e2), fmaxf(e3, 0.0f));
-    return __builtin_fmaf(e, e, sd * sd);
+    const V3 dx = p - V3{r.g.x, r.g.y, r.g.z};
+    const float sd = dotF(V3{r.n.x, r.n.y, r.n.z}, dx), ad = dotF(V3{r.u.x, r.u.y, r.u.z}, dx);
+    const float lat2 = __builtin_fmaf(-ad, ad, __builtin_fmaf(-sd, sd, dotF(dx, dx)));
+    const float ou = fmaxf(fabsf(ad) - r.g.w, 0.0f);
+    const float ov = fmaxf(boundSqrt(fmaxf(lat2, 0.0f)) - r.n.w, 0.0f);
+    return __builtin_fmaf(ov, ov, __builtin_fmaf(ou, ou, sd * sd));
 }
 // The slack (a distance) a lower bound must exceed the best distance by before anything is dropped.  What it has to cover
 // (u = 2^-24, D the distance, M the largest coordinate; every f32 subtraction p - g is relatively exact, so most errors
 // scale with D and are absorbed by rejectBound's factor 1.00001 on the square, i.e. 5e-6 D):
 //   the reference's closest point q = a + t ab (or (u a + v b) + w c) is rounded where it is formed: <= 3 u M off the
 //     triangle, so its distance may come out that much below the true one                                  1.8e-7 M
-//   the record's planes miss the triangle's vertices by <= 3e-7 of the scale each (mesh_tripre_kernel checks;
-//     across and within the plane together: sqrt 2 of that)                                                 4.3e-7 M
+//   the record's plane misses the triangle's vertices by e <= 4e-7 of the scale (mesh_tripre_kernel checks) 4.0e-7 M
 //   n . (p - g), |p - g|^2 - (n . (p - g))^2, |n| - 1: ~16 u D                                              (factor)
 // 2e-6 of the scale is three and a half times their sum.  (Round 2 ran with 2e-5; the margin it adds around every foot
 // point, sqrt(2 D slack), was most of what the samples far from the surface queued: a triangle's width and more.)
@@ -296,7 +292,7 @@ HPSDF_HD float meshSignedDistance(const MeshDev& m, V3 pt, uint32_t& hint) {
     auto visitLeaf = [&](int32_t c) {
         for (uint32_t k = 0, first = leafFirst(c), cnt = leafCount(c); k < cnt; ++k) {
             const TriPre rec = loadTriPre(m, first + k);
-            if (!(triLowerBound2(pt, rec) > reject)) visitTri(slotTriangle(m, first + k));
+            if (!(triLowerBound2(pt, rec) > reject)) visitTri(triPreTriangle(rec));
         }
     };
     auto boxDist = [&](const float* lo, const float* hi) {
@@ -385,7 +381,7 @@ __device__ float meshSignedDistanceWave(const MeshDev& m, V3 pt, bool activeIn, 
     auto visitLeaf = [&](int32_t c) {
         for (uint32_t k = 0, first = leafFirst(c), cnt = leafCount(c); k < cnt; ++k) {
             const TriPre rec = loadTriPre(m, first + k);
-            if (!(triLowerBound2(pt, rec) > reject)) visitTri(slotTriangle(m, first + k));
+            if (!(triLowerBound2(pt, rec) > reject)) visitTri(triPreTriangle(rec));
         }
     };
     auto boxDist = [&](const float* lo, const float* hi) {  // clamp = median of (p, lo, hi): lo <= hi in every box
@@ -522,6 +518,9 @@ struct MeshWaveLds {
     uint8_t aLane[256];
     uint8_t bLane[128];
     uint8_t redo[64];             // lanes whose pairs found the pool full
+#ifdef HPSDF_MESH_STALE_STATS
+    float bLb[128];               // (diagnostic) ring B: the lower bound each pair passed with
+#endif
 };
 // lower bound of the squared distance from p to anything inside the slab |n . (x - g)| <= e cut by the ball |x - g| <= rho
 // (g = (g.xyz), rho = g.w, n = nh.xyz, e = nh.w): along n at least |n . (p - g)| - e, across it at least the distance of p
@@ -573,6 +572,9 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool activeIn,
         const uint32_t t = on ? L.bTri[at] : 0u;
         const int src = on ? (int)L.bLane[at] : lane;
         const V3 p = ownerPoint(src);
+#ifdef HPSDF_MESH_STALE_STATS  // [7]: pairs whose bound no longer passes when their closest-point test runs (the owner's best has improved since)
+        nSeedExact += (unsigned)__popcll(__ballot(on && L.bLb[at] > L.rj[src]));
+#endif
         if (on) {
             V3 q;
             const float4 tp[3] = {m.triPos[3 * (size_t)t], m.triPos[3 * (size_t)t + 1], m.triPos[3 * (size_t)t + 2]};
@@ -615,10 +617,12 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool activeIn,
         const float rj = L.rj[src];
         bool pass = false;
         uint32_t tri = 0u;
+        float lbv = 0.0f;
         if (on) {
             const TriPre rec = loadTriPre(m, slot);
-            pass = !(triLowerBound2(p, rec) > rj);  // (a NaN passes)
-            if (pass) tri = slotTriangle(m, slot);
+            tri = triPreTriangle(rec);
+            lbv = triLowerBound2(p, rec);
+            pass = !(lbv > rj);  // (a NaN passes)
 #if HPSDF_MESH_ABL == 6  // (lab: the lower-bound test twice)
             {
                 V3 p2 = p;
@@ -633,6 +637,9 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool activeIn,
             const uint32_t pos = (bHead + bCount + (uint32_t)__popcll(pb & below)) & 127u;
             L.bTri[pos] = tri;
             L.bLane[pos] = (uint8_t)src;
+#ifdef HPSDF_MESH_STALE_STATS
+            L.bLb[pos] = lbv;
+#endif
         }
         bCount += (uint32_t)__popcll(pb);
         aHead = (aHead + pairs) & 255u;
@@ -723,7 +730,7 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool activeIn,
                 const uint32_t k = (uint32_t)__ffs((int)restMask) - 1u;
                 restMask &= restMask - 1u;
                 const TriPre rec = loadTriPre(m, seedFirst + k);
-                if (!(triLowerBound2(pt, rec) > rj)) tryTriangle(slotTriangle(m, seedFirst + k), seedFirst + k);
+                if (!(triLowerBound2(pt, rec) > rj)) tryTriangle(triPreTriangle(rec), seedFirst + k);
             }
         }
         for (int pass = 0; pass < HPSDF_SEED_EXCHANGE; ++pass) {
@@ -737,10 +744,10 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool activeIn,
                 if (active && slot != 0xFFFFFFFFu && slot != bestSlot) {
                     const TriPre rec = loadTriPre(m, slot);
                     const float lb = triLowerBound2(pt, rec);
-                    if (lb < candLb && !(lb > rj)) candLb = lb, candSlot = slot;
+                    if (lb < candLb && !(lb > rj)) candLb = lb, candSlot = slot, candTri = triPreTriangle(rec);
                 }
             }
-            if (candSlot != 0xFFFFFFFFu) candTri = slotTriangle(m, candSlot), tryTriangle(candTri, candSlot);
+            if (candSlot != 0xFFFFFFFFu) tryTriangle(candTri, candSlot);
         }
         {
             // (one triangle per lane and step: at a corner the edge that starts there first, and if that does not help the
@@ -963,7 +970,9 @@ __device__ float meshSignedDistanceWaveQ(const MeshDev& m, V3 pt, bool activeIn,
 #endif
 #ifdef HPSDF_MESH_STATS_BUILD
 #ifndef HPSDF_MESH_VISIT_HIST
+#ifndef HPSDF_MESH_STALE_STATS
     nSeedExact = (unsigned)__popcll(__ballot(active && seedBest == ownerBest(lane)));
+#endif
 #endif
 #ifdef HPSDF_MESH_POOL_STATS  // [7]: (lane, node) pairs that went through the pool
     nSeedExact = nPoolPairs;
@@ -2860,7 +2869,10 @@ static uint32_t meshXcdRun() {  // HPSDF_MESH_XCD_RUN overrides (experiments); 1
     }();
     return v;
 }
-__global__ __launch_bounds__(kMeshWg) void mesh_sample_kernel(const FitTask* __restrict__ tasks, int degree,
+#ifndef HPSDF_MESH_MIN_WAVES
+#define HPSDF_MESH_MIN_WAVES 6  // <= 80 registers, six waves a SIMD (round 6; 88 registers and five waves until then: the kernel is bound by instruction issue with a third of the slots empty, and a sixth wave fills some of them -- Create on the 2.1 M-triangle torus at 1e-6 32.1 -> 30.7 ms, 1.3 M-triangle icosphere 11.4 -> 10.9, at the price of 48 more bytes of scratch)
+#endif
+__global__ __launch_bounds__(kMeshWg, HPSDF_MESH_MIN_WAVES) void mesh_sample_kernel(const FitTask* __restrict__ tasks, int degree,
                                                           const DeviceTables* __restrict__ T, MeshDev mesh, RootMap rm,
                                                           double* __restrict__ samples, const uint32_t* __restrict__ range,
                                                           uint32_t nTasksArg, uint32_t xcdRun) {
@@ -3104,75 +3116,85 @@ __global__ __launch_bounds__(256) void mesh_tripos_kernel(const float* __restric
     triPos[3 * t + 2] = make_float4(c.z, n.x, n.y, n.z);
 }
 
-// MeshDev::triPre: per leaf slot the triangle's PRISM (triLowerBound2): vertex a, the unit normal n and the unit in-plane outward
-// normals of the three edges, mab = ab x n, mbc = bc x n, mca = ca x n (normalised), with obc = mbc . (b - a).  The bound is valid for ANY
-// unit n and any unit m perpendicular to it as long as every point x of the triangle has |n . (x - a)| <= e and m . (x - a) <= offset + e
-// -- all linear in x, so the vertices decide, and every one of these is MEASURED here with the arithmetic of the test.  A record whose
-// residuals exceed 3e-7 of the mesh's scale (slivers, whose cross product cancels) or whose frame is not orthonormal to 1e-6 is zeroed
-// ("no bound": the test passes and the closest-point routine decides).  What is left of the residuals -- across the plane and within
-// it together at most sqrt 2 x 3e-7 of the scale -- is covered by the caller's slack (2e-6 of that scale: meshSlack).
-// slotTriOut (device builds): which triangle the slot holds, kept with the field (MeshDev::slotTri).
+// MeshDev::triPre: per leaf slot the data of the lower-bound test (triLowerBound2) and the triangle's index: the unit normal n,
+// a unit vector u along the longest edge, the centre g of the triangle's bounding rectangle in the (u, n x u) frame and the
+// rectangle's half-extents.  The bound is valid for ANY orthonormal n, u as long as every point x of the triangle has
+// |n . (x - g)| <= e, |u . (x - g)| <= hu and sqrt(|x - g|^2 - (n . (x - g))^2 - (u . (x - g))^2) <= hv -- all three are convex in x,
+// so the vertices decide, and all three are MEASURED here against the g that is stored, with the arithmetic of the test.  When e
+// is not negligible (slivers, whose cross product cancels) or the frame is not orthonormal to 1e-6, n and u are set to zero and hv
+// to the largest distance of a vertex from g, which turns the test into the ball's bound |p - g| - rho.  What is left of e
+// (<= 4e-7 of the mesh's scale) and of the frame's rounding is covered by the caller's slack (2e-6 of that scale: meshSlack).
 __global__ __launch_bounds__(256) void mesh_tripre_kernel(const float* __restrict__ verts, const uint32_t* __restrict__ tris,
-                                                          const uint32_t* __restrict__ slotTri, uint64_t nTris, float4* __restrict__ triPre,
-                                                          uint32_t* __restrict__ slotTriOut) {
+                                                          const uint32_t* __restrict__ slotTri, uint64_t nTris, float4* __restrict__ triPre) {
     const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (s >= nTris) return;
     const uint32_t t = slotTri ? slotTri[s] : (uint32_t)s;
-    if (slotTriOut) slotTriOut[s] = t;
     const uint32_t ia = tris[3 * (size_t)t], ib = tris[3 * (size_t)t + 1], ic = tris[3 * (size_t)t + 2];
     const V3 a = {verts[3 * (size_t)ia], verts[3 * (size_t)ia + 1], verts[3 * (size_t)ia + 2]};
     const V3 b = {verts[3 * (size_t)ib], verts[3 * (size_t)ib + 1], verts[3 * (size_t)ib + 2]};
     const V3 c = {verts[3 * (size_t)ic], verts[3 * (size_t)ic + 1], verts[3 * (size_t)ic + 2]};
     const V3 ab = b - a, ac = c - a, bc = c - b;
+    const float lab = sqnorm(ab), lac = sqnorm(ac), lbc = sqnorm(bc);
     const V3 n = cross(ab, ac);
     const float inf = __builtin_inff();
-    const float len = sqrtf(sqnorm(n));
-    V3 nh = {0.0f, 0.0f, 0.0f}, m1 = nh, m2 = nh, m3 = nh;
-    float obc = 0.0f;
-    bool framed = len > 0.0f && len < inf;
+    // the frame: n, u along the longest edge, v = n x u; the rectangle's centre from the vertices' (u, v) ranges about a
+    const V3 le = lab >= lac && lab >= lbc ? ab : (lac >= lbc ? ac : bc);
+    const float len = sqrtf(sqnorm(n)), ll = sqrtf(sqnorm(le));
+    V3 nh = {0.0f, 0.0f, 0.0f}, uh = {0.0f, 0.0f, 0.0f};
+    const float third = 1.0f / 3.0f;
+    V3 g = third * (a + (b + c));
+    bool framed = len > 0.0f && len < inf && ll > 0.0f && ll < inf;
     if (framed) {
         nh = (1.0f / len) * n;
-        // outward in the triangle's plane: ab x n points away from c (ab x (ab x ac) = ab (ab . ac) - ac |ab|^2)
-        const V3 x1 = cross(ab, nh), x2 = cross(bc, nh), x3 = cross(V3{0.0f, 0.0f, 0.0f} - ac, nh);
-        const float l1 = sqrtf(sqnorm(x1)), l2 = sqrtf(sqnorm(x2)), l3 = sqrtf(sqnorm(x3));
-        framed = l1 > 0.0f && l1 < inf && l2 > 0.0f && l2 < inf && l3 > 0.0f && l3 < inf;
-        if (framed) {
-            m1 = (1.0f / l1) * x1, m2 = (1.0f / l2) * x2, m3 = (1.0f / l3) * x3;
-            // the scale the caller's slack is proportional to is at least this (the mesh's extent or its largest coordinate)
-            const float rho = sqrtf(fmaxf(sqnorm(ab), sqnorm(ac)));
-            const float scale = fmaxf(rho, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fabsf(a.z)));
-            const float tol = 3e-7f * scale;
-            // the vertices against every plane, with the test's own arithmetic (vertex a sits at dx = 0)
-            const float sb = dotF(nh, ab), sc = dotF(nh, ac);
-            const float e1b = dotF(m1, ab), e1c = dotF(m1, ac);
-            const float e2b = dotF(m2, ab), e2c = dotF(m2, ac);
-            const float e3b = dotF(m3, ab), e3c = dotF(m3, ac);
-            obc = fmaxf(e2b, e2c);
-            const bool unit = fabsf(sqnorm(nh) - 1.0f) <= 1e-6f && fabsf(sqnorm(m1) - 1.0f) <= 1e-6f && fabsf(sqnorm(m2) - 1.0f) <= 1e-6f &&
-                              fabsf(sqnorm(m3) - 1.0f) <= 1e-6f && fabsf(dot(nh, m1)) <= 1e-6f && fabsf(dot(nh, m2)) <= 1e-6f && fabsf(dot(nh, m3)) <= 1e-6f;
-            framed = unit && fabsf(sb) <= tol && fabsf(sc) <= tol && e1b <= tol && e1c <= tol && e3b <= tol && e3c <= tol && obc >= -tol && obc < inf &&
-                     rho < inf;
-        }
+        uh = (1.0f / ll) * le;
+        const V3 vh = cross(nh, uh);
+        const float ub = dot(uh, ab), uc = dot(uh, ac), vb = dot(vh, ab), vc = dot(vh, ac);  // (vertex a sits at (0, 0))
+        const float um = 0.5f * (fminf(0.0f, fminf(ub, uc)) + fmaxf(0.0f, fmaxf(ub, uc)));
+        const float vm = 0.5f * (fminf(0.0f, fminf(vb, vc)) + fmaxf(0.0f, fmaxf(vb, vc)));
+        g = a + (um * uh + vm * vh);
+        framed = fabsf(sqnorm(nh) - 1.0f) <= 1e-6f && fabsf(sqnorm(uh) - 1.0f) <= 1e-6f && fabsf(dot(nh, uh)) <= 1e-6f;
     }
-    if (!framed) {  // "no bound": s = 0 and e = 0 whatever the point (non-finite input: NaN, which passes as well)
-        nh = V3{0.0f, 0.0f, 0.0f}, m1 = nh, m2 = nh, m3 = nh;
-        obc = 0.0f;
+    const V3 da = a - g, db = b - g, dc = c - g;
+    const float ra = sqnorm(da), rb = sqnorm(db), rcq = sqnorm(dc);
+    const float rho = sqrtf(fmaxf(ra, fmaxf(rb, rcq))) * 1.00001f + 1e-30f;
+    // the scale the caller's slack is proportional to is at least this (the mesh's extent or its largest coordinate)
+    const float scale = fmaxf(rho, fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fabsf(g.z)));
+    float hu = 0.0f, hv = rho;
+    if (framed) {
+        const float sa = dot(nh, da), sb = dot(nh, db), sc = dot(nh, dc);
+        const float ua = dot(uh, da), ub = dot(uh, db), uc = dot(uh, dc);
+        const float e = fmaxf(fabsf(sa), fmaxf(fabsf(sb), fabsf(sc)));
+        const float wa = sqrtf(fmaxf(ra - sa * sa - ua * ua, 0.0f)), wb = sqrtf(fmaxf(rb - sb * sb - ub * ub, 0.0f)),
+                    wc = sqrtf(fmaxf(rcq - sc * sc - uc * uc, 0.0f));
+        // The rectangle holds the TRIANGLE (measured above, with allowances for its own rounding).  What the closest-point routine
+        // returns for the triangle lies within a quarter of the traversal's slack of it: closestSimplex does not take a face-case
+        // point farther outside than that (until round 4 the rectangle was widened by a "play" of 1e-6 longest edge / sin(smallest
+        // angle) instead, an estimate of how far the reference's barycentric quotients can throw q: it did not hold on needles).
+        hu = fmaxf(fabsf(ua), fmaxf(fabsf(ub), fabsf(uc))) * 1.00001f + 4e-7f * scale;
+        // (hv also takes 1e-3 hu: the test forms the in-plane distance across u as sqrt(|d|^2 - s^2 - a^2), whose cancellation leaves up to
+        // sqrt(2 ulp) |d| = 3.5e-4 |d| where the true value is nearly zero -- beside a needle that is more than its width; past ~3 hu from
+        // g the excess is below 1e-6 of the bound itself, which rejectBound's factor covers)
+        hv = fmaxf(wa, fmaxf(wb, wc)) * 1.00001f + 4e-7f * scale + 1e-3f * hu;
+        framed = e <= 4e-7f * scale && hu < inf && hv < inf;
     }
-    triPre[4 * s] = make_float4(a.x, a.y, a.z, nh.x);
-    triPre[4 * s + 1] = make_float4(nh.y, nh.z, m1.x, m1.y);
-    triPre[4 * s + 2] = make_float4(m1.z, m2.x, m2.y, m2.z);
-    triPre[4 * s + 3] = make_float4(m3.x, m3.y, m3.z, obc);
+    if (!framed || !(rho < inf)) {  // (non-finite input: the bound degenerates to "always passes" via NaN)
+        nh = V3{0.0f, 0.0f, 0.0f}, uh = V3{0.0f, 0.0f, 0.0f};
+        hu = 0.0f, hv = rho;
+    }
+    triPre[3 * s] = make_float4(g.x, g.y, g.z, hu);
+    triPre[3 * s + 1] = make_float4(nh.x, nh.y, nh.z, hv);
+    triPre[3 * s + 2] = make_float4(uh.x, uh.y, uh.z, __uint_as_float(t));
 }
 
 hipError_t launchMeshTriPos(hipStream_t stream, const float* dVerts, const uint32_t* dTris, uint64_t nTris, float* dTriPos,
-                            const uint32_t* dSlotTri, float* dTriPre, uint32_t* dSlotTriOut) {
+                            const uint32_t* dSlotTri, float* dTriPre) {
     if (nTris == 0) return hipSuccess;
     if (dTriPos)
         hipLaunchKernelGGL(mesh_tripos_kernel, dim3((unsigned)((nTris + 255) / 256)), dim3(256), 0, stream, dVerts, dTris, nTris,
                            reinterpret_cast<float4*>(dTriPos));
     if (dTriPre)
         hipLaunchKernelGGL(mesh_tripre_kernel, dim3((unsigned)((nTris + 255) / 256)), dim3(256), 0, stream, dVerts, dTris, dSlotTri, nTris,
-                           reinterpret_cast<float4*>(dTriPre), dSlotTriOut);
+                           reinterpret_cast<float4*>(dTriPre));
     return hipGetLastError();
 }
 

@@ -73,10 +73,10 @@ void meshEvalHostPoints(const MeshDev& hm, const double* xyz, size_t n, double* 
 hipError_t launchMeshNaive(hipStream_t stream, const FieldDev& f, const double* dXyz, size_t n, double* dOut, unsigned long long* dKeys = nullptr);
 hipError_t launchAcosfSelftest(hipStream_t stream, uint32_t first, uint32_t stride, size_t n, float* dOut);
 constexpr int kTriRecordFloats = 12;  // MeshDev::triPos: a, b, c, cross(b - a, c - a)
-constexpr int kTriPreFloats = 16;     // MeshDev::triPre: a.xyz n.x | n.yz mab.xy | mab.z mbc.xyz | mca.xyz obc
+constexpr int kTriPreFloats = 12;     // MeshDev::triPre: g hu | unit normal hv | unit edge vector, triangle index
 // dSlotTri: which triangle sits in leaf slot s (nullptr: slot s = triangle s); either output may be nullptr (skipped)
 hipError_t launchMeshTriPos(hipStream_t stream, const float* dVerts, const uint32_t* dTris, uint64_t nTris, float* dTriPos,
-                            const uint32_t* dSlotTri, float* dTriPre, uint32_t* dSlotTriOut = nullptr);
+                            const uint32_t* dSlotTri, float* dTriPre);
 // mesh fields: F at every sample of nTasks fits of one degree -> dSamples[FitTask::sampleOff + sample]
 hipError_t launchMeshSample(hipStream_t stream, const FitTask* dTasks, uint32_t nTasks, int degree, const DeviceTables* dTables,
                             const FieldDev& field, const RootMap& rm, double* dSamples);

@@ -436,7 +436,6 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
         const size_t oVerts = carve(fb, 3 * nVerts * sizeof(float)), oTris = carve(fb, nCorners * sizeof(uint32_t)),
                      oTriPos = carve(fb, (size_t)nTris * kTriRecordFloats * sizeof(float)),
                      oTriPre = carve(fb, (size_t)nTris * kTriPreFloats * sizeof(float)), oHe = carve(fb, nCorners * sizeof(uint32_t)),
-                     oSlotTri = carve(fb, (size_t)nTris * sizeof(uint32_t)),
                      oBvh = carve(fb, (size_t)(n - 1) * sizeof(BvhNode)), oSlab = carve(fb, (size_t)(n - 1) * sizeof(NodeSlab));
         size_t tb = 0;
         const size_t oT64 = carve(tb, nCorners * sizeof(uint64_t)), oBox = carve(tb, 6 * nTris * sizeof(float)),
@@ -469,7 +468,6 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
             f->dBlock = fieldBlock;
             f->dVerts = (float*)(fieldBlock + oVerts), f->dTris = (uint32_t*)(fieldBlock + oTris), f->dTriPos = (float*)(fieldBlock + oTriPos);
             f->dTriPre = (float*)(fieldBlock + oTriPre);
-            f->dSlotTri = (uint32_t*)(fieldBlock + oSlotTri);
             f->dHalfEdges = (uint32_t*)(fieldBlock + oHe), f->dBvh = (BvhNode*)(fieldBlock + oBvh);
             f->dSlabs = (NodeSlab*)(fieldBlock + oSlab);
             dRanges = (int32_t*)(tempBlock + oRan);
@@ -487,7 +485,7 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
         if (fieldBlock) (void)hipFree(fieldBlock);
         fieldBlock = nullptr;
         f->dBlock = nullptr;
-        f->dVerts = nullptr, f->dTris = nullptr, f->dTriPos = nullptr, f->dTriPre = nullptr, f->dSlotTri = nullptr, f->dHalfEdges = nullptr, f->dBvh = nullptr;
+        f->dVerts = nullptr, f->dTris = nullptr, f->dTriPos = nullptr, f->dTriPre = nullptr, f->dHalfEdges = nullptr, f->dBvh = nullptr;
         f->dSlabs = nullptr;
     };
     const double t1 = now();
@@ -547,7 +545,7 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
     hipLaunchKernelGGL(mb_boxes_kernel, dim3(gt), dim3(256), 0, s, f->dTriPos, (uint32_t)nTris, dTriBox, dFlags);
     hipLaunchKernelGGL(mb_morton_kernel, dim3(gt), dim3(256), 0, s, dTriBox, (uint32_t)nTris, dFlags, dKeys, dIds);
     if (e == hipSuccess) e = rocprim::radix_sort_pairs(dSortTmp, sortTmpBytes, dKeys, dKeysOut, dIds, dIdsOut, (size_t)nTris, 0, 63, s);
-    if (e == hipSuccess) e = launchMeshTriPos(s, f->dVerts, f->dTris, nTris, nullptr, dIdsOut, f->dTriPre, f->dSlotTri);  // slot order = sorted order
+    if (e == hipSuccess) e = launchMeshTriPos(s, f->dVerts, f->dTris, nTris, nullptr, dIdsOut, f->dTriPre);  // slot order = sorted order
     hipLaunchKernelGGL(mb_hierarchy_kernel, dim3(gt), dim3(256), 0, s, dKeysOut, n, leafTris, f->dBvh, dParent, dRanges);
     hipLaunchKernelGGL(mb_fit_kernel, dim3(gt), dim3(256), 0, s, dIdsOut, dTriBox, n, f->dBvh, dParent, dArrived);
     if (!noSlabs)

@@ -162,7 +162,6 @@ struct hpsdf_field {
     uint32_t* dTris = nullptr;
     float* dTriPos = nullptr;
     float* dTriPre = nullptr;
-    uint32_t* dSlotTri = nullptr;  // device-built meshes (part of dBlock): the triangle of every leaf slot; nullptr: slot = triangle
     uint32_t* dHalfEdges = nullptr;
     hpsdf::BvhNode* dBvh = nullptr;
     hpsdf::NodeSlab* dSlabs = nullptr;  // device-built meshes only (part of dBlock)
@@ -174,7 +173,7 @@ struct hpsdf_field {
     // SDF lambda costs decides whether code written against the reference is usable as it is
     struct HostMirror {
         std::vector<float> verts, triPos, triPre;
-        std::vector<uint32_t> tris, halfEdges, slotTri;
+        std::vector<uint32_t> tris, halfEdges;
         std::vector<hpsdf::BvhNode> bvh;
         hpsdf::MeshDev dev{};
     };

@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (counter_record is the code bench.py itself uses)
 
 bad = 0
-for name, keys in (("mesh_pmc.json", ("frac_valu_issue",)), ("fit_pmc.json", ("degrees",))):
+for name, keys in (("mesh_pmc.json", ("frac_valu_issue",)), ("fit_pmc.json", ("degrees",)), ("fit_mfma_pmc.json", ("degrees",))):
     m = bench.counter_record(name, keys)["measured_from"]
     state = "MISSING" if m is None else ("STALE" if m["stale"] else "current")
     bad += state != "current"

@@ -3,7 +3,8 @@
 writes profiles-ready JSON stamped with a hash of the kernels' source, so that bench.py can tell a stale record from a live one
 (it reports null instead of yesterday's counters).
   pmc_json.py mesh <pmc dir> <out.json> <tag>
-  pmc_json.py fit <out.json> <tag> <degree>=<pmc dir> ..."""
+  pmc_json.py fit <out.json> <tag> <degree>=<pmc dir> ...
+  pmc_json.py mfma <out.json> <tag> <degree>:<field>=<pmc dir> ...      (tools/fit_mfma_pmc.sh: the fast fit's matrix-core counters)"""
 import csv, glob, hashlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "hp-adaptive-signed-distance-field-octree_amd", "csrc")
@@ -18,6 +19,7 @@ def source_sha16(files):
 
 MESH_FILES = ["kernels.hip", "device_types.hpp", "acosf_host_libm.hpp"]
 FIT_FILES = ["kernels.hip", "fit_low.hip", "field_eval.hpp", "device_types.hpp"]
+MFMA_FILES = ["fit_mfma.hip", "field_eval.hpp", "device_types.hpp"]
 
 
 def counters(pmc_dir, want):
@@ -50,6 +52,20 @@ def main():
                "fetched_bytes_per_sample": 2 * c["FETCH_SIZE"] * 1024 / (w * 64) if w and c.get("FETCH_SIZE") else None,
                "written_bytes_per_sample": c["WRITE_SIZE"] * 1024 / (w * 64) if w and c.get("WRITE_SIZE") else None,
                "note": "rocprofv3 --pmc passes of tools/mesh_probe.py (tools/mesh_pmc.sh); averages over the kernel's launches"}
+    elif sys.argv[1] == "mfma":
+        out, tag = sys.argv[2:4]
+        rec = {"profile": tag, "source_sha16": source_sha16(MFMA_FILES), "degrees": {},
+               "note": "rocprofv3 --pmc passes of tools/fit_one.py <field> <degree> 16384 fast (tools/fit_mfma_pmc.sh), kernel fit_mfma_kernel: mfma_busy = "
+                       "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) -- the fraction of the chip's matrix-pipe cycles in use while the kernel "
+                       "ran; union3 = fused with the headline field, plane = contraction only"}
+        for arg in sys.argv[4:]:
+            key, pmc_dir = arg.split("=", 1)
+            deg, fld = key.split(":")
+            c, n = counters(pmc_dir, lambda k: "fit_mfma_kernel" in k)
+            d = rec["degrees"].setdefault("p" + deg, {})
+            if c.get("SQ_VALU_MFMA_BUSY_CYCLES") and c.get("GRBM_GUI_ACTIVE"):
+                d[fld] = {"mfma_busy": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), "frac_valu_issue": valu_issue(c),
+                          "mfma_mops_f64": c.get("SQ_INSTS_VALU_MFMA_MOPS_F64"), "gui_active_cycles": c["GRBM_GUI_ACTIVE"], "launches": n.get("GRBM_GUI_ACTIVE")}
     else:
         out, tag = sys.argv[2:4]
         rec = {"profile": tag, "source_sha16": source_sha16(FIT_FILES), "field": "union3", "degrees": {},
