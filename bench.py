@@ -279,6 +279,14 @@ def main():
         repeated_ms = r0.elapsed_time(r1) / 20
         # sanity: the output is the real answer (spot parity against the oracle on rank 0; d_out now holds the first batch's values)
         got = d_out[:: max(1, n // 2000)].cpu().numpy()
+        # ... and on EVERY rank, with or without the CPU-baseline leg, a cross-check that needs no oracle: the timed
+        # kernel's values against the library's other implementation of Query -- calls of <= 32 points are answered on the calling thread
+        # (csrc/host_query.cpp: the same statements compiled for the host) -- on 16 strided groups of 32 points, bit for bit
+        stride_g = max(1, (n - 32) // 16)
+        for g0 in range(0, n - 31, stride_g):
+            pts32 = d_xyz[g0:g0 + 32].cpu().numpy()
+            assert np.array_equal(tree.query(pts32).view(np.uint64), d_out[g0:g0 + 32].cpu().numpy().view(np.uint64)), \
+                "the timed Query kernel and the host-answered Query disagree (rank %d, points %d..)" % (rank, g0)
 
         # ---------------- Create() with the frontier sharded over the ranks (one all-gather per round).  Behind the headline leg and
         # inside a try: this is the part of the run that needs RCCL to take an in-place all-gather on the library's stream, which no

@@ -1336,8 +1336,9 @@ __device__ __forceinline__ void frMirror(const FrDev& d) {
 // SIMD (waves 4, 8 and 12 do nothing); the twelve waves of the other three SIMDs bring the next 2048 operands into the other half of an
 // LDS buffer meanwhile, each lane's loads in flight together (a lone wave loading its own operands waits out an L2 round trip every
 // 64 jobs: 129 us for round 0's 4096 additions; three loader waves taking their elements one round trip after the other still left
-// the adder waiting).  The adder's pace is that of v_add_f64 with a fresh operand, 8.6 cycles: tools/chain_lab.hip tried what else
-// could feed it -- DPP broadcasts, SGPR operands through scalar loads, one active lane, a hand-scheduled loop -- and nothing did better.
+// the adder waiting).  Rounds 2-5 added with v_add_f64, 8.6 cycles an addition with a fresh operand (tools/chain_lab.hip tried what else
+// could feed it -- DPP broadcasts, SGPR operands through scalar loads, one active lane, a hand-scheduled loop -- nothing did better);
+// since round 6 the additions run four at a time on the matrix pipe, in the same order with the same roundings: 5.2 cycles (below).
 // All waves that are still there call (barriers inside).
 __device__ double frRunChain(const FrDev& d, FrLds& L, double total, uint32_t nOps, bool round0) {
     const FrHdr* h = d.hdr;
@@ -1367,69 +1368,52 @@ __device__ double frRunChain(const FrDev& d, FrLds& L, double total, uint32_t nO
         if (loader) {
             if (c0 + 2048u < nOps) loadChunk(c0 + 2048u, sOps + (half ^ 1u) * 2048u);
         } else if (adder) {
-            // Thirty-two operands a turn, in two batches of sixteen registers: while one batch is added (16 dependent additions, ~140
-            // cycles) the other's LDS reads are in flight.  Written out as instructions: from the plain statements the compiler builds
-            // "read 32, wait, add 32" -- every turn then pays the LDS latency in the open, 12.7 cycles an addition instead of 8.6
-            // (tools/chain_lab.hip; the additions are v_add_f64 in the statements' order either way).
+            // FOUR additions an instruction, on the matrix pipe (round 6).  v_mfma_f64_4x4x4_4b_f64 computes D = A B + C with k = 4; with
+            // B = 1 every product is exact, and the hardware accumulates the four terms of an output one after the other, each through
+            // a fused multiply-add -- i.e. D = (((C + a0) + a1) + a2) + a3 with IEEE rounding after every step, the very additions of
+            // Octree.cpp:253-290 in the reference's order (tools/mfma_chain_lab.hip: 262 144 random sums of mixed magnitudes and signs,
+            // signed zeros, subnormals and half-ulp ties bit for bit equal to the sequential v_add_f64 sum -- and unequal to the reversed
+            // and to the exactly rounded sum).  A dependent chain of them costs 20.6 cycles an instruction = 5.2 cycles an addition
+            // against v_add_f64's 8.7 (rounds 2-5: 9.3 with its operands fed from LDS).  Output (0, 0) of block 0 -- lane 0 -- sums
+            // the A operands of lanes 0, 16, 32, 48 in that order, so lane l supplies operand 4 t + (l >> 4) of step t; the other
+            // fifteen outputs of every block compute sums nobody reads.  Sixteen steps' operands are in registers while the next
+            // sixteen's LDS reads are in flight.
             const double* src = sOps + half * 2048u;
             uint32_t q = 0;
-            if (n >= 32) {
-                uint32_t addr = (uint32_t)(uintptr_t)src;  // (a shared pointer's low word is its LDS address)
-                uint32_t turns = __builtin_amdgcn_readfirstlane(n >> 5);
-                q = turns << 5;
-                asm volatile(
-                    "ds_read2_b64 v[64:67], %[addr] offset0:0 offset1:1\n"
-                    "ds_read2_b64 v[68:71], %[addr] offset0:2 offset1:3\n"
-                    "ds_read2_b64 v[72:75], %[addr] offset0:4 offset1:5\n"
-                    "ds_read2_b64 v[76:79], %[addr] offset0:6 offset1:7\n"
-                    "ds_read2_b64 v[80:83], %[addr] offset0:8 offset1:9\n"
-                    "ds_read2_b64 v[84:87], %[addr] offset0:10 offset1:11\n"
-                    "ds_read2_b64 v[88:91], %[addr] offset0:12 offset1:13\n"
-                    "ds_read2_b64 v[92:95], %[addr] offset0:14 offset1:15\n"
-                    "1:\n"
-                    "ds_read2_b64 v[96:99], %[addr] offset0:16 offset1:17\n"
-                    "ds_read2_b64 v[100:103], %[addr] offset0:18 offset1:19\n"
-                    "ds_read2_b64 v[104:107], %[addr] offset0:20 offset1:21\n"
-                    "ds_read2_b64 v[108:111], %[addr] offset0:22 offset1:23\n"
-                    "ds_read2_b64 v[112:115], %[addr] offset0:24 offset1:25\n"
-                    "ds_read2_b64 v[116:119], %[addr] offset0:26 offset1:27\n"
-                    "ds_read2_b64 v[120:123], %[addr] offset0:28 offset1:29\n"
-                    "ds_read2_b64 v[124:127], %[addr] offset0:30 offset1:31\n"
-                    "s_waitcnt lgkmcnt(8)\n"
-                    "v_add_f64 %[t], %[t], v[64:65]\nv_add_f64 %[t], %[t], v[66:67]\n"
-                    "v_add_f64 %[t], %[t], v[68:69]\nv_add_f64 %[t], %[t], v[70:71]\n"
-                    "v_add_f64 %[t], %[t], v[72:73]\nv_add_f64 %[t], %[t], v[74:75]\n"
-                    "v_add_f64 %[t], %[t], v[76:77]\nv_add_f64 %[t], %[t], v[78:79]\n"
-                    "v_add_f64 %[t], %[t], v[80:81]\nv_add_f64 %[t], %[t], v[82:83]\n"
-                    "v_add_f64 %[t], %[t], v[84:85]\nv_add_f64 %[t], %[t], v[86:87]\n"
-                    "v_add_f64 %[t], %[t], v[88:89]\nv_add_f64 %[t], %[t], v[90:91]\n"
-                    "v_add_f64 %[t], %[t], v[92:93]\nv_add_f64 %[t], %[t], v[94:95]\n"
-                    // (the next turn's first batch: at most 16 entries past the chunk -- inside the LDS block, never added)
-                    "ds_read2_b64 v[64:67], %[addr] offset0:32 offset1:33\n"
-                    "ds_read2_b64 v[68:71], %[addr] offset0:34 offset1:35\n"
-                    "ds_read2_b64 v[72:75], %[addr] offset0:36 offset1:37\n"
-                    "ds_read2_b64 v[76:79], %[addr] offset0:38 offset1:39\n"
-                    "ds_read2_b64 v[80:83], %[addr] offset0:40 offset1:41\n"
-                    "ds_read2_b64 v[84:87], %[addr] offset0:42 offset1:43\n"
-                    "ds_read2_b64 v[88:91], %[addr] offset0:44 offset1:45\n"
-                    "ds_read2_b64 v[92:95], %[addr] offset0:46 offset1:47\n"
-                    "s_waitcnt lgkmcnt(8)\n"
-                    "v_add_f64 %[t], %[t], v[96:97]\nv_add_f64 %[t], %[t], v[98:99]\n"
-                    "v_add_f64 %[t], %[t], v[100:101]\nv_add_f64 %[t], %[t], v[102:103]\n"
-                    "v_add_f64 %[t], %[t], v[104:105]\nv_add_f64 %[t], %[t], v[106:107]\n"
-                    "v_add_f64 %[t], %[t], v[108:109]\nv_add_f64 %[t], %[t], v[110:111]\n"
-                    "v_add_f64 %[t], %[t], v[112:113]\nv_add_f64 %[t], %[t], v[114:115]\n"
-                    "v_add_f64 %[t], %[t], v[116:117]\nv_add_f64 %[t], %[t], v[118:119]\n"
-                    "v_add_f64 %[t], %[t], v[120:121]\nv_add_f64 %[t], %[t], v[122:123]\n"
-                    "v_add_f64 %[t], %[t], v[124:125]\nv_add_f64 %[t], %[t], v[126:127]\n"
-                    "v_add_u32 %[addr], 0x100, %[addr]\n"
-                    "s_sub_u32 %[turns], %[turns], 1\n"
-                    "s_cmp_lg_u32 %[turns], 0\n"
-                    "s_cbranch_scc1 1b\n"
-                    "s_waitcnt lgkmcnt(0)\n"
-                    : [t] "+v"(total), [addr] "+v"(addr), [turns] "+s"(turns)
-                    :
-                    : "memory", "scc", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+            {
+                const uint32_t lane = tid & 63u;
+                const double* mine = src + (lane >> 4);
+                const uint32_t steps = n >> 2, batches = steps >> 4;
+                uint32_t t = 0;
+                if (batches) {
+                    // two register batches taking turns (no copies between them: the wait for a batch's reads then sits in front of ITS
+                    // additions, behind the other batch's)
+                    double ra[16], rb[16];
+#define FR_CHAIN_LOAD(r, batch)                                                                  \
+    _Pragma("unroll") for (int u = 0; u < 16; ++u) r[u] = mine[4u * (16u * (batch) + (uint32_t)u)];
+#define FR_CHAIN_ADD(r) \
+    _Pragma("unroll") for (int u = 0; u < 16; ++u) total = __builtin_amdgcn_mfma_f64_4x4x4f64(r[u], 1.0, total, 0, 0, 0);
+                    FR_CHAIN_LOAD(ra, 0u)
+                    uint32_t b = 0;
+                    for (; b + 2u <= batches; b += 2u) {
+                        FR_CHAIN_LOAD(rb, b + 1u)
+                        __builtin_amdgcn_sched_barrier(0);  // (the other batch's reads are issued before this batch's additions)
+                        FR_CHAIN_ADD(ra)
+                        if (b + 2u < batches) {
+                            FR_CHAIN_LOAD(ra, b + 2u)
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        FR_CHAIN_ADD(rb)
+                    }
+                    if (b < batches) {
+                        FR_CHAIN_ADD(ra)
+                    }
+#undef FR_CHAIN_LOAD
+#undef FR_CHAIN_ADD
+                    t = batches << 4;
+                }
+                for (; t < steps; ++t) total = __builtin_amdgcn_mfma_f64_4x4x4f64(mine[4u * t], 1.0, total, 0, 0, 0);
+                q = steps << 2;
             }
             for (; q < n; ++q) total = total + src[q];
             if (d.stamps && tid == 0 && c0 == 0) d.hdr->dbg[16] = __builtin_readcyclecounter();

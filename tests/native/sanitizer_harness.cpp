@@ -20,7 +20,7 @@ int fail(int code, const std::string& msg) {
 }
 int hipFail(hipError_t, const char*) { return HPSDF_ERR_HIP; }
 const hpsdf_field* innermost(const hpsdf_field* f) { return f; }
-int makeFieldDev(const hpsdf_field*, const double*, FieldDev*) { return HPSDF_ERR_UNSUPPORTED; }
+int makeFieldDev(const hpsdf_ctx*, const hpsdf_field*, const double*, FieldDev*) { return HPSDF_ERR_UNSUPPORTED; }
 // the GPU legs are not exercised here (no device): link-time stand-ins for the launch wrappers of kernels.hip
 size_t fitLdsBytes(int, int, int) { return 0; }
 FitShape fitShape(int, int, uint32_t, bool, bool) { return FitShape{1, 1, 1, 0}; }
@@ -34,11 +34,12 @@ hipError_t launchFitMfma(hipStream_t, int, const FitBlock*, uint32_t, const FitT
                          const RootMap&, const uint32_t*) { return hipErrorNoDevice; }
 bool fitSplitSupports(int, int) { return false; }
 static int gLeft = 0;  // capi.cpp's hpsdf_set_reduction_order(); here from HPSDF_REDUCTION_ORDER (main)
-int reductionLeftAssoc() { return gLeft; }
-int meshFaceRuleReference() { return 0; }
+int reductionLeftAssoc(const hpsdf_ctx*) { return gLeft; }
+int meshFaceRuleReference(const hpsdf_ctx*) { return 0; }
 void setReductionLeftAssoc(int left) { gLeft = left != 0; }
+int checkBuildLimits(const hpsdf_ctx*, uint64_t, uint64_t, uint64_t, uint64_t*, uint64_t, double, double) { return HPSDF_OK; }
 hipError_t launchFitMfmaLow(hipStream_t, int, const FitTask*, const uint32_t*, uint32_t, uint32_t, uint32_t, double*, const DeviceTables*, const double*,
-                            const RootMap&) { return hipErrorNoDevice; }
+                            const RootMap&, int) { return hipErrorNoDevice; }
 hipError_t launchCgIterations(hipStream_t, const CgDev&, int, int, uint32_t) { return hipErrorNoDevice; }
 hipError_t launchCgStart(hipStream_t, const CgDev&) { return hipErrorNoDevice; }
 hipError_t launchCgFinish(hipStream_t, const CgDev&) { return hipErrorNoDevice; }
@@ -310,7 +311,7 @@ int main(int argc, char** argv) {
         for (size_t i = 0; i < np; ++i) {
             res[i] = hpsdf::hostQueryPoint(tree, xyz.data() + 3 * i);
             double v = 0.0;
-            hpsdf::hostQueryPointWithGradient(tree, xyz.data() + 3 * i, &v, res.data() + np + 3 * i);
+            hpsdf::hostQueryPointWithGradient(tree, xyz.data() + 3 * i, &v, res.data() + np + 3 * i, hpsdf::reductionLeftAssoc(nullptr));
             if (memcmp(&v, &res[i], 8) != 0) { printf("Query and QueryWithGradient disagree on the value of point %zu\n", i); return 12; }
         }
         FILE* of = fopen(argv[5], "wb"); fwrite(res.data(), 8, res.size(), of); fclose(of);

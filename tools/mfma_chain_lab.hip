@@ -30,7 +30,10 @@ __global__ void chain(const double* __restrict__ a, double* __restrict__ out, un
     double tot = 0.0;
     double x = a[l];
     const unsigned long long t0 = __builtin_readcyclecounter();
-    for (int i = 0; i < iters; ++i) tot = __builtin_amdgcn_mfma_f64_4x4x4f64(x, 1.0, tot, 0, 0, 0);
+    for (int i = 0; i < iters; i += 32) {
+#pragma unroll
+        for (int u = 0; u < 32; ++u) tot = __builtin_amdgcn_mfma_f64_4x4x4f64(x, 1.0, tot, 0, 0, 0);
+    }
     const unsigned long long t1 = __builtin_readcyclecounter();
     out[l] = tot;
     if (l == 0) ticks[0] = t1 - t0;
@@ -40,9 +43,12 @@ __global__ void chainAdd(const double* __restrict__ a, double* __restrict__ out,
     double tot = 0.0;
     const double x = a[l];
     const unsigned long long t0 = __builtin_readcyclecounter();
-    for (int i = 0; i < iters; ++i) {
-        tot = tot + x;
-        asm volatile("" : "+v"(tot));
+    for (int i = 0; i < iters; i += 32) {
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            tot = tot + x;
+            asm volatile("" : "+v"(tot));
+        }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
     out[l] = tot;
@@ -84,10 +90,17 @@ int main() {
     for (auto& v : c) v = rnd();
     // a few adversarial ones: half-ulp terms that a sequential sum drops and an exact sum keeps
     for (int l = 0; l < 64; ++l) a[l] = 0x1.0p-53, c[l] = 1.0;
+    // signed zeros, subnormals (operands and totals), values that overflow: instructions 1..63
+    {
+        const double sp[] = {0.0, -0.0, 4.9406564584124654e-324, -4.9406564584124654e-324, 2.2250738585072009e-308, -2.2250738585072014e-308, 1.0e-310, -3.0e-315,
+                             1.7976931348623157e308, -1.7976931348623157e308, 8.9e307, 1.0, -1.0, 409600.0, 1.0e-300, -1.0e-300};
+        for (int t = 1; t < 64; ++t)
+            for (int l = 0; l < 64; ++l) a[(size_t)t * 64 + l] = sp[next() % 16], c[(size_t)t * 64 + l] = sp[next() % 16];
+    }
     hipMemcpy(dA, a.data(), a.size() * 8, hipMemcpyHostToDevice), hipMemcpy(dC, c.data(), c.size() * 8, hipMemcpyHostToDevice);
     hipLaunchKernelGGL(sums, dim3(n), dim3(64), 0, 0, dA, dC, dOut, n);
     hipMemcpy(got.data(), dOut, got.size() * 8, hipMemcpyDeviceToHost);
-    long fwd = 0, rev = 0, exact = 0, total = 0;
+    long fwd = 0, rev = 0, exact = 0, total = 0, special = 0, specialOk = 0;
     for (int t = 0; t < n; ++t)
         for (int l = 0; l < 64; ++l) {
             const double* at = &a[(size_t)t * 64];
@@ -96,9 +109,11 @@ int main() {
             volatile double r = cc; r = r + x3; r = r + x2; r = r + x1; r = r + x0;
             const long double e = (long double)cc + x0 + x1 + x2 + x3;  // (80-bit: not exact, an indication only)
             const double g = got[(size_t)t * 64 + l];
-            ++total, fwd += std::memcmp(&g, (const void*)&f, 8) == 0, rev += std::memcmp(&g, (const void*)&r, 8) == 0, exact += g == (double)e;
+            if (t >= 1 && t < 64) special += 1, specialOk += std::memcmp(&g, (const void*)&f, 8) == 0 || (g != g && f != f);
+            ++total, fwd += std::memcmp(&g, (const void*)&f, 8) == 0 || (g != g && f != f), rev += std::memcmp(&g, (const void*)&r, 8) == 0, exact += g == (double)e;
         }
     std::printf("%ld sums: equal to c + a0 + a1 + a2 + a3 in lane order %ld, in reverse order %ld, to the (80-bit) sum rounded once %ld\n", total, fwd, rev, exact);
+    std::printf("of them %ld with signed zeros, subnormal and near-overflow operands and totals: %ld equal to the sequential sum (NaN = NaN)\n", special, specialOk);
     std::printf("adversarial (c = 1, four terms of 2^-53): got %.17g  (sequential: 1, exact: 1.0000000000000004)\n", got[0]);
     for (int iters : {1024, 4096}) {
         unsigned long long tk = 0;
