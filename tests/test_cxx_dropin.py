@@ -372,3 +372,82 @@ def test_multi_gpu_example_runs_on_the_gpus_present(H, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "blocks identical to the single-GPU build" in r.stdout, r.stdout
+
+
+DEFAULT_CONFIG_SRC = r'''
+// The first thing a user of the drop-in writes: SDF::Config cfg; tree.Create(cfg, F) -- the reference's default-constructed Config
+// (Source/HP/Config.cpp:5-14: 1e-10, continuity on) on the reference's own test field (HPUnitTests.cpp:48-51).  The reference does not
+// finish this build (SURVEY 6: 900 s and counting); here it is refused by the default build limits within seconds, with a status of its
+// own and a message that says how far it got; with a limit on nodes it is refused earlier; a reachable threshold builds as ever, and
+// two Octrees of one process follow two reduction orders.
+#include "HP/Octree.h"
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+int main() {
+    try {
+        const auto field = SDF::DeviceField::Sphere(0.25, 0, 0, 0.5);
+        SDF::Config cfg;   // the defaults, as they stand
+        if (cfg.targetErrorThreshold != 1e-10 || !cfg.continuity.enforce) { printf("defaults\n"); return 2; }
+        SDF::Octree tree;
+        const auto t0 = std::chrono::steady_clock::now();
+        int status = 0;
+        std::string what;
+        try {
+            tree.Create(cfg, field);
+        } catch (const SDF::Error& e) {
+            status = e.status, what = e.what();
+        }
+        const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        printf("default Config(): status %d after %.2f s: %s\n", status, secs, what.c_str());
+        if (status != HPSDF_ERR_BUILD_LIMIT || what.find("nodes") == std::string::npos || what.find("hpsdf_ctx_set_build_limits") == std::string::npos) return 3;
+        if (secs > 20.0) return 4;
+        tree.SetBuildLimits(10000, 0);   // a bound on nodes: the same build stops at the round that crosses it
+        status = 0;
+        try {
+            tree.Create(cfg, field);
+        } catch (const SDF::Error& e) {
+            status = e.status, what = e.what();
+        }
+        if (status != HPSDF_ERR_BUILD_LIMIT || what.find("(limit 10000)") == std::string::npos) { printf("node limit: %d %s\n", status, what.c_str()); return 5; }
+        cfg.targetErrorThreshold = 1e-8;   // reachable: builds under the same limits, continuity included
+        tree.Create(cfg, field);
+        const double q = tree.Query(Eigen::Vector3d(0.1, -0.2, 0.3));
+        if (!(std::fabs(q - (std::sqrt(0.15 * 0.15 + 0.2 * 0.2 + 0.3 * 0.3) - 0.5)) < 1e-2)) { printf("accuracy %g\n", q); return 6; }
+        // two Octrees, two reduction orders, one process
+        SDF::Config c5;
+        c5.targetErrorThreshold = 1e-5, c5.continuity.enforce = false;
+        SDF::Octree a, b;
+        b.SetReductionOrderHere(1);
+        a.Create(c5, field), b.Create(c5, field);
+        MemoryBlock ma = a.ToMemoryBlock(), mb = b.ToMemoryBlock();
+        const bool differ = ma.size != mb.size || memcmp(ma.ptr, mb.ptr, ma.size) != 0;
+        SDF::Octree a2;
+        a2.Create(c5, field);
+        MemoryBlock ma2 = a2.ToMemoryBlock();
+        const bool same = ma.size == ma2.size && memcmp(ma.ptr, ma2.ptr, ma.size) == 0;
+        free(ma.ptr), free(mb.ptr), free(ma2.ptr);
+        if (!differ || !same) { printf("reduction orders: differ %d same %d\n", (int)differ, (int)same); return 7; }
+        printf("OK\n");
+        return 0;
+    } catch (const SDF::Error& e) {
+        printf("SDF::Error %d: %s\n", e.status, e.what());
+        return e.status == HPSDF_ERR_NO_DEVICE ? 42 : 1;
+    }
+}
+'''
+
+
+@pytest.mark.gpu
+def test_default_config_is_refused_with_a_status_of_its_own(H, tmp_path):
+    src, exe = str(tmp_path / "dflt.cpp"), str(tmp_path / "dflt")
+    open(src, "w").write(DEFAULT_CONFIG_SRC)
+    libdir = os.path.dirname(H.LIB_PATH)
+    cmd = ["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"), src, "-o", exe, "-L", libdir,
+           "-lhpsdf", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-pthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
