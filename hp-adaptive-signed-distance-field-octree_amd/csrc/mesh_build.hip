@@ -225,16 +225,85 @@ __device__ __forceinline__ float mbWaveMax(float v) {
     for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
     return v;
 }
+// One child's slab from its triangles [a, b] (sorted slots), by the NT threads that call this together: NT = 64, one wave (children of
+// up to kSlabWaveTris triangles: mb_slab_kernel), or NT = 1024, a whole workgroup (larger children, mb_slab_big_kernel: one wave
+// walking 131 072 triangles twice was 2.7 ms of a 3.5 ms preparation, alone on its CU).  sRed: 16 x 3 floats of LDS (NT = 1024).
+template <int NT>
+__device__ __forceinline__ void mbChildSlab(const uint32_t* __restrict__ slotTri, const float* __restrict__ triPos, int a, int b, const float* blo,
+                                            const float* bhi, float* sRed, float4* og_, float4* on_) {
+    const int tid = threadIdx.x % NT, lane = threadIdx.x & 63;
+    const float inf = __builtin_inff();
+    const float cx = 0.5f * (blo[0] + bhi[0]), cy = 0.5f * (blo[1] + bhi[1]), cz = 0.5f * (blo[2] + bhi[2]);
+    auto sum3 = [&](float& x, float& y, float& z) {
+        x = mbWaveSum(x), y = mbWaveSum(y), z = mbWaveSum(z);
+        if constexpr (NT > 64) {
+            __syncthreads();
+            if (lane == 0) sRed[3 * (threadIdx.x >> 6)] = x, sRed[3 * (threadIdx.x >> 6) + 1] = y, sRed[3 * (threadIdx.x >> 6) + 2] = z;
+            __syncthreads();
+            x = y = z = 0.0f;
+            for (int w = 0; w < NT / 64; ++w) x += sRed[3 * w], y += sRed[3 * w + 1], z += sRed[3 * w + 2];  // (every thread, the same order)
+        }
+    };
+    auto max3 = [&](float& x, float& y, float& z) {
+        x = mbWaveMax(x), y = mbWaveMax(y), z = mbWaveMax(z);
+        if constexpr (NT > 64) {
+            __syncthreads();
+            if (lane == 0) sRed[3 * (threadIdx.x >> 6)] = x, sRed[3 * (threadIdx.x >> 6) + 1] = y, sRed[3 * (threadIdx.x >> 6) + 2] = z;
+            __syncthreads();
+            x = y = z = -inf;
+            for (int w = 0; w < NT / 64; ++w) x = fmaxf(x, sRed[3 * w]), y = fmaxf(y, sRed[3 * w + 1]), z = fmaxf(z, sRed[3 * w + 2]);
+        }
+    };
+    float nx = 0.0f, ny = 0.0f, nz = 0.0f;
+    for (int s = a + tid; s <= b; s += NT) {
+        const float* p = triPos + (size_t)kTriRecordFloats * slotTri[s];
+        nx += p[9], ny += p[10], nz += p[11];
+    }
+    sum3(nx, ny, nz);
+    const float len = sqrtf(nx * nx + (ny * ny + nz * nz));
+    if (len > 0.0f && len < inf) {
+        nx /= len, ny /= len, nz /= len;
+        if (!(fabsf(nx * nx + (ny * ny + nz * nz) - 1.0f) <= 1e-6f)) nx = ny = nz = 0.0f;
+    } else {
+        nx = ny = nz = 0.0f;
+    }
+    // one pass over the vertices: the range of n . (v - c) and the largest |v - c|, c the centre of the child's box
+    float tminNeg = -inf, tmax = -inf, r2 = 0.0f;
+    for (int s = a + tid; s <= b; s += NT) {
+        const float* p = triPos + (size_t)kTriRecordFloats * slotTri[s];
+        for (int v = 0; v < 3; ++v) {
+            const float dx = p[3 * v] - cx, dy = p[3 * v + 1] - cy, dz = p[3 * v + 2] - cz;
+            const float t = nx * dx + (ny * dy + nz * dz);
+            tminNeg = fmaxf(tminNeg, -t), tmax = fmaxf(tmax, t);
+            r2 = fmaxf(r2, dx * dx + (dy * dy + dz * dz));
+        }
+    }
+    max3(tminNeg, tmax, r2);
+    const float tmin = -tminNeg;
+    // g in the middle of the slab.  With g = c + mid n (rounded: each coordinate off by <= u |g_i|, u = 2^-24):
+    //   n . (v - g) = n . (v - c) - mid |n|^2 - n . (rounding of g)   =>  |n . (v - g)| <= (tmax - tmin) / 2 + 4 u |v - c| + 6 u |mid| + 2 u M
+    //   |v - g| <= |v - c| + |mid| (1 + 3 u) + 2 u M                      (M: the largest coordinate around here)
+    // -- both widened by 1e-5 of themselves and 4e-7 of the local scale, i.e. twice what the terms above come to
+    const float mid = 0.5f * (tmin + tmax), rc = sqrtf(r2);
+    const float gx = cx + mid * nx, gy = cy + mid * ny, gz = cz + mid * nz;
+    const float local = fmaxf(fmaxf(fabsf(cx), fabsf(cy)), fabsf(cz)) + rc;
+    const float e = (0.5f * (tmax - tmin)) * 1.00001f + 4e-7f * local;
+    const float rho = (rc + fabsf(mid)) * 1.00001f + 4e-7f * local;
+    if (rho < inf && e < inf && gx - gx == 0.0f && gy - gy == 0.0f && gz - gz == 0.0f) {  // (non-finite input: no bound)
+        *og_ = make_float4(gx, gy, gz, rho);
+        *on_ = make_float4(nx, ny, nz, e);
+    }
+}
+constexpr int kSlabWaveTris = 1024;  // children of more triangles than this go to mb_slab_big_kernel's list
 __global__ __launch_bounds__(256) void mb_slab_kernel(const int32_t* __restrict__ ranges, const uint32_t* __restrict__ slotTri,
                                                       const float* __restrict__ triPos, int n, int leafTris, const BvhNode* __restrict__ nodes,
-                                                      NodeSlab* __restrict__ slabs) {
+                                                      NodeSlab* __restrict__ slabs, uint32_t* __restrict__ bigList, uint32_t bigCap) {
     const int node = (int)(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (node >= n - 1) return;
     const int lane = threadIdx.x & 63;
     const int lo = ranges[3 * (size_t)node], gamma = ranges[3 * (size_t)node + 1], hi = ranges[3 * (size_t)node + 2];
     if (node != 0 && hi - lo + 1 <= leafTris) return;  // below a leaf: nothing refers to this node (the root is always visited)
     const BvhNode& nd = nodes[node];
-    const float inf = __builtin_inff();
     for (int child = 0; child < 2; ++child) {
         const int a = child ? gamma + 1 : lo, b = child ? hi : gamma;
         const float* blo = child ? nd.lo1 : nd.lo0;
@@ -243,45 +312,12 @@ __global__ __launch_bounds__(256) void mb_slab_kernel(const int32_t* __restrict_
         // (no slab: the ball around the box, and e = -1 tells the walk to leave the test out)
         const float hx = 0.5f * (bhi[0] - blo[0]), hy = 0.5f * (bhi[1] - blo[1]), hz = 0.5f * (bhi[2] - blo[2]);
         float4 og = make_float4(cx, cy, cz, sqrtf(hx * hx + (hy * hy + hz * hz)) * 1.00001f + 1e-30f), on = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
-        if (b - a + 1 <= kSlabMaxTris) {
-            float nx = 0.0f, ny = 0.0f, nz = 0.0f;
-            for (int s = a + lane; s <= b; s += 64) {
-                const float* p = triPos + (size_t)kTriRecordFloats * slotTri[s];
-                nx += p[9], ny += p[10], nz += p[11];
-            }
-            nx = mbWaveSum(nx), ny = mbWaveSum(ny), nz = mbWaveSum(nz);
-            const float len = sqrtf(nx * nx + (ny * ny + nz * nz));
-            if (len > 0.0f && len < inf) {
-                nx /= len, ny /= len, nz /= len;
-                if (!(fabsf(nx * nx + (ny * ny + nz * nz) - 1.0f) <= 1e-6f)) nx = ny = nz = 0.0f;
-            } else {
-                nx = ny = nz = 0.0f;
-            }
-            // one pass over the vertices: the range of n . (v - c) and the largest |v - c|, c the centre of the child's box
-            float tmin = inf, tmax = -inf, r2 = 0.0f;
-            for (int s = a + lane; s <= b; s += 64) {
-                const float* p = triPos + (size_t)kTriRecordFloats * slotTri[s];
-                for (int v = 0; v < 3; ++v) {
-                    const float dx = p[3 * v] - cx, dy = p[3 * v + 1] - cy, dz = p[3 * v + 2] - cz;
-                    const float t = nx * dx + (ny * dy + nz * dz);
-                    tmin = fminf(tmin, t), tmax = fmaxf(tmax, t);
-                    r2 = fmaxf(r2, dx * dx + (dy * dy + dz * dz));
-                }
-            }
-            tmin = -mbWaveMax(-tmin), tmax = mbWaveMax(tmax), r2 = mbWaveMax(r2);
-            // g in the middle of the slab.  With g = c + mid n (rounded: each coordinate off by <= u |g_i|, u = 2^-24):
-            //   n . (v - g) = n . (v - c) - mid |n|^2 - n . (rounding of g)   =>  |n . (v - g)| <= (tmax - tmin) / 2 + 4 u |v - c| + 6 u |mid| + 2 u M
-            //   |v - g| <= |v - c| + |mid| (1 + 3 u) + 2 u M                      (M: the largest coordinate around here)
-            // -- both widened by 1e-5 of themselves and 4e-7 of the local scale, i.e. twice what the terms above come to
-            const float mid = 0.5f * (tmin + tmax), rc = sqrtf(r2);
-            const float gx = cx + mid * nx, gy = cy + mid * ny, gz = cz + mid * nz;
-            const float local = fmaxf(fmaxf(fabsf(cx), fabsf(cy)), fabsf(cz)) + rc;
-            float e = (0.5f * (tmax - tmin)) * 1.00001f + 4e-7f * local;
-            const float rho = (rc + fabsf(mid)) * 1.00001f + 4e-7f * local;
-            if (rho < inf && e < inf && gx - gx == 0.0f && gy - gy == 0.0f && gz - gz == 0.0f) {  // (non-finite input: no bound)
-                og = make_float4(gx, gy, gz, rho);
-                on = make_float4(nx, ny, nz, e);
-            }
+        const int count = b - a + 1;
+        if (count <= kSlabWaveTris) {
+            mbChildSlab<64>(slotTri, triPos, a, b, blo, bhi, nullptr, &og, &on);
+        } else if (count <= kSlabMaxTris && bigList != nullptr && lane == 0) {
+            const uint32_t at = atomicAdd(bigList, 1u);  // (a whole workgroup takes it, behind this kernel: the record below stands until then, and if the list is full)
+            if (at < bigCap) bigList[1u + at] = (uint32_t)node * 2u + (uint32_t)child;
         }
         if (lane == 0) {
             if (child)
@@ -289,6 +325,26 @@ __global__ __launch_bounds__(256) void mb_slab_kernel(const int32_t* __restrict_
             else
                 slabs[node].g0 = og, slabs[node].n0 = on;
         }
+    }
+}
+__global__ __launch_bounds__(1024) void mb_slab_big_kernel(const int32_t* __restrict__ ranges, const uint32_t* __restrict__ slotTri,
+                                                           const float* __restrict__ triPos, const BvhNode* __restrict__ nodes,
+                                                           NodeSlab* __restrict__ slabs, const uint32_t* __restrict__ bigList, uint32_t bigCap) {
+    __shared__ float sRed[3 * 16];
+    const uint32_t have = bigList[0] < bigCap ? bigList[0] : bigCap;
+    if (blockIdx.x >= have) return;
+    const uint32_t entry = bigList[1u + blockIdx.x];
+    const int node = (int)(entry >> 1), child = (int)(entry & 1u);
+    const int lo = ranges[3 * (size_t)node], gamma = ranges[3 * (size_t)node + 1], hi = ranges[3 * (size_t)node + 2];
+    const int a = child ? gamma + 1 : lo, b = child ? hi : gamma;
+    const BvhNode& nd = nodes[node];
+    float4 og = child ? slabs[node].g1 : slabs[node].g0, on = child ? slabs[node].n1 : slabs[node].n0;  // (the ball, "no slab": kept if the input is not finite)
+    mbChildSlab<1024>(slotTri, triPos, a, b, child ? nd.lo1 : nd.lo0, child ? nd.hi1 : nd.hi0, sRed, &og, &on);
+    if (threadIdx.x == 0) {
+        if (child)
+            slabs[node].g1 = og, slabs[node].n1 = on;
+        else
+            slabs[node].g0 = og, slabs[node].n0 = on;
     }
 }
 
@@ -412,7 +468,9 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
     uint64_t* dTris64 = nullptr;
     float* dTriBox = nullptr;
     uint64_t *dKeys = nullptr, *dKeysOut = nullptr;
-    uint32_t *dIds = nullptr, *dIdsOut = nullptr, *dArrived = nullptr, *dTabVal = nullptr;
+    uint32_t *dIds = nullptr, *dIdsOut = nullptr, *dArrived = nullptr, *dTabVal = nullptr, *dBigList = nullptr;
+    // children of more than 1024 triangles (mb_slab_big_kernel's list): disjoint on every level of the tree -- a few thousand on millions of triangles
+    const uint32_t bigCap = (uint32_t)std::min<uint64_t>(65535, 8 * (nTris / 1024) + 64);
     unsigned long long* dTabKey = nullptr;
     int32_t *dParent = nullptr, *dRanges = nullptr;
     MeshBuildFlags* dFlags = nullptr;
@@ -443,6 +501,7 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
                      oI2 = carve(tb, nTris * sizeof(uint32_t)), oArr = carve(tb, nTris * sizeof(uint32_t)),
                      oPar = carve(tb, 2 * nTris * sizeof(int32_t)), oRan = carve(tb, 3 * nTris * sizeof(int32_t)), oTK = carve(tb, tabSize * sizeof(unsigned long long)),
                      oTV = carve(tb, tabSize * sizeof(uint32_t)), oFl = carve(tb, sizeof(MeshBuildFlags)),
+                     oBig = carve(tb, ((size_t)bigCap + 1) * sizeof(uint32_t)),
                      oSort = carve(tb, sortTmpBytes ? sortTmpBytes : 16);
         // Both blocks come from a stream-ordered pool of the library's OWN (meshPool: the application's default pool and its
         // attributes are left alone), which keeps up to a bounded amount of what is freed: a plain hipMalloc of a few hundred
@@ -475,6 +534,7 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
             dKeysOut = (uint64_t*)(tempBlock + oK2), dIds = (uint32_t*)(tempBlock + oI), dIdsOut = (uint32_t*)(tempBlock + oI2);
             dArrived = (uint32_t*)(tempBlock + oArr), dParent = (int32_t*)(tempBlock + oPar), dTabKey = (unsigned long long*)(tempBlock + oTK);
             dTabVal = (uint32_t*)(tempBlock + oTV), dFlags = (MeshBuildFlags*)(tempBlock + oFl), dSortTmp = tempBlock + oSort;
+            dBigList = (uint32_t*)(tempBlock + oBig);
         }
     }
     auto freeTemps = [&] {
@@ -499,6 +559,7 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
     }
     if (e == hipSuccess) e = hipMemsetAsync(dTabKey, 0xFF, tabSize * sizeof(unsigned long long), s);
     if (e == hipSuccess) e = hipMemsetAsync(dArrived, 0, nTris * sizeof(uint32_t), s);
+    if (e == hipSuccess) e = hipMemsetAsync(dBigList, 0, sizeof(uint32_t), s);
     if (e != hipSuccess) {
         freeTemps(), freeField();
         return hipFail(e, "mesh preparation buffers");
@@ -548,9 +609,12 @@ int meshBuildDevice(hpsdf_ctx* ctx, const float* verts, uint64_t nVerts, const u
     if (e == hipSuccess) e = launchMeshTriPos(s, f->dVerts, f->dTris, nTris, nullptr, dIdsOut, f->dTriPre);  // slot order = sorted order
     hipLaunchKernelGGL(mb_hierarchy_kernel, dim3(gt), dim3(256), 0, s, dKeysOut, n, leafTris, f->dBvh, dParent, dRanges);
     hipLaunchKernelGGL(mb_fit_kernel, dim3(gt), dim3(256), 0, s, dIdsOut, dTriBox, n, f->dBvh, dParent, dArrived);
-    if (!noSlabs)
+    if (!noSlabs) {
         hipLaunchKernelGGL(mb_slab_kernel, dim3((unsigned)((n - 1 + 3) / 4)), dim3(256), 0, s, dRanges, dIdsOut, f->dTriPos, n, leafTris, f->dBvh,
-                           f->dSlabs);
+                           f->dSlabs, dBigList, bigCap);
+        // children of more than kSlabWaveTris triangles: a workgroup each, from the list the kernel above wrote (the grid is its capacity)
+        hipLaunchKernelGGL(mb_slab_big_kernel, dim3(bigCap), dim3(1024), 0, s, dRanges, dIdsOut, f->dTriPos, f->dBvh, f->dSlabs, dBigList, bigCap);
+    }
     if (es != s) {
         // join: everything behind this point on s (the flags' download, the temporaries' stream-ordered release) is behind the twin search too
         hipError_t je = joined ? hipStreamWaitEvent(s, side.join, 0) : hipErrorUnknown;
