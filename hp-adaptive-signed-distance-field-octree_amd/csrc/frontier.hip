@@ -73,7 +73,6 @@ constexpr uint32_t kFrExact = 64;   // candidates left when the digit-by-digit r
 // enters the exchange all the same; the round kernel's leader finds it (frPeerCheck) and every rank leaves with an error instead of
 // waiting in a later collective for a rank that has gone.
 constexpr uint32_t kFrStatusPad = 8;
-constexpr uint32_t kStoreParts = 4;  // fr_store_kernel hands the coefficients over in so many runs of positions, one flag each
 
 struct FrHdr {
     uint32_t nNodes, nQueued, nJobs, done;
@@ -105,15 +104,14 @@ struct FrHdr {
     uint32_t chainStamp;  // round + 1 once rTotal holds that round's running total
     uint32_t landed;      // (mirror only) the build's stamp, written when round 0's closing launch starts: the fit before it has finished, so
                           // the rows it wrote into pinned host memory are there
-    uint32_t stored[1 + kStoreParts];   // (mirror only) the build's stamp once fr_store_kernel's node array / the coefficients of one part of the
-                                        // store (positions [part n / kStoreParts, (part + 1) n / kStoreParts)) are in pinned host memory
-    uint32_t storeArrive[1 + kStoreParts];  // workgroups of fr_store_kernel that have finished a phase
+    uint32_t stored[2];   // (mirror only) the build's stamp once fr_store_kernel's node array / coefficients are in pinned host memory
+    uint32_t storeArrive[2];  // workgroups of fr_store_kernel that have finished a phase
     uint32_t hist1[2048];  // queued nodes per exponent bin (kept by update / batch)
     uint32_t hist2[2048];  // level-1 digits of the candidates of the current selection (grid selection only)
     uint64_t agg[kFrJobs / 128];  // fr_round_kernel: per update workgroup {round stamp, splitting jobs << 16 | P jobs}
 };
 constexpr size_t kFrHdrCopyBytes = offsetof(FrHdr, hist1);
-static_assert(kFrHdrCopyBytes / 4 <= 1024 && offsetof(FrHdr, hist1) % 8 == 0, "frMirror copies the header with one thread a word; hist1 follows the 64-bit fields' alignment");
+static_assert(kFrHdrCopyBytes / 4 <= 1024, "frMirror copies the header with one thread a word");
 static inline void frCpuRelax() {  // the host's spin on the header mirror
 #if defined(__x86_64__) || defined(__i386__)
     __builtin_ia32_pause();
@@ -441,29 +439,6 @@ __device__ __forceinline__ uint32_t frErrSlotNext(const FrDev& d, const uint32_t
 }
 __device__ __forceinline__ double* frStatusSlotNext(const FrDev& d, int r) { return d.errs + (size_t)r * d.errStrideNext + (d.errStrideNext - 1u); }
 
-// One LDS atomic a wave and word instead of one a lane.  A round's jobs fall into a handful of shape classes and exponent bins, so the
-// lanes of a wave mostly add to the same few words, and the LDS takes same-word atomics one lane after the other: 8192 jobs' three
-// additions each were most of the batch's longest phase.  The lanes that share a word take consecutive places behind ONE addition by
-// the first of them.  Every lane of the wave calls (inactive ones with active = false); returns the word's value before this lane's
-// addition.
-__device__ __forceinline__ uint32_t frWaveAdd(uint32_t* words, uint32_t key, bool active, uint32_t step) {
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t mine = 0;
-    unsigned long long left = __ballot(active);
-    while (left) {
-        const int first = __ffsll((long long)left) - 1;
-        const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, first);
-        const bool hit = active && key == k0;
-        const unsigned long long m = __ballot(hit);
-        uint32_t old = 0;
-        if (lane == (uint32_t)first) old = atomicAdd(&words[k0], step * (uint32_t)__popcll(m));
-        old = (uint32_t)__builtin_amdgcn_readlane((int)old, first);
-        if (hit) mine = old + step * (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        left &= ~m;
-    }
-    return mine;
-}
-
 // From the selection's level 0 to the round's shape classes.  nQ: queued nodes; above / cand / taken: level 0's counts
 // (nodes in exponent bins above the threshold bin -- already in d.taken --, candidates in d.candA, entries of d.taken).
 // INLINE (fr_round_kernel's workgroup 0, which has just run level 0 itself: L.hist holds the level-1 digits of the
@@ -641,24 +616,20 @@ __device__ bool frBatchBody(const FrDev& d, FrLds& L, uint32_t nQ, uint32_t abov
             const hpsdf_node& n = d.nodes[jIdx[q]];
             jP[q] = n.degree, jDep[q] = n.depth;
         }
-        FR_STAMP(17);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint32_t j = tid * 4u + (uint32_t)q;
-            const bool live = j < nJobs;
+            if (j >= nJobs) continue;
             const uint32_t idx = jIdx[q];
             const uint64_t bits = jBits[q];
             const double e = __longlong_as_double((long long)bits);
-            if (live) {
-                d.wBatchIdx[j] = idx;
-                d.wBatchErr[j] = e;
-                d.qErr[idx] = kNotQueued;
-                jCoarse[q] = fabs(e - HPSDF_INITIAL_NODE_ERR) < DBL_EPSILON;  // coarse, Octree.cpp:806,831
-                own += frJobCost(jP[q], jDep[q], jCoarse[q]);
-            }
-            (void)frWaveAdd(sHist, live ? frDigit(0, bits, idx) : 0u, live, 1u);
+            d.wBatchIdx[j] = idx;
+            d.wBatchErr[j] = e;
+            d.qErr[idx] = kNotQueued;
+            atomicAdd(&sHist[frDigit(0, bits, idx)], 1u);
+            jCoarse[q] = fabs(e - HPSDF_INITIAL_NODE_ERR) < DBL_EPSILON;  // coarse, Octree.cpp:806,831
+            own += frJobCost(jP[q], jDep[q], jCoarse[q]);
         }
-        FR_STAMP(18);
         if (d.world > 1) {
             // inclusive scan of the costs (wave shuffles, then the 16 wave totals), slice ends by binary search
             uint64_t inc = own;
@@ -718,9 +689,9 @@ __device__ bool frBatchBody(const FrDev& d, FrLds& L, uint32_t nQ, uint32_t abov
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint32_t j = tid * 4u + (uint32_t)q;
-            const bool live = j < nJobs;
+            if (j >= nJobs) continue;
             uint32_t o = 0;
-            if (live && d.world > 1) {
+            if (d.world > 1) {
                 for (int r = 1; r < d.world; ++r) o += L.slice[r] <= j ? 1u : 0u;
                 d.jobOwner[j] = (uint8_t)o;
             }
@@ -731,20 +702,17 @@ __device__ bool frBatchBody(const FrDev& d, FrLds& L, uint32_t nQ, uint32_t abov
                 // every job takes its place in its OWNER's lists, and the same place on every rank -- the arena is laid out alike
                 // everywhere -- so not by an atomic's luck: the keys wait in LDS and one wave hands the slots out in job order (below)
                 const uint32_t none = 0xFFFFu, base = o * (uint32_t)kFrClasses;
-                if (live) {
-                    sKeyH[j] = (uint16_t)((!jCoarse[q] && dep < kMaxDepth) ? base + (uint32_t)frClass(p, false, dep + 1) : none);
-                    sKeyP[j] = (uint16_t)(jCoarse[q] ? base + (uint32_t)frClass(2, false, dep) : (p < kMaxDegree - 1 ? base + (uint32_t)frClass(p + 1, true, dep) : none));
+                sKeyH[j] = (uint16_t)((!jCoarse[q] && dep < kMaxDepth) ? base + (uint32_t)frClass(p, false, dep + 1) : none);
+                sKeyP[j] = (uint16_t)(jCoarse[q] ? base + (uint32_t)frClass(2, false, dep) : (p < kMaxDegree - 1 ? base + (uint32_t)frClass(p + 1, true, dep) : none));
+            } else if (ours) {
+                if (jCoarse[q]) {
+                    slotP = atomicAdd(&sCount[frClass(2, false, dep)], 1u);  // :836-843
+                } else {
+                    if (dep < kMaxDepth) slotH = atomicAdd(&sCount[frClass(p, false, dep + 1)], 8u);     // :814-822
+                    if (p < kMaxDegree - 1) slotP = atomicAdd(&sCount[frClass(p + 1, true, dep)], 1u);  // :846-851
                 }
-            } else {
-                // (whole waves: the lanes that share a class share the addition, frWaveAdd)
-                const bool wantH = live && ours && !jCoarse[q] && dep < kMaxDepth;                 // :814-822
-                const bool wantP = live && ours && (jCoarse[q] || p < kMaxDegree - 1);             // :836-843 (coarse), :846-851
-                const uint32_t keyH = wantH ? (uint32_t)frClass(p, false, dep + 1) : 0u;
-                const uint32_t keyP = wantP ? (uint32_t)(jCoarse[q] ? frClass(2, false, dep) : frClass(p + 1, true, dep)) : 0u;
-                slotH = frWaveAdd(sCount, keyH, wantH, 8u);
-                slotP = frWaveAdd(sCount, keyP, wantP, 1u);
             }
-            if (live && (INLINE || d.replica)) {
+            if (INLINE || d.replica) {
                 sJobA[j] = slotH | (slotP << 16) | ((uint32_t)p << 28);
                 sJobB[j] = (uint16_t)((jCoarse[q] ? 1u : 0u) | (ours ? 2u : 0u) | (o << 2) | ((uint32_t)dep << 5));
             }
@@ -1298,12 +1266,10 @@ __device__ void frUpdateJobs(const FrDev& d, FrLds& L) {
             if (coarse || d.weighted) d.segFirst[idx] = (uint8_t)np;
             d.segOff[(size_t)idx * kFrSegs + (np - first)] = (d.jobP[j] & kOffMask) | ((uint64_t)(d.replica ? 0u : owner) << 56);
             d.nodes[idx].degree = (uint8_t)np;
-            d.qErr[idx] = (uint64_t)__double_as_longlong(pErr);
+            const uint64_t bits = (uint64_t)__double_as_longlong(pErr);
+            d.qErr[idx] = bits;
+            atomicAdd(&L.hist[frDigit(0, bits, idx)], 1u);
         }
-    }
-    {   // (the node's new place in the exponent histogram: whole waves, frWaveAdd)
-        const bool requeued = apply && kind == 1 && sub == 0;
-        (void)frWaveAdd(L.hist, requeued ? frDigit(0, (uint64_t)__double_as_longlong(pErr), idx) : 0u, requeued, 1u);
     }
     {   // :262-279, :286-290; Octree::Subdivide :1115-1128 -- the eight children of a splitting job are eight consecutive nodes:
         // lane `sub` makes child `sub`, the wave stores its 64 records in order (frStoreRecords)
@@ -1328,14 +1294,15 @@ __device__ void frUpdateJobs(const FrDev& d, FrLds& L) {
             d.sub[ch] = 0;
             d.segFirst[ch] = (uint8_t)p;
             d.segOff[(size_t)ch * kFrSegs] = ((d.jobH[j] + (uint64_t)sub * frCoef(p)) & kOffMask) | ((uint64_t)(d.replica ? 0u : owner) << 56);
-            d.qErr[ch] = (uint64_t)__double_as_longlong(e);
+            const uint64_t bits = (uint64_t)__double_as_longlong(e);
+            d.qErr[ch] = bits;
+            atomicAdd(&L.hist[frDigit(0, bits, ch)], 1u);
             if (sub == 0) {
                 d.nodes[idx].child_idx = c0;
                 d.nodes[idx].degree = kInteriorDegree;
                 d.nodes[idx].coeffs_start = 0;
             }
         }
-        (void)frWaveAdd(L.hist, split ? frDigit(0, (uint64_t)__double_as_longlong(e), ch) : 0u, split, 1u);
     }
     __syncthreads();
     for (uint32_t i = tid; i < 2048; i += 1024)
@@ -1354,7 +1321,7 @@ __device__ __forceinline__ void frMirror(const FrDev& d) {
     constexpr uint32_t kRoundWord = offsetof(FrHdr, round) / 4;
     __syncthreads();  // (the header's writers have drained their stores; the copy reads past the L1)
     constexpr uint32_t kLandedWord = offsetof(FrHdr, landed) / 4;  // (landed and stored[] live in the mirror alone)
-    if (tid < kFrHdrCopyBytes / 4 && tid != kRoundWord && (tid < kLandedWord || tid > kLandedWord + 1u + kStoreParts))
+    if (tid < kFrHdrCopyBytes / 4 && tid != kRoundWord && (tid < kLandedWord || tid > kLandedWord + 2))
         reinterpret_cast<volatile uint32_t*>(d.hostHdr)[tid] = reinterpret_cast<volatile uint32_t*>(d.hdr)[tid];
     __syncthreads();  // (... and the copying waves theirs)
     if (tid == 0) {
@@ -1776,43 +1743,34 @@ __global__ __launch_bounds__(256) void fr_store_kernel(FrDev d) {
         }
     }
     __syncthreads();
-    // ---- phase 2, every wave: a lane per row -- in kStoreParts passes over the workgroup's rows, pass q moving those whose place in the
-    //      store lies in [q n / kStoreParts, (q + 1) n / kStoreParts): every workgroup is resident from the start and the kernel is bound
-    //      by the link, so part q of the store is complete -- and flagged -- after about (q + 1) / kStoreParts of the kernel's time, and
-    //      the host moves it into the block while the parts behind it are still crossing (one flag for everything left the whole
-    //      copy, 1.2 MB for a 12 000-node tree, behind the kernel's end)
+    // ---- phase 2, every wave: a lane per row
     const uint32_t total = sRows[kStoreNodes];
-    for (uint32_t part = 0; part < kStoreParts; ++part) {
-        const uint64_t pLo = nCoeffs * part / kStoreParts, pHi = nCoeffs * (part + 1u) / kStoreParts;
-        for (uint32_t e = tid; e < total; e += 256u) {
-            uint32_t lo = 0, hi = kStoreNodes;  // the leaf whose rows hold element e: the last one with sRows[leaf] <= e
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (sRows[mid] <= e)
-                    lo = mid;
-                else
-                    hi = mid;
-            }
-            const uint32_t node = blockIdx.x * kStoreNodes + lo, r = e - sRows[lo];
-            const uint64_t at = (uint64_t)sStart[lo] + r;
-            if (at < pLo || at >= pHi) continue;
-            const int first = d.segFirst[node];
-            int sg = 0;  // the segment row r lies in: rows [coef(first + sg - 1), coef(first + sg))
-            while (r >= frCoef(first + sg)) ++sg;
-            const uint32_t r0 = sg == 0 ? 0u : frCoef(first + sg - 1);
-            const uint64_t so = d.segOff[(size_t)node * kFrSegs + sg];
-            // one rank: straight from the arena; several: from the all-gathered pack buffers (fr_pack_kernel)
-            const double* src = (d.world == 1 || d.replica) ? d.arena + (so & kOffMask) : d.pack + (size_t)(so >> 56) * d.packStride + d.packPos[(size_t)node * kFrSegs + sg];
-            d.store[at] = src[r - r0];
+    for (uint32_t e = tid; e < total; e += 256u) {
+        uint32_t lo = 0, hi = kStoreNodes;  // the leaf whose rows hold element e: the last one with sRows[leaf] <= e
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (sRows[mid] <= e)
+                lo = mid;
+            else
+                hi = mid;
         }
-        __syncthreads();  // (every wave's stores of this part have left)
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        const uint32_t node = blockIdx.x * kStoreNodes + lo, r = e - sRows[lo];
+        const int first = d.segFirst[node];
+        int sg = 0;  // the segment row r lies in: rows [coef(first + sg - 1), coef(first + sg))
+        while (r >= frCoef(first + sg)) ++sg;
+        const uint32_t r0 = sg == 0 ? 0u : frCoef(first + sg - 1);
+        const uint64_t so = d.segOff[(size_t)node * kFrSegs + sg];
+        // one rank: straight from the arena; several: from the all-gathered pack buffers (fr_pack_kernel)
+        const double* src = (d.world == 1 || d.replica) ? d.arena + (so & kOffMask) : d.pack + (size_t)(so >> 56) * d.packStride + d.packPos[(size_t)node * kFrSegs + sg];
+        d.store[(size_t)sStart[lo] + r] = src[r - r0];
+    }
+    __syncthreads();  // (every wave's stores have left)
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (atomicAdd(&h->storeArrive[1], 1u) == gridDim.x - 1u) {
+            *(volatile uint32_t*)&d.hostHdr->stored[1] = d.buildStamp;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (atomicAdd(&h->storeArrive[1u + part], 1u) == gridDim.x - 1u) {
-                *(volatile uint32_t*)&d.hostHdr->stored[1u + part] = d.buildStamp;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
         }
     }
 }
@@ -2788,7 +2746,6 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
             if (!hh->done && pre) {
                 std::fprintf(stderr, " | select %lld batch", (long long)(hh->dbg[0] - hh->dbg[11]));
                 for (int k = 1; k <= 8; ++k) std::fprintf(stderr, " %lld", (long long)(hh->dbg[k] - hh->dbg[k - 1]));
-                std::fprintf(stderr, " (jobs: records %lld leave %lld slots %lld)", (long long)(hh->dbg[17] - hh->dbg[3]), (long long)(hh->dbg[18] - hh->dbg[17]), (long long)(hh->dbg[4] - hh->dbg[18]));
                 std::fprintf(stderr, " | total+commit %lld", (long long)(hh->dbg[12] - hh->dbg[8]));
             }
             std::fprintf(stderr, " | chain %lld (first operands %lld, first 2048 additions %lld)", (long long)(hh->dbg[14] - hh->dbg[13]), (long long)(hh->dbg[15] - hh->dbg[13]),
@@ -2895,7 +2852,7 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
     std::memcpy(p, &nc, 8);
     std::memcpy(p + 8 + 8 * (size_t)nc, &nn, 8);
     std::memcpy(p + 16 + 8 * (size_t)nc + sizeof(hpsdf_node) * (size_t)nn, &cfg, sizeof cfg);
-    for (uint32_t part = 0; part <= kStoreParts; ++part) {  // 0: the node array; 1 ..: the coefficients, a run of positions each
+    for (int part = 0; part < 2; ++part) {  // 0: the node array, 1: the coefficients
         const volatile uint32_t* flag = &hh->stored[part];
         const double limit = now() + 2.0e3;
         while (*flag != d.buildStamp && now() < limit) frCpuRelax();
@@ -2907,12 +2864,10 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
             }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
-        if (part == 0) {
+        if (part == 0)
             std::memcpy(p + 16 + 8 * (size_t)nc, ws->pinned + 8 * (size_t)nc, sizeof(hpsdf_node) * (size_t)nn);
-        } else {
-            const uint64_t lo = nc * (part - 1u) / kStoreParts, hi = nc * part / kStoreParts;  // (fr_store_kernel's cut)
-            std::memcpy(p + 8 + 8 * (size_t)lo, ws->pinned + 8 * (size_t)lo, 8 * (size_t)(hi - lo));
-        }
+        else
+            std::memcpy(p + 8, ws->pinned, 8 * (size_t)nc);
     }
     const double tcopy = now() - tc;
     *block = p;
