@@ -237,7 +237,10 @@ HPSDF_API int hpsdf_field_release_host_copies(hpsdf_field* f);
  * edges' closest points, f32) takes its place.  Consequences: the four evaluation paths
  * below (naive scan, per-lane traversal, shared traversal, hpsdf_field_eval_*) agree BIT FOR BIT on every mesh; against the
  * reference's arithmetic they differ exactly at the points where its own value is such an artefact (6 points in 8 000 random
- * meshes x 5 301 points, all on meshes squashed 100 : 1 or more; tests/test_gpu_configs.py::test_needle_meshes_one_answer_on_every_path). */
+ * meshes x 5 301 points, all on meshes squashed 100 : 1 or more; tests/test_gpu_configs.py::test_needle_meshes_one_answer_on_every_path).
+ * At such a point the value is the distance to the triangle's boundary: at least the true distance, and above it by a fraction of the
+ * needle's width when the true closest point lies inside the needle (largest seen in the sweeps: 2.9e-4 of the mesh's extent, where the
+ * reference's value was 4e-3 of the extent BELOW the distance; tools/fuzz_mesh_bvh.py, seed 910968). */
 /* ... and the way back to the reference's values: hpsdf_set_mesh_face_rule(1) (process-wide, for launches prepared afterwards; the
  * environment variable HPSDF_MESH_FACE_RULE=reference sets it from the start) makes the closest-point routine return Utility.cpp:5-97's
  * face-case point unconditionally.  The O(n) scan (hpsdf_field_eval_naive_host) then equals the reference's Mesh::SignedDistanceAtPt(pt),
