@@ -728,6 +728,29 @@ def test_device_frontier_paths_agree(H, ctx, monkeypatch, env, target, K):
 
 
 @pytest.mark.gpu
+def test_round_one_launched_behind_round_zero_on_a_guess(H, O, monkeypatch):
+    """When a context's last build went on past round 0, the next build's second-round lists and fits are enqueued right behind round
+    0's closing launch (round 6).  The guess can be wrong either way: a build that stops after round 0 behind one that went on (two
+    empty launches), a build that goes on behind one that stopped (the ordinary wait), and builds that go on one after the other --
+    every block equals the one built with the guess switched off, on a fresh context, and the oracle's."""
+    f = H.Field.union3()
+    seq = [(1e-7, 1024), (1e-5, 1024), (1e-7, 256), (1e-6, 1024), (1e-5, 1024), (1e-5, 1024), (1e-7, 1024)]
+    monkeypatch.setenv("HPSDF_FRONTIER_NO_BLIND", "1")
+    c0 = H.Context(0)
+    want = {tk: H.create_block(c0, H.make_config(tk[0]), f, tk[1]) for tk in set(seq)}
+    c0.close()
+    monkeypatch.delenv("HPSDF_FRONTIER_NO_BLIND")
+    c = H.Context(0)
+    for tk in seq:
+        got, st = H.create_block(c, H.make_config(tk[0]), f, tk[1])
+        assert got == want[tk][0] and st == want[tk][1], tk
+        assert st["device_frontier"] == 1
+    c.close()
+    ot = O.Tree.create(O.default_config(1e-7), O.union3_field(), 1024)
+    assert want[(1e-7, 1024)][0] == ot.to_block()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("target,K", [(1e-7, 256), (1e-8, 1024)])
 def test_split_mode_schedulers_agree_byte_for_byte(H, monkeypatch, target, K):
     """HPSDF_FIT_SPLIT with the split forced from degree 2 (every from-scratch fit of these trees is split): whether a round splits
