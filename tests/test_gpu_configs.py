@@ -748,6 +748,24 @@ def test_round_one_launched_behind_round_zero_on_a_guess(H, O, monkeypatch):
     c.close()
     ot = O.Tree.create(O.default_config(1e-7), O.union3_field(), 1024)
     assert want[(1e-7, 1024)][0] == ot.to_block()
+    # ... and with a mesh field (the second round's samples are then launched on the guess too)
+    verts, tris = _mesh()
+    mseq = [1e-6, 1e-3, 1e-6, 1e-5]
+    monkeypatch.setenv("HPSDF_FRONTIER_NO_BLIND", "1")
+    c0 = H.Context(0)
+    m0 = H.Field.mesh(c0, verts, tris)
+    mwant = {t: H.create_block(c0, H.make_config(t, *MESH_ROOT), m0, MESH_K) for t in set(mseq)}
+    m0.close(), c0.close()
+    monkeypatch.delenv("HPSDF_FRONTIER_NO_BLIND")
+    c = H.Context(0)
+    m = H.Field.mesh(c, verts, tris)
+    rounds = []
+    for t in mseq:
+        got, st = H.create_block(c, H.make_config(t, *MESH_ROOT), m, MESH_K)
+        assert got == mwant[t][0] and st == mwant[t][1], t
+        rounds.append(st["rounds"])
+    assert rounds[0] > 1 and rounds[1] == 1, rounds  # (a build that goes on, then one that stops after round 0)
+    m.close(), c.close()
 
 
 @pytest.mark.gpu
