@@ -328,7 +328,8 @@ int builderCompute(hpsdf_build* b, hpsdf_ctx* ctx, const hpsdf_field* field) {
         if (!sampled && !meshSampled) samples = 0;  // (the hand-over buffer of split fits is optional: ensureSampleBuffer's failure makes the round exact)
         const uint64_t bytes = (b->arenaUsed + rows + std::min<uint64_t>(samples, 1ull << 31)) * sizeof(double);
         const uint64_t held = (ws.arenaCap + ws.meshSamplesCap) * sizeof(double);
-        const int lrc = checkBuildLimits(ctx, b->nodes.size(), bytes, held, &b->measuredLimit, b->stats.rounds, b->total, b->cfg.target_error_threshold);
+        const uint64_t growBytes = (b->arenaUsed + rows) * sizeof(double);  // (what grows with the tree: the default limit's subject)
+        const int lrc = checkBuildLimits(ctx, b->nodes.size(), bytes, growBytes, held, &b->measuredLimit, b->stats.rounds, b->total, b->cfg.target_error_threshold);
         if (lrc) return lrc;
     }
     if (meshSampled) {

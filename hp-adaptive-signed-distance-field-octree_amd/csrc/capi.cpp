@@ -71,10 +71,10 @@ int meshFaceRuleReference(const hpsdf_ctx* ctx) { return ctx && ctx->meshFaceRul
 void setMeshFaceRuleReference(int on) { gMeshFaceReference.store(on != 0, std::memory_order_relaxed); }
 float meshFaceTolOfSlack(const hpsdf_ctx* ctx) { return meshFaceRuleReference(ctx) ? std::numeric_limits<float>::infinity() : 0.25f; }
 
-uint64_t buildByteLimit(const hpsdf_ctx* ctx, uint64_t bytes, uint64_t held, uint64_t* measured) {
+uint64_t buildByteLimit(const hpsdf_ctx* ctx, uint64_t growBytes, uint64_t held, uint64_t* measured) {
     constexpr uint64_t kNone = ~0ull, kMeasureFrom = 256ull << 20;
     if (ctx->limitBytes) return ctx->limitBytes;
-    if (bytes <= kMeasureFrom) return kNone;  // (nothing is measured for builds that stay small: every BASELINE config)
+    if (growBytes <= kMeasureFrom) return kNone;  // (nothing is measured for builds that stay small: every BASELINE config)
     if (*measured == 0) {  // the default: 1/256 of what the device could give this build, at least 1 GiB
         size_t freeB = 0, totalB = 0;
         if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) {
@@ -85,20 +85,25 @@ uint64_t buildByteLimit(const hpsdf_ctx* ctx, uint64_t bytes, uint64_t held, uin
     }
     return *measured;
 }
-
-int checkBuildLimits(const hpsdf_ctx* ctx, uint64_t nodes, uint64_t bytes, uint64_t held, uint64_t* measured, uint64_t rounds, double total, double target) {
+// bytes: everything the round about to open needs on the device; growBytes: the part of it that grows with the tree (nodes, coefficient
+// arena).  A limit the caller set bounds `bytes`.  The DEFAULT exists to end a build that will not end by itself (the reference's default
+// Config()) in seconds instead of minutes, and bounds `growBytes` only: a round's sample buffer -- a mesh field's, K x up to 150 000
+// samples a job, at most 2^31 samples = 16 GiB whatever the tree's size -- is what an ordinary mesh build at K = 4096 needs (2.9 GiB at
+// degree 4) and says nothing about whether the build runs away.
+int checkBuildLimits(const hpsdf_ctx* ctx, uint64_t nodes, uint64_t bytes, uint64_t growBytes, uint64_t held, uint64_t* measured, uint64_t rounds, double total, double target) {
     constexpr uint64_t kNone = ~0ull;
     const uint64_t maxNodes = ctx->limitNodes ? ctx->limitNodes : kNone;
-    const uint64_t maxBytes = buildByteLimit(ctx, bytes, held, measured);
-    const char* how = ctx->limitBytes ? "hpsdf_ctx_set_build_limits" : "the default: 1/256 of the device memory that was free, at least 1 GiB";
-    if (nodes <= maxNodes && bytes <= maxBytes) return HPSDF_OK;
-    char msg[640];
+    const uint64_t maxBytes = buildByteLimit(ctx, growBytes, held, measured);
+    const uint64_t counted = ctx->limitBytes ? bytes : growBytes;
+    const char* how = ctx->limitBytes ? "hpsdf_ctx_set_build_limits" : "the default, on nodes and coefficients: 1/256 of the device memory that was free, at least 1 GiB";
+    if (nodes <= maxNodes && counted <= maxBytes) return HPSDF_OK;
+    char msg[704];
     std::snprintf(msg, sizeof msg,
                   "build limit: after %llu rounds the tree has %llu nodes (limit %s%llu) and the next round needs %.3f GiB of device memory (limit %.3f GiB, %s); "
                   "total error %.3e against the threshold %.3e -- the threshold may be below what the error estimate reaches on this field. "
                   "hpsdf_ctx_set_build_limits(ctx, max_nodes, max_bytes) raises the limits (UINT64_MAX: none)",
                   (unsigned long long)rounds, (unsigned long long)nodes, maxNodes == kNone ? "none, " : "", (unsigned long long)(maxNodes == kNone ? 0 : maxNodes),
-                  (double)bytes / (double)(1ull << 30), maxBytes == kNone ? 0.0 : (double)maxBytes / (double)(1ull << 30), maxBytes == kNone ? "none" : how, total, target);
+                  (double)counted / (double)(1ull << 30), maxBytes == kNone ? 0.0 : (double)maxBytes / (double)(1ull << 30), maxBytes == kNone ? "none" : how, total, target);
     return fail(HPSDF_ERR_BUILD_LIMIT, msg);
 }
 

@@ -2535,7 +2535,8 @@ int frontierCreate(hpsdf_ctx* ctx, const hpsdf_config* cfgIn, const hpsdf_field*
             const uint64_t needSamples = mesh ? std::min<uint64_t>((uint64_t)Kj * samplesPerJob(degBound), 1ull << 31) : 0ull;
             const uint64_t bytes = needNodes * FrontierWorkspace::kBytesPerNode + (needArena + needSamples) * sizeof(double);
             const uint64_t held = (uint64_t)ws->nodeCap * FrontierWorkspace::kBytesPerNode + (ws->arenaCap + ws->sampleCap) * sizeof(double);
-            const int lrc = checkBuildLimits(ctx, knownNodes, bytes, held, &measuredLimit, (uint64_t)roundsDone, roundsDone ? hh->total : 8.0 * 8.0 * 8.0 * 8.0 * HPSDF_INITIAL_NODE_ERR,
+            const uint64_t growBytes = needNodes * FrontierWorkspace::kBytesPerNode + needArena * sizeof(double);  // (the default limit's subject)
+            const int lrc = checkBuildLimits(ctx, knownNodes, bytes, growBytes, held, &measuredLimit, (uint64_t)roundsDone, roundsDone ? hh->total : 8.0 * 8.0 * 8.0 * 8.0 * HPSDF_INITIAL_NODE_ERR,
                                              cfg.target_error_threshold);
             if (lrc) return lrc;
         }

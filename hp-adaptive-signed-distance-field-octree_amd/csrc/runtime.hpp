@@ -222,7 +222,7 @@ int makeFieldDev(const hpsdf_ctx* ctx, const hpsdf_field* f, const double* dSamp
 // measured); *measured: the build's cache of that measurement (0 = not taken yet; one hipMemGetInfo per Create, and only once a build
 // needs more than 256 MiB).  HPSDF_OK, or HPSDF_ERR_BUILD_LIMIT with the message set.
 uint64_t buildByteLimit(const hpsdf_ctx* ctx, uint64_t bytes, uint64_t held, uint64_t* measured);  // the bound on bytes in effect (UINT64_MAX: none)
-int checkBuildLimits(const hpsdf_ctx* ctx, uint64_t nodes, uint64_t bytes, uint64_t held, uint64_t* measured, uint64_t rounds, double total, double target);
+int checkBuildLimits(const hpsdf_ctx* ctx, uint64_t nodes, uint64_t bytes, uint64_t growBytes, uint64_t held, uint64_t* measured, uint64_t rounds, double total, double target);
 // the two semantic switches as a context sees them: its own setting, or the process-wide one when it has none (ctx may be null)
 int meshFaceRuleReference(const hpsdf_ctx* ctx);  // hpsdf_[ctx_]set_mesh_face_rule(): 1 = the reference's face-case point whatever its weights
 float meshFaceTolOfSlack(const hpsdf_ctx* ctx);   // MeshDev::faceTolOfSlack for launches prepared now

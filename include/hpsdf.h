@@ -174,7 +174,9 @@ HPSDF_API int hpsdf_ctx_get_reduction_order(const hpsdf_ctx* ctx, int* left_asso
  * 256 MiB, at least 1 GiB (measured then, once per Create; nothing is measured for builds that stay below, i.e. for every BASELINE
  * config; 1.1 GiB on an idle MI355X -- a tree of several hundred thousand nodes, which the runaway builds on file reach within a second or two:
  * profiles/r06_default_config.txt).  The hand-over buffer of split fits (HPSDF_FIT_SPLIT) does not count: it is bounded by 2^31 samples
- * (16 GiB) whatever the tree's size.
+ * (16 GiB) whatever the tree's size.  The DEFAULT bound applies to what grows with the tree -- node arrays and coefficient arena -- and
+ * leaves a mesh field's sample buffer out as well (same bound; an ordinary mesh build at 4096 jobs a round needs 1.5-3 GiB of it at
+ * degrees 3-4 with a tree of 25 000 nodes); a max_bytes the caller sets bounds all of it.
  * UINT64_MAX = no limit.  A build that crosses a limit returns HPSDF_ERR_BUILD_LIMIT; hpsdf_last_error() names rounds, nodes,
  * bytes, both limits, and the total error against the threshold.  No block is returned.  On several ranks a rank that stops on its
  * bytes alone takes the others out through the FAILURES protocol of hpsdf_create_distributed. */

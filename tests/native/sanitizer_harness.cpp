@@ -37,7 +37,7 @@ static int gLeft = 0;  // capi.cpp's hpsdf_set_reduction_order(); here from HPSD
 int reductionLeftAssoc(const hpsdf_ctx*) { return gLeft; }
 int meshFaceRuleReference(const hpsdf_ctx*) { return 0; }
 void setReductionLeftAssoc(int left) { gLeft = left != 0; }
-int checkBuildLimits(const hpsdf_ctx*, uint64_t, uint64_t, uint64_t, uint64_t*, uint64_t, double, double) { return HPSDF_OK; }
+int checkBuildLimits(const hpsdf_ctx*, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t*, uint64_t, double, double) { return HPSDF_OK; }
 hipError_t launchFitMfmaLow(hipStream_t, int, const FitTask*, const uint32_t*, uint32_t, uint32_t, uint32_t, double*, const DeviceTables*, const double*,
                             const RootMap&, int) { return hipErrorNoDevice; }
 hipError_t launchCgIterations(hipStream_t, const CgDev&, int, int, uint32_t) { return hipErrorNoDevice; }

@@ -1241,6 +1241,29 @@ def test_build_limits_stop_a_runaway_build(H, ctx, golden, monkeypatch, host):
     c.close()
 
 
+@pytest.mark.parametrize("host", ["0", "1"])
+def test_default_limits_leave_a_mesh_builds_sample_buffer_alone(H, monkeypatch, host):
+    """The default limit bounds what grows with the tree (nodes, coefficient arena): a mesh build at 4096 jobs a round needs 1.5 GiB of
+    SAMPLE buffer for its third round with a tree of 25 000 nodes -- above the default's 1.1 GiB -- and is an ordinary build (the first
+    version of the limits refused it).  A max_bytes the caller sets counts the sample buffer too.  Both schedulers."""
+    monkeypatch.setenv("HPSDF_HOST_FRONTIER", host)
+    verts, tris = displaced_torus(48, 32)
+    c = H.Context(0)
+    f = H.Field.mesh(c, verts, tris)
+    cfg = H.make_config(1e-7, *MESH_ROOT)
+    blk, st = H.create_block(c, cfg, f, 4096)
+    assert st["n_nodes"] > 25000 and st["rounds"] >= 3 and st["device_frontier"] == (0 if host == "1" else 1), st
+    # (the host scheduler samples a mesh inside its fits: no sample buffer, and a tree of this size needs far less than a GiB)
+    c.set_build_limits(max_bytes=(1 << 30) if host == "0" else (16 << 20))
+    with pytest.raises(H.HpsdfError) as e:
+        H.create_block(c, cfg, f, 4096)
+    assert e.value.status == H.ERR_BUILD_LIMIT and "hpsdf_ctx_set_build_limits" in str(e.value), str(e.value)
+    c.set_build_limits(max_bytes=8 << 30)
+    blk2, st2 = H.create_block(c, cfg, f, 4096)
+    assert blk2 == blk and st2 == st
+    f.close(), c.close()
+
+
 def test_build_limits_on_simulated_ranks(H):
     """The same on two ranks: a bound on nodes stops every rank in the same round (the tree is replicated) -- each returns
     HPSDF_ERR_BUILD_LIMIT itself; a bound on bytes that only ONE rank has takes the other out through the failing-rank protocol
