@@ -387,7 +387,7 @@ class Context:
         return v.value
 
     def set_build_limits(self, max_nodes=0, max_bytes=0):
-        """Bounds on a Create (hpsdf_ctx_set_build_limits): 0 = the default (no bound on nodes; bytes: 1/256 of the free device
+        """Bounds on a Create (hpsdf_ctx_set_build_limits): 0 = the default (no bound on nodes; bytes: 1/64 of the free device
         memory, at least 1 GiB), None = no limit.  A build that crosses one raises HpsdfError with status ERR_BUILD_LIMIT."""
         none = (1 << 64) - 1
         check(lib().hpsdf_ctx_set_build_limits(self.handle, none if max_nodes is None else int(max_nodes), none if max_bytes is None else int(max_bytes)))

@@ -75,13 +75,13 @@ uint64_t buildByteLimit(const hpsdf_ctx* ctx, uint64_t growBytes, uint64_t held,
     constexpr uint64_t kNone = ~0ull, kMeasureFrom = 256ull << 20;
     if (ctx->limitBytes) return ctx->limitBytes;
     if (growBytes <= kMeasureFrom) return kNone;  // (nothing is measured for builds that stay small: every BASELINE config)
-    if (*measured == 0) {  // the default: 1/256 of what the device could give this build, at least 1 GiB
+    if (*measured == 0) {  // the default: 1/64 of what the device could give this build, at least 1 GiB
         size_t freeB = 0, totalB = 0;
         if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) {
             (void)hipGetLastError();
             freeB = 0;
         }
-        *measured = std::max<uint64_t>(1ull << 30, ((uint64_t)freeB + held) / 256);
+        *measured = std::max<uint64_t>(1ull << 30, ((uint64_t)freeB + held) / 64);
     }
     return *measured;
 }
@@ -89,13 +89,14 @@ uint64_t buildByteLimit(const hpsdf_ctx* ctx, uint64_t growBytes, uint64_t held,
 // arena).  A limit the caller set bounds `bytes`.  The DEFAULT exists to end a build that will not end by itself (the reference's default
 // Config()) in seconds instead of minutes, and bounds `growBytes` only: a round's sample buffer -- a mesh field's, K x up to 150 000
 // samples a job, at most 2^31 samples = 16 GiB whatever the tree's size -- is what an ordinary mesh build at K = 4096 needs (2.9 GiB at
-// degree 4) and says nothing about whether the build runs away.
+// degree 4) and says nothing about whether the build runs away.  (1/64: 4.5 GiB on an idle MI355X, a tree of some 10 M nodes; at 1/256 a
+// mesh build at 1e-8 that was two thirds of the way to its threshold with 3.7 M nodes was refused.)
 int checkBuildLimits(const hpsdf_ctx* ctx, uint64_t nodes, uint64_t bytes, uint64_t growBytes, uint64_t held, uint64_t* measured, uint64_t rounds, double total, double target) {
     constexpr uint64_t kNone = ~0ull;
     const uint64_t maxNodes = ctx->limitNodes ? ctx->limitNodes : kNone;
     const uint64_t maxBytes = buildByteLimit(ctx, growBytes, held, measured);
     const uint64_t counted = ctx->limitBytes ? bytes : growBytes;
-    const char* how = ctx->limitBytes ? "hpsdf_ctx_set_build_limits" : "the default, on nodes and coefficients: 1/256 of the device memory that was free, at least 1 GiB";
+    const char* how = ctx->limitBytes ? "hpsdf_ctx_set_build_limits" : "the default, on nodes and coefficients: 1/64 of the device memory that was free, at least 1 GiB";
     if (nodes <= maxNodes && counted <= maxBytes) return HPSDF_OK;
     char msg[704];
     std::snprintf(msg, sizeof msg,

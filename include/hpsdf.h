@@ -170,10 +170,10 @@ HPSDF_API int hpsdf_ctx_get_reduction_order(const hpsdf_ctx* ctx, int* left_asso
  *   max_nodes: the tree's node count (identical on every rank, so every rank stops in the same round);
  *   max_bytes: the device memory this rank's build state needs for the round about to open (node arrays, coefficient arena, sample
  *              buffer -- capacities grow by doubling, so the allocation can reach twice this).
- * 0 = the default: no bound on nodes; bytes = 1/256 of the device memory that is free when the build first needs more than
+ * 0 = the default: no bound on nodes; bytes = 1/64 of the device memory that is free when the build first needs more than
  * 256 MiB, at least 1 GiB (measured then, once per Create; nothing is measured for builds that stay below, i.e. for every BASELINE
- * config; 1.1 GiB on an idle MI355X -- a tree of several hundred thousand nodes, which the runaway builds on file reach within a second or two:
- * profiles/r06_default_config.txt).  The hand-over buffer of split fits (HPSDF_FIT_SPLIT) does not count: it is bounded by 2^31 samples
+ * config; 4.5 GiB on an idle MI355X -- a tree of one to ten million nodes, which the runaway builds on file reach within 3-15 seconds:
+ * profiles/r06_default_config.txt; the first version, 1/256, refused a mesh build at 1e-8 that was most of the way to its threshold).  The hand-over buffer of split fits (HPSDF_FIT_SPLIT) does not count: it is bounded by 2^31 samples
  * (16 GiB) whatever the tree's size.  The DEFAULT bound applies to what grows with the tree -- node arrays and coefficient arena -- and
  * leaves a mesh field's sample buffer out as well (same bound; an ordinary mesh build at 4096 jobs a round needs 1.5-3 GiB of it at
  * degrees 3-4 with a tree of 25 000 nodes); a max_bytes the caller sets bounds all of it.

@@ -318,7 +318,7 @@ class Octree {
     void SetFastFit(bool on) { SetFitMode(on ? HPSDF_FIT_FAST : HPSDF_FIT_SPLIT); }
     /// Additive: bounds on Create (hpsdf_ctx_set_build_limits).  The reference's build has none: a threshold below what the error
     /// estimate reaches on a field -- the default Config()'s 1e-10 on most -- refines until memory ends.  0 = the default (nodes:
-    /// unbounded; bytes: 1/256 of the free device memory, at least 1 GiB), UINT64_MAX = none.  A Create that crosses a limit throws SDF::Error
+    /// unbounded; bytes of nodes and coefficients: 1/64 of the free device memory, at least 1 GiB), UINT64_MAX = none.  A Create that crosses a limit throws SDF::Error
     /// with status HPSDF_ERR_BUILD_LIMIT and a message that names rounds, nodes, bytes and the error reached.
     void SetBuildLimits(uint64_t maxNodes, uint64_t maxBytes) {
         ensureCtx();

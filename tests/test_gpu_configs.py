@@ -1244,7 +1244,7 @@ def test_build_limits_stop_a_runaway_build(H, ctx, golden, monkeypatch, host):
 @pytest.mark.parametrize("host", ["0", "1"])
 def test_default_limits_leave_a_mesh_builds_sample_buffer_alone(H, monkeypatch, host):
     """The default limit bounds what grows with the tree (nodes, coefficient arena): a mesh build at 4096 jobs a round needs 1.5 GiB of
-    SAMPLE buffer for its third round with a tree of 25 000 nodes -- above the default's 1.1 GiB -- and is an ordinary build (the first
+    SAMPLE buffer for its third round with a tree of 25 000 nodes -- above 1/256 of the device, the first default -- and is an ordinary build (the first
     version of the limits refused it).  A max_bytes the caller sets counts the sample buffer too.  Both schedulers."""
     monkeypatch.setenv("HPSDF_HOST_FRONTIER", host)
     verts, tris = displaced_torus(48, 32)

@@ -45,7 +45,7 @@ for lim in limits:
     ctx = H.Context(0)
     if lim:
         ctx.set_build_limits(max_bytes=int(lim * 2**30))
-    print("--- build limits: %s" % ("the library's defaults (nodes: none; bytes: 1/256 of the free device memory, at least 1 GiB)" if not lim else "max_bytes = %g GiB" % lim), flush=True)
+    print("--- build limits: %s" % ("the library's defaults (nodes: none; bytes of nodes and coefficients: 1/64 of the free device memory, at least 1 GiB)" if not lim else "max_bytes = %g GiB" % lim), flush=True)
     for name, field in (("sphere", H.Field.sphere), ("union3", H.Field.union3)):
         for target in (1e-9, 1e-10):
             cfg = H.make_config(target)
